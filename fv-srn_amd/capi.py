@@ -1,0 +1,321 @@
+"""
+ctypes binding of ``libfvsrn.so`` (include/fvsrn.h).
+
+This is the thin Python host layer used by the tests, ``bench.py`` and the multi-GPU driver: it only
+moves pointers.  All arithmetic happens in the HIP kernels behind the C ABI; there is NO CPU fallback:
+if the library or a GPU is missing the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfvsrn.so")
+
+ACTIVATIONS = {"ReLU": 0, "Sine": 1, "Snake": 2, "SnakeAlt": 3, "Sigmoid": 4, "None": 5}
+OUTPUT_MODES = {"density": 0, "density:direct": 1, "rgbo": 2, "rgbo:direct": 3, "densitygrad": 4,
+                "densitygrad:direct": 5, "densitygrad:cubic": 6, "densitycurvature": 7, "densitycurvature:direct": 8}
+TF_NONE, TF_IDENTITY, TF_GAUSSIAN, TF_PIECEWISE, TF_TEXTURE = range(5)
+TF_COLS = {TF_NONE: 0, TF_IDENTITY: 0, TF_GAUSSIAN: 6, TF_PIECEWISE: 5, TF_TEXTURE: 4}
+BLEND_ALPHA, BLEND_BEER_LAMBERT = 0, 1
+ORIENTATIONS = {"Xp": 0, "Xm": 1, "Yp": 2, "Ym": 3, "Zp": 4, "Zm": 5}
+
+
+class FvsrnError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(message if message else "fvsrn error %d" % code)
+        self.code = code
+
+
+class NetworkInfo(C.Structure):
+    _fields_ = [("num_layers", C.c_int), ("hidden_channels", C.c_int), ("num_fourier", C.c_int),
+                ("has_direction", C.c_int), ("has_time", C.c_int), ("use_direction_in_fourier", C.c_int),
+                ("output_mode", C.c_int), ("output_channels", C.c_int), ("activation", C.c_int),
+                ("activation_param", C.c_float), ("grid_channels", C.c_int), ("grid_encoding", C.c_int),
+                ("grid_res", C.c_int * 3), ("time_num", C.c_int), ("ensemble_num", C.c_int),
+                ("num_parameters", C.c_int), ("max_warps_shared", C.c_int), ("max_warps_mixed", C.c_int),
+                ("flops_per_sample", C.c_double), ("mfma_flops_per_sample", C.c_double),
+                ("box_min", C.c_float * 3), ("box_size", C.c_float * 3)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("cam_eye", C.c_float * 3), ("cam_right", C.c_float * 3), ("cam_up", C.c_float * 3),
+                ("fov_y_radians", C.c_float), ("stepsize", C.c_float), ("density_min", C.c_float),
+                ("density_max", C.c_float), ("early_out", C.c_int), ("blend_mode", C.c_int), ("tf_kind", C.c_int),
+                ("tf_scale_absorption", C.c_float), ("tf_scale_emission", C.c_float),
+                ("tf_table", C.POINTER(C.c_float)), ("tf_rows", C.c_int)]
+
+
+# every symbol include/fvsrn.h declares: (name, restype, argtypes)
+_VP, _SZ, _I, _F, _D = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
+_FP, _DP, _U16P = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint16)
+SYMBOLS = [
+    ("fvsrn_last_error", C.c_char_p, []),
+    ("fvsrn_version", C.c_char_p, []),
+    ("fvsrn_device_count", _I, []),
+    ("fvsrn_network_create_from_volnet", _I, [_VP, _SZ, C.POINTER(_VP)]),
+    ("fvsrn_network_create", _I, [C.POINTER(_VP)]),
+    ("fvsrn_network_destroy", None, [_VP]),
+    ("fvsrn_network_set_input", _I, [_VP, _I, _I, _FP, _I, _I, _I]),
+    ("fvsrn_network_set_output_mode", _I, [_VP, _I]),
+    ("fvsrn_network_add_layer", _I, [_VP, _FP, _FP, _I, _I, _I, _F]),
+    ("fvsrn_network_set_box", _I, [_VP, _FP, _FP]),
+    ("fvsrn_network_set_latent_grid_layout", _I, [_VP, _I, _I, _I, _I, _I]),
+    ("fvsrn_network_set_latent_grid", _I, [_VP, _I, _I, _FP, _I, _I, _I, _I, _I, _DP]),
+    ("fvsrn_network_valid", _I, [_VP]),
+    ("fvsrn_network_save_volnet", _I, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
+    ("fvsrn_network_set_time_and_ensemble", _I, [_VP, _F, _I]),
+    ("fvsrn_network_clear_gpu_resources", _I, [_VP]),
+    ("fvsrn_network_get_info", _I, [_VP, C.POINTER(NetworkInfo)]),
+    ("fvsrn_network_get_layer", _I, [_VP, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _FP, _U16P, _U16P]),
+    ("fvsrn_network_get_fourier", _I, [_VP, _U16P, _I, C.POINTER(_I)]),
+    ("fvsrn_evaluate_points", _I, [_VP, _VP, _VP, _SZ, _VP, _VP]),
+    ("fvsrn_scene_create", _I, [C.POINTER(SceneDesc), C.POINTER(_VP)]),
+    ("fvsrn_scene_update", _I, [_VP, C.POINTER(SceneDesc)]),
+    ("fvsrn_scene_destroy", None, [_VP]),
+    ("fvsrn_camera_on_a_sphere", _I, [_I, _DP, _D, _D, _D, _FP, _FP, _FP]),
+    ("fvsrn_render", _I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP]),
+    ("fvsrn_network_kernel_name", _I, [_VP, _I, C.c_char_p, _SZ]),
+]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads libfvsrn.so (built by ``__graft_entry__.build()`` / ``make -C fv-srn_amd/csrc``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FvsrnError(-6, "libfvsrn.so not found at %s: build it first (python -c 'import __graft_entry__ as g; "
+                                 "g.build()'); there is no CPU fallback" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def _check(code: int) -> None:
+    if code != 0:
+        raise FvsrnError(code, lib().fvsrn_last_error().decode("utf-8", "replace"))
+
+
+def _fptr(a: np.ndarray):
+    return a.ctypes.data_as(_FP)
+
+
+def device_count() -> int:
+    return lib().fvsrn_device_count()
+
+
+def _torch_ptr(t, dtype_name: str, what: str) -> int:
+    import torch
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise FvsrnError(-1, "%s must be a CUDA(HIP) tensor" % what)
+    if str(t.dtype) != dtype_name or not t.is_contiguous():
+        raise FvsrnError(-1, "%s must be contiguous %s" % (what, dtype_name))
+    return t.data_ptr()
+
+
+def _current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Network:
+    """SceneNetwork handle (reference pyrenderer.SceneNetwork, volume_interpolation_network.cpp:1928-1972)."""
+
+    def __init__(self, handle: int):
+        self._h = C.c_void_p(handle)
+
+    @staticmethod
+    def from_volnet(data: bytes) -> "Network":
+        h = _VP()
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        _check(lib().fvsrn_network_create_from_volnet(C.cast(buf, _VP), len(data), C.byref(h)))
+        return Network(h.value)
+
+    @staticmethod
+    def create() -> "Network":
+        h = _VP()
+        _check(lib().fvsrn_network_create(C.byref(h)))
+        return Network(h.value)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().fvsrn_network_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- builder (mirrors export_to_pyrenderer's calls) -------------------------------------------------
+    def set_input(self, fourier: Optional[np.ndarray], has_time=False, has_direction=False, premultiplied=True):
+        if fourier is None:
+            _check(lib().fvsrn_network_set_input(self._h, int(has_time), int(has_direction), None, 0, 3, 1))
+        else:
+            f = np.ascontiguousarray(fourier, dtype=np.float32)
+            _check(lib().fvsrn_network_set_input(self._h, int(has_time), int(has_direction), _fptr(f), f.shape[0],
+                                                 f.shape[1], int(premultiplied)))
+
+    def set_output_mode(self, mode: str):
+        _check(lib().fvsrn_network_set_output_mode(self._h, OUTPUT_MODES[mode]))
+
+    def add_layer(self, weight: np.ndarray, bias: np.ndarray, activation: str, param: float = 1.0):
+        w = np.ascontiguousarray(weight, dtype=np.float32)
+        b = np.ascontiguousarray(bias, dtype=np.float32)
+        _check(lib().fvsrn_network_add_layer(self._h, _fptr(w), _fptr(b), w.shape[0], w.shape[1],
+                                             ACTIVATIONS[activation], float(param)))
+
+    def set_box(self, box_min: Sequence[float], box_size: Sequence[float]):
+        a = np.asarray(box_min, np.float32)
+        b = np.asarray(box_size, np.float32)
+        _check(lib().fvsrn_network_set_box(self._h, _fptr(a), _fptr(b)))
+
+    def set_latent_grid_layout(self, time_min, time_num, time_step, ensemble_min, ensemble_num):
+        _check(lib().fvsrn_network_set_latent_grid_layout(self._h, time_min, time_num, time_step, ensemble_min, ensemble_num))
+
+    def set_latent_grid(self, is_ensemble: bool, index: int, grid: np.ndarray, encoding: int) -> float:
+        g = np.ascontiguousarray(grid, dtype=np.float32)
+        if g.ndim == 5:
+            g = g[0]
+        err = C.c_double(0)
+        _check(lib().fvsrn_network_set_latent_grid(self._h, int(is_ensemble), index, _fptr(g), g.shape[0], g.shape[1],
+                                                   g.shape[2], g.shape[3], encoding, C.byref(err)))
+        return err.value
+
+    # -- queries -----------------------------------------------------------------------------------------
+    def valid(self) -> bool:
+        return lib().fvsrn_network_valid(self._h) == 1
+
+    def last_error(self) -> str:
+        return lib().fvsrn_last_error().decode()
+
+    def save(self) -> bytes:
+        n = _SZ(0)
+        _check(lib().fvsrn_network_save_volnet(self._h, None, 0, C.byref(n)))
+        buf = (C.c_char * n.value)()
+        _check(lib().fvsrn_network_save_volnet(self._h, C.cast(buf, _VP), n.value, C.byref(n)))
+        return bytes(buf)
+
+    def info(self) -> NetworkInfo:
+        i = NetworkInfo()
+        _check(lib().fvsrn_network_get_info(self._h, C.byref(i)))
+        return i
+
+    def layer(self, index: int):
+        co, ci, act, p = _I(), _I(), _I(), _F()
+        _check(lib().fvsrn_network_get_layer(self._h, index, C.byref(co), C.byref(ci), C.byref(act), C.byref(p), None, None))
+        w = np.zeros(co.value * ci.value, np.uint16)
+        b = np.zeros(co.value, np.uint16)
+        _check(lib().fvsrn_network_get_layer(self._h, index, None, None, None, None, w.ctypes.data_as(_U16P),
+                                             b.ctypes.data_as(_U16P)))
+        return co.value, ci.value, act.value, p.value, w, b
+
+    def fourier(self) -> np.ndarray:
+        n = _I()
+        _check(lib().fvsrn_network_get_fourier(self._h, None, 0, C.byref(n)))
+        m = np.zeros(n.value, np.uint16)
+        _check(lib().fvsrn_network_get_fourier(self._h, m.ctypes.data_as(_U16P), n.value, C.byref(n)))
+        return m
+
+    def kernel_name(self, render: bool = True) -> str:
+        buf = C.create_string_buffer(256)
+        _check(lib().fvsrn_network_kernel_name(self._h, int(render), buf, 256))
+        return buf.value.decode()
+
+    def set_time_and_ensemble(self, time: float, ensemble: int = 0):
+        _check(lib().fvsrn_network_set_time_and_ensemble(self._h, float(time), int(ensemble)))
+
+    def clear_gpu_resources(self):
+        _check(lib().fvsrn_network_clear_gpu_resources(self._h))
+
+    # -- IVolumeInterpolation.evaluate (volume_interpolation.cpp:26-127) ---------------------------------
+    def evaluate(self, positions, directions=None, out=None, stream: Optional[int] = None):
+        import torch
+        n = positions.shape[0]
+        pp = _torch_ptr(positions, "torch.float32", "positions")
+        dp = _torch_ptr(directions, "torch.float32", "directions") if directions is not None else None
+        oc = self.info().output_channels
+        if out is None:
+            out = torch.empty((n, oc), dtype=torch.float32, device=positions.device)
+        op = _torch_ptr(out, "torch.float32", "out")
+        _check(lib().fvsrn_evaluate_points(self._h, pp, dp, n, op, _current_stream() if stream is None else stream))
+        return out
+
+
+class Scene:
+    """Camera + DVR + TF + blending POD (reference: the module tree below ImageEvaluatorSimple)."""
+
+    def __init__(self, **kw):
+        self._h = None
+        self._keep = None
+        d = self._desc(**kw)
+        h = _VP()
+        _check(lib().fvsrn_scene_create(C.byref(d), C.byref(h)))
+        self._h = C.c_void_p(h.value)
+
+    def _desc(self, *, eye, right, up, fov_y_radians, stepsize, density_min=0.0, density_max=1.0, early_out=True,
+              blend_mode=BLEND_BEER_LAMBERT, tf_kind=TF_IDENTITY, tf_scale_absorption=1.0, tf_scale_emission=1.0,
+              tf_table=None) -> SceneDesc:
+        d = SceneDesc()
+        d.cam_eye[:] = [float(v) for v in eye]
+        d.cam_right[:] = [float(v) for v in right]
+        d.cam_up[:] = [float(v) for v in up]
+        d.fov_y_radians = fov_y_radians
+        d.stepsize = stepsize
+        d.density_min, d.density_max = density_min, density_max
+        d.early_out = int(early_out)
+        d.blend_mode = blend_mode
+        d.tf_kind = tf_kind
+        d.tf_scale_absorption, d.tf_scale_emission = tf_scale_absorption, tf_scale_emission
+        if tf_table is not None:
+            t = np.ascontiguousarray(tf_table, dtype=np.float32)
+            assert t.ndim == 2 and t.shape[1] == TF_COLS[tf_kind], "TF table shape does not match its kind"
+            self._keep = t
+            d.tf_table = _fptr(t)
+            d.tf_rows = t.shape[0]
+        else:
+            d.tf_table = None
+            d.tf_rows = 0
+        return d
+
+    def update(self, **kw):
+        d = self._desc(**kw)
+        _check(lib().fvsrn_scene_update(self._h, C.byref(d)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().fvsrn_scene_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def render(self, net: Network, width: int, height: int, y0: int = 0, y1: Optional[int] = None, out=None,
+               stats=None, stream: Optional[int] = None):
+        """ImageEvaluatorSimple::render: returns the (1,8,H,W) fp32 tensor (rows [y0,y1) written)."""
+        import torch
+        if y1 is None:
+            y1 = height
+        if out is None:
+            out = torch.zeros((1, 8, height, width), dtype=torch.float32, device="cuda")
+        op = _torch_ptr(out, "torch.float32", "out")
+        sp = _torch_ptr(stats, "torch.int64", "stats") if stats is not None else None
+        _check(lib().fvsrn_render(self._h, net._h, width, height, y0, y1, op, sp,
+                                  _current_stream() if stream is None else stream))
+        return out
+
+
+def camera_on_a_sphere(orientation: str, center, pitch: float, yaw: float, distance: float):
+    """CameraOnASphere -> (eye, right, up) fp32 (renderer/camera.cpp:458-490,553-581)."""
+    c = (C.c_double * 3)(*[float(v) for v in center])
+    eye, right, up = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)()
+    _check(lib().fvsrn_camera_on_a_sphere(ORIENTATIONS[orientation], c, pitch, yaw, distance, eye, right, up))
+    return np.array(eye, np.float32), np.array(right, np.float32), np.array(up, np.float32)

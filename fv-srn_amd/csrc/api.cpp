@@ -1,0 +1,577 @@
+// C ABI of libfvsrn.so (see include/fvsrn.h for the reference interfaces each entry replaces).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "../../include/fvsrn.h"
+#include "half.hpp"
+#include "launch.hpp"
+#include "pack.hpp"
+#include "scene_network.hpp"
+
+using namespace fvsrn;
+
+namespace {
+thread_local std::string g_lastError;
+
+int fail(int code, const std::string& msg) {
+    g_lastError = msg;
+    return code;
+}
+
+template <class F>
+int guarded(F&& f) {
+    try {
+        g_lastError.clear();
+        return f();
+    } catch (const FormatError& e) {
+        return fail(FVSRN_ERR_FORMAT, e.what());
+    } catch (const InvalidNetwork& e) {
+        return fail(FVSRN_ERR_INVALID_NETWORK, e.what());
+    } catch (const Unsupported& e) {
+        return fail(FVSRN_ERR_UNSUPPORTED, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, e.what());
+    }
+}
+
+struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
+#define HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            throw DeviceError(std::string(#expr) + " failed: " + hipGetErrorString(_e));                  \
+    } while (0)
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        HIP_CHECK(hipMalloc(&ptr, bytes));
+        cap = bytes;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+int actIndex(fvsrn_activation a) {
+    switch (a) {
+        case FVSRN_ACT_RELU: return 0;
+        case FVSRN_ACT_SINE: return 1;
+        case FVSRN_ACT_SNAKE: return 2;
+        case FVSRN_ACT_SNAKEALT: return 3;
+        default: return -1;
+    }
+}
+}  // namespace
+
+struct fvsrn_network {
+    std::shared_ptr<SceneNetwork> net = std::make_shared<SceneNetwork>();
+    // device image (lazy; invalidated by any mutation)
+    bool deviceValid = false;
+    PackedNetwork packed;
+    DeviceBuffer dLds, dGrid;
+    VariantKey key{};
+    KernelInfo kinfo{};
+    int numCUs = 0;
+    std::mutex mu;
+
+    void invalidate() { deviceValid = false; }
+
+    void pack() {  // host part only (no GPU needed): variant selection + LDS image
+        packed = packNetwork(*net);
+        key.CD = packed.cfg.hiddenChannels / 16;
+        key.act = actIndex(packed.cfg.activation);
+        key.grid = packed.cfg.gridChannels > 0;
+        key.dir = packed.cfg.directionMode > 0;
+        if (!kernel_info(key, &kinfo))
+            throw Unsupported("no ahead-of-time kernel for hidden width " + std::to_string(packed.cfg.hiddenChannels) +
+                              ", activation " + activationName(packed.cfg.activation) +
+                              (key.dir ? ", with view direction" : "") + " (compiled: widths 32/48/64, no direction)");
+    }
+
+    void ensureDevice(hipStream_t stream) {
+        if (deviceValid) return;
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+            throw DeviceError("no HIP device available: the MI355X kernels cannot run (there is no CPU fallback)");
+        pack();
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        numCUs = prop.multiProcessorCount;
+        dLds.ensure(packed.ldsImage.size());
+        HIP_CHECK(hipMemcpyAsync(dLds.ptr, packed.ldsImage.data(), packed.ldsImage.size(), hipMemcpyHostToDevice, stream));
+        packed.params.ldsImage = dLds.ptr;
+        if (!packed.grid.empty()) {
+            dGrid.ensure(packed.grid.size() * 2);
+            HIP_CHECK(hipMemcpyAsync(dGrid.ptr, packed.grid.data(), packed.grid.size() * 2, hipMemcpyHostToDevice, stream));
+            packed.params.grid = dGrid.ptr;
+        } else {
+            packed.params.grid = nullptr;
+        }
+        // the staging vectors are pageable: the copies above complete before hipMemcpyAsync returns
+        const size_t maxLds = packed.ldsImage.size() + 4096 + 256 * 6 * 4;
+        HIP_CHECK(hipFuncSetAttribute(kinfo.evalFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
+        HIP_CHECK(hipFuncSetAttribute(kinfo.renderFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
+        deviceValid = true;
+    }
+
+    ~fvsrn_network() {
+        dLds.release();
+        dGrid.release();
+    }
+};
+
+struct fvsrn_scene {
+    fvsrn_scene_desc desc{};
+    std::vector<float> tfTable;
+    DeviceBuffer dTf;
+    bool tfDirty = true;
+    std::mutex mu;
+    ~fvsrn_scene() { dTf.release(); }
+};
+
+static int tfCols(int kind) {
+    switch (kind) {
+        case FVSRN_TF_GAUSSIAN: return 6;
+        case FVSRN_TF_PIECEWISE: return 5;
+        case FVSRN_TF_TEXTURE: return 4;
+        default: return 0;
+    }
+}
+
+extern "C" {
+
+const char* fvsrn_last_error(void) { return g_lastError.c_str(); }
+const char* fvsrn_version(void) { return "fvsrn 0.1.0 gfx950"; }
+
+int fvsrn_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------- network
+int fvsrn_network_create_from_volnet(const void* bytes, size_t len, fvsrn_network** out) {
+    return guarded([&] {
+        if (!bytes || !out) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        auto n = std::make_unique<fvsrn_network>();
+        n->net = SceneNetwork::load(bytes, len);
+        *out = n.release();
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_network_create(fvsrn_network** out) {
+    return guarded([&] {
+        if (!out) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        *out = new fvsrn_network();
+        return FVSRN_OK;
+    });
+}
+
+void fvsrn_network_destroy(fvsrn_network* net) { delete net; }
+
+int fvsrn_network_set_input(fvsrn_network* net, int has_time, int has_direction, const float* fourier_matrix,
+                            int num_fourier, int fourier_cols, int premultiplied) {
+    return guarded([&] {
+        if (!net) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null network");
+        std::lock_guard<std::mutex> lock(net->mu);
+        net->net->input.hasTime = has_time != 0;
+        net->net->input.hasDirection = has_direction != 0;
+        if (num_fourier > 0) {
+            if (!fourier_matrix) return fail(FVSRN_ERR_INVALID_ARGUMENT, "fourier matrix is null");
+            net->net->setFourierMatrix(fourier_matrix, num_fourier, fourier_cols, premultiplied != 0);
+        } else {  // disableFourierFeatures, volume_interpolation_network.cpp:158-163
+            net->net->input.numFourierFeatures = 0;
+            net->net->input.useDirectionInFourierFeatures = false;
+            net->net->input.fourierMatrix.clear();
+        }
+        net->invalidate();
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_network_set_output_mode(fvsrn_network* net, fvsrn_output_mode mode) {
+    return guarded([&] {
+        if (!net || int(mode) < 0 || int(mode) > 8) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad output mode");
+        std::lock_guard<std::mutex> lock(net->mu);
+        net->net->outputMode = mode;
+        net->invalidate();
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_network_add_layer(fvsrn_network* net, const float* weights, const float* bias, int channels_out,
+                            int channels_in, fvsrn_activation act, float act_param) {
+    return guarded([&] {
+        if (!net || !weights || !bias || channels_out <= 0 || channels_in <= 0 || int(act) < 0 || int(act) > 5)
+            return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad layer arguments");
+        std::lock_guard<std::mutex> lock(net->mu);
+        net->net->addLayerFromFloat(weights, bias, channels_out, channels_in, act, act_param);
+        net->invalidate();
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_network_set_box(fvsrn_network* net, const float box_min[3], const float box_size[3]) {
+    return guarded([&] {
+        if (!net || !box_min || !box_size) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        std::lock_guard<std::mutex> lock(net->mu);
+        for (int i = 0; i < 3; ++i) {
+            net->net->boxMin[i] = box_min[i];
+            net->net->boxSize[i] = box_size[i];
+        }
+        net->invalidate();
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_network_set_latent_grid_layout(fvsrn_network* net, int time_min, int time_num, int time_step,
+                                         int ensemble_min, int ensemble_num) {
+    return guarded([&] {
+        if (!net || time_num < 0 || ensemble_num < 0 || time_step == 0)
+            return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad latent grid layout");
+        std::lock_guard<std::mutex> lock(net->mu);
+        auto g = std::make_shared<LatentGridTimeAndEnsemble>();
+        g->timeMin = time_min; g->timeNum = time_num; g->timeStep = time_step;
+        g->ensembleMin = ensemble_min; g->ensembleNum = ensemble_num;
+        g->timeGrids.resize(size_t(time_num));
+        g->ensembleGrids.resize(size_t(ensemble_num));
+        net->net->latentGrid = g;
+        net->invalidate();
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_network_set_latent_grid(fvsrn_network* net, int is_ensemble, int index, const float* grid, int C, int Z,
+                                  int Y, int X, fvsrn_grid_encoding enc, double* encoding_error) {
+    return guarded([&] {
+        if (!net || !grid || C <= 0 || Z <= 0 || Y <= 0 || X <= 0 || int(enc) < 0 || int(enc) > 2)
+            return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad latent grid arguments");
+        std::lock_guard<std::mutex> lock(net->mu);
+        if (!net->net->latentGrid) return fail(FVSRN_ERR_INVALID_ARGUMENT, "set the latent grid layout first");
+        auto& list = is_ensemble ? net->net->latentGrid->ensembleGrids : net->net->latentGrid->timeGrids;
+        if (index < 0 || size_t(index) >= list.size()) return fail(FVSRN_ERR_INVALID_ARGUMENT, "index out of bounds!");
+        list[size_t(index)] = LatentGrid::fromFloat(grid, C, Z, Y, X, enc, encoding_error);
+        net->invalidate();
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_network_valid(const fvsrn_network* net) {
+    if (!net) return 0;
+    std::string why;
+    const bool ok = net->net->valid(&why);
+    g_lastError = ok ? "" : why;
+    return ok ? 1 : 0;
+}
+
+int fvsrn_network_save_volnet(const fvsrn_network* net, void* buf, size_t cap, size_t* len) {
+    return guarded([&] {
+        if (!net || !len) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        const std::vector<char> bytes = net->net->save();
+        *len = bytes.size();
+        if (buf) {
+            if (cap < bytes.size()) return fail(FVSRN_ERR_INVALID_ARGUMENT, "buffer too small");
+            std::memcpy(buf, bytes.data(), bytes.size());
+        }
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_network_set_time_and_ensemble(fvsrn_network* net, float time, int ensemble) {
+    return guarded([&] {
+        if (!net) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null network");
+        std::lock_guard<std::mutex> lock(net->mu);
+        net->net->setTimeAndEnsemble(time, ensemble);
+        net->invalidate();
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_network_clear_gpu_resources(fvsrn_network* net) {
+    return guarded([&] {
+        if (!net) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null network");
+        std::lock_guard<std::mutex> lock(net->mu);
+        net->invalidate();
+        net->dLds.release();
+        net->dGrid.release();
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_network_get_info(const fvsrn_network* netc, fvsrn_network_info* info) {
+    return guarded([&] {
+        if (!netc || !info) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        const SceneNetwork& n = *netc->net;
+        std::memset(info, 0, sizeof(*info));
+        info->num_layers = int(n.hidden.size());
+        info->num_fourier = n.input.numFourierFeatures;
+        info->has_direction = n.input.hasDirection;
+        info->has_time = n.input.hasTime;
+        info->use_direction_in_fourier = n.input.useDirectionInFourierFeatures;
+        info->output_mode = int(n.outputMode);
+        info->output_channels = n.outputChannels();
+        if (n.latentGrid) {
+            info->grid_channels = n.latentGrid->totalChannels();
+            info->grid_encoding = int(n.latentGrid->commonEncoding());
+            const LatentGrid* g = n.latentGrid->hasTimeGrids() ? n.latentGrid->timeGrids[0].get()
+                                                               : (n.latentGrid->hasEnsembleGrids() ? n.latentGrid->ensembleGrids[0].get() : nullptr);
+            if (g) { info->grid_res[0] = g->gridSizeX; info->grid_res[1] = g->gridSizeY; info->grid_res[2] = g->gridSizeZ; }
+            info->time_num = n.latentGrid->timeNum;
+            info->ensemble_num = n.latentGrid->ensembleNum;
+        }
+        info->num_parameters = n.numParameters();
+        info->max_warps_shared = n.computeMaxWarps(true, false);
+        info->max_warps_mixed = n.computeMaxWarps(false, false);
+        for (int i = 0; i < 3; ++i) { info->box_min[i] = n.boxMin[i]; info->box_size[i] = n.boxSize[i]; }
+        std::string why;
+        if (n.valid(&why)) {
+            const NetworkConfig c = n.config();
+            info->hidden_channels = c.hiddenChannels;
+            info->activation = int(c.activation);
+            info->activation_param = c.activationParam;
+            info->flops_per_sample = n.flopsPerSample();
+            try {
+                info->mfma_flops_per_sample = packNetwork(n).mfmaFlopsPerSample;
+            } catch (const Unsupported&) {
+                info->mfma_flops_per_sample = 0;
+            }
+        }
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_network_get_layer(const fvsrn_network* net, int index, int* channels_out, int* channels_in, int* activation,
+                            float* act_param, uint16_t* weights, uint16_t* bias) {
+    return guarded([&] {
+        if (!net || index < 0 || size_t(index) >= net->net->hidden.size())
+            return fail(FVSRN_ERR_INVALID_ARGUMENT, "layer index out of bounds");
+        const Layer& l = net->net->hidden[size_t(index)];
+        if (channels_out) *channels_out = l.channelsOut;
+        if (channels_in) *channels_in = l.channelsIn;
+        if (activation) *activation = int(l.activation);
+        if (act_param) *act_param = l.activationParameter;
+        if (weights) std::memcpy(weights, l.weights.data(), 2 * l.weights.size());
+        if (bias) std::memcpy(bias, l.bias.data(), 2 * l.bias.size());
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_network_get_fourier(const fvsrn_network* net, uint16_t* matrix, int cap, int* count) {
+    return guarded([&] {
+        if (!net || !count) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        const auto& m = net->net->input.fourierMatrix;
+        *count = int(m.size());
+        if (matrix) {
+            if (cap < int(m.size())) return fail(FVSRN_ERR_INVALID_ARGUMENT, "buffer too small");
+            std::memcpy(matrix, m.data(), 2 * m.size());
+        }
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t cap) {
+    return guarded([&] {
+        if (!net || !buf || cap == 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        std::lock_guard<std::mutex> lock(net->mu);
+        net->pack();
+        const char* name = render ? net->kinfo.renderName : net->kinfo.evalName;
+        std::strncpy(buf, name, cap - 1);
+        buf[cap - 1] = 0;
+        return FVSRN_OK;
+    });
+}
+
+// ------------------------------------------------------------------------------------------- evaluation
+int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const float* d_directions, size_t n,
+                          float* d_out, void* stream) {
+    return guarded([&] {
+        if (!net || (n > 0 && (!d_positions || !d_out))) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        std::lock_guard<std::mutex> lock(net->mu);
+        try {
+            hipStream_t s = static_cast<hipStream_t>(stream);
+            net->ensureDevice(s);
+            if (n == 0) return FVSRN_OK;
+            if (net->key.dir && !d_directions)
+                return fail(FVSRN_ERR_INVALID_ARGUMENT, "the network uses the view direction, but no directions were given");
+            EvalArgs a{net->packed.params, d_positions, d_directions, n, d_out, net->net->outputChannels()};
+            const size_t batches = (n + 63) / 64;
+            const size_t blocks = (batches + 3) / 4;
+            const unsigned grid = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 8));
+            const hipError_t e = launch_eval(net->key, a, grid, size_t(net->packed.params.ldsBytes), s);
+            if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during evaluation! ") + hipGetErrorString(e));
+            return FVSRN_OK;
+        } catch (const DeviceError& e) {
+            return fail(fvsrn_device_count() == 0 ? FVSRN_ERR_NO_DEVICE : FVSRN_ERR_DEVICE, e.what());
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ scene
+static int sceneValidate(const fvsrn_scene_desc* d) {
+    if (!d) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null scene description");
+    if (d->tf_kind < FVSRN_TF_NONE || d->tf_kind > FVSRN_TF_TEXTURE) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad tf_kind");
+    if (tfCols(d->tf_kind) > 0 && (!d->tf_table || d->tf_rows <= 0))
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "this transfer function needs a table");
+    if (d->tf_kind == FVSRN_TF_PIECEWISE && d->tf_rows < 2)
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "a piecewise transfer function needs at least two control points");
+    if (tfCols(d->tf_kind) * d->tf_rows > 1024)
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "transfer function table too large (max 1024 floats)");
+    if (!(d->stepsize > 0)) return fail(FVSRN_ERR_INVALID_ARGUMENT, "stepsize must be positive");
+    if (d->blend_mode != FVSRN_BLEND_ALPHA && d->blend_mode != FVSRN_BLEND_BEER_LAMBERT)
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad blend mode");
+    return FVSRN_OK;
+}
+
+int fvsrn_scene_update(fvsrn_scene* scene, const fvsrn_scene_desc* desc) {
+    return guarded([&] {
+        if (!scene) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null scene");
+        if (int r = sceneValidate(desc)) return r;
+        std::lock_guard<std::mutex> lock(scene->mu);
+        const size_t n = size_t(tfCols(desc->tf_kind)) * size_t(std::max(desc->tf_rows, 0));
+        std::vector<float> table(desc->tf_table ? desc->tf_table : nullptr, desc->tf_table ? desc->tf_table + n : nullptr);
+        if (table != scene->tfTable) scene->tfDirty = true;
+        scene->tfTable = std::move(table);
+        scene->desc = *desc;
+        scene->desc.tf_table = nullptr;
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_scene_create(const fvsrn_scene_desc* desc, fvsrn_scene** out) {
+    return guarded([&] {
+        if (!out) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        if (int r = sceneValidate(desc)) return r;
+        auto s = std::make_unique<fvsrn_scene>();
+        const int r = fvsrn_scene_update(s.get(), desc);
+        if (r != FVSRN_OK) return r;
+        *out = s.release();
+        return FVSRN_OK;
+    });
+}
+
+void fvsrn_scene_destroy(fvsrn_scene* scene) { delete scene; }
+
+int fvsrn_camera_on_a_sphere(int orientation, const double center[3], double pitch, double yaw, double distance,
+                             float eye[3], float right[3], float up[3]) {
+    return guarded([&] {
+        if (orientation < 0 || orientation > 5 || !center || !eye || !right || !up)
+            return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad camera arguments");
+        // tables of renderer/camera.cpp:17-35
+        static const double kUp[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+        static const int kPerm[6][3] = {{2, -1, -3}, {-2, 1, 3}, {1, 2, 3}, {-1, -2, -3}, {-3, -1, 2}, {3, 1, -2}};
+        static const bool kInvertYaw[6] = {false, true, true, false, true, false};
+        // eulerToCartesian, camera.cpp:553-569
+        const double y2 = !kInvertYaw[orientation] ? -yaw : +yaw;
+        const double p2 = -pitch;  // OrientationInvertPitch is false for every orientation
+        const double pos[3] = {std::cos(p2) * std::cos(y2) * distance, std::sin(p2) * distance,
+                               std::cos(p2) * std::sin(y2) * distance};
+        double origin[3];
+        for (int i = 0; i < 3; ++i) {
+            const int p = kPerm[orientation][i];
+            origin[i] = pos[std::abs(p) - 1] * (p > 0 ? 1 : -1) + center[i];
+        }
+        // look-at frame, camera.cpp:484-490
+        auto norm = [](double v[3]) {
+            const double l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            v[0] /= l; v[1] /= l; v[2] /= l;
+        };
+        auto cross = [](const double a[3], const double b[3], double o[3]) {
+            o[0] = a[1] * b[2] - a[2] * b[1];
+            o[1] = a[2] * b[0] - a[0] * b[2];
+            o[2] = a[0] * b[1] - a[1] * b[0];
+        };
+        double front[3] = {center[0] - origin[0], center[1] - origin[1], center[2] - origin[2]};
+        norm(front);
+        double r[3], u[3];
+        cross(front, kUp[orientation], r);
+        norm(r);
+        cross(r, front, u);
+        norm(u);
+        for (int i = 0; i < 3; ++i) { eye[i] = float(origin[i]); right[i] = float(r[i]); up[i] = float(u[i]); }
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_render(fvsrn_scene* scene, fvsrn_network* net, int width, int height, int y0, int y1, float* d_out8,
+                 unsigned long long* d_stats, void* stream) {
+    return guarded([&] {
+        if (!scene || !net || !d_out8) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        if (width <= 0 || height <= 0 || y0 < 0 || y1 > height || y0 > y1)
+            return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad image size or row range");
+        std::lock_guard<std::mutex> lockN(net->mu);
+        std::lock_guard<std::mutex> lockS(scene->mu);
+        try {
+            hipStream_t s = static_cast<hipStream_t>(stream);
+            net->ensureDevice(s);
+            const fvsrn_scene_desc& d = scene->desc;
+            const NetworkConfig& c = net->packed.cfg;
+            const bool rgbo = c.outputMode == FVSRN_OUT_RGBO || c.outputMode == FVSRN_OUT_RGBO_DIRECT;
+            // ray_evaluation_stepping.cpp:560-601: the TF is skipped iff the volume emits colour
+            if (rgbo && d.tf_kind != FVSRN_TF_NONE)
+                return fail(FVSRN_ERR_INVALID_ARGUMENT, "the network outputs colour; the scene must use FVSRN_TF_NONE");
+            if (!rgbo && d.tf_kind == FVSRN_TF_NONE)
+                return fail(FVSRN_ERR_INVALID_ARGUMENT, "the network outputs densities; the scene needs a transfer function");
+            if (y0 == y1) return FVSRN_OK;
+
+            const size_t tfFloats = scene->tfTable.size();
+            if (scene->tfDirty) {
+                if (tfFloats) {
+                    scene->dTf.ensure(tfFloats * 4);
+                    HIP_CHECK(hipMemcpyAsync(scene->dTf.ptr, scene->tfTable.data(), tfFloats * 4, hipMemcpyHostToDevice, s));
+                }
+                scene->tfDirty = false;
+            }
+            RenderArgs a{};
+            a.P = net->packed.params;
+            SceneParams& S = a.S;
+            for (int i = 0; i < 3; ++i) { S.eye[i] = d.cam_eye[i]; S.right[i] = d.cam_right[i]; S.up[i] = d.cam_up[i]; }
+            // front = cross(up, right), renderer_camera.cuh:47
+            S.front[0] = S.up[1] * S.right[2] - S.up[2] * S.right[1];
+            S.front[1] = S.up[2] * S.right[0] - S.up[0] * S.right[2];
+            S.front[2] = S.up[0] * S.right[1] - S.up[1] * S.right[0];
+            S.tanFovY = std::tan(d.fov_y_radians / 2);
+            S.tanFovX = S.tanFovY * (float(width) / float(height));  // setAspectRatio, image_evaluator_simple.cpp:204
+            S.stepsize = d.stepsize;
+            S.alphaEarlyOut = 1.0f - 1e-5f;  // ray_evaluation_stepping.cpp:536
+            S.densityMin = d.density_min;
+            S.divDensityRange = 1.0f / (d.density_max - d.density_min);
+            S.earlyOut = d.early_out;
+            S.blendMode = d.blend_mode;
+            S.tfKind = d.tf_kind;
+            S.tfRows = d.tf_rows;
+            S.tfScaleAbsorption = d.tf_scale_absorption;
+            S.tfScaleEmission = d.tf_scale_emission;
+            S.tfTable = static_cast<const float*>(scene->dTf.ptr);
+            S.width = width; S.height = height; S.y0 = y0; S.y1 = y1;
+            a.out = d_out8;
+            a.stats = d_stats;
+            const int tiles = ((width + 7) / 8) * ((y1 - y0 + 7) / 8);
+            const unsigned grid = unsigned((tiles + 3) / 4);
+            const size_t lds = size_t(a.P.ldsBytes) + tfFloats * 4;
+            const hipError_t e = launch_render(net->key, a, grid, lds, s);
+            if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during rendering! ") + hipGetErrorString(e));
+            return FVSRN_OK;
+        } catch (const DeviceError& e) {
+            return fail(fvsrn_device_count() == 0 ? FVSRN_ERR_NO_DEVICE : FVSRN_ERR_DEVICE, e.what());
+        }
+    });
+}
+
+}  // extern "C"

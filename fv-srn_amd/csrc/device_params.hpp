@@ -1,0 +1,49 @@
+// PODs shared by host code and the HIP kernels (passed by value as kernel arguments).
+#pragma once
+#include <cstdint>
+
+#include "../../include/fvsrn.h"
+
+namespace fvsrn {
+
+// MFMA tiling of one SRN (v_mfma_f32_32x32x16_f16):
+//   M tile = 32 output channels, K step = 16 input channels, N tile = 32 samples.
+// LDS image (built by pack.cpp, copied global->LDS once per workgroup):
+//   A fragments: 1 KiB each = 64 lanes x 8 halfs, lane-linear (ds_read_b128 at base+16*lane)
+//     [phase: MT] [layer0: MT x KS0] [layer l=1..NL-1: MT x KS] [last: KS]
+//   biases: fp32, natural channel order, 32*MT per C->C layer, 32 for the last layer
+constexpr int kFragBytes = 1024;
+
+struct NetParams {
+    const void* ldsImage;  // device pointer
+    int ldsBytes;          // multiple of 16
+    int numLayers;         // NL: number of C->C Linear layers (>= 1), the first one consumes Fourier(+grid)
+    int gridK;             // latent grid channels / 16 (0 = none)
+    int outputMode;        // fvsrn_output_mode
+    int offPhase, offLayer0, offHidden, offLast, offBias;  // byte offsets into the LDS image
+    int fourierNeedsFract;  // |phase| may exceed the v_cos_f32 domain of 256 revolutions
+    float actA, actB;       // activation constants, see act() in srn_device.hpp
+    float boxMin[3];
+    float boxSize[3];
+    float invBoxSize[3];
+    // latent grid working copy: f16 [Z][Y][X][G], already time-blended / decoded (FLOAT, BYTE_LINEAR)
+    const void* grid;
+    int gridX, gridY, gridZ, gridC;
+};
+
+struct SceneParams {
+    // camera (renderer_camera.cuh:33-52), front = cross(up,right) and tan(fov/2) precomputed on the host
+    float eye[3], right[3], up[3], front[3];
+    float tanFovX, tanFovY;
+    // DVR (renderer_ray_evaluation_stepping_dvr.cuh:22-30)
+    float stepsize, alphaEarlyOut, densityMin, divDensityRange;
+    int earlyOut, blendMode;
+    // TF
+    int tfKind, tfRows;
+    float tfScaleAbsorption, tfScaleEmission;
+    const float* tfTable;  // device pointer
+    // image
+    int width, height, y0, y1;
+};
+
+}  // namespace fvsrn

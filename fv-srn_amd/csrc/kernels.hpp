@@ -1,0 +1,243 @@
+// Kernel templates: point evaluation and the fused DVR ray-marching renderer.
+#pragma once
+#include "srn_device.hpp"
+
+namespace fvsrn {
+
+constexpr int kBlockThreads = 256;  // 4 waves share one LDS copy of the network
+constexpr int kWavesPerBlock = kBlockThreads / 64;
+
+__device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* lds) {
+    const uint4_t* src = reinterpret_cast<const uint4_t*>(P.ldsImage);
+    uint4_t* dst = reinterpret_cast<uint4_t*>(lds);
+    const int n = P.ldsBytes >> 4;
+    for (int i = threadIdx.x; i < n; i += kBlockThreads) dst[i] = src[i];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// EvaluateNoBatches (reference renderer/renderer_volume_kernels1.cuh:15): positions -> network value
+// ------------------------------------------------------------------------------------------------
+template <int CD, int ACT, bool HAS_GRID, bool HAS_DIR>
+__global__ __launch_bounds__(kBlockThreads) void evaluate_kernel(NetParams P, const float* __restrict__ pos,
+                                                                 const float* __restrict__ dir, size_t n,
+                                                                 float* __restrict__ out, int outChannels) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    load_network_to_lds(P, lds);
+    const int lane = lane_id();
+    const size_t wave = size_t(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+    const size_t numWaves = size_t(gridDim.x) * kWavesPerBlock;
+    const size_t batches = (n + 63) / 64;
+    for (size_t b = wave; b < batches; b += numWaves) {  // wave-uniform trip count: EXEC stays full
+        const size_t i = b * 64 + lane;
+        const bool valid = i < n;
+        const size_t j = valid ? i : 0;
+        float px = pos[3 * j + 0], py = pos[3 * j + 1], pz = pos[3 * j + 2];
+        float dx = 0, dy = 0, dz = 0;
+        if constexpr (HAS_DIR) { dx = dir[3 * j + 0]; dy = dir[3 * j + 1]; dz = dir[3 * j + 2]; }
+        // renderer_volume_tensorcores.cuh:744-746
+        px = (px - P.boxMin[0]) * P.invBoxSize[0];
+        py = (py - P.boxMin[1]) * P.invBoxSize[1];
+        pz = (pz - P.boxMin[2]) * P.invBoxSize[2];
+        const float4_t o = srn_forward<CD, ACT, HAS_GRID, HAS_DIR>(P, lds, px, py, pz, dx, dy, dz);
+        if (valid) {
+            switch (P.outputMode) {
+                case FVSRN_OUT_DENSITY:
+                case FVSRN_OUT_DENSITY_GRADIENT:
+                    out[i * outChannels] = sigmoid_f(o[0]);
+                    break;
+                case FVSRN_OUT_RGBO:
+                    out[i * 4 + 0] = sigmoid_f(o[0]);
+                    out[i * 4 + 1] = sigmoid_f(o[1]);
+                    out[i * 4 + 2] = sigmoid_f(o[2]);
+                    out[i * 4 + 3] = softplus_f(o[3]);
+                    break;
+                case FVSRN_OUT_RGBO_DIRECT:
+                    out[i * 4 + 0] = fminf(fmaxf(o[0], 0.f), 1.f);
+                    out[i * 4 + 1] = fminf(fmaxf(o[1], 0.f), 1.f);
+                    out[i * 4 + 2] = fminf(fmaxf(o[2], 0.f), 1.f);
+                    out[i * 4 + 3] = fmaxf(o[3], 0.f);
+                    break;
+                default:  // density:direct and the direct gradient modes: un-clamped
+                    out[i * outChannels] = o[0];
+                    break;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// transfer functions (reference renderer/renderer_tf_*.cuh); density already mapped by the DVR loop
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* __restrict__ tfLds, float density) {
+    density = fminf(fmaxf(density, 0.f), 1.f);
+    float4_t c = {0, 0, 0, 0};
+    switch (S.tfKind) {
+        case FVSRN_TF_IDENTITY: {  // renderer_tf_identity.cuh:36-54
+            const float e = density * S.tfScaleEmission;
+            c = float4_t{e, e, e, density * S.tfScaleAbsorption * S.stepsize};
+        } break;
+        case FVSRN_TF_GAUSSIAN: {  // renderer_tf_gaussian.cuh:43-86 (non-analytic, no gradient scaling)
+            for (int i = 0; i < S.tfRows; ++i) {
+                const float* r = tfLds + 6 * i;
+                const float t = density - r[4];
+                const float ni = __expf(-t * t / (r[5] * r[5]));
+                c[0] += r[0] * ni; c[1] += r[1] * ni; c[2] += r[2] * ni; c[3] += r[3] * ni;
+            }
+            c[3] *= S.stepsize;
+        } break;
+        case FVSRN_TF_PIECEWISE: {  // renderer_tf_piecewise.cuh:29-62
+            int i;
+            for (i = 0; i < S.tfRows - 2; ++i)
+                if (tfLds[5 * (i + 1) + 4] > density) break;
+            const float* a = tfLds + 5 * i;
+            const float* b = tfLds + 5 * (i + 1);
+            const float d = fminf(fmaxf(density, a[4]), b[4]);
+            const float f = (d - a[4]) / (b[4] - a[4]);
+            c = float4_t{a[0] + f * (b[0] - a[0]), a[1] + f * (b[1] - a[1]), a[2] + f * (b[2] - a[2]),
+                         (a[3] + f * (b[3] - a[3])) * S.stepsize};
+        } break;
+        case FVSRN_TF_TEXTURE: {  // renderer_tf_texture.cuh:46-55 (tensor mode)
+            const int R = S.tfRows;
+            const float d = density * R - 0.5f;
+            const int di = int(floorf(d));
+            const float df = d - di;
+            const float* a = tfLds + 4 * min(max(di, 0), R - 1);
+            const float* b = tfLds + 4 * min(max(di + 1, 0), R - 1);
+            c = float4_t{a[0] + df * (b[0] - a[0]), a[1] + df * (b[1] - a[1]), a[2] + df * (b[2] - a[2]),
+                         (a[3] + df * (b[3] - a[3])) * S.stepsize};
+        } break;
+        default: break;
+    }
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ImageEvaluatorSimpleKernel + CameraReferenceFrame + RayEvaluationSteppingDvr + Blending, fused.
+//   reference: renderer_image_evaluator_simple.cuh:36-127, renderer_camera.cuh:33-52,
+//              renderer_utils.cuh:91-105, renderer_ray_evaluation_stepping_dvr.cuh:48-157,
+//              renderer_blending.cuh:35-51
+// One wave = one 8x8 pixel tile (the reference: 32 consecutive x of one row; per-pixel results do not
+// depend on the grouping because blending is guarded by isValid).  Stepping is wave-synchronous like
+// the reference's __any_sync loop: all 64 lanes evaluate the network until no lane is valid.
+// ------------------------------------------------------------------------------------------------
+template <int CD, int ACT, bool HAS_GRID, bool HAS_DIR>
+__global__ __launch_bounds__(kBlockThreads) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+                                                               unsigned long long* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    load_network_to_lds(P, lds);
+    // TF table behind the network image
+    float* tfLds = reinterpret_cast<float*>(lds + P.ldsBytes);
+    {
+        const int cols = S.tfKind == FVSRN_TF_GAUSSIAN ? 6 : (S.tfKind == FVSRN_TF_PIECEWISE ? 5 : (S.tfKind == FVSRN_TF_TEXTURE ? 4 : 0));
+        for (int i = threadIdx.x; i < cols * S.tfRows; i += kBlockThreads) tfLds[i] = S.tfTable[i];
+        __syncthreads();
+    }
+
+    const int lane = lane_id();
+    const int tilesX = (S.width + 7) >> 3;
+    const int tilesY = (S.y1 - S.y0 + 7) >> 3;
+    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile >= tilesX * tilesY) return;  // whole wave leaves together
+    const int tx = tile % tilesX, ty = tile / tilesX;
+    const int x = tx * 8 + (lane & 7);
+    const int y = S.y0 + ty * 8 + (lane >> 3);
+    const bool inImage = x < S.width && y < S.y1;
+
+    // camera ray (renderer_image_evaluator_simple.cuh:84-88, renderer_camera.cuh:33-52)
+    const float ndcx = 2.f * (float(x) + 0.5f) / float(S.width) - 1.f;
+    const float ndcy = 2.f * (float(y) + 0.5f) / float(S.height) - 1.f;
+    float dx = S.front[0] + ndcx * S.tanFovX * S.right[0] + ndcy * S.tanFovY * S.up[0];
+    float dy = S.front[1] + ndcx * S.tanFovX * S.right[1] + ndcy * S.tanFovY * S.up[1];
+    float dz = S.front[2] + ndcx * S.tanFovX * S.right[2] + ndcy * S.tanFovY * S.up[2];
+    const float invLen = rsqrtf(dx * dx + dy * dy + dz * dz);
+    dx *= invLen; dy *= invLen; dz *= invLen;
+    const float ox = S.eye[0], oy = S.eye[1], oz = S.eye[2];
+
+    // box intersection (renderer_utils.cuh:91-105)
+    float tmin, tmax;
+    {
+        const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+        const float t1 = (P.boxMin[0] - ox) * ix, t2 = (P.boxMin[0] + P.boxSize[0] - ox) * ix;
+        const float t3 = (P.boxMin[1] - oy) * iy, t4 = (P.boxMin[1] + P.boxSize[1] - oy) * iy;
+        const float t5 = (P.boxMin[2] - oz) * iz, t6 = (P.boxMin[2] + P.boxSize[2] - oz) * iz;
+        tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+        tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    }
+    tmin = fmaxf(tmin, 0.f);  // stepping_dvr.cuh:66-67 (tmax input of the image evaluator is FLT_MAX)
+    if (!inImage) tmax = -1.f;  // padding lanes never become valid
+
+    float cr = 0, cg = 0, cb = 0, ca = 0, nx = 0, ny = 0, nz = 0, depth = 0;
+    unsigned nValid = 0, nSteps = 0;
+    const bool rgboNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
+    const bool gradNet = P.outputMode >= FVSRN_OUT_DENSITY_GRADIENT && P.outputMode <= FVSRN_OUT_DENSITY_GRADIENT_CUBIC;
+
+    for (int i = 0;; ++i) {
+        const float t = tmin + float(i) * S.stepsize;
+        const bool valid = (t <= tmax) && (!S.earlyOut || ca < S.alphaEarlyOut);
+        if (!__any(valid)) break;  // wave-uniform
+        ++nSteps;
+        nValid += valid ? 1u : 0u;
+
+        const float wx = ox + dx * t, wy = oy + dy * t, wz = oz + dz * t;
+        const float px = (wx - P.boxMin[0]) * P.invBoxSize[0];
+        const float py = (wy - P.boxMin[1]) * P.invBoxSize[1];
+        const float pz = (wz - P.boxMin[2]) * P.invBoxSize[2];
+        const float4_t o = srn_forward<CD, ACT, HAS_GRID, HAS_DIR>(P, lds, px, py, pz, dx, dy, dz);
+
+        float4_t color = {0, 0, 0, 0};
+        float gx = 0, gy = 0, gz = 0;
+        if (rgboNet) {  // stepping_dvr.cuh:104-109
+            if (P.outputMode == FVSRN_OUT_RGBO)
+                color = float4_t{sigmoid_f(o[0]), sigmoid_f(o[1]), sigmoid_f(o[2]), softplus_f(o[3])};
+            else
+                color = float4_t{fminf(fmaxf(o[0], 0.f), 1.f), fminf(fmaxf(o[1], 0.f), 1.f), fminf(fmaxf(o[2], 0.f), 1.f), fmaxf(o[3], 0.f)};
+            color[3] *= S.stepsize;
+        } else {  // stepping_dvr.cuh:110-135
+            const float value = (P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_GRADIENT) ? sigmoid_f(o[0]) : o[0];
+            const float density2 = (value - S.densityMin) * S.divDensityRange;
+            const bool requireNormal = valid && (value >= S.densityMin);
+            if (gradNet) {
+                gx = o[1]; gy = o[2]; gz = o[3];
+                if (P.outputMode == FVSRN_OUT_DENSITY_GRADIENT_CUBIC) { gx = gx * gx * gx; gy = gy * gy * gy; gz = gz * gz * gz; }
+            }
+            if (requireNormal) color = tf_eval(S, tfLds, density2);
+        }
+        if (color[3] > 0.f && valid) {  // BRDF Lambert without Phong / magnitude scaling passes through
+            // safeNormalize (helper_math.cuh:2443-2448)
+            const float l2 = gx * gx + gy * gy + gz * gz;
+            if (l2 >= 1e-8f) { const float il = rsqrtf(l2); gx *= il; gy *= il; gz *= il; }
+            // Blending::eval (renderer_blending.cuh:35-51)
+            const float a = S.blendMode == FVSRN_BLEND_BEER_LAMBERT ? 1.f - __expf(-color[3]) : fminf(1.f, color[3]);
+            const float w = (1.f - ca) * a;
+            cr += w * color[0]; cg += w * color[1]; cb += w * color[2];
+            nx += w * gx; ny += w * gy; nz += w * gz;
+            depth += w * t;
+            ca += w;
+        }
+    }
+
+    if (inImage) {  // renderer_image_evaluator_simple.cuh:100-124 with samples == 1
+        const size_t plane = size_t(S.width) * S.height;
+        const size_t o = size_t(y) * S.width + x;
+        out[o] = cr;
+        out[plane + o] = cg;
+        out[2 * plane + o] = cb;
+        out[3 * plane + o] = ca;
+        out[4 * plane + o] = nx * ca;  // out.normal += nout.normal * nout.color.w
+        out[5 * plane + o] = ny * ca;
+        out[6 * plane + o] = nz * ca;
+        out[7 * plane + o] = depth * ca / ca;  // (depth*alpha)/alpha, NaN for alpha == 0 like the reference
+    }
+    if (stats) {
+        unsigned long long v = nValid;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) {
+            atomicAdd(&stats[0], v);
+            atomicAdd(&stats[1], (unsigned long long)nSteps * 64ull);
+        }
+    }
+}
+
+}  // namespace fvsrn

@@ -1,0 +1,48 @@
+// Variant dispatch: one translation unit per hidden width (CD = C/16) instantiates the kernels for
+// every activation x {grid, no grid}; the host picks a variant from NetworkConfig.  This replaces
+// the reference's run-time NVRTC specialisation (renderer/kernel_loader.cpp:197-273, the 13 #defines
+// of SceneNetwork::getDefines) by a bounded ahead-of-time matrix.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_params.hpp"
+
+namespace fvsrn {
+
+struct EvalArgs {
+    NetParams P;
+    const float* pos;
+    const float* dir;
+    size_t n;
+    float* out;
+    int outChannels;
+};
+struct RenderArgs {
+    NetParams P;
+    SceneParams S;
+    float* out;
+    unsigned long long* stats;
+};
+struct VariantKey {
+    int CD;    // hidden channels / 16
+    int act;   // ACT_*
+    bool grid;
+    bool dir;
+};
+struct KernelInfo {
+    const void* evalFn = nullptr;
+    const void* renderFn = nullptr;
+    const char* evalName = "";
+    const char* renderName = "";
+};
+
+// implemented per CD in kernels_cd*.hip; returns false if the variant is not compiled in
+template <int CD> bool kernel_info_cd(const VariantKey& k, KernelInfo* info);
+template <int CD> hipError_t launch_eval_cd(const VariantKey& k, const EvalArgs& a, unsigned gridDim, size_t ldsBytes, hipStream_t s);
+template <int CD> hipError_t launch_render_cd(const VariantKey& k, const RenderArgs& a, unsigned gridDim, size_t ldsBytes, hipStream_t s);
+
+bool kernel_info(const VariantKey& k, KernelInfo* info);
+hipError_t launch_eval(const VariantKey& k, const EvalArgs& a, unsigned gridDim, size_t ldsBytes, hipStream_t s);
+hipError_t launch_render(const VariantKey& k, const RenderArgs& a, unsigned gridDim, size_t ldsBytes, hipStream_t s);
+
+}  // namespace fvsrn

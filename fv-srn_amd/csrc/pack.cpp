@@ -1,0 +1,246 @@
+// Builds the LDS image (MFMA A-operand fragments + fp32 biases) of a network.
+//
+// What the reference does at this point: SceneNetwork::fillConstantMemory
+// (renderer/volume_interpolation_network.cpp:1236-1417) copies the stored half matrices into a
+// __constant__ block and the kernel ctor copies them to shared memory
+// (renderer/renderer_volume_tensorcores.cuh:401-564).  Here the matrices are permuted ONCE on the
+// host into the exact per-lane order v_mfma_f32_32x32x16_f16 wants, so that the accumulator of
+// layer l is directly the B operand of layer l+1 (no LDS round trip for activations).
+#include "pack.hpp"
+
+#include <cmath>
+#include <cstring>
+
+#include "half.hpp"
+
+namespace fvsrn {
+
+namespace {
+
+// Row of the layer-0 input tile ("X0", produced by the phase MFMA) -> channel index of the padded
+// Fourier vector [x,y,z,(t|0),(dx,dy,dz,0),cos...,sin...] the reference builds
+// (renderer_volume_tensorcores.cuh:768-808).
+//  no direction: pass-through channels live in accumulator registers 0,1 of M tile 0, i.e. rows
+//                {0,1} (lane half 0) and {4,5} (lane half 1)
+//  direction:    registers 0..3 -> rows 0..7 = channels 0..7 (identity)
+std::vector<int> rowToChannel(int C, bool hasDirection) {
+    std::vector<int> map(size_t(C), -1);
+    if (hasDirection) {
+        for (int r = 0; r < C; ++r) map[size_t(r)] = r;
+        return map;
+    }
+    map[0] = 0; map[1] = 1; map[4] = 2; map[5] = 3;
+    int next = 4;
+    for (int r = 0; r < C; ++r)
+        if (map[size_t(r)] < 0) map[size_t(r)] = next++;
+    return map;
+}
+
+struct Frag {  // one A fragment: [lane 0..63][j 0..7] half bits
+    uint16_t v[64][8];
+};
+
+void putFrag(std::vector<char>& img, size_t off, const Frag& f) { std::memcpy(img.data() + off, f.v, kFragBytes); }
+
+}  // namespace
+
+void packLatentGrid(const SceneNetwork& net, PackedNetwork& out) {
+    out.grid.clear();
+    out.gridX = out.gridY = out.gridZ = out.gridC = 0;
+    if (!net.latentGrid) return;
+    const LatentGridTimeAndEnsemble& lg = *net.latentGrid;
+    const fvsrn_grid_encoding enc = lg.commonEncoding();
+    if (enc == FVSRN_GRID_BYTE_GAUSSIAN)
+        throw Unsupported("latent grid encoding BYTE_GAUSSIAN is not in the compiled variant set (FLOAT, BYTE_LINEAR)");
+    const LatentGrid& first = lg.hasTimeGrids() ? *lg.timeGrids[0] : *lg.ensembleGrids[0];
+    const int X = first.gridSizeX, Y = first.gridSizeY, Z = first.gridSizeZ;
+    for (const auto* list : {&lg.timeGrids, &lg.ensembleGrids})
+        for (const auto& g : *list)
+            if (g->gridSizeX != X || g->gridSizeY != Y || g->gridSizeZ != Z)
+                throw Unsupported("all latent grids must share one resolution");
+    const int Gt = lg.timeChannels(), Ge = lg.ensembleChannels(), G = Gt + Ge;
+    out.gridX = X; out.gridY = Y; out.gridZ = Z; out.gridC = G;
+    out.grid.assign(size_t(X) * Y * Z * G, 0);
+
+    auto decode = [&](const LatentGrid& g, const LatentGrid& coeffs, int c, int z, int y, int x) {
+        const float r = g.raw(c, z, y, x);
+        if (enc == FVSRN_GRID_FLOAT) return r;
+        return coeffs.gridOffsetOrMean[size_t(c)] + r * coeffs.gridScaleOrStd[size_t(c)];
+    };
+
+    if (lg.hasTimeGrids()) {
+        // volume_interpolation_network.cpp:1308-1329 + renderer_volume_tensorcores.cuh:581-591
+        const float time = lg.interpolateTime(net.currentTime);
+        const int lo = std::min(int(time), lg.timeNum - 1);
+        const int hi = std::min(lo + 1, lg.timeNum - 1);
+        const float f = time - std::floor(time);
+        const LatentGrid& A = *lg.timeGrids[size_t(lo)];
+        const LatentGrid& B = *lg.timeGrids[size_t(hi)];
+        for (int z = 0; z < Z; ++z) for (int y = 0; y < Y; ++y) for (int x = 0; x < X; ++x)
+            for (int c = 0; c < Gt; ++c) {
+                const float a = decode(A, A, c, z, y, x);
+                const float b = decode(B, A, c, z, y, x);  // reference quirk: B decoded with A's coefficients
+                const float v = a + f * (b - a);
+                out.grid[((size_t(z) * Y + y) * X + x) * G + c] = float_to_half_bits(v);
+            }
+    }
+    if (lg.hasEnsembleGrids()) {  // :1332-1350, no interpolation
+        const LatentGrid& E = *lg.ensembleGrids[size_t(lg.interpolateEnsemble(net.currentEnsemble))];
+        for (int z = 0; z < Z; ++z) for (int y = 0; y < Y; ++y) for (int x = 0; x < X; ++x)
+            for (int c = 0; c < Ge; ++c)
+                out.grid[((size_t(z) * Y + y) * X + x) * G + Gt + c] = float_to_half_bits(decode(E, E, c, z, y, x));
+    }
+}
+
+PackedNetwork packNetwork(const SceneNetwork& net) {
+    std::string why;
+    if (!net.valid(&why)) throw InvalidNetwork(why);
+    PackedNetwork P;
+    P.cfg = net.config();
+    const NetworkConfig& c = P.cfg;
+    if (!c.hasFourier) throw Unsupported("networks without Fourier features are not in the compiled variant set");
+    if (c.outputMode >= FVSRN_OUT_DENSITY_CURVATURE)
+        throw Unsupported(std::string("output mode ") + outputModeName(c.outputMode) + " is not in the compiled variant set");
+    const int C = c.hiddenChannels;
+    if (C != 32 && C != 48 && C != 64 && C != 96 && C != 128)
+        throw Unsupported("hidden width " + std::to_string(C) + " is not in the compiled variant set (32,48,64,96,128)");
+    if (c.gridChannels % 16 != 0) throw InvalidNetwork("latent grid channels must be a multiple of 16");
+    const int MT = (C + 31) / 32, KS = C / 16, KG = c.gridChannels / 16, KS0 = KS + KG;
+    const int NL = c.numHiddenLayers + 1;  // C->C layers; hidden[0] is the first, hidden[NL] the last
+    if (int(net.hidden.size()) != NL + 1) throw InvalidNetwork("unexpected layer count");
+    const int Cout = net.outputChannelsIn();
+    if (Cout > 4) throw Unsupported("more than 4 network outputs are not in the compiled variant set");
+    P.MT = MT; P.KS = KS; P.KS0 = KS0; P.NL = NL;
+
+    NetParams& np = P.params;
+    size_t off = 0;
+    np.offPhase = int(off);  off += size_t(MT) * kFragBytes;
+    np.offLayer0 = int(off); off += size_t(MT) * KS0 * kFragBytes;
+    np.offHidden = int(off); off += size_t(NL - 1) * MT * KS * kFragBytes;
+    np.offLast = int(off);   off += size_t(KS) * kFragBytes;
+    np.offBias = int(off);   off += (size_t(NL) * 32 * MT + 32) * sizeof(float);
+    np.ldsBytes = int(off);
+    P.ldsImage.assign(off, 0);
+    np.numLayers = NL;
+    np.gridK = KG;
+    np.outputMode = int(c.outputMode);
+
+    const bool hasDir = c.directionMode > 0;
+    const std::vector<int> chanOfRow = rowToChannel(C, hasDir);
+    const int F = c.numFourier;
+    const int base = hasDir ? 8 : 4;
+    const int fcols = c.directionMode == 2 ? 6 : 3;
+
+    // ---- phase fragments: D = Fm * [x,x,y,y,z,z,1,0 | dx,dx,dy,dy,dz,dz,0,0] in revolutions --------
+    double maxPhase = 0;
+    for (int m = 0; m < MT; ++m) {
+        Frag f{};
+        for (int lane = 0; lane < 64; ++lane) {
+            const int row = 32 * m + (lane & 31), h = lane >> 5;
+            if (row >= C) continue;
+            const int ch = chanOfRow[size_t(row)];
+            float slots[16] = {0};
+            if (ch < base) {
+                if (ch < 3) slots[2 * ch] = 1.f;  // position pass-through
+                else if (ch == 3) slots[6] = c.passTime ? half_bits_to_float(float_to_half_bits(
+                                       net.latentGrid ? net.latentGrid->interpolateTime(net.currentTime) : 0.f)) : 0.f;
+                else if (ch < 7) slots[8 + 2 * (ch - 4)] = 1.f;  // direction pass-through
+            } else {
+                const int idx = ch - base;
+                const int feat = idx < F ? idx : idx - F;
+                double sumAbs = 0;
+                for (int cin = 0; cin < fcols; ++cin) {
+                    const double v = double(half_bits_to_float(net.input.fourierMatrix[size_t(feat) + size_t(F) * cin])) /
+                                     (2.0 * 3.14159265358979323846);
+                    const float hi = half_bits_to_float(float_to_half_bits(float(v)));
+                    const float lo = half_bits_to_float(float_to_half_bits(float(v - double(hi))));
+                    const int s0 = (cin < 3 ? 0 : 8) + 2 * (cin % 3);
+                    slots[s0] = hi;
+                    slots[s0 + 1] = lo;
+                    sumAbs += std::fabs(v) * (cin < 3 ? 1.0 : 1.0);
+                }
+                if (idx >= F) slots[6] = -0.25f;  // sin(2 pi x) = cos(2 pi (x - 1/4))
+                maxPhase = std::max(maxPhase, sumAbs + 0.25);
+            }
+            for (int j = 0; j < 8; ++j) f.v[lane][j] = float_to_half_bits(slots[8 * h + j]);
+        }
+        putFrag(P.ldsImage, size_t(np.offPhase) + size_t(m) * kFragBytes, f);
+    }
+    np.fourierNeedsFract = maxPhase >= 255.0 ? 1 : 0;
+
+    // ---- C->C layers ---------------------------------------------------------------------------------
+    float* bias = reinterpret_cast<float*>(P.ldsImage.data() + np.offBias);
+    for (int l = 0; l < NL; ++l) {
+        const Layer& L = net.hidden[size_t(l)];
+        const int ks = l == 0 ? KS0 : KS;
+        const size_t baseOff = l == 0 ? size_t(np.offLayer0) : size_t(np.offHidden) + size_t(l - 1) * MT * KS * kFragBytes;
+        if (L.channelsOut != C) throw InvalidNetwork("hidden layer width mismatch");
+        for (int m = 0; m < MT; ++m)
+            for (int s = 0; s < ks; ++s) {
+                Frag f{};
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int row = 32 * m + (lane & 31), h = lane >> 5;
+                    if (row >= C) continue;
+                    for (int j = 0; j < 8; ++j) {
+                        int col;
+                        if (s < KS) {
+                            const int prevRow = chiOfSlot(16 * s + 8 * h + j);
+                            col = l == 0 ? chanOfRow[size_t(prevRow)] : prevRow;
+                        } else {
+                            col = C + 16 * (s - KS) + 8 * h + j;  // latent grid channel
+                        }
+                        f.v[lane][j] = L.weights[size_t(row) * L.channelsIn + col];
+                    }
+                }
+                putFrag(P.ldsImage, baseOff + (size_t(m) * ks + s) * kFragBytes, f);
+            }
+        for (int r = 0; r < C; ++r) bias[size_t(l) * 32 * MT + r] = half_bits_to_float(L.bias[size_t(r)]);
+    }
+
+    // ---- last layer: outputs replicated on rows 0..3 and 4..7 so both lane halves see them -------------
+    {
+        const Layer& L = net.hidden[size_t(NL)];
+        if (L.channelsIn != C || L.channelsOut != Cout) throw InvalidNetwork("last layer shape mismatch");
+        const bool transposed = L.channelsIn < 16 || L.channelsOut < 16;  // addLayer stores [in][out]
+        for (int s = 0; s < KS; ++s) {
+            Frag f{};
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = lane & 31, h = lane >> 5;
+                if (row >= 8 || (row & 3) >= Cout) continue;
+                const int o = row & 3;
+                for (int j = 0; j < 8; ++j) {
+                    const int col = chiOfSlot(16 * s + 8 * h + j);
+                    f.v[lane][j] = transposed ? L.weights[size_t(col) * Cout + o] : L.weights[size_t(o) * C + col];
+                }
+            }
+            putFrag(P.ldsImage, size_t(np.offLast) + size_t(s) * kFragBytes, f);
+        }
+        float* bl = bias + size_t(NL) * 32 * MT;
+        for (int o = 0; o < Cout; ++o) bl[o] = bl[4 + o] = half_bits_to_float(L.bias[size_t(o)]);
+    }
+
+    // ---- activation constants (see act() in srn_device.hpp) --------------------------------------------
+    const double p = c.activationParam;
+    const double pi = 3.14159265358979323846;
+    switch (c.activation) {
+        case FVSRN_ACT_RELU: np.actA = 0; np.actB = 0; break;
+        case FVSRN_ACT_SINE: np.actA = float(p / (2 * pi)); np.actB = 0; break;
+        case FVSRN_ACT_SNAKE: np.actA = float(p / pi); np.actB = float(1.0 / (2 * p)); break;
+        case FVSRN_ACT_SNAKEALT: np.actA = float(p / pi); np.actB = float(1.0 / (2 * p)); break;
+        default:
+            throw Unsupported(std::string("hidden activation ") + activationName(c.activation) +
+                              " is not in the compiled variant set (ReLU, Sine, Snake, SnakeAlt)");
+    }
+    for (int i = 0; i < 3; ++i) {
+        np.boxMin[i] = net.boxMin[i];
+        np.boxSize[i] = net.boxSize[i];
+        np.invBoxSize[i] = 1.0f / net.boxSize[i];
+    }
+    P.mfmaFlopsPerSample = 1024.0 * (MT + double(MT) * KS0 + double(NL - 1) * MT * KS + KS);
+
+    packLatentGrid(net, P);
+    np.gridX = P.gridX; np.gridY = P.gridY; np.gridZ = P.gridZ; np.gridC = P.gridC;
+    return P;
+}
+
+}  // namespace fvsrn

@@ -1,0 +1,201 @@
+/*
+ * fvsrn.h -- C ABI of the MI355X-native fV-SRN inference renderer (libfvsrn.so).
+ *
+ * This is the drop-in boundary for ONE hot path of shamanDevel/fV-SRN: the fused
+ * SRN-MLP + DVR ray-stepping renderer.  Every entry point names
+ * the reference interface it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, PODs; no torch / pybind / C++ types cross this line
+ *   - every function returns FVSRN_OK (0) or a negative error code; the text of the
+ *     last error of the calling thread is available from fvsrn_last_error()
+ *     (reference: C++ exceptions -> Python RuntimeError, renderer/kernel_loader.cpp:19-31)
+ *   - pointers named d_* are DEVICE pointers (HIP), h_* / unprefixed are host pointers
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); all device work is
+ *     enqueued asynchronously on it, like the reference uses the current torch stream
+ *     (renderer/iimage_evaluator.cpp:167-170)
+ *   - handles are re-entrant per object; distinct objects may be used from distinct threads
+ */
+#ifndef FVSRN_H_
+#define FVSRN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FVSRN_OK 0
+#define FVSRN_ERR_INVALID_ARGUMENT (-1) /* bad pointer / size / enum                       */
+#define FVSRN_ERR_FORMAT (-2)           /* malformed or unsupported .volnet bytes          */
+#define FVSRN_ERR_INVALID_NETWORK (-3)  /* SceneNetwork::valid() failed                    */
+#define FVSRN_ERR_UNSUPPORTED (-4)      /* outside the ahead-of-time compiled variant set  */
+#define FVSRN_ERR_DEVICE (-5)           /* HIP runtime error                               */
+#define FVSRN_ERR_NO_DEVICE (-6)        /* no GPU / kernels not usable                     */
+
+/* activation of the hidden layers: renderer/volume_interpolation_network.cpp:223-230 */
+typedef enum {
+    FVSRN_ACT_RELU = 0, FVSRN_ACT_SINE = 1, FVSRN_ACT_SNAKE = 2,
+    FVSRN_ACT_SNAKEALT = 3, FVSRN_ACT_SIGMOID = 4, FVSRN_ACT_NONE = 5
+} fvsrn_activation;
+
+/* output parametrization: renderer/volume_interpolation_network.cpp:165-181 */
+typedef enum {
+    FVSRN_OUT_DENSITY = 0, FVSRN_OUT_DENSITY_DIRECT = 1, FVSRN_OUT_RGBO = 2, FVSRN_OUT_RGBO_DIRECT = 3,
+    FVSRN_OUT_DENSITY_GRADIENT = 4, FVSRN_OUT_DENSITY_GRADIENT_DIRECT = 5, FVSRN_OUT_DENSITY_GRADIENT_CUBIC = 6,
+    FVSRN_OUT_DENSITY_CURVATURE = 7, FVSRN_OUT_DENSITY_CURVATURE_DIRECT = 8
+} fvsrn_output_mode;
+
+/* latent grid encodings: renderer/volume_interpolation_network.h (LatentGrid::Encoding) */
+typedef enum { FVSRN_GRID_FLOAT = 0, FVSRN_GRID_BYTE_LINEAR = 1, FVSRN_GRID_BYTE_GAUSSIAN = 2 } fvsrn_grid_encoding;
+
+/* transfer functions: renderer/renderer_tf_{identity,gaussian,piecewise,texture}.cuh */
+typedef enum {
+    FVSRN_TF_NONE = 0,      /* network emits rgbo directly (RAY_EVALUATION_STEPPING__SKIP_TRANSFER_FUNCTION) */
+    FVSRN_TF_IDENTITY = 1,  /* table unused; tf_scale_absorption / tf_scale_emission                          */
+    FVSRN_TF_GAUSSIAN = 2,  /* table (R,6): r,g,b,opacity*absorptionScaling,mean,sigma                        */
+    FVSRN_TF_PIECEWISE = 3, /* table (R,5): r,g,b,absorption,position (sorted)                                */
+    FVSRN_TF_TEXTURE = 4    /* table (R,4): rgba texels, sampled as d*R-0.5 lerp (tensor mode)                */
+} fvsrn_tf_kind;
+
+/* blending: renderer/renderer_blending.cuh:16-52 */
+typedef enum { FVSRN_BLEND_ALPHA = 0, FVSRN_BLEND_BEER_LAMBERT = 1 } fvsrn_blend_mode;
+
+typedef struct fvsrn_network fvsrn_network; /* SceneNetwork + its device image          */
+typedef struct fvsrn_scene fvsrn_scene;     /* camera + DVR + TF + blending parameters   */
+
+/* ----------------------------------------------------------------------------------------
+ * library
+ * -------------------------------------------------------------------------------------- */
+/* text of the last error raised on the calling thread ("" if none) */
+const char* fvsrn_last_error(void);
+/* "fvsrn <version> gfx950" */
+const char* fvsrn_version(void);
+/* number of visible HIP devices (0 without a GPU; never fails) */
+int fvsrn_device_count(void);
+
+/* ----------------------------------------------------------------------------------------
+ * SceneNetwork  (replaces renderer::SceneNetwork, renderer/volume_interpolation_network.{h,cpp})
+ * -------------------------------------------------------------------------------------- */
+/* SceneNetwork::load(std::istream&)   volume_interpolation_network.cpp:1059-1086 */
+int fvsrn_network_create_from_volnet(const void* bytes, size_t len, fvsrn_network** out);
+/* SceneNetwork()                      volume_interpolation_network.cpp:798-804 */
+int fvsrn_network_create(fvsrn_network** out);
+void fvsrn_network_destroy(fvsrn_network* net);
+
+/* InputParametrization fields + setFourierMatrixFromTensor   :129-156
+ * matrix is row-major (num_fourier, 3|6) fp32; multiplied by 2*pi unless premultiplied. */
+int fvsrn_network_set_input(fvsrn_network* net, int has_time, int has_direction,
+                            const float* fourier_matrix, int num_fourier, int fourier_cols,
+                            int premultiplied);
+/* OutputParametrization::outputMode   :183-200 */
+int fvsrn_network_set_output_mode(fvsrn_network* net, fvsrn_output_mode mode);
+/* SceneNetwork::addLayerFromTorch     :896-921 (weights (out,in) row-major fp32, bias (out)) */
+int fvsrn_network_add_layer(fvsrn_network* net, const float* weights, const float* bias,
+                            int channels_out, int channels_in, fvsrn_activation act, float act_param);
+/* SceneNetwork::setBoxMin/setBoxSize */
+int fvsrn_network_set_box(fvsrn_network* net, const float box_min[3], const float box_size[3]);
+/* LatentGridTimeAndEnsemble(time_min,time_num,time_step,ensemble_min,ensemble_num)   .h:328-338 */
+int fvsrn_network_set_latent_grid_layout(fvsrn_network* net, int time_min, int time_num, int time_step,
+                                         int ensemble_min, int ensemble_num);
+/* setTimeGridFromTorch / setEnsembleGridFromTorch  :616-630; grid is (C,Z,Y,X) fp32.
+ * *encoding_error receives the average absolute encoding error (LastEncodingError). */
+int fvsrn_network_set_latent_grid(fvsrn_network* net, int is_ensemble, int index, const float* grid,
+                                  int C, int Z, int Y, int X, fvsrn_grid_encoding enc,
+                                  double* encoding_error);
+/* SceneNetwork::valid()               :940-985   (1 valid, 0 invalid + message) */
+int fvsrn_network_valid(const fvsrn_network* net);
+/* SceneNetwork::save(std::ostream&)   :1088-1104. Call with buf==NULL to query *len. */
+int fvsrn_network_save_volnet(const fvsrn_network* net, void* buf, size_t cap, size_t* len);
+/* SceneNetwork::setTimeAndEnsemble    :923-938 (clamps silently) */
+int fvsrn_network_set_time_and_ensemble(fvsrn_network* net, float time, int ensemble);
+/* SceneNetwork::clearGPUResources     :1106-1112 */
+int fvsrn_network_clear_gpu_resources(fvsrn_network* net);
+
+typedef struct {
+    int num_layers;          /* hidden_.size() (all Linear layers incl. the last)          */
+    int hidden_channels;     /* HIDDEN_CHANNELS of getDefines()                             */
+    int num_fourier;         /* NUM_FOURIER_FEATURES                                        */
+    int has_direction, has_time, use_direction_in_fourier;
+    int output_mode;         /* fvsrn_output_mode                                           */
+    int output_channels;     /* OutputModeNumChannelsOut: 1 or 4                            */
+    int activation;          /* fvsrn_activation of the hidden layers                       */
+    float activation_param;
+    int grid_channels;       /* total latent channels (0 = none)                            */
+    int grid_encoding;
+    int grid_res[3];         /* X,Y,Z of the first grid                                     */
+    int time_num, ensemble_num;
+    int num_parameters;      /* SceneNetwork::numParameters()  :1043-1055                   */
+    int max_warps_shared, max_warps_mixed; /* computeMaxWarps(true/false,false) :987-1041   */
+    double flops_per_sample; /* algorithmic FLOPs, SURVEY.md 8(d)                           */
+    double mfma_flops_per_sample; /* padded FLOPs actually issued to the matrix cores       */
+    float box_min[3], box_size[3];
+} fvsrn_network_info;
+int fvsrn_network_get_info(const fvsrn_network* net, fvsrn_network_info* info);
+/* Layer i as stored after addLayer (weights half bits, rows=out, cols=in): for round-trip tests
+ * (unittests/testSRN.cpp:413-430). Pass NULL buffers to query sizes. */
+int fvsrn_network_get_layer(const fvsrn_network* net, int index, int* channels_out, int* channels_in,
+                            int* activation, float* act_param, uint16_t* weights, uint16_t* bias);
+/* Fourier matrix as stored (half bits, feature-fastest [cin*F + f]); returns F*cols entries */
+int fvsrn_network_get_fourier(const fvsrn_network* net, uint16_t* matrix, int cap, int* count);
+
+/* ----------------------------------------------------------------------------------------
+ * IVolumeInterpolation::evaluate   (renderer/volume_interpolation.cpp:26-127, kernel
+ * EvaluateNoBatches renderer/renderer_volume_kernels1.cuh:15).
+ * d_positions (n,3) fp32 in WORLD space of the network's box, d_directions (n,3) or NULL,
+ * d_out (n, output_channels) fp32.
+ * -------------------------------------------------------------------------------------- */
+int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const float* d_directions,
+                          size_t n, float* d_out, void* stream);
+
+/* ----------------------------------------------------------------------------------------
+ * scene = ImageEvaluatorSimple + CameraOnASphere(->reference frame) + RayEvaluationSteppingDvr
+ *         + TF + BRDFLambert(pass-through) + Blending, as ONE POD
+ *   renderer/image_evaluator_simple.cpp:198-361, renderer/camera.cpp:458-551,
+ *   renderer/ray_evaluation_stepping.cpp:535-623, renderer/transfer_function*.cpp, blending.cpp
+ * -------------------------------------------------------------------------------------- */
+typedef struct {
+    /* kernel::CameraReferenceFrameParameters (renderer/renderer_camera.cuh:12-24):
+     * matrix rows = eye, right, up */
+    float cam_eye[3], cam_right[3], cam_up[3];
+    float fov_y_radians;
+    /* kernel::RayEvaluationSteppingDvrParameters (renderer_ray_evaluation_stepping_dvr.cuh:22-30) */
+    float stepsize;       /* world units */
+    float density_min, density_max;
+    int early_out;        /* RAY_EVALUATION_STEPPING__ENABLE_EARLY_OUT, alphaEarlyOut = 1-1e-5 */
+    int blend_mode;       /* fvsrn_blend_mode */
+    /* transfer function */
+    int tf_kind;          /* fvsrn_tf_kind */
+    float tf_scale_absorption, tf_scale_emission; /* Identity */
+    const float* tf_table; /* host pointer, (tf_rows, cols(kind)) row-major; copied */
+    int tf_rows;
+} fvsrn_scene_desc;
+
+int fvsrn_scene_create(const fvsrn_scene_desc* desc, fvsrn_scene** out);
+int fvsrn_scene_update(fvsrn_scene* scene, const fvsrn_scene_desc* desc);
+void fvsrn_scene_destroy(fvsrn_scene* scene);
+
+/* CameraOnASphere -> reference frame (renderer/camera.cpp:458-490,553-581); orientation 0..5 =
+ * Xp,Xm,Yp,Ym,Zp,Zm. Pure host math in fp64 like the reference, results cast to fp32. */
+int fvsrn_camera_on_a_sphere(int orientation, const double center[3], double pitch, double yaw,
+                             double distance, float eye[3], float right[3], float up[3]);
+
+/* ImageEvaluatorSimple::render  (renderer/image_evaluator_simple.cpp:198-361, kernel
+ * ImageEvaluatorSimpleKernel renderer/renderer_image_evaluator_simple.cuh:36-127).
+ * Renders image rows [y0,y1) of a width x height frame (aspect = width/height) into d_out8,
+ * a planar fp32 image [8][height][width] (rgb, alpha, normal xyz, depth); rows outside
+ * [y0,y1) are not touched (multi-GPU row stripes).
+ * d_stats (optional, may be NULL): 2 x uint64 on the device, ATOMICALLY incremented by
+ *   [0] lane-exact evaluated samples, [1] wave-granular executed samples (64 per wave step). */
+int fvsrn_render(fvsrn_scene* scene, fvsrn_network* net, int width, int height, int y0, int y1,
+                 float* d_out8, unsigned long long* d_stats, void* stream);
+
+/* Kernel name + resources of the variant fvsrn_render / fvsrn_evaluate_points would launch for
+ * this network (for profiles and bench): writes a 0-terminated string. */
+int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FVSRN_H_ */

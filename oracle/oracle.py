@@ -1,0 +1,253 @@
+"""
+ctypes front end of the CPU oracle (oracle/srn_oracle.c).        *** TEST INFRASTRUCTURE ONLY ***
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+``OracleNetwork`` assembles, from the layers of a .volnet (``fv-srn_amd/volnet_io.VolnetData``), the
+arrays of the reference's constant block exactly the way ``SceneNetwork::fillConstantMemory`` does
+(renderer/volume_interpolation_network.cpp:1236-1417), and hands them to the C restatement.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrn_oracle.so")
+
+ACC_HALF, ACC_FLOAT = 0, 1
+ACTIVATIONS = {"ReLU": 0, "Sine": 1, "Snake": 2, "SnakeAlt": 3}
+OUTPUT_MODES = {"density": 0, "density:direct": 1, "rgbo": 2, "rgbo:direct": 3, "densitygrad": 4,
+                "densitygrad:direct": 5, "densitygrad:cubic": 6}
+TF_NONE, TF_IDENTITY, TF_GAUSSIAN, TF_PIECEWISE, TF_TEXTURE = range(5)
+BLEND_ALPHA, BLEND_BEER_LAMBERT = 0, 1
+
+_U16P = C.POINTER(C.c_uint16)
+_FP = C.POINTER(C.c_float)
+
+
+class _OracleNet(C.Structure):
+    _fields_ = [("C", C.c_int), ("F", C.c_int), ("G", C.c_int), ("NH", C.c_int), ("Cout", C.c_int),
+                ("outputMode", C.c_int), ("activation", C.c_int), ("gridEncoding", C.c_int), ("passTime", C.c_int),
+                ("accMode", C.c_int), ("actParam", C.c_float), ("boxMin", C.c_float * 3), ("boxSize", C.c_float * 3),
+                ("fourier", _U16P), ("wFirst", _U16P), ("bFirst", _U16P), ("wHidden", _U16P), ("bHidden", _U16P),
+                ("wLast", _U16P), ("bLast", _U16P), ("gridX", C.c_int), ("gridY", C.c_int), ("gridZ", C.c_int),
+                ("gridTexA", C.POINTER(C.c_void_p)), ("gridTexB", C.POINTER(C.c_void_p)),
+                ("gridOffsetA", _FP), ("gridScaleA", _FP), ("gridInterpolation", _FP)]
+
+
+class _OracleScene(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("right", C.c_float * 3), ("up", C.c_float * 3), ("fovY", C.c_float),
+                ("stepsize", C.c_float), ("densityMin", C.c_float), ("densityMax", C.c_float),
+                ("earlyOut", C.c_int), ("blendMode", C.c_int), ("tfKind", C.c_int), ("tfRows", C.c_int),
+                ("tfScaleAbsorption", C.c_float), ("tfScaleEmission", C.c_float), ("tfTable", _FP)]
+
+
+_lib = None
+
+
+def build() -> None:
+    """Compiles the C restatement with gcc (test infrastructure; `make -C oracle`)."""
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        l = C.CDLL(LIB_PATH)
+        l.oracle_eval_points.restype = C.c_int
+        l.oracle_eval_points.argtypes = [C.POINTER(_OracleNet), _FP, C.c_size_t, _FP]
+        l.oracle_render.restype = C.c_int
+        l.oracle_render.argtypes = [C.POINTER(_OracleNet), C.POINTER(_OracleScene), C.c_int, C.c_int, C.c_int, C.c_int,
+                                    _FP, C.POINTER(C.c_ulonglong)]
+        l.oracle_count_samples.restype = C.c_ulonglong
+        l.oracle_count_samples.argtypes = [C.POINTER(_OracleNet), C.POINTER(_OracleScene), C.c_int, C.c_int, C.c_int, C.c_int]
+        l.oracle_float_to_half.restype = C.c_uint16
+        l.oracle_float_to_half.argtypes = [C.c_float]
+        l.oracle_half_to_float.restype = C.c_float
+        l.oracle_half_to_float.argtypes = [C.c_uint16]
+        _lib = l
+    return _lib
+
+
+def _u16(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint16)
+
+
+class OracleNetwork:
+    """The reference constant block of one SceneNetwork (a volnet_io.VolnetData) at (time, ensemble)."""
+
+    def __init__(self, vn, acc_mode: int = ACC_HALF, time: float = 0.0, ensemble: int = 0):
+        n = _OracleNet()
+        keep = []
+        F = vn.num_fourier
+        if F <= 0:
+            raise ValueError("the oracle restates the Fourier-feature path only")
+        if vn.has_direction:
+            raise ValueError("direction inputs are not restated")
+        has_grid = vn.has_grid()
+        L = vn.layers
+        G = 0
+        if has_grid:
+            tg, eg = vn.time_grids or [], vn.ensemble_grids or []
+            G = (tg[0].channels if tg else 0) + (eg[0].channels if eg else 0)
+        # getDefines (:1139-1219)
+        Cc = L[0].channels_in - G
+        assert Cc == 4 + 2 * F, "2*num_fourier+4 == hidden[0].channelsIn must hold"
+        start_hidden = 1 if has_grid else 0
+        NH = len(L) - start_hidden - 1
+        n.C, n.F, n.G, n.NH = Cc, F, G, NH
+        n.Cout = L[-1].channels_out
+        n.outputMode = OUTPUT_MODES[vn.output_mode]
+        n.activation = ACTIVATIONS[L[0].activation]
+        n.actParam = L[0].activation_param
+        n.passTime = int(vn.has_time)
+        n.accMode = acc_mode
+        n.boxMin[:] = list(vn.box_min)
+        n.boxSize[:] = list(vn.box_size)
+
+        def ptr16(a):
+            a = _u16(a)
+            keep.append(a)
+            return a.ctypes.data_as(_U16P)
+
+        n.fourier = ptr16(vn.fourier)
+        if has_grid:
+            n.wFirst = ptr16(L[0].weights)
+            n.bFirst = ptr16(L[0].bias)
+        hidden = L[start_hidden:len(L) - 1]
+        n.wHidden = ptr16(np.concatenate([_u16(l.weights) for l in hidden]) if hidden else np.zeros(1, np.uint16))
+        n.bHidden = ptr16(np.concatenate([_u16(l.bias) for l in hidden]) if hidden else np.zeros(1, np.uint16))
+        n.wLast = ptr16(L[-1].weights)  # stored [cin][cout] (addLayer transposes small layers)
+        n.bLast = ptr16(L[-1].bias)
+
+        if has_grid:  # :1289-1362
+            tg, eg = vn.time_grids or [], vn.ensemble_grids or []
+            first = (tg or eg)[0]
+            n.gridEncoding = first.encoding
+            n.gridX, n.gridY, n.gridZ = first.size_x, first.size_y, first.size_z
+            texA, texB, off, sc, interp = [], [], [], [], []
+
+            def tex_ptr(g, i):
+                a = np.ascontiguousarray(g.data[i])
+                keep.append(a)
+                return a.ctypes.data
+
+            if tg:
+                tnum = len(tg)
+                # setTimeAndEnsemble clamps to the key-frame range (:923-938), interpolateTime (.h:353-357)
+                tmax_incl = vn.time_min + (tnum - 1) * vn.time_step
+                t = min(max(float(time), float(vn.time_min)), float(tmax_incl))
+                tt = np.float32((np.float32(t) - np.float32(vn.time_min)) / np.float32(vn.time_step))
+                tt = float(min(max(tt, np.float32(0)), np.float32(tnum - 1)))
+                lo = min(int(tt), tnum - 1)
+                hi = min(lo + 1, tnum - 1)
+                for i in range(tg[0].channels // 4):
+                    texA.append(tex_ptr(tg[lo], i))
+                    texB.append(tex_ptr(tg[hi], i))
+                    interp.append(tt)
+                if first.encoding != 0:
+                    off += list(tg[lo].offset)
+                    sc += list(tg[lo].scale)
+                else:
+                    off += [0.0] * tg[0].channels
+                    sc += [1.0] * tg[0].channels
+            if eg:
+                idx = min(max(int(ensemble) - vn.ensemble_min, 0), len(eg) - 1)
+                for i in range(eg[0].channels // 4):
+                    texA.append(tex_ptr(eg[idx], i))
+                    texB.append(tex_ptr(eg[idx], i))
+                    interp.append(0.0)
+                if first.encoding != 0:
+                    off += list(eg[idx].offset)
+                    sc += list(eg[idx].scale)
+                else:
+                    off += [0.0] * eg[0].channels
+                    sc += [1.0] * eg[0].channels
+            ta = (C.c_void_p * len(texA))(*texA)
+            tb = (C.c_void_p * len(texB))(*texB)
+            oa = np.asarray(off, np.float32)
+            sa = np.asarray(sc, np.float32)
+            ia = np.asarray(interp, np.float32)
+            keep += [ta, tb, oa, sa, ia]
+            n.gridTexA = C.cast(ta, C.POINTER(C.c_void_p))
+            n.gridTexB = C.cast(tb, C.POINTER(C.c_void_p))
+            n.gridOffsetA = oa.ctypes.data_as(_FP)
+            n.gridScaleA = sa.ctypes.data_as(_FP)
+            n.gridInterpolation = ia.ctypes.data_as(_FP)
+        self._n = n
+        self._keep = keep
+        self.output_channels = 4 if vn.output_mode in ("rgbo", "rgbo:direct") else 1
+
+    def evaluate(self, world_positions: np.ndarray) -> np.ndarray:
+        p = np.ascontiguousarray(world_positions, dtype=np.float32)
+        out = np.zeros((p.shape[0], self.output_channels), np.float32)
+        r = lib().oracle_eval_points(C.byref(self._n), p.ctypes.data_as(_FP), p.shape[0], out.ctypes.data_as(_FP))
+        if r != 0:
+            raise RuntimeError("oracle_eval_points failed")
+        return out
+
+
+class OracleScene:
+    def __init__(self, *, eye, right, up, fov_y_radians, stepsize, density_min=0.0, density_max=1.0, early_out=True,
+                 blend_mode=BLEND_BEER_LAMBERT, tf_kind=TF_IDENTITY, tf_scale_absorption=1.0, tf_scale_emission=1.0,
+                 tf_table=None):
+        s = _OracleScene()
+        s.eye[:] = [float(v) for v in eye]
+        s.right[:] = [float(v) for v in right]
+        s.up[:] = [float(v) for v in up]
+        s.fovY = fov_y_radians
+        s.stepsize = stepsize
+        s.densityMin, s.densityMax = density_min, density_max
+        s.earlyOut, s.blendMode, s.tfKind = int(early_out), blend_mode, tf_kind
+        s.tfScaleAbsorption, s.tfScaleEmission = tf_scale_absorption, tf_scale_emission
+        self._t = None
+        if tf_table is not None:
+            self._t = np.ascontiguousarray(tf_table, dtype=np.float32)
+            s.tfTable = self._t.ctypes.data_as(_FP)
+            s.tfRows = self._t.shape[0]
+        self._s = s
+
+    def render(self, net: OracleNetwork, width: int, height: int, y0: int = 0, y1: Optional[int] = None):
+        """-> ((8,H,W) fp32 image, evaluated sample count)"""
+        if y1 is None:
+            y1 = height
+        out = np.zeros((8, height, width), np.float32)
+        cnt = C.c_ulonglong(0)
+        r = lib().oracle_render(C.byref(net._n), C.byref(self._s), width, height, y0, y1, out.ctypes.data_as(_FP), C.byref(cnt))
+        if r != 0:
+            raise RuntimeError("oracle_render failed")
+        return out, cnt.value
+
+    def count_samples(self, net: OracleNetwork, width: int, height: int, y0: int = 0, y1: Optional[int] = None) -> int:
+        if y1 is None:
+            y1 = height
+        return int(lib().oracle_count_samples(C.byref(net._n), C.byref(self._s), width, height, y0, y1))
+
+
+def camera_on_a_sphere(orientation: str, center, pitch: float, yaw: float, distance: float):
+    """numpy float64 restatement of CameraOnASphere (renderer/camera.cpp:17-35,458-490,553-581)."""
+    names = ["Xp", "Xm", "Yp", "Ym", "Zp", "Zm"]
+    ups = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    perms = [(2, -1, -3), (-2, 1, 3), (1, 2, 3), (-1, -2, -3), (-3, -1, 2), (3, 1, -2)]
+    inv_yaw = [False, True, True, False, True, False]
+    o = names.index(orientation)
+    yaw = -yaw if not inv_yaw[o] else yaw
+    pitch = -pitch
+    pos = np.array([np.cos(pitch) * np.cos(yaw) * distance, np.sin(pitch) * distance, np.cos(pitch) * np.sin(yaw) * distance])
+    pos2 = np.array([pos[abs(p) - 1] * (1 if p > 0 else -1) for p in perms[o]])
+    look_at = np.asarray(center, np.float64)
+    origin = pos2 + look_at
+    front = look_at - origin
+    front /= np.linalg.norm(front)
+    right = np.cross(front, np.asarray(ups[o], np.float64))
+    right /= np.linalg.norm(right)
+    up = np.cross(right, front)
+    up /= np.linalg.norm(up)
+    return origin.astype(np.float32), right.astype(np.float32), up.astype(np.float32)

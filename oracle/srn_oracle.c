@@ -1,0 +1,469 @@
+/*
+ * srn_oracle.c -- CPU restatement of the fV-SRN hot path.   *** TEST INFRASTRUCTURE ONLY ***
+ *
+ * Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py may load this file's
+ * library.  Nothing in the product path (fv-srn_amd/) links, imports or calls it.
+ *
+ * It restates, in scalar C, the algorithm of the reference CUDA path (paths relative to the
+ * reference checkout, shamanDevel/fV-SRN):
+ *   network     renderer/renderer_volume_tensorcores.cuh:735-1164   (eval)
+ *   activations renderer/renderer_activations.cuh
+ *   latent grid renderer/renderer_volume_tensorcores.cuh:572-605 + tex3D semantics set up in
+ *               renderer/volume_interpolation_network.cpp:470-504 (normalized, clamp, linear)
+ *   camera      renderer/renderer_camera.cuh:33-52
+ *   box test    renderer/renderer_utils.cuh:91-105
+ *   DVR loop    renderer/renderer_ray_evaluation_stepping_dvr.cuh:48-157
+ *   TFs         renderer/renderer_tf_{identity,gaussian,piecewise,texture}.cuh
+ *   blending    renderer/renderer_blending.cuh:35-51
+ *   image       renderer/renderer_image_evaluator_simple.cuh:53-125
+ *
+ * Inputs are the arrays of the reference's __constant__ block
+ * (kernel::VolumeInterpolationTensorcoresParameters, renderer_volume_tensorcores.cuh:195-249),
+ * i.e. the half matrices exactly as SceneNetwork::fillConstantMemory lays them out.
+ *
+ * Two arithmetic models (ORACLE_ACC_*):
+ *   HALF  : the reference's: half storage AND half accumulation (WMMA accumulator fragments of
+ *           type half, bias pre-loaded, :849-858/:965-972), half activations, half Fourier chain,
+ *           sequential hfma last layer.  A WMMA k=16 step is modelled as one exact dot product
+ *           added to the accumulator and rounded to half once.
+ *   FLOAT : what the MI355X kernels compute: same half-quantised inputs/weights/activations,
+ *           but fp32 accumulation over the whole K, fp32 activations, exact Fourier phases.
+ * The pinning of this file against the reference's own Python implementation lives in
+ * tests/test_oracle_golden.py (golden vectors made by tests/golden/make_golden.py).
+ */
+#include "srn_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ half */
+static uint16_t f2h(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+    if (x < 0x38800000u) {
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int e = (int)(x >> 23);
+        const uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - e;
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (r & 1u))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = (x - 0x38000000u) >> 13;
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;
+    return (uint16_t)(sign | r);
+}
+
+static float h2f(uint16_t h) {
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 0x1fu;
+    uint32_t m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else {
+            int k = 0;
+            while (!(m & 0x400u)) { m <<= 1; ++k; }
+            m &= 0x3ffu;
+            x = sign | ((uint32_t)(113 - k) << 23) | (m << 13);
+        }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+/* round a double to the nearest half (ties to even) in ONE rounding, result as float */
+static float rh_d(double v) {
+    if (v != v || v == 0.0) return (float)v;
+    const double a = fabs(v);
+    if (a >= 65520.0) return v < 0 ? -INFINITY : INFINITY;
+    int e;
+    (void)frexp(a, &e); /* a = m * 2^e, m in [0.5,1) */
+    const int ulp_exp = (e - 1 < -14) ? -24 : (e - 1 - 10);
+    const double r = nearbyint(ldexp(a, -ulp_exp)); /* default rounding mode: nearest even */
+    const double q = ldexp(r, ulp_exp);
+    return (float)(v < 0 ? -q : q);
+}
+static float rh(float v) { return h2f(f2h(v)); }
+/* half intrinsics of the reference (cuda_fp16): one rounding per operation */
+static float hmul(float a, float b) { return rh(a * b); /* product of two halves is exact in fp32 */ }
+static float hadd(float a, float b) { return rh_d((double)a + (double)b); }
+static float hsub(float a, float b) { return rh_d((double)a - (double)b); }
+static float hfma(float a, float b, float c) { return rh_d((double)a * (double)b + (double)c); }
+static float hdivf(float a, float b) { return rh_d((double)a / (double)b); }
+static float hcosf(float a) { return rh_d(cos((double)a)); }
+static float hsinf(float a) { return rh_d(sin((double)a)); }
+
+/* ------------------------------------------------------------------------------------ activations */
+/* half versions: renderer_activations.cuh (ReLU :40-60, Sine :97-120, Snake :263-285, SnakeAlt :329-358) */
+static float act_half(int act, float v, float param) {
+    switch (act) {
+        case ORACLE_ACT_RELU: return v > 0.f ? v : 0.f;
+        case ORACLE_ACT_SINE: return hsinf(hmul(v, rh(param)));
+        case ORACLE_ACT_SNAKE: {
+            const float f = rh(param), divf = rh(1.0f / param);
+            const float v2 = hsinf(hmul(f, v));
+            return hadd(v, hmul(divf, hmul(v2, v2)));
+        }
+        case ORACLE_ACT_SNAKEALT: {
+            const float f2 = rh(2 * param);
+            const float x0 = hcosf(hmul(f2, v));
+            const float x1 = hsub(hadd(v, 1.0f), x0);
+            return hdivf(x1, f2);
+        }
+        default: return v;
+    }
+}
+/* fp32 versions: the double-precision overloads of the same file evaluated in fp32 */
+static float act_float(int act, float v, float param) {
+    switch (act) {
+        case ORACLE_ACT_RELU: return v > 0.f ? v : 0.f;
+        case ORACLE_ACT_SINE: return (float)sin((double)v * param);
+        case ORACLE_ACT_SNAKE: { const double s = sin((double)param * v); return (float)(v + s * s / param); }
+        case ORACLE_ACT_SNAKEALT: return (float)(((double)v + 1.0 - cos(2.0 * param * v)) / (2.0 * param));
+        default: return v;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ latent grid */
+/* Accurate single-precision erfinv (Giles 2010); the reference calls CUDA's erfinvf (:374). */
+static float erfinv_f(float x) {
+    float w = -logf((1.0f - x) * (1.0f + x)), p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f; p = 3.43273939e-07f + p * w; p = -3.5233877e-06f + p * w;
+        p = -4.39150654e-06f + p * w; p = 0.00021858087f + p * w; p = -0.00125372503f + p * w;
+        p = -0.00417768164f + p * w; p = 0.246640727f + p * w; p = 1.50140941f + p * w;
+    } else {
+        w = sqrtf(w) - 3.0f;
+        p = -0.000200214257f; p = 0.000100950558f + p * w; p = 0.00134934322f + p * w;
+        p = -0.00367342844f + p * w; p = 0.00573950773f + p * w; p = -0.0076224613f + p * w;
+        p = 0.00943887047f + p * w; p = 1.00167406f + p * w; p = 2.83297682f + p * w;
+    }
+    return p * x;
+}
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* tex3D<float4> with normalized coordinates, clamp addressing, linear filtering; byte textures are
+ * read as normalized floats.  One texture = 4 channels, layout [Z][Y][X][4]. */
+static void tex3d(const OracleNet* n, const void* tex, float px, float py, float pz, float out[4]) {
+    const int X = n->gridX, Y = n->gridY, Z = n->gridZ;
+    const float fx = px * (float)X - 0.5f, fy = py * (float)Y - 0.5f, fz = pz * (float)Z - 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy), z0f = floorf(fz);
+    const float wx = fx - x0f, wy = fy - y0f, wz = fz - z0f;
+    const int xs[2] = {clampi((int)x0f, 0, X - 1), clampi((int)x0f + 1, 0, X - 1)};
+    const int ys[2] = {clampi((int)y0f, 0, Y - 1), clampi((int)y0f + 1, 0, Y - 1)};
+    const int zs[2] = {clampi((int)z0f, 0, Z - 1), clampi((int)z0f + 1, 0, Z - 1)};
+    for (int c = 0; c < 4; ++c) out[c] = 0.f;
+    for (int dz = 0; dz < 2; ++dz)
+        for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx) {
+                const float w = (dz ? wz : 1.f - wz) * (dy ? wy : 1.f - wy) * (dx ? wx : 1.f - wx);
+                const size_t o = (((size_t)zs[dz] * Y + ys[dy]) * X + xs[dx]) * 4;
+                for (int c = 0; c < 4; ++c) {
+                    const float v = n->gridEncoding == ORACLE_GRID_FLOAT ? ((const float*)tex)[o + c]
+                                                                       : ((const uint8_t*)tex)[o + c] / 255.0f;
+                    out[c] += w * v;
+                }
+            }
+}
+
+/* EncodeGridValue<enc, false> -- note the reference decodes grid B with A's coefficients (:586-587) */
+static float decode_grid(const OracleNet* n, float v, int channel) {
+    if (n->gridEncoding == ORACLE_GRID_FLOAT) return v;
+    if (n->gridEncoding == ORACLE_GRID_BYTE_GAUSSIAN)
+        v = 1.4142135623730950488f * erfinv_f((2.0f - 1e-4f) * (v - 0.5f));
+    return n->gridOffsetA[channel] + v * n->gridScaleA[channel];
+}
+
+/* LoadVolumetricFeatures :572-605: 16 channels starting at 16*chunk, as half values */
+static void grid_features(const OracleNet* n, const float p[3], int chunk, float out16[16]) {
+    for (int i = 0; i < 4; ++i) {
+        const int t = 4 * chunk + i;
+        float a[4], b[4];
+        tex3d(n, n->gridTexA[t], p[0], p[1], p[2], a);
+        tex3d(n, n->gridTexB[t], p[0], p[1], p[2], b);
+        const float time = n->gridInterpolation[t];
+        const float f = time - floorf(time);
+        for (int c = 0; c < 4; ++c) {
+            const float va = decode_grid(n, a[c], 4 * t + c), vb = decode_grid(n, b[c], 4 * t + c);
+            out16[4 * i + c] = rh(va + f * (vb - va));
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------- network */
+#define ORACLE_MAX_C 256
+
+/* one WMMA-style layer: y = act(W x + b), W row-major [cout][cin] */
+static void dense_layer(const OracleNet* n, const uint16_t* W, const uint16_t* b, int cin, int cout, const float* x,
+                        float* y) {
+    for (int o = 0; o < cout; ++o) {
+        const uint16_t* w = W + (size_t)o * cin;
+        float r;
+        if (n->accMode == ORACLE_ACC_HALF) {
+            float acc = h2f(b[o]);
+            for (int k0 = 0; k0 < cin; k0 += 16) {
+                double s = 0;
+                for (int k = k0; k < k0 + 16 && k < cin; ++k) s += (double)h2f(w[k]) * (double)x[k];
+                acc = rh_d((double)acc + s);
+            }
+            r = act_half(n->activation, acc, n->actParam);
+        } else {
+            double s = h2f(b[o]);
+            for (int k = 0; k < cin; ++k) s += (double)h2f(w[k]) * (double)x[k];
+            r = rh(act_float(n->activation, (float)s, n->actParam));
+        }
+        y[o] = r;
+    }
+}
+
+static float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+static float softplusf_(float x) { return x > 20.f ? x : logf(1.f + expf(x)); }
+
+/* eval<>: world position -> out[0..3] = value (1 or 4 channels used), nrm[3] = predicted normal */
+static void srn_eval(const OracleNet* n, const float wpos[3], float out[4], float nrm[3]) {
+    const int C = n->C, F = n->F, G = n->G;
+    float p[3];
+    for (int i = 0; i < 3; ++i) p[i] = (wpos[i] - n->boxMin[i]) / n->boxSize[i]; /* :746 */
+    float x[ORACLE_MAX_C + 64], y[ORACLE_MAX_C];
+    /* Fourier layer :768-808 */
+    const float vx = rh(p[0]), vy = rh(p[1]), vz = rh(p[2]);
+    x[0] = vx; x[1] = vy; x[2] = vz;
+    x[3] = n->passTime ? rh(n->gridInterpolation[0]) : 0.f;
+    for (int i = 0; i < F; ++i) {
+        const float f0 = h2f(n->fourier[i]), f1 = h2f(n->fourier[i + F]), f2 = h2f(n->fourier[i + 2 * F]);
+        if (n->accMode == ORACLE_ACC_HALF) {
+            float c = hmul(vx, f0);
+            c = hfma(vy, f1, c);
+            c = hfma(vz, f2, c);
+            x[4 + i] = hcosf(c);
+            x[4 + F + i] = hsinf(c);
+        } else {
+            const double c = (double)vx * f0 + (double)vy * f1 + (double)vz * f2;
+            x[4 + i] = rh_d(cos(c));
+            x[4 + F + i] = rh_d(sin(c));
+        }
+    }
+    /* latent grid layer :839-948 */
+    if (G > 0) {
+        for (int g = 0; g < G / 16; ++g) grid_features(n, p, g, x + C + 16 * g);
+        dense_layer(n, n->wFirst, n->bFirst, C + G, C, x, y);
+        memcpy(x, y, sizeof(float) * (size_t)C);
+    }
+    /* hidden layers :956-1033 */
+    for (int l = 0; l < n->NH; ++l) {
+        dense_layer(n, n->wHidden + (size_t)l * C * C, n->bHidden + (size_t)l * C, C, C, x, y);
+        memcpy(x, y, sizeof(float) * (size_t)C);
+    }
+    /* last layer :1045-1053, :1138-1143; weights stored [cin][cout] */
+    const int Co = n->Cout;
+    float o[4] = {0, 0, 0, 0};
+    for (int c = 0; c < Co; ++c) {
+        if (n->accMode == ORACLE_ACC_HALF) {
+            float acc = h2f(n->bLast[c]);
+            for (int k = 0; k < C; ++k) acc = hfma(x[k], h2f(n->wLast[(size_t)k * Co + c]), acc);
+            o[c] = acc;
+        } else {
+            double s = h2f(n->bLast[c]);
+            for (int k = 0; k < C; ++k) s += (double)x[k] * (double)h2f(n->wLast[(size_t)k * Co + c]);
+            o[c] = (float)s;
+        }
+    }
+    nrm[0] = nrm[1] = nrm[2] = 0.f;
+    out[0] = out[1] = out[2] = out[3] = 0.f;
+    switch (n->outputMode) { /* :1054-1158 */
+        case ORACLE_OUT_DENSITY: out[0] = sigmoidf_(o[0]); break;
+        case ORACLE_OUT_DENSITY_DIRECT: out[0] = o[0]; break;
+        case ORACLE_OUT_RGBO:
+            out[0] = sigmoidf_(o[0]); out[1] = sigmoidf_(o[1]); out[2] = sigmoidf_(o[2]); out[3] = softplusf_(o[3]);
+            break;
+        case ORACLE_OUT_RGBO_DIRECT:
+            for (int c = 0; c < 3; ++c) out[c] = fminf(fmaxf(o[c], 0.f), 1.f);
+            out[3] = fmaxf(o[3], 0.f);
+            break;
+        case ORACLE_OUT_DENSITY_GRADIENT: out[0] = sigmoidf_(o[0]); nrm[0] = o[1]; nrm[1] = o[2]; nrm[2] = o[3]; break;
+        case ORACLE_OUT_DENSITY_GRADIENT_DIRECT: out[0] = o[0]; nrm[0] = o[1]; nrm[1] = o[2]; nrm[2] = o[3]; break;
+        case ORACLE_OUT_DENSITY_GRADIENT_CUBIC:
+            out[0] = o[0]; nrm[0] = o[1] * o[1] * o[1]; nrm[1] = o[2] * o[2] * o[2]; nrm[2] = o[3] * o[3] * o[3];
+            break;
+        default: break;
+    }
+}
+
+int oracle_eval_points(const OracleNet* n, const float* pos, size_t count, float* out) {
+    if (!n || n->C > ORACLE_MAX_C || n->G > 64) return -1;
+    const int oc = (n->outputMode == ORACLE_OUT_RGBO || n->outputMode == ORACLE_OUT_RGBO_DIRECT) ? 4 : 1;
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)count; ++i) {
+        float o[4], nr[3];
+        srn_eval(n, pos + 3 * i, o, nr);
+        for (int c = 0; c < oc; ++c) out[(size_t)i * oc + c] = o[c];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- TFs */
+static float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+
+static void tf_eval(const OracleScene* s, float density, float c[4]) {
+    density = clamp01(density);
+    c[0] = c[1] = c[2] = c[3] = 0.f;
+    const float* T = s->tfTable;
+    switch (s->tfKind) {
+        case ORACLE_TF_IDENTITY: /* renderer_tf_identity.cuh:36-54 */
+            c[0] = c[1] = c[2] = density * s->tfScaleEmission;
+            c[3] = density * s->tfScaleAbsorption * s->stepsize;
+            break;
+        case ORACLE_TF_GAUSSIAN: /* renderer_tf_gaussian.cuh:43-86 */
+            for (int i = 0; i < s->tfRows; ++i) {
+                const float* r = T + 6 * i;
+                const float ni = expf(-(density - r[4]) * (density - r[4]) / (r[5] * r[5]));
+                for (int k = 0; k < 4; ++k) c[k] += r[k] * ni;
+            }
+            c[3] *= s->stepsize;
+            break;
+        case ORACLE_TF_PIECEWISE: { /* renderer_tf_piecewise.cuh:29-62 */
+            int i;
+            for (i = 0; i < s->tfRows - 2; ++i)
+                if (T[5 * (i + 1) + 4] > density) break;
+            const float* a = T + 5 * i;
+            const float* b = T + 5 * (i + 1);
+            const float d = fminf(fmaxf(density, a[4]), b[4]);
+            const float f = (d - a[4]) / (b[4] - a[4]);
+            for (int k = 0; k < 4; ++k) c[k] = a[k] + f * (b[k] - a[k]);
+            c[3] *= s->stepsize;
+        } break;
+        case ORACLE_TF_TEXTURE: { /* renderer_tf_texture.cuh:46-55 (tensor mode) */
+            const int R = s->tfRows;
+            const float d = density * R - 0.5f;
+            const int di = (int)floorf(d);
+            const float df = d - di;
+            const float* a = T + 4 * clampi(di, 0, R - 1);
+            const float* b = T + 4 * clampi(di + 1, 0, R - 1);
+            for (int k = 0; k < 4; ++k) c[k] = a[k] + df * (b[k] - a[k]);
+            c[3] *= s->stepsize;
+        } break;
+        default: break;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- DVR */
+static void render_pixel(const OracleNet* n, const OracleScene* s, int W, int H, int x, int y, float px8[8],
+                         unsigned long long* samples) {
+    /* renderer_image_evaluator_simple.cuh:84-88 */
+    const float ndcx = 2 * ((float)x + 0.5f) / (float)W - 1, ndcy = 2 * ((float)y + 0.5f) / (float)H - 1;
+    /* renderer_camera.cuh:41-52 */
+    const float tanFovY = tanf(s->fovY / 2), tanFovX = tanFovY * ((float)W / (float)H);
+    const float* eye = s->eye; const float* right = s->right; const float* up = s->up;
+    const float front[3] = {up[1] * right[2] - up[2] * right[1], up[2] * right[0] - up[0] * right[2],
+                            up[0] * right[1] - up[1] * right[0]};
+    float dir[3];
+    for (int i = 0; i < 3; ++i) dir[i] = front[i] + ndcx * tanFovX * right[i] + ndcy * tanFovY * up[i];
+    const float il = 1.0f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    for (int i = 0; i < 3; ++i) dir[i] *= il;
+    /* renderer_utils.cuh:91-105 */
+    float tlo[3], thi[3];
+    for (int i = 0; i < 3; ++i) {
+        const float inv = 1.0f / dir[i];
+        const float ta = (n->boxMin[i] - eye[i]) * inv, tb = (n->boxMin[i] + n->boxSize[i] - eye[i]) * inv;
+        tlo[i] = fminf(ta, tb);
+        thi[i] = fmaxf(ta, tb);
+    }
+    float tmin = fmaxf(fmaxf(tlo[0], tlo[1]), tlo[2]);
+    const float tmax = fminf(fminf(thi[0], thi[1]), thi[2]);
+    tmin = fmaxf(tmin, 0.f); /* stepping_dvr.cuh:66 */
+    const float alphaEarlyOut = 1.0f - 1e-5f;
+    const float divRange = 1.0f / (s->densityMax - s->densityMin);
+    const int rgbo = n->outputMode == ORACLE_OUT_RGBO || n->outputMode == ORACLE_OUT_RGBO_DIRECT;
+    float col[4] = {0, 0, 0, 0}, nacc[3] = {0, 0, 0}, depth = 0;
+    unsigned long long cnt = 0;
+    for (int i = 0;; ++i) { /* :84-154, per-lane view of the warp-synchronous loop */
+        const float t = tmin + (float)i * s->stepsize;
+        const int valid = (t <= tmax) && (!s->earlyOut || col[3] < alphaEarlyOut);
+        if (!valid) break; /* later iterations of an invalid lane never blend (:151) and never turn valid again */
+        ++cnt;
+        const float pos[3] = {eye[0] + dir[0] * t, eye[1] + dir[1] * t, eye[2] + dir[2] * t};
+        float v[4], g[3], c[4] = {0, 0, 0, 0};
+        srn_eval(n, pos, v, g);
+        if (rgbo) {
+            c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3] * s->stepsize; /* :104-108 */
+        } else {
+            const float density2 = (v[0] - s->densityMin) * divRange;
+            if (v[0] >= s->densityMin) tf_eval(s, density2, c); /* :113-133 */
+        }
+        if (c[3] > 0) { /* :138-153, BRDFLambert::eval without its optional defines is the identity */
+            const float l2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+            if (l2 >= 1e-8f) { const float k = 1.0f / sqrtf(l2); g[0] *= k; g[1] *= k; g[2] *= k; }
+            const float a = s->blendMode == ORACLE_BLEND_BEER_LAMBERT ? 1.0f - expf(-c[3]) : fminf(1.0f, c[3]);
+            const float w = (1 - col[3]) * a;
+            for (int k = 0; k < 3; ++k) { col[k] += w * c[k]; nacc[k] += w * g[k]; }
+            depth += w * t;
+            col[3] += w;
+        }
+    }
+    /* renderer_image_evaluator_simple.cuh:100-124, samples == 1 */
+    px8[0] = col[0]; px8[1] = col[1]; px8[2] = col[2]; px8[3] = col[3];
+    for (int k = 0; k < 3; ++k) px8[4 + k] = nacc[k] * col[3];
+    px8[7] = depth * col[3] / col[3];
+    *samples = cnt;
+}
+
+int oracle_render(const OracleNet* n, const OracleScene* s, int W, int H, int y0, int y1, float* out8,
+                  unsigned long long* evaluatedSamples) {
+    if (!n || !s || n->C > ORACLE_MAX_C || n->G > 64 || W <= 0 || H <= 0 || y0 < 0 || y1 > H) return -1;
+    unsigned long long total = 0;
+    const size_t plane = (size_t)W * H;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+    for (int y = y0; y < y1; ++y)
+        for (int x = 0; x < W; ++x) {
+            float p[8];
+            unsigned long long c;
+            render_pixel(n, s, W, H, x, y, p, &c);
+            total += c;
+            for (int k = 0; k < 8; ++k) out8[k * plane + (size_t)y * W + x] = p[k];
+        }
+    if (evaluatedSamples) *evaluatedSamples = total;
+    return 0;
+}
+
+/* lane-exact evaluated sample count without evaluating the network (early-out off), SURVEY 8(d) */
+unsigned long long oracle_count_samples(const OracleNet* n, const OracleScene* s, int W, int H, int y0, int y1) {
+    unsigned long long total = 0;
+    for (int y = y0; y < y1; ++y)
+        for (int x = 0; x < W; ++x) {
+            const float ndcx = 2 * ((float)x + 0.5f) / (float)W - 1, ndcy = 2 * ((float)y + 0.5f) / (float)H - 1;
+            const float tanFovY = tanf(s->fovY / 2), tanFovX = tanFovY * ((float)W / (float)H);
+            const float* right = s->right; const float* up = s->up;
+            const float front[3] = {up[1] * right[2] - up[2] * right[1], up[2] * right[0] - up[0] * right[2],
+                                    up[0] * right[1] - up[1] * right[0]};
+            float dir[3];
+            for (int i = 0; i < 3; ++i) dir[i] = front[i] + ndcx * tanFovX * right[i] + ndcy * tanFovY * up[i];
+            const float il = 1.0f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+            float tmin = -INFINITY, tmax = INFINITY;
+            for (int i = 0; i < 3; ++i) {
+                const float inv = 1.0f / (dir[i] * il);
+                const float ta = (n->boxMin[i] - s->eye[i]) * inv, tb = (n->boxMin[i] + n->boxSize[i] - s->eye[i]) * inv;
+                tmin = fmaxf(tmin, fminf(ta, tb));
+                tmax = fminf(tmax, fmaxf(ta, tb));
+            }
+            tmin = fmaxf(tmin, 0.f);
+            for (int i = 0;; ++i) {
+                if (!(tmin + (float)i * s->stepsize <= tmax)) break;
+                ++total;
+            }
+        }
+    return total;
+}
+
+uint16_t oracle_float_to_half(float f) { return f2h(f); }
+float oracle_half_to_float(uint16_t h) { return h2f(h); }

@@ -1,0 +1,65 @@
+/* srn_oracle.h -- CPU restatement of the fV-SRN hot path.  TEST INFRASTRUCTURE ONLY (see srn_oracle.c). */
+#ifndef SRN_ORACLE_H_
+#define SRN_ORACLE_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORACLE_ACC_HALF = 0, ORACLE_ACC_FLOAT = 1 };
+enum { ORACLE_ACT_RELU = 0, ORACLE_ACT_SINE = 1, ORACLE_ACT_SNAKE = 2, ORACLE_ACT_SNAKEALT = 3 };
+enum {
+    ORACLE_OUT_DENSITY = 0, ORACLE_OUT_DENSITY_DIRECT = 1, ORACLE_OUT_RGBO = 2, ORACLE_OUT_RGBO_DIRECT = 3,
+    ORACLE_OUT_DENSITY_GRADIENT = 4, ORACLE_OUT_DENSITY_GRADIENT_DIRECT = 5, ORACLE_OUT_DENSITY_GRADIENT_CUBIC = 6
+};
+enum { ORACLE_GRID_FLOAT = 0, ORACLE_GRID_BYTE_LINEAR = 1, ORACLE_GRID_BYTE_GAUSSIAN = 2 };
+enum { ORACLE_TF_NONE = 0, ORACLE_TF_IDENTITY = 1, ORACLE_TF_GAUSSIAN = 2, ORACLE_TF_PIECEWISE = 3, ORACLE_TF_TEXTURE = 4 };
+enum { ORACLE_BLEND_ALPHA = 0, ORACLE_BLEND_BEER_LAMBERT = 1 };
+
+/* The reference's constant block, kernel::VolumeInterpolationTensorcoresParameters
+ * (renderer/renderer_volume_tensorcores.cuh:195-249); all matrices are half bits. */
+typedef struct {
+    int C;           /* HIDDEN_CHANNELS = 4 + 2F                         */
+    int F;           /* NUM_FOURIER_FEATURES                             */
+    int G;           /* latent grid channels (0 = none)                  */
+    int NH;          /* NUM_HIDDEN_LAYERS (C x C)                        */
+    int Cout;        /* last layer outputs: 1 or 4                       */
+    int outputMode, activation, gridEncoding, passTime, accMode;
+    float actParam;
+    float boxMin[3], boxSize[3];
+    const uint16_t* fourier; /* cWeightsFourier [3*F], feature-fastest   */
+    const uint16_t* wFirst;  /* cWeightsLatentGrid [C][(C+G)] row-major  */
+    const uint16_t* bFirst;  /* cBiasLatentGrid [C]                      */
+    const uint16_t* wHidden; /* cWeightsHidden [NH][C][C] row-major      */
+    const uint16_t* bHidden; /* cBiasHidden [NH][C]                      */
+    const uint16_t* wLast;   /* cWeightsLast [C][Cout]                   */
+    const uint16_t* bLast;   /* cBiasLast [Cout]                         */
+    int gridX, gridY, gridZ;
+    const void* const* gridTexA; /* G/4 textures, each [Z][Y][X][4] float | uint8 (cLatentGridA)  */
+    const void* const* gridTexB; /* cLatentGridB                                                     */
+    const float* gridOffsetA;    /* per channel [G] (cLatentGridOffsetA)                             */
+    const float* gridScaleA;     /* per channel [G]                                                  */
+    const float* gridInterpolation; /* per texture [G/4] (cLatentGridInterpolation.x)                */
+} OracleNet;
+
+typedef struct {
+    float eye[3], right[3], up[3], fovY;
+    float stepsize, densityMin, densityMax;
+    int earlyOut, blendMode, tfKind, tfRows;
+    float tfScaleAbsorption, tfScaleEmission;
+    const float* tfTable;
+} OracleScene;
+
+int oracle_eval_points(const OracleNet* n, const float* worldPos, size_t count, float* out);
+int oracle_render(const OracleNet* n, const OracleScene* s, int W, int H, int y0, int y1, float* out8,
+                  unsigned long long* evaluatedSamples);
+unsigned long long oracle_count_samples(const OracleNet* n, const OracleScene* s, int W, int H, int y0, int y1);
+uint16_t oracle_float_to_half(float f);
+float oracle_half_to_float(uint16_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

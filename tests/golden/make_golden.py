@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""
+Generates the golden vectors under tests/golden/ by IMPORTING the reference's own Python
+implementation from /root/reference (read-only), with a stub `pyrenderer` module:
+
+  * applications/volnet/network.py   SceneRepresentationNetwork.forward        (network outputs)
+  * applications/volnet/raytracing.py Raytracing._full_trace_forward            (rgbo ray march)
+
+Run in the build container only (the GPU box has no /root/reference):
+    python tests/golden/make_golden.py
+The outputs (*.npz) are data: seeded inputs + the reference's outputs.  No reference source is copied.
+
+Conventions of the fixtures
+  * all network parameters, the Fourier matrix, the latent grids and the query positions are rounded
+    to fp16-representable values BEFORE the reference is evaluated, so weight/position quantisation
+    (which the reference's CUDA path applies on load, volume_interpolation_network.cpp:154,914) is
+    not an error source of the comparison
+  * out_fp32 = reference forward in fp32, out_fp16 = reference forward with .half() module and
+    inputs (the closest runnable analogue of the fp16 libtorch oracle of unittests/testSRN.cpp:94-208)
+  * outputs are taken in the reference's mode='world' (network.py:204-237): identical to 'screen'
+    for density / rgbo, and UN-clamped for the ':direct' modes -- which is what the CUDA kernel
+    returns (renderer_volume_tensorcores.cuh:1153-1157); mode='screen' would clamp them to [0,1]
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/applications"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+class _Any:
+    def __init__(self, *a, **k):
+        pass
+
+    def __getattr__(self, n):
+        return _Any
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        return _Any
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    sys.modules["pyrenderer"] = _Stub("pyrenderer")
+    from volnet.network import SceneRepresentationNetwork  # noqa
+    from volnet.raytracing import Raytracing  # noqa
+    return SceneRepresentationNetwork, Raytracing
+
+
+class FakeInput:
+    """Stands in for volnet.input_data.TrainingInputData (only the two counts are used)."""
+
+    def __init__(self, timekeyframes=1, ensembles=1):
+        self._t, self._e = timekeyframes, ensembles
+
+    def num_timekeyframes(self):
+        return self._t
+
+    def num_ensembles(self):
+        return self._e
+
+
+def make_network(SRN, *, layers, activation, fouriercount, fourierstd, outputmode, grid_channels=0, grid_res=0,
+                 time_dependent=False, time_features=0, ensemble_features=0, num_time=1, num_ens=1,
+                 use_time_direct=False, seed=0):
+    p = argparse.ArgumentParser()
+    SRN.init_parser(p)
+    args = ["--layers", layers, "--activation", activation, "--fouriercount", str(fouriercount), "--fourierstd",
+            str(fourierstd), "--outputmode", outputmode]
+    if grid_channels:
+        args += ["--volumetric_features_channels", str(grid_channels), "--volumetric_features_resolution", str(grid_res)]
+    if time_dependent:
+        args += ["--volumetric_features_time_dependent", "--time_features", str(time_features), "--ensemble_features",
+                 str(ensemble_features)]
+    if use_time_direct:
+        args += ["--use_time_direct"]
+    opt = vars(p.parse_args(args))
+    torch.manual_seed(seed)
+    net = SRN(opt, FakeInput(num_time, num_ens), torch.float32, torch.device("cpu"))
+    with torch.no_grad():  # fp16-representable parameters (see module docstring)
+        for q in net.parameters():
+            q.copy_(q.half().float())
+        B = net._input_parametrization.B
+        B.copy_(B.half().float())
+        # a grid of std 0.01 hardly influences the output; scale it up so grid bugs are visible
+        for name in ("_volumetric_latent_space", "_volumetric_latent_space_time", "_volumetric_latent_space_ensemble"):
+            if hasattr(net, name):
+                g = getattr(net, name)
+                g.copy_((g * 30).half().float())
+    return net, opt
+
+
+def positions(n, grid_res, seed):
+    rng = np.random.RandomState(seed)
+    p = rng.rand(n, 3).astype(np.float32)
+    edge = [[0, 0, 0], [1, 1, 1], [0, 1, 0.5], [1, 0, 0.25], [0.5, 0.5, 0.5]]
+    if grid_res:  # texel centres and texel borders
+        r = grid_res
+        edge += [[(i + 0.5) / r, (i + 0.5) / r, (i + 0.5) / r] for i in range(0, r, max(1, r // 4))]
+        edge += [[i / r, 0.5 / r, 1 - 0.5 / r] for i in range(0, r, max(1, r // 4))]
+    p[:len(edge)] = np.asarray(edge, np.float32)
+    return p.astype(np.float16).astype(np.float32)
+
+
+def forward(net, pos, time=0.0, ensemble=0.0, half=False, mode="world"):
+    x = torch.from_numpy(pos)
+    n = x.shape[0]
+    tf = torch.zeros(n)
+    t = torch.full((n,), float(time))
+    e = torch.full((n,), float(ensemble))
+    with torch.no_grad():
+        if half:
+            import copy
+            nh = copy.deepcopy(net).half()
+            return nh(x.half(), tf.half(), t.half(), e.half(), mode).float().numpy()
+        return net(x, tf, t, e, mode).numpy()
+
+
+def save_case(name, net, opt, pos, extra_meta=None, times=None, **arrays):
+    sd = net.state_dict()
+    n_lin = len(opt["layers"].split(":")) + 1
+    data = {"B": sd["_input_parametrization.B"].numpy(), "positions": pos}
+    for i in range(n_lin):
+        data["W%d" % i] = sd["_hidden_layers.linear%d.weight" % i].numpy()
+        data["b%d" % i] = sd["_hidden_layers.linear%d.bias" % i].numpy()
+    for key, store in (("_volumetric_latent_space", "grid"), ("_volumetric_latent_space_time", "grid_time"),
+                       ("_volumetric_latent_space_ensemble", "grid_ensemble")):
+        if key in sd:
+            data[store] = sd[key].numpy()
+    act = opt["activation"].split(":")
+    meta = {"name": name, "layers": opt["layers"], "activation": act[0],
+            "activation_param": float(act[1]) if len(act) > 1 else 1.0, "output_mode": opt["outputmode"],
+            "fouriercount": opt["fouriercount"], "fourierstd": opt["fourierstd"],
+            "use_time_direct": bool(opt["use_time_direct"]), "torch": torch.__version__}
+    meta.update(extra_meta or {})
+    data["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    data.update(arrays)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **data)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in data.items() if k not in ("meta",)})
+
+
+def main():
+    SRN, Raytracing = import_reference()
+    N = 1024
+
+    # ---- G1a: 32x4 Fourier-only, all activations x output modes ------------------------------------
+    k = 0
+    for act in ["ReLU", "SnakeAlt:1", "Sine:1", "Snake:2"]:
+        for om in ["density", "density:direct", "rgbo", "rgbo:direct"]:
+            k += 1
+            std = -1 if k % 2 else 0.6  # alternate NeRF block-identity and random gaussian matrices
+            net, opt = make_network(SRN, layers="32:32:32", activation=act, fouriercount=14, fourierstd=std,
+                                    outputmode=om, seed=100 + k)
+            pos = positions(N, 0, k)
+            save_case("g1_c32l4_%s_%s" % (act.split(":")[0].lower(), om.replace(":", "-")), net, opt, pos,
+                      out_fp32=forward(net, pos), out_fp16=forward(net, pos, half=True))
+
+    # ---- G1b: latent grids ------------------------------------------------------------------------
+    for name, kw in [
+        ("g1_c32l4_grid16r8_relu_density", dict(layers="32:32:32", activation="ReLU", outputmode="density", gc=16, gr=8)),
+        ("g1_c32l4_grid16r8_snakealt_rgbo", dict(layers="32:32:32", activation="SnakeAlt:1", outputmode="rgbo", gc=16, gr=8)),
+        ("g1_c32l4_grid16r16_snakealt_density-direct", dict(layers="32:32:32", activation="SnakeAlt:1", outputmode="density:direct", gc=16, gr=16)),
+        ("g1_c32l3_grid32r8_sine_density", dict(layers="32:32", activation="Sine:1", outputmode="density", gc=32, gr=8)),
+        ("g1_c64l6_grid16r8_snakealt_density-direct", dict(layers="64:64:64:64:64", activation="SnakeAlt:1", outputmode="density:direct", gc=16, gr=8, F=30)),
+        ("g1_c48l3_grid16r8_snake_rgbo-direct", dict(layers="48:48", activation="Snake:2", outputmode="rgbo:direct", gc=16, gr=8, F=22)),
+    ]:
+        k += 1
+        net, opt = make_network(SRN, layers=kw["layers"], activation=kw["activation"], fouriercount=kw.get("F", 14),
+                                fourierstd=-1, outputmode=kw["outputmode"], grid_channels=kw["gc"], grid_res=kw["gr"],
+                                seed=100 + k)
+        pos = positions(N, kw["gr"], k)
+        save_case(name, net, opt, pos, out_fp32=forward(net, pos), out_fp16=forward(net, pos, half=True))
+
+    # ---- G1c: wider / deeper without grid -------------------------------------------------------------
+    for name, kw in [
+        ("g1_c64l6_relu_density", dict(layers="64:64:64:64:64", activation="ReLU", outputmode="density", F=30)),
+        ("g1_c48l4_snakealt_density-direct", dict(layers="48:48:48", activation="SnakeAlt:1", outputmode="density:direct", F=22)),
+        ("g1_c64l2_sine_rgbo", dict(layers="64", activation="Sine:1", outputmode="rgbo", F=30)),
+    ]:
+        k += 1
+        net, opt = make_network(SRN, layers=kw["layers"], activation=kw["activation"], fouriercount=kw["F"],
+                                fourierstd=0.5, outputmode=kw["outputmode"], seed=100 + k)
+        pos = positions(N, 0, k)
+        save_case(name, net, opt, pos, out_fp32=forward(net, pos), out_fp16=forward(net, pos, half=True))
+
+    # ---- G2: time-dependent / ensemble latent grids ---------------------------------------------------
+    times = [0.0, 0.25, 1.0, 1.75, 2.0]
+    k += 1
+    net, opt = make_network(SRN, layers="32:32:32", activation="SnakeAlt:1", fouriercount=14, fourierstd=-1,
+                            outputmode="density:direct", grid_channels=16, grid_res=8, time_dependent=True,
+                            time_features=16, ensemble_features=0, num_time=3, seed=100 + k)
+    pos = positions(512, 8, k)
+    save_case("g2_time3_c32l4_grid16r8", net, opt, pos, extra_meta={"times": times},
+              out_fp32=np.stack([forward(net, pos, time=t) for t in times]))
+    k += 1
+    net, opt = make_network(SRN, layers="32:32:32", activation="ReLU", fouriercount=14, fourierstd=-1,
+                            outputmode="density", grid_channels=32, grid_res=8, time_dependent=True,
+                            time_features=16, ensemble_features=16, num_time=3, num_ens=2, seed=100 + k)
+    pos = positions(512, 8, k)
+    te = [(0.5, 0), (1.5, 1), (2.0, 1)]
+    save_case("g2_time3_ens2_c32l4_grid32r8", net, opt, pos, extra_meta={"time_ensemble": te},
+              out_fp32=np.stack([forward(net, pos, time=t, ensemble=e) for t, e in te]))
+    k += 1
+    net, opt = make_network(SRN, layers="32:32:32", activation="SnakeAlt:1", fouriercount=14, fourierstd=-1,
+                            outputmode="density:direct", grid_channels=16, grid_res=8, time_dependent=True,
+                            time_features=16, ensemble_features=0, num_time=3, use_time_direct=True, seed=100 + k)
+    pos = positions(512, 8, k)
+    save_case("g2_time3_passtime_c32l4_grid16r8", net, opt, pos, extra_meta={"times": times},
+              out_fp32=np.stack([forward(net, pos, time=t) for t in times]))
+
+    # ---- G3: rgbo ray march with explicit rays (Raytracing._full_trace_forward) ------------------------
+    k += 1
+    net, opt = make_network(SRN, layers="32:32:32", activation="SnakeAlt:1", fouriercount=14, fourierstd=0.35,
+                            outputmode="rgbo", seed=100 + k)
+    W = H = 32
+    stepsize = 1.0 / 48
+    box_min, box_size = np.array([-0.5, -0.5, -0.5], np.float32), np.array([1, 1, 1], np.float32)
+    # CameraOnASphere(Ym, center 0, pitch 0.4, yaw 0.7, distance 1.6), fovY 45 deg -- computed here in numpy
+    eye, right, up = camera_frame(pitch=0.4, yaw=0.7, distance=1.6)
+    fov = np.deg2rad(45.0)
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    ndcx = (2 * (xs + 0.5) / W - 1).astype(np.float32)
+    ndcy = (2 * (ys + 0.5) / H - 1).astype(np.float32)
+    front = np.cross(up, right)
+    tan_y = np.float32(np.tan(fov / 2))
+    tan_x = tan_y * np.float32(W / H)
+    d = front[None, None] + (ndcx * tan_x)[..., None] * right[None, None] + (ndcy * tan_y)[..., None] * up[None, None]
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    start = np.broadcast_to(eye[None, None], d.shape).astype(np.float32).copy()
+    # sentinel ray along the box diagonal (pixel 0,0): the reference clips ALL rays to
+    # int(max(tmax-tmin)/stepsize) steps (raytracing.py:301); the sentinel keeps that bound above
+    # every camera ray so their last sample is not cut.  Tests ignore pixel (0,0).
+    start[0, 0] = np.array([-0.6, -0.6, -0.6], np.float32)
+    d[0, 0] = (np.ones(3) / np.sqrt(3)).astype(np.float32)
+    rt = Raytracing.__new__(Raytracing)
+    rt._network_output = "rgbo"
+    rt._stepsize = stepsize
+    rt._dtype, rt._device = torch.float32, torch.device("cpu")
+    rt._box_min = torch.from_numpy(box_min).unsqueeze(0)
+    rt._box_size = torch.from_numpy(box_size).unsqueeze(0)
+    net.use_direction = lambda: False
+    z = torch.zeros(1, 1)
+    with torch.no_grad():
+        img = rt._full_trace_forward(net, torch.from_numpy(start)[None], torch.from_numpy(d)[None], None, False, True,
+                                     [z, z, z, "screen"])
+    save_case("g3_trace_rgbo_32x32", net, opt, np.zeros((1, 3), np.float32),
+              extra_meta={"W": W, "H": H, "stepsize": stepsize, "fov_y": float(fov), "pitch": 0.4, "yaw": 0.7,
+                          "distance": 1.6, "orientation": "Ym", "box_min": box_min.tolist(), "box_size": box_size.tolist()},
+              ray_start=start, ray_dir=d, image=img.numpy()[0], eye=eye, right=right, up=up)
+
+
+def camera_frame(pitch, yaw, distance):
+    """CameraOnASphere, orientation Ym, centre 0 (formulas of renderer/camera.cpp:458-490,553-569)."""
+    up_axis = np.array([0.0, -1.0, 0.0])
+    yaw2, pitch2 = -yaw, -pitch  # Ym: no yaw inversion -> negated, pitch always negated
+    pos = np.array([np.cos(pitch2) * np.cos(yaw2) * distance, np.sin(pitch2) * distance, np.cos(pitch2) * np.sin(yaw2) * distance])
+    origin = -pos  # permutation (-1,-2,-3)
+    front = -origin / np.linalg.norm(origin)
+    right = np.cross(front, up_axis)
+    right /= np.linalg.norm(right)
+    up = np.cross(right, front)
+    up /= np.linalg.norm(up)
+    return origin.astype(np.float32), right.astype(np.float32), up.astype(np.float32)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,232 @@
+"""
+Parity of the HIP path (through the C ABI, include/fvsrn.h) against the CPU oracle and the golden
+vectors.  All tests here need a real MI355X:  pytest -m gpu
+
+Tolerances (fp32 outputs; the kernels store activations as fp16 and accumulate in fp32):
+  * network outputs vs oracle FLOAT model (same arithmetic model):              2e-3
+  * network outputs vs reference fp32 golden:                                   2e-3
+  * network outputs vs reference fp16 golden / oracle HALF (reference's bar):   1e-2  (testSRN.cpp:409)
+  * rendered RGBA vs oracle FLOAT image:                                        3e-3
+  * rendered RGBA vs oracle HALF image (fp16-accumulation tolerance):           2e-2
+"""
+import numpy as np
+import pytest
+
+import util
+from oracle import oracle
+from test_oracle_golden import expected_output
+
+pytestmark = pytest.mark.gpu
+
+TOL_SAME_MODEL = 2e-3
+TOL_REF_BAR = 1e-2
+TOL_IMG = 3e-3
+TOL_IMG_HALF = 2e-2
+
+
+def gpu_eval(vn, positions, time=None, ensemble=0):
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    if time is not None:
+        net.set_time_and_ensemble(time, ensemble)
+    out = net.evaluate(torch.from_numpy(np.ascontiguousarray(positions, np.float32)).cuda())
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_extension_is_loaded_and_gpu_visible():
+    from fvsrn_amd import capi
+    assert capi.device_count() >= 1
+    assert b"gfx950" in capi.lib().fvsrn_version()
+
+
+@pytest.mark.parametrize("name", util.golden_names("g1_"))
+def test_evaluate_points_golden(name):
+    d, meta = util.load_golden(name)
+    vn = util.golden_to_volnet(d, meta)
+    out = gpu_eval(vn, d["positions"])
+    assert np.isfinite(out).all()
+    out_f = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(d["positions"])
+    out_h = oracle.OracleNetwork(vn, oracle.ACC_HALF).evaluate(d["positions"])
+    ref32, ref16 = expected_output(d, meta, "out_fp32"), expected_output(d, meta, "out_fp16")
+    spread = np.abs(ref32 - ref16).max()
+    assert np.abs(out - out_f).max() < TOL_SAME_MODEL
+    assert np.abs(out - ref32).max() < TOL_SAME_MODEL
+    assert np.abs(out - ref16).max() < max(TOL_REF_BAR, 1.5 * spread)
+    assert np.abs(out - out_h).max() < max(TOL_REF_BAR, 1.5 * spread)
+
+
+@pytest.mark.parametrize("name", util.golden_names("g2_"))
+def test_time_and_ensemble_golden(name):
+    d, meta = util.load_golden(name)
+    vn = util.golden_to_volnet(d, meta)
+    tes = [(t, 0) for t in meta["times"]] if "times" in meta else meta["time_ensemble"]
+    for i, (t, e) in enumerate(tes):
+        out = gpu_eval(vn, d["positions"], time=t, ensemble=e)
+        assert np.abs(out - d["out_fp32"][i]).max() < TOL_SAME_MODEL, (t, e)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000, 4097])
+def test_evaluate_ragged_sizes(n):
+    vn = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode="rgbo", seed=3)
+    pos = np.random.RandomState(n).rand(n, 3).astype(np.float32)
+    out = gpu_eval(vn, pos)
+    assert out.shape == (n, 4)
+    if n:
+        ref = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos)
+        assert np.abs(out - ref).max() < TOL_SAME_MODEL
+
+
+@pytest.mark.parametrize("enc", [0, 1])
+def test_evaluate_grid_encodings_and_box(enc):
+    vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density", grid=(16, 8), seed=5,
+                             box_min=(-0.5, -0.25, 0.1), box_size=(1.0, 0.5, 2.0), encoding=enc)
+    rng = np.random.RandomState(1)
+    pos = (rng.rand(2000, 3) * np.array([1.0, 0.5, 2.0]) + np.array([-0.5, -0.25, 0.1])).astype(np.float32)
+    out = gpu_eval(vn, pos)
+    ref = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos)
+    assert np.abs(out - ref).max() < TOL_SAME_MODEL
+
+
+def make_scene_kwargs(pitch=0.4, yaw=0.7, distance=1.6, stepsize=1 / 48, **kw):
+    eye, right, up = oracle.camera_on_a_sphere("Ym", (0, 0, 0), pitch, yaw, distance)
+    d = dict(eye=eye, right=right, up=up, fov_y_radians=float(np.deg2rad(45.0)), stepsize=stepsize)
+    d.update(kw)
+    return d
+
+
+def render_both(vn, scene_kw, W, H, y0=0, y1=None, acc=oracle.ACC_FLOAT):
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    scene = capi.Scene(**scene_kw)
+    stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+    img = scene.render(net, W, H, y0, y1, stats=stats)
+    torch.cuda.synchronize()
+    ref, count = oracle.OracleScene(**scene_kw).render(oracle.OracleNetwork(vn, acc), W, H, y0, H if y1 is None else y1)
+    return img.cpu().numpy()[0], ref, stats.cpu().numpy(), count
+
+
+def assert_images_close(img, ref, tol, y0=0, y1=None):
+    y1 = img.shape[1] if y1 is None else y1
+    a, b = img[:, y0:y1], ref[:, y0:y1]
+    # depth (channel 7) is 0/0 = NaN where alpha == 0 in the reference as well
+    assert np.array_equal(np.isnan(a[7]), np.isnan(b[7]))
+    assert np.abs(a[:7] - b[:7]).max() < tol
+    m = ~np.isnan(b[7])
+    if m.any():
+        assert np.abs(a[7][m] - b[7][m]).max() < 10 * tol
+
+
+def test_render_golden_trace_rgbo():
+    d, meta = util.load_golden("g3_trace_rgbo_32x32")
+    vn = util.golden_to_volnet(d, meta, box_min=meta["box_min"], box_size=meta["box_size"])
+    kw = dict(eye=d["eye"], right=d["right"], up=d["up"], fov_y_radians=meta["fov_y"], stepsize=meta["stepsize"],
+              early_out=False, tf_kind=oracle.TF_NONE)
+    img, ref, stats, count = render_both(vn, kw, meta["W"], meta["H"])
+    diff = np.abs(img[:4] - d["image"])
+    diff[:, 0, 0] = 0
+    assert diff.max() < TOL_IMG       # vs the reference's Python ray marcher
+    assert_images_close(img, ref, TOL_IMG)
+    assert stats[0] == count
+
+
+GAUSS_TF = np.array([[0.9, 0.1, 0.1, 30.0, 0.25, 0.08], [0.1, 0.9, 0.2, 60.0, 0.5, 0.05], [0.2, 0.3, 0.95, 90.0, 0.8, 0.1]], np.float32)
+PIECE_TF = np.array([[0, 0, 0, 0, -1], [0.2, 0.1, 0.8, 0, 0.2], [0.9, 0.5, 0.1, 40, 0.5], [1, 1, 1, 120, 0.9], [1, 1, 1, 120, 2]], np.float32)
+TEX_TF = np.stack([np.linspace(0, 1, 32), np.linspace(1, 0, 32) ** 2, np.full(32, 0.3), np.linspace(0, 80, 32)], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", [
+    dict(act="SnakeAlt", out="density", tf=dict(tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=20.0, tf_scale_emission=1.0)),
+    dict(act="ReLU", out="density", tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)),
+    dict(act="Sine", out="density", tf=dict(tf_kind=oracle.TF_PIECEWISE, tf_table=PIECE_TF)),
+    dict(act="Snake", out="density", tf=dict(tf_kind=oracle.TF_TEXTURE, tf_table=TEX_TF), param=2.0),
+    dict(act="SnakeAlt", out="density", tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF, blend_mode=oracle.BLEND_ALPHA)),
+    dict(act="ReLU", out="rgbo", tf=dict(tf_kind=oracle.TF_NONE)),
+    dict(act="SnakeAlt", out="rgbo:direct", tf=dict(tf_kind=oracle.TF_NONE, blend_mode=oracle.BLEND_ALPHA)),
+    dict(act="SnakeAlt", out="density", tf=dict(tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=40.0, density_min=0.45, density_max=0.8)),
+    dict(act="SnakeAlt", out="density", grid=(16, 8), tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)),
+    dict(act="ReLU", out="density", C=64, layers=6, grid=(16, 8), tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)),
+    dict(act="SnakeAlt", out="density", C=48, layers=3, tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)),
+])
+@pytest.mark.parametrize("early_out", [False, True])
+def test_render_matches_oracle(case, early_out):
+    vn = util.random_network(C=case.get("C", 32), layers=case.get("layers", 4), activation=case["act"],
+                             param=case.get("param", 1.0), output_mode=case["out"], grid=case.get("grid"), seed=11,
+                             box_min=(-0.5, -0.5, -0.5), fourier_std=0.4)
+    kw = make_scene_kwargs(early_out=early_out, **case["tf"])
+    img, ref, stats, count = render_both(vn, kw, 40, 24)  # 40 = 5 pixel tiles, 24 = 3 tiles
+    assert_images_close(img, ref, TOL_IMG)
+    assert stats[0] == count
+    assert stats[1] >= stats[0] and stats[1] % 64 == 0
+    assert img[3].max() > 0.05, "scene is empty, the comparison would be vacuous"
+    img_h, ref_h, _, _ = render_both(vn, kw, 40, 24, acc=oracle.ACC_HALF)
+    assert_images_close(img_h, ref_h, TOL_IMG_HALF)
+
+
+def test_render_ragged_image_and_row_stripes():
+    """W, H not multiples of the 8x8 pixel tile; stripes [y0,y1) compose to the full frame bit-exactly."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode="density", seed=2, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4)
+    kw = make_scene_kwargs(tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=30.0)
+    W, H = 37, 29
+    img, ref, stats, count = render_both(vn, kw, W, H)
+    assert_images_close(img, ref, TOL_IMG)
+    assert stats[0] == count
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    scene = capi.Scene(**kw)
+    full = scene.render(net, W, H)
+    parts = torch.full_like(full, -7.0)
+    for y0, y1 in [(0, 5), (5, 16), (16, 17), (17, 29)]:
+        scene.render(net, W, H, y0, y1, out=parts)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(full, nan=-1.0), torch.nan_to_num(parts, nan=-1.0))
+
+
+def test_render_camera_inside_box_and_missing_rays():
+    vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density", seed=4, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4)
+    kw = make_scene_kwargs(distance=0.2, tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=5.0)  # eye inside: tmin clamps to 0
+    img, ref, stats, count = render_both(vn, kw, 24, 16)
+    assert_images_close(img, ref, TOL_IMG)
+    assert stats[0] == count
+    kw = make_scene_kwargs(distance=40.0, tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=5.0)  # box covers ~1 pixel
+    img, ref, stats, count = render_both(vn, kw, 24, 16)
+    assert_images_close(img, ref, TOL_IMG)
+    assert stats[0] == count
+
+
+def test_full_size_properties_1024x512steps():
+    """BASELINE size (1024^2, 512 steps): properties that need no oracle run.
+    (a) evaluated sample counter == host count of the loop bound, (b) two row stripes == full frame,
+    (c) alpha in [0,1], finite colour."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density:direct", seed=1234, box_min=(-0.5, -0.5, -0.5))
+    kw = make_scene_kwargs(stepsize=1 / 512, early_out=False, tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=10.0)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    scene = capi.Scene(**kw)
+    stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+    full = scene.render(net, 1024, 1024, stats=stats)
+    halves = torch.zeros_like(full)
+    scene.render(net, 1024, 1024, 0, 512, out=halves)
+    scene.render(net, 1024, 1024, 512, 1024, out=halves)
+    torch.cuda.synchronize()
+    expected = oracle.OracleScene(**kw).count_samples(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), 1024, 1024)
+    assert int(stats[0]) == expected
+    assert torch.equal(torch.nan_to_num(full, nan=-1.0), torch.nan_to_num(halves, nan=-1.0))
+    rgba = full[0, :4]
+    assert torch.isfinite(rgba).all() and rgba[3].min() >= 0 and rgba[3].max() <= 1.0 + 1e-6
+
+
+def test_errors_are_reported():
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="rgbo", seed=1)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    scene = capi.Scene(**make_scene_kwargs(tf_kind=oracle.TF_IDENTITY))
+    with pytest.raises(capi.FvsrnError, match="FVSRN_TF_NONE"):
+        scene.render(net, 16, 16)
+    with pytest.raises(capi.FvsrnError):
+        capi.Scene(**make_scene_kwargs(tf_kind=oracle.TF_NONE)).render(net, 16, 16, 4, 40)

@@ -1,0 +1,76 @@
+"""Shared helpers of the test-suite: golden fixtures -> .volnet -> oracle / HIP path."""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import fvsrn_amd  # noqa: E402  (alias of the package directory fv-srn_amd/)
+from fvsrn_amd import volnet_io  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_names(prefix=""):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+
+
+def load_golden(name):
+    d = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    meta = json.loads(bytes(d.pop("meta")).decode())
+    return d, meta
+
+
+def golden_to_volnet(d, meta, *, encoding=volnet_io.ENC_FLOAT, box_min=(0.0, 0.0, 0.0), box_size=(1.0, 1.0, 1.0)):
+    """The export_to_pyrenderer hand-off (reference network.py:798-897) on the arrays of a fixture."""
+    n = len(meta["layers"].split(":")) + 1
+    weights = [d["W%d" % i] for i in range(n)]
+    biases = [d["b%d" % i] for i in range(n)]
+    time_grids = ensemble_grids = None
+    if "grid" in d:  # static grid = one time key-frame (network.py:856-864)
+        time_grids = [d["grid"][0]]
+    if "grid_time" in d:
+        time_grids = [g for g in d["grid_time"]]
+    if "grid_ensemble" in d:
+        ensemble_grids = [g for g in d["grid_ensemble"]]
+        if time_grids is None:
+            time_grids = []
+    return volnet_io.build_volnet(
+        fourier_B=d["B"], weights=weights, biases=biases, activation=meta["activation"],
+        activation_param=meta["activation_param"], output_mode=meta["output_mode"], box_min=box_min, box_size=box_size,
+        premultiplied=True, time_grids=time_grids, ensemble_grids=ensemble_grids, grid_encoding=encoding,
+        has_time=meta.get("use_time_direct", False))
+
+
+def random_network(*, C=32, layers=4, activation="SnakeAlt", param=1.0, output_mode="density:direct", grid=None,
+                   fourier_std=None, seed=0, box_min=(0.0, 0.0, 0.0), box_size=(1.0, 1.0, 1.0), encoding=volnet_io.ENC_FLOAT,
+                   grid_scale=0.3, time_grids=1):
+    """Seeded random SRN in the reference's shape conventions: nn.Linear default init U(+-1/sqrt(in)),
+    NeRF block-identity Fourier matrix (network.py:55-63) unless fourier_std is given; grid = (channels, res)."""
+    rng = np.random.RandomState(seed)
+    F = (C - 4) // 2
+    if fourier_std is None:
+        blocks = [(2.0 ** i) * np.eye(3) for i in range((F + 2) // 3)]
+        B = (np.concatenate(blocks, axis=0)[:F] * 2 * np.pi).astype(np.float32)
+    else:
+        B = (rng.randn(F, 3) * fourier_std * 2 * np.pi).astype(np.float32)
+    G = grid[0] if grid else 0
+    cout = 4 if output_mode.startswith("rgbo") or output_mode.startswith("densitygrad") else 1
+    dims = [3 + 2 * F + G] + [C] * (layers - 1) + [cout]
+    weights, biases = [], []
+    for i in range(layers):
+        k = 1.0 / np.sqrt(dims[i])
+        weights.append(rng.uniform(-k, k, (dims[i + 1], dims[i])).astype(np.float32))
+        biases.append(rng.uniform(-k, k, dims[i + 1]).astype(np.float32))
+    tg = None
+    if grid:
+        tg = [(rng.randn(G, grid[1], grid[1], grid[1]) * grid_scale).astype(np.float32) for _ in range(time_grids)]
+    vn = volnet_io.build_volnet(fourier_B=B, weights=weights, biases=biases, activation=activation, activation_param=param,
+                                output_mode=output_mode, box_min=box_min, box_size=box_size, time_grids=tg,
+                                grid_encoding=encoding)
+    return vn
