@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the MI355X fV-SRN renderer.
+
+A "step" = one frame of the fused SRN-MLP + DVR ray-stepping hot path (fvsrn_render[_stripes]) on
+synthetic inputs already resident in HBM:
+  network  32-wide x 4-layer fp16 SRN, Fourier-only encoding (F=14, NeRF block-identity matrix),
+           seeded nn.Linear-style init, output density:direct              (BASELINE.json configs[1] net)
+  frame    1024 x 1024, world step 1/512 (512 steps across the unit box), box [-0.5,0.5]^3,
+           CameraOnASphere(Ym, pitch 0.4, distance 1.6, fovY 45 deg), yaw advancing 2*pi/64 per frame,
+           Identity TF (absorption 10, emission 1), Beer-Lambert, early-out OFF (every sample evaluated)
+  activation  ReLU by default: the activation the reference's own timing harness runs
+           (applications/volnet/eval_NetworkConfigsGrid.py:31, activationX = ["ReLU"]); the paper's SnakeAlt
+           twin is timed beside it and reported in "snakealt_twin".
+metric: SRN samples/s, counting lane-exact EVALUATED samples (the loop bound of
+renderer_ray_evaluation_stepping_dvr.cuh:84-90 summed over all rays), read from the kernel's own counter.
+
+N > 1 (launched with torch.distributed.run): the SAME frame is split into round-robin 16-row stripes, one
+process per GPU, each rank renders its stripes and one RCCL all-gather assembles the frame ("strong" scaling;
+the gather of frame i overlaps the render of frame i+1 on a second stream).
+
+Prints ONE JSON line (see the contract in the task description) with "roofline" and "cpu_baseline".
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+STRIPE = 16
+
+CONFIGS = {
+    # name: (C, layers, grid(ch,res)|None, width, height, steps)
+    "c32l4_fourier_512x256": (32, 4, None, 512, 512, 256),       # BASELINE.json configs[1]
+    "c32l4_fourier_1024x512": (32, 4, None, 1024, 1024, 512),    # the size the metric is quoted on
+    "c32l4_grid16_1024x512": (32, 4, (16, 16), 1024, 1024, 512),  # configs[2]
+    "c64l6_grid16_1024x512": (64, 6, (16, 32), 1024, 1024, 512),  # configs[3]
+}
+
+
+def build_scene_kwargs(capi, yaw, stepsize, early_out):
+    eye, right, up = capi.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, yaw, 1.6)
+    return dict(eye=eye, right=right, up=up, fov_y_radians=float(np.deg2rad(45.0)), stepsize=stepsize,
+                early_out=early_out, tf_kind=capi.TF_IDENTITY, tf_scale_absorption=10.0, tf_scale_emission=1.0)
+
+
+def make_network(util, volnet_io, capi, cfg, activation):
+    C, layers, grid, *_ = cfg
+    vn = util.random_network(C=C, layers=layers, activation=activation, param=1.0, output_mode="density:direct",
+                             grid=grid, seed=1234, box_min=(-0.5, -0.5, -0.5), grid_scale=0.01)
+    return vn, capi.Network.from_volnet(volnet_io.save_volnet(vn))
+
+
+class Runner:
+    """Renders frames of one network on this rank (whole frame, or this rank's stripes + all-gather)."""
+
+    def __init__(self, capi, net, cfg, rank, world, early_out):
+        self.capi, self.net, self.rank, self.world = capi, net, rank, world
+        _, _, _, self.W, self.H, steps = cfg
+        self.stepsize = 1.0 / steps
+        self.early_out = early_out
+        self.scene = capi.Scene(**build_scene_kwargs(capi, 0.0, self.stepsize, early_out))
+        self.stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+        if world == 1:
+            self.out = torch.zeros((1, 8, self.H, self.W), dtype=torch.float32, device="cuda")
+        else:
+            assert self.H % (STRIPE * world) == 0, "image height must be a multiple of stripe*world"
+            rows = capi.stripe_rows(self.H, STRIPE, rank, world)
+            self.local = [torch.zeros((8, rows, self.W), dtype=torch.float32, device="cuda") for _ in range(2)]
+            self.gathered = [torch.zeros((world, 8, rows, self.W), dtype=torch.float32, device="cuda") for _ in range(2)]
+            self.comm_stream = torch.cuda.Stream()
+            self.render_done = [torch.cuda.Event() for _ in range(2)]
+            self.gather_done = [torch.cuda.Event() for _ in range(2)]
+        self.kernel_events = []
+
+    def frame(self, index, record=False):
+        import torch.distributed as dist
+        yaw = 2 * math.pi * (index % 64) / 64
+        self.scene.update(**build_scene_kwargs(self.capi, yaw, self.stepsize, self.early_out))
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        if self.world == 1:
+            self.scene.render(self.net, self.W, self.H, out=self.out, stats=self.stats)
+        else:
+            b = index & 1
+            torch.cuda.current_stream().wait_event(self.gather_done[b])  # buffer b free again
+            self.capi.render_stripes(self.scene, self.net, self.W, self.H, STRIPE, self.rank, self.world,
+                                     out=self.local[b], stats=self.stats)
+            self.render_done[b].record()
+        if record:
+            e1.record()
+            self.kernel_events.append((e0, e1))
+        if self.world > 1:
+            with torch.cuda.stream(self.comm_stream):  # gather(frame i) overlaps render(frame i+1)
+                self.comm_stream.wait_event(self.render_done[b])
+                dist.all_gather_into_tensor(self.gathered[b].view(self.world * 8, -1, self.W), self.local[b])
+                self.gather_done[b].record()
+
+    def finish(self):
+        if self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def assemble(self, b=0):
+        """(world, 8, rows, W) -> (1, 8, H, W): undo the round-robin stripe order."""
+        if self.world == 1:
+            return self.out
+        g = self.gathered[b]
+        R, _, rows, W = g.shape
+        return g.view(R, 8, rows // STRIPE, STRIPE, W).permute(1, 2, 0, 3, 4).reshape(1, 8, self.H, W)
+
+
+def timed_run(runner, steps, warmup, distributed):
+    import torch.distributed as dist
+    for i in range(warmup):
+        runner.frame(i)
+    runner.finish()
+    torch.cuda.synchronize()
+    runner.stats.zero_()
+    runner.kernel_events.clear()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        runner.frame(warmup + i, record=True)
+    runner.finish()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in runner.kernel_events]
+    st = runner.stats.cpu().numpy().astype(np.int64)
+    return dt, kernel_ms, int(st[0]), int(st[1])
+
+
+def cpu_baseline(util, cfg, activation):
+    """The reference's PyTorch path (port: oracle/torch_port.py) on the host cores, bounded sample."""
+    from oracle import torch_port
+    from fvsrn_amd import capi
+    C, layers, grid, *_ = cfg
+    rng = np.random.RandomState(1234)
+    F = (C - 4) // 2
+    blocks = [(2.0 ** i) * np.eye(3) for i in range((F + 2) // 3)]
+    B = (np.concatenate(blocks, axis=0)[:F] * 2 * np.pi).astype(np.float32)
+    G = grid[0] if grid else 0
+    dims = [3 + 2 * F + G] + [C] * (layers - 1) + [1]
+    ws = [rng.uniform(-1, 1, (dims[i + 1], dims[i])).astype(np.float32) / np.sqrt(dims[i]) for i in range(layers)]
+    bs = [rng.uniform(-1, 1, dims[i + 1]).astype(np.float32) / np.sqrt(dims[i]) for i in range(layers)]
+    g = (rng.randn(1, G, grid[1], grid[1], grid[1]) * 0.01).astype(np.float32) if grid else None
+    net = torch_port.TorchSRN(B, ws, bs, activation, 1.0, "density:direct", g)
+    eye, right, up = capi.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, 0.0, 1.6)
+    cores = os.cpu_count() or 1
+    W = H = 256
+    steps = 128
+    r = torch_port.time_cpu_baseline(net, eye, right, up, float(np.deg2rad(45.0)), (-0.5, -0.5, -0.5), (1, 1, 1), width=W,
+                                     height=H, stepsize=1.0 / steps, tf_identity=(10.0, 1.0), threads=cores, repeats=1)
+    return {"value": r["value"], "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "PyTorch-CPU fp32 port of SceneRepresentationNetwork.forward + Raytracing._full_trace_forward, "
+                      "same network/camera, one %dx%d frame at step 1/%d = %d network samples in %.1f s"
+                      % (W, H, steps, r["samples"], r["seconds"])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--config", default="c32l4_fourier_1024x512", choices=sorted(CONFIGS))
+    ap.add_argument("--activation", default="ReLU", choices=["ReLU", "SnakeAlt", "Snake", "Sine"])
+    ap.add_argument("--early-out", action="store_true", help="as-shipped DVR with alpha early-out")
+    ap.add_argument("--no-twin", action="store_true", help="skip the second-activation twin run")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP kernels have no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or not distributed, "--gpus must equal WORLD_SIZE"
+
+    import util
+    import fvsrn_amd  # noqa: F401
+    from fvsrn_amd import capi, volnet_io
+
+    cfg = CONFIGS[args.config]
+    vn, net = make_network(util, volnet_io, capi, cfg, args.activation)
+    info = net.info()
+    runner = Runner(capi, net, cfg, rank, world, args.early_out)
+    dt, kernel_ms, evaluated, executed = timed_run(runner, args.steps, args.warmup, distributed)
+    if distributed:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        c = torch.tensor([evaluated, executed], dtype=torch.int64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        evaluated, executed = int(c[0]), int(c[1])
+
+    twin = None
+    if not args.no_twin and not distributed:
+        other = "SnakeAlt" if args.activation == "ReLU" else "ReLU"
+        _, net2 = make_network(util, volnet_io, capi, cfg, other)
+        r2 = Runner(capi, net2, cfg, rank, world, args.early_out)
+        dt2, k2, ev2, ex2 = timed_run(r2, max(4, args.steps // 4), 2, False)
+        twin = {"activation": other, "value": ev2 / dt2, "unit": "samples/s", "ms_per_step": 1e3 * dt2 / max(4, args.steps // 4),
+                "kernel": net2.kernel_name(True),
+                "mfma_frac": (ev2 * info.flops_per_sample / (sum(k2) * 1e-3)) / (MFMA_F16_PEAK_TFLOPS * 1e12)}
+
+    if rank == 0:
+        _, _, _, W, H, steps = cfg
+        kernel_s = sum(kernel_ms) * 1e-3 / len(kernel_ms)             # average launch duration on this rank
+        flops_per_launch = info.flops_per_sample * (evaluated / world) / args.steps  # algorithmic, SURVEY 8(d)
+        achieved = flops_per_launch / kernel_s / 1e12
+        out = {
+            "metric": "srn_samples_per_s", "value": evaluated / dt, "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "%s: %dx%d, %d steps/ray, %d-wide x %d-layer fp16 SRN%s, %s, density:direct + Identity TF, "
+                                   "early-out %s" % (args.config, W, H, steps, cfg[0], cfg[1],
+                                                     (" + %d-ch %d^3 latent grid" % cfg[2]) if cfg[2] else " (Fourier-only)",
+                                                     args.activation, "on" if args.early_out else "off"),
+                       "parallelism": "1 GPU" if world == 1 else "%d GPUs, round-robin %d-row stripes + RCCL all-gather" % (world, STRIPE)},
+            "frames_per_s": args.steps / dt,
+            "evaluated_samples_per_frame": evaluated / args.steps,
+            "nominal_samples_per_frame": W * H * steps,
+            "wave_executed_samples_per_frame": executed / args.steps,
+            "kernel": net.kernel_name(True),
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                         "flops_per_sample": info.flops_per_sample, "mfma_flops_per_sample": info.mfma_flops_per_sample,
+                         "kernel_ms_avg": 1e3 * kernel_s},
+        }
+        if twin:
+            out["twin"] = twin
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(util, cfg, args.activation)
+        print(json.dumps(out))
+    if distributed:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

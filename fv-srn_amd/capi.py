@@ -79,6 +79,8 @@ SYMBOLS = [
     ("fvsrn_scene_destroy", None, [_VP]),
     ("fvsrn_camera_on_a_sphere", _I, [_I, _DP, _D, _D, _D, _FP, _FP, _FP]),
     ("fvsrn_render", _I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP]),
+    ("fvsrn_stripe_rows", _I, [_I, _I, _I, _I]),
+    ("fvsrn_render_stripes", _I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     ("fvsrn_network_kernel_name", _I, [_VP, _I, C.c_char_p, _SZ]),
 ]
 
@@ -92,6 +94,13 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise FvsrnError(-6, "libfvsrn.so not found at %s: build it first (python -c 'import __graft_entry__ as g; "
                                  "g.build()'); there is no CPU fallback" % LIB_PATH)
+        # Share ONE HIP runtime with PyTorch: torch ships its own libamdhip64.so.7; if it is loaded first our
+        # library binds to it by SONAME.  (Loaded the other way round the process would hold two HIP/HSA
+        # runtimes and the second one finds no device.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(l, name)
@@ -311,6 +320,24 @@ class Scene:
         _check(lib().fvsrn_render(self._h, net._h, width, height, y0, y1, op, sp,
                                   _current_stream() if stream is None else stream))
         return out
+
+
+def stripe_rows(height: int, stripe: int, rank: int, world: int) -> int:
+    return lib().fvsrn_stripe_rows(height, stripe, rank, world)
+
+
+def render_stripes(scene: Scene, net: Network, width: int, height: int, stripe: int, rank: int, world: int, out=None,
+                   stats=None, stream: Optional[int] = None):
+    """Renders the rows {y : (y // stripe) % world == rank} into a compact (8, local_rows, W) tensor."""
+    import torch
+    rows = stripe_rows(height, stripe, rank, world)
+    if out is None:
+        out = torch.zeros((8, rows, width), dtype=torch.float32, device="cuda")
+    op = _torch_ptr(out, "torch.float32", "out")
+    sp = _torch_ptr(stats, "torch.int64", "stats") if stats is not None else None
+    _check(lib().fvsrn_render_stripes(scene._h, net._h, width, height, stripe, rank, world, op, sp,
+                                      _current_stream() if stream is None else stream))
+    return out
 
 
 def camera_on_a_sphere(orientation: str, center, pitch: float, yaw: float, distance: float):

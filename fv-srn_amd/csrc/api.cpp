@@ -509,8 +509,9 @@ int fvsrn_camera_on_a_sphere(int orientation, const double center[3], double pit
     });
 }
 
-int fvsrn_render(fvsrn_scene* scene, fvsrn_network* net, int width, int height, int y0, int y1, float* d_out8,
-                 unsigned long long* d_stats, void* stream) {
+static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int height, int y0, int y1, int numLocalRows,
+                      int stripeRows, int stripeRank, int stripeWorld, int compact, float* d_out8,
+                      unsigned long long* d_stats, void* stream) {
     return guarded([&] {
         if (!scene || !net || !d_out8) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
         if (width <= 0 || height <= 0 || y0 < 0 || y1 > height || y0 > y1)
@@ -528,7 +529,7 @@ int fvsrn_render(fvsrn_scene* scene, fvsrn_network* net, int width, int height, 
                 return fail(FVSRN_ERR_INVALID_ARGUMENT, "the network outputs colour; the scene must use FVSRN_TF_NONE");
             if (!rgbo && d.tf_kind == FVSRN_TF_NONE)
                 return fail(FVSRN_ERR_INVALID_ARGUMENT, "the network outputs densities; the scene needs a transfer function");
-            if (y0 == y1) return FVSRN_OK;
+            if (numLocalRows == 0) return FVSRN_OK;
 
             const size_t tfFloats = scene->tfTable.size();
             if (scene->tfDirty) {
@@ -560,9 +561,11 @@ int fvsrn_render(fvsrn_scene* scene, fvsrn_network* net, int width, int height, 
             S.tfScaleEmission = d.tf_scale_emission;
             S.tfTable = static_cast<const float*>(scene->dTf.ptr);
             S.width = width; S.height = height; S.y0 = y0; S.y1 = y1;
+            S.numLocalRows = numLocalRows; S.stripeRows = stripeRows; S.stripeRank = stripeRank;
+            S.stripeWorld = stripeWorld; S.compact = compact;
             a.out = d_out8;
             a.stats = d_stats;
-            const int tiles = ((width + 7) / 8) * ((y1 - y0 + 7) / 8);
+            const int tiles = ((width + 7) / 8) * ((numLocalRows + 7) / 8);
             const unsigned grid = unsigned((tiles + 3) / 4);
             const size_t lds = size_t(a.P.ldsBytes) + tfFloats * 4;
             const hipError_t e = launch_render(net->key, a, grid, lds, s);
@@ -572,6 +575,27 @@ int fvsrn_render(fvsrn_scene* scene, fvsrn_network* net, int width, int height, 
             return fail(fvsrn_device_count() == 0 ? FVSRN_ERR_NO_DEVICE : FVSRN_ERR_DEVICE, e.what());
         }
     });
+}
+
+int fvsrn_render(fvsrn_scene* scene, fvsrn_network* net, int width, int height, int y0, int y1, float* d_out8,
+                 unsigned long long* d_stats, void* stream) {
+    return renderImpl(scene, net, width, height, y0, y1, y1 - y0, 8, 0, 1, 0, d_out8, d_stats, stream);
+}
+
+int fvsrn_stripe_rows(int height, int stripe_rows, int rank, int world) {
+    if (height <= 0 || stripe_rows <= 0 || world <= 0 || rank < 0 || rank >= world) return -1;
+    int rows = 0;
+    for (int y = rank * stripe_rows; y < height; y += stripe_rows * world) rows += std::min(stripe_rows, height - y);
+    return rows;
+}
+
+int fvsrn_render_stripes(fvsrn_scene* scene, fvsrn_network* net, int width, int height, int stripe_rows, int rank,
+                         int world, float* d_out_local, unsigned long long* d_stats, void* stream) {
+    if (stripe_rows <= 0 || stripe_rows % 8 != 0 || world <= 0 || rank < 0 || rank >= world)
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "stripe_rows must be a positive multiple of 8 and 0 <= rank < world");
+    // local rows are laid out stripe after stripe; a short last stripe only ever is the LAST local stripe
+    const int rows = fvsrn_stripe_rows(height, stripe_rows, rank, world);
+    return renderImpl(scene, net, width, height, 0, height, rows, stripe_rows, rank, world, 1, d_out_local, d_stats, stream);
 }
 
 }  // extern "C"

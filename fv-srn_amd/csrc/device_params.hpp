@@ -42,8 +42,11 @@ struct SceneParams {
     int tfKind, tfRows;
     float tfScaleAbsorption, tfScaleEmission;
     const float* tfTable;  // device pointer
-    // image
+    // image: the launch covers `numLocalRows` rows; local row l is image row
+    //   y = y0 + ((l / stripeRows) * stripeWorld + stripeRank) * stripeRows + l % stripeRows   (y < y1)
+    // (stripeWorld == 1: the contiguous range [y0,y1)); compact != 0 writes a [8][numLocalRows][width] image
     int width, height, y0, y1;
+    int numLocalRows, stripeRows, stripeRank, stripeWorld, compact;
 };
 
 }  // namespace fvsrn

@@ -136,13 +136,14 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(NetParams P, Scen
 
     const int lane = lane_id();
     const int tilesX = (S.width + 7) >> 3;
-    const int tilesY = (S.y1 - S.y0 + 7) >> 3;
+    const int tilesY = (S.numLocalRows + 7) >> 3;
     const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (tile >= tilesX * tilesY) return;  // whole wave leaves together
     const int tx = tile % tilesX, ty = tile / tilesX;
     const int x = tx * 8 + (lane & 7);
-    const int y = S.y0 + ty * 8 + (lane >> 3);
-    const bool inImage = x < S.width && y < S.y1;
+    const int lrow = ty * 8 + (lane >> 3);
+    const int y = S.y0 + ((lrow / S.stripeRows) * S.stripeWorld + S.stripeRank) * S.stripeRows + lrow % S.stripeRows;
+    const bool inImage = x < S.width && lrow < S.numLocalRows && y < S.y1;
 
     // camera ray (renderer_image_evaluator_simple.cuh:84-88, renderer_camera.cuh:33-52)
     const float ndcx = 2.f * (float(x) + 0.5f) / float(S.width) - 1.f;
@@ -218,8 +219,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_kernel(NetParams P, Scen
     }
 
     if (inImage) {  // renderer_image_evaluator_simple.cuh:100-124 with samples == 1
-        const size_t plane = size_t(S.width) * S.height;
-        const size_t o = size_t(y) * S.width + x;
+        const size_t plane = size_t(S.width) * (S.compact ? S.numLocalRows : S.height);
+        const size_t o = size_t(S.compact ? lrow : y) * S.width + x;
         out[o] = cr;
         out[plane + o] = cg;
         out[2 * plane + o] = cb;

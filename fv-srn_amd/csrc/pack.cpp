@@ -106,8 +106,9 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
         throw Unsupported("hidden width " + std::to_string(C) + " is not in the compiled variant set (32,48,64,96,128)");
     if (c.gridChannels % 16 != 0) throw InvalidNetwork("latent grid channels must be a multiple of 16");
     const int MT = (C + 31) / 32, KS = C / 16, KG = c.gridChannels / 16, KS0 = KS + KG;
-    const int NL = c.numHiddenLayers + 1;  // C->C layers; hidden[0] is the first, hidden[NL] the last
-    if (int(net.hidden.size()) != NL + 1) throw InvalidNetwork("unexpected layer count");
+    // C->C layers: hidden[0] (behind Fourier features, or the latent-grid layer) .. hidden[NL-1]; hidden[NL] is the last
+    const int NL = int(net.hidden.size()) - 1;
+    if (NL != c.numHiddenLayers + (c.gridChannels > 0 ? 1 : 0) || NL < 1) throw InvalidNetwork("unexpected layer count");
     const int Cout = net.outputChannelsIn();
     if (Cout > 4) throw Unsupported("more than 4 network outputs are not in the compiled variant set");
     P.MT = MT; P.KS = KS; P.KS0 = KS0; P.NL = NL;

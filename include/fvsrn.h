@@ -191,6 +191,15 @@ int fvsrn_camera_on_a_sphere(int orientation, const double center[3], double pit
 int fvsrn_render(fvsrn_scene* scene, fvsrn_network* net, int width, int height, int y0, int y1,
                  float* d_out8, unsigned long long* d_stats, void* stream);
 
+/* Multi-GPU row stripes (no reference counterpart): rank r of `world` renders the image rows
+ * y with (y / stripe_rows) % world == r -- round-robin stripes balance empty and dense image regions -- into
+ * a COMPACT planar image d_out_local [8][fvsrn_stripe_rows(...)][width] whose rows are the owned rows in
+ * increasing y.  Equal-sized compact images of all ranks are exchanged by one RCCL all-gather.
+ * stripe_rows must be a multiple of 8 (the pixel tile of one wave). */
+int fvsrn_stripe_rows(int height, int stripe_rows, int rank, int world);
+int fvsrn_render_stripes(fvsrn_scene* scene, fvsrn_network* net, int width, int height, int stripe_rows, int rank,
+                         int world, float* d_out_local, unsigned long long* d_stats, void* stream);
+
 /* Kernel name + resources of the variant fvsrn_render / fvsrn_evaluate_points would launch for
  * this network (for profiles and bench): writes a 0-terminated string. */
 int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t cap);

@@ -214,7 +214,9 @@ def test_full_size_properties_1024x512steps():
     scene.render(net, 1024, 1024, 512, 1024, out=halves)
     torch.cuda.synchronize()
     expected = oracle.OracleScene(**kw).count_samples(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), 1024, 1024)
-    assert int(stats[0]) == expected
+    # 3.4e8 samples: the device's rcp/rsqrt differ from the host's division by an ulp, which moves a
+    # handful of rays across the t <= tmax boundary of their last sample
+    assert abs(int(stats[0]) - expected) <= 1e-6 * expected
     assert torch.equal(torch.nan_to_num(full, nan=-1.0), torch.nan_to_num(halves, nan=-1.0))
     rgba = full[0, :4]
     assert torch.isfinite(rgba).all() and rgba[3].min() >= 0 and rgba[3].max() <= 1.0 + 1e-6

@@ -1,0 +1,72 @@
+"""
+The N > 1 path on CPU: two processes (gloo), round-robin row stripes, all-gather, assembly.
+The stripe images come from the CPU oracle (this is a test of the partition / exchange logic in
+fv-srn_amd/tiles.py, the same code bench.py drives with RCCL).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import util
+from fvsrn_amd import capi, tiles
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, H, W, stripe, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density", seed=5, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4)
+    eye, right, up = oracle.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, 0.7, 1.6)
+    kw = dict(eye=eye, right=right, up=up, fov_y_radians=float(np.deg2rad(45)), stepsize=1 / 16, tf_kind=oracle.TF_IDENTITY,
+              tf_scale_absorption=20.0)
+    net, scene = oracle.OracleNetwork(vn, oracle.ACC_FLOAT), oracle.OracleScene(**kw)
+    rows = tiles.owned_rows(H, stripe, rank, world)
+    assert len(rows) == capi.stripe_rows(H, stripe, rank, world)
+    local = np.zeros((8, len(rows), W), np.float32)
+    for i, y in enumerate(rows):  # each rank computes ONLY the rows it owns
+        img, _ = scene.render(net, W, H, y, y + 1)
+        local[:, i] = img[:, y]
+    gathered = tiles.all_gather_frame(torch.from_numpy(local))
+    frame = tiles.assemble(gathered, H, stripe)
+    full, _ = scene.render(net, W, H)
+    ok = np.array_equal(np.nan_to_num(frame[0].numpy(), nan=-1), np.nan_to_num(full, nan=-1))
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        open(tmp, "w").write(str(int(flag.item())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,stripe,H", [(2, 8, 32), (2, 16, 64)])
+def test_two_rank_stripe_render_and_gather(tmp_path, world, stripe, H):
+    out = str(tmp_path / "ok.txt")
+    mp.spawn(_worker, args=(world, _free_port(), H, 24, stripe, out), nprocs=world, join=True)
+    assert open(out).read() == "1"
+
+
+def test_partition_covers_every_row_exactly_once():
+    for H, stripe, world in [(1024, 16, 8), (1024, 16, 4), (64, 8, 2), (40, 8, 3), (8, 8, 1)]:
+        seen = []
+        for r in range(world):
+            rows = tiles.owned_rows(H, stripe, r, world)
+            assert len(rows) == capi.stripe_rows(H, stripe, r, world)
+            seen += rows
+        assert sorted(seen) == list(range(H))
+    with pytest.raises(ValueError):
+        tiles.check_even_partition(40, 8, 3)
+    with pytest.raises(ValueError):
+        tiles.check_even_partition(64, 12, 2)

@@ -67,6 +67,8 @@ def random_network(*, C=32, layers=4, activation="SnakeAlt", param=1.0, output_m
         k = 1.0 / np.sqrt(dims[i])
         weights.append(rng.uniform(-k, k, (dims[i + 1], dims[i])).astype(np.float32))
         biases.append(rng.uniform(-k, k, dims[i + 1]).astype(np.float32))
+    if cout == 4:  # reference network.py:404-405: positive rgba bias "to see something"
+        biases[-1] = np.abs(biases[-1]) + 1.0
     tg = None
     if grid:
         tg = [(rng.randn(G, grid[1], grid[1], grid[1]) * grid_scale).astype(np.float32) for _ in range(time_grids)]
