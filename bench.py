@@ -159,14 +159,16 @@ def cpu_baseline(util, cfg, activation):
     g = (rng.randn(1, G, grid[1], grid[1], grid[1]) * 0.01).astype(np.float32) if grid else None
     net = torch_port.TorchSRN(B, ws, bs, activation, 1.0, "density:direct", g)
     eye, right, up = capi.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, 0.0, 1.6)
-    cores = os.cpu_count() or 1
-    W = H = 256
-    steps = 128
+    # torch's intra-op pool degrades badly beyond a few dozen threads on these small GEMMs (256 threads: 1.3e4
+    # samples/s, measured r01) -- use at most 32 host threads and say so in "cores"
+    cores = min(os.cpu_count() or 1, 32)
+    W = H = 512
+    steps = 256
     r = torch_port.time_cpu_baseline(net, eye, right, up, float(np.deg2rad(45.0)), (-0.5, -0.5, -0.5), (1, 1, 1), width=W,
-                                     height=H, stepsize=1.0 / steps, tf_identity=(10.0, 1.0), threads=cores, repeats=1)
+                                     height=H, stepsize=1.0 / steps, tf_identity=(10.0, 1.0), threads=cores, budget_s=15.0)
     return {"value": r["value"], "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": "PyTorch-CPU fp32 port of SceneRepresentationNetwork.forward + Raytracing._full_trace_forward, "
-                      "same network/camera, one %dx%d frame at step 1/%d = %d network samples in %.1f s"
+                      "same network/camera, %dx%d rays at step 1/%d, the first %d network samples (%.1f s of the step loop)"
                       % (W, H, steps, r["samples"], r["seconds"])}
 
 

@@ -73,7 +73,7 @@ SYMBOLS = [
     ("fvsrn_network_get_info", _I, [_VP, C.POINTER(NetworkInfo)]),
     ("fvsrn_network_get_layer", _I, [_VP, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _FP, _U16P, _U16P]),
     ("fvsrn_network_get_fourier", _I, [_VP, _U16P, _I, C.POINTER(_I)]),
-    ("fvsrn_evaluate_points", _I, [_VP, _VP, _VP, _SZ, _VP, _VP]),
+    ("fvsrn_evaluate_points", _I, [_VP, _VP, _VP, _SZ, _VP, _I, _VP]),
     ("fvsrn_scene_create", _I, [C.POINTER(SceneDesc), C.POINTER(_VP)]),
     ("fvsrn_scene_update", _I, [_VP, C.POINTER(SceneDesc)]),
     ("fvsrn_scene_destroy", None, [_VP]),
@@ -246,7 +246,8 @@ class Network:
         _check(lib().fvsrn_network_clear_gpu_resources(self._h))
 
     # -- IVolumeInterpolation.evaluate (volume_interpolation.cpp:26-127) ---------------------------------
-    def evaluate(self, positions, directions=None, out=None, stream: Optional[int] = None):
+    def evaluate(self, positions, directions=None, out=None, stream: Optional[int] = None, world: bool = False):
+        """positions: unit-box coordinates like the reference; world=True maps world positions through the box."""
         import torch
         n = positions.shape[0]
         pp = _torch_ptr(positions, "torch.float32", "positions")
@@ -255,7 +256,8 @@ class Network:
         if out is None:
             out = torch.empty((n, oc), dtype=torch.float32, device=positions.device)
         op = _torch_ptr(out, "torch.float32", "out")
-        _check(lib().fvsrn_evaluate_points(self._h, pp, dp, n, op, _current_stream() if stream is None else stream))
+        _check(lib().fvsrn_evaluate_points(self._h, pp, dp, n, op, 1 if world else 0,
+                                           _current_stream() if stream is None else stream))
         return out
 
 

@@ -400,7 +400,7 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
 
 // ------------------------------------------------------------------------------------------- evaluation
 int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const float* d_directions, size_t n,
-                          float* d_out, void* stream) {
+                          float* d_out, int flags, void* stream) {
     return guarded([&] {
         if (!net || (n > 0 && (!d_positions || !d_out))) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
         std::lock_guard<std::mutex> lock(net->mu);
@@ -411,6 +411,8 @@ int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const fl
             if (net->key.dir && !d_directions)
                 return fail(FVSRN_ERR_INVALID_ARGUMENT, "the network uses the view direction, but no directions were given");
             EvalArgs a{net->packed.params, d_positions, d_directions, n, d_out, net->net->outputChannels()};
+            if (!(flags & FVSRN_EVAL_WORLD_POSITIONS))  // volume_interpolation.cpp:46-49: box := [0,1]^3
+                for (int i = 0; i < 3; ++i) { a.P.boxMin[i] = 0.f; a.P.boxSize[i] = 1.f; a.P.invBoxSize[i] = 1.f; }
             const size_t batches = (n + 63) / 64;
             const size_t blocks = (batches + 3) / 4;
             const unsigned grid = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 8));

@@ -19,7 +19,7 @@ __device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* ld
 // EvaluateNoBatches (reference renderer/renderer_volume_kernels1.cuh:15): positions -> network value
 // ------------------------------------------------------------------------------------------------
 template <int CD, int ACT, bool HAS_GRID, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads) void evaluate_kernel(NetParams P, const float* __restrict__ pos,
+__global__ __launch_bounds__(kBlockThreads, 2) void evaluate_kernel(NetParams P, const float* __restrict__ pos,
                                                                  const float* __restrict__ dir, size_t n,
                                                                  float* __restrict__ out, int outChannels) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -122,7 +122,7 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // the reference's __any_sync loop: all 64 lanes evaluate the network until no lane is valid.
 // ------------------------------------------------------------------------------------------------
 template <int CD, int ACT, bool HAS_GRID, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+__global__ __launch_bounds__(kBlockThreads, 2) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     load_network_to_lds(P, lds);

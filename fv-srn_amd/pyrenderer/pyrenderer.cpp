@@ -1,0 +1,910 @@
+// pyrenderer -- pybind11 module mirroring the reference's `pyrenderer` surface for the SRN/DVR hot path.
+//
+// It is a CLIENT of the C ABI (include/fvsrn.h): every class below only holds parameters and forwards to
+// libfvsrn.so; torch tensors are used for device memory and the current stream only.
+// Reference surface: bindings/bindings.cpp:136-283, renderer/module_registry.cpp:37-106,
+// renderer/volume_interpolation_network.cpp:1817-2007, renderer/image_evaluator_simple.cpp:427-475,
+// renderer/iimage_evaluator.cpp:325-358, renderer/ray_evaluation_stepping.cpp:80-93,781-801,
+// renderer/camera.cpp:184-224,375-397, renderer/volume_interpolation.cpp:615-695, renderer/blending.cpp:31-43,
+// renderer/transfer_function*.cpp, renderer/brdf.cpp.
+//
+// Not mirrored (outside the path): GUI hooks (drawUI), OpenGL rasterisation, Monte-Carlo /
+// iso ray evaluators, implicit / grid volumes, importance sampling, compression bindings, interp1D.
+#include <torch/extension.h>
+
+#include <cmath>
+#include <fstream>
+#include <memory>
+#include <optional>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/fvsrn.h"
+
+namespace py = pybind11;
+
+namespace {
+
+[[noreturn]] void raise(const std::string& what) { throw std::runtime_error(what); }
+
+void check(int code) {
+    if (code != FVSRN_OK) {
+        const char* m = fvsrn_last_error();
+        raise(m && *m ? std::string(m) : "fvsrn error " + std::to_string(code));
+    }
+}
+
+void* currentStream() {
+    // plumbing: the HIP stream torch is currently recording on (reference: c10::cuda::getCurrentCUDAStream,
+    // renderer/iimage_evaluator.cpp:167-170)
+    py::object s = py::module_::import("torch").attr("cuda").attr("current_stream")();
+    return reinterpret_cast<void*>(s.attr("cuda_stream").cast<uintptr_t>());
+}
+
+// ------------------------------------------------------------------------------------------- value types
+template <class T> struct V2 { T x{}, y{}; };
+template <class T> struct V3 { T x{}, y{}, z{}; };
+template <class T> struct V4 { T x{}, y{}, z{}, w{}; };
+using float3 = V3<float>; using double3 = V3<double>; using int3 = V3<int>;
+using float4 = V4<float>; using double4 = V4<double>; using int2 = V2<int>;
+
+template <class T> void bindV3(py::module_& m, const char* name) {
+    using V = V3<T>;
+    py::class_<V>(m, name)
+        .def(py::init<>())
+        .def(py::init([](T x, T y, T z) { return V{x, y, z}; }))
+        .def_readwrite("x", &V::x).def_readwrite("y", &V::y).def_readwrite("z", &V::z)
+        .def("__str__", [](const V& v) { std::ostringstream s; s << "(" << v.x << ", " << v.y << ", " << v.z << ")"; return s.str(); })
+        .def("__add__", [](const V& a, const V& b) { return V{T(a.x + b.x), T(a.y + b.y), T(a.z + b.z)}; })
+        .def("__sub__", [](const V& a, const V& b) { return V{T(a.x - b.x), T(a.y - b.y), T(a.z - b.z)}; })
+        .def("__mul__", [](const V& a, T s) { return V{T(a.x * s), T(a.y * s), T(a.z * s)}; })
+        .def("__rmul__", [](const V& a, T s) { return V{T(a.x * s), T(a.y * s), T(a.z * s)}; });
+}
+template <class T> void bindV4(py::module_& m, const char* name) {
+    using V = V4<T>;
+    py::class_<V>(m, name)
+        .def(py::init<>())
+        .def(py::init([](T x, T y, T z, T w) { return V{x, y, z, w}; }))
+        .def_readwrite("x", &V::x).def_readwrite("y", &V::y).def_readwrite("z", &V::z).def_readwrite("w", &V::w)
+        .def("__str__", [](const V& v) { std::ostringstream s; s << "(" << v.x << ", " << v.y << ", " << v.z << ", " << v.w << ")"; return s.str(); });
+}
+
+// Parameter_<T> (renderer/module_registry.cpp:42-67): scalar value only; tensors / gradients are a training feature
+template <class T> struct Parameter {
+    T value{};
+    bool supportsGradients = false;
+};
+template <class T> void bindParameter(py::module_& m, const char* name) {
+    py::class_<Parameter<T>, std::shared_ptr<Parameter<T>>>(m, name)
+        .def_readwrite("value", &Parameter<T>::value)
+        .def_readonly("supports_gradients", &Parameter<T>::supportsGradients);
+}
+
+// GPUTimer (bindings/bindings.cpp:101-131): an event pair on the current stream
+struct GPUTimer {
+    py::object e0, e1;
+    GPUTimer() {
+        py::object ev = py::module_::import("torch").attr("cuda").attr("Event");
+        e0 = ev(py::arg("enable_timing") = true);
+        e1 = ev(py::arg("enable_timing") = true);
+    }
+    void start() { e0.attr("record")(); }
+    void stop() { e1.attr("record")(); }
+    float elapsed() { e1.attr("synchronize")(); return e0.attr("elapsed_time")(e1).cast<float>(); }
+};
+
+// --------------------------------------------------------------------------------------------- SceneNetwork
+struct SceneNetwork;
+
+struct InputParametrization {
+    bool hasTime = false, hasDirection = false;
+    int numFourier = 0;
+    bool useDirInFourier = false;
+    std::vector<float> fourier;  // row-major (F, cols), already premultiplied as given
+    bool premultiplied = true;
+    std::weak_ptr<SceneNetwork> owner;
+    void push();
+    int channelsOut() const {
+        return numFourier > 0 ? 4 + (hasDirection ? 4 : 0) + 2 * numFourier : 3 + (hasDirection ? 3 : 0);
+    }
+};
+
+struct OutputParametrization {
+    fvsrn_output_mode mode = FVSRN_OUT_DENSITY;
+    std::weak_ptr<SceneNetwork> owner;
+    void push();
+};
+
+struct Layer {  // read-only view of a stored layer
+    int channelsIn = 0, channelsOut = 0;
+    fvsrn_activation activation = FVSRN_ACT_NONE;
+    float activationParameter = 1.f;
+};
+
+struct LatentGrid {
+    fvsrn_grid_encoding encoding = FVSRN_GRID_FLOAT;
+    int gridChannels = 0, gridSizeZ = 0, gridSizeY = 0, gridSizeX = 0;
+    std::vector<float> values;  // (C,Z,Y,X) fp32 as given
+    bool isValid() const { return gridChannels > 0 && gridChannels % 16 == 0 && gridSizeX > 0 && gridSizeY > 0 && gridSizeZ > 0; }
+    static std::shared_ptr<LatentGrid> fromTensor(const torch::Tensor& t_, fvsrn_grid_encoding enc) {
+        TORCH_CHECK(t_.dim() == 5 && t_.size(0) == 1, "latent grid tensor must be of shape (1,C,Z,Y,X)");
+        torch::Tensor t = t_.detach().to(c10::kCPU, c10::kFloat).contiguous();
+        auto g = std::make_shared<LatentGrid>();
+        g->encoding = enc;
+        g->gridChannels = int(t.size(1)); g->gridSizeZ = int(t.size(2)); g->gridSizeY = int(t.size(3)); g->gridSizeX = int(t.size(4));
+        g->values.assign(t.data_ptr<float>(), t.data_ptr<float>() + t.numel());
+        return g;
+    }
+};
+
+struct LatentGridTimeAndEnsemble {
+    int timeMin = 0, timeNum = 0, timeStep = 1, ensembleMin = 0, ensembleNum = 0;
+    std::vector<std::shared_ptr<LatentGrid>> timeGrids, ensembleGrids;
+    fvsrn_network* scratch = nullptr;  // holds the encoded grids so encoding errors can be reported at set time
+    LatentGridTimeAndEnsemble() = default;
+    LatentGridTimeAndEnsemble(int tmin, int tnum, int tstep, int emin, int enumm)
+        : timeMin(tmin), timeNum(tnum), timeStep(tstep), ensembleMin(emin), ensembleNum(enumm),
+          timeGrids(size_t(tnum)), ensembleGrids(size_t(enumm)) {
+        check(fvsrn_network_create(&scratch));
+        check(fvsrn_network_set_latent_grid_layout(scratch, tmin, tnum, tstep, emin, enumm));
+    }
+    ~LatentGridTimeAndEnsemble() { fvsrn_network_destroy(scratch); }
+    LatentGridTimeAndEnsemble(const LatentGridTimeAndEnsemble&) = delete;
+    int timeMaxInclusive() const { return timeMin + (timeNum - 1) * timeStep; }
+    int ensembleMaxInclusive() const { return ensembleMin + ensembleNum - 1; }
+    float interpolateTime(float t) const { return std::min(std::max((t - timeMin) / float(timeStep), 0.f), float(timeNum - 1)); }
+    int interpolateEnsemble(int e) const { return std::min(std::max(e - ensembleMin, 0), ensembleNum - 1); }
+    double setGrid(bool ensemble, int index, const torch::Tensor& t, fvsrn_grid_encoding enc) {
+        auto& list = ensemble ? ensembleGrids : timeGrids;
+        TORCH_CHECK(index >= 0 && size_t(index) < list.size(), "index out of bounds!");
+        list[size_t(index)] = LatentGrid::fromTensor(t, enc);
+        const LatentGrid& g = *list[size_t(index)];
+        double err = 0;
+        if (!scratch) {
+            check(fvsrn_network_create(&scratch));
+            check(fvsrn_network_set_latent_grid_layout(scratch, timeMin, timeNum, timeStep, ensembleMin, ensembleNum));
+        }
+        check(fvsrn_network_set_latent_grid(scratch, ensemble, index, g.values.data(), g.gridChannels, g.gridSizeZ,
+                                            g.gridSizeY, g.gridSizeX, enc, &err));
+        return err;
+    }
+    bool isValid() const {
+        if (timeGrids.empty() && ensembleGrids.empty()) return false;
+        for (auto* l : {&timeGrids, &ensembleGrids})
+            for (auto& g : *l)
+                if (!g || !g->isValid()) return false;
+        return true;
+    }
+    fvsrn_grid_encoding commonEncoding() const {
+        if (!timeGrids.empty() && timeGrids[0]) return timeGrids[0]->encoding;
+        if (!ensembleGrids.empty() && ensembleGrids[0]) return ensembleGrids[0]->encoding;
+        raise("at least one grid must be active!");
+    }
+    int timeChannels() const { return timeGrids.empty() || !timeGrids[0] ? 0 : timeGrids[0]->gridChannels; }
+    int ensembleChannels() const { return ensembleGrids.empty() || !ensembleGrids[0] ? 0 : ensembleGrids[0]->gridChannels; }
+};
+
+struct SceneNetwork : std::enable_shared_from_this<SceneNetwork> {
+    fvsrn_network* h = nullptr;
+    std::shared_ptr<InputParametrization> input = std::make_shared<InputParametrization>();
+    std::shared_ptr<OutputParametrization> output = std::make_shared<OutputParametrization>();
+    std::shared_ptr<LatentGridTimeAndEnsemble> latentGrid;
+    float3 boxMin{-5.f, -5.f, -5.f}, boxSize{1.f, 1.f, 1.f};  // volume_interpolation_network.cpp:799-800
+
+    SceneNetwork() { check(fvsrn_network_create(&h)); }
+    ~SceneNetwork() { fvsrn_network_destroy(h); }
+    SceneNetwork(const SceneNetwork&) = delete;
+    void link() { input->owner = weak_from_this(); output->owner = weak_from_this(); }
+
+    static std::shared_ptr<SceneNetwork> create() {
+        auto n = std::make_shared<SceneNetwork>();
+        n->link();
+        return n;
+    }
+
+    static std::shared_ptr<SceneNetwork> load(const std::string& filename) {
+        std::ifstream in(filename, std::ifstream::binary);
+        if (!in.is_open()) raise("Unable to open the file " + filename);
+        std::vector<char> bytes((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        auto n = std::make_shared<SceneNetwork>();
+        fvsrn_network_destroy(n->h);
+        n->h = nullptr;
+        check(fvsrn_network_create_from_volnet(bytes.data(), bytes.size(), &n->h));
+        n->link();
+        n->pullFromHandle();
+        return n;
+    }
+
+    void pullFromHandle() {  // mirror the handle's state into the Python-visible objects
+        fvsrn_network_info i;
+        check(fvsrn_network_get_info(h, &i));
+        input->hasTime = i.has_time; input->hasDirection = i.has_direction; input->numFourier = i.num_fourier;
+        input->useDirInFourier = i.use_direction_in_fourier;
+        output->mode = fvsrn_output_mode(i.output_mode);
+        boxMin = {i.box_min[0], i.box_min[1], i.box_min[2]};
+        boxSize = {i.box_size[0], i.box_size[1], i.box_size[2]};
+        if (i.grid_channels > 0) {
+            latentGrid = std::make_shared<LatentGridTimeAndEnsemble>();
+            latentGrid->timeNum = i.time_num; latentGrid->ensembleNum = i.ensemble_num;
+        }
+        loadedFromFile = true;
+    }
+    bool loadedFromFile = false;
+
+    void save(const std::string& filename) const {
+        size_t n = 0;
+        check(fvsrn_network_save_volnet(h, nullptr, 0, &n));
+        std::vector<char> buf(n);
+        check(fvsrn_network_save_volnet(h, buf.data(), n, &n));
+        std::ofstream out(filename, std::ofstream::binary);
+        if (!out.is_open()) raise("Unable to open the file " + filename);
+        out.write(buf.data(), std::streamsize(n));
+    }
+
+    void addLayer(const torch::Tensor& weights, const torch::Tensor& bias, fvsrn_activation act, float param) {
+        TORCH_CHECK(weights.dim() == 2, "weights must be (out,in)");
+        TORCH_CHECK(bias.dim() == 1 && bias.size(0) == weights.size(0), "bias must be (out)");
+        torch::Tensor w = weights.detach().to(c10::kCPU, c10::kFloat).contiguous();
+        torch::Tensor b = bias.detach().to(c10::kCPU, c10::kFloat).contiguous();
+        check(fvsrn_network_add_layer(h, w.data_ptr<float>(), b.data_ptr<float>(), int(w.size(0)), int(w.size(1)), act, param));
+    }
+    int numLayers() const {
+        fvsrn_network_info i;
+        check(fvsrn_network_get_info(h, &i));
+        return i.num_layers;
+    }
+    std::shared_ptr<Layer> getLayer(int index) const {
+        auto l = std::make_shared<Layer>();
+        int act = 0;
+        check(fvsrn_network_get_layer(h, index, &l->channelsOut, &l->channelsIn, &act, &l->activationParameter, nullptr, nullptr));
+        l->activation = fvsrn_activation(act);
+        return l;
+    }
+    void setBox(float3 mn, float3 sz) {
+        boxMin = mn; boxSize = sz;
+        const float a[3] = {mn.x, mn.y, mn.z}, b[3] = {sz.x, sz.y, sz.z};
+        check(fvsrn_network_set_box(h, a, b));
+    }
+    void setLatentGrid(std::shared_ptr<LatentGridTimeAndEnsemble> g) {
+        latentGrid = std::move(g);
+        if (!latentGrid) return;
+        check(fvsrn_network_set_latent_grid_layout(h, latentGrid->timeMin, latentGrid->timeNum, latentGrid->timeStep,
+                                                   latentGrid->ensembleMin, latentGrid->ensembleNum));
+        for (int e = 0; e < 2; ++e) {
+            auto& list = e ? latentGrid->ensembleGrids : latentGrid->timeGrids;
+            for (size_t i = 0; i < list.size(); ++i) {
+                if (!list[i]) continue;
+                const LatentGrid& lg = *list[i];
+                check(fvsrn_network_set_latent_grid(h, e, int(i), lg.values.data(), lg.gridChannels, lg.gridSizeZ, lg.gridSizeY,
+                                                    lg.gridSizeX, lg.encoding, nullptr));
+            }
+        }
+    }
+    bool valid() const {
+        const bool ok = fvsrn_network_valid(h) == 1;
+        if (!ok) py::print(fvsrn_last_error(), py::arg("file") = py::module_::import("sys").attr("stderr"));
+        return ok;
+    }
+    fvsrn_network_info info() const {
+        fvsrn_network_info i;
+        check(fvsrn_network_get_info(h, &i));
+        return i;
+    }
+};
+
+void InputParametrization::push() {
+    if (auto n = owner.lock())
+        check(fvsrn_network_set_input(n->h, hasTime, hasDirection, fourier.empty() ? nullptr : fourier.data(), numFourier,
+                                      useDirInFourier ? 6 : 3, premultiplied));
+}
+void OutputParametrization::push() {
+    if (auto n = owner.lock()) check(fvsrn_network_set_output_mode(n->h, mode));
+}
+
+// ------------------------------------------------------------------------------------- volume interpolation
+struct IVolumeInterpolation {
+    virtual ~IVolumeInterpolation() = default;
+    double3 boxMin_{-0.5, -0.5, -0.5}, boxMax_{0.5, 0.5, 0.5};
+    virtual void setBoxMin(double3 v) { boxMin_ = v; }
+    virtual void setBoxMax(double3 v) { boxMax_ = v; }
+    double3 boxSize() const { return {boxMax_.x - boxMin_.x, boxMax_.y - boxMin_.y, boxMax_.z - boxMin_.z}; }
+    virtual int outputChannels() const = 0;
+    virtual torch::Tensor evaluate(const torch::Tensor& positions, const std::optional<torch::Tensor>& direction) = 0;
+};
+
+enum GradientMode { OFF_OR_DIRECT = 0, FINITE_DIFFERENCES = 1, ADJOINT_METHOD = 2 };
+enum Orientation { Xp = 0, Xm = 1, Yp = 2, Ym = 3, Zp = 4, Zm = 5 };
+
+struct VolumeInterpolationNetwork : IVolumeInterpolation {
+    std::shared_ptr<SceneNetwork> net;
+    bool onlySharedMemory = false;
+    GradientMode gradientMode = OFF_OR_DIRECT;
+    float finiteDifferencesStepsize = 1 / 256.f;
+    float adjointScale = 4;
+
+    void setNetwork(std::shared_ptr<SceneNetwork> n) {  // :1481-1485 + selectNetwork :1448-1472
+        if (!n) raise("network is None");
+        net = std::move(n);
+        const fvsrn_network_info i = net->info();
+        boxMin_ = {i.box_min[0], i.box_min[1], i.box_min[2]};
+        boxMax_ = {double(i.box_min[0]) + i.box_size[0], double(i.box_min[1]) + i.box_size[1], double(i.box_min[2]) + i.box_size[2]};
+    }
+    std::shared_ptr<SceneNetwork> currentNetwork() const {
+        if (!net) raise("No network loaded");
+        return net;
+    }
+    void pushBox() {  // :1500-1520
+        if (!net) return;
+        const double3 s = boxSize();
+        net->setBox({float(boxMin_.x), float(boxMin_.y), float(boxMin_.z)}, {float(s.x), float(s.y), float(s.z)});
+    }
+    void setBoxMin(double3 v) override { boxMin_ = v; pushBox(); }
+    void setBoxMax(double3 v) override { boxMax_ = v; pushBox(); }
+    int outputChannels() const override { return currentNetwork()->info().output_channels; }
+    void setTimeAndEnsemble(float t, int e) { check(fvsrn_network_set_time_and_ensemble(currentNetwork()->h, t, e)); }
+
+    torch::Tensor evaluate(const torch::Tensor& positions, const std::optional<torch::Tensor>& direction) override {
+        // IVolumeInterpolation::evaluate, renderer/volume_interpolation.cpp:26-127
+        TORCH_CHECK(positions.is_cuda(), "positions must reside on the GPU");
+        TORCH_CHECK(positions.dim() == 2 && positions.size(1) == 3, "positions must be of shape (N,3)");
+        torch::Tensor p = positions.to(c10::kFloat).contiguous();
+        torch::Tensor d;
+        if (direction.has_value() && direction->defined()) {
+            TORCH_CHECK(direction->is_cuda() && direction->dim() == 2 && direction->size(1) == 3, "direction must be a CUDA tensor of shape (N,3)");
+            d = direction->to(c10::kFloat).contiguous();
+        }
+        const int channels = outputChannels();
+        torch::Tensor out = torch::empty({p.size(0), channels}, p.options());
+        check(fvsrn_evaluate_points(currentNetwork()->h, p.data_ptr<float>(), d.defined() ? d.data_ptr<float>() : nullptr,
+                                    size_t(p.size(0)), out.data_ptr<float>(), 0, currentStream()));
+        return out.to(positions.scalar_type());
+    }
+};
+
+// ----------------------------------------------------------------------------------------------- TF / BRDF
+struct ITransferFunction {
+    virtual ~ITransferFunction() = default;
+    virtual void fill(fvsrn_scene_desc& d, std::vector<float>& table) const = 0;
+};
+struct TransferFunctionIdentity : ITransferFunction {
+    // transfer_function_identity.cpp:34-38: absorption_emission = (scaleAbsorption, scaleEmission)
+    std::shared_ptr<Parameter<V2<double>>> absorptionEmission = std::make_shared<Parameter<V2<double>>>();
+    TransferFunctionIdentity() { absorptionEmission->value = {1.0, 1.0}; }
+    void fill(fvsrn_scene_desc& d, std::vector<float>&) const override {
+        d.tf_kind = FVSRN_TF_IDENTITY;
+        d.tf_scale_absorption = float(absorptionEmission->value.x);
+        d.tf_scale_emission = float(absorptionEmission->value.y);
+    }
+};
+struct TableTF : ITransferFunction {
+    torch::Tensor tensor;  // (1,R,cols) like the reference's textureTensor_
+    int kind, cols;
+    TableTF(int k, int c) : kind(k), cols(c) {}
+    void setTensor(const torch::Tensor& t) {
+        TORCH_CHECK(t.dim() == 3 && t.size(0) == 1 && t.size(2) == cols, "TF tensor must be of shape (1,R,", cols, ")");
+        tensor = t.detach().to(c10::kCPU, c10::kFloat).contiguous();
+    }
+    void fill(fvsrn_scene_desc& d, std::vector<float>& table) const override {
+        if (!tensor.defined()) raise("the transfer function has no control points");
+        d.tf_kind = kind;
+        d.tf_rows = int(tensor.size(1));
+        table.assign(tensor.data_ptr<float>(), tensor.data_ptr<float>() + tensor.numel());
+    }
+};
+struct TransferFunctionGaussian : TableTF { TransferFunctionGaussian() : TableTF(FVSRN_TF_GAUSSIAN, 6) {} };
+struct TransferFunctionPiecewise : TableTF { TransferFunctionPiecewise() : TableTF(FVSRN_TF_PIECEWISE, 5) {} };
+struct TransferFunctionTexture : TableTF { TransferFunctionTexture() : TableTF(FVSRN_TF_TEXTURE, 4) {} };
+
+struct BRDFLambert {  // renderer/brdf.cpp:208-225: only the pass-through configuration is on the compiled path
+    bool enableMagnitudeScaling = false, enablePhong = false;
+};
+
+struct Blending {
+    int blendMode = FVSRN_BLEND_BEER_LAMBERT;  // blending.h:54 default
+};
+
+// ---------------------------------------------------------------------------------------------- ray evaluator
+struct IRayEvaluation { virtual ~IRayEvaluation() = default; };
+struct RayEvaluationSteppingDvr : IRayEvaluation {
+    double stepsize = 0.005;
+    double minDensity = 0.0, maxDensity = 1.0;
+    bool enableEarlyOut = true;
+    std::shared_ptr<Blending> blending = std::make_shared<Blending>();
+    std::shared_ptr<ITransferFunction> tf = std::make_shared<TransferFunctionIdentity>();
+    std::shared_ptr<BRDFLambert> brdf = std::make_shared<BRDFLambert>();
+};
+
+// ----------------------------------------------------------------------------------------------------- camera
+struct ICamera {
+    virtual ~ICamera() = default;
+    double aspectRatio = 1.0;
+    virtual void frame(float eye[3], float right[3], float up[3]) = 0;
+    double fovYRadians = 45.0 * 3.14159265358979323846 / 180.0;
+};
+struct CameraOnASphere : ICamera {
+    int orientation = 3;  // Ym, camera.cpp:225-233
+    std::shared_ptr<Parameter<double3>> center = std::make_shared<Parameter<double3>>();
+    std::shared_ptr<Parameter<double3>> pitchYawDistance = std::make_shared<Parameter<double3>>();
+    torch::Tensor external;  // (B,3,3) from set_parameters
+    CameraOnASphere() { pitchYawDistance->value = {0, 0, 1}; }
+    void frame(float eye[3], float right[3], float up[3]) override {
+        if (external.defined() && external.numel() > 0) {
+            TORCH_CHECK(external.size(0) == 1, "batched cameras are not supported (the reference throws here as well, camera.cpp:519)");
+            torch::Tensor m = external.to(c10::kCPU, c10::kFloat).contiguous();
+            const float* p = m.data_ptr<float>();
+            for (int i = 0; i < 3; ++i) { eye[i] = p[i]; right[i] = p[3 + i]; up[i] = p[6 + i]; }
+            return;
+        }
+        const double c[3] = {center->value.x, center->value.y, center->value.z};
+        check(fvsrn_camera_on_a_sphere(orientation, c, pitchYawDistance->value.x, pitchYawDistance->value.y,
+                                       pitchYawDistance->value.z, eye, right, up));
+    }
+    torch::Tensor getParameters() {
+        float e[3], r[3], u[3];
+        frame(e, r, u);
+        torch::Tensor m = torch::empty({1, 3, 3}, torch::kFloat);
+        float* p = m.data_ptr<float>();
+        for (int i = 0; i < 3; ++i) { p[i] = e[i]; p[3 + i] = r[i]; p[6 + i] = u[i]; }
+        return m.to(torch::kCUDA);
+    }
+    void setParameters(const torch::Tensor& t) {
+        if (!t.defined() || t.numel() == 0) { external = torch::Tensor(); return; }
+        TORCH_CHECK(t.dim() == 3 && t.size(1) == 3 && t.size(2) == 3, "camera matrix must be of shape B,3,3, but is of shape", t.sizes());
+        external = t;
+    }
+    double3 getOrigin(int batch) {
+        TORCH_CHECK(batch == 0, "getOrigin is only available for batch=0 (for now)");
+        float e[3], r[3], u[3];
+        frame(e, r, u);
+        return {e[0], e[1], e[2]};
+    }
+    double3 getFront(int batch) {
+        TORCH_CHECK(batch == 0, "getFront is only available for batch=0 (for now)");
+        float e[3], r[3], u[3];
+        frame(e, r, u);
+        return {double(u[1] * r[2] - u[2] * r[1]), double(u[2] * r[0] - u[0] * r[2]), double(u[0] * r[1] - u[1] * r[0])};
+    }
+};
+
+// -------------------------------------------------------------------------------------------- image evaluator
+enum ChannelMode { ChannelMask = 0, ChannelNormal = 1, ChannelDepth = 2, ChannelColor = 3 };
+
+struct ImageEvaluatorSimple {
+    std::shared_ptr<ICamera> camera = std::make_shared<CameraOnASphere>();
+    std::shared_ptr<IRayEvaluation> rayEvaluator = std::make_shared<RayEvaluationSteppingDvr>();
+    std::shared_ptr<IVolumeInterpolation> volume;
+    ChannelMode selectedChannel = ChannelColor;
+    bool doublePrecision = false;
+    int sppLog2 = 0;
+    bool useTonemapping = false;
+    float tonemappingShoulder = 1.0f, lastMaxExposure = 1.0f, fixedMaxExposure = 1.0f;
+    bool fixMaxExposure = false;
+    fvsrn_scene* scene = nullptr;
+    ~ImageEvaluatorSimple() { fvsrn_scene_destroy(scene); }
+
+    torch::Tensor render(int width, int height) {  // image_evaluator_simple.cpp:198-361
+        auto vol = std::dynamic_pointer_cast<VolumeInterpolationNetwork>(volume);
+        if (!vol) raise("ImageEvaluatorSimple.volume must be a VolumeInterpolationNetwork (the SRN path is the only volume of this build)");
+        auto dvr = std::dynamic_pointer_cast<RayEvaluationSteppingDvr>(rayEvaluator);
+        if (!dvr) raise("ImageEvaluatorSimple.ray_evaluator must be a RayEvaluationSteppingDvr");
+        if (!camera) raise("no camera selected");
+        if (doublePrecision) raise("double precision rendering is not supported by the SRN path");
+        if (dvr->brdf && (dvr->brdf->enablePhong || dvr->brdf->enableMagnitudeScaling))
+            raise("BRDFLambert with Phong shading / magnitude scaling is not in the compiled variant set");
+        camera->aspectRatio = double(width) / height;
+        fvsrn_scene_desc d{};
+        std::vector<float> table;
+        camera->frame(d.cam_eye, d.cam_right, d.cam_up);
+        d.fov_y_radians = float(camera->fovYRadians);
+        d.stepsize = float(dvr->stepsize);
+        d.density_min = float(dvr->minDensity);
+        d.density_max = float(dvr->maxDensity);
+        d.early_out = dvr->enableEarlyOut;
+        d.blend_mode = dvr->blending ? dvr->blending->blendMode : FVSRN_BLEND_BEER_LAMBERT;
+        const fvsrn_network_info info = vol->currentNetwork()->info();
+        const bool rgbo = info.output_mode == FVSRN_OUT_RGBO || info.output_mode == FVSRN_OUT_RGBO_DIRECT;
+        if (rgbo) {
+            d.tf_kind = FVSRN_TF_NONE;  // ray_evaluation_stepping.cpp:560-601: colour volumes skip the TF
+        } else {
+            if (!dvr->tf) raise("no transfer function selected");
+            dvr->tf->fill(d, table);
+        }
+        d.tf_table = table.empty() ? nullptr : table.data();
+        if (!scene) check(fvsrn_scene_create(&d, &scene));
+        else check(fvsrn_scene_update(scene, &d));
+        torch::Tensor out = torch::empty({1, 8, height, width}, torch::TensorOptions().dtype(torch::kFloat).device(torch::kCUDA));
+        check(fvsrn_render(scene, vol->currentNetwork()->h, width, height, 0, height, out.data_ptr<float>(), nullptr, currentStream()));
+        lastRender = out;
+        exposureStale = true;
+        return out;
+    }
+    torch::Tensor lastRender;
+    bool exposureStale = false;
+    float exposure() {
+        // the reference ends render() with a blocking max().item() (image_evaluator_simple.cpp:358); here the
+        // device->host sync is deferred until the value is actually needed
+        if (exposureStale && lastRender.defined()) {
+            lastMaxExposure = lastRender.slice(1, 0, 3).max().item<float>();
+            exposureStale = false;
+        }
+        if (fixMaxExposure) return std::fmax(0.001f, fixedMaxExposure * tonemappingShoulder);
+        return std::fmax(0.001f, lastMaxExposure * tonemappingShoulder);
+    }
+
+    // IImageEvaluator::ExtractColor (renderer/iimage_evaluator.cpp:26-135, kernels iimage_evaluator_cuda.cu:82-101,
+    // 168-262) expressed with tensor ops on the device the input lives on.
+    static torch::Tensor extractColorStatic(const torch::Tensor& raw, bool tonemap, float maxExposure, ChannelMode channel) {
+        TORCH_CHECK(raw.dim() == 4 && raw.size(1) == 8, "raw input must be of shape (B,8,H,W)");
+        auto ch = [&](int c) { return raw.select(1, c); };
+        switch (channel) {
+            case ChannelColor: {
+                if (!tonemap) return raw.slice(1, 0, 4).clone();
+                torch::Tensor rgb = raw.slice(1, 0, 3) / maxExposure;  // ACES filmic curve + gamma
+                rgb = (rgb * (2.51f * rgb + 0.03f)) / (rgb * (2.43f * rgb + 0.59f) + 0.14f);
+                rgb = rgb.clamp(0, 1).pow(1.0f / 2.4f);
+                return torch::cat({rgb, raw.slice(1, 3, 4)}, 1);
+            }
+            case ChannelDepth: {
+                const float mn = ch(7).min().item<float>(), mx = ch(7).max().item<float>();
+                torch::Tensor v = ch(7) * (1 / (mx - mn)) + (-mn / (mx - mn));
+                return torch::stack({v, v, v, torch::ones_like(v)}, 1);
+            }
+            case ChannelMask: {
+                torch::Tensor a = ch(3);
+                return torch::stack({a, a, a, torch::ones_like(a)}, 1);
+            }
+            case ChannelNormal:
+                return torch::cat({raw.slice(1, 4, 7) * 0.5f + 0.5f, raw.slice(1, 3, 4)}, 1);
+        }
+        raise("unknown channel");
+    }
+};
+
+// -------------------------------------------------------------------------------------------- JSON scene files
+// ModuleRegistry::loadTree (renderer/module_registry.cpp:288-305) for the modules of this path; the JSON is parsed
+// by Python's json module (plumbing) and walked here.
+template <class T> T jget(const py::dict& d, const char* key, T def) {
+    if (!d.contains(key)) return def;
+    return d[key].cast<T>();
+}
+py::dict jsub(const py::dict& root, const std::string& tag, const std::string& name) {
+    if (!root.contains(tag.c_str())) raise("scene file has no section '" + tag + "'");
+    py::dict sec = root[tag.c_str()].cast<py::dict>();
+    if (!sec.contains(name.c_str())) raise("scene file has no module '" + tag + "/" + name + "'");
+    return sec[name.c_str()].cast<py::dict>();
+}
+
+std::shared_ptr<ImageEvaluatorSimple> loadFromJson(const std::string& filename) {
+    py::object json = py::module_::import("json");
+    py::object io = py::module_::import("io");
+    py::dict root = json.attr("load")(io.attr("open")(filename, "r")).cast<py::dict>();
+    const std::string rootName = jget<std::string>(root, "root", "Simple");
+    if (rootName != "Simple") raise("only the 'Simple' image evaluator is supported, the scene file selects '" + rootName + "'");
+    py::dict je = jsub(root, "ImageEvaluator", "Simple");
+    auto ev = std::make_shared<ImageEvaluatorSimple>();
+    ev->sppLog2 = jget<int>(je, "samplesPerIterationLog2", 0);
+    ev->useTonemapping = jget<bool>(je, "useTonemapping", false);
+    ev->tonemappingShoulder = jget<float>(je, "tonemappingShoulder", 1.f);
+    ev->fixMaxExposure = jget<bool>(je, "fixMaxExposure", false);
+    ev->fixedMaxExposure = jget<float>(je, "fixedMaxExposure", 1.f);
+    // camera (camera.cpp:349-362)
+    {
+        const std::string sel = jget<std::string>(je, "selectedCamera", "Sphere");
+        if (sel != "Sphere") raise("camera '" + sel + "' is not supported (only 'Sphere')");
+        py::dict jc = jsub(root, "camera", "Sphere");
+        auto cam = std::make_shared<CameraOnASphere>();
+        static const char* names[6] = {"Xp", "Xm", "Yp", "Ym", "Zp", "Zm"};
+        const std::string o = jget<std::string>(jc, "orientation", "Ym");
+        cam->orientation = -1;
+        for (int i = 0; i < 6; ++i)
+            if (o == names[i]) cam->orientation = i;
+        if (cam->orientation < 0) raise("unknown camera orientation " + o);
+        if (jc.contains("center")) {
+            auto c = jc["center"].cast<std::vector<double>>();
+            cam->center->value = {c.at(0), c.at(1), c.at(2)};
+        }
+        cam->pitchYawDistance->value = {jget<double>(jc, "pitch", 0.0), jget<double>(jc, "yaw", 0.0), jget<double>(jc, "distance", 1.0)};
+        cam->fovYRadians = jget<double>(jc, "fovY", cam->fovYRadians);
+        ev->camera = cam;
+    }
+    // ray evaluator (ray_evaluation_stepping.cpp:62-72,740-755)
+    {
+        const std::string sel = jget<std::string>(je, "selectedRayEvaluator", "DVR");
+        if (sel != "DVR") raise("ray evaluator '" + sel + "' is not supported (only 'DVR')");
+        py::dict jr = jsub(root, "RayEvaluation", "DVR");
+        auto dvr = std::make_shared<RayEvaluationSteppingDvr>();
+        double step = jget<double>(jr, "stepsize", 0.005);
+        if (jget<bool>(jr, "stepsizeIsObjectSpace", false)) step /= 256.0;
+        dvr->stepsize = step;
+        dvr->minDensity = jget<double>(jr, "minDensity", 0.0);
+        dvr->maxDensity = jget<double>(jr, "maxDensity", 1.0);
+        dvr->enableEarlyOut = jget<bool>(jr, "earlyOut", true);
+        if (root.contains("blending")) {
+            py::dict jb = jsub(root, "blending", "blending");
+            dvr->blending->blendMode = jget<std::string>(jb, "blending", "BeerLambert") == "Alpha" ? FVSRN_BLEND_ALPHA : FVSRN_BLEND_BEER_LAMBERT;
+        }
+        if (root.contains("brdf") && root["brdf"].cast<py::dict>().contains("Lambert")) {
+            py::dict jl = jsub(root, "brdf", "Lambert");
+            dvr->brdf->enablePhong = jget<bool>(jl, "enablePhong", false);
+            dvr->brdf->enableMagnitudeScaling = jget<bool>(jl, "enableMagnitudeScaling", false);
+        }
+        const std::string tfSel = jget<std::string>(jr, "selectedTF", "Identity");
+        py::dict jt = jsub(root, "tf", tfSel);
+        if (tfSel == "Identity") {  // transfer_function_identity.cpp:101-140
+            auto tf = std::make_shared<TransferFunctionIdentity>();
+            tf->absorptionEmission->value = {jget<double>(jt, "absorptionScaling", 1.0), jget<double>(jt, "emissionScaling", 1.0)};
+            dvr->tf = tf;
+        } else if (tfSel == "Gaussian") {  // transfer_function_gaussian.cpp:234-242,340-360
+            auto tf = std::make_shared<TransferFunctionGaussian>();
+            const double scale = jget<double>(jt, "absorptionScaling", 1.0);
+            auto pts = jt["points"].cast<std::vector<std::vector<double>>>();
+            torch::Tensor t = torch::empty({1, int64_t(pts.size()), 6}, torch::kFloat);
+            for (size_t i = 0; i < pts.size(); ++i) {
+                float* r = t.data_ptr<float>() + 6 * i;
+                r[0] = float(pts[i].at(0)); r[1] = float(pts[i].at(1)); r[2] = float(pts[i].at(2));
+                r[3] = float(pts[i].at(3) * scale); r[4] = float(pts[i].at(4)); r[5] = float(pts[i].at(5));
+            }
+            tf->setTensor(t);
+            dvr->tf = tf;
+        } else {
+            raise("transfer function '" + tfSel + "' cannot be loaded from JSON yet (Identity, Gaussian)");
+        }
+        ev->rayEvaluator = dvr;
+    }
+    // volume: networks are not stored in the JSON (volume_interpolation_network.cpp:1664-1672)
+    {
+        const std::string sel = jget<std::string>(je, "selectedVolume", "SRN");
+        if (sel != "SRN") raise("volume '" + sel + "' is not supported by this build (only 'SRN'); attach a VolumeInterpolationNetwork");
+        ev->volume = std::make_shared<VolumeInterpolationNetwork>();
+    }
+    return ev;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(pyrenderer, m) {
+    m.doc() = "MI355X-native drop-in for the SRN/DVR path of fV-SRN's pyrenderer";
+    // bindings/bindings.cpp:155-171: cache configuration is meaningless for ahead-of-time kernels; kept as no-ops
+    m.def("set_cuda_cache_dir", [](const std::string&) {});
+    m.def("set_kernel_cache_file", [](const std::string&) {});
+    m.def("disable_cuda_cache", []() {});
+    m.def("cleanup", []() {});
+    m.def("sync", []() { py::module_::import("torch").attr("cuda").attr("synchronize")(); });
+    m.def("version", []() { return std::string(fvsrn_version()); });
+
+    bindV3<float>(m, "float3"); bindV3<double>(m, "double3"); bindV3<int>(m, "int3");
+    bindV4<float>(m, "float4"); bindV4<double>(m, "double4");
+    py::class_<int2>(m, "int2").def(py::init<>()).def(py::init([](int x, int y) { return int2{x, y}; }))
+        .def_readwrite("x", &int2::x).def_readwrite("y", &int2::y);
+    py::class_<V2<double>>(m, "double2").def(py::init<>()).def(py::init([](double x, double y) { return V2<double>{x, y}; }))
+        .def_readwrite("x", &V2<double>::x).def_readwrite("y", &V2<double>::y);
+    bindParameter<double3>(m, "Parameter_double3");
+    bindParameter<V2<double>>(m, "Parameter_double2");
+
+    py::class_<GPUTimer>(m, "GPUTimer").def(py::init<>()).def("start", &GPUTimer::start).def("stop", &GPUTimer::stop)
+        .def("elapsed_milliseconds", &GPUTimer::elapsed);
+
+    // ---- SceneNetwork and nested classes (volume_interpolation_network.cpp:1828-1972)
+    py::class_<SceneNetwork, std::shared_ptr<SceneNetwork>> sn(m, "SceneNetwork");
+    py::class_<InputParametrization, std::shared_ptr<InputParametrization>>(sn, "InputParametrization")
+        .def_property("has_time", [](InputParametrization& p) { return p.hasTime; }, [](InputParametrization& p, bool v) { p.hasTime = v; p.push(); })
+        .def_property("has_direction", [](InputParametrization& p) { return p.hasDirection; }, [](InputParametrization& p, bool v) { p.hasDirection = v; p.push(); })
+        .def("num_fourier_features", [](InputParametrization& p) { return p.numFourier; })
+        .def("set_fourier_matrix_from_tensor", [](InputParametrization& p, const torch::Tensor& t, bool premultiplied) {
+            TORCH_CHECK(t.dim() == 2, "the fourier matrix must be of shape (F,3) or (F,6)");
+            const int cols = int(t.size(1));
+            if (cols == 6 && !p.hasDirection) raise("hasDirection==false, but the fourier matrix has input channels for the direction");
+            if (cols != 3 && cols != 6) raise("Unrecognized number of input channels. Actual: " + std::to_string(cols) + ", expected: 3 or 6");
+            torch::Tensor c = t.detach().to(c10::kCPU, c10::kFloat).contiguous();
+            p.fourier.assign(c.data_ptr<float>(), c.data_ptr<float>() + c.numel());
+            p.numFourier = int(t.size(0));
+            p.useDirInFourier = cols == 6;
+            p.premultiplied = premultiplied;
+            p.push();
+        })
+        .def("disable_fourier_features", [](InputParametrization& p) { p.numFourier = 0; p.useDirInFourier = false; p.fourier.clear(); p.push(); })
+        .def("channels_out", &InputParametrization::channelsOut)
+        .def("valid", [](InputParametrization& p) { return !(p.useDirInFourier && !p.hasDirection) && p.numFourier % 2 == 0; });
+
+    py::class_<OutputParametrization, std::shared_ptr<OutputParametrization>> om(sn, "OutputParametrization");
+    py::enum_<fvsrn_output_mode>(om, "OutputMode")
+        .value("DENSITY", FVSRN_OUT_DENSITY).value("DENSITY_DIRECT", FVSRN_OUT_DENSITY_DIRECT)
+        .value("RGBO", FVSRN_OUT_RGBO).value("RGBO_DIRECT", FVSRN_OUT_RGBO_DIRECT)
+        .value("DENSITY_GRADIENT", FVSRN_OUT_DENSITY_GRADIENT).value("DENSITY_GRADIENT_DIRECT", FVSRN_OUT_DENSITY_GRADIENT_DIRECT)
+        .value("DENSITY_GRADIENT_CUBIC", FVSRN_OUT_DENSITY_GRADIENT_CUBIC)
+        .value("DENSITY_CURVATURE", FVSRN_OUT_DENSITY_CURVATURE).value("DENSITY_CURVATURE_DIRECT", FVSRN_OUT_DENSITY_CURVATURE_DIRECT)
+        .export_values();
+    om.def_property("output_mode", [](OutputParametrization& o) { return o.mode; }, [](OutputParametrization& o, fvsrn_output_mode v) { o.mode = v; o.push(); })
+        .def_static("OutputModeFromString", [](const std::string& s) {
+            static const char* names[9] = {"density", "density:direct", "rgbo", "rgbo:direct", "densitygrad", "densitygrad:direct",
+                                           "densitygrad:cubic", "densitycurvature", "densitycurvature:direct"};
+            for (int i = 0; i < 9; ++i)
+                if (s == names[i]) return fvsrn_output_mode(i);
+            raise("No output mode found matching string " + s);
+        })
+        .def("channels_in", [](OutputParametrization& o) { static const int c[9] = {1, 1, 4, 4, 4, 4, 4, 6, 6}; return c[int(o.mode)]; });
+
+    py::class_<Layer, std::shared_ptr<Layer>> l(sn, "Layer");
+    py::enum_<fvsrn_activation>(l, "Activation")
+        .value("ReLU", FVSRN_ACT_RELU).value("Sine", FVSRN_ACT_SINE).value("Snake", FVSRN_ACT_SNAKE)
+        .value("SnakeAlt", FVSRN_ACT_SNAKEALT).value("Sigmoid", FVSRN_ACT_SIGMOID).value("NONE", FVSRN_ACT_NONE)
+        .export_values();
+    l.def_readonly("activation", &Layer::activation)
+        .def_static("ActivationFromString", [](const std::string& s) {
+            static const char* names[6] = {"ReLU", "Sine", "Snake", "SnakeAlt", "Sigmoid", "None"};
+            for (int i = 0; i < 6; ++i)
+                if (s == names[i]) return fvsrn_activation(i);
+            raise("No output mode found matching string " + s);
+        })
+        .def_readonly("channels_in", &Layer::channelsIn)
+        .def_readonly("channels_out", &Layer::channelsOut);
+
+    py::class_<LatentGrid, std::shared_ptr<LatentGrid>> lg(sn, "LatentGrid");
+    py::enum_<fvsrn_grid_encoding>(lg, "Encoding")
+        .value("Float", FVSRN_GRID_FLOAT).value("ByteLinear", FVSRN_GRID_BYTE_LINEAR).value("ByteGaussian", FVSRN_GRID_BYTE_GAUSSIAN)
+        .export_values();
+    lg.def(py::init<>())
+        .def(py::init(&LatentGrid::fromTensor))
+        .def("is_valid", &LatentGrid::isValid)
+        .def_readonly("grid_channels", &LatentGrid::gridChannels)
+        .def_readonly("grid_size_z", &LatentGrid::gridSizeZ)
+        .def_readonly("grid_size_y", &LatentGrid::gridSizeY)
+        .def_readonly("grid_size_x", &LatentGrid::gridSizeX)
+        .def_readonly("encoding", &LatentGrid::encoding);
+
+    py::class_<LatentGridTimeAndEnsemble, std::shared_ptr<LatentGridTimeAndEnsemble>>(sn, "LatentGridTimeAndEnsemble")
+        .def(py::init<>())
+        .def(py::init<int, int, int, int, int>(), py::arg("time_min"), py::arg("time_num"), py::arg("time_step"),
+             py::arg("ensemble_min"), py::arg("ensemble_num"))
+        .def_readonly("time_min", &LatentGridTimeAndEnsemble::timeMin)
+        .def_readonly("time_num", &LatentGridTimeAndEnsemble::timeNum)
+        .def_readonly("time_step", &LatentGridTimeAndEnsemble::timeStep)
+        .def_readonly("ensemble_min", &LatentGridTimeAndEnsemble::ensembleMin)
+        .def_readonly("ensemble_num", &LatentGridTimeAndEnsemble::ensembleNum)
+        .def_property_readonly("time_max_inclusive", &LatentGridTimeAndEnsemble::timeMaxInclusive)
+        .def_property_readonly("ensemble_max_inclusive", &LatentGridTimeAndEnsemble::ensembleMaxInclusive)
+        .def("interpolate_time", &LatentGridTimeAndEnsemble::interpolateTime, py::arg("time"))
+        .def("interpolate_ensemble", &LatentGridTimeAndEnsemble::interpolateEnsemble, py::arg("time"))
+        .def("get_time_grid", [](LatentGridTimeAndEnsemble& g, int i) { TORCH_CHECK(i >= 0 && i < g.timeNum, "Index out of bounds"); return g.timeGrids[size_t(i)]; }, py::arg("index"))
+        .def("get_ensemble_grid", [](LatentGridTimeAndEnsemble& g, int i) { TORCH_CHECK(i >= 0 && i < g.ensembleNum, "Index out of bounds"); return g.ensembleGrids[size_t(i)]; }, py::arg("index"))
+        .def("set_time_grid_from_torch", [](LatentGridTimeAndEnsemble& g, int i, const torch::Tensor& t, fvsrn_grid_encoding e) { return g.setGrid(false, i, t, e); },
+             py::arg("index"), py::arg("tensor"), py::arg("encoding"))
+        .def("set_ensemble_grid_from_torch", [](LatentGridTimeAndEnsemble& g, int i, const torch::Tensor& t, fvsrn_grid_encoding e) { return g.setGrid(true, i, t, e); },
+             py::arg("index"), py::arg("tensor"), py::arg("encoding"))
+        .def("is_valid", &LatentGridTimeAndEnsemble::isValid)
+        .def("common_encoding", &LatentGridTimeAndEnsemble::commonEncoding)
+        .def("time_channels", &LatentGridTimeAndEnsemble::timeChannels)
+        .def("ensemble_channels", &LatentGridTimeAndEnsemble::ensembleChannels);
+
+    sn.def(py::init(&SceneNetwork::create))
+        .def_property_readonly("input", [](SceneNetwork& n) { return n.input; })
+        .def_property_readonly("output", [](SceneNetwork& n) { return n.output; })
+        .def_property("latent_grid", [](SceneNetwork& n) { return n.latentGrid; }, &SceneNetwork::setLatentGrid)
+        .def("add_layer", &SceneNetwork::addLayer, py::arg("weights"), py::arg("bias"), py::arg("activation"),
+             py::arg("activation_parameter") = 1.0f)
+        .def("num_layers", &SceneNetwork::numLayers)
+        .def("get_layer", &SceneNetwork::getLayer)
+        .def_property("box_min", [](SceneNetwork& n) { return n.boxMin; }, [](SceneNetwork& n, float3 v) { n.setBox(v, n.boxSize); })
+        .def_property("box_size", [](SceneNetwork& n) { return n.boxSize; }, [](SceneNetwork& n, float3 v) { n.setBox(n.boxMin, v); })
+        .def("valid", &SceneNetwork::valid)
+        .def("save", &SceneNetwork::save)
+        .def_static("load", &SceneNetwork::load)
+        .def("num_parameters", [](SceneNetwork& n) { return n.info().num_parameters; })
+        .def("compute_max_warps", [](SceneNetwork& n, bool onlyShared, bool adjoint) {
+            if (adjoint) raise("the adjoint method is not part of this build");
+            const fvsrn_network_info i = n.info();
+            return onlyShared ? i.max_warps_shared : i.max_warps_mixed;
+        }, py::arg("only_shared_memory"), py::arg("adjoint") = false)
+        .def("clear_gpu_resources", [](SceneNetwork& n) { check(fvsrn_network_clear_gpu_resources(n.h)); })
+        .def("set_time_and_ensemble", [](SceneNetwork& n, float t, int e) { check(fvsrn_network_set_time_and_ensemble(n.h, t, e)); },
+             py::arg("time"), py::arg("ensemble"))
+        .def("flops_per_sample", [](SceneNetwork& n) { return n.info().flops_per_sample; });
+
+    // ---- volumes (volume_interpolation.cpp:615-695, volume_interpolation_network.cpp:1974-2005)
+    py::class_<IVolumeInterpolation, std::shared_ptr<IVolumeInterpolation>>(m, "IVolumeInterpolation")
+        .def("box_min", [](IVolumeInterpolation& v) { return v.boxMin_; })
+        .def("box_max", [](IVolumeInterpolation& v) { return v.boxMax_; })
+        .def("box_size", &IVolumeInterpolation::boxSize)
+        .def("set_box_min", &IVolumeInterpolation::setBoxMin)
+        .def("set_box_max", &IVolumeInterpolation::setBoxMax)
+        .def("output_channels", &IVolumeInterpolation::outputChannels)
+        .def("evaluate", &IVolumeInterpolation::evaluate, py::arg("positions"), py::arg("direction") = std::optional<torch::Tensor>{});
+    py::class_<VolumeInterpolationNetwork, IVolumeInterpolation, std::shared_ptr<VolumeInterpolationNetwork>> vn(m, "VolumeInterpolationNetwork");
+    py::enum_<GradientMode>(vn, "GradientMode")
+        .value("OFF_OR_DIRECT", OFF_OR_DIRECT).value("FINITE_DIFFERENCES", FINITE_DIFFERENCES).value("ADJOINT_METHOD", ADJOINT_METHOD);
+    vn.def(py::init<>())
+        .def("set_network", &VolumeInterpolationNetwork::setNetwork)
+        .def("current_network", &VolumeInterpolationNetwork::currentNetwork)
+        .def("set_time_and_ensemble", &VolumeInterpolationNetwork::setTimeAndEnsemble)
+        .def_readwrite("only_shared_memory", &VolumeInterpolationNetwork::onlySharedMemory)
+        .def_property("gradient_mode", [](VolumeInterpolationNetwork& v) { return v.gradientMode; },
+                      [](VolumeInterpolationNetwork& v, GradientMode mode) {
+                          if (mode != OFF_OR_DIRECT) raise("gradient modes FINITE_DIFFERENCES / ADJOINT_METHOD are not part of this build");
+                          v.gradientMode = mode;
+                      })
+        .def_readwrite("finite_differences_stepsize", &VolumeInterpolationNetwork::finiteDifferencesStepsize)
+        .def_readwrite("adjoint_latent_grid_central_differences_stepsize_scale", &VolumeInterpolationNetwork::adjointScale);
+
+    // ---- transfer functions, BRDF, blending
+    py::class_<ITransferFunction, std::shared_ptr<ITransferFunction>>(m, "ITransferFunction");
+    py::class_<TransferFunctionIdentity, ITransferFunction, std::shared_ptr<TransferFunctionIdentity>>(m, "TransferFunctionIdentity")
+        .def(py::init<>())
+        .def_readonly("absorption_emission", &TransferFunctionIdentity::absorptionEmission);
+    py::class_<TransferFunctionGaussian, ITransferFunction, std::shared_ptr<TransferFunctionGaussian>>(m, "TransferFunctionGaussian")
+        .def(py::init<>())
+        .def_property("tensor", [](TransferFunctionGaussian& t) { return t.tensor; }, &TransferFunctionGaussian::setTensor);
+    py::class_<TransferFunctionPiecewise, ITransferFunction, std::shared_ptr<TransferFunctionPiecewise>>(m, "TransferFunctionPiecewise")
+        .def(py::init<>())
+        .def_property("tensor", [](TransferFunctionPiecewise& t) { return t.tensor; }, &TransferFunctionPiecewise::setTensor);
+    py::class_<TransferFunctionTexture, ITransferFunction, std::shared_ptr<TransferFunctionTexture>>(m, "TransferFunctionTexture")
+        .def(py::init<>())
+        .def_property("tensor", [](TransferFunctionTexture& t) { return t.tensor; }, &TransferFunctionTexture::setTensor);
+    py::class_<BRDFLambert, std::shared_ptr<BRDFLambert>>(m, "BRDFLambert")
+        .def(py::init<>())
+        .def_readwrite("enable_phong", &BRDFLambert::enablePhong)
+        .def_readwrite("enable_magnitude_scaling", &BRDFLambert::enableMagnitudeScaling);
+    py::class_<Blending, std::shared_ptr<Blending>> bl(m, "Blending");
+    py::enum_<fvsrn_blend_mode>(bl, "BlendMode").value("Alpha", FVSRN_BLEND_ALPHA).value("BeerLambert", FVSRN_BLEND_BEER_LAMBERT).export_values();
+    bl.def(py::init<>())
+        .def_property("blendMode", [](Blending& b) { return fvsrn_blend_mode(b.blendMode); }, [](Blending& b, fvsrn_blend_mode v) { b.blendMode = v; });
+
+    // ---- ray evaluators (ray_evaluation_stepping.cpp:80-93,781-801)
+    py::class_<IRayEvaluation, std::shared_ptr<IRayEvaluation>>(m, "IRayEvaluation");
+    py::class_<RayEvaluationSteppingDvr, IRayEvaluation, std::shared_ptr<RayEvaluationSteppingDvr>>(m, "RayEvaluationSteppingDvr")
+        .def(py::init<>())
+        .def_readwrite("stepsize", &RayEvaluationSteppingDvr::stepsize)
+        .def_readwrite("min_density", &RayEvaluationSteppingDvr::minDensity)
+        .def_readwrite("max_density", &RayEvaluationSteppingDvr::maxDensity)
+        .def_readwrite("early_out", &RayEvaluationSteppingDvr::enableEarlyOut)
+        .def_readonly("blending", &RayEvaluationSteppingDvr::blending)
+        .def_readwrite("tf", &RayEvaluationSteppingDvr::tf)
+        .def_readwrite("brdf", &RayEvaluationSteppingDvr::brdf);
+
+    // ---- cameras (camera.cpp:184-224,375-397)
+    py::class_<ICamera, std::shared_ptr<ICamera>>(m, "ICamera")
+        .def_readonly("aspect_ratio", &ICamera::aspectRatio)
+        .def_readwrite("fov_y_radians", &ICamera::fovYRadians);
+    py::class_<CameraOnASphere, ICamera, std::shared_ptr<CameraOnASphere>> cs(m, "CameraOnASphere");
+    py::enum_<Orientation>(cs, "Orientation")
+        .value("Xp", Xp).value("Xm", Xm).value("Yp", Yp).value("Ym", Ym).value("Zp", Zp).value("Zm", Zm).export_values();
+    cs.def(py::init<>())
+        .def_property("orientation", [](CameraOnASphere& c) { return Orientation(c.orientation); },
+                      [](CameraOnASphere& c, Orientation o) { c.orientation = int(o); })
+        .def_readonly("center", &CameraOnASphere::center)
+        .def_readonly("pitchYawDistance", &CameraOnASphere::pitchYawDistance)
+        .def("get_origin", &CameraOnASphere::getOrigin, py::arg("batch") = 0)
+        .def("get_front", &CameraOnASphere::getFront, py::arg("batch") = 0)
+        .def("get_parameters", &CameraOnASphere::getParameters)
+        .def("set_parameters", &CameraOnASphere::setParameters);
+
+    // ---- image evaluators (iimage_evaluator.cpp:325-358, image_evaluator_simple.cpp:427-475)
+    py::class_<ImageEvaluatorSimple, std::shared_ptr<ImageEvaluatorSimple>> ie(m, "ImageEvaluatorSimple");
+    py::enum_<ChannelMode>(ie, "ChannelMode")
+        .value("Mask", ChannelMask).value("Normal", ChannelNormal).value("Depth", ChannelDepth).value("Color", ChannelColor)
+        .export_values();
+    ie.def(py::init<>())
+        .def_readwrite("selected_channel", &ImageEvaluatorSimple::selectedChannel)
+        .def_readwrite("double_precision", &ImageEvaluatorSimple::doublePrecision)
+        .def("render", &ImageEvaluatorSimple::render, py::arg("width"), py::arg("height"))
+        .def("compute_batch_count", [](ImageEvaluatorSimple&) { return 1; })
+        .def("is_iterative_refining", [](ImageEvaluatorSimple&) { return false; })
+        .def("get_supported_tags", [](ImageEvaluatorSimple&) { return std::vector<std::string>{"camera", "volume", "RayEvaluation"}; })
+        .def_readwrite("camera", &ImageEvaluatorSimple::camera)
+        .def_readwrite("ray_evaluator", &ImageEvaluatorSimple::rayEvaluator)
+        .def_readwrite("volume", &ImageEvaluatorSimple::volume)
+        .def_readwrite("spp_log2", &ImageEvaluatorSimple::sppLog2)
+        .def_readwrite("use_tonemapping", &ImageEvaluatorSimple::useTonemapping)
+        .def_readwrite("tonemapping_shoulder", &ImageEvaluatorSimple::tonemappingShoulder)
+        .def_property_readonly("last_max_exposure", [](ImageEvaluatorSimple& e) { e.exposure(); return e.lastMaxExposure; })
+        .def_readwrite("fix_max_exposure", &ImageEvaluatorSimple::fixMaxExposure)
+        .def_readwrite("fixed_max_exposure", &ImageEvaluatorSimple::fixedMaxExposure)
+        .def_static("Extract_color", &ImageEvaluatorSimple::extractColorStatic, py::arg("raw_input"), py::arg("use_tonemapping"),
+                    py::arg("max_exposure"), py::arg("channel") = ChannelColor)
+        .def("extract_color", [](ImageEvaluatorSimple& e, const torch::Tensor& raw) {
+            return ImageEvaluatorSimple::extractColorStatic(raw, e.useTonemapping, e.useTonemapping ? e.exposure() : 1.f, e.selectedChannel);
+        }, py::arg("raw_input"));
+    m.attr("IImageEvaluator") = m.attr("ImageEvaluatorSimple");
+
+    m.def("load_from_json", &loadFromJson, py::arg("filename"));
+}

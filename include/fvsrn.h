@@ -143,11 +143,14 @@ int fvsrn_network_get_fourier(const fvsrn_network* net, uint16_t* matrix, int ca
 /* ----------------------------------------------------------------------------------------
  * IVolumeInterpolation::evaluate   (renderer/volume_interpolation.cpp:26-127, kernel
  * EvaluateNoBatches renderer/renderer_volume_kernels1.cuh:15).
- * d_positions (n,3) fp32 in WORLD space of the network's box, d_directions (n,3) or NULL,
- * d_out (n, output_channels) fp32.
+ * d_positions (n,3) fp32, d_directions (n,3) or NULL, d_out (n, output_channels) fp32.
+ * Like the reference -- which resets the box to [0,1]^3 around this call (:46-49) -- positions are
+ * in UNIT-BOX coordinates unless FVSRN_EVAL_WORLD_POSITIONS is set, in which case they are world
+ * positions and mapped through the network's box_min / box_size as the renderer does.
  * -------------------------------------------------------------------------------------- */
+#define FVSRN_EVAL_WORLD_POSITIONS 1
 int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const float* d_directions,
-                          size_t n, float* d_out, void* stream);
+                          size_t n, float* d_out, int flags, void* stream);
 
 /* ----------------------------------------------------------------------------------------
  * scene = ImageEvaluatorSimple + CameraOnASphere(->reference frame) + RayEvaluationSteppingDvr

@@ -91,10 +91,12 @@ def camera_rays(eye, right, up, fov_y, W, H):
     return eye.expand_as(d).reshape(-1, 3), d.reshape(-1, 3)
 
 
-def trace(net: TorchSRN, ray_start, ray_dir, box_min, box_size, stepsize: float, *, tf_identity=None, dtype=torch.float32):
+def trace(net: TorchSRN, ray_start, ray_dir, box_min, box_size, stepsize: float, *, tf_identity=None, dtype=torch.float32,
+          budget_s: Optional[float] = None):
     """Raytracing._full_trace_forward; tf_identity=(scale_absorption, scale_emission) maps a density network
     through the Identity TF (renderer_tf_identity.cuh:36-54), None = rgbo network.
-    Returns (rgba (N,4), number of network samples evaluated = N * max_steps)."""
+    Returns (rgba (N,4), number of network samples evaluated = N * steps done).  budget_s stops the step loop
+    early (timing runs only: the image is then incomplete)."""
     box_min = torch.as_tensor(np.asarray(box_min, np.float32)).unsqueeze(0)
     box_size = torch.as_tensor(np.asarray(box_size, np.float32)).unsqueeze(0)
     inv = 1.0 / ray_dir
@@ -106,8 +108,13 @@ def trace(net: TorchSRN, ray_start, ray_dir, box_min, box_size, stepsize: float,
     n = ray_start.shape[0]
     color = torch.zeros((n, 3))
     alpha = torch.zeros((n, 1))
+    t_start = time.perf_counter()
+    done = 0
     with torch.no_grad():
         for t in range(max_steps):
+            if budget_s is not None and t > 0 and time.perf_counter() - t_start > budget_s:
+                break
+            done += 1
             tcur = tmin + t * stepsize
             pos = ((ray_start + tcur * ray_dir) - box_min) / box_size
             pred = net(pos.to(dtype), "screen").float()
@@ -120,19 +127,16 @@ def trace(net: TorchSRN, ray_start, ray_dir, box_min, box_size, stepsize: float,
             a = torch.where(tcur < tmax, a, torch.zeros(1, 1))
             color = color + (1 - alpha) * c[:, :3] * a
             alpha = alpha + (1 - alpha) * a
-    return torch.cat((color, alpha), dim=1), n * max_steps
+    return torch.cat((color, alpha), dim=1), n * done
 
 
 def time_cpu_baseline(net: TorchSRN, eye, right, up, fov_y, box_min, box_size, *, width, height, stepsize, tf_identity,
-                      threads: int, repeats: int = 1, dtype=torch.float32):
-    """Times `repeats` frames of the port; returns dict(value=samples/s, seconds, samples, cores)."""
+                      threads: int, budget_s: float = 15.0, dtype=torch.float32):
+    """Times the port for at most ~budget_s seconds of step loop; returns dict(value=samples/s, seconds, samples, cores)."""
     torch.set_num_threads(threads)
     rs, rd = camera_rays(eye, right, up, fov_y, width, height)
-    trace(net, rs[:64], rd[:64], box_min, box_size, stepsize, tf_identity=tf_identity, dtype=dtype)  # warm up
+    trace(net, rs, rd, box_min, box_size, stepsize, tf_identity=tf_identity, dtype=dtype, budget_s=0.5)  # warm up
     t0 = time.perf_counter()
-    samples = 0
-    for _ in range(repeats):
-        _, s = trace(net, rs, rd, box_min, box_size, stepsize, tf_identity=tf_identity, dtype=dtype)
-        samples += s
+    _, samples = trace(net, rs, rd, box_min, box_size, stepsize, tf_identity=tf_identity, dtype=dtype, budget_s=budget_s)
     dt = time.perf_counter() - t0
     return {"value": samples / dt, "seconds": dt, "samples": samples, "cores": threads}

@@ -34,7 +34,7 @@ def test_no_gpu_calls_fail_loudly_without_a_device():
     from fvsrn_amd import volnet_io
     vn = util.random_network()
     net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
-    rc = capi.lib().fvsrn_evaluate_points(net._h, 16, None, 1, 16, None)
+    rc = capi.lib().fvsrn_evaluate_points(net._h, 16, None, 1, 16, 0, None)
     assert rc == -6 and b"no HIP device" in capi.lib().fvsrn_last_error()
 
 

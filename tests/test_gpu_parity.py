@@ -24,13 +24,13 @@ TOL_IMG = 3e-3
 TOL_IMG_HALF = 2e-2
 
 
-def gpu_eval(vn, positions, time=None, ensemble=0):
+def gpu_eval(vn, positions, time=None, ensemble=0, world=False):
     import torch
     from fvsrn_amd import capi, volnet_io
     net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
     if time is not None:
         net.set_time_and_ensemble(time, ensemble)
-    out = net.evaluate(torch.from_numpy(np.ascontiguousarray(positions, np.float32)).cuda())
+    out = net.evaluate(torch.from_numpy(np.ascontiguousarray(positions, np.float32)).cuda(), world=world)
     torch.cuda.synchronize()
     return out.cpu().numpy()
 
@@ -84,9 +84,13 @@ def test_evaluate_grid_encodings_and_box(enc):
                              box_min=(-0.5, -0.25, 0.1), box_size=(1.0, 0.5, 2.0), encoding=enc)
     rng = np.random.RandomState(1)
     pos = (rng.rand(2000, 3) * np.array([1.0, 0.5, 2.0]) + np.array([-0.5, -0.25, 0.1])).astype(np.float32)
-    out = gpu_eval(vn, pos)
+    out = gpu_eval(vn, pos, world=True)
     ref = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos)
     assert np.abs(out - ref).max() < TOL_SAME_MODEL
+    # unit-box entry (the reference's IVolumeInterpolation::evaluate resets the box to [0,1]^3)
+    unit = ((pos - np.array([-0.5, -0.25, 0.1], np.float32)) / np.array([1.0, 0.5, 2.0], np.float32)).astype(np.float32)
+    out_u = gpu_eval(vn, unit)
+    assert np.abs(out_u - ref).max() < TOL_SAME_MODEL
 
 
 def make_scene_kwargs(pitch=0.4, yaw=0.7, distance=1.6, stepsize=1 / 48, **kw):

@@ -1,0 +1,157 @@
+"""
+The C++ pybind11 `pyrenderer` module (fv-srn_amd/pyrenderer/) -- the reference's own Python-visible surface for
+this path -- driven exactly like the reference's callers drive it:
+  * export_to_pyrenderer's call sequence (applications/volnet/network.py:798-897)
+  * LoadedModel.render_network's call sequence (applications/volnet/inference.py:529-625)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import util
+
+sys.path.insert(0, os.path.join(util.ROOT, "fv-srn_amd", "pyrenderer"))
+pr = pytest.importorskip("pyrenderer", reason="pyrenderer module not built (python fv-srn_amd/pyrenderer/build.py)")
+from fvsrn_amd import volnet_io  # noqa: E402
+
+
+def export_like_the_reference(d, meta, encoding=None):
+    n = pr.SceneNetwork()
+    n.input.has_direction = False
+    n.input.set_fourier_matrix_from_tensor(torch.from_numpy(d["B"]), True)
+    n.input.has_time = meta.get("use_time_direct", False)
+    n.output.output_mode = pr.SceneNetwork.OutputParametrization.OutputModeFromString(meta["output_mode"])
+    enc = encoding if encoding is not None else pr.SceneNetwork.LatentGrid.Float
+    if "grid" in d:
+        g = pr.SceneNetwork.LatentGridTimeAndEnsemble(time_min=0, time_num=1, time_step=1, ensemble_min=0, ensemble_num=0)
+        g.set_time_grid_from_torch(0, torch.from_numpy(d["grid"]), enc)
+        n.latent_grid = g
+    elif "grid_time" in d:
+        tg, eg = d["grid_time"], d.get("grid_ensemble", np.zeros((0,)))
+        g = pr.SceneNetwork.LatentGridTimeAndEnsemble(time_min=0, time_num=len(tg), time_step=1, ensemble_min=0, ensemble_num=len(eg))
+        for i in range(len(tg)):
+            g.set_time_grid_from_torch(i, torch.from_numpy(tg[i:i + 1]), enc)
+        for i in range(len(eg)):
+            g.set_ensemble_grid_from_torch(i, torch.from_numpy(eg[i:i + 1]), enc)
+        assert g.is_valid()
+        n.latent_grid = g
+    act = pr.SceneNetwork.Layer.ActivationFromString(meta["activation"])
+    k = len(meta["layers"].split(":"))
+    for i in range(k):
+        n.add_layer(torch.from_numpy(d["W%d" % i]), torch.from_numpy(d["b%d" % i]), act, meta["activation_param"])
+    n.add_layer(torch.from_numpy(d["W%d" % k]), torch.from_numpy(d["b%d" % k]), pr.SceneNetwork.Layer.Activation.NONE)
+    n.box_min = pr.float3(0, 0, 0)
+    n.box_size = pr.float3(1, 1, 1)
+    assert n.valid()
+    return n
+
+
+@pytest.mark.parametrize("name", ["g1_c32l4_snakealt_density", "g1_c32l4_grid16r8_snakealt_rgbo", "g2_time3_ens2_c32l4_grid32r8",
+                                  "g2_time3_passtime_c32l4_grid16r8"])
+def test_export_sequence_writes_reference_format(tmp_path, name):
+    d, meta = util.load_golden(name)
+    n = export_like_the_reference(d, meta)
+    path = str(tmp_path / "net.volnet")
+    n.save(path)
+    assert open(path, "rb").read() == volnet_io.save_volnet(util.golden_to_volnet(d, meta))
+    m = pr.SceneNetwork.load(path)
+    assert m.num_layers() == n.num_layers() and m.num_parameters() == n.num_parameters()
+    assert m.input.num_fourier_features() == d["B"].shape[0]
+    assert m.get_layer(0).channels_out == int(meta["layers"].split(":")[0])
+    assert m.get_layer(m.num_layers() - 1).activation == pr.SceneNetwork.Layer.Activation.NONE
+    assert m.output.output_mode == n.output.output_mode
+
+
+def test_value_types_and_enums():
+    a = pr.double3(1, 2, 3) + pr.double3(1, 1, 1)
+    assert (a.x, a.y, a.z) == (2, 3, 4) and str(pr.float3(1, 2, 3)) == "(1, 2, 3)"
+    assert pr.SceneNetwork.OutputParametrization.OutputModeFromString("rgbo:direct") == pr.SceneNetwork.OutputParametrization.RGBO_DIRECT
+    assert pr.SceneNetwork.Layer.ActivationFromString("SnakeAlt") == pr.SceneNetwork.Layer.SnakeAlt
+    with pytest.raises(RuntimeError):
+        pr.SceneNetwork.Layer.ActivationFromString("Tanh")
+    lg = pr.SceneNetwork.LatentGridTimeAndEnsemble(2, 3, 2, 5, 2)
+    assert lg.time_max_inclusive == 6 and lg.ensemble_max_inclusive == 6
+    assert lg.interpolate_time(5.0) == 1.5 and lg.interpolate_time(99) == 2 and lg.interpolate_ensemble(0) == 0
+
+
+def test_load_from_json_builds_the_module_tree(tmp_path):
+    scene = {"version": 1, "root": "Simple",
+             "ImageEvaluator": {"Simple": {"selectedCamera": "Sphere", "selectedVolume": "SRN", "selectedRayEvaluator": "DVR",
+                                           "samplesPerIterationLog2": 0, "useTonemapping": False}},
+             "camera": {"Sphere": {"orientation": "Zp", "center": [0.1, 0.2, 0.3], "pitch": 0.3, "yaw": 1.1, "distance": 2.5, "fovY": 0.7}},
+             "RayEvaluation": {"DVR": {"stepsize": 0.5, "stepsizeIsObjectSpace": True, "minDensity": 0.1, "maxDensity": 0.9,
+                                       "earlyOut": False, "selectedTF": "Gaussian", "selectedBRDF": "Lambert"}},
+             "tf": {"Gaussian": {"absorptionScaling": 2.0, "points": [[1, 0, 0, 10, 0.3, 0.1], [0, 1, 0, 20, 0.7, 0.05]]}},
+             "brdf": {"Lambert": {"enablePhong": False}}, "blending": {"blending": {"blending": "Alpha"}},
+             "volume": {"SRN": {}}}
+    p = tmp_path / "scene.json"
+    p.write_text(json.dumps(scene))
+    ev = pr.load_from_json(str(p))
+    cam = ev.camera
+    assert cam.orientation == pr.CameraOnASphere.Zp and cam.pitchYawDistance.value.z == 2.5 and cam.center.value.y == 0.2
+    assert abs(cam.fov_y_radians - 0.7) < 1e-12
+    r = ev.ray_evaluator
+    assert abs(r.stepsize - 0.5 / 256) < 1e-12 and r.min_density == 0.1 and r.max_density == 0.9 and not r.early_out
+    assert r.blending.blendMode == pr.Blending.Alpha
+    t = r.tf.tensor
+    assert tuple(t.shape) == (1, 2, 6) and float(t[0, 0, 3]) == 20.0 and float(t[0, 1, 3]) == 40.0
+    assert isinstance(ev.volume, pr.VolumeInterpolationNetwork)
+    with pytest.raises(RuntimeError, match="No network loaded"):
+        ev.volume.current_network()
+
+
+def test_extract_color_channels_cpu():
+    raw = torch.rand(1, 8, 5, 7)
+    ch = pr.ImageEvaluatorSimple.ChannelMode
+    c = pr.ImageEvaluatorSimple.Extract_color(raw, False, 1.0, ch.Color)
+    assert torch.equal(c, raw[:, :4])
+    n = pr.ImageEvaluatorSimple.Extract_color(raw, False, 1.0, ch.Normal)
+    assert torch.allclose(n[:, :3], raw[:, 4:7] * 0.5 + 0.5) and torch.equal(n[:, 3], raw[:, 3])
+    m = pr.ImageEvaluatorSimple.Extract_color(raw, False, 1.0, ch.Mask)
+    assert torch.equal(m[:, 0], raw[:, 3]) and bool((m[:, 3] == 1).all())
+    dpt = pr.ImageEvaluatorSimple.Extract_color(raw, False, 1.0, ch.Depth)
+    assert abs(float(dpt[:, 0].min())) < 1e-6 and abs(float(dpt[:, 0].max()) - 1) < 1e-6
+    t = pr.ImageEvaluatorSimple.Extract_color(raw, True, 2.0, ch.Color)
+    x = raw[:, :3] / 2.0
+    ref = ((x * (2.51 * x + 0.03)) / (x * (2.43 * x + 0.59) + 0.14)).clamp(0, 1) ** (1 / 2.4)
+    assert torch.allclose(t[:, :3], ref, atol=1e-6) and torch.equal(t[:, 3], raw[:, 3])
+
+
+@pytest.mark.gpu
+def test_render_network_sequence_matches_oracle():
+    """inference.py:529-625: set camera / stepsize / volume, render, extract_color -- vs the CPU oracle."""
+    from oracle import oracle
+    d, meta = util.load_golden("g3_trace_rgbo_32x32")
+    n = export_like_the_reference(d, meta)
+    n.box_min = pr.float3(*meta["box_min"])
+    n.box_size = pr.float3(*meta["box_size"])
+    vol = pr.VolumeInterpolationNetwork()
+    vol.set_network(n)
+    ev = pr.ImageEvaluatorSimple()
+    ev.volume = vol
+    ev.camera.orientation = pr.CameraOnASphere.Ym
+    ev.camera.pitchYawDistance.value = pr.double3(meta["pitch"], meta["yaw"], meta["distance"])
+    ev.camera.fov_y_radians = meta["fov_y"]
+    ev.ray_evaluator.stepsize = meta["stepsize"]
+    ev.ray_evaluator.early_out = False
+    timer = pr.GPUTimer()
+    timer.start()
+    img = ev.render(meta["W"], meta["H"])
+    rgba = ev.extract_color(img)
+    timer.stop()
+    pr.sync()
+    assert timer.elapsed_milliseconds() > 0
+    assert tuple(img.shape) == (1, 8, 32, 32) and tuple(rgba.shape) == (1, 4, 32, 32)
+    diff = (rgba[0].cpu().numpy() - d["image"])
+    diff[:, 0, 0] = 0
+    assert np.abs(diff).max() < 3e-3
+    # evaluate(): unit-box positions like IVolumeInterpolation::evaluate
+    pos = torch.rand(500, 3, device="cuda")
+    out = vol.evaluate(pos)
+    vn = util.golden_to_volnet(d, meta, box_min=meta["box_min"], box_size=meta["box_size"])
+    ref = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos.cpu().numpy() * np.array(meta["box_size"], np.float32) + np.array(meta["box_min"], np.float32))
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-3
