@@ -5,6 +5,9 @@
 namespace fvsrn {
 
 constexpr int kBlockThreads = 256;  // 4 waves share one LDS copy of the network
+// __launch_bounds__(256, 2): at most 256 registers per lane, which also makes hipcc use the VGPR form of the MFMA
+// (accumulators in AGPRs cost one v_accvgpr_read per value before the VALU can touch them: +32 VALU per layer).
+// C = 128 needs more than 256 registers and takes the 512-register budget instead.
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 
 __device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* lds) {
@@ -19,7 +22,7 @@ __device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* ld
 // EvaluateNoBatches (reference renderer/renderer_volume_kernels1.cuh:15): positions -> network value
 // ------------------------------------------------------------------------------------------------
 template <int CD, int ACT, bool HAS_GRID, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads, 2) void evaluate_kernel(NetParams P, const float* __restrict__ pos,
+__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : 2)) void evaluate_kernel(NetParams P, const float* __restrict__ pos,
                                                                  const float* __restrict__ dir, size_t n,
                                                                  float* __restrict__ out, int outChannels) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -122,7 +125,7 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // the reference's __any_sync loop: all 64 lanes evaluate the network until no lane is valid.
 // ------------------------------------------------------------------------------------------------
 template <int CD, int ACT, bool HAS_GRID, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads, 2) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : 2)) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     load_network_to_lds(P, lds);
@@ -168,6 +171,13 @@ __global__ __launch_bounds__(kBlockThreads, 2) void render_kernel(NetParams P, S
     tmin = fmaxf(tmin, 0.f);  // stepping_dvr.cuh:66-67 (tmax input of the image evaluator is FLT_MAX)
     if (!inImage) tmax = -1.f;  // padding lanes never become valid
 
+    // position in unit-box coordinates as a function of t: p = pn0 + dn * t
+    // (the reference evaluates ((o + d t) - boxMin) / boxSize, renderer_volume_tensorcores.cuh:746; same value up
+    // to fp32 rounding, far below the fp16 quantisation the network applies to p)
+    const float pn0x = (ox - P.boxMin[0]) * P.invBoxSize[0], dnx = dx * P.invBoxSize[0];
+    const float pn0y = (oy - P.boxMin[1]) * P.invBoxSize[1], dny = dy * P.invBoxSize[1];
+    const float pn0z = (oz - P.boxMin[2]) * P.invBoxSize[2], dnz = dz * P.invBoxSize[2];
+
     float cr = 0, cg = 0, cb = 0, ca = 0, nx = 0, ny = 0, nz = 0, depth = 0;
     unsigned nValid = 0, nSteps = 0;
     const bool rgboNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
@@ -180,10 +190,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void render_kernel(NetParams P, S
         ++nSteps;
         nValid += valid ? 1u : 0u;
 
-        const float wx = ox + dx * t, wy = oy + dy * t, wz = oz + dz * t;
-        const float px = (wx - P.boxMin[0]) * P.invBoxSize[0];
-        const float py = (wy - P.boxMin[1]) * P.invBoxSize[1];
-        const float pz = (wz - P.boxMin[2]) * P.invBoxSize[2];
+        const float px = fmaf(dnx, t, pn0x), py = fmaf(dny, t, pn0y), pz = fmaf(dnz, t, pn0z);
         const float4_t o = srn_forward<CD, ACT, HAS_GRID, HAS_DIR>(P, lds, px, py, pz, dx, dy, dz);
 
         float4_t color = {0, 0, 0, 0};
@@ -205,16 +212,18 @@ __global__ __launch_bounds__(kBlockThreads, 2) void render_kernel(NetParams P, S
             if (requireNormal) color = tf_eval(S, tfLds, density2);
         }
         if (color[3] > 0.f && valid) {  // BRDF Lambert without Phong / magnitude scaling passes through
-            // safeNormalize (helper_math.cuh:2443-2448)
-            const float l2 = gx * gx + gy * gy + gz * gz;
-            if (l2 >= 1e-8f) { const float il = rsqrtf(l2); gx *= il; gy *= il; gz *= il; }
             // Blending::eval (renderer_blending.cuh:35-51)
             const float a = S.blendMode == FVSRN_BLEND_BEER_LAMBERT ? 1.f - __expf(-color[3]) : fminf(1.f, color[3]);
             const float w = (1.f - ca) * a;
             cr += w * color[0]; cg += w * color[1]; cb += w * color[2];
-            nx += w * gx; ny += w * gy; nz += w * gz;
             depth += w * t;
             ca += w;
+            if (gradNet) {  // wave-uniform: only networks that predict gradients carry a normal
+                // safeNormalize (helper_math.cuh:2443-2448)
+                const float l2 = gx * gx + gy * gy + gz * gz;
+                if (l2 >= 1e-8f) { const float il = rsqrtf(l2); gx *= il; gy *= il; gz *= il; }
+                nx += w * gx; ny += w * gy; nz += w * gz;
+            }
         }
     }
 

@@ -7,6 +7,8 @@ namespace fvsrn {
         case 2: return expr_prefix<2>(__VA_ARGS__);  \
         case 3: return expr_prefix<3>(__VA_ARGS__);  \
         case 4: return expr_prefix<4>(__VA_ARGS__);  \
+        case 6: return expr_prefix<6>(__VA_ARGS__);  \
+        case 8: return expr_prefix<8>(__VA_ARGS__);  \
         default: break;                              \
     }
 

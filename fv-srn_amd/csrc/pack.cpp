@@ -60,7 +60,8 @@ void packLatentGrid(const SceneNetwork& net, PackedNetwork& out) {
                 throw Unsupported("all latent grids must share one resolution");
     const int Gt = lg.timeChannels(), Ge = lg.ensembleChannels(), G = Gt + Ge;
     out.gridX = X; out.gridY = Y; out.gridZ = Z; out.gridC = G;
-    out.grid.assign(size_t(X) * Y * Z * G, 0);
+    // decoded + time-blended values, [Z][Y][X][G] fp32 (host only)
+    std::vector<float> val(size_t(X) * Y * Z * G, 0.f);
 
     auto decode = [&](const LatentGrid& g, const LatentGrid& coeffs, int c, int z, int y, int x) {
         const float r = g.raw(c, z, y, x);
@@ -80,15 +81,27 @@ void packLatentGrid(const SceneNetwork& net, PackedNetwork& out) {
             for (int c = 0; c < Gt; ++c) {
                 const float a = decode(A, A, c, z, y, x);
                 const float b = decode(B, A, c, z, y, x);  // reference quirk: B decoded with A's coefficients
-                const float v = a + f * (b - a);
-                out.grid[((size_t(z) * Y + y) * X + x) * G + c] = float_to_half_bits(v);
+                val[((size_t(z) * Y + y) * X + x) * G + c] = a + f * (b - a);
             }
     }
     if (lg.hasEnsembleGrids()) {  // :1332-1350, no interpolation
         const LatentGrid& E = *lg.ensembleGrids[size_t(lg.interpolateEnsemble(net.currentEnsemble))];
         for (int z = 0; z < Z; ++z) for (int y = 0; y < Y; ++y) for (int x = 0; x < X; ++x)
-            for (int c = 0; c < Ge; ++c)
-                out.grid[((size_t(z) * Y + y) * X + x) * G + Gt + c] = float_to_half_bits(decode(E, E, c, z, y, x));
+            for (int c = 0; c < Ge; ++c) val[((size_t(z) * Y + y) * X + x) * G + Gt + c] = decode(E, E, c, z, y, x);
+    }
+
+    // Device layout: x-pair records.  Record (z, y, xi), xi = floor(texel x) + 1 in [0, X], holds for every channel
+    // the two x-neighbours a linear fetch at that x needs, clamp addressing already applied:
+    //   [Z][Y][X+1][G][2] fp16 = { v(clamp(xi-1)), v(clamp(xi)) }
+    // so one v_dot2_f32_f16 per channel does the x-lerp of a (z,y) row.
+    out.grid.assign(size_t(Z) * Y * (X + 1) * G * 2, 0);
+    for (int z = 0; z < Z; ++z) for (int y = 0; y < Y; ++y) for (int xi = 0; xi <= X; ++xi) {
+        const int xa = std::min(std::max(xi - 1, 0), X - 1), xb = std::min(std::max(xi, 0), X - 1);
+        for (int c = 0; c < G; ++c) {
+            uint16_t* rec = &out.grid[(((size_t(z) * Y + y) * (X + 1) + xi) * G + c) * 2];
+            rec[0] = float_to_half_bits(val[((size_t(z) * Y + y) * X + xa) * G + c]);
+            rec[1] = float_to_half_bits(val[((size_t(z) * Y + y) * X + xb) * G + c]);
+        }
     }
 }
 

@@ -54,6 +54,26 @@ __device__ __forceinline__ float act_f32(float x, float a, float b) {
     }
 }
 
+template <int ACT>
+__device__ __forceinline__ float2_t act_f32x2(float2_t x, float a, float b) {
+    if constexpr (ACT == ACT_SINE) {
+        const float2_t t = x * a;
+        return float2_t{__builtin_amdgcn_sinf(t[0]), __builtin_amdgcn_sinf(t[1])};
+    } else if constexpr (ACT == ACT_SNAKE) {
+        const float2_t t = x * a;
+        const float2_t c = {__builtin_amdgcn_cosf(t[0]), __builtin_amdgcn_cosf(t[1])};
+        const float2_t bb = {b, b};
+        return __builtin_elementwise_fma(-c, bb, x + bb);
+    } else if constexpr (ACT == ACT_SNAKEALT) {
+        const float2_t t = x * a;
+        const float2_t c = {__builtin_amdgcn_cosf(t[0]), __builtin_amdgcn_cosf(t[1])};
+        const float2_t bb = {b, b};
+        return __builtin_elementwise_fma(x - c, bb, bb);
+    } else {
+        return float2_t{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+    }
+}
+
 // 16 fp32 accumulator values of one M tile -> two B fragments (K steps 2m, 2m+1) with activation
 template <int ACT>
 __device__ __forceinline__ void act_pack(const floatx16& d, float a, float b, half8_t& f0, half8_t& f1) {
@@ -72,12 +92,13 @@ __device__ __forceinline__ void act_pack(const floatx16& d, float a, float b, ha
             f1[2 * i] = h1[0]; f1[2 * i + 1] = h1[1];
         }
     } else {
+        // two values per instruction where the ISA has a packed fp32 form (v_pk_mul/add/fma_f32); cos/sin are scalar
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float2_t v0 = {act_f32<ACT>(d[2 * i], a, b), act_f32<ACT>(d[2 * i + 1], a, b)};
-            float2_t v1 = {act_f32<ACT>(d[8 + 2 * i], a, b), act_f32<ACT>(d[8 + 2 * i + 1], a, b)};
-            half2_t h0 = __builtin_convertvector(v0, half2_t);
-            half2_t h1 = __builtin_convertvector(v1, half2_t);
+            const float2_t x0 = {d[2 * i], d[2 * i + 1]};
+            const float2_t x1 = {d[8 + 2 * i], d[8 + 2 * i + 1]};
+            const half2_t h0 = __builtin_convertvector(act_f32x2<ACT>(x0, a, b), half2_t);
+            const half2_t h1 = __builtin_convertvector(act_f32x2<ACT>(x1, a, b), half2_t);
             f0[2 * i] = h0[0]; f0[2 * i + 1] = h0[1];
             f1[2 * i] = h1[0]; f1[2 * i + 1] = h1[1];
         }
@@ -100,36 +121,77 @@ __device__ __forceinline__ floatx16 lds_bias(const char* lds, int byteOff, int h
     return c;
 }
 
-// trilinear latent features: 8 channels [16*g + 8*h, +8) of the sample at normalized position p,
-// texture semantics of the reference (normalized coords, clamp, linear; :581-596):
-// texel coordinate = p*N - 0.5.
-__device__ __forceinline__ half8_t grid_features(const NetParams& P, float px, float py, float pz, int g, int h) {
+// ---- latent grid ------------------------------------------------------------------------------------------
+// Texture semantics of the reference (normalized coords, clamp addressing, linear filter;
+// renderer_volume_tensorcores.cuh:581-596, volume_interpolation_network.cpp:495-503): texel coordinate = p*N - 0.5.
+// The working grid is stored as x-pair records (pack.cpp), so a trilinear fetch of one channel is 4 x
+// v_dot2_f32_f16: record (z,y) holds {v(x0), v(x0+1)} and the packed fp16 weight pair is
+// {w_zy*(1-wx), w_zy*wx}.  (fp16 filter weights: 11 bits; CUDA texture units filter with 8 fractional bits.)
+struct GridTap {
+    unsigned off[4];  // byte offsets of the 4 (z,y) records of this sample (channel 0)
+    unsigned w[4];    // packed fp16 weight pairs
+};
+
+__device__ __forceinline__ GridTap grid_tap(const NetParams& P, float px, float py, float pz) {
     const float fx = px * float(P.gridX) - 0.5f, fy = py * float(P.gridY) - 0.5f, fz = pz * float(P.gridZ) - 0.5f;
     const float x0f = floorf(fx), y0f = floorf(fy), z0f = floorf(fz);
     const float wx = fx - x0f, wy = fy - y0f, wz = fz - z0f;
-    const int x0 = min(max(int(x0f), 0), P.gridX - 1), x1 = min(max(int(x0f) + 1, 0), P.gridX - 1);
+    const int xi = min(max(int(x0f) + 1, 0), P.gridX);  // record index: x-clamping is baked into the records
     const int y0 = min(max(int(y0f), 0), P.gridY - 1), y1 = min(max(int(y0f) + 1, 0), P.gridY - 1);
     const int z0 = min(max(int(z0f), 0), P.gridZ - 1), z1 = min(max(int(z0f) + 1, 0), P.gridZ - 1);
-    const half8_t* base = reinterpret_cast<const half8_t*>(P.grid) + (2 * g + h);
-    const int cs = P.gridC >> 3;  // half8 per voxel
-    auto at = [&](int z, int y, int x) { return base[size_t((z * P.gridY + y) * P.gridX + x) * cs]; };
-    const half8_t v000 = at(z0, y0, x0), v001 = at(z0, y0, x1), v010 = at(z0, y1, x0), v011 = at(z0, y1, x1);
-    const half8_t v100 = at(z1, y0, x0), v101 = at(z1, y0, x1), v110 = at(z1, y1, x0), v111 = at(z1, y1, x1);
+    const unsigned rec = unsigned(P.gridC) * 4u;             // bytes per record: G channels x 2 x fp16
+    const unsigned row = unsigned(P.gridX + 1) * rec;
+    const unsigned xo = unsigned(xi) * rec;
+    GridTap t;
+    t.off[0] = unsigned(z0 * P.gridY + y0) * row + xo;
+    t.off[1] = unsigned(z0 * P.gridY + y1) * row + xo;
+    t.off[2] = unsigned(z1 * P.gridY + y0) * row + xo;
+    t.off[3] = unsigned(z1 * P.gridY + y1) * row + xo;
     const float ux = 1.f - wx, uy = 1.f - wy, uz = 1.f - wz;
-    const float w000 = uz * uy * ux, w001 = uz * uy * wx, w010 = uz * wy * ux, w011 = uz * wy * wx;
-    const float w100 = wz * uy * ux, w101 = wz * uy * wx, w110 = wz * wy * ux, w111 = wz * wy * wx;
+    const float w4[4] = {uz * uy, uz * wy, wz * uy, wz * wy};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float2_t v = {w4[k] * ux, w4[k] * wx};
+        t.w[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
+    }
+    return t;
+}
+
+// own-sample tap -> taps of sample (lane&31) of tile 0 / tile 1
+__device__ __forceinline__ void grid_tap_bcast(const GridTap& own, GridTap& t0, GridTap& t1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        auto a = __builtin_amdgcn_permlane32_swap(own.off[k], own.off[k], false, false);
+        t0.off[k] = a[0]; t1.off[k] = a[1];
+        auto b = __builtin_amdgcn_permlane32_swap(own.w[k], own.w[k], false, false);
+        t0.w[k] = b[0]; t1.w[k] = b[1];
+    }
+}
+
+// 8 channels [16*g + 8*h, +8) of the tile sample described by `t`, as the B fragment of latent K step g
+__device__ __forceinline__ half8_t grid_features(const NetParams& P, const GridTap& t, int g, int h) {
+    const char* base = reinterpret_cast<const char*>(P.grid) + (g * 64 + h * 32);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint4_t* p = reinterpret_cast<const uint4_t*>(base + t.off[k]);
+        const uint4_t v0 = p[0], v1 = p[1];
+        const half2_t w = __builtin_bit_cast(half2_t, t.w[k]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // NB: __builtin_bit_cast applied directly to a vector ELEMENT (v0[j]) is miscompiled by clang 22 /
+            // ROCm 7.2 (only element 0 survives): go through a scalar temporary
+            const unsigned u0 = v0[j], u1 = v1[j];
+            acc[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u0), w, acc[j], false);
+            acc[4 + j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u1), w, acc[4 + j], false);
+        }
+    }
     half8_t out;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float a = float(v000[j]) * w000;
-        a = fmaf(float(v001[j]), w001, a);
-        a = fmaf(float(v010[j]), w010, a);
-        a = fmaf(float(v011[j]), w011, a);
-        a = fmaf(float(v100[j]), w100, a);
-        a = fmaf(float(v101[j]), w101, a);
-        a = fmaf(float(v110[j]), w110, a);
-        a = fmaf(float(v111[j]), w111, a);
-        out[j] = _Float16(a);
+    for (int i = 0; i < 4; ++i) {
+        const float2_t v = {acc[2 * i], acc[2 * i + 1]};
+        const half2_t hh = __builtin_convertvector(v, half2_t);
+        out[2 * i] = hh[0]; out[2 * i + 1] = hh[1];
     }
     return out;
 }
@@ -149,11 +211,23 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
     const int h = lane >> 5;
     const float actA = P.actA, actB = P.actB;
 
-    // tile positions
-    float tp[2][3];
-    tile_bcast(px, tp[0][0], tp[1][0]);
-    tile_bcast(py, tp[0][1], tp[1][1]);
-    tile_bcast(pz, tp[0][2], tp[1][2]);
+    // Positions of the two sample tiles.  Without a latent grid only their fp16 images are needed: convert first
+    // (one v_cvt_pk per coordinate, both halves = the hi/lo slot pair of the phase matrix), then exchange.
+    unsigned tph[2][3];
+    {
+        const float pp[3] = {px, py, pz};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float2_t v = {pp[i], pp[i]};
+            const half2_t hh = __builtin_convertvector(v, half2_t);
+            const unsigned u = __builtin_bit_cast(unsigned, hh);
+            auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            tph[0][i] = r[0];
+            tph[1][i] = r[1];
+        }
+    }
+    GridTap gt[2];
+    if constexpr (HAS_GRID) grid_tap_bcast(grid_tap(P, px, py, pz), gt[0], gt[1]);
     float td[2][3] = {{0, 0, 0}, {0, 0, 0}};
     if constexpr (HAS_DIR) {
         tile_bcast(dx, td[0][0], td[1][0]);
@@ -168,14 +242,17 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
     for (int t = 0; t < 2; ++t) {
         half8_t b0;
         if constexpr (HAS_DIR) {
-            const float sx = h ? td[t][0] : tp[t][0], sy = h ? td[t][1] : tp[t][1], sz = h ? td[t][2] : tp[t][2];
-            const _Float16 hx = _Float16(sx), hy = _Float16(sy), hz = _Float16(sz);
-            b0 = half8_t{hx, hx, hy, hy, hz, hz, h ? _Float16(0) : _Float16(1), _Float16(0)};
+            const float2_t vx = {td[t][0], td[t][0]}, vy = {td[t][1], td[t][1]}, vz = {td[t][2], td[t][2]};
+            const unsigned dxh = __builtin_bit_cast(unsigned, __builtin_convertvector(vx, half2_t));
+            const unsigned dyh = __builtin_bit_cast(unsigned, __builtin_convertvector(vy, half2_t));
+            const unsigned dzh = __builtin_bit_cast(unsigned, __builtin_convertvector(vz, half2_t));
+            const uint4_t u = {h ? dxh : tph[t][0], h ? dyh : tph[t][1], h ? dzh : tph[t][2], h ? 0u : 0x00003c00u};
+            b0 = __builtin_bit_cast(half8_t, u);
         } else {
-            const _Float16 hx = _Float16(tp[t][0]), hy = _Float16(tp[t][1]), hz = _Float16(tp[t][2]);
-            const half8_t v = {hx, hx, hy, hy, hz, hz, _Float16(1), _Float16(0)};
-            const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-            b0 = h ? z : v;
+            // lane half 1 supplies K slots 8..15, whose phase-matrix entries are all zero: its B values are
+            // multiplied by 0 and only need to be finite, so no select is needed
+            const uint4_t u = {tph[t][0], tph[t][1], tph[t][2], 0x00003c00u /* (1.0h, 0) */};
+            b0 = __builtin_bit_cast(half8_t, u);
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -230,8 +307,8 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
         if constexpr (HAS_GRID) {
             if (l == 0) {
                 for (int g = 0; g < P.gridK; ++g) {
-                    const half8_t g0 = grid_features(P, tp[0][0], tp[0][1], tp[0][2], g, h);
-                    const half8_t g1 = grid_features(P, tp[1][0], tp[1][1], tp[1][2], g, h);
+                    const half8_t g0 = grid_features(P, gt[0], g, h);
+                    const half8_t g1 = grid_features(P, gt[1], g, h);
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const half8_t a = lds_frag(lds, wOff + (m * ks + KS + g) * kFragBytes, lane);

@@ -236,3 +236,23 @@ def test_errors_are_reported():
         scene.render(net, 16, 16)
     with pytest.raises(capi.FvsrnError):
         capi.Scene(**make_scene_kwargs(tf_kind=oracle.TF_NONE)).render(net, 16, 16, 4, 40)
+
+
+@pytest.mark.parametrize("world,stripe", [(2, 8), (4, 16), (8, 16)])
+def test_stripe_render_of_every_rank_composes_the_frame(world, stripe):
+    """fvsrn_render_stripes: the compact stripe images of all ranks, assembled like the RCCL all-gather would,
+    equal the single-GPU frame bit for bit (all 'ranks' run on this one GPU)."""
+    import torch
+    from fvsrn_amd import capi, tiles, volnet_io
+    vn = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode="density", seed=9, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4)
+    kw = make_scene_kwargs(tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=30.0)
+    W, H = 72, stripe * world * 2
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    scene = capi.Scene(**kw)
+    full = scene.render(net, W, H)
+    parts = [capi.render_stripes(scene, net, W, H, stripe, r, world) for r in range(world)]
+    torch.cuda.synchronize()
+    frame = tiles.assemble(torch.stack(parts), H, stripe)
+    assert torch.equal(torch.nan_to_num(full, nan=-1.0), torch.nan_to_num(frame, nan=-1.0))
+    for r in range(world):
+        assert parts[r].shape[1] == len(tiles.owned_rows(H, stripe, r, world))
