@@ -1,7 +1,9 @@
 // C ABI of libfvsrn.so (see include/fvsrn.h for the reference interfaces each entry replaces).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -9,10 +11,25 @@
 #include "../../include/fvsrn.h"
 #include "half.hpp"
 #include "launch.hpp"
+#include "srn_device_enums.hpp"
 #include "pack.hpp"
 #include "scene_network.hpp"
 
 using namespace fvsrn;
+
+// Waves per workgroup: as few as the LDS budget allows.  16 waves per CU (4 per SIMD) must fit their network copies
+// into the 160 KiB of LDS; a workgroup's slot is only recycled when its slowest wave is done, so fewer waves per
+// workgroup = better balance between long and empty pixel tiles (measured r01: 1 wave 110.8, 4 waves 92.3 Gsamples/s).
+static int wavesPerBlockFor(size_t ldsBytesPerBlock) {
+    if (const char* e = std::getenv("FVSRN_WAVES_PER_BLOCK")) {
+        const int w = std::atoi(e);
+        if (w == 1 || w == 2 || w == 4) return w;
+    }
+    const size_t budget = 160 * 1024;
+    for (int w : {1, 2, 4})
+        if (size_t(16 / w) * ldsBytesPerBlock <= budget) return w;
+    return 4;
+}
 
 namespace {
 thread_local std::string g_lastError;
@@ -82,9 +99,12 @@ struct fvsrn_network {
     // device image (lazy; invalidated by any mutation)
     bool deviceValid = false;
     PackedNetwork packed;
-    DeviceBuffer dLds, dGrid;
-    VariantKey key{};
-    KernelInfo kinfo{};
+    DeviceBuffer dLds, dLdsScaled, dGrid, dKeysTime, dKeysEns, dCoeffs;
+    const void* scaledImage = nullptr;
+    bool timeDirty = true;  // working grid / time slot do not match net->currentTime yet
+    VariantKey key{};       // plain image
+    VariantKey keyScaled{};  // ReLU networks: [0,1]-scaled image (render only)
+    KernelInfo kinfo{}, kinfoScaled{};
     int numCUs = 0;
     std::mutex mu;
 
@@ -100,6 +120,12 @@ struct fvsrn_network {
             throw Unsupported("no ahead-of-time kernel for hidden width " + std::to_string(packed.cfg.hiddenChannels) +
                               ", activation " + activationName(packed.cfg.activation) +
                               (key.dir ? ", with view direction" : "") + " (compiled: widths 32/48/64/96/128, no view direction)");
+        keyScaled = key;
+        kinfoScaled = kinfo;
+        if (!packed.ldsImageScaled.empty() && !std::getenv("FVSRN_DISABLE_RELU_CLAMP")) {
+            keyScaled.act = ACT_RELU01;
+            if (!kernel_info(keyScaled, &kinfoScaled)) throw Unsupported("scaled-ReLU kernel variant missing");
+        }
     }
 
     void ensureDevice(hipStream_t stream) {
@@ -116,33 +142,134 @@ struct fvsrn_network {
         dLds.ensure(packed.ldsImage.size());
         HIP_CHECK(hipMemcpyAsync(dLds.ptr, packed.ldsImage.data(), packed.ldsImage.size(), hipMemcpyHostToDevice, stream));
         packed.params.ldsImage = dLds.ptr;
-        if (!packed.grid.empty()) {
-            dGrid.ensure(packed.grid.size() * 2);
-            HIP_CHECK(hipMemcpyAsync(dGrid.ptr, packed.grid.data(), packed.grid.size() * 2, hipMemcpyHostToDevice, stream));
+        packed.params.reluClamp = 0;
+        scaledImage = nullptr;
+        if (keyScaled.act == ACT_RELU01) {
+            dLdsScaled.ensure(packed.ldsImageScaled.size());
+            HIP_CHECK(hipMemcpyAsync(dLdsScaled.ptr, packed.ldsImageScaled.data(), packed.ldsImageScaled.size(), hipMemcpyHostToDevice, stream));
+            scaledImage = dLdsScaled.ptr;
+        }
+        // latent key frames: uploaded once and kept resident; the working grid is blended from them on the device
+        const GridKeyframes& K = packed.keys;
+        if (K.records) {
+            if (!K.timeData.empty()) {
+                dKeysTime.ensure(K.timeData.size());
+                HIP_CHECK(hipMemcpyAsync(dKeysTime.ptr, K.timeData.data(), K.timeData.size(), hipMemcpyHostToDevice, stream));
+            }
+            if (!K.ensData.empty()) {
+                dKeysEns.ensure(K.ensData.size());
+                HIP_CHECK(hipMemcpyAsync(dKeysEns.ptr, K.ensData.data(), K.ensData.size(), hipMemcpyHostToDevice, stream));
+            }
+            std::vector<float> coeffs;
+            for (const auto* v : {&K.timeOffset, &K.timeScale, &K.ensOffset, &K.ensScale}) coeffs.insert(coeffs.end(), v->begin(), v->end());
+            dCoeffs.ensure(std::max<size_t>(coeffs.size(), 1) * 4);
+            if (!coeffs.empty()) HIP_CHECK(hipMemcpyAsync(dCoeffs.ptr, coeffs.data(), coeffs.size() * 4, hipMemcpyHostToDevice, stream));
+            dGrid.ensure(K.records * size_t(K.Gt + K.Ge) * 2 * 2);
             packed.params.grid = dGrid.ptr;
         } else {
             packed.params.grid = nullptr;
         }
+        timeDirty = true;
         // the staging vectors are pageable: the copies above complete before hipMemcpyAsync returns
         const size_t maxLds = packed.ldsImage.size() + 4096 + 256 * 6 * 4;
         HIP_CHECK(hipFuncSetAttribute(kinfo.evalFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
-        HIP_CHECK(hipFuncSetAttribute(kinfo.renderFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
+        HIP_CHECK(hipFuncSetAttribute(kinfoScaled.renderFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         deviceValid = true;
     }
 
+    // Brings the working grid and the time input of the network in line with net->currentTime/currentEnsemble:
+    // one small kernel + (networks that take the time as input) a 2-byte patch, both stream-ordered -- no host
+    // synchronisation, no re-upload (the reference re-fills its constant block and lazily uploads textures with a
+    // synchronous cudaMemcpy3D, volume_interpolation_network.cpp:482-488,923-938,1308-1315).
+    void syncTime(hipStream_t stream) {
+        if (!timeDirty) return;
+        const GridKeyframes& K = packed.keys;
+        if (K.records) {
+            const GridSelection g = selectGrid(*net);
+            BlendParams b{};
+            b.timeData = dKeysTime.ptr; b.ensData = dKeysEns.ptr;
+            const float* c = static_cast<const float*>(dCoeffs.ptr);
+            b.timeOffset = c; b.timeScale = c + K.timeOffset.size();
+            b.ensOffset = c + 2 * K.timeOffset.size(); b.ensScale = b.ensOffset + K.ensOffset.size();
+            b.out = dGrid.ptr; b.records = K.records; b.enc = int(K.enc); b.Gt = K.Gt; b.Ge = K.Ge;
+            b.lo = g.lo; b.hi = g.hi; b.ens = g.ens; b.frac = g.frac;
+            HIP_CHECK(launch_grid_blend(b, stream));
+            if (packed.timeSlotOffset >= 0) {
+                timeSlotStaging = float_to_half_bits(g.timeIndex);
+                HIP_CHECK(hipMemcpyAsync(static_cast<char*>(dLds.ptr) + packed.timeSlotOffset, &timeSlotStaging, 2, hipMemcpyHostToDevice, stream));
+                if (scaledImage)
+                    HIP_CHECK(hipMemcpyAsync(static_cast<char*>(dLdsScaled.ptr) + packed.timeSlotOffset, &timeSlotStaging, 2, hipMemcpyHostToDevice, stream));
+            }
+        }
+        timeDirty = false;
+    }
+    uint16_t timeSlotStaging = 0;
+
     ~fvsrn_network() {
         dLds.release();
+        dLdsScaled.release();
         dGrid.release();
+        dKeysTime.release();
+        dKeysEns.release();
+        dCoeffs.release();
     }
 };
+
+struct BoxCenter { float c[3]; };
+static BoxCenter P_boxCenter(const NetParams& P) {
+    return {{P.boxMin[0] + 0.5f * P.boxSize[0], P.boxMin[1] + 0.5f * P.boxSize[1], P.boxMin[2] + 0.5f * P.boxSize[2]}};
+}
 
 struct fvsrn_scene {
     fvsrn_scene_desc desc{};
     std::vector<float> tfTable;
-    DeviceBuffer dTf;
+    DeviceBuffer dTf, dOrder;
     bool tfDirty = true;
     std::mutex mu;
-    ~fvsrn_scene() { dTf.release(); }
+    // cached launch order of the 8x8 pixel tiles
+    struct OrderKey { int tilesX = -1, tilesY = -1, cx = 0, cy = 0, y0 = 0, stripeRows = 0, stripeRank = 0, stripeWorld = 0; } orderKey;
+    std::vector<int> order;
+    ~fvsrn_scene() { dTf.release(); dOrder.release(); }
+
+    // Tiles sorted by distance from the projection of the box centre: rays through the middle of the box are the
+    // longest, rays that miss it cost one iteration.  The hardware dispatches workgroups in index order, so the
+    // expensive tiles start first and the cheap ones fill the tail.  Pure scheduling: any order gives the same image.
+    const int* tileOrder(const SceneParams& S, const BoxCenter& bc, int tilesX, int tilesY, hipStream_t stream) {
+        const float v[3] = {bc.c[0] - S.eye[0], bc.c[1] - S.eye[1], bc.c[2] - S.eye[2]};
+        const float zf = v[0] * S.front[0] + v[1] * S.front[1] + v[2] * S.front[2];
+        float px = 0.5f * S.width, py = 0.5f * S.height;
+        if (zf > 1e-6f) {
+            const float xr = v[0] * S.right[0] + v[1] * S.right[1] + v[2] * S.right[2];
+            const float yu = v[0] * S.up[0] + v[1] * S.up[1] + v[2] * S.up[2];
+            px = (xr / (zf * S.tanFovX) + 1.f) * 0.5f * S.width;
+            py = (yu / (zf * S.tanFovY) + 1.f) * 0.5f * S.height;
+        }
+        OrderKey k;
+        k.tilesX = tilesX; k.tilesY = tilesY;
+        k.cx = int(std::floor(px / 8.f)); k.cy = int(std::floor(py / 8.f));
+        k.y0 = S.y0; k.stripeRows = S.stripeRows; k.stripeRank = S.stripeRank; k.stripeWorld = S.stripeWorld;
+        if (std::memcmp(&k, &orderKey, sizeof(k)) != 0 || order.empty()) {
+            const int n = tilesX * tilesY;
+            std::vector<std::pair<float, int>> keyed(static_cast<size_t>(n));
+            for (int ty = 0; ty < tilesY; ++ty) {
+                const int l = ty * 8;  // first local row of the tile -> image row (same mapping as the kernel)
+                const int y = S.y0 + ((l / S.stripeRows) * S.stripeWorld + S.stripeRank) * S.stripeRows + l % S.stripeRows;
+                const float dy = (float(y) + 4.f) - py;
+                for (int tx = 0; tx < tilesX; ++tx) {
+                    const float dx = (float(tx * 8) + 4.f) - px;
+                    keyed[size_t(ty * tilesX + tx)] = {dx * dx + dy * dy, ty * tilesX + tx};
+                }
+            }
+            std::sort(keyed.begin(), keyed.end());
+            order.resize(size_t(n));
+            for (int i = 0; i < n; ++i) order[size_t(i)] = keyed[size_t(i)].second;
+            dOrder.ensure(size_t(n) * sizeof(int));
+            if (hipMemcpyAsync(dOrder.ptr, order.data(), size_t(n) * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess)
+                return nullptr;
+            orderKey = k;
+        }
+        return static_cast<const int*>(dOrder.ptr);
+    }
 };
 
 static int tfCols(int kind) {
@@ -299,7 +426,7 @@ int fvsrn_network_set_time_and_ensemble(fvsrn_network* net, float time, int ense
         if (!net) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null network");
         std::lock_guard<std::mutex> lock(net->mu);
         net->net->setTimeAndEnsemble(time, ensemble);
-        net->invalidate();
+        net->timeDirty = true;  // key frames stay resident; the next launch re-blends on the device
         return FVSRN_OK;
     });
 }
@@ -310,7 +437,11 @@ int fvsrn_network_clear_gpu_resources(fvsrn_network* net) {
         std::lock_guard<std::mutex> lock(net->mu);
         net->invalidate();
         net->dLds.release();
+        net->dLdsScaled.release();
         net->dGrid.release();
+        net->dKeysTime.release();
+        net->dKeysEns.release();
+        net->dCoeffs.release();
         return FVSRN_OK;
     });
 }
@@ -391,7 +522,7 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
         if (!net || !buf || cap == 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
         std::lock_guard<std::mutex> lock(net->mu);
         net->pack();
-        const char* name = render ? net->kinfo.renderName : net->kinfo.evalName;
+        const char* name = render ? net->kinfoScaled.renderName : net->kinfo.evalName;
         std::strncpy(buf, name, cap - 1);
         buf[cap - 1] = 0;
         return FVSRN_OK;
@@ -407,6 +538,7 @@ int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const fl
         try {
             hipStream_t s = static_cast<hipStream_t>(stream);
             net->ensureDevice(s);
+            net->syncTime(s);
             if (n == 0) return FVSRN_OK;
             if (net->key.dir && !d_directions)
                 return fail(FVSRN_ERR_INVALID_ARGUMENT, "the network uses the view direction, but no directions were given");
@@ -414,9 +546,10 @@ int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const fl
             if (!(flags & FVSRN_EVAL_WORLD_POSITIONS))  // volume_interpolation.cpp:46-49: box := [0,1]^3
                 for (int i = 0; i < 3; ++i) { a.P.boxMin[i] = 0.f; a.P.boxSize[i] = 1.f; a.P.invBoxSize[i] = 1.f; }
             const size_t batches = (n + 63) / 64;
-            const size_t blocks = (batches + 3) / 4;
-            const unsigned grid = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 8));
-            const hipError_t e = launch_eval(net->key, a, grid, size_t(net->packed.params.ldsBytes), s);
+            const size_t wpb = size_t(wavesPerBlockFor(size_t(net->packed.params.ldsBytes)));
+            const size_t blocks = (batches + wpb - 1) / wpb;
+            const unsigned grid = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 32 / wpb));
+            const hipError_t e = launch_eval(net->key, a, grid, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during evaluation! ") + hipGetErrorString(e));
             return FVSRN_OK;
         } catch (const DeviceError& e) {
@@ -523,6 +656,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
         try {
             hipStream_t s = static_cast<hipStream_t>(stream);
             net->ensureDevice(s);
+            net->syncTime(s);
             const fvsrn_scene_desc& d = scene->desc;
             const NetworkConfig& c = net->packed.cfg;
             const bool rgbo = c.outputMode == FVSRN_OUT_RGBO || c.outputMode == FVSRN_OUT_RGBO_DIRECT;
@@ -543,6 +677,10 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             }
             RenderArgs a{};
             a.P = net->packed.params;
+            if (net->scaledImage) {  // ReLU network: image with activations scaled into [0,1] (pack.cpp)
+                a.P.ldsImage = net->scaledImage;
+                a.P.reluClamp = 1;
+            }
             SceneParams& S = a.S;
             for (int i = 0; i < 3; ++i) { S.eye[i] = d.cam_eye[i]; S.right[i] = d.cam_right[i]; S.up[i] = d.cam_up[i]; }
             // front = cross(up, right), renderer_camera.cuh:47
@@ -567,10 +705,19 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             S.stripeWorld = stripeWorld; S.compact = compact;
             a.out = d_out8;
             a.stats = d_stats;
-            const int tiles = ((width + 7) / 8) * ((numLocalRows + 7) / 8);
-            const unsigned grid = unsigned((tiles + 3) / 4);
+            const int tilesX = (width + 7) / 8, tilesY = (numLocalRows + 7) / 8;
+            const int tiles = tilesX * tilesY;
             const size_t lds = size_t(a.P.ldsBytes) + tfFloats * 4;
-            const hipError_t e = launch_render(net->key, a, grid, lds, s);
+            const int wpb = wavesPerBlockFor(lds);
+            const unsigned grid = unsigned((tiles + wpb - 1) / wpb);
+            // Launch order of the pixel tiles.  Measured (r01, 1024^2 x 512): centre-first helps whenever a workgroup
+            // holds several waves or the kernel waits on memory (latent grid): 64x6+grid 18.5 -> 21.1, 32x4+grid 58.5 ->
+            // 61.0 Gsamples/s; the one-wave-per-workgroup Fourier-only kernel is faster in raster order (107 -> 114):
+            // there the equally long centre tiles would all start together and march through MFMA / VALU phases in step.
+            const char* ord = std::getenv("FVSRN_TILE_ORDER");  // "0" / "1" force, unset = heuristic
+            const bool useOrder = ord ? ord[0] == '1' : (wpb > 1 || net->key.grid);
+            S.tileOrder = useOrder ? scene->tileOrder(S, P_boxCenter(a.P), tilesX, tilesY, s) : nullptr;
+            const hipError_t e = launch_render(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during rendering! ") + hipGetErrorString(e));
             return FVSRN_OK;
         } catch (const DeviceError& e) {

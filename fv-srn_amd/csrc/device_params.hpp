@@ -22,6 +22,7 @@ struct NetParams {
     int outputMode;        // fvsrn_output_mode
     int offPhase, offLayer0, offHidden, offLast, offBias;  // byte offsets into the LDS image
     int fourierNeedsFract;  // |phase| may exceed the v_cos_f32 domain of 256 revolutions
+    int reluClamp;          // ldsImage is the [0,1]-scaled ReLU image: convert+ReLU is one clamped v_cvt_pk_f16_f32
     float actA, actB;       // activation constants, see act() in srn_device.hpp
     float boxMin[3];
     float boxSize[3];
@@ -47,6 +48,7 @@ struct SceneParams {
     // (stripeWorld == 1: the contiguous range [y0,y1)); compact != 0 writes a [8][numLocalRows][width] image
     int width, height, y0, y1;
     int numLocalRows, stripeRows, stripeRank, stripeWorld, compact;
+    const int* tileOrder;  // device pointer: permutation of the 8x8 pixel tiles of this launch, or null
 };
 
 }  // namespace fvsrn

@@ -4,17 +4,22 @@
 
 namespace fvsrn {
 
-constexpr int kBlockThreads = 256;  // 4 waves share one LDS copy of the network
+#ifndef FVSRN_WAVES_PER_EU
+#define FVSRN_WAVES_PER_EU 2
+#endif
+// Workgroups are 1..4 waves (blockDim.x = 64..256, chosen by the host from the LDS footprint of the network): the
+// waves of a workgroup share one LDS copy of the network, and a workgroup's resources are only recycled when its
+// slowest wave (= longest ray of 4 pixel tiles) is done, so small networks run one wave per workgroup.
+constexpr int kBlockThreads = 256;  // upper bound (launch bounds)
 // __launch_bounds__(256, 2): at most 256 registers per lane, which also makes hipcc use the VGPR form of the MFMA
 // (accumulators in AGPRs cost one v_accvgpr_read per value before the VALU can touch them: +32 VALU per layer).
 // C = 128 needs more than 256 registers and takes the 512-register budget instead.
-constexpr int kWavesPerBlock = kBlockThreads / 64;
 
 __device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* lds) {
     const uint4_t* src = reinterpret_cast<const uint4_t*>(P.ldsImage);
     uint4_t* dst = reinterpret_cast<uint4_t*>(lds);
     const int n = P.ldsBytes >> 4;
-    for (int i = threadIdx.x; i < n; i += kBlockThreads) dst[i] = src[i];
+    for (int i = threadIdx.x; i < n; i += int(blockDim.x)) dst[i] = src[i];
     __syncthreads();
 }
 
@@ -22,14 +27,15 @@ __device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* ld
 // EvaluateNoBatches (reference renderer/renderer_volume_kernels1.cuh:15): positions -> network value
 // ------------------------------------------------------------------------------------------------
 template <int CD, int ACT, bool HAS_GRID, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : 2)) void evaluate_kernel(NetParams P, const float* __restrict__ pos,
+__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) void evaluate_kernel(NetParams P, const float* __restrict__ pos,
                                                                  const float* __restrict__ dir, size_t n,
                                                                  float* __restrict__ out, int outChannels) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     load_network_to_lds(P, lds);
     const int lane = lane_id();
-    const size_t wave = size_t(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
-    const size_t numWaves = size_t(gridDim.x) * kWavesPerBlock;
+    const size_t wavesPerBlock = blockDim.x >> 6;
+    const size_t wave = size_t(blockIdx.x) * wavesPerBlock + (threadIdx.x >> 6);
+    const size_t numWaves = size_t(gridDim.x) * wavesPerBlock;
     const size_t batches = (n + 63) / 64;
     for (size_t b = wave; b < batches; b += numWaves) {  // wave-uniform trip count: EXEC stays full
         const size_t i = b * 64 + lane;
@@ -125,7 +131,7 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // the reference's __any_sync loop: all 64 lanes evaluate the network until no lane is valid.
 // ------------------------------------------------------------------------------------------------
 template <int CD, int ACT, bool HAS_GRID, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : 2)) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     load_network_to_lds(P, lds);
@@ -133,15 +139,18 @@ __global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : 2)) void render_kerne
     float* tfLds = reinterpret_cast<float*>(lds + P.ldsBytes);
     {
         const int cols = S.tfKind == FVSRN_TF_GAUSSIAN ? 6 : (S.tfKind == FVSRN_TF_PIECEWISE ? 5 : (S.tfKind == FVSRN_TF_TEXTURE ? 4 : 0));
-        for (int i = threadIdx.x; i < cols * S.tfRows; i += kBlockThreads) tfLds[i] = S.tfTable[i];
+        for (int i = threadIdx.x; i < cols * S.tfRows; i += int(blockDim.x)) tfLds[i] = S.tfTable[i];
         __syncthreads();
     }
 
     const int lane = lane_id();
     const int tilesX = (S.width + 7) >> 3;
     const int tilesY = (S.numLocalRows + 7) >> 3;
-    const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (tile >= tilesX * tilesY) return;  // whole wave leaves together
+    const int slot = blockIdx.x * int(blockDim.x >> 6) + int(threadIdx.x >> 6);
+    if (slot >= tilesX * tilesY) return;  // whole wave leaves together
+    // launch slot -> pixel tile: the host orders tiles by expected ray length (centre of the projected box first), so
+    // the long tiles start first and the empty ones fill the tail of the launch
+    const int tile = S.tileOrder ? S.tileOrder[slot] : slot;
     const int tx = tile % tilesX, ty = tile / tilesX;
     const int x = tx * 8 + (lane & 7);
     const int lrow = ty * 8 + (lane >> 3);

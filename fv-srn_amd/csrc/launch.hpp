@@ -38,11 +38,24 @@ struct KernelInfo {
 
 // implemented per CD in kernels_cd*.hip; returns false if the variant is not compiled in
 template <int CD> bool kernel_info_cd(const VariantKey& k, KernelInfo* info);
-template <int CD> hipError_t launch_eval_cd(const VariantKey& k, const EvalArgs& a, unsigned gridDim, size_t ldsBytes, hipStream_t s);
-template <int CD> hipError_t launch_render_cd(const VariantKey& k, const RenderArgs& a, unsigned gridDim, size_t ldsBytes, hipStream_t s);
+template <int CD> hipError_t launch_eval_cd(const VariantKey& k, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
+template <int CD> hipError_t launch_render_cd(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
+
+// decode + A/B time blend of the resident latent key frames into the fp16 working grid (pack.cpp, packLatentGrid)
+struct BlendParams {
+    const void* timeData;  // [timeNum][records][Gt][2] fp32 | uint8
+    const void* ensData;   // [ensNum][records][Ge][2]
+    const float* timeOffset; const float* timeScale;  // [timeNum][Gt]
+    const float* ensOffset; const float* ensScale;    // [ensNum][Ge]
+    void* out;             // fp16 [records][Gt+Ge][2]
+    unsigned long long records;
+    int enc, Gt, Ge, lo, hi, ens;
+    float frac;
+};
+hipError_t launch_grid_blend(const BlendParams& p, hipStream_t s);
 
 bool kernel_info(const VariantKey& k, KernelInfo* info);
-hipError_t launch_eval(const VariantKey& k, const EvalArgs& a, unsigned gridDim, size_t ldsBytes, hipStream_t s);
-hipError_t launch_render(const VariantKey& k, const RenderArgs& a, unsigned gridDim, size_t ldsBytes, hipStream_t s);
+hipError_t launch_eval(const VariantKey& k, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
+hipError_t launch_render(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 
 }  // namespace fvsrn

@@ -44,8 +44,31 @@ void putFrag(std::vector<char>& img, size_t off, const Frag& f) { std::memcpy(im
 
 }  // namespace
 
+GridSelection selectGrid(const SceneNetwork& net) {
+    // volume_interpolation_network.cpp:1308-1315 (time) and :1332-1334 (ensemble)
+    GridSelection g{};
+    if (!net.latentGrid) return g;
+    const LatentGridTimeAndEnsemble& lg = *net.latentGrid;
+    if (lg.hasTimeGrids()) {
+        const float time = lg.interpolateTime(net.currentTime);
+        g.timeIndex = time;
+        g.lo = std::min(int(time), lg.timeNum - 1);
+        g.hi = std::min(g.lo + 1, lg.timeNum - 1);
+        g.frac = time - std::floor(time);
+    }
+    if (lg.hasEnsembleGrids()) g.ens = lg.interpolateEnsemble(net.currentEnsemble);
+    return g;
+}
+
+// Key-frame store for the device.  Every key frame is re-laid-out ONCE into x-pair records
+//   [Z][Y][X+1][Gc][2] = { v(clamp(xi-1)), v(clamp(xi)) },  xi = floor(texel x) + 1 in [0, X]
+// (clamp addressing baked in, so one v_dot2_f32_f16 per channel does the x-lerp of a (z,y) row) and stays RAW
+// (fp32 values or bytes): decoding and the A/B time blend happen on the device (grid_blend_kernel), because the
+// reference decodes key frame B with A's coefficients (renderer_volume_tensorcores.cuh:586-587).
 void packLatentGrid(const SceneNetwork& net, PackedNetwork& out) {
-    out.grid.clear();
+    GridKeyframes& K = out.keys;
+    K = GridKeyframes{};
+    out.gridMaxAbs.clear();
     out.gridX = out.gridY = out.gridZ = out.gridC = 0;
     if (!net.latentGrid) return;
     const LatentGridTimeAndEnsemble& lg = *net.latentGrid;
@@ -60,49 +83,50 @@ void packLatentGrid(const SceneNetwork& net, PackedNetwork& out) {
                 throw Unsupported("all latent grids must share one resolution");
     const int Gt = lg.timeChannels(), Ge = lg.ensembleChannels(), G = Gt + Ge;
     out.gridX = X; out.gridY = Y; out.gridZ = Z; out.gridC = G;
-    // decoded + time-blended values, [Z][Y][X][G] fp32 (host only)
-    std::vector<float> val(size_t(X) * Y * Z * G, 0.f);
+    K.enc = enc; K.X = X; K.Y = Y; K.Z = Z; K.Gt = Gt; K.Ge = Ge;
+    K.timeNum = lg.hasTimeGrids() ? lg.timeNum : 0;
+    K.ensNum = lg.hasEnsembleGrids() ? lg.ensembleNum : 0;
+    K.records = size_t(Z) * Y * (X + 1);
+    const size_t esz = enc == FVSRN_GRID_FLOAT ? 4 : 1;
+    out.gridMaxAbs.assign(size_t(G), 0.f);
 
-    auto decode = [&](const LatentGrid& g, const LatentGrid& coeffs, int c, int z, int y, int x) {
-        const float r = g.raw(c, z, y, x);
-        if (enc == FVSRN_GRID_FLOAT) return r;
-        return coeffs.gridOffsetOrMean[size_t(c)] + r * coeffs.gridScaleOrStd[size_t(c)];
-    };
-
-    if (lg.hasTimeGrids()) {
-        // volume_interpolation_network.cpp:1308-1329 + renderer_volume_tensorcores.cuh:581-591
-        const float time = lg.interpolateTime(net.currentTime);
-        const int lo = std::min(int(time), lg.timeNum - 1);
-        const int hi = std::min(lo + 1, lg.timeNum - 1);
-        const float f = time - std::floor(time);
-        const LatentGrid& A = *lg.timeGrids[size_t(lo)];
-        const LatentGrid& B = *lg.timeGrids[size_t(hi)];
-        for (int z = 0; z < Z; ++z) for (int y = 0; y < Y; ++y) for (int x = 0; x < X; ++x)
-            for (int c = 0; c < Gt; ++c) {
-                const float a = decode(A, A, c, z, y, x);
-                const float b = decode(B, A, c, z, y, x);  // reference quirk: B decoded with A's coefficients
-                val[((size_t(z) * Y + y) * X + x) * G + c] = a + f * (b - a);
+    auto layout = [&](const std::vector<std::shared_ptr<LatentGrid>>& grids, int Gc, int chanBase, std::vector<char>& data,
+                      std::vector<float>& off, std::vector<float>& scale, bool timeQuirk) {
+        data.assign(grids.size() * K.records * size_t(Gc) * 2 * esz, 0);
+        off.assign(grids.size() * size_t(Gc), 0.f);
+        scale.assign(grids.size() * size_t(Gc), 1.f);
+        for (size_t k = 0; k < grids.size(); ++k) {
+            const LatentGrid& g = *grids[k];
+            for (int c = 0; c < Gc; ++c) {
+                if (enc != FVSRN_GRID_FLOAT) { off[k * Gc + c] = g.gridOffsetOrMean[size_t(c)]; scale[k * Gc + c] = g.gridScaleOrStd[size_t(c)]; }
             }
-    }
-    if (lg.hasEnsembleGrids()) {  // :1332-1350, no interpolation
-        const LatentGrid& E = *lg.ensembleGrids[size_t(lg.interpolateEnsemble(net.currentEnsemble))];
-        for (int z = 0; z < Z; ++z) for (int y = 0; y < Y; ++y) for (int x = 0; x < X; ++x)
-            for (int c = 0; c < Ge; ++c) val[((size_t(z) * Y + y) * X + x) * G + Gt + c] = decode(E, E, c, z, y, x);
-    }
-
-    // Device layout: x-pair records.  Record (z, y, xi), xi = floor(texel x) + 1 in [0, X], holds for every channel
-    // the two x-neighbours a linear fetch at that x needs, clamp addressing already applied:
-    //   [Z][Y][X+1][G][2] fp16 = { v(clamp(xi-1)), v(clamp(xi)) }
-    // so one v_dot2_f32_f16 per channel does the x-lerp of a (z,y) row.
-    out.grid.assign(size_t(Z) * Y * (X + 1) * G * 2, 0);
-    for (int z = 0; z < Z; ++z) for (int y = 0; y < Y; ++y) for (int xi = 0; xi <= X; ++xi) {
-        const int xa = std::min(std::max(xi - 1, 0), X - 1), xb = std::min(std::max(xi, 0), X - 1);
-        for (int c = 0; c < G; ++c) {
-            uint16_t* rec = &out.grid[(((size_t(z) * Y + y) * (X + 1) + xi) * G + c) * 2];
-            rec[0] = float_to_half_bits(val[((size_t(z) * Y + y) * X + xa) * G + c]);
-            rec[1] = float_to_half_bits(val[((size_t(z) * Y + y) * X + xb) * G + c]);
+            char* base = data.data() + k * K.records * size_t(Gc) * 2 * esz;
+            for (int z = 0; z < Z; ++z) for (int y = 0; y < Y; ++y) for (int xi = 0; xi <= X; ++xi) {
+                const int xs[2] = {std::min(std::max(xi - 1, 0), X - 1), std::min(std::max(xi, 0), X - 1)};
+                for (int c = 0; c < Gc; ++c)
+                    for (int p = 0; p < 2; ++p) {
+                        const size_t i = (((size_t(z) * Y + y) * (X + 1) + xi) * Gc + c) * 2 + p;
+                        const size_t src = g.idx(c / 4, z, y, xs[p], c % 4);
+                        float r;
+                        if (enc == FVSRN_GRID_FLOAT) {
+                            r = reinterpret_cast<const float*>(g.grid.data())[src];
+                            reinterpret_cast<float*>(base)[i] = r;
+                        } else {
+                            const uint8_t b = reinterpret_cast<const uint8_t*>(g.grid.data())[src];
+                            reinterpret_cast<uint8_t*>(base)[i] = b;
+                            r = b / 255.0f;
+                        }
+                        // range of the decoded values, for the ReLU scaling: own coefficients, and (time grids) the
+                        // previous key frame's coefficients, which is what a blend with this frame as "B" uses
+                        float m = std::fabs(off[k * Gc + c] + r * scale[k * Gc + c]);
+                        if (timeQuirk && k > 0) m = std::max(m, std::fabs(off[(k - 1) * Gc + c] + r * scale[(k - 1) * Gc + c]));
+                        out.gridMaxAbs[size_t(chanBase + c)] = std::max(out.gridMaxAbs[size_t(chanBase + c)], m);
+                    }
+            }
         }
-    }
+    };
+    if (K.timeNum) layout(lg.timeGrids, Gt, 0, K.timeData, K.timeOffset, K.timeScale, true);
+    if (K.ensNum) layout(lg.ensembleGrids, Ge, Gt, K.ensData, K.ensOffset, K.ensScale, false);
 }
 
 PackedNetwork packNetwork(const SceneNetwork& net) {
@@ -181,41 +205,55 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
         putFrag(P.ldsImage, size_t(np.offPhase) + size_t(m) * kFragBytes, f);
     }
     np.fourierNeedsFract = maxPhase >= 255.0 ? 1 : 0;
+    // byte offset of the fp16 "time" entry inside the phase fragment (patched on the device when the time changes):
+    // channel 3 sits on row 5 (no direction) / row 3 (direction) of M tile 0, lane half 0, K slot 6
+    P.timeSlotOffset = c.passTime ? np.offPhase + (hasDir ? 3 : 5) * 16 + 6 * 2 : -1;
 
-    // ---- C->C layers ---------------------------------------------------------------------------------
-    float* bias = reinterpret_cast<float*>(P.ldsImage.data() + np.offBias);
-    for (int l = 0; l < NL; ++l) {
-        const Layer& L = net.hidden[size_t(l)];
-        const int ks = l == 0 ? KS0 : KS;
-        const size_t baseOff = l == 0 ? size_t(np.offLayer0) : size_t(np.offHidden) + size_t(l - 1) * MT * KS * kFragBytes;
-        if (L.channelsOut != C) throw InvalidNetwork("hidden layer width mismatch");
-        for (int m = 0; m < MT; ++m)
-            for (int s = 0; s < ks; ++s) {
-                Frag f{};
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int row = 32 * m + (lane & 31), h = lane >> 5;
-                    if (row >= C) continue;
-                    for (int j = 0; j < 8; ++j) {
-                        int col;
-                        if (s < KS) {
-                            const int prevRow = chiOfSlot(16 * s + 8 * h + j);
-                            col = l == 0 ? chanOfRow[size_t(prevRow)] : prevRow;
-                        } else {
-                            col = C + 16 * (s - KS) + 8 * h + j;  // latent grid channel
+    // The latent grid is packed first: the ReLU scaling below needs the range of its channels.
+    packLatentGrid(net, P);
+    np.gridX = P.gridX; np.gridY = P.gridY; np.gridZ = P.gridZ; np.gridC = P.gridC;
+
+    // ---- C->C layers + last layer, optionally with power-of-two activation scaling (see reluExponents) -----
+    // exps == nullptr: plain image.  exps[l] = e_l: layer l produces h_l * 2^-e_l, i.e. W'_l = W_l * 2^(e_{l-1} - e_l),
+    // b'_l = b_l * 2^-e_l, and the last layer multiplies by 2^(e_{NL-1}).  Powers of two: exact in fp16 / fp32.
+    auto scaleHalf = [](uint16_t bits, int k) {
+        return k == 0 ? bits : float_to_half_bits(std::ldexp(half_bits_to_float(bits), k));
+    };
+    auto packLayers = [&](std::vector<char>& img, const std::vector<int>* exps) {
+        float* bias = reinterpret_cast<float*>(img.data() + np.offBias);
+        for (int l = 0; l < NL; ++l) {
+            const Layer& L = net.hidden[size_t(l)];
+            const int ks = l == 0 ? KS0 : KS;
+            const size_t baseOff = l == 0 ? size_t(np.offLayer0) : size_t(np.offHidden) + size_t(l - 1) * MT * KS * kFragBytes;
+            if (L.channelsOut != C) throw InvalidNetwork("hidden layer width mismatch");
+            const int kW = exps ? (l > 0 ? (*exps)[size_t(l - 1)] : 0) - (*exps)[size_t(l)] : 0;
+            const int kB = exps ? -(*exps)[size_t(l)] : 0;
+            for (int m = 0; m < MT; ++m)
+                for (int s = 0; s < ks; ++s) {
+                    Frag f{};
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int row = 32 * m + (lane & 31), h = lane >> 5;
+                        if (row >= C) continue;
+                        for (int j = 0; j < 8; ++j) {
+                            int col;
+                            if (s < KS) {
+                                const int prevRow = chiOfSlot(16 * s + 8 * h + j);
+                                col = l == 0 ? chanOfRow[size_t(prevRow)] : prevRow;
+                            } else {
+                                col = C + 16 * (s - KS) + 8 * h + j;  // latent grid channel
+                            }
+                            f.v[lane][j] = scaleHalf(L.weights[size_t(row) * L.channelsIn + col], kW);
                         }
-                        f.v[lane][j] = L.weights[size_t(row) * L.channelsIn + col];
                     }
+                    putFrag(img, baseOff + (size_t(m) * ks + s) * kFragBytes, f);
                 }
-                putFrag(P.ldsImage, baseOff + (size_t(m) * ks + s) * kFragBytes, f);
-            }
-        for (int r = 0; r < C; ++r) bias[size_t(l) * 32 * MT + r] = half_bits_to_float(L.bias[size_t(r)]);
-    }
-
-    // ---- last layer: outputs replicated on rows 0..3 and 4..7 so both lane halves see them -------------
-    {
+            for (int r = 0; r < C; ++r) bias[size_t(l) * 32 * MT + r] = std::ldexp(half_bits_to_float(L.bias[size_t(r)]), kB);
+        }
+        // last layer: outputs replicated on rows 0..3 and 4..7 so both lane halves see them
         const Layer& L = net.hidden[size_t(NL)];
         if (L.channelsIn != C || L.channelsOut != Cout) throw InvalidNetwork("last layer shape mismatch");
         const bool transposed = L.channelsIn < 16 || L.channelsOut < 16;  // addLayer stores [in][out]
+        const int kL = exps ? (*exps)[size_t(NL - 1)] : 0;
         for (int s = 0; s < KS; ++s) {
             Frag f{};
             for (int lane = 0; lane < 64; ++lane) {
@@ -224,13 +262,62 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
                 const int o = row & 3;
                 for (int j = 0; j < 8; ++j) {
                     const int col = chiOfSlot(16 * s + 8 * h + j);
-                    f.v[lane][j] = transposed ? L.weights[size_t(col) * Cout + o] : L.weights[size_t(o) * C + col];
+                    f.v[lane][j] = scaleHalf(transposed ? L.weights[size_t(col) * Cout + o] : L.weights[size_t(o) * C + col], kL);
                 }
             }
-            putFrag(P.ldsImage, size_t(np.offLast) + size_t(s) * kFragBytes, f);
+            putFrag(img, size_t(np.offLast) + size_t(s) * kFragBytes, f);
         }
         float* bl = bias + size_t(NL) * 32 * MT;
         for (int o = 0; o < Cout; ++o) bl[o] = bl[4 + o] = half_bits_to_float(L.bias[size_t(o)]);
+    };
+    packLayers(P.ldsImage, nullptr);
+
+    // ---- ReLU networks: second image with activations scaled into [0,1] ------------------------------------
+    // relu(x) = max(x,0) costs the VALU one v_pk_max_f16 per two values on top of the fp32->fp16 convert.  With
+    // h'_l = h_l * 2^-e_l <= 1 guaranteed, "convert + ReLU" is ONE v_cvt_pk_f16_f32 with the clamp modifier
+    // (clamp to [0,1]).  e_l comes from interval arithmetic over the actual weights, so the bound is a guarantee,
+    // and because all factors are powers of two the scaled network computes bit-for-bit the scaled values (up to
+    // fp16 subnormals).  Inputs are bounded for samples inside the box (positions in [0,1], |cos|,|sin| <= 1,
+    // latent features by the grid's range), which is what the renderer evaluates; evaluate_points keeps the
+    // plain image because callers may pass positions outside the box.
+    P.ldsImageScaled.clear();
+    if (c.activation == FVSRN_ACT_RELU) {
+        std::vector<double> bound(size_t(C + c.gridChannels), 1.0005);  // stored input order of layer 0
+        if (c.passTime && net.latentGrid) bound[3] = double(std::max(net.latentGrid->timeNum - 1, 0)) + 1e-3;  // any time index
+        for (int g = 0; g < c.gridChannels; ++g) bound[size_t(C + g)] = double(P.gridMaxAbs[size_t(g)]) * 1.0005;
+        std::vector<int> exps(size_t(NL), 0);
+        bool ok = true;
+        double maxScaledW = 0;
+        for (int l = 0; l < NL && ok; ++l) {
+            const Layer& L = net.hidden[size_t(l)];
+            std::vector<double> next(size_t(C), 0.0);
+            double S = 0;
+            for (int r = 0; r < C; ++r) {
+                double a = std::fabs(double(half_bits_to_float(L.bias[size_t(r)])));
+                for (int j = 0; j < L.channelsIn; ++j)
+                    a += std::fabs(double(half_bits_to_float(L.weights[size_t(r) * L.channelsIn + j]))) * bound[size_t(j)];
+                next[size_t(r)] = a;
+                S = std::max(S, a);
+            }
+            const int e = std::max(0, int(std::ceil(std::log2(S * 1.0005 + 1e-30))));
+            exps[size_t(l)] = e;
+            if (e > 12) ok = false;  // beyond this the scaled activations sink into fp16 subnormals
+            bound = next;
+        }
+        if (ok) {
+            // scaled weights must stay in the fp16 normal range where it matters
+            for (int l = 0; l <= NL; ++l) {
+                const Layer& L = net.hidden[size_t(l)];
+                const int k = l == NL ? exps[size_t(NL - 1)] : (l > 0 ? exps[size_t(l - 1)] : 0) - exps[size_t(l)];
+                for (uint16_t wbits : L.weights) maxScaledW = std::max(maxScaledW, std::fabs(std::ldexp(double(half_bits_to_float(wbits)), k)));
+            }
+            if (maxScaledW >= 60000.0) ok = false;
+        }
+        if (ok) {
+            P.ldsImageScaled = P.ldsImage;  // phase fragments are shared
+            packLayers(P.ldsImageScaled, &exps);
+            P.reluExponents = exps;
+        }
     }
 
     // ---- activation constants (see act() in srn_device.hpp) --------------------------------------------
@@ -251,9 +338,6 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
         np.invBoxSize[i] = 1.0f / net.boxSize[i];
     }
     P.mfmaFlopsPerSample = 1024.0 * (MT + double(MT) * KS0 + double(NL - 1) * MT * KS + KS);
-
-    packLatentGrid(net, P);
-    np.gridX = P.gridX; np.gridY = P.gridY; np.gridZ = P.gridZ; np.gridC = P.gridC;
     return P;
 }
 

@@ -7,15 +7,32 @@
 
 namespace fvsrn {
 
+// all latent key frames in device layout (see packLatentGrid)
+struct GridKeyframes {
+    fvsrn_grid_encoding enc = FVSRN_GRID_FLOAT;
+    int X = 0, Y = 0, Z = 0, Gt = 0, Ge = 0, timeNum = 0, ensNum = 0;
+    size_t records = 0;                    // Z*Y*(X+1)
+    std::vector<char> timeData, ensData;   // [key][record][Gc][2] fp32 | uint8
+    std::vector<float> timeOffset, timeScale, ensOffset, ensScale;  // [key][Gc]
+};
+struct GridSelection {
+    int lo = 0, hi = 0, ens = 0;
+    float frac = 0.f, timeIndex = 0.f;
+};
+GridSelection selectGrid(const SceneNetwork& net);
+
 struct PackedNetwork {
     NetworkConfig cfg;
     int MT = 0, KS = 0, KS0 = 0, NL = 0;
     std::vector<char> ldsImage;  // see device_params.hpp
+    std::vector<char> ldsImageScaled;  // ReLU networks: activations scaled into [0,1] (empty if not applicable)
+    std::vector<int> reluExponents;    // e_l of the scaled image
+    std::vector<float> gridMaxAbs;     // per latent channel
     NetParams params{};          // pointers left null (filled by the device layer)
     double mfmaFlopsPerSample = 0;
-    // working latent grid, f16 bits [Z][Y][X][G] (empty without a grid)
-    std::vector<uint16_t> grid;
+    GridKeyframes keys;
     int gridX = 0, gridY = 0, gridZ = 0, gridC = 0;
+    int timeSlotOffset = -1;  // see pack.cpp
 };
 
 // K slot k of a chained 32x32x16 MFMA -> row (= channel) of the producing accumulator tile
@@ -26,7 +43,6 @@ inline int chiOfSlot(int k) {
 
 // Throws Unsupported for networks outside the compiled variant set, InvalidNetwork like getDefines.
 PackedNetwork packNetwork(const SceneNetwork& net);
-// (re)build only the blended working grid for net.currentTime / currentEnsemble
 void packLatentGrid(const SceneNetwork& net, PackedNetwork& out);
 
 }  // namespace fvsrn

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_params.hpp"
+#include "srn_device_enums.hpp"
 
 namespace fvsrn {
 
@@ -27,7 +28,7 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 
-enum { ACT_RELU = 0, ACT_SINE = 1, ACT_SNAKE = 2, ACT_SNAKEALT = 3 };
+
 
 __device__ __forceinline__ int lane_id() { return int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); }
 
@@ -77,7 +78,20 @@ __device__ __forceinline__ float2_t act_f32x2(float2_t x, float a, float b) {
 // 16 fp32 accumulator values of one M tile -> two B fragments (K steps 2m, 2m+1) with activation
 template <int ACT>
 __device__ __forceinline__ void act_pack(const floatx16& d, float a, float b, half8_t& f0, half8_t& f1) {
-    if constexpr (ACT == ACT_RELU) {
+    if constexpr (ACT == ACT_RELU01) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float2_t v0 = {d[2 * i], d[2 * i + 1]};
+            float2_t v1 = {d[8 + 2 * i], d[8 + 2 * i + 1]};
+            half2_t h0 = __builtin_convertvector(v0, half2_t);
+            half2_t h1 = __builtin_convertvector(v1, half2_t);
+            const half2_t z = {0, 0}, o = {1, 1};
+            h0 = __builtin_elementwise_min(__builtin_elementwise_max(h0, z), o);  // folds into the convert's clamp bit
+            h1 = __builtin_elementwise_min(__builtin_elementwise_max(h1, z), o);
+            f0[2 * i] = h0[0]; f0[2 * i + 1] = h0[1];
+            f1[2 * i] = h1[0]; f1[2 * i + 1] = h1[1];
+        }
+    } else if constexpr (ACT == ACT_RELU) {
         // convert first, then one packed max per register pair
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -297,11 +311,29 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const floatx16 bias = lds_bias(lds, bOff + m * 128, h);
+#ifndef FVSRN_K_MAJOR
+            if constexpr (KS <= 4) {
+                // tile-major issue order: tile 0's chain completes while tile 1's MFMAs still run, so the VALU work
+                // on tile 0's accumulators overlaps the matrix pipe inside one wave
+                half8_t a[KS];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const half8_t a = lds_frag(lds, wOff + (m * ks + s) * kFragBytes, lane);
-                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[0][s], s == 0 ? bias : acc[0][m], 0, 0, 0);
-                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[1][s], s == 0 ? bias : acc[1][m], 0, 0, 0);
+                for (int s = 0; s < KS; ++s) a[s] = lds_frag(lds, wOff + (m * ks + s) * kFragBytes, lane);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s)
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], xb[t][s], s == 0 ? bias : acc[t][m], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);  // keep the two chains apart (hipcc would re-interleave them)
+                }
+            } else
+#endif
+            {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const half8_t a = lds_frag(lds, wOff + (m * ks + s) * kFragBytes, lane);
+                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[0][s], s == 0 ? bias : acc[0][m], 0, 0, 0);
+                    acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[1][s], s == 0 ? bias : acc[1][m], 0, 0, 0);
+                }
             }
         }
         if constexpr (HAS_GRID) {

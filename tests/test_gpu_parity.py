@@ -256,3 +256,66 @@ def test_stripe_render_of_every_rank_composes_the_frame(world, stripe):
     assert torch.equal(torch.nan_to_num(full, nan=-1.0), torch.nan_to_num(frame, nan=-1.0))
     for r in range(world):
         assert parts[r].shape[1] == len(tiles.owned_rows(H, stripe, r, world))
+
+
+@pytest.mark.parametrize("C,layers,grid", [(32, 4, None), (64, 6, (16, 8)), (32, 4, (16, 8))])
+def test_relu_scaled_image_equals_plain_image(C, layers, grid, monkeypatch):
+    """ReLU networks render from a second weight image whose activations are scaled by powers of two into [0,1]
+    (convert+ReLU = one clamped v_cvt_pk_f16_f32).  The scaling is exact: both images give the same picture."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=C, layers=layers, activation="ReLU", output_mode="density", grid=grid, seed=21,
+                             box_min=(-0.5, -0.5, -0.5), fourier_std=0.4)
+    kw = make_scene_kwargs(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF, early_out=False)
+    data = volnet_io.save_volnet(vn)
+    scene = capi.Scene(**kw)
+    monkeypatch.setenv("FVSRN_DISABLE_RELU_CLAMP", "1")
+    net_plain = capi.Network.from_volnet(data)
+    plain = scene.render(net_plain, 64, 48)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("FVSRN_DISABLE_RELU_CLAMP")
+    net_scaled = capi.Network.from_volnet(data)
+    scaled = scene.render(net_scaled, 64, 48)
+    torch.cuda.synchronize()
+    a, b = plain[0, :4].cpu().numpy(), scaled[0, :4].cpu().numpy()
+    assert a[3].max() > 0.05
+    assert "RELU01" in net_scaled.kernel_name(True)
+    # exact up to fp16 subnormal effects of the scaled activations: far below the parity tolerances
+    assert np.abs(a - b).max() < 5e-4, np.abs(a - b).max()
+
+
+@pytest.mark.parametrize("name", util.golden_names("g2_"))
+def test_time_change_on_a_live_network_reblends_on_the_device(name):
+    """set_time_and_ensemble on a network whose key frames are already resident: only the device-side blend kernel
+    (and the 2-byte time patch) run; results equal the reference at every time, in any order."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    d, meta = util.load_golden(name)
+    vn = util.golden_to_volnet(d, meta)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    pos = torch.from_numpy(d["positions"]).cuda()
+    tes = [(t, 0) for t in meta["times"]] if "times" in meta else meta["time_ensemble"]
+    order = list(range(len(tes))) + list(reversed(range(len(tes))))
+    for i in order:
+        t, e = tes[i]
+        net.set_time_and_ensemble(t, e)
+        out = net.evaluate(pos).cpu().numpy()
+        assert np.abs(out - d["out_fp32"][i]).max() < TOL_SAME_MODEL, (t, e)
+
+
+def test_render_time_dependent_byte_linear_grid():
+    """Time-interpolated BYTE_LINEAR grids through the renderer, including the reference's quirk of decoding key
+    frame B with A's offset/scale; compared with the oracle at two times on ONE live network."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode="density", grid=(16, 8), seed=31,
+                             box_min=(-0.5, -0.5, -0.5), fourier_std=0.4, encoding=volnet_io.ENC_BYTE_LINEAR, time_grids=3)
+    kw = make_scene_kwargs(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    scene = capi.Scene(**kw)
+    for t in (0.3, 1.6, 0.3, 2.0):
+        net.set_time_and_ensemble(t, 0)
+        img = scene.render(net, 40, 24)
+        torch.cuda.synchronize()
+        ref, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT, time=t), 40, 24)
+        assert_images_close(img.cpu().numpy()[0], ref, TOL_IMG)
