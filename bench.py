@@ -190,11 +190,18 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP kernels have no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # FVSRN_BENCH_BACKEND=gloo lets the N>1 orchestration be exercised on a box with ONE GPU (all ranks share it);
+    # the driver's multi-GPU runs use the default "nccl" (= RCCL over xGMI), one rank per GPU.
+    backend = os.environ.get("FVSRN_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus or not distributed, "--gpus must equal WORLD_SIZE"
 
     import util
@@ -214,6 +221,19 @@ def main():
         c = torch.tensor([evaluated, executed], dtype=torch.int64, device="cuda")
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         evaluated, executed = int(c[0]), int(c[1])
+
+    frame_check = None
+    if distributed:  # untimed: the gathered stripes of the last frame equal a whole-frame render on this rank
+        last = args.warmup + args.steps - 1
+        gathered = runner.assemble(last & 1)
+        yaw = 2 * math.pi * (last % 64) / 64
+        scene = capi.Scene(**build_scene_kwargs(capi, yaw, runner.stepsize, args.early_out))
+        full = scene.render(net, runner.W, runner.H)
+        torch.cuda.synchronize()
+        frame_check = bool(torch.equal(torch.nan_to_num(full, nan=-1.0), torch.nan_to_num(gathered, nan=-1.0)))
+        ok = torch.tensor([1 if frame_check else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        frame_check = bool(ok.item())
 
     twin = None
     if not args.no_twin and not distributed:
@@ -249,6 +269,8 @@ def main():
                          "flops_per_sample": info.flops_per_sample, "mfma_flops_per_sample": info.mfma_flops_per_sample,
                          "kernel_ms_avg": 1e3 * kernel_s},
         }
+        if frame_check is not None:
+            out["gathered_frame_equals_single_gpu_frame"] = frame_check
         if twin:
             out["twin"] = twin
         if not args.no_cpu_baseline and world == 1:

@@ -99,7 +99,7 @@ struct fvsrn_network {
     // device image (lazy; invalidated by any mutation)
     bool deviceValid = false;
     PackedNetwork packed;
-    DeviceBuffer dLds, dLdsScaled, dGrid, dKeysTime, dKeysEns, dCoeffs;
+    DeviceBuffer dLds, dLdsScaled, dGrid, dGridB, dKeysTime, dKeysEns, dCoeffs;
     const void* scaledImage = nullptr;
     bool timeDirty = true;  // working grid / time slot do not match net->currentTime yet
     VariantKey key{};       // plain image
@@ -114,7 +114,7 @@ struct fvsrn_network {
         packed = packNetwork(*net);
         key.CD = packed.cfg.hiddenChannels / 16;
         key.act = actIndex(packed.cfg.activation);
-        key.grid = packed.cfg.gridChannels > 0;
+        key.grid = packed.cfg.gridChannels == 0 ? 0 : (packed.cfg.gridEncoding == FVSRN_GRID_BYTE_GAUSSIAN ? 2 : 1);
         key.dir = packed.cfg.directionMode > 0;
         if (!kernel_info(key, &kinfo))
             throw Unsupported("no ahead-of-time kernel for hidden width " + std::to_string(packed.cfg.hiddenChannels) +
@@ -166,6 +166,13 @@ struct fvsrn_network {
             if (!coeffs.empty()) HIP_CHECK(hipMemcpyAsync(dCoeffs.ptr, coeffs.data(), coeffs.size() * 4, hipMemcpyHostToDevice, stream));
             dGrid.ensure(K.records * size_t(K.Gt + K.Ge) * 2 * 2);
             packed.params.grid = dGrid.ptr;
+            packed.params.gridB = nullptr;
+            if (K.enc == FVSRN_GRID_BYTE_GAUSSIAN) {
+                dGridB.ensure(K.records * size_t(K.Gt + K.Ge) * 2 * 2);
+                packed.params.gridB = dGridB.ptr;
+            }
+            packed.params.gridEncoding = int(K.enc);
+            packed.params.gridTimeChannels = K.Gt;
         } else {
             packed.params.grid = nullptr;
         }
@@ -191,9 +198,15 @@ struct fvsrn_network {
             const float* c = static_cast<const float*>(dCoeffs.ptr);
             b.timeOffset = c; b.timeScale = c + K.timeOffset.size();
             b.ensOffset = c + 2 * K.timeOffset.size(); b.ensScale = b.ensOffset + K.ensOffset.size();
-            b.out = dGrid.ptr; b.records = K.records; b.enc = int(K.enc); b.Gt = K.Gt; b.Ge = K.Ge;
+            b.out = dGrid.ptr; b.outB = dGridB.ptr; b.records = K.records; b.enc = int(K.enc); b.Gt = K.Gt; b.Ge = K.Ge;
             b.lo = g.lo; b.hi = g.hi; b.ens = g.ens; b.frac = g.frac;
             HIP_CHECK(launch_grid_blend(b, stream));
+            // decode coefficients of the selected key frames (BYTE_GAUSSIAN decodes inside the render kernel)
+            packed.params.gridFrac = g.frac;
+            packed.params.gridMeanTime = b.timeOffset + size_t(g.lo) * K.Gt;
+            packed.params.gridStdTime = b.timeScale + size_t(g.lo) * K.Gt;
+            packed.params.gridMeanEns = b.ensOffset + size_t(g.ens) * K.Ge;
+            packed.params.gridStdEns = b.ensScale + size_t(g.ens) * K.Ge;
             if (packed.timeSlotOffset >= 0) {
                 timeSlotStaging = float_to_half_bits(g.timeIndex);
                 HIP_CHECK(hipMemcpyAsync(static_cast<char*>(dLds.ptr) + packed.timeSlotOffset, &timeSlotStaging, 2, hipMemcpyHostToDevice, stream));
@@ -209,6 +222,7 @@ struct fvsrn_network {
         dLds.release();
         dLdsScaled.release();
         dGrid.release();
+        dGridB.release();
         dKeysTime.release();
         dKeysEns.release();
         dCoeffs.release();
@@ -439,6 +453,7 @@ int fvsrn_network_clear_gpu_resources(fvsrn_network* net) {
         net->dLds.release();
         net->dLdsScaled.release();
         net->dGrid.release();
+        net->dGridB.release();
         net->dKeysTime.release();
         net->dKeysEns.release();
         net->dCoeffs.release();
@@ -715,7 +730,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             // 61.0 Gsamples/s; the one-wave-per-workgroup Fourier-only kernel is faster in raster order (107 -> 114):
             // there the equally long centre tiles would all start together and march through MFMA / VALU phases in step.
             const char* ord = std::getenv("FVSRN_TILE_ORDER");  // "0" / "1" force, unset = heuristic
-            const bool useOrder = ord ? ord[0] == '1' : (wpb > 1 || net->key.grid);
+            const bool useOrder = ord ? ord[0] == '1' : (wpb > 1 || net->key.grid != 0);
             S.tileOrder = useOrder ? scene->tileOrder(S, P_boxCenter(a.P), tilesX, tilesY, s) : nullptr;
             const hipError_t e = launch_render(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during rendering! ") + hipGetErrorString(e));

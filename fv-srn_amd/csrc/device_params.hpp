@@ -27,8 +27,17 @@ struct NetParams {
     float boxMin[3];
     float boxSize[3];
     float invBoxSize[3];
-    // latent grid working copy: f16 [Z][Y][X][G], already time-blended / decoded (FLOAT, BYTE_LINEAR)
+    // latent grid working copy (x-pair records, see pack.cpp): fp16 [Z][Y][X+1][G][2].
+    //  FLOAT / BYTE_LINEAR: decoded and time-blended values in `grid`.
+    //  BYTE_GAUSSIAN: the decode is non-linear and sits between the spatial and the time interpolation
+    //  (renderer_volume_tensorcores.cuh:581-591), so `grid` / `gridB` hold the raw byte values (0..255) of key
+    //  frames A / B and the kernel decodes: mean + std * sqrt2 * erfinv((2-1e-4)(x-0.5)), then lerps with gridFrac.
     const void* grid;
+    const void* gridB;
+    const float* gridMeanTime; const float* gridStdTime;  // [Gt] of key frame A (the reference uses A's for B too)
+    const float* gridMeanEns; const float* gridStdEns;    // [Ge]
+    float gridFrac;
+    int gridEncoding, gridTimeChannels;
     int gridX, gridY, gridZ, gridC;
 };
 

@@ -26,7 +26,7 @@ __device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* ld
 // ------------------------------------------------------------------------------------------------
 // EvaluateNoBatches (reference renderer/renderer_volume_kernels1.cuh:15): positions -> network value
 // ------------------------------------------------------------------------------------------------
-template <int CD, int ACT, bool HAS_GRID, bool HAS_DIR>
+template <int CD, int ACT, int GRID, bool HAS_DIR>
 __global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) void evaluate_kernel(NetParams P, const float* __restrict__ pos,
                                                                  const float* __restrict__ dir, size_t n,
                                                                  float* __restrict__ out, int outChannels) {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) 
         px = (px - P.boxMin[0]) * P.invBoxSize[0];
         py = (py - P.boxMin[1]) * P.invBoxSize[1];
         pz = (pz - P.boxMin[2]) * P.invBoxSize[2];
-        const float4_t o = srn_forward<CD, ACT, HAS_GRID, HAS_DIR>(P, lds, px, py, pz, dx, dy, dz);
+        const float4_t o = srn_forward<CD, ACT, GRID, HAS_DIR>(P, lds, px, py, pz, dx, dy, dz);
         if (valid) {
             switch (P.outputMode) {
                 case FVSRN_OUT_DENSITY:
@@ -130,7 +130,7 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // depend on the grouping because blending is guarded by isValid).  Stepping is wave-synchronous like
 // the reference's __any_sync loop: all 64 lanes evaluate the network until no lane is valid.
 // ------------------------------------------------------------------------------------------------
-template <int CD, int ACT, bool HAS_GRID, bool HAS_DIR>
+template <int CD, int ACT, int GRID, bool HAS_DIR>
 __global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -188,19 +188,23 @@ __global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) 
     const float pn0z = (oz - P.boxMin[2]) * P.invBoxSize[2], dnz = dz * P.invBoxSize[2];
 
     float cr = 0, cg = 0, cb = 0, ca = 0, nx = 0, ny = 0, nz = 0, depth = 0;
-    unsigned nValid = 0, nSteps = 0;
+    unsigned nValid = 0, nSteps = 0;  // wave-uniform (scalar registers): lane-exact samples / executed wave steps
     const bool rgboNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
     const bool gradNet = P.outputMode >= FVSRN_OUT_DENSITY_GRADIENT && P.outputMode <= FVSRN_OUT_DENSITY_GRADIENT_CUBIC;
 
     for (int i = 0;; ++i) {
         const float t = tmin + float(i) * S.stepsize;
-        const bool valid = (t <= tmax) && (!S.earlyOut || ca < S.alphaEarlyOut);
-        if (!__any(valid)) break;  // wave-uniform
+        const bool inRange = t <= tmax, notOpaque = ca < S.alphaEarlyOut;
+        const bool valid = bool(int(inRange) & (int(!S.earlyOut) | int(notOpaque)));  // branch-free
+        // wave mask straight from the two v_cmp results (scalar ops only)
+        const unsigned long long validMask =
+            __builtin_amdgcn_ballot_w64(inRange) & (S.earlyOut ? __builtin_amdgcn_ballot_w64(notOpaque) : ~0ull);
+        if (validMask == 0) break;  // wave-uniform: no lane of the wave is valid any more
         ++nSteps;
-        nValid += valid ? 1u : 0u;
+        nValid += unsigned(__builtin_popcountll(validMask));
 
         const float px = fmaf(dnx, t, pn0x), py = fmaf(dny, t, pn0y), pz = fmaf(dnz, t, pn0z);
-        const float4_t o = srn_forward<CD, ACT, HAS_GRID, HAS_DIR>(P, lds, px, py, pz, dx, dy, dz);
+        const float4_t o = srn_forward<CD, ACT, GRID, HAS_DIR>(P, lds, px, py, pz, dx, dy, dz);
 
         float4_t color = {0, 0, 0, 0};
         float gx = 0, gy = 0, gz = 0;
@@ -248,14 +252,9 @@ __global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) 
         out[6 * plane + o] = nz * ca;
         out[7 * plane + o] = depth * ca / ca;  // (depth*alpha)/alpha, NaN for alpha == 0 like the reference
     }
-    if (stats) {
-        unsigned long long v = nValid;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) {
-            atomicAdd(&stats[0], v);
-            atomicAdd(&stats[1], (unsigned long long)nSteps * 64ull);
-        }
+    if (stats && lane == 0) {
+        atomicAdd(&stats[0], (unsigned long long)nValid);
+        atomicAdd(&stats[1], (unsigned long long)nSteps * 64ull);
     }
 }
 

@@ -16,6 +16,22 @@ __global__ void grid_blend_kernel(BlendParams p) {
         const int w = int(i % (unsigned)(2 * G));
         const int c = w >> 1, pp = w & 1;
         float v;
+        if (p.enc == FVSRN_GRID_BYTE_GAUSSIAN) {  // no decode, no blend: byte values of A and B for the render kernel
+            float a, b;
+            if (c < p.Gt) {
+                const unsigned long long per = p.records * (unsigned long long)(2 * p.Gt);
+                const unsigned long long idx = rec * (unsigned)(2 * p.Gt) + (unsigned)(2 * c + pp);
+                a = float(static_cast<const unsigned char*>(p.timeData)[p.lo * per + idx]);
+                b = float(static_cast<const unsigned char*>(p.timeData)[p.hi * per + idx]);
+            } else {
+                const int ce = c - p.Gt;
+                const unsigned long long per = p.records * (unsigned long long)(2 * p.Ge);
+                a = b = float(static_cast<const unsigned char*>(p.ensData)[p.ens * per + rec * (unsigned)(2 * p.Ge) + (unsigned)(2 * ce + pp)]);
+            }
+            static_cast<_Float16*>(p.out)[i] = _Float16(a);
+            static_cast<_Float16*>(p.outB)[i] = _Float16(b);
+            continue;
+        }
         if (c < p.Gt) {
             const unsigned long long per = p.records * (unsigned long long)(2 * p.Gt);
             const unsigned long long idx = rec * (unsigned)(2 * p.Gt) + (unsigned)(2 * c + pp);

@@ -26,7 +26,7 @@ struct RenderArgs {
 struct VariantKey {
     int CD;    // hidden channels / 16
     int act;   // ACT_*
-    bool grid;
+    int grid;  // 0 none, 1 decoded/blended working grid (FLOAT, BYTE_LINEAR), 2 BYTE_GAUSSIAN
     bool dir;
 };
 struct KernelInfo {
@@ -48,6 +48,7 @@ struct BlendParams {
     const float* timeOffset; const float* timeScale;  // [timeNum][Gt]
     const float* ensOffset; const float* ensScale;    // [ensNum][Ge]
     void* out;             // fp16 [records][Gt+Ge][2]
+    void* outB;            // BYTE_GAUSSIAN only: raw bytes of key frame B (out = key frame A)
     unsigned long long records;
     int enc, Gt, Ge, lo, hi, ens;
     float frac;

@@ -73,8 +73,6 @@ void packLatentGrid(const SceneNetwork& net, PackedNetwork& out) {
     if (!net.latentGrid) return;
     const LatentGridTimeAndEnsemble& lg = *net.latentGrid;
     const fvsrn_grid_encoding enc = lg.commonEncoding();
-    if (enc == FVSRN_GRID_BYTE_GAUSSIAN)
-        throw Unsupported("latent grid encoding BYTE_GAUSSIAN is not in the compiled variant set (FLOAT, BYTE_LINEAR)");
     const LatentGrid& first = lg.hasTimeGrids() ? *lg.timeGrids[0] : *lg.ensembleGrids[0];
     const int X = first.gridSizeX, Y = first.gridSizeY, Z = first.gridSizeZ;
     for (const auto* list : {&lg.timeGrids, &lg.ensembleGrids})
@@ -118,8 +116,15 @@ void packLatentGrid(const SceneNetwork& net, PackedNetwork& out) {
                         }
                         // range of the decoded values, for the ReLU scaling: own coefficients, and (time grids) the
                         // previous key frame's coefficients, which is what a blend with this frame as "B" uses
-                        float m = std::fabs(off[k * Gc + c] + r * scale[k * Gc + c]);
-                        if (timeQuirk && k > 0) m = std::max(m, std::fabs(off[(k - 1) * Gc + c] + r * scale[(k - 1) * Gc + c]));
+                        float m;
+                        if (enc == FVSRN_GRID_BYTE_GAUSSIAN) {
+                            // |mean| + std * sqrt2 * erfinv(0.99995) bounds every decoded value
+                            m = std::fabs(off[k * Gc + c]) + 3.9f * std::fabs(scale[k * Gc + c]);
+                            if (timeQuirk && k > 0) m = std::max(m, std::fabs(off[(k - 1) * Gc + c]) + 3.9f * std::fabs(scale[(k - 1) * Gc + c]));
+                        } else {
+                            m = std::fabs(off[k * Gc + c] + r * scale[k * Gc + c]);
+                            if (timeQuirk && k > 0) m = std::max(m, std::fabs(off[(k - 1) * Gc + c] + r * scale[(k - 1) * Gc + c]));
+                        }
                         out.gridMaxAbs[size_t(chanBase + c)] = std::max(out.gridMaxAbs[size_t(chanBase + c)], m);
                     }
             }

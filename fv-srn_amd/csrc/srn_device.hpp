@@ -144,6 +144,7 @@ __device__ __forceinline__ floatx16 lds_bias(const char* lds, int byteOff, int h
 struct GridTap {
     unsigned off[4];  // byte offsets of the 4 (z,y) records of this sample (channel 0)
     unsigned w[4];    // packed fp16 weight pairs
+    unsigned wlo[4];  // their fp16 rounding residuals (only the BYTE_GAUSSIAN path, whose erfinv amplifies errors, uses them)
 };
 
 __device__ __forceinline__ GridTap grid_tap(const NetParams& P, float px, float py, float pz) {
@@ -166,12 +167,16 @@ __device__ __forceinline__ GridTap grid_tap(const NetParams& P, float px, float 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float2_t v = {w4[k] * ux, w4[k] * wx};
-        t.w[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
+        const half2_t hi = __builtin_convertvector(v, half2_t);
+        const float2_t r = v - __builtin_convertvector(hi, float2_t);
+        t.w[k] = __builtin_bit_cast(unsigned, hi);
+        t.wlo[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, half2_t));
     }
     return t;
 }
 
 // own-sample tap -> taps of sample (lane&31) of tile 0 / tile 1
+template <bool WITH_LO>
 __device__ __forceinline__ void grid_tap_bcast(const GridTap& own, GridTap& t0, GridTap& t1) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -179,13 +184,36 @@ __device__ __forceinline__ void grid_tap_bcast(const GridTap& own, GridTap& t0, 
         t0.off[k] = a[0]; t1.off[k] = a[1];
         auto b = __builtin_amdgcn_permlane32_swap(own.w[k], own.w[k], false, false);
         t0.w[k] = b[0]; t1.w[k] = b[1];
+        if constexpr (WITH_LO) {
+            auto c = __builtin_amdgcn_permlane32_swap(own.wlo[k], own.wlo[k], false, false);
+            t0.wlo[k] = c[0]; t1.wlo[k] = c[1];
+        }
     }
 }
 
-// 8 channels [16*g + 8*h, +8) of the tile sample described by `t`, as the B fragment of latent K step g
-__device__ __forceinline__ half8_t grid_features(const NetParams& P, const GridTap& t, int g, int h) {
-    const char* base = reinterpret_cast<const char*>(P.grid) + (g * 64 + h * 32);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// single-precision inverse error function (M. Giles 2010), relative error ~1e-7 like CUDA's erfinvf
+__device__ __forceinline__ float erfinv_dev(float x) {
+    float w = -__logf((1.0f - x) * (1.0f + x)), p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f; p = fmaf(p, w, 3.43273939e-07f); p = fmaf(p, w, -3.5233877e-06f);
+        p = fmaf(p, w, -4.39150654e-06f); p = fmaf(p, w, 0.00021858087f); p = fmaf(p, w, -0.00125372503f);
+        p = fmaf(p, w, -0.00417768164f); p = fmaf(p, w, 0.246640727f); p = fmaf(p, w, 1.50140941f);
+    } else {
+        w = sqrtf(w) - 3.0f;
+        p = -0.000200214257f; p = fmaf(p, w, 0.000100950558f); p = fmaf(p, w, 0.00134934322f);
+        p = fmaf(p, w, -0.00367342844f); p = fmaf(p, w, 0.00573950773f); p = fmaf(p, w, -0.0076224613f);
+        p = fmaf(p, w, 0.00943887047f); p = fmaf(p, w, 1.00167406f); p = fmaf(p, w, 2.83297682f);
+    }
+    return p * x;
+}
+
+// trilinear fetch of 8 channels [16*g + 8*h, +8) from one working grid: fp32 results
+template <bool WITH_LO>
+__device__ __forceinline__ void grid_fetch8(const void* grid, const GridTap& t, int g, int h, float acc[8]) {
+    const char* base = reinterpret_cast<const char*>(grid) + (g * 64 + h * 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint4_t* p = reinterpret_cast<const uint4_t*>(base + t.off[k]);
@@ -198,6 +226,36 @@ __device__ __forceinline__ half8_t grid_features(const NetParams& P, const GridT
             const unsigned u0 = v0[j], u1 = v1[j];
             acc[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u0), w, acc[j], false);
             acc[4 + j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u1), w, acc[4 + j], false);
+            if constexpr (WITH_LO) {
+                const half2_t wl = __builtin_bit_cast(half2_t, t.wlo[k]);
+                acc[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u0), wl, acc[j], false);
+                acc[4 + j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u1), wl, acc[4 + j], false);
+            }
+        }
+    }
+}
+
+// 8 channels [16*g + 8*h, +8) of the tile sample described by `t`, as the B fragment of latent K step g
+// GRID: 1 = `grid` holds decoded, time-blended values (FLOAT, BYTE_LINEAR); 2 = BYTE_GAUSSIAN
+template <int GRID>
+__device__ __forceinline__ half8_t grid_features(const NetParams& P, const GridTap& t, int g, int h) {
+    float acc[8];
+    grid_fetch8<GRID == 2>(P.grid, t, g, h, acc);
+    if constexpr (GRID == 2) {  // EncodeGridValue<BYTE_GAUSSIAN> :370-383
+        float accB[8];
+        grid_fetch8<true>(P.gridB, t, g, h, accB);
+        const int c0 = 16 * g + 8 * h;
+        const bool isTime = c0 < P.gridTimeChannels;  // a 16-channel chunk never straddles time / ensemble channels
+        const float* mean = isTime ? P.gridMeanTime + c0 : P.gridMeanEns + (c0 - P.gridTimeChannels);
+        const float* sd = isTime ? P.gridStdTime + c0 : P.gridStdEns + (c0 - P.gridTimeChannels);
+        const float f = isTime ? P.gridFrac : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xa = acc[j] * (1.0f / 255.0f), xb = accB[j] * (1.0f / 255.0f);  // cudaReadModeNormalizedFloat
+            const float ya = 1.4142135623730950488f * erfinv_dev((2.0f - 1e-4f) * (xa - 0.5f));
+            const float yb = 1.4142135623730950488f * erfinv_dev((2.0f - 1e-4f) * (xb - 0.5f));
+            const float va = mean[j] + ya * sd[j], vb = mean[j] + yb * sd[j];
+            acc[j] = va + f * (vb - va);
         }
     }
     half8_t out;
@@ -215,7 +273,7 @@ __device__ __forceinline__ half8_t grid_features(const NetParams& P, const GridT
 //   (dx,dy,dz): this lane's view direction (only read when the network uses it)
 // Returns the raw last-layer outputs (before the output parametrization) of this lane's sample.
 // EXEC must be all ones.
-template <int CD, int ACT, bool HAS_GRID, bool HAS_DIR>
+template <int CD, int ACT, int GRID, bool HAS_DIR>
 __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* lds, float px, float py, float pz,
                                                 float dx, float dy, float dz) {
     constexpr int C = 16 * CD;
@@ -241,7 +299,7 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
         }
     }
     GridTap gt[2];
-    if constexpr (HAS_GRID) grid_tap_bcast(grid_tap(P, px, py, pz), gt[0], gt[1]);
+    if constexpr (GRID != 0) grid_tap_bcast<GRID == 2>(grid_tap(P, px, py, pz), gt[0], gt[1]);
     float td[2][3] = {{0, 0, 0}, {0, 0, 0}};
     if constexpr (HAS_DIR) {
         tile_bcast(dx, td[0][0], td[1][0]);
@@ -304,7 +362,7 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
     // ---- C -> C layers -----------------------------------------------------------------------------------
     const int NL = P.numLayers;
     for (int l = 0; l < NL; ++l) {
-        const int ks = (HAS_GRID && l == 0) ? KS + P.gridK : KS;
+        const int ks = (GRID != 0 && l == 0) ? KS + P.gridK : KS;
         const int wOff = l == 0 ? P.offLayer0 : P.offHidden + (l - 1) * MT * KS * kFragBytes;
         const int bOff = P.offBias + l * 32 * MT * 4;
         floatx16 acc[2][MT];
@@ -336,11 +394,11 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
                 }
             }
         }
-        if constexpr (HAS_GRID) {
+        if constexpr (GRID != 0) {
             if (l == 0) {
                 for (int g = 0; g < P.gridK; ++g) {
-                    const half8_t g0 = grid_features(P, gt[0], g, h);
-                    const half8_t g1 = grid_features(P, gt[1], g, h);
+                    const half8_t g0 = grid_features<GRID>(P, gt[0], g, h);
+                    const half8_t g1 = grid_features<GRID>(P, gt[1], g, h);
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const half8_t a = lds_frag(lds, wOff + (m * ks + KS + g) * kFragBytes, lane);
@@ -371,11 +429,13 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[1][s], o1, 0, 0, 0);
     }
     // rows 0..3 (lane half 0) and rows 4..7 (lane half 1) both carry outputs 0..3 of sample c of the tile
-    float4_t out;
+    float4_t out = {0, 0, 0, 0};
     out[0] = h ? o1[0] : o0[0];
-    out[1] = h ? o1[1] : o0[1];
-    out[2] = h ? o1[2] : o0[2];
-    out[3] = h ? o1[3] : o0[3];
+    if (P.outputMode >= FVSRN_OUT_RGBO) {  // wave-uniform: only colour / gradient networks have outputs 1..3
+        out[1] = h ? o1[1] : o0[1];
+        out[2] = h ? o1[2] : o0[2];
+        out[3] = h ? o1[3] : o0[3];
+    }
     return out;
 }
 

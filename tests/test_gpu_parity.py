@@ -78,7 +78,7 @@ def test_evaluate_ragged_sizes(n):
         assert np.abs(out - ref).max() < TOL_SAME_MODEL
 
 
-@pytest.mark.parametrize("enc", [0, 1])
+@pytest.mark.parametrize("enc", [0, 1, 2])
 def test_evaluate_grid_encodings_and_box(enc):
     vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density", grid=(16, 8), seed=5,
                              box_min=(-0.5, -0.25, 0.1), box_size=(1.0, 0.5, 2.0), encoding=enc)
@@ -86,11 +86,14 @@ def test_evaluate_grid_encodings_and_box(enc):
     pos = (rng.rand(2000, 3) * np.array([1.0, 0.5, 2.0]) + np.array([-0.5, -0.25, 0.1])).astype(np.float32)
     out = gpu_eval(vn, pos, world=True)
     ref = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos)
-    assert np.abs(out - ref).max() < TOL_SAME_MODEL
+    # BYTE_GAUSSIAN: erfinv amplifies filter-weight rounding near bytes 0 / 255, so that path filters with hi+lo
+    # fp16 weight pairs (~22 bits); the reference's texture units filter with 8 fractional bits
+    tol = TOL_SAME_MODEL
+    assert np.abs(out - ref).max() < tol
     # unit-box entry (the reference's IVolumeInterpolation::evaluate resets the box to [0,1]^3)
     unit = ((pos - np.array([-0.5, -0.25, 0.1], np.float32)) / np.array([1.0, 0.5, 2.0], np.float32)).astype(np.float32)
     out_u = gpu_eval(vn, unit)
-    assert np.abs(out_u - ref).max() < TOL_SAME_MODEL
+    assert np.abs(out_u - ref).max() < tol
 
 
 def make_scene_kwargs(pitch=0.4, yaw=0.7, distance=1.6, stepsize=1 / 48, **kw):
@@ -303,13 +306,14 @@ def test_time_change_on_a_live_network_reblends_on_the_device(name):
         assert np.abs(out - d["out_fp32"][i]).max() < TOL_SAME_MODEL, (t, e)
 
 
-def test_render_time_dependent_byte_linear_grid():
-    """Time-interpolated BYTE_LINEAR grids through the renderer, including the reference's quirk of decoding key
-    frame B with A's offset/scale; compared with the oracle at two times on ONE live network."""
+@pytest.mark.parametrize("enc", [1, 2])
+def test_render_time_dependent_byte_grids(enc):
+    """Time-interpolated BYTE_LINEAR / BYTE_GAUSSIAN grids through the renderer, including the reference's quirk of
+    decoding key frame B with A's offset/scale; compared with the oracle at several times on ONE live network."""
     import torch
     from fvsrn_amd import capi, volnet_io
     vn = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode="density", grid=(16, 8), seed=31,
-                             box_min=(-0.5, -0.5, -0.5), fourier_std=0.4, encoding=volnet_io.ENC_BYTE_LINEAR, time_grids=3)
+                             box_min=(-0.5, -0.5, -0.5), fourier_std=0.4, encoding=enc, time_grids=3)
     kw = make_scene_kwargs(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)
     net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
     scene = capi.Scene(**kw)
