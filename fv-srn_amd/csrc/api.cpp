@@ -119,7 +119,7 @@ struct fvsrn_network {
         if (!kernel_info(key, &kinfo))
             throw Unsupported("no ahead-of-time kernel for hidden width " + std::to_string(packed.cfg.hiddenChannels) +
                               ", activation " + activationName(packed.cfg.activation) +
-                              (key.dir ? ", with view direction" : "") + " (compiled: widths 32/48/64/96/128, no view direction)");
+                              (key.dir ? ", with view direction" : "") + " (compiled: widths 32/48/64/96/128)");
         keyScaled = key;
         kinfoScaled = kinfo;
         if (!packed.ldsImageScaled.empty() && !std::getenv("FVSRN_DISABLE_RELU_CLAMP")) {

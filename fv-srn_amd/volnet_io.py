@@ -253,9 +253,9 @@ def build_volnet(*, fourier_B: np.ndarray, weights: Sequence[np.ndarray], biases
                  box_min=(0.0, 0.0, 0.0), box_size=(1.0, 1.0, 1.0), premultiplied: bool = True,
                  time_grids: Optional[Sequence[np.ndarray]] = None, ensemble_grids: Optional[Sequence[np.ndarray]] = None,
                  grid_encoding: int = ENC_FLOAT, time_min: int = 0, time_step: int = 1, ensemble_min: int = 0,
-                 has_time: bool = False) -> VolnetData:
+                 has_time: bool = False, has_direction: bool = False) -> VolnetData:
     """The hand-off order of export_to_pyrenderer (network.py:877-890) on plain numpy arrays."""
-    net = VolnetData(has_time=has_time, output_mode=output_mode, box_min=tuple(box_min), box_size=tuple(box_size),
+    net = VolnetData(has_time=has_time, has_direction=has_direction, output_mode=output_mode, box_min=tuple(box_min), box_size=tuple(box_size),
                      time_min=time_min, time_step=time_step, ensemble_min=ensemble_min)
     B = np.asarray(fourier_B, np.float32)
     net.num_fourier = B.shape[0]

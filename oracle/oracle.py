@@ -33,7 +33,7 @@ _FP = C.POINTER(C.c_float)
 class _OracleNet(C.Structure):
     _fields_ = [("C", C.c_int), ("F", C.c_int), ("G", C.c_int), ("NH", C.c_int), ("Cout", C.c_int),
                 ("outputMode", C.c_int), ("activation", C.c_int), ("gridEncoding", C.c_int), ("passTime", C.c_int),
-                ("accMode", C.c_int), ("actParam", C.c_float), ("boxMin", C.c_float * 3), ("boxSize", C.c_float * 3),
+                ("accMode", C.c_int), ("useDirection", C.c_int), ("actParam", C.c_float), ("boxMin", C.c_float * 3), ("boxSize", C.c_float * 3),
                 ("fourier", _U16P), ("wFirst", _U16P), ("bFirst", _U16P), ("wHidden", _U16P), ("bHidden", _U16P),
                 ("wLast", _U16P), ("bLast", _U16P), ("gridX", C.c_int), ("gridY", C.c_int), ("gridZ", C.c_int),
                 ("gridTexA", C.POINTER(C.c_void_p)), ("gridTexB", C.POINTER(C.c_void_p)),
@@ -62,7 +62,7 @@ def lib() -> C.CDLL:
             build()
         l = C.CDLL(LIB_PATH)
         l.oracle_eval_points.restype = C.c_int
-        l.oracle_eval_points.argtypes = [C.POINTER(_OracleNet), _FP, C.c_size_t, _FP]
+        l.oracle_eval_points.argtypes = [C.POINTER(_OracleNet), _FP, _FP, C.c_size_t, _FP]
         l.oracle_render.restype = C.c_int
         l.oracle_render.argtypes = [C.POINTER(_OracleNet), C.POINTER(_OracleScene), C.c_int, C.c_int, C.c_int, C.c_int,
                                     _FP, C.POINTER(C.c_ulonglong)]
@@ -89,8 +89,6 @@ class OracleNetwork:
         F = vn.num_fourier
         if F <= 0:
             raise ValueError("the oracle restates the Fourier-feature path only")
-        if vn.has_direction:
-            raise ValueError("direction inputs are not restated")
         has_grid = vn.has_grid()
         L = vn.layers
         G = 0
@@ -99,7 +97,9 @@ class OracleNetwork:
             G = (tg[0].channels if tg else 0) + (eg[0].channels if eg else 0)
         # getDefines (:1139-1219)
         Cc = L[0].channels_in - G
-        assert Cc == 4 + 2 * F, "2*num_fourier+4 == hidden[0].channelsIn must hold"
+        base = 8 if vn.has_direction else 4
+        assert Cc == base + 2 * F, "2*num_fourier+%d == hidden[0].channelsIn must hold" % base
+        n.useDirection = (2 if vn.use_direction_in_fourier else 1) if vn.has_direction else 0
         start_hidden = 1 if has_grid else 0
         NH = len(L) - start_hidden - 1
         n.C, n.F, n.G, n.NH = Cc, F, G, NH
@@ -185,10 +185,12 @@ class OracleNetwork:
         self._keep = keep
         self.output_channels = 4 if vn.output_mode in ("rgbo", "rgbo:direct") else 1
 
-    def evaluate(self, world_positions: np.ndarray) -> np.ndarray:
+    def evaluate(self, world_positions: np.ndarray, directions: Optional[np.ndarray] = None) -> np.ndarray:
         p = np.ascontiguousarray(world_positions, dtype=np.float32)
+        d = np.ascontiguousarray(directions, dtype=np.float32) if directions is not None else None
         out = np.zeros((p.shape[0], self.output_channels), np.float32)
-        r = lib().oracle_eval_points(C.byref(self._n), p.ctypes.data_as(_FP), p.shape[0], out.ctypes.data_as(_FP))
+        r = lib().oracle_eval_points(C.byref(self._n), p.ctypes.data_as(_FP), d.ctypes.data_as(_FP) if d is not None else None,
+                                     p.shape[0], out.ctypes.data_as(_FP))
         if r != 0:
             raise RuntimeError("oracle_eval_points failed")
         return out

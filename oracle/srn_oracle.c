@@ -230,9 +230,10 @@ static void dense_layer(const OracleNet* n, const uint16_t* W, const uint16_t* b
 static float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 static float softplusf_(float x) { return x > 20.f ? x : logf(1.f + expf(x)); }
 
-/* eval<>: world position -> out[0..3] = value (1 or 4 channels used), nrm[3] = predicted normal */
-static void srn_eval(const OracleNet* n, const float wpos[3], float out[4], float nrm[3]) {
+/* eval<>: world position (+ view direction) -> out[0..3] = value (1 or 4 channels used), nrm[3] = predicted normal */
+static void srn_eval(const OracleNet* n, const float wpos[3], const float dir[3], float out[4], float nrm[3]) {
     const int C = n->C, F = n->F, G = n->G;
+    const int base = n->useDirection >= 1 ? 8 : 4; /* fourierOffset :794 */
     float p[3];
     for (int i = 0; i < 3; ++i) p[i] = (wpos[i] - n->boxMin[i]) / n->boxSize[i]; /* :746 */
     float x[ORACLE_MAX_C + 64], y[ORACLE_MAX_C];
@@ -240,18 +241,28 @@ static void srn_eval(const OracleNet* n, const float wpos[3], float out[4], floa
     const float vx = rh(p[0]), vy = rh(p[1]), vz = rh(p[2]);
     x[0] = vx; x[1] = vy; x[2] = vz;
     x[3] = n->passTime ? rh(n->gridInterpolation[0]) : 0.f;
+    float dxh = 0, dyh = 0, dzh = 0;
+    if (n->useDirection >= 1) { /* :784-792 */
+        dxh = rh(dir[0]); dyh = rh(dir[1]); dzh = rh(dir[2]);
+        x[4] = dxh; x[5] = dyh; x[6] = dzh; x[7] = 0.f;
+    }
     for (int i = 0; i < F; ++i) {
         const float f0 = h2f(n->fourier[i]), f1 = h2f(n->fourier[i + F]), f2 = h2f(n->fourier[i + 2 * F]);
+        const int d6 = n->useDirection == 2; /* USE_DIRECTION==2: direction inside the Fourier matrix :800-804 */
+        const float f3 = d6 ? h2f(n->fourier[i + 3 * F]) : 0.f, f4 = d6 ? h2f(n->fourier[i + 4 * F]) : 0.f,
+                    f5 = d6 ? h2f(n->fourier[i + 5 * F]) : 0.f;
         if (n->accMode == ORACLE_ACC_HALF) {
             float c = hmul(vx, f0);
             c = hfma(vy, f1, c);
             c = hfma(vz, f2, c);
-            x[4 + i] = hcosf(c);
-            x[4 + F + i] = hsinf(c);
+            if (d6) { c = hfma(dxh, f3, c); c = hfma(dyh, f4, c); c = hfma(dzh, f5, c); }
+            x[base + i] = hcosf(c);
+            x[base + F + i] = hsinf(c);
         } else {
-            const double c = (double)vx * f0 + (double)vy * f1 + (double)vz * f2;
-            x[4 + i] = rh_d(cos(c));
-            x[4 + F + i] = rh_d(sin(c));
+            double c = (double)vx * f0 + (double)vy * f1 + (double)vz * f2;
+            if (d6) c += (double)dxh * f3 + (double)dyh * f4 + (double)dzh * f5;
+            x[base + i] = rh_d(cos(c));
+            x[base + F + i] = rh_d(sin(c));
         }
     }
     /* latent grid layer :839-948 */
@@ -300,13 +311,14 @@ static void srn_eval(const OracleNet* n, const float wpos[3], float out[4], floa
     }
 }
 
-int oracle_eval_points(const OracleNet* n, const float* pos, size_t count, float* out) {
+int oracle_eval_points(const OracleNet* n, const float* pos, const float* dirs, size_t count, float* out) {
     if (!n || n->C > ORACLE_MAX_C || n->G > 64) return -1;
     const int oc = (n->outputMode == ORACLE_OUT_RGBO || n->outputMode == ORACLE_OUT_RGBO_DIRECT) ? 4 : 1;
 #pragma omp parallel for schedule(static)
     for (long long i = 0; i < (long long)count; ++i) {
         float o[4], nr[3];
-        srn_eval(n, pos + 3 * i, o, nr);
+        const float zero[3] = {0, 0, 0};
+        srn_eval(n, pos + 3 * i, dirs ? dirs + 3 * i : zero, o, nr);
         for (int c = 0; c < oc; ++c) out[(size_t)i * oc + c] = o[c];
     }
     return 0;
@@ -394,7 +406,7 @@ static void render_pixel(const OracleNet* n, const OracleScene* s, int W, int H,
         ++cnt;
         const float pos[3] = {eye[0] + dir[0] * t, eye[1] + dir[1] * t, eye[2] + dir[2] * t};
         float v[4], g[3], c[4] = {0, 0, 0, 0};
-        srn_eval(n, pos, v, g);
+        srn_eval(n, pos, dir, v, g);
         if (rgbo) {
             c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3] * s->stepsize; /* :104-108 */
         } else {

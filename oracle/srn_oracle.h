@@ -21,12 +21,13 @@ enum { ORACLE_BLEND_ALPHA = 0, ORACLE_BLEND_BEER_LAMBERT = 1 };
 /* The reference's constant block, kernel::VolumeInterpolationTensorcoresParameters
  * (renderer/renderer_volume_tensorcores.cuh:195-249); all matrices are half bits. */
 typedef struct {
-    int C;           /* HIDDEN_CHANNELS = 4 + 2F                         */
+    int C;           /* HIDDEN_CHANNELS = 4 + 2F (8 + 2F with direction) */
     int F;           /* NUM_FOURIER_FEATURES                             */
     int G;           /* latent grid channels (0 = none)                  */
     int NH;          /* NUM_HIDDEN_LAYERS (C x C)                        */
     int Cout;        /* last layer outputs: 1 or 4                       */
     int outputMode, activation, gridEncoding, passTime, accMode;
+    int useDirection; /* USE_DIRECTION: 0 none, 1 extra inputs, 2 extra inputs + inside the Fourier matrix (6 columns) */
     float actParam;
     float boxMin[3], boxSize[3];
     const uint16_t* fourier; /* cWeightsFourier [3*F], feature-fastest   */
@@ -52,7 +53,7 @@ typedef struct {
     const float* tfTable;
 } OracleScene;
 
-int oracle_eval_points(const OracleNet* n, const float* worldPos, size_t count, float* out);
+int oracle_eval_points(const OracleNet* n, const float* worldPos, const float* directions /* or NULL */, size_t count, float* out);
 int oracle_render(const OracleNet* n, const OracleScene* s, int W, int H, int y0, int y1, float* out8,
                   unsigned long long* evaluatedSamples);
 unsigned long long oracle_count_samples(const OracleNet* n, const OracleScene* s, int W, int H, int y0, int y1);

@@ -72,7 +72,7 @@ class FakeInput:
 
 def make_network(SRN, *, layers, activation, fouriercount, fourierstd, outputmode, grid_channels=0, grid_res=0,
                  time_dependent=False, time_features=0, ensemble_features=0, num_time=1, num_ens=1,
-                 use_time_direct=False, seed=0):
+                 use_time_direct=False, use_direction=False, direction_in_fourier=False, seed=0):
     p = argparse.ArgumentParser()
     SRN.init_parser(p)
     args = ["--layers", layers, "--activation", activation, "--fouriercount", str(fouriercount), "--fourierstd",
@@ -84,6 +84,10 @@ def make_network(SRN, *, layers, activation, fouriercount, fourierstd, outputmod
                  str(ensemble_features)]
     if use_time_direct:
         args += ["--use_time_direct"]
+    if use_direction:
+        args += ["--use_direction"]
+        if not direction_in_fourier:
+            args += ["--disable_direction_in_fourier_features"]
     opt = vars(p.parse_args(args))
     torch.manual_seed(seed)
     net = SRN(opt, FakeInput(num_time, num_ens), torch.float32, torch.device("cpu"))
@@ -112,8 +116,8 @@ def positions(n, grid_res, seed):
     return p.astype(np.float16).astype(np.float32)
 
 
-def forward(net, pos, time=0.0, ensemble=0.0, half=False, mode="world"):
-    x = torch.from_numpy(pos)
+def forward(net, pos, time=0.0, ensemble=0.0, half=False, mode="world", directions=None):
+    x = torch.from_numpy(pos if directions is None else np.concatenate([pos, directions], axis=1))
     n = x.shape[0]
     tf = torch.zeros(n)
     t = torch.full((n,), float(time))
@@ -141,7 +145,8 @@ def save_case(name, net, opt, pos, extra_meta=None, times=None, **arrays):
     meta = {"name": name, "layers": opt["layers"], "activation": act[0],
             "activation_param": float(act[1]) if len(act) > 1 else 1.0, "output_mode": opt["outputmode"],
             "fouriercount": opt["fouriercount"], "fourierstd": opt["fourierstd"],
-            "use_time_direct": bool(opt["use_time_direct"]), "torch": torch.__version__}
+            "use_time_direct": bool(opt["use_time_direct"]), "use_direction": bool(opt["use_direction"]),
+            "torch": torch.__version__}
     meta.update(extra_meta or {})
     data["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     data.update(arrays)
@@ -192,6 +197,23 @@ def main():
                                 fourierstd=0.5, outputmode=kw["outputmode"], seed=100 + k)
         pos = positions(N, 0, k)
         save_case(name, net, opt, pos, out_fp32=forward(net, pos), out_fp16=forward(net, pos, half=True))
+
+    # ---- G1d: view direction as network input (USE_DIRECTION 1 and 2) ---------------------------------------
+    for name, kw in [
+        ("g1_dir1_c32l4_snakealt_rgbo", dict(layers="32:32:32", activation="SnakeAlt:1", outputmode="rgbo", F=12, dif=False)),
+        ("g1_dir2_c32l4_relu_density", dict(layers="32:32:32", activation="ReLU", outputmode="density", F=12, dif=True)),
+        ("g1_dir2_c64l3_grid16r8_sine_rgbo-direct", dict(layers="64:64", activation="Sine:1", outputmode="rgbo:direct", F=28, dif=True, gc=16, gr=8)),
+    ]:
+        k += 1
+        net, opt = make_network(SRN, layers=kw["layers"], activation=kw["activation"], fouriercount=kw["F"], fourierstd=0.5,
+                                outputmode=kw["outputmode"], grid_channels=kw.get("gc", 0), grid_res=kw.get("gr", 0),
+                                use_direction=True, direction_in_fourier=kw["dif"], seed=100 + k)
+        pos = positions(N, kw.get("gr", 0), k)
+        rng = np.random.RandomState(1000 + k)
+        dirs = rng.randn(N, 3)
+        dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float16).astype(np.float32)
+        save_case(name, net, opt, pos, directions=dirs, out_fp32=forward(net, pos, directions=dirs),
+                  out_fp16=forward(net, pos, half=True, directions=dirs))
 
     # ---- G2: time-dependent / ensemble latent grids ---------------------------------------------------
     times = [0.0, 0.25, 1.0, 1.75, 2.0]

@@ -24,13 +24,14 @@ TOL_IMG = 3e-3
 TOL_IMG_HALF = 2e-2
 
 
-def gpu_eval(vn, positions, time=None, ensemble=0, world=False):
+def gpu_eval(vn, positions, time=None, ensemble=0, world=False, directions=None):
     import torch
     from fvsrn_amd import capi, volnet_io
     net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
     if time is not None:
         net.set_time_and_ensemble(time, ensemble)
-    out = net.evaluate(torch.from_numpy(np.ascontiguousarray(positions, np.float32)).cuda(), world=world)
+    dirs = torch.from_numpy(np.ascontiguousarray(directions, np.float32)).cuda() if directions is not None else None
+    out = net.evaluate(torch.from_numpy(np.ascontiguousarray(positions, np.float32)).cuda(), dirs, world=world)
     torch.cuda.synchronize()
     return out.cpu().numpy()
 
@@ -45,10 +46,10 @@ def test_extension_is_loaded_and_gpu_visible():
 def test_evaluate_points_golden(name):
     d, meta = util.load_golden(name)
     vn = util.golden_to_volnet(d, meta)
-    out = gpu_eval(vn, d["positions"])
+    out = gpu_eval(vn, d["positions"], directions=d.get("directions"))
     assert np.isfinite(out).all()
-    out_f = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(d["positions"])
-    out_h = oracle.OracleNetwork(vn, oracle.ACC_HALF).evaluate(d["positions"])
+    out_f = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(d["positions"], d.get("directions"))
+    out_h = oracle.OracleNetwork(vn, oracle.ACC_HALF).evaluate(d["positions"], d.get("directions"))
     ref32, ref16 = expected_output(d, meta, "out_fp32"), expected_output(d, meta, "out_fp16")
     spread = np.abs(ref32 - ref16).max()
     assert np.abs(out - out_f).max() < TOL_SAME_MODEL
@@ -323,3 +324,20 @@ def test_render_time_dependent_byte_grids(enc):
         torch.cuda.synchronize()
         ref, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT, time=t), 40, 24)
         assert_images_close(img.cpu().numpy()[0], ref, TOL_IMG)
+
+
+@pytest.mark.parametrize("name", util.golden_names("g1_dir"))
+def test_render_view_dependent_network(name):
+    """USE_DIRECTION 1 / 2: the ray direction is a network input (renderer_volume_tensorcores.cuh:784-804)."""
+    d, meta = util.load_golden(name)
+    vn = util.golden_to_volnet(d, meta, box_min=(-0.5, -0.5, -0.5))
+    rgbo = meta["output_mode"].startswith("rgbo")
+    kw = make_scene_kwargs(tf_kind=oracle.TF_NONE) if rgbo else make_scene_kwargs(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)
+    img, ref, stats, count = render_both(vn, kw, 40, 24)
+    assert_images_close(img, ref, TOL_IMG)
+    assert stats[0] == count and img[3].max() > 0.05
+    from fvsrn_amd import capi, volnet_io
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    import torch
+    with pytest.raises(capi.FvsrnError, match="direction"):
+        net.evaluate(torch.rand(8, 3, device="cuda"))

@@ -26,8 +26,8 @@ def expected_output(d, meta, key):
 def test_network_outputs_match_reference_python(name):
     d, meta = util.load_golden(name)
     vn = util.golden_to_volnet(d, meta)
-    out_f = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(d["positions"])
-    out_h = oracle.OracleNetwork(vn, oracle.ACC_HALF).evaluate(d["positions"])
+    out_f = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(d["positions"], d.get("directions"))
+    out_h = oracle.OracleNetwork(vn, oracle.ACC_HALF).evaluate(d["positions"], d.get("directions"))
     assert np.isfinite(out_f).all() and np.isfinite(out_h).all()
     assert np.abs(out_f - expected_output(d, meta, "out_fp32")).max() < 5e-4
     assert np.abs(out_h - expected_output(d, meta, "out_fp16")).max() < 1e-2

@@ -15,7 +15,7 @@ from fvsrn_amd import capi, volnet_io
 def build_via_c_abi(d, meta, encoding=0):
     """The export_to_pyrenderer call sequence (reference network.py:798-897) through the C ABI."""
     net = capi.Network.create()
-    net.set_input(d["B"], has_time=meta.get("use_time_direct", False), premultiplied=True)
+    net.set_input(d["B"], has_time=meta.get("use_time_direct", False), has_direction=meta.get("use_direction", False), premultiplied=True)
     net.set_output_mode(meta["output_mode"])
     net.set_box((0, 0, 0), (1, 1, 1))
     if "grid" in d:

@@ -44,7 +44,7 @@ def golden_to_volnet(d, meta, *, encoding=volnet_io.ENC_FLOAT, box_min=(0.0, 0.0
         fourier_B=d["B"], weights=weights, biases=biases, activation=meta["activation"],
         activation_param=meta["activation_param"], output_mode=meta["output_mode"], box_min=box_min, box_size=box_size,
         premultiplied=True, time_grids=time_grids, ensemble_grids=ensemble_grids, grid_encoding=encoding,
-        has_time=meta.get("use_time_direct", False))
+        has_time=meta.get("use_time_direct", False), has_direction=meta.get("use_direction", False))
 
 
 def random_network(*, C=32, layers=4, activation="SnakeAlt", param=1.0, output_mode="density:direct", grid=None,
