@@ -44,7 +44,10 @@ CONFIGS = {
     "c32l4_fourier_1024x512": (32, 4, None, 1024, 1024, 512),    # the size the metric is quoted on
     "c32l4_grid16_1024x512": (32, 4, (16, 16), 1024, 1024, 512),  # configs[2]
     "c64l6_grid16_1024x512": (64, 6, (16, 32), 1024, 1024, 512),  # configs[3]
+    # configs[4]: time-dependent latent grids, 16 key frames, the time advances 0.25 key frames per rendered frame
+    "c64l6_grid16_time16_1024x512": (64, 6, (16, 32), 1024, 1024, 512),
 }
+TIME_KEYS = {"c64l6_grid16_time16_1024x512": 16}
 
 
 def build_scene_kwargs(capi, yaw, stepsize, early_out):
@@ -53,18 +56,19 @@ def build_scene_kwargs(capi, yaw, stepsize, early_out):
                 early_out=early_out, tf_kind=capi.TF_IDENTITY, tf_scale_absorption=10.0, tf_scale_emission=1.0)
 
 
-def make_network(util, volnet_io, capi, cfg, activation):
+def make_network(util, volnet_io, capi, cfg, activation, time_keys=1):
     C, layers, grid, *_ = cfg
     vn = util.random_network(C=C, layers=layers, activation=activation, param=1.0, output_mode="density:direct",
-                             grid=grid, seed=1234, box_min=(-0.5, -0.5, -0.5), grid_scale=0.01)
+                             grid=grid, seed=1234, box_min=(-0.5, -0.5, -0.5), grid_scale=0.01, time_grids=time_keys)
     return vn, capi.Network.from_volnet(volnet_io.save_volnet(vn))
 
 
 class Runner:
     """Renders frames of one network on this rank (whole frame, or this rank's stripes + all-gather)."""
 
-    def __init__(self, capi, net, cfg, rank, world, early_out):
+    def __init__(self, capi, net, cfg, rank, world, early_out, time_keys=1):
         self.capi, self.net, self.rank, self.world = capi, net, rank, world
+        self.time_keys = time_keys
         _, _, _, self.W, self.H, steps = cfg
         self.stepsize = 1.0 / steps
         self.early_out = early_out
@@ -86,6 +90,8 @@ class Runner:
         import torch.distributed as dist
         yaw = 2 * math.pi * (index % 64) / 64
         self.scene.update(**build_scene_kwargs(self.capi, yaw, self.stepsize, self.early_out))
+        if self.time_keys > 1:  # key frames are resident in HBM; this only schedules the device-side blend
+            self.net.set_time_and_ensemble((0.25 * index) % (self.time_keys - 1), 0)
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -209,9 +215,10 @@ def main():
     from fvsrn_amd import capi, volnet_io
 
     cfg = CONFIGS[args.config]
-    vn, net = make_network(util, volnet_io, capi, cfg, args.activation)
+    time_keys = TIME_KEYS.get(args.config, 1)
+    vn, net = make_network(util, volnet_io, capi, cfg, args.activation, time_keys)
     info = net.info()
-    runner = Runner(capi, net, cfg, rank, world, args.early_out)
+    runner = Runner(capi, net, cfg, rank, world, args.early_out, time_keys)
     dt, kernel_ms, evaluated, executed = timed_run(runner, args.steps, args.warmup, distributed)
     if distributed:
         import torch.distributed as dist
@@ -238,8 +245,8 @@ def main():
     twin = None
     if not args.no_twin and not distributed:
         other = "SnakeAlt" if args.activation == "ReLU" else "ReLU"
-        _, net2 = make_network(util, volnet_io, capi, cfg, other)
-        r2 = Runner(capi, net2, cfg, rank, world, args.early_out)
+        _, net2 = make_network(util, volnet_io, capi, cfg, other, time_keys)
+        r2 = Runner(capi, net2, cfg, rank, world, args.early_out, time_keys)
         dt2, k2, ev2, ex2 = timed_run(r2, max(4, args.steps // 4), 2, False)
         twin = {"activation": other, "value": ev2 / dt2, "unit": "samples/s", "ms_per_step": 1e3 * dt2 / max(4, args.steps // 4),
                 "kernel": net2.kernel_name(True),
