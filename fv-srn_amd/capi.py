@@ -14,7 +14,8 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfvsrn.so")
+# FVSRN_LIBRARY: developer override for A/B builds of the same ABI (tools/ablate.sh)
+LIB_PATH = os.environ.get("FVSRN_LIBRARY") or os.path.join(_HERE, "libfvsrn.so")
 
 ACTIVATIONS = {"ReLU": 0, "Sine": 1, "Snake": 2, "SnakeAlt": 3, "Sigmoid": 4, "None": 5}
 OUTPUT_MODES = {"density": 0, "density:direct": 1, "rgbo": 2, "rgbo:direct": 3, "densitygrad": 4,

@@ -108,7 +108,21 @@ struct fvsrn_network {
     int numCUs = 0;
     std::mutex mu;
 
-    void invalidate() { deviceValid = false; }
+    void invalidate() { deviceValid = false; occKey = 0; }
+
+    // resident workgroups per CU of the render kernel for (blockDim, dynamic LDS); cached
+    unsigned long long occKey = 0;
+    int occBlocks = 0;
+    int renderBlocksPerCU(unsigned blockDim, size_t ldsBytes) {
+        const unsigned long long k = (static_cast<unsigned long long>(ldsBytes) << 16) | blockDim;
+        if (k != occKey) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kinfoScaled.renderFn, int(blockDim), ldsBytes) != hipSuccess) n = 0;
+            occBlocks = n;
+            occKey = k;
+        }
+        return occBlocks;
+    }
 
     void pack() {  // host part only (no GPU needed): variant selection + LDS image
         packed = packNetwork(*net);
@@ -237,13 +251,28 @@ static BoxCenter P_boxCenter(const NetParams& P) {
 struct fvsrn_scene {
     fvsrn_scene_desc desc{};
     std::vector<float> tfTable;
-    DeviceBuffer dTf, dOrder;
+    DeviceBuffer dTf, dOrder, dCounters;
+    unsigned launches = 0;  // parity selects which of the two tile counters a launch uses (the kernel zeroes the other)
     bool tfDirty = true;
     std::mutex mu;
     // cached launch order of the 8x8 pixel tiles
     struct OrderKey { int tilesX = -1, tilesY = -1, cx = 0, cy = 0, y0 = 0, stripeRows = 0, stripeRank = 0, stripeWorld = 0; } orderKey;
     std::vector<int> order;
-    ~fvsrn_scene() { dTf.release(); dOrder.release(); }
+    ~fvsrn_scene() { dTf.release(); dOrder.release(); dCounters.release(); }
+
+    // Two work counters for the persistent render waves.  Launches of one scene must be ordered on one stream
+    // (like everything else a scene owns: TF table, tile order).
+    bool tileCounters(hipStream_t stream, int** cur, int** next) {
+        if (!dCounters.ptr) {
+            dCounters.ensure(2 * sizeof(int));
+            if (hipMemsetAsync(dCounters.ptr, 0, 2 * sizeof(int), stream) != hipSuccess) return false;
+        }
+        int* c = static_cast<int*>(dCounters.ptr);
+        *cur = c + (launches & 1u);
+        *next = c + ((launches + 1u) & 1u);
+        ++launches;
+        return true;
+    }
 
     // Tiles sorted by distance from the projection of the box centre: rays through the middle of the box are the
     // longest, rays that miss it cost one iteration.  The hardware dispatches workgroups in index order, so the
@@ -724,13 +753,25 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const int tiles = tilesX * tilesY;
             const size_t lds = size_t(a.P.ldsBytes) + tfFloats * 4;
             const int wpb = wavesPerBlockFor(lds);
-            const unsigned grid = unsigned((tiles + wpb - 1) / wpb);
-            // Launch order of the pixel tiles.  Measured (r01, 1024^2 x 512): centre-first helps whenever a workgroup
-            // holds several waves or the kernel waits on memory (latent grid): 64x6+grid 18.5 -> 21.1, 32x4+grid 58.5 ->
-            // 61.0 Gsamples/s; the one-wave-per-workgroup Fourier-only kernel is faster in raster order (107 -> 114):
-            // there the equally long centre tiles would all start together and march through MFMA / VALU phases in step.
+            unsigned grid = unsigned((tiles + wpb - 1) / wpb);
+            // persistent waves: no more workgroups than the chip holds at once; the rest of the tiles is handed out by
+            // a device counter (kernels.hpp).  FVSRN_PERSISTENT=0: one tile per wave, hardware dispatch order.
+            const char* pers = std::getenv("FVSRN_PERSISTENT");
+            if (!pers || pers[0] != '0') {
+                const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds);
+                const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));
+                if (perCU > 0 && grid > resident) {
+                    grid = resident;
+                    if (!scene->tileCounters(s, &S.tileCounter, &S.tileCounterNext))
+                        return fail(FVSRN_ERR_DEVICE, "could not set up the tile counters");
+                }
+            }
+            // Launch order of the pixel tiles.  Persistent waves balance the load themselves and are fastest in raster
+            // order (neighbouring tiles share latent-grid lines in L1/L2: 64x6+grid 22.1 centre-first vs 23.2 raster
+            // Gsamples/s, r01).  Without them (FVSRN_PERSISTENT=0, or a launch that fits on the chip at once) centre-first
+            // starts the long rays first, which pays whenever a workgroup holds several waves or waits on memory.
             const char* ord = std::getenv("FVSRN_TILE_ORDER");  // "0" / "1" force, unset = heuristic
-            const bool useOrder = ord ? ord[0] == '1' : (wpb > 1 || net->key.grid != 0);
+            const bool useOrder = ord ? ord[0] == '1' : (S.tileCounter == nullptr && (wpb > 1 || net->key.grid != 0));
             S.tileOrder = useOrder ? scene->tileOrder(S, P_boxCenter(a.P), tilesX, tilesY, s) : nullptr;
             const hipError_t e = launch_render(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during rendering! ") + hipGetErrorString(e));

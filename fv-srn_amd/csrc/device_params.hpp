@@ -10,8 +10,10 @@ namespace fvsrn {
 //   M tile = 32 output channels, K step = 16 input channels, N tile = 32 samples.
 // LDS image (built by pack.cpp, copied global->LDS once per workgroup):
 //   A fragments: 1 KiB each = 64 lanes x 8 halfs, lane-linear (ds_read_b128 at base+16*lane)
-//     [phase: MT] [layer0: MT x KS0] [layer l=1..NL-1: MT x KS] [last: KS]
-//   biases: fp32, natural channel order, 32*MT per C->C layer, 32 for the last layer
+//     [phase: MT] [layer 0: MT x KS (Fourier part, [m][s]) + G/16 x MT (latent steps, [g][m])] [last: KS]
+//     [layer l=1..NL-1: MT x KS, [m][s]]   (the last layer sits before the hidden ones so that "fragment i of the
+//     next layer" is always readable, see srn_forward_pipelined)
+//   biases: fp32, natural channel order, 32*MT per C->C layer, 32*MT (first 8 rows used) for the last layer
 constexpr int kFragBytes = 1024;
 
 struct NetParams {
@@ -58,6 +60,10 @@ struct SceneParams {
     int width, height, y0, y1;
     int numLocalRows, stripeRows, stripeRank, stripeWorld, compact;
     const int* tileOrder;  // device pointer: permutation of the 8x8 pixel tiles of this launch, or null
+    // persistent-wave scheduling (kernels.hpp): counter of this launch (starts at 0) and the one to reset for the next
+    // launch; null = every wave renders the slots {w, w + totalWaves, ...}
+    int* tileCounter;
+    int* tileCounterNext;
 };
 
 }  // namespace fvsrn

@@ -26,12 +26,9 @@ __device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* ld
 // ------------------------------------------------------------------------------------------------
 // EvaluateNoBatches (reference renderer/renderer_volume_kernels1.cuh:15): positions -> network value
 // ------------------------------------------------------------------------------------------------
-template <int CD, int ACT, int GRID, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) void evaluate_kernel(NetParams P, const float* __restrict__ pos,
-                                                                 const float* __restrict__ dir, size_t n,
-                                                                 float* __restrict__ out, int outChannels) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    load_network_to_lds(P, lds);
+template <int CD, int ACT, int GRID, bool HAS_DIR, bool FRACT>
+__device__ __forceinline__ void evaluate_body(const NetParams& P, const char* lds, const float* __restrict__ pos,
+                                              const float* __restrict__ dir, size_t n, float* __restrict__ out, int outChannels) {
     const int lane = lane_id();
     const size_t wavesPerBlock = blockDim.x >> 6;
     const size_t wave = size_t(blockIdx.x) * wavesPerBlock + (threadIdx.x >> 6);
@@ -48,7 +45,7 @@ __global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) 
         px = (px - P.boxMin[0]) * P.invBoxSize[0];
         py = (py - P.boxMin[1]) * P.invBoxSize[1];
         pz = (pz - P.boxMin[2]) * P.invBoxSize[2];
-        const float4_t o = srn_forward<CD, ACT, GRID, HAS_DIR>(P, lds, px, py, pz, dx, dy, dz);
+        const float4_t o = srn_forward<CD, ACT, GRID, HAS_DIR, FRACT>(P, lds, px, py, pz, dx, dy, dz);
         if (valid) {
             switch (P.outputMode) {
                 case FVSRN_OUT_DENSITY:
@@ -73,6 +70,19 @@ __global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) 
             }
         }
     }
+}
+
+// FRACT (Fourier phases beyond the v_cos_f32 domain need a v_fract first) is a property of the network: resolved by ONE
+// wave-uniform branch around the whole body instead of one per sample, which keeps the sample loop a single
+// schedulable region.
+template <int CD, int ACT, int GRID, bool HAS_DIR>
+__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) void evaluate_kernel(NetParams P, const float* __restrict__ pos,
+                                                                 const float* __restrict__ dir, size_t n,
+                                                                 float* __restrict__ out, int outChannels) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    load_network_to_lds(P, lds);
+    if (P.fourierNeedsFract) evaluate_body<CD, ACT, GRID, HAS_DIR, true>(P, lds, pos, dir, n, out, outChannels);
+    else evaluate_body<CD, ACT, GRID, HAS_DIR, false>(P, lds, pos, dir, n, out, outChannels);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -130,24 +140,24 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // depend on the grouping because blending is guarded by isValid).  Stepping is wave-synchronous like
 // the reference's __any_sync loop: all 64 lanes evaluate the network until no lane is valid.
 // ------------------------------------------------------------------------------------------------
-template <int CD, int ACT, int GRID, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
-                                                               unsigned long long* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    load_network_to_lds(P, lds);
-    // TF table behind the network image
-    float* tfLds = reinterpret_cast<float*>(lds + P.ldsBytes);
-    {
-        const int cols = S.tfKind == FVSRN_TF_GAUSSIAN ? 6 : (S.tfKind == FVSRN_TF_PIECEWISE ? 5 : (S.tfKind == FVSRN_TF_TEXTURE ? 4 : 0));
-        for (int i = threadIdx.x; i < cols * S.tfRows; i += int(blockDim.x)) tfLds[i] = S.tfTable[i];
-        __syncthreads();
-    }
-
+template <int CD, int ACT, int GRID, bool HAS_DIR, bool FRACT>
+__device__ __forceinline__ void render_body(const NetParams& P, const SceneParams& S, const char* lds, const float* tfLds,
+                                            float* __restrict__ out, unsigned long long* __restrict__ stats) {
     const int lane = lane_id();
     const int tilesX = (S.width + 7) >> 3;
     const int tilesY = (S.numLocalRows + 7) >> 3;
-    const int slot = blockIdx.x * int(blockDim.x >> 6) + int(threadIdx.x >> 6);
-    if (slot >= tilesX * tilesY) return;  // whole wave leaves together
+    const int numTiles = tilesX * tilesY;
+    // Persistent waves: the launch holds as many workgroups as fit on the chip; every wave renders launch slot
+    // (its own index), then keeps taking the next unrendered slot from a device counter until none is left.  Ray lengths
+    // differ by 500x between tiles, so a static assignment leaves a quarter of the wave slots idle on average (r01 PMC:
+    // SQ_WAVE_CYCLES).  The counter of the NEXT launch is zeroed here (launches of one scene are stream-ordered).
+    const int wavesPerBlock = int(blockDim.x >> 6);
+    const int totalWaves = int(gridDim.x) * wavesPerBlock;
+    if (S.tileCounterNext && blockIdx.x == 0 && threadIdx.x == 0) *S.tileCounterNext = 0;
+    unsigned nValid = 0, nSteps = 0;  // wave-uniform (scalar registers): lane-exact samples / executed wave steps
+    const bool rgboNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
+    const bool gradNet = P.outputMode >= FVSRN_OUT_DENSITY_GRADIENT && P.outputMode <= FVSRN_OUT_DENSITY_GRADIENT_CUBIC;
+    for (int slot = int(blockIdx.x) * wavesPerBlock + int(threadIdx.x >> 6); slot < numTiles;) {
     // launch slot -> pixel tile: the host orders tiles by expected ray length (centre of the projected box first), so
     // the long tiles start first and the empty ones fill the tail of the launch
     const int tile = S.tileOrder ? S.tileOrder[slot] : slot;
@@ -188,9 +198,6 @@ __global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) 
     const float pn0z = (oz - P.boxMin[2]) * P.invBoxSize[2], dnz = dz * P.invBoxSize[2];
 
     float cr = 0, cg = 0, cb = 0, ca = 0, nx = 0, ny = 0, nz = 0, depth = 0;
-    unsigned nValid = 0, nSteps = 0;  // wave-uniform (scalar registers): lane-exact samples / executed wave steps
-    const bool rgboNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
-    const bool gradNet = P.outputMode >= FVSRN_OUT_DENSITY_GRADIENT && P.outputMode <= FVSRN_OUT_DENSITY_GRADIENT_CUBIC;
 
     for (int i = 0;; ++i) {
         const float t = tmin + float(i) * S.stepsize;
@@ -204,8 +211,12 @@ __global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) 
         nValid += unsigned(__builtin_popcountll(validMask));
 
         const float px = fmaf(dnx, t, pn0x), py = fmaf(dny, t, pn0y), pz = fmaf(dnz, t, pn0z);
-        const float4_t o = srn_forward<CD, ACT, GRID, HAS_DIR>(P, lds, px, py, pz, dx, dy, dz);
+        const float4_t o = srn_forward<CD, ACT, GRID, HAS_DIR, FRACT>(P, lds, px, py, pz, dx, dy, dz);
 
+#ifdef FVSRN_ABL_NOTAIL  // ablation build (tools/ablate.sh): no output parametrization / TF / blending
+        cr += o[0] * 1e-30f;
+        continue;
+#endif
         float4_t color = {0, 0, 0, 0};
         float gx = 0, gy = 0, gz = 0;
         if (rgboNet) {  // stepping_dvr.cuh:104-109
@@ -252,10 +263,34 @@ __global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) 
         out[6 * plane + o] = nz * ca;
         out[7 * plane + o] = depth * ca / ca;  // (depth*alpha)/alpha, NaN for alpha == 0 like the reference
     }
+    if (S.tileCounter) {
+        int next = 0;
+        if (lane == 0) next = atomicAdd(S.tileCounter, 1);
+        slot = totalWaves + __builtin_amdgcn_readfirstlane(next);
+    } else {
+        slot += totalWaves;
+    }
+    }  // slot loop
     if (stats && lane == 0) {
         atomicAdd(&stats[0], (unsigned long long)nValid);
         atomicAdd(&stats[1], (unsigned long long)nSteps * 64ull);
     }
+}
+
+template <int CD, int ACT, int GRID, bool HAS_DIR>
+__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+                                                               unsigned long long* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    load_network_to_lds(P, lds);
+    // TF table behind the network image
+    float* tfLds = reinterpret_cast<float*>(lds + P.ldsBytes);
+    {
+        const int cols = S.tfKind == FVSRN_TF_GAUSSIAN ? 6 : (S.tfKind == FVSRN_TF_PIECEWISE ? 5 : (S.tfKind == FVSRN_TF_TEXTURE ? 4 : 0));
+        for (int i = threadIdx.x; i < cols * S.tfRows; i += int(blockDim.x)) tfLds[i] = S.tfTable[i];
+        __syncthreads();
+    }
+    if (P.fourierNeedsFract) render_body<CD, ACT, GRID, HAS_DIR, true>(P, S, lds, tfLds, out, stats);
+    else render_body<CD, ACT, GRID, HAS_DIR, false>(P, S, lds, tfLds, out, stats);
 }
 
 }  // namespace fvsrn

@@ -158,10 +158,12 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
     NetParams& np = P.params;
     size_t off = 0;
     np.offPhase = int(off);  off += size_t(MT) * kFragBytes;
-    np.offLayer0 = int(off); off += size_t(MT) * KS0 * kFragBytes;
-    np.offHidden = int(off); off += size_t(NL - 1) * MT * KS * kFragBytes;
+    np.offLayer0 = int(off); off += size_t(MT) * KS0 * kFragBytes;  // [m][s < KS] like a hidden layer, then the latent steps [g][m]
     np.offLast = int(off);   off += size_t(KS) * kFragBytes;
-    np.offBias = int(off);   off += (size_t(NL) * 32 * MT + 32) * sizeof(float);
+    np.offHidden = int(off); off += size_t(NL - 1) * MT * KS * kFragBytes;
+    // the kernels prefetch "the next layer" as MT*KS fragments, also when that is the last one (only KS of them are used)
+    off = std::max(off, size_t(np.offLast) + size_t(MT) * KS * kFragBytes);
+    np.offBias = int(off);   off += (size_t(NL) * 32 * MT + 32 * MT) * sizeof(float);  // same reason: MT blocks for the last layer
     np.ldsBytes = int(off);
     P.ldsImage.assign(off, 0);
     np.numLayers = NL;
@@ -250,7 +252,8 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
                             f.v[lane][j] = scaleHalf(L.weights[size_t(row) * L.channelsIn + col], kW);
                         }
                     }
-                    putFrag(img, baseOff + (size_t(m) * ks + s) * kFragBytes, f);
+                    const size_t fragIndex = s < KS ? size_t(m) * KS + s : size_t(MT) * KS + size_t(s - KS) * MT + m;
+                    putFrag(img, baseOff + fragIndex * kFragBytes, f);
                 }
             for (int r = 0; r < C; ++r) bias[size_t(l) * 32 * MT + r] = std::ldexp(half_bits_to_float(L.bias[size_t(r)]), kB);
         }

@@ -16,6 +16,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "device_params.hpp"
 #include "srn_device_enums.hpp"
 
@@ -208,31 +210,64 @@ __device__ __forceinline__ float erfinv_dev(float x) {
     return p * x;
 }
 
-// trilinear fetch of 8 channels [16*g + 8*h, +8) from one working grid: fp32 results
+// The trilinear fetch of 8 channels [16*g + 8*h, +8) of one working grid, in three pieces so that the loads can be
+// issued long before the arithmetic: 8 x 16-byte loads -> 32 x v_dot2_f32_f16 (4 records) -> 4 x v_cvt_pk.
+struct GridRaw {
+    uint4_t v[4][2];
+};
+
+__device__ __forceinline__ void grid_load(const void* grid, const GridTap& t, int g, int h, GridRaw& r) {
+    const char* base = reinterpret_cast<const char*>(grid) + (g * 64 + h * 32);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#ifdef FVSRN_ABL_NOGRIDLOAD  // ablation build (tools/ablate.sh): no memory access
+        r.v[k][0] = uint4_t{t.off[k], t.w[k], 0x3c003c00u, 0x38003800u};
+        r.v[k][1] = uint4_t{t.w[k], t.off[k], 0x3c003c00u, 0x38003800u};
+#else
+        const uint4_t* p = reinterpret_cast<const uint4_t*>(base + t.off[k]);
+        r.v[k][0] = p[0];
+        r.v[k][1] = p[1];
+#endif
+    }
+}
+
+template <bool WITH_LO>
+__device__ __forceinline__ void grid_reduce_record(const GridRaw& r, const GridTap& t, int k, float acc[8]) {
+    const half2_t w = __builtin_bit_cast(half2_t, t.w[k]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // NB: __builtin_bit_cast applied directly to a vector ELEMENT (v[j]) is miscompiled by clang 22 /
+        // ROCm 7.2 (only element 0 survives): go through a scalar temporary
+        const unsigned u0 = r.v[k][0][j], u1 = r.v[k][1][j];
+        acc[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u0), w, acc[j], false);
+        acc[4 + j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u1), w, acc[4 + j], false);
+        if constexpr (WITH_LO) {
+            const half2_t wl = __builtin_bit_cast(half2_t, t.wlo[k]);
+            acc[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u0), wl, acc[j], false);
+            acc[4 + j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u1), wl, acc[4 + j], false);
+        }
+    }
+}
+
+__device__ __forceinline__ half8_t grid_pack(const float acc[8]) {
+    half8_t out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float2_t v = {acc[2 * i], acc[2 * i + 1]};
+        const half2_t hh = __builtin_convertvector(v, half2_t);
+        out[2 * i] = hh[0]; out[2 * i + 1] = hh[1];
+    }
+    return out;
+}
+
 template <bool WITH_LO>
 __device__ __forceinline__ void grid_fetch8(const void* grid, const GridTap& t, int g, int h, float acc[8]) {
-    const char* base = reinterpret_cast<const char*>(grid) + (g * 64 + h * 32);
+    GridRaw r;
+    grid_load(grid, t, g, h, r);
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint4_t* p = reinterpret_cast<const uint4_t*>(base + t.off[k]);
-        const uint4_t v0 = p[0], v1 = p[1];
-        const half2_t w = __builtin_bit_cast(half2_t, t.w[k]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // NB: __builtin_bit_cast applied directly to a vector ELEMENT (v0[j]) is miscompiled by clang 22 /
-            // ROCm 7.2 (only element 0 survives): go through a scalar temporary
-            const unsigned u0 = v0[j], u1 = v1[j];
-            acc[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u0), w, acc[j], false);
-            acc[4 + j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u1), w, acc[4 + j], false);
-            if constexpr (WITH_LO) {
-                const half2_t wl = __builtin_bit_cast(half2_t, t.wlo[k]);
-                acc[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u0), wl, acc[j], false);
-                acc[4 + j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u1), wl, acc[4 + j], false);
-            }
-        }
-    }
+    for (int k = 0; k < 4; ++k) grid_reduce_record<WITH_LO>(r, t, k, acc);
 }
 
 // 8 channels [16*g + 8*h, +8) of the tile sample described by `t`, as the B fragment of latent K step g
@@ -258,12 +293,296 @@ __device__ __forceinline__ half8_t grid_features(const NetParams& P, const GridT
             acc[j] = va + f * (vb - va);
         }
     }
-    half8_t out;
+    return grid_pack(acc);
+}
+
+// ---- building blocks of the forward pass -------------------------------------------------------------------
+// quarter q (0..3) of one M tile: accumulator registers {2q,2q+1} / {8+2q,9+2q} -> half pairs q of the two B fragments
+// (K steps 2m and 2m+1 of the next layer), with the activation
+template <int ACT>
+__device__ __forceinline__ void act_pack_quarter(const floatx16& d, int q, float a, float b, half8_t& f0, half8_t& f1) {
+    const float2_t v0 = {d[2 * q], d[2 * q + 1]};
+    const float2_t v1 = {d[8 + 2 * q], d[9 + 2 * q]};
+    half2_t h0, h1;
+    if constexpr (ACT == ACT_RELU01) {
+        const half2_t z = {0, 0}, o = {1, 1};
+        h0 = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_convertvector(v0, half2_t), z), o);  // = the convert's clamp bit
+        h1 = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_convertvector(v1, half2_t), z), o);
+    } else if constexpr (ACT == ACT_RELU) {
+        const half2_t z = {0, 0};
+        h0 = __builtin_elementwise_max(__builtin_convertvector(v0, half2_t), z);
+        h1 = __builtin_elementwise_max(__builtin_convertvector(v1, half2_t), z);
+    } else {
+        h0 = __builtin_convertvector(act_f32x2<ACT>(v0, a, b), half2_t);
+        h1 = __builtin_convertvector(act_f32x2<ACT>(v1, a, b), half2_t);
+    }
+    f0[2 * q] = h0[0]; f0[2 * q + 1] = h0[1];
+    f1[2 * q] = h1[0]; f1[2 * q + 1] = h1[1];
+}
+
+// same quarter of a Fourier phase tile (revolutions): cos, except on the first `npass` registers (pass-through channels)
+template <bool FRACT>
+__device__ __forceinline__ void phase_pack_quarter(const floatx16& d, int q, int npass, half8_t& f0, half8_t& f1) {
+    float x[4] = {d[2 * q], d[2 * q + 1], d[8 + 2 * q], d[9 + 2 * q]};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float2_t v = {acc[2 * i], acc[2 * i + 1]};
-        const half2_t hh = __builtin_convertvector(v, half2_t);
-        out[2 * i] = hh[0]; out[2 * i + 1] = hh[1];
+    for (int k = 0; k < 4; ++k) {
+        const int r = k < 2 ? 2 * q + k : 8 + 2 * q + (k - 2);
+#ifdef FVSRN_ABL_NOCOS
+        if (false) {
+#else
+        if (r >= npass) {
+#endif
+            if constexpr (FRACT) x[k] = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(x[k]));  // keep v_cos_f32 inside +-256 revolutions
+            else x[k] = __builtin_amdgcn_cosf(x[k]);
+        }
+    }
+    const float2_t v0 = {x[0], x[1]}, v1 = {x[2], x[3]};
+    const half2_t h0 = __builtin_convertvector(v0, half2_t), h1 = __builtin_convertvector(v1, half2_t);
+    f0[2 * q] = h0[0]; f0[2 * q + 1] = h0[1];
+    f1[2 * q] = h1[0]; f1[2 * q + 1] = h1[1];
+}
+
+// Instruction-order helper.  Issues fm(0..NMF-1) (one MFMA each) with the NCH pieces of independent VALU work
+// fv(0..NCH-1) spread between them, and pins that order (hipcc would otherwise group the MFMAs).  A wave issues in order:
+// VALU work placed behind an MFMA runs in the 32 cycles the matrix pipe needs for it.
+template <int NMF, int NCH, class FM, class FV>
+__device__ __forceinline__ void interleave(FM&& fm, FV&& fv) {
+#pragma unroll
+    for (int i = 0; i < NMF; ++i) {
+        fm(i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = (i * NCH) / NMF; j < ((i + 1) * NCH) / NMF; ++j) fv(j);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// B operand of the phase MFMA for one tile
+template <bool HAS_DIR>
+__device__ __forceinline__ half8_t phase_operand(const unsigned (&tp)[3], const float (&tdir)[3], int h) {
+    if constexpr (HAS_DIR) {
+        const float2_t vx = {tdir[0], tdir[0]}, vy = {tdir[1], tdir[1]}, vz = {tdir[2], tdir[2]};
+        const unsigned dxh = __builtin_bit_cast(unsigned, __builtin_convertvector(vx, half2_t));
+        const unsigned dyh = __builtin_bit_cast(unsigned, __builtin_convertvector(vy, half2_t));
+        const unsigned dzh = __builtin_bit_cast(unsigned, __builtin_convertvector(vz, half2_t));
+        const uint4_t u = {h ? dxh : tp[0], h ? dyh : tp[1], h ? dzh : tp[2], h ? 0u : 0x00003c00u};
+        return __builtin_bit_cast(half8_t, u);
+    } else {
+        // lane half 1 supplies K slots 8..15, whose phase-matrix entries are all zero: its B values are
+        // multiplied by 0 and only need to be finite, so no select is needed
+        const uint4_t u = {tp[0], tp[1], tp[2], 0x00003c00u /* (1.0h, 0) */};
+        return __builtin_bit_cast(half8_t, u);
+    }
+}
+
+// Evaluates the network for the 64 samples of this wave.
+//   (px,py,pz): this lane's sample position, already normalized to the unit box
+//   (dx,dy,dz): this lane's view direction (only read when the network uses it)
+// Returns the raw last-layer outputs (before the output parametrization) of this lane's sample.
+// EXEC must be all ones.
+//
+// Schedule (hidden widths up to 64).  The two sample tiles t0,t1 of the wave run half a layer apart:
+//     A_l: MFMAs of layer l for t0   ||  activation+convert of layer l-1 for t1, bias(l)   -> accumulators of t1
+//     B_l: MFMAs of layer l for t1   ||  activation+convert of layer l   for t0, bias(l+1) -> accumulators of t0,
+//                                        weight fragments of layer l+1 -> registers (each right after its last use)
+// so inside ONE wave the matrix pipe always has the other tile's chain to work on while the VALU converts, every LDS
+// read (weights, biases) is issued at least half a layer before its use, and the first latent-grid chunk is fetched
+// from L2/HBM before the Fourier stage and reduced behind the first layer's MFMAs.  Biases are read straight into the
+// accumulator registers (the MFMA C operand), weight fragments are read once per layer and shared by both tiles.
+// Measured motivation (r01 PMC, 64x6+grid): with loads issued right before their use and all converts after all
+// MFMAs of a layer the matrix pipe was 49% busy and waves spent half their cycles in s_waitcnt.
+template <int CD, int ACT, int GRID, bool HAS_DIR, bool FRACT>
+__device__ __forceinline__ float4_t srn_forward_pipelined(const NetParams& P, const char* lds, float px, float py, float pz,
+                                                          float dx, float dy, float dz) {
+    constexpr int C = 16 * CD;
+    constexpr int MT = (C + 31) / 32, KS = CD, NM = MT * KS, NX = KS + (KS & 1), NV = 4 * MT;
+    constexpr int NPASS = HAS_DIR ? 4 : 2;
+    const int lane = lane_id();
+    const int h = lane >> 5;
+    const float actA = P.actA, actB = P.actB;
+    const char* ldsA = lds + 16 * lane;  // A fragments are lane-linear
+    const char* ldsB = lds + 16 * h;     // bias blocks: this lane half's rows 8g + 4h .. +3 at 32g bytes
+    auto frag = [&](int byteOff) { return *reinterpret_cast<const half8_t*>(ldsA + byteOff); };
+    auto bias = [&](int byteOff) {
+        floatx16 c;
+        const float4_t* p = reinterpret_cast<const float4_t*>(ldsB + byteOff);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4_t v = p[2 * g];
+            c[4 * g + 0] = v[0]; c[4 * g + 1] = v[1]; c[4 * g + 2] = v[2]; c[4 * g + 3] = v[3];
+        }
+        return c;
+    };
+
+    half8_t aph[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) aph[m] = frag(P.offPhase + m * kFragBytes);
+
+    // Positions of the two sample tiles: fp16 images (both halves of a register = the hi/lo slot pair of the phase
+    // matrix), then exchanged between the lane halves.
+    unsigned tph[2][3];
+    {
+        const float pp[3] = {px, py, pz};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float2_t v = {pp[i], pp[i]};
+            const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
+            auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            tph[0][i] = r[0];
+            tph[1][i] = r[1];
+        }
+    }
+    float td[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    if constexpr (HAS_DIR) {
+        tile_bcast(dx, td[0][0], td[1][0]);
+        tile_bcast(dy, td[0][1], td[1][1]);
+        tile_bcast(dz, td[0][2], td[1][2]);
+    }
+
+    floatx16 acc[2][MT];
+    half8_t xb[2][NX];
+
+    // ---- Fourier phases: MT MFMAs per tile ----------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const half8_t b0 = phase_operand<HAS_DIR>(tph[t], td[t], h);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const floatx16 z = {0};
+            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aph[m], b0, z, 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // weight fragments of the first layer (its Fourier part has the layout of a hidden layer)
+    half8_t a[NM];
+#pragma unroll
+    for (int i = 0; i < NM; ++i) a[i] = frag(P.offLayer0 + i * kFragBytes);
+    const int offGridW = P.offLayer0 + NM * kFragBytes;  // [g][m] fragments of the latent K steps
+    half8_t ag[MT];
+    GridTap gt[2];
+    GridRaw raw;
+    if constexpr (GRID != 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) ag[m] = frag(offGridW + m * kFragBytes);
+        grid_tap_bcast<GRID == 2>(grid_tap(P, px, py, pz), gt[0], gt[1]);
+        if constexpr (GRID == 1) grid_load(P.grid, gt[0], 0, h, raw);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- cos + convert; the freed accumulators take the bias of the first layer ----------------------------------
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) phase_pack_quarter<FRACT>(acc[t][m], q, m == 0 ? NPASS : 0, xb[t][2 * m], xb[t][2 * m + 1]);
+            acc[t][m] = bias(P.offBias + m * 128);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    const int NL = P.numLayers;
+    constexpr int kBiasLayer = 32 * MT * 4;
+    // ---- first layer, tile 0 -------------------------------------------------------------------------------------
+    half8_t gf;
+    if constexpr (GRID == 1) {
+        float gacc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gacc[j] = 0.f;
+        interleave<NM, 5>([&](int i) { acc[0][i / KS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], xb[0][i % KS], acc[0][i / KS], 0, 0, 0); },
+                          [&](int j) {
+                              if (j < 4) grid_reduce_record<false>(raw, gt[0], j, gacc);
+                              else gf = grid_pack(gacc);
+                          });
+        grid_load(P.grid, gt[1], 0, h, raw);  // tile 1's chunk: in flight behind tile 1's first-layer MFMAs
+    } else {
+#pragma unroll
+        for (int i = 0; i < NM; ++i) acc[0][i / KS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], xb[0][i % KS], acc[0][i / KS], 0, 0, 0);
+    }
+    if constexpr (GRID != 0) {
+        for (int g = 0; g < P.gridK; ++g) {
+            if (GRID == 2 || g > 0) gf = grid_features<GRID>(P, gt[0], g, h);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const half8_t w = g == 0 ? ag[m] : frag(offGridW + (g * MT + m) * kFragBytes);
+                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, gf, acc[0][m], 0, 0, 0);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // One half-layer slot: MFMAs of tile T over the fragments in a[] || activation+convert of the other tile, whose
+    // accumulators then take the bias block at `biasOff`; RELOAD: a[i] <- fragment i at `nextW` right after its use.
+    auto slot = [&](auto tileTag, auto reloadTag, int biasOff, int nextW) {
+        constexpr int T = decltype(tileTag)::value, O = 1 - T;
+        constexpr bool RELOAD = decltype(reloadTag)::value;
+        interleave<NM, NV>(
+            [&](int i) {
+                acc[T][i / KS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], xb[T][i % KS], acc[T][i / KS], 0, 0, 0);
+                if constexpr (RELOAD) a[i] = frag(nextW + i * kFragBytes);
+            },
+            [&](int j) {
+                const int m = j / 4, q = j % 4;
+                act_pack_quarter<ACT>(acc[O][m], q, actA, actB, xb[O][2 * m], xb[O][2 * m + 1]);
+                if (q == 3) acc[O][m] = bias(biasOff + m * 128);
+            });
+    };
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+    using Yes = std::true_type;
+    using No = std::false_type;
+
+    // ---- first layer, tile 1 || convert tile 0 -----------------------------------------------------------------------
+    slot(T1{}, Yes{}, P.offBias + kBiasLayer, NL > 1 ? P.offHidden : P.offLast);
+    if constexpr (GRID != 0) {
+        for (int g = 0; g < P.gridK; ++g) {
+            if (GRID == 1 && g == 0) {
+                float gacc[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gacc[j] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) grid_reduce_record<false>(raw, gt[1], k, gacc);
+                gf = grid_pack(gacc);
+            } else {
+                gf = grid_features<GRID>(P, gt[1], g, h);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const half8_t w = g == 0 ? ag[m] : frag(offGridW + (g * MT + m) * kFragBytes);
+                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, gf, acc[1][m], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- layers 1 .. NL-1 -----------------------------------------------------------------------------------------------
+#ifdef FVSRN_ABL_NOHIDDEN
+    for (int l = 1; l < NL; l += 1000) {
+#else
+    for (int l = 1; l < NL; ++l) {
+#endif
+        slot(T0{}, No{}, P.offBias + l * kBiasLayer, 0);
+        slot(T1{}, Yes{}, P.offBias + (l + 1) * kBiasLayer, l + 1 < NL ? P.offHidden + l * NM * kFragBytes : P.offLast);
+    }
+
+    // ---- last layer (rows replicated for both lane halves; its fragments are a[0..KS-1], its bias is in place) ----
+    interleave<KS, NV>([&](int s) { acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], xb[0][s], acc[0][0], 0, 0, 0); },
+                       [&](int j) {
+                           const int m = j / 4, q = j % 4;
+                           act_pack_quarter<ACT>(acc[1][m], q, actA, actB, xb[1][2 * m], xb[1][2 * m + 1]);
+                           if (j == 3) acc[1][0] = bias(P.offBias + NL * kBiasLayer);
+                       });
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], xb[1][s], acc[1][0], 0, 0, 0);
+
+    // rows 0..3 (lane half 0) and rows 4..7 (lane half 1) both carry outputs 0..3 of sample c of the tile
+    float4_t out = {0, 0, 0, 0};
+    out[0] = h ? acc[1][0][0] : acc[0][0][0];
+    if (P.outputMode >= FVSRN_OUT_RGBO) {  // wave-uniform: only colour / gradient networks have outputs 1..3
+        out[1] = h ? acc[1][0][1] : acc[0][0][1];
+        out[2] = h ? acc[1][0][2] : acc[0][0][2];
+        out[3] = h ? acc[1][0][3] : acc[0][0][3];
     }
     return out;
 }
@@ -273,8 +592,10 @@ __device__ __forceinline__ half8_t grid_features(const NetParams& P, const GridT
 //   (dx,dy,dz): this lane's view direction (only read when the network uses it)
 // Returns the raw last-layer outputs (before the output parametrization) of this lane's sample.
 // EXEC must be all ones.
-template <int CD, int ACT, int GRID, bool HAS_DIR>
-__device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* lds, float px, float py, float pz,
+// Weight-fragment-major order for wide networks (C >= 96): a layer's fragments do not fit into registers next to the
+// accumulators, so each fragment is read from LDS right before its two MFMAs (one per tile).
+template <int CD, int ACT, int GRID, bool HAS_DIR, bool FRACT>
+__device__ __forceinline__ float4_t srn_forward_kmajor(const NetParams& P, const char* lds, float px, float py, float pz,
                                                 float dx, float dy, float dz) {
     constexpr int C = 16 * CD;
     constexpr int MT = (C + 31) / 32;
@@ -312,27 +633,14 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
     // ---- Fourier layer: phases by MFMA, then cos ------------------------------------------------------
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        half8_t b0;
-        if constexpr (HAS_DIR) {
-            const float2_t vx = {td[t][0], td[t][0]}, vy = {td[t][1], td[t][1]}, vz = {td[t][2], td[t][2]};
-            const unsigned dxh = __builtin_bit_cast(unsigned, __builtin_convertvector(vx, half2_t));
-            const unsigned dyh = __builtin_bit_cast(unsigned, __builtin_convertvector(vy, half2_t));
-            const unsigned dzh = __builtin_bit_cast(unsigned, __builtin_convertvector(vz, half2_t));
-            const uint4_t u = {h ? dxh : tph[t][0], h ? dyh : tph[t][1], h ? dzh : tph[t][2], h ? 0u : 0x00003c00u};
-            b0 = __builtin_bit_cast(half8_t, u);
-        } else {
-            // lane half 1 supplies K slots 8..15, whose phase-matrix entries are all zero: its B values are
-            // multiplied by 0 and only need to be finite, so no select is needed
-            const uint4_t u = {tph[t][0], tph[t][1], tph[t][2], 0x00003c00u /* (1.0h, 0) */};
-            b0 = __builtin_bit_cast(half8_t, u);
-        }
+        const half8_t b0 = phase_operand<HAS_DIR>(tph[t], td[t], h);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             floatx16 d = {0};
             d = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(lds, P.offPhase + m * kFragBytes, lane), b0, d, 0, 0, 0);
             // registers 0,1 (0..3 with direction) of M tile 0 are pass-through channels
             floatx16 x;
-            if (P.fourierNeedsFract) {  // keep v_cos_f32 inside its +-256 revolution domain
+            if constexpr (FRACT) {  // keep v_cos_f32 inside its +-256 revolution domain
 #pragma unroll
                 for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(d[r]));
             } else {
@@ -362,36 +670,17 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
     // ---- C -> C layers -----------------------------------------------------------------------------------
     const int NL = P.numLayers;
     for (int l = 0; l < NL; ++l) {
-        const int ks = (GRID != 0 && l == 0) ? KS + P.gridK : KS;
         const int wOff = l == 0 ? P.offLayer0 : P.offHidden + (l - 1) * MT * KS * kFragBytes;
         const int bOff = P.offBias + l * 32 * MT * 4;
         floatx16 acc[2][MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const floatx16 bias = lds_bias(lds, bOff + m * 128, h);
-#ifndef FVSRN_K_MAJOR
-            if constexpr (KS <= 4) {
-                // tile-major issue order: tile 0's chain completes while tile 1's MFMAs still run, so the VALU work
-                // on tile 0's accumulators overlaps the matrix pipe inside one wave
-                half8_t a[KS];
 #pragma unroll
-                for (int s = 0; s < KS; ++s) a[s] = lds_frag(lds, wOff + (m * ks + s) * kFragBytes, lane);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                    for (int s = 0; s < KS; ++s)
-                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], xb[t][s], s == 0 ? bias : acc[t][m], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);  // keep the two chains apart (hipcc would re-interleave them)
-                }
-            } else
-#endif
-            {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const half8_t a = lds_frag(lds, wOff + (m * ks + s) * kFragBytes, lane);
-                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[0][s], s == 0 ? bias : acc[0][m], 0, 0, 0);
-                    acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[1][s], s == 0 ? bias : acc[1][m], 0, 0, 0);
-                }
+            for (int s = 0; s < KS; ++s) {
+                const half8_t a = lds_frag(lds, wOff + (m * KS + s) * kFragBytes, lane);
+                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[0][s], s == 0 ? bias : acc[0][m], 0, 0, 0);
+                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[1][s], s == 0 ? bias : acc[1][m], 0, 0, 0);
             }
         }
         if constexpr (GRID != 0) {
@@ -401,7 +690,7 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
                     const half8_t g1 = grid_features<GRID>(P, gt[1], g, h);
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
-                        const half8_t a = lds_frag(lds, wOff + (m * ks + KS + g) * kFragBytes, lane);
+                        const half8_t a = lds_frag(lds, wOff + (MT * KS + g * MT + m) * kFragBytes, lane);
                         acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, g0, acc[0][m], 0, 0, 0);
                         acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, g1, acc[1][m], 0, 0, 0);
                     }
@@ -437,6 +726,18 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
         out[3] = h ? o1[3] : o0[3];
     }
     return out;
+}
+
+template <int CD, int ACT, int GRID, bool HAS_DIR, bool FRACT>
+__device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* lds, float px, float py, float pz,
+                                                float dx, float dy, float dz) {
+#ifndef FVSRN_NO_PIPELINE
+    // measured (r01): the pipelined order wins for Fourier-only networks; with a latent grid its extra registers
+    // (197 / 256 vs 120 / 163) cost more occupancy than the schedule gains
+    if constexpr (CD <= 4 && GRID == 0) return srn_forward_pipelined<CD, ACT, GRID, HAS_DIR, FRACT>(P, lds, px, py, pz, dx, dy, dz);
+    else
+#endif
+        return srn_forward_kmajor<CD, ACT, GRID, HAS_DIR, FRACT>(P, lds, px, py, pz, dx, dy, dz);
 }
 
 // output parametrization, renderer_volume_tensorcores.cuh:1054-1158. The reference rounds the

@@ -1,0 +1,22 @@
+#!/bin/bash
+# usage (on the GPU box): tools/pmc_profile.sh <tag> [bench args...]
+# Runs rocprofv3 --kernel-trace --stats once and the PMC passes (separate runs, counters only) for bench.py with the
+# given arguments and writes the per-launch summary of the render kernel to gpurun_out/<tag>_{stats,pmc}.csv.
+tag=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/prof_$tag
+mkdir -p $O
+B="$R/bench.py --steps 6 --warmup 2 --no-twin --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $B > $O/stats.log 2>&1
+i=0
+for set in \
+  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" \
+  "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM" \
+  "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_LEVEL_WAVES" \
+  "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "TCP_TCC_READ_REQ TCP_PENDING_STALL_CYCLES TCC_HIT TCC_MISS"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc$i -- python3 $B > $O/pmc$i.log 2>&1
+done
+python3 $R/tools/pmc_summary.py $O $tag > $R/gpurun_out/${tag}_pmc.csv
+cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $R/gpurun_out/${tag}_kernel_stats.csv 2>/dev/null
+cat $R/gpurun_out/${tag}_pmc.csv
