@@ -23,7 +23,8 @@ struct NetParams {
     int gridK;             // latent grid channels / 16 (0 = none)
     int outputMode;        // fvsrn_output_mode
     int offPhase, offLayer0, offHidden, offLast, offBias;  // byte offsets into the LDS image
-    int fourierNeedsFract;  // |phase| may exceed the v_cos_f32 domain of 256 revolutions
+    int fourierNeedsFract;      // |phase| may exceed the v_cos_f32 domain of 256 revolutions for positions inside the box
+    int fourierNeedsFractEval;  // ... for positions up to 4 box sizes away (evaluate_points takes arbitrary positions)
     int reluClamp;          // ldsImage is the [0,1]-scaled ReLU image: convert+ReLU is one clamped v_cvt_pk_f16_f32
     float actA, actB;       // activation constants, see act() in srn_device.hpp
     float boxMin[3];

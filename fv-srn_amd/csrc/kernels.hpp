@@ -7,10 +7,15 @@ namespace fvsrn {
 #ifndef FVSRN_WAVES_PER_EU
 #define FVSRN_WAVES_PER_EU 2
 #endif
+#ifndef FVSRN_WAVES_PER_EU_CD2
+#define FVSRN_WAVES_PER_EU_CD2 3
+#endif
 // Workgroups are 1..4 waves (blockDim.x = 64..256, chosen by the host from the LDS footprint of the network): the
 // waves of a workgroup share one LDS copy of the network, and a workgroup's resources are only recycled when its
 // slowest wave (= longest ray of 4 pixel tiles) is done, so small networks run one wave per workgroup.
 constexpr int kBlockThreads = 256;  // upper bound (launch bounds)
+// register budget: 512 / waves.  32-wide Fourier-only kernels (input features + their rotation in registers) fit 168.
+constexpr int min_waves_per_simd(int CD, int GRID) { return CD >= 8 ? 1 : (CD == 2 && GRID == 0 ? FVSRN_WAVES_PER_EU_CD2 : FVSRN_WAVES_PER_EU); }
 // __launch_bounds__(256, 2): at most 256 registers per lane, which also makes hipcc use the VGPR form of the MFMA
 // (accumulators in AGPRs cost one v_accvgpr_read per value before the VALU can touch them: +32 VALU per layer).
 // C = 128 needs more than 256 registers and takes the 512-register budget instead.
@@ -76,12 +81,12 @@ __device__ __forceinline__ void evaluate_body(const NetParams& P, const char* ld
 // wave-uniform branch around the whole body instead of one per sample, which keeps the sample loop a single
 // schedulable region.
 template <int CD, int ACT, int GRID, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) void evaluate_kernel(NetParams P, const float* __restrict__ pos,
+__global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void evaluate_kernel(NetParams P, const float* __restrict__ pos,
                                                                  const float* __restrict__ dir, size_t n,
                                                                  float* __restrict__ out, int outChannels) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     load_network_to_lds(P, lds);
-    if (P.fourierNeedsFract) evaluate_body<CD, ACT, GRID, HAS_DIR, true>(P, lds, pos, dir, n, out, outChannels);
+    if (P.fourierNeedsFractEval) evaluate_body<CD, ACT, GRID, HAS_DIR, true>(P, lds, pos, dir, n, out, outChannels);
     else evaluate_body<CD, ACT, GRID, HAS_DIR, false>(P, lds, pos, dir, n, out, outChannels);
 }
 
@@ -198,6 +203,15 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     const float pn0z = (oz - P.boxMin[2]) * P.invBoxSize[2], dnz = dz * P.invBoxSize[2];
 
     float cr = 0, cg = 0, cb = 0, ca = 0, nx = 0, ny = 0, nz = 0, depth = 0;
+    // 32-wide Fourier-only networks keep the input features of the current sample and their per-step rotation in
+    // registers (measured r01, 1024^2 x 512: 111.7 -> 118.1 Gsamples/s at 3 waves/SIMD; with a latent grid the 64 extra
+    // registers cost more than the saved v_cos: 64.9 -> 62.4)
+#ifdef FVSRN_NO_ROTATE
+    constexpr bool kRotate = false;
+#else
+    constexpr bool kRotate = CD == 2 && GRID == 0;
+#endif
+    floatx16 feat[2][mtiles(CD)], dfeat[2][mtiles(CD)];
 
     for (int i = 0;; ++i) {
         const float t = tmin + float(i) * S.stepsize;
@@ -211,7 +225,19 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
         nValid += unsigned(__builtin_popcountll(validMask));
 
         const float px = fmaf(dnx, t, pn0x), py = fmaf(dny, t, pn0y), pz = fmaf(dnz, t, pn0z);
-        const float4_t o = srn_forward<CD, ACT, GRID, HAS_DIR, FRACT>(P, lds, px, py, pz, dx, dy, dz);
+        float4_t o;
+        if constexpr (kRotate) {
+            // Fourier features by rotation (fourier_advance): exact features every kFourierResync steps, the per-step
+            // rotation once per ray
+            if ((i & (kFourierResync - 1)) == 0) {  // wave-uniform
+                fourier_features<CD, HAS_DIR, FRACT>(P, lds, px, py, pz, dx, dy, dz, feat);
+                if (i == 0)
+                    fourier_features<CD, HAS_DIR, false, true>(P, lds, dnx * S.stepsize, dny * S.stepsize, dnz * S.stepsize, 0.f, 0.f, 0.f, dfeat);
+            }
+            o = srn_forward_rotating<CD, ACT, GRID, HAS_DIR>(P, lds, feat, dfeat, px, py, pz);
+        } else {
+            o = srn_forward<CD, ACT, GRID, HAS_DIR, FRACT>(P, lds, px, py, pz, dx, dy, dz);
+        }
 
 #ifdef FVSRN_ABL_NOTAIL  // ablation build (tools/ablate.sh): no output parametrization / TF / blending
         cr += o[0] * 1e-30f;
@@ -278,7 +304,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
 }
 
 template <int CD, int ACT, int GRID, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : FVSRN_WAVES_PER_EU)) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+__global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     load_network_to_lds(P, lds);

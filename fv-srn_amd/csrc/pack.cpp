@@ -18,21 +18,30 @@ namespace fvsrn {
 namespace {
 
 // Row of the layer-0 input tile ("X0", produced by the phase MFMA) -> channel index of the padded
-// Fourier vector [x,y,z,(t|0),(dx,dy,dz,0),cos...,sin...] the reference builds
+// Fourier vector [x,y,z,(t|0),(dx,dy,dz,0),cos(0..F-1),sin(0..F-1)] the reference builds
 // (renderer_volume_tensorcores.cuh:768-808).
 //  no direction: pass-through channels live in accumulator registers 0,1 of M tile 0, i.e. rows
 //                {0,1} (lane half 0) and {4,5} (lane half 1)
 //  direction:    registers 0..3 -> rows 0..7 = channels 0..7 (identity)
-std::vector<int> rowToChannel(int C, bool hasDirection) {
+//  features:     every further even-aligned row pair (2p, 2p+1) = (cos_j, sin_j) of one feature.  Such a pair is a
+//                pair of consecutive accumulator registers of ONE lane, which is what the renderer's phase rotation
+//                (srn_device.hpp, fourier_advance) needs.
+std::vector<int> rowToChannel(int C, bool hasDirection, int numFourier) {
     std::vector<int> map(size_t(C), -1);
+    const int base = hasDirection ? 8 : 4;
     if (hasDirection) {
-        for (int r = 0; r < C; ++r) map[size_t(r)] = r;
-        return map;
+        for (int r = 0; r < 8; ++r) map[size_t(r)] = r;
+    } else {
+        map[0] = 0; map[1] = 1; map[4] = 2; map[5] = 3;
     }
-    map[0] = 0; map[1] = 1; map[4] = 2; map[5] = 3;
-    int next = 4;
-    for (int r = 0; r < C; ++r)
-        if (map[size_t(r)] < 0) map[size_t(r)] = next++;
+    int j = 0;
+    for (int r = 0; r + 1 < C; r += 2)
+        if (map[size_t(r)] < 0 && map[size_t(r + 1)] < 0 && j < numFourier) {
+            map[size_t(r)] = base + j;
+            map[size_t(r + 1)] = base + numFourier + j;
+            ++j;
+        }
+    if (j != numFourier) throw InvalidNetwork("Fourier feature count does not fill the hidden width");
     return map;
 }
 
@@ -171,13 +180,17 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
     np.outputMode = int(c.outputMode);
 
     const bool hasDir = c.directionMode > 0;
-    const std::vector<int> chanOfRow = rowToChannel(C, hasDir);
     const int F = c.numFourier;
+    const std::vector<int> chanOfRow = rowToChannel(C, hasDir, F);
     const int base = hasDir ? 8 : 4;
     const int fcols = c.directionMode == 2 ? 6 : 3;
 
-    // ---- phase fragments: D = Fm * [x,x,y,y,z,z,1,0 | dx,dx,dy,dy,dz,dz,0,0] in revolutions --------
-    double maxPhase = 0;
+    // ---- phase fragments: D = Fm * [x,x,y,y,z,z,1,1 | dx,dx,dy,dy,dz,dz,0,0] in revolutions --------
+    // Matrix entries are split hi + lo in fp16 (two K slots per input).  The two constant slots carry, also split,
+    // -1/4 for sine rows (sin 2 pi x = cos 2 pi (x - 1/4)) minus the integer nearest to the centre of the row's phase
+    // range over the unit box (directions in [-1,1]): a whole number of revolutions does not change cos, and centred
+    // phases stay inside the +-256 revolution domain of v_cos_f32 twice as long (NeRF ladders up to 2^9 need no v_fract).
+    double maxPhase = 0, maxPhaseUncentred = 0;
     for (int m = 0; m < MT; ++m) {
         Frag f{};
         for (int lane = 0; lane < 64; ++lane) {
@@ -193,25 +206,33 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
             } else {
                 const int idx = ch - base;
                 const int feat = idx < F ? idx : idx - F;
-                double sumAbs = 0;
+                double lo = 0, hi = 0;  // phase range over positions in [0,1]^3, directions in [-1,1]^3
                 for (int cin = 0; cin < fcols; ++cin) {
                     const double v = double(half_bits_to_float(net.input.fourierMatrix[size_t(feat) + size_t(F) * cin])) /
                                      (2.0 * 3.14159265358979323846);
-                    const float hi = half_bits_to_float(float_to_half_bits(float(v)));
-                    const float lo = half_bits_to_float(float_to_half_bits(float(v - double(hi))));
+                    const float vh = half_bits_to_float(float_to_half_bits(float(v)));
+                    const float vl = half_bits_to_float(float_to_half_bits(float(v - double(vh))));
                     const int s0 = (cin < 3 ? 0 : 8) + 2 * (cin % 3);
-                    slots[s0] = hi;
-                    slots[s0 + 1] = lo;
-                    sumAbs += std::fabs(v) * (cin < 3 ? 1.0 : 1.0);
+                    slots[s0] = vh;
+                    slots[s0 + 1] = vl;
+                    if (cin < 3) { lo += std::min(v, 0.0); hi += std::max(v, 0.0); }
+                    else { lo -= std::fabs(v); hi += std::fabs(v); }
                 }
-                if (idx >= F) slots[6] = -0.25f;  // sin(2 pi x) = cos(2 pi (x - 1/4))
-                maxPhase = std::max(maxPhase, sumAbs + 0.25);
+                const double centre = std::nearbyint(0.5 * (lo + hi));
+                const double konst = (idx >= F ? -0.25 : 0.0) - centre;
+                const float kh = half_bits_to_float(float_to_half_bits(float(konst)));
+                slots[6] = kh;
+                slots[7] = half_bits_to_float(float_to_half_bits(float(konst - double(kh))));
+                maxPhase = std::max(maxPhase, 0.5 * (hi - lo) + 0.75);
+                maxPhaseUncentred = std::max(maxPhaseUncentred, std::max(std::fabs(lo), std::fabs(hi)) + 0.25);
             }
             for (int j = 0; j < 8; ++j) f.v[lane][j] = float_to_half_bits(slots[8 * h + j]);
         }
         putFrag(P.ldsImage, size_t(np.offPhase) + size_t(m) * kFragBytes, f);
     }
     np.fourierNeedsFract = maxPhase >= 255.0 ? 1 : 0;
+    // evaluate_points takes arbitrary positions: stay exact up to 4 box sizes away without the v_fract
+    np.fourierNeedsFractEval = (4.0 * maxPhaseUncentred + std::fabs(maxPhase)) >= 255.0 ? 1 : 0;
     // byte offset of the fp16 "time" entry inside the phase fragment (patched on the device when the time changes):
     // channel 3 sits on row 5 (no direction) / row 3 (direction) of M tile 0, lane half 0, K slot 6
     P.timeSlotOffset = c.passTime ? np.offPhase + (hasDir ? 3 : 5) * 16 + 6 * 2 : -1;

@@ -297,14 +297,20 @@ __device__ __forceinline__ half8_t grid_features(const NetParams& P, const GridT
 }
 
 // ---- building blocks of the forward pass -------------------------------------------------------------------
+constexpr int mtiles(int CD) { return (16 * CD + 31) / 32; }
+
 // quarter q (0..3) of one M tile: accumulator registers {2q,2q+1} / {8+2q,9+2q} -> half pairs q of the two B fragments
-// (K steps 2m and 2m+1 of the next layer), with the activation
+// (K steps 2m and 2m+1 of the next layer), with the activation (ACT_NONE: plain convert)
+constexpr int ACT_NONE = -1;
 template <int ACT>
 __device__ __forceinline__ void act_pack_quarter(const floatx16& d, int q, float a, float b, half8_t& f0, half8_t& f1) {
     const float2_t v0 = {d[2 * q], d[2 * q + 1]};
     const float2_t v1 = {d[8 + 2 * q], d[9 + 2 * q]};
     half2_t h0, h1;
-    if constexpr (ACT == ACT_RELU01) {
+    if constexpr (ACT == ACT_NONE) {
+        h0 = __builtin_convertvector(v0, half2_t);
+        h1 = __builtin_convertvector(v1, half2_t);
+    } else if constexpr (ACT == ACT_RELU01) {
         const half2_t z = {0, 0}, o = {1, 1};
         h0 = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_convertvector(v0, half2_t), z), o);  // = the convert's clamp bit
         h1 = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_convertvector(v1, half2_t), z), o);
@@ -320,31 +326,10 @@ __device__ __forceinline__ void act_pack_quarter(const floatx16& d, int q, float
     f1[2 * q] = h1[0]; f1[2 * q + 1] = h1[1];
 }
 
-// same quarter of a Fourier phase tile (revolutions): cos, except on the first `npass` registers (pass-through channels)
-template <bool FRACT>
-__device__ __forceinline__ void phase_pack_quarter(const floatx16& d, int q, int npass, half8_t& f0, half8_t& f1) {
-    float x[4] = {d[2 * q], d[2 * q + 1], d[8 + 2 * q], d[9 + 2 * q]};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int r = k < 2 ? 2 * q + k : 8 + 2 * q + (k - 2);
-#ifdef FVSRN_ABL_NOCOS
-        if (false) {
-#else
-        if (r >= npass) {
-#endif
-            if constexpr (FRACT) x[k] = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(x[k]));  // keep v_cos_f32 inside +-256 revolutions
-            else x[k] = __builtin_amdgcn_cosf(x[k]);
-        }
-    }
-    const float2_t v0 = {x[0], x[1]}, v1 = {x[2], x[3]};
-    const half2_t h0 = __builtin_convertvector(v0, half2_t), h1 = __builtin_convertvector(v1, half2_t);
-    f0[2 * q] = h0[0]; f0[2 * q + 1] = h0[1];
-    f1[2 * q] = h1[0]; f1[2 * q + 1] = h1[1];
-}
-
 // Instruction-order helper.  Issues fm(0..NMF-1) (one MFMA each) with the NCH pieces of independent VALU work
-// fv(0..NCH-1) spread between them, and pins that order (hipcc would otherwise group the MFMAs).  A wave issues in order:
-// VALU work placed behind an MFMA runs in the 32 cycles the matrix pipe needs for it.
+// fv(0..NCH-1) spread between them, and pins that order (hipcc would otherwise group the MFMAs).  Measured on MI355X
+// (profiles/r01/microbench_issue_model.md): while a wave has an MFMA ready, no OTHER wave of the SIMD issues VALU work,
+// but up to ~4 VALU instructions of the SAME wave placed behind an MFMA run in the 32 cycles the matrix pipe needs.
 template <int NMF, int NCH, class FM, class FV>
 __device__ __forceinline__ void interleave(FM&& fm, FV&& fv) {
 #pragma unroll
@@ -357,7 +342,7 @@ __device__ __forceinline__ void interleave(FM&& fm, FV&& fv) {
     }
 }
 
-// B operand of the phase MFMA for one tile
+// B operand of the phase MFMA for one tile: K slots [x,x,y,y,z,z,1,1 | dx,dx,dy,dy,dz,dz,0,0]
 template <bool HAS_DIR>
 __device__ __forceinline__ half8_t phase_operand(const unsigned (&tp)[3], const float (&tdir)[3], int h) {
     if constexpr (HAS_DIR) {
@@ -365,38 +350,175 @@ __device__ __forceinline__ half8_t phase_operand(const unsigned (&tp)[3], const 
         const unsigned dxh = __builtin_bit_cast(unsigned, __builtin_convertvector(vx, half2_t));
         const unsigned dyh = __builtin_bit_cast(unsigned, __builtin_convertvector(vy, half2_t));
         const unsigned dzh = __builtin_bit_cast(unsigned, __builtin_convertvector(vz, half2_t));
-        const uint4_t u = {h ? dxh : tp[0], h ? dyh : tp[1], h ? dzh : tp[2], h ? 0u : 0x00003c00u};
+        const uint4_t u = {h ? dxh : tp[0], h ? dyh : tp[1], h ? dzh : tp[2], h ? 0u : 0x3c003c00u};
         return __builtin_bit_cast(half8_t, u);
     } else {
         // lane half 1 supplies K slots 8..15, whose phase-matrix entries are all zero: its B values are
         // multiplied by 0 and only need to be finite, so no select is needed
-        const uint4_t u = {tp[0], tp[1], tp[2], 0x00003c00u /* (1.0h, 0) */};
+        const uint4_t u = {tp[0], tp[1], tp[2], 0x3c003c00u /* (1.0h, 1.0h) */};
         return __builtin_bit_cast(half8_t, u);
     }
 }
 
-// Evaluates the network for the 64 samples of this wave.
+// Input features of the first Linear layer for the two sample tiles of the wave, in fp32 and in accumulator layout:
+// register r of f[t][m] = row 32m + (r&3) + 8(r>>2) + 4h = [pass-through x,y | z,time (, direction)] on the first 2 (4)
+// registers of M tile 0, (cos, sin) of one Fourier feature on every further register pair (pack.cpp, rowToChannel).
 //   (px,py,pz): this lane's sample position, already normalized to the unit box
 //   (dx,dy,dz): this lane's view direction (only read when the network uses it)
-// Returns the raw last-layer outputs (before the output parametrization) of this lane's sample.
-// EXEC must be all ones.
+// The phases are an MFMA (positions as a K=16 B operand, matrix in revolutions, split hi/lo in fp16), replacing the
+// half hmul/hfma chain + hcos/hsin of the reference (renderer_volume_tensorcores.cuh:797-806).
+// DELTA: (px,py,pz) is the per-step position increment of a ray instead: the pairs become (cos, sin) of the per-step
+// phase increment and the pass-through registers the position increment (0 for time / direction) -- see fourier_advance.
+template <bool FRACT>
+__device__ __forceinline__ void phase_cos(floatx16& d, int npass) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (r >= npass) {
+            if constexpr (FRACT) d[r] = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(d[r]));  // v_cos_f32 domain: +-256 revolutions
+            else d[r] = __builtin_amdgcn_cosf(d[r]);
+        }
+}
+
+// B operands of the phase MFMA for the two tiles from this lane's own position / direction
+template <bool HAS_DIR, bool WITH_DIR_VALUES>
+__device__ __forceinline__ void phase_operands(float px, float py, float pz, float dx, float dy, float dz, int h, half8_t (&b0)[2]) {
+    // Positions of the two sample tiles: fp16 images (both halves of a register = the hi/lo slot pair of the phase
+    // matrix), then exchanged between the lane halves.
+    unsigned tph[2][3];
+    const float pp[3] = {px, py, pz};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float2_t v = {pp[i], pp[i]};
+        const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
+        auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        tph[0][i] = r[0];
+        tph[1][i] = r[1];
+    }
+    float td[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    if constexpr (HAS_DIR && WITH_DIR_VALUES) {
+        tile_bcast(dx, td[0][0], td[1][0]);
+        tile_bcast(dy, td[0][1], td[1][1]);
+        tile_bcast(dz, td[0][2], td[1][2]);
+    }
+    b0[0] = phase_operand<HAS_DIR>(tph[0], td[0], h);
+    b0[1] = phase_operand<HAS_DIR>(tph[1], td[1], h);
+}
+
+template <int CD, bool HAS_DIR, bool FRACT, bool DELTA = false>
+__device__ __forceinline__ void fourier_features(const NetParams& P, const char* lds, float px, float py, float pz, float dx,
+                                                 float dy, float dz, floatx16 (&f)[2][mtiles(CD)]) {
+    constexpr int MT = mtiles(CD);
+    constexpr int NPASS = HAS_DIR ? 4 : 2;
+    const int lane = lane_id();
+    const int h = lane >> 5;
+    half8_t aph[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) aph[m] = lds_frag(lds, P.offPhase + m * kFragBytes, lane);
+    half8_t b0[2];
+    phase_operands<HAS_DIR, !DELTA>(px, py, pz, dx, dy, dz, h, b0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const floatx16 z = {0};
+            f[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aph[m], b0[t], z, 0, 0, 0);
+        }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) phase_cos<FRACT>(f[t][m], m == 0 ? NPASS : 0);
+    if constexpr (DELTA) {
+        // the constant K slot also carries the time pass-through (row 5: lane half 1, register 1; with direction row 3:
+        // lane half 0, register 3): its increment is 0
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if constexpr (HAS_DIR) f[t][0][3] = h ? f[t][0][3] : 0.f;
+            else f[t][0][1] = h ? 0.f : f[t][0][1];
+        }
+    }
+}
+
+// the same features as fp16 B fragments of the first layer, tile by tile (few live registers)
+template <int CD, bool HAS_DIR, bool FRACT>
+__device__ __forceinline__ void fourier_fragments(const NetParams& P, const char* lds, float px, float py, float pz, float dx,
+                                                  float dy, float dz, half8_t (&xb)[2][2 * mtiles(CD)]) {
+    constexpr int MT = mtiles(CD);
+    constexpr int NPASS = HAS_DIR ? 4 : 2;
+    const int lane = lane_id();
+    const int h = lane >> 5;
+    half8_t b0[2];
+    phase_operands<HAS_DIR, true>(px, py, pz, dx, dy, dz, h, b0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            floatx16 d = {0};
+            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(lds, P.offPhase + m * kFragBytes, lane), b0[t], d, 0, 0, 0);
+            phase_cos<FRACT>(d, m == 0 ? NPASS : 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d, q, 0.f, 0.f, xb[t][2 * m], xb[t][2 * m + 1]);
+        }
+}
+
+template <int CD>
+__device__ __forceinline__ void feature_fragments(const floatx16 (&f)[2][mtiles(CD)], half8_t (&xb)[2][2 * mtiles(CD)]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < mtiles(CD); ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(f[t][m], q, 0.f, 0.f, xb[t][2 * m], xb[t][2 * m + 1]);
+}
+
+// Features of the next sample along the rays: every ray advances by the same step, so each phase grows by a constant
+// and (cos, sin) rotate by a constant angle:  c' = c cd - s sd,  s' = s cd + c sd  -- two packed-fp32 instructions per
+// feature instead of two v_cos_f32 (8.3 cycles each, profiles/r01/microbench_issue_model.md) plus the phase MFMA, the
+// position converts and lane exchanges.  Rounding errors grow linearly with the number of rotations (~6e-8 each); the
+// renderer re-derives the features from the positions every kFourierResync steps.
+constexpr int kFourierResync = 64;
+// piece c of the rotation, c in [0, 16 * mtiles(CD)): one register pair (<= 2 VALU instructions)
+template <int CD, bool HAS_DIR>
+__device__ __forceinline__ void fourier_advance_piece(floatx16 (&f)[2][mtiles(CD)], const floatx16 (&d)[2][mtiles(CD)], int c) {
+    constexpr int MT = mtiles(CD);
+    constexpr int NPASS = HAS_DIR ? 4 : 2;
+    const int t = c / (8 * MT), m = (c / 8) % MT, k = c % 8;
+    float2_t cs = {f[t][m][2 * k], f[t][m][2 * k + 1]};
+    const float2_t dd = {d[t][m][2 * k], d[t][m][2 * k + 1]};
+    if (m == 0 && 2 * k < NPASS) {
+        cs += dd;
+    } else {
+        float2_t tmp;
+        // tmp = (c cd, s cd);  cs = (s * -sd + tmp.x, c * sd + tmp.y)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(tmp) : "v"(cs), "v"(dd));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(cs) : "v"(cs), "v"(dd), "v"(tmp));
+    }
+    f[t][m][2 * k] = cs[0];
+    f[t][m][2 * k + 1] = cs[1];
+}
+
+// The network behind the input features, for the 64 samples of this wave: returns the raw last-layer outputs (before
+// the output parametrization) of this lane's sample.  EXEC must be all ones.
+//   * the fp32 accumulator tile of layer l is converted in registers (v_cvt_pk_f16_f32) into the B operand of layer
+//     l+1 -- weights were permuted on the host for that (pack.cpp); the reference round-trips activations through shared
+//     memory every layer (renderer_volume_tensorcores.cuh:1019-1023)
+//   * biases enter as the MFMA C operand (fp32), accumulation is fp32 (reference: half, :965)
+//   * the last (C -> 1|4) layer is one more MFMA whose rows are replicated for both lane halves, replacing the per-lane
+//     hfma loop :1138-1143
 //
-// Schedule (hidden widths up to 64).  The two sample tiles t0,t1 of the wave run half a layer apart:
+// Schedule (Fourier-only networks up to 64 wide).  The two sample tiles t0,t1 of the wave run half a layer apart:
 //     A_l: MFMAs of layer l for t0   ||  activation+convert of layer l-1 for t1, bias(l)   -> accumulators of t1
 //     B_l: MFMAs of layer l for t1   ||  activation+convert of layer l   for t0, bias(l+1) -> accumulators of t0,
 //                                        weight fragments of layer l+1 -> registers (each right after its last use)
-// so inside ONE wave the matrix pipe always has the other tile's chain to work on while the VALU converts, every LDS
-// read (weights, biases) is issued at least half a layer before its use, and the first latent-grid chunk is fetched
-// from L2/HBM before the Fourier stage and reduced behind the first layer's MFMAs.  Biases are read straight into the
+// so inside ONE wave the matrix pipe always has the other tile's chain to work on while the VALU converts, and every
+// LDS read (weights, biases) is issued at least half a layer before its use.  Biases are read straight into the
 // accumulator registers (the MFMA C operand), weight fragments are read once per layer and shared by both tiles.
-// Measured motivation (r01 PMC, 64x6+grid): with loads issued right before their use and all converts after all
-// MFMAs of a layer the matrix pipe was 49% busy and waves spent half their cycles in s_waitcnt.
-template <int CD, int ACT, int GRID, bool HAS_DIR, bool FRACT>
-__device__ __forceinline__ float4_t srn_forward_pipelined(const NetParams& P, const char* lds, float px, float py, float pz,
-                                                          float dx, float dy, float dz) {
-    constexpr int C = 16 * CD;
-    constexpr int MT = (C + 31) / 32, KS = CD, NM = MT * KS, NX = KS + (KS & 1), NV = 4 * MT;
-    constexpr int NPASS = HAS_DIR ? 4 : 2;
+//   pre():    produces xb (the first layer's B fragments); called after the first layer's LDS reads are issued
+//   fill(j):  NFILL pieces of independent VALU work for the MFMAs that have none of their own (first layer of tile 0,
+//             last layer of tile 1)
+template <int CD, int ACT, int GRID, bool HAS_DIR, int NFILL, class Pre, class Fill>
+__device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, const char* lds, half8_t (&xb)[2][2 * mtiles(CD)],
+                                                         float px, float py, float pz, Pre&& pre, Fill&& fill) {
+    constexpr int MT = mtiles(CD), KS = CD, NM = MT * KS, NV = 4 * MT;
     const int lane = lane_id();
     const int h = lane >> 5;
     const float actA = P.actA, actB = P.actB;
@@ -414,50 +536,15 @@ __device__ __forceinline__ float4_t srn_forward_pipelined(const NetParams& P, co
         return c;
     };
 
-    half8_t aph[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) aph[m] = frag(P.offPhase + m * kFragBytes);
-
-    // Positions of the two sample tiles: fp16 images (both halves of a register = the hi/lo slot pair of the phase
-    // matrix), then exchanged between the lane halves.
-    unsigned tph[2][3];
-    {
-        const float pp[3] = {px, py, pz};
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float2_t v = {pp[i], pp[i]};
-            const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
-            auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-            tph[0][i] = r[0];
-            tph[1][i] = r[1];
-        }
-    }
-    float td[2][3] = {{0, 0, 0}, {0, 0, 0}};
-    if constexpr (HAS_DIR) {
-        tile_bcast(dx, td[0][0], td[1][0]);
-        tile_bcast(dy, td[0][1], td[1][1]);
-        tile_bcast(dz, td[0][2], td[1][2]);
-    }
-
-    floatx16 acc[2][MT];
-    half8_t xb[2][NX];
-
-    // ---- Fourier phases: MT MFMAs per tile ----------------------------------------------------------------
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const half8_t b0 = phase_operand<HAS_DIR>(tph[t], td[t], h);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const floatx16 z = {0};
-            acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aph[m], b0, z, 0, 0, 0);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // weight fragments of the first layer (its Fourier part has the layout of a hidden layer)
+    // weight fragments of the first layer (its Fourier part has the layout of a hidden layer), its bias, latent taps
     half8_t a[NM];
 #pragma unroll
     for (int i = 0; i < NM; ++i) a[i] = frag(P.offLayer0 + i * kFragBytes);
+    floatx16 acc[2][MT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[t][m] = bias(P.offBias + m * 128);
     const int offGridW = P.offLayer0 + NM * kFragBytes;  // [g][m] fragments of the latent K steps
     half8_t ag[MT];
     GridTap gt[2];
@@ -469,21 +556,12 @@ __device__ __forceinline__ float4_t srn_forward_pipelined(const NetParams& P, co
         if constexpr (GRID == 1) grid_load(P.grid, gt[0], 0, h, raw);
     }
     __builtin_amdgcn_sched_barrier(0);
-
-    // ---- cos + convert; the freed accumulators take the bias of the first layer ----------------------------------
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) phase_pack_quarter<FRACT>(acc[t][m], q, m == 0 ? NPASS : 0, xb[t][2 * m], xb[t][2 * m + 1]);
-            acc[t][m] = bias(P.offBias + m * 128);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    pre();
+    __builtin_amdgcn_sched_barrier(0);
 
     const int NL = P.numLayers;
     constexpr int kBiasLayer = 32 * MT * 4;
+    constexpr int NF0 = NFILL / 2;
     // ---- first layer, tile 0 -------------------------------------------------------------------------------------
     half8_t gf;
     if constexpr (GRID == 1) {
@@ -496,9 +574,11 @@ __device__ __forceinline__ float4_t srn_forward_pipelined(const NetParams& P, co
                               else gf = grid_pack(gacc);
                           });
         grid_load(P.grid, gt[1], 0, h, raw);  // tile 1's chunk: in flight behind tile 1's first-layer MFMAs
-    } else {
 #pragma unroll
-        for (int i = 0; i < NM; ++i) acc[0][i / KS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], xb[0][i % KS], acc[0][i / KS], 0, 0, 0);
+        for (int j = 0; j < NF0; ++j) fill(j);
+    } else {
+        interleave<NM, NF0>([&](int i) { acc[0][i / KS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], xb[0][i % KS], acc[0][i / KS], 0, 0, 0); },
+                            [&](int j) { fill(j); });
     }
     if constexpr (GRID != 0) {
         for (int g = 0; g < P.gridK; ++g) {
@@ -573,8 +653,8 @@ __device__ __forceinline__ float4_t srn_forward_pipelined(const NetParams& P, co
                            act_pack_quarter<ACT>(acc[1][m], q, actA, actB, xb[1][2 * m], xb[1][2 * m + 1]);
                            if (j == 3) acc[1][0] = bias(P.offBias + NL * kBiasLayer);
                        });
-#pragma unroll
-    for (int s = 0; s < KS; ++s) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], xb[1][s], acc[1][0], 0, 0, 0);
+    interleave<KS, NFILL - NF0>([&](int s) { acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], xb[1][s], acc[1][0], 0, 0, 0); },
+                                [&](int j) { fill(NF0 + j); });
 
     // rows 0..3 (lane half 0) and rows 4..7 (lane half 1) both carry outputs 0..3 of sample c of the tile
     float4_t out = {0, 0, 0, 0};
@@ -587,85 +667,21 @@ __device__ __forceinline__ float4_t srn_forward_pipelined(const NetParams& P, co
     return out;
 }
 
-// Evaluates the network for the 64 samples of this wave.
-//   (px,py,pz): this lane's sample position, already normalized to the unit box
-//   (dx,dy,dz): this lane's view direction (only read when the network uses it)
-// Returns the raw last-layer outputs (before the output parametrization) of this lane's sample.
-// EXEC must be all ones.
-// Weight-fragment-major order for wide networks (C >= 96): a layer's fragments do not fit into registers next to the
-// accumulators, so each fragment is read from LDS right before its two MFMAs (one per tile).
-template <int CD, int ACT, int GRID, bool HAS_DIR, bool FRACT>
-__device__ __forceinline__ float4_t srn_forward_kmajor(const NetParams& P, const char* lds, float px, float py, float pz,
-                                                float dx, float dy, float dz) {
-    constexpr int C = 16 * CD;
-    constexpr int MT = (C + 31) / 32;
-    constexpr int KS = CD;
+// Weight-fragment-major order: each fragment is read from LDS right before its two MFMAs (one per tile).  Used for wide
+// networks (C >= 96: a layer's fragments do not fit into registers next to the accumulators) and for latent-grid
+// networks (measured r01: there the extra registers of the pipelined order cost more occupancy than the schedule gains).
+template <int CD, int ACT, int GRID, bool HAS_DIR, int NFILL, class Pre, class Fill>
+__device__ __forceinline__ float4_t srn_layers_kmajor(const NetParams& P, const char* lds, half8_t (&xb)[2][2 * mtiles(CD)],
+                                                      float px, float py, float pz, Pre&& pre, Fill&& fill) {
+    constexpr int MT = mtiles(CD), KS = CD;
     const int lane = lane_id();
     const int h = lane >> 5;
     const float actA = P.actA, actB = P.actB;
-
-    // Positions of the two sample tiles.  Without a latent grid only their fp16 images are needed: convert first
-    // (one v_cvt_pk per coordinate, both halves = the hi/lo slot pair of the phase matrix), then exchange.
-    unsigned tph[2][3];
-    {
-        const float pp[3] = {px, py, pz};
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float2_t v = {pp[i], pp[i]};
-            const half2_t hh = __builtin_convertvector(v, half2_t);
-            const unsigned u = __builtin_bit_cast(unsigned, hh);
-            auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-            tph[0][i] = r[0];
-            tph[1][i] = r[1];
-        }
-    }
     GridTap gt[2];
     if constexpr (GRID != 0) grid_tap_bcast<GRID == 2>(grid_tap(P, px, py, pz), gt[0], gt[1]);
-    float td[2][3] = {{0, 0, 0}, {0, 0, 0}};
-    if constexpr (HAS_DIR) {
-        tile_bcast(dx, td[0][0], td[1][0]);
-        tile_bcast(dy, td[0][1], td[1][1]);
-        tile_bcast(dz, td[0][2], td[1][2]);
-    }
-
-    half8_t xb[2][KS + (KS & 1)];  // B fragments of the current layer input, per tile
-
-    // ---- Fourier layer: phases by MFMA, then cos ------------------------------------------------------
+    pre();
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const half8_t b0 = phase_operand<HAS_DIR>(tph[t], td[t], h);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            floatx16 d = {0};
-            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(lds, P.offPhase + m * kFragBytes, lane), b0, d, 0, 0, 0);
-            // registers 0,1 (0..3 with direction) of M tile 0 are pass-through channels
-            floatx16 x;
-            if constexpr (FRACT) {  // keep v_cos_f32 inside its +-256 revolution domain
-#pragma unroll
-                for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(d[r]));
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) x[r] = __builtin_amdgcn_cosf(d[r]);
-            }
-            if (m == 0) {
-                constexpr int NP = HAS_DIR ? 4 : 2;
-#pragma unroll
-                for (int r = 0; r < NP; ++r) x[r] = d[r];
-            }
-            half8_t f0, f1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float2_t v0 = {x[2 * i], x[2 * i + 1]};
-                float2_t v1 = {x[8 + 2 * i], x[8 + 2 * i + 1]};
-                half2_t h0 = __builtin_convertvector(v0, half2_t);
-                half2_t h1 = __builtin_convertvector(v1, half2_t);
-                f0[2 * i] = h0[0]; f0[2 * i + 1] = h0[1];
-                f1[2 * i] = h1[0]; f1[2 * i + 1] = h1[1];
-            }
-            xb[t][2 * m] = f0;
-            if (2 * m + 1 < KS + (KS & 1)) xb[t][2 * m + 1] = f1;
-        }
-    }
+    for (int j = 0; j < NFILL; ++j) fill(j);
 
     // ---- C -> C layers -----------------------------------------------------------------------------------
     const int NL = P.numLayers;
@@ -700,12 +716,7 @@ __device__ __forceinline__ float4_t srn_forward_kmajor(const NetParams& P, const
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                half8_t f0, f1;
-                act_pack<ACT>(acc[t][m], actA, actB, f0, f1);
-                xb[t][2 * m] = f0;
-                if (2 * m + 1 < KS + (KS & 1)) xb[t][2 * m + 1] = f1;
-            }
+            for (int m = 0; m < MT; ++m) act_pack<ACT>(acc[t][m], actA, actB, xb[t][2 * m], xb[t][2 * m + 1]);
     }
 
     // ---- last layer ----------------------------------------------------------------------------------------
@@ -728,16 +739,42 @@ __device__ __forceinline__ float4_t srn_forward_kmajor(const NetParams& P, const
     return out;
 }
 
+template <int CD, int ACT, int GRID, bool HAS_DIR, int NFILL, class Pre, class Fill>
+__device__ __forceinline__ float4_t srn_layers(const NetParams& P, const char* lds, half8_t (&xb)[2][2 * mtiles(CD)], float px,
+                                               float py, float pz, Pre&& pre, Fill&& fill) {
+#ifndef FVSRN_NO_PIPELINE
+    // measured (r01): the pipelined order wins for Fourier-only networks; with a latent grid its extra registers
+    // cost more occupancy than the schedule gains
+    if constexpr (CD <= 4 && GRID == 0) return srn_layers_pipelined<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill);
+    else
+#endif
+        return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill);
+}
+
+// positions -> raw network outputs (evaluate_points, and render steps of networks without the rotation shortcut)
 template <int CD, int ACT, int GRID, bool HAS_DIR, bool FRACT>
 __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* lds, float px, float py, float pz,
                                                 float dx, float dy, float dz) {
-#ifndef FVSRN_NO_PIPELINE
-    // measured (r01): the pipelined order wins for Fourier-only networks; with a latent grid its extra registers
-    // (197 / 256 vs 120 / 163) cost more occupancy than the schedule gains
-    if constexpr (CD <= 4 && GRID == 0) return srn_forward_pipelined<CD, ACT, GRID, HAS_DIR, FRACT>(P, lds, px, py, pz, dx, dy, dz);
-    else
-#endif
-        return srn_forward_kmajor<CD, ACT, GRID, HAS_DIR, FRACT>(P, lds, px, py, pz, dx, dy, dz);
+    half8_t xb[2][2 * mtiles(CD)];
+    return srn_layers<CD, ACT, GRID, HAS_DIR, 0>(
+        P, lds, xb, px, py, pz, [&]() { fourier_fragments<CD, HAS_DIR, FRACT>(P, lds, px, py, pz, dx, dy, dz, xb); }, [](int) {});
+}
+
+// the same from the input features `feat` of the current sample, which are advanced to the next sample of the rays
+template <int CD, int ACT, int GRID, bool HAS_DIR>
+__device__ __forceinline__ float4_t srn_forward_rotating(const NetParams& P, const char* lds, floatx16 (&feat)[2][mtiles(CD)],
+                                                         const floatx16 (&dfeat)[2][mtiles(CD)], float px, float py, float pz) {
+    constexpr int NP = 16 * mtiles(CD);  // rotation pieces: half of them cover the LDS latency of the first layer's reads,
+    constexpr int NFILL = NP / 2;        // half sit behind MFMAs that have no conversion work of their own
+    half8_t xb[2][2 * mtiles(CD)];
+    return srn_layers<CD, ACT, GRID, HAS_DIR, NFILL>(
+        P, lds, xb, px, py, pz,
+        [&]() {
+            feature_fragments<CD>(feat, xb);
+#pragma unroll
+            for (int c = 0; c < NP - NFILL; ++c) fourier_advance_piece<CD, HAS_DIR>(feat, dfeat, c);
+        },
+        [&](int j) { fourier_advance_piece<CD, HAS_DIR>(feat, dfeat, NP - NFILL + j); });
 }
 
 // output parametrization, renderer_volume_tensorcores.cuh:1054-1158. The reference rounds the
