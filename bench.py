@@ -178,6 +178,26 @@ def cpu_baseline(util, cfg, activation):
                       % (W, H, steps, r["samples"], r["seconds"])}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC summary of this workload
+    (profiles/r*/<workload>_*_pmc.csv, written by tools/pmc_profile.sh: separate --pmc passes; WRITE_SIZE is exact,
+    FETCH_SIZE counts 128-B requests as 64 B on gfx950 and is doubled, MI355X_MICROARCH.md).  None if there is no
+    profile of this workload: the counters cannot be read inside the timed run.  Unit: bytes per launch."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", workload + "_*pmc.csv")))
+    if not files:
+        return None
+    vals = {}
+    with open(files[-1]) as f:
+        for row in csv.reader(l for l in f if not l.startswith("#")):
+            if len(row) == 5 and row[2] in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[row[2]] = float(row[4])
+    if len(vals) != 2:
+        return None
+    return 1024.0 * (vals["WRITE_SIZE"] + 2.0 * vals["FETCH_SIZE"])  # bytes per launch
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,7 +292,7 @@ def main():
             "wave_executed_samples_per_frame": executed / args.steps,
             "kernel": net.kernel_name(True),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": pmc_traffic(args.config) if world == 1 else None,
                          "flops_per_sample": info.flops_per_sample, "mfma_flops_per_sample": info.mfma_flops_per_sample,
                          "kernel_ms_avg": 1e3 * kernel_s},
         }
