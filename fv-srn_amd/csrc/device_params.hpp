@@ -19,7 +19,8 @@ constexpr int kFragBytes = 1024;
 struct NetParams {
     const void* ldsImage;  // device pointer
     int ldsBytes;          // multiple of 16
-    int numLayers;         // NL: number of C->C Linear layers (>= 1), the first one consumes Fourier(+grid)
+    int numLayers;         // NL: number of C->C Linear layers, the first one consumes Fourier(+grid) features; 0 only with noFourier
+    int noFourier;         // the "phase" fragments are the scalar first layer (3|6 -> C, bias in the constant slot): activation instead of cos
     int gridK;             // latent grid channels / 16 (0 = none)
     int outputMode;        // fvsrn_output_mode
     int offPhase, offLayer0, offHidden, offLast, offBias;  // byte offsets into the LDS image

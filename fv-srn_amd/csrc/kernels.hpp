@@ -31,7 +31,7 @@ __device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* ld
 // ------------------------------------------------------------------------------------------------
 // EvaluateNoBatches (reference renderer/renderer_volume_kernels1.cuh:15): positions -> network value
 // ------------------------------------------------------------------------------------------------
-template <int CD, int ACT, int GRID, bool HAS_DIR, bool FRACT>
+template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE>
 __device__ __forceinline__ void evaluate_body(const NetParams& P, const char* lds, const float* __restrict__ pos,
                                               const float* __restrict__ dir, size_t n, float* __restrict__ out, int outChannels) {
     const int lane = lane_id();
@@ -50,11 +50,12 @@ __device__ __forceinline__ void evaluate_body(const NetParams& P, const char* ld
         px = (px - P.boxMin[0]) * P.invBoxSize[0];
         py = (py - P.boxMin[1]) * P.invBoxSize[1];
         pz = (pz - P.boxMin[2]) * P.invBoxSize[2];
-        const float4_t o = srn_forward<CD, ACT, GRID, HAS_DIR, FRACT>(P, lds, px, py, pz, dx, dy, dz);
+        const float4_t o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz);
         if (valid) {
             switch (P.outputMode) {
                 case FVSRN_OUT_DENSITY:
                 case FVSRN_OUT_DENSITY_GRADIENT:
+                case FVSRN_OUT_DENSITY_CURVATURE:
                     out[i * outChannels] = sigmoid_f(o[0]);
                     break;
                 case FVSRN_OUT_RGBO:
@@ -77,17 +78,20 @@ __device__ __forceinline__ void evaluate_body(const NetParams& P, const char* ld
     }
 }
 
-// FRACT (Fourier phases beyond the v_cos_f32 domain need a v_fract first) is a property of the network: resolved by ONE
-// wave-uniform branch around the whole body instead of one per sample, which keeps the sample loop a single
-// schedulable region.
+// FMODE (srn_device.hpp: Fourier phases need a v_fract first / no Fourier features at all) is a property of the network:
+// resolved by ONE wave-uniform branch around the whole body instead of one per sample, which keeps the sample loop a
+// single schedulable region.
 template <int CD, int ACT, int GRID, bool HAS_DIR>
 __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void evaluate_kernel(NetParams P, const float* __restrict__ pos,
                                                                  const float* __restrict__ dir, size_t n,
                                                                  float* __restrict__ out, int outChannels) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     load_network_to_lds(P, lds);
-    if (P.fourierNeedsFractEval) evaluate_body<CD, ACT, GRID, HAS_DIR, true>(P, lds, pos, dir, n, out, outChannels);
-    else evaluate_body<CD, ACT, GRID, HAS_DIR, false>(P, lds, pos, dir, n, out, outChannels);
+    if constexpr (GRID == 0) {  // a latent grid needs Fourier features (SceneNetwork::valid)
+        if (P.noFourier) return evaluate_body<CD, ACT, GRID, HAS_DIR, FM_FIRST_LAYER>(P, lds, pos, dir, n, out, outChannels);
+    }
+    if (P.fourierNeedsFractEval) evaluate_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS>(P, lds, pos, dir, n, out, outChannels);
+    else evaluate_body<CD, ACT, GRID, HAS_DIR, FM_COS>(P, lds, pos, dir, n, out, outChannels);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -145,7 +149,7 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // depend on the grouping because blending is guarded by isValid).  Stepping is wave-synchronous like
 // the reference's __any_sync loop: all 64 lanes evaluate the network until no lane is valid.
 // ------------------------------------------------------------------------------------------------
-template <int CD, int ACT, int GRID, bool HAS_DIR, bool FRACT>
+template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE>
 __device__ __forceinline__ void render_body(const NetParams& P, const SceneParams& S, const char* lds, const float* tfLds,
                                             float* __restrict__ out, unsigned long long* __restrict__ stats) {
     const int lane = lane_id();
@@ -161,7 +165,8 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     if (S.tileCounterNext && blockIdx.x == 0 && threadIdx.x == 0) *S.tileCounterNext = 0;
     unsigned nValid = 0, nSteps = 0;  // wave-uniform (scalar registers): lane-exact samples / executed wave steps
     const bool rgboNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
-    const bool gradNet = P.outputMode >= FVSRN_OUT_DENSITY_GRADIENT && P.outputMode <= FVSRN_OUT_DENSITY_GRADIENT_CUBIC;
+    // networks that predict the gradient (and, in the curvature modes, two curvature values the DVR path has no use for)
+    const bool gradNet = P.outputMode >= FVSRN_OUT_DENSITY_GRADIENT && P.outputMode <= FVSRN_OUT_DENSITY_CURVATURE_DIRECT;
     for (int slot = int(blockIdx.x) * wavesPerBlock + int(threadIdx.x >> 6); slot < numTiles;) {
     // launch slot -> pixel tile: the host orders tiles by expected ray length (centre of the projected box first), so
     // the long tiles start first and the empty ones fill the tail of the launch
@@ -209,7 +214,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
 #ifdef FVSRN_NO_ROTATE
     constexpr bool kRotate = false;
 #else
-    constexpr bool kRotate = CD == 2 && GRID == 0;
+    constexpr bool kRotate = CD == 2 && GRID == 0 && FMODE != FM_FIRST_LAYER;
 #endif
     floatx16 feat[2][mtiles(CD)], dfeat[2][mtiles(CD)];
 
@@ -230,13 +235,13 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             // Fourier features by rotation (fourier_advance): exact features every kFourierResync steps, the per-step
             // rotation once per ray
             if ((i & (kFourierResync - 1)) == 0) {  // wave-uniform
-                fourier_features<CD, HAS_DIR, FRACT>(P, lds, px, py, pz, dx, dy, dz, feat);
+                fourier_features<CD, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, feat);
                 if (i == 0)
-                    fourier_features<CD, HAS_DIR, false, true>(P, lds, dnx * S.stepsize, dny * S.stepsize, dnz * S.stepsize, 0.f, 0.f, 0.f, dfeat);
+                    fourier_features<CD, HAS_DIR, FM_COS, true>(P, lds, dnx * S.stepsize, dny * S.stepsize, dnz * S.stepsize, 0.f, 0.f, 0.f, dfeat);
             }
             o = srn_forward_rotating<CD, ACT, GRID, HAS_DIR>(P, lds, feat, dfeat, px, py, pz);
         } else {
-            o = srn_forward<CD, ACT, GRID, HAS_DIR, FRACT>(P, lds, px, py, pz, dx, dy, dz);
+            o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz);
         }
 
 #ifdef FVSRN_ABL_NOTAIL  // ablation build (tools/ablate.sh): no output parametrization / TF / blending
@@ -252,7 +257,9 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
                 color = float4_t{fminf(fmaxf(o[0], 0.f), 1.f), fminf(fmaxf(o[1], 0.f), 1.f), fminf(fmaxf(o[2], 0.f), 1.f), fmaxf(o[3], 0.f)};
             color[3] *= S.stepsize;
         } else {  // stepping_dvr.cuh:110-135
-            const float value = (P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_GRADIENT) ? sigmoid_f(o[0]) : o[0];
+            const bool sigmoidDensity = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_GRADIENT ||
+                                        P.outputMode == FVSRN_OUT_DENSITY_CURVATURE;
+            const float value = sigmoidDensity ? sigmoid_f(o[0]) : o[0];
             const float density2 = (value - S.densityMin) * S.divDensityRange;
             const bool requireNormal = valid && (value >= S.densityMin);
             if (gradNet) {
@@ -315,8 +322,11 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void r
         for (int i = threadIdx.x; i < cols * S.tfRows; i += int(blockDim.x)) tfLds[i] = S.tfTable[i];
         __syncthreads();
     }
-    if (P.fourierNeedsFract) render_body<CD, ACT, GRID, HAS_DIR, true>(P, S, lds, tfLds, out, stats);
-    else render_body<CD, ACT, GRID, HAS_DIR, false>(P, S, lds, tfLds, out, stats);
+    if constexpr (GRID == 0) {
+        if (P.noFourier) return render_body<CD, ACT, GRID, HAS_DIR, FM_FIRST_LAYER>(P, S, lds, tfLds, out, stats);
+    }
+    if (P.fourierNeedsFract) render_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS>(P, S, lds, tfLds, out, stats);
+    else render_body<CD, ACT, GRID, HAS_DIR, FM_COS>(P, S, lds, tfLds, out, stats);
 }
 
 }  // namespace fvsrn

@@ -149,27 +149,29 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
     PackedNetwork P;
     P.cfg = net.config();
     const NetworkConfig& c = P.cfg;
-    if (!c.hasFourier) throw Unsupported("networks without Fourier features are not in the compiled variant set");
-    if (c.outputMode >= FVSRN_OUT_DENSITY_CURVATURE)
-        throw Unsupported(std::string("output mode ") + outputModeName(c.outputMode) + " is not in the compiled variant set");
     const int C = c.hiddenChannels;
     if (C != 32 && C != 48 && C != 64 && C != 96 && C != 128)
         throw Unsupported("hidden width " + std::to_string(C) + " is not in the compiled variant set (32,48,64,96,128)");
     if (c.gridChannels % 16 != 0) throw InvalidNetwork("latent grid channels must be a multiple of 16");
     const int MT = (C + 31) / 32, KS = C / 16, KG = c.gridChannels / 16, KS0 = KS + KG;
-    // C->C layers: hidden[0] (behind Fourier features, or the latent-grid layer) .. hidden[NL-1]; hidden[NL] is the last
-    const int NL = int(net.hidden.size()) - 1;
-    if (NL != c.numHiddenLayers + (c.gridChannels > 0 ? 1 : 0) || NL < 1) throw InvalidNetwork("unexpected layer count");
+    // C->C layers: hidden[L0] (behind Fourier features, or the latent-grid layer) .. hidden[L0+NL-1]; hidden.back() is the
+    // last one.  Without Fourier features hidden[0] is the scalar 3|6 -> C first layer (it takes the place of the phase
+    // stage, see below) and NL may be 0.
+    const int L0 = c.hasFourier ? 0 : 1;
+    const int NL = int(net.hidden.size()) - 1 - L0;
+    if (NL != c.numHiddenLayers + (c.gridChannels > 0 ? 1 : 0) || NL < (c.hasFourier ? 1 : 0)) throw InvalidNetwork("unexpected layer count");
+    if (!c.hasFourier && c.gridChannels > 0) throw InvalidNetwork("a latent grid needs Fourier features");
     const int Cout = net.outputChannelsIn();
-    if (Cout > 4) throw Unsupported("more than 4 network outputs are not in the compiled variant set");
+    // curvature modes: 6 outputs, of which the DVR path and evaluate() use density + gradient (outputs 0..3)
+    if (Cout > 4 && c.outputMode < FVSRN_OUT_DENSITY_CURVATURE) throw Unsupported("more than 4 network outputs are not in the compiled variant set");
     P.MT = MT; P.KS = KS; P.KS0 = KS0; P.NL = NL;
 
     NetParams& np = P.params;
     size_t off = 0;
     np.offPhase = int(off);  off += size_t(MT) * kFragBytes;
-    np.offLayer0 = int(off); off += size_t(MT) * KS0 * kFragBytes;  // [m][s < KS] like a hidden layer, then the latent steps [g][m]
+    np.offLayer0 = int(off); off += size_t(NL > 0 ? 1 : 0) * MT * KS0 * kFragBytes;  // [m][s < KS] like a hidden layer, then the latent steps [g][m]
     np.offLast = int(off);   off += size_t(KS) * kFragBytes;
-    np.offHidden = int(off); off += size_t(NL - 1) * MT * KS * kFragBytes;
+    np.offHidden = int(off); off += size_t(std::max(NL - 1, 0)) * MT * KS * kFragBytes;
     // the kernels prefetch "the next layer" as MT*KS fragments, also when that is the last one (only KS of them are used)
     off = std::max(off, size_t(np.offLast) + size_t(MT) * KS * kFragBytes);
     np.offBias = int(off);   off += (size_t(NL) * 32 * MT + 32 * MT) * sizeof(float);  // same reason: MT blocks for the last layer
@@ -181,7 +183,10 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
 
     const bool hasDir = c.directionMode > 0;
     const int F = c.numFourier;
-    const std::vector<int> chanOfRow = rowToChannel(C, hasDir, F);
+    np.noFourier = c.hasFourier ? 0 : 1;
+    std::vector<int> chanOfRow(size_t(C), 0);
+    if (c.hasFourier) chanOfRow = rowToChannel(C, hasDir, F);
+    else for (int r = 0; r < C; ++r) chanOfRow[size_t(r)] = r;  // rows of the first layer's output = channels
     const int base = hasDir ? 8 : 4;
     const int fcols = c.directionMode == 2 ? 6 : 3;
 
@@ -198,7 +203,14 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
             if (row >= C) continue;
             const int ch = chanOfRow[size_t(row)];
             float slots[16] = {0};
-            if (ch < base) {
+            if (!c.hasFourier) {
+                // scalar first layer (renderer_volume_tensorcores.cuh:810-823): out = b + W p (+ W' d); stored [cin][cout]
+                const Layer& L1 = net.hidden[0];
+                if (L1.channelsOut != C || L1.channelsIn != (hasDir ? 6 : 3)) throw InvalidNetwork("first layer shape mismatch");
+                for (int cin = 0; cin < L1.channelsIn; ++cin)
+                    slots[(cin < 3 ? 0 : 8) + 2 * (cin % 3)] = half_bits_to_float(L1.weights[size_t(cin) * C + row]);
+                slots[6] = half_bits_to_float(L1.bias[size_t(row)]);
+            } else if (ch < base) {
                 if (ch < 3) slots[2 * ch] = 1.f;  // position pass-through
                 else if (ch == 3) slots[6] = c.passTime ? half_bits_to_float(float_to_half_bits(
                                        net.latentGrid ? net.latentGrid->interpolateTime(net.currentTime) : 0.f)) : 0.f;
@@ -230,6 +242,7 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
         }
         putFrag(P.ldsImage, size_t(np.offPhase) + size_t(m) * kFragBytes, f);
     }
+    if (!c.hasFourier) maxPhase = maxPhaseUncentred = 0;
     np.fourierNeedsFract = maxPhase >= 255.0 ? 1 : 0;
     // evaluate_points takes arbitrary positions: stay exact up to 4 box sizes away without the v_fract
     np.fourierNeedsFractEval = (4.0 * maxPhaseUncentred + std::fabs(maxPhase)) >= 255.0 ? 1 : 0;
@@ -250,7 +263,7 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
     auto packLayers = [&](std::vector<char>& img, const std::vector<int>* exps) {
         float* bias = reinterpret_cast<float*>(img.data() + np.offBias);
         for (int l = 0; l < NL; ++l) {
-            const Layer& L = net.hidden[size_t(l)];
+            const Layer& L = net.hidden[size_t(L0 + l)];
             const int ks = l == 0 ? KS0 : KS;
             const size_t baseOff = l == 0 ? size_t(np.offLayer0) : size_t(np.offHidden) + size_t(l - 1) * MT * KS * kFragBytes;
             if (L.channelsOut != C) throw InvalidNetwork("hidden layer width mismatch");
@@ -279,15 +292,15 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
             for (int r = 0; r < C; ++r) bias[size_t(l) * 32 * MT + r] = std::ldexp(half_bits_to_float(L.bias[size_t(r)]), kB);
         }
         // last layer: outputs replicated on rows 0..3 and 4..7 so both lane halves see them
-        const Layer& L = net.hidden[size_t(NL)];
+        const Layer& L = net.hidden.back();
         if (L.channelsIn != C || L.channelsOut != Cout) throw InvalidNetwork("last layer shape mismatch");
         const bool transposed = L.channelsIn < 16 || L.channelsOut < 16;  // addLayer stores [in][out]
-        const int kL = exps ? (*exps)[size_t(NL - 1)] : 0;
+        const int kL = exps && NL > 0 ? (*exps)[size_t(NL - 1)] : 0;
         for (int s = 0; s < KS; ++s) {
             Frag f{};
             for (int lane = 0; lane < 64; ++lane) {
                 const int row = lane & 31, h = lane >> 5;
-                if (row >= 8 || (row & 3) >= Cout) continue;
+                if (row >= 8 || (row & 3) >= Cout) continue;  // outputs 0..3 (curvature outputs 4,5 have no consumer on this path)
                 const int o = row & 3;
                 for (int j = 0; j < 8; ++j) {
                     const int col = chiOfSlot(16 * s + 8 * h + j);
@@ -297,7 +310,7 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
             putFrag(img, size_t(np.offLast) + size_t(s) * kFragBytes, f);
         }
         float* bl = bias + size_t(NL) * 32 * MT;
-        for (int o = 0; o < Cout; ++o) bl[o] = bl[4 + o] = half_bits_to_float(L.bias[size_t(o)]);
+        for (int o = 0; o < std::min(Cout, 4); ++o) bl[o] = bl[4 + o] = half_bits_to_float(L.bias[size_t(o)]);
     };
     packLayers(P.ldsImage, nullptr);
 
@@ -310,7 +323,7 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
     // latent features by the grid's range), which is what the renderer evaluates; evaluate_points keeps the
     // plain image because callers may pass positions outside the box.
     P.ldsImageScaled.clear();
-    if (c.activation == FVSRN_ACT_RELU) {
+    if (c.activation == FVSRN_ACT_RELU && c.hasFourier) {
         std::vector<double> bound(size_t(C + c.gridChannels), 1.0005);  // stored input order of layer 0
         if (c.passTime && net.latentGrid) bound[3] = double(std::max(net.latentGrid->timeNum - 1, 0)) + 1e-3;  // any time index
         for (int g = 0; g < c.gridChannels; ++g) bound[size_t(C + g)] = double(P.gridMaxAbs[size_t(g)]) * 1.0005;
@@ -366,7 +379,7 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
         np.boxSize[i] = net.boxSize[i];
         np.invBoxSize[i] = 1.0f / net.boxSize[i];
     }
-    P.mfmaFlopsPerSample = 1024.0 * (MT + double(MT) * KS0 + double(NL - 1) * MT * KS + KS);
+    P.mfmaFlopsPerSample = 1024.0 * (MT + (NL > 0 ? double(MT) * KS0 : 0.0) + double(std::max(NL - 1, 0)) * MT * KS + KS);
     return P;
 }
 

@@ -44,7 +44,7 @@ __device__ __forceinline__ void tile_bcast(float v, float& t0, float& t1) {
 
 template <int ACT>
 __device__ __forceinline__ float act_f32(float x, float a, float b) {
-    if constexpr (ACT == ACT_RELU) {
+    if constexpr (ACT == ACT_RELU || ACT == ACT_RELU01) {
         return fmaxf(x, 0.f);
     } else if constexpr (ACT == ACT_SINE) {  // sin(p x), a = p/(2 pi)          renderer_activations.cuh: Sine
         return __builtin_amdgcn_sinf(x * a);
@@ -369,12 +369,20 @@ __device__ __forceinline__ half8_t phase_operand(const unsigned (&tp)[3], const 
 // half hmul/hfma chain + hcos/hsin of the reference (renderer_volume_tensorcores.cuh:797-806).
 // DELTA: (px,py,pz) is the per-step position increment of a ray instead: the pairs become (cos, sin) of the per-step
 // phase increment and the pass-through registers the position increment (0 for time / direction) -- see fourier_advance.
-template <bool FRACT>
+// What follows the "phase" MFMA (FMODE, resolved once per kernel launch):
+//   FM_COS / FM_FRACT_COS: Fourier features, cos of the phase (after v_fract if it can leave the +-256 revolution
+//                          domain of v_cos_f32)
+//   FM_FIRST_LAYER:        network without Fourier features: the fragments are the scalar first layer 3|6 -> C
+//                          (renderer_volume_tensorcores.cuh:810-823) with the bias in the constant slot, followed by the
+//                          hidden activation
+enum { FM_COS = 0, FM_FRACT_COS = 1, FM_FIRST_LAYER = 2 };
+template <int FMODE>
 __device__ __forceinline__ void phase_cos(floatx16& d, int npass) {
+    static_assert(FMODE != FM_FIRST_LAYER, "no cos stage without Fourier features");
 #pragma unroll
     for (int r = 0; r < 16; ++r)
         if (r >= npass) {
-            if constexpr (FRACT) d[r] = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(d[r]));  // v_cos_f32 domain: +-256 revolutions
+            if constexpr (FMODE == FM_FRACT_COS) d[r] = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(d[r]));
             else d[r] = __builtin_amdgcn_cosf(d[r]);
         }
 }
@@ -404,7 +412,7 @@ __device__ __forceinline__ void phase_operands(float px, float py, float pz, flo
     b0[1] = phase_operand<HAS_DIR>(tph[1], td[1], h);
 }
 
-template <int CD, bool HAS_DIR, bool FRACT, bool DELTA = false>
+template <int CD, bool HAS_DIR, int FMODE, bool DELTA = false>
 __device__ __forceinline__ void fourier_features(const NetParams& P, const char* lds, float px, float py, float pz, float dx,
                                                  float dy, float dz, floatx16 (&f)[2][mtiles(CD)]) {
     constexpr int MT = mtiles(CD);
@@ -426,7 +434,7 @@ __device__ __forceinline__ void fourier_features(const NetParams& P, const char*
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) phase_cos<FRACT>(f[t][m], m == 0 ? NPASS : 0);
+        for (int m = 0; m < MT; ++m) phase_cos<FMODE>(f[t][m], m == 0 ? NPASS : 0);
     if constexpr (DELTA) {
         // the constant K slot also carries the time pass-through (row 5: lane half 1, register 1; with direction row 3:
         // lane half 0, register 3): its increment is 0
@@ -439,7 +447,7 @@ __device__ __forceinline__ void fourier_features(const NetParams& P, const char*
 }
 
 // the same features as fp16 B fragments of the first layer, tile by tile (few live registers)
-template <int CD, bool HAS_DIR, bool FRACT>
+template <int CD, int ACT, bool HAS_DIR, int FMODE>
 __device__ __forceinline__ void fourier_fragments(const NetParams& P, const char* lds, float px, float py, float pz, float dx,
                                                   float dy, float dz, half8_t (&xb)[2][2 * mtiles(CD)]) {
     constexpr int MT = mtiles(CD);
@@ -454,9 +462,15 @@ __device__ __forceinline__ void fourier_fragments(const NetParams& P, const char
         for (int m = 0; m < MT; ++m) {
             floatx16 d = {0};
             d = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(lds, P.offPhase + m * kFragBytes, lane), b0[t], d, 0, 0, 0);
-            phase_cos<FRACT>(d, m == 0 ? NPASS : 0);
+            if constexpr (FMODE == FM_FIRST_LAYER) {
+                constexpr int A = ACT == ACT_RELU01 ? ACT_RELU : ACT;  // no scaled image without Fourier features
 #pragma unroll
-            for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d, q, 0.f, 0.f, xb[t][2 * m], xb[t][2 * m + 1]);
+                for (int q = 0; q < 4; ++q) act_pack_quarter<A>(d, q, P.actA, P.actB, xb[t][2 * m], xb[t][2 * m + 1]);
+            } else {
+                phase_cos<FMODE>(d, m == 0 ? NPASS : 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d, q, 0.f, 0.f, xb[t][2 * m], xb[t][2 * m + 1]);
+            }
         }
 }
 
@@ -745,19 +759,22 @@ __device__ __forceinline__ float4_t srn_layers(const NetParams& P, const char* l
 #ifndef FVSRN_NO_PIPELINE
     // measured (r01): the pipelined order wins for Fourier-only networks; with a latent grid its extra registers
     // cost more occupancy than the schedule gains
-    if constexpr (CD <= 4 && GRID == 0) return srn_layers_pipelined<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill);
-    else
+    if constexpr (CD <= 4 && GRID == 0) {
+        if (P.numLayers > 0)  // wave-uniform; 0 = first + last layer only (networks without Fourier features)
+            return srn_layers_pipelined<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill);
+        return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill);
+    } else
 #endif
         return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill);
 }
 
 // positions -> raw network outputs (evaluate_points, and render steps of networks without the rotation shortcut)
-template <int CD, int ACT, int GRID, bool HAS_DIR, bool FRACT>
+template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE>
 __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* lds, float px, float py, float pz,
                                                 float dx, float dy, float dz) {
     half8_t xb[2][2 * mtiles(CD)];
     return srn_layers<CD, ACT, GRID, HAS_DIR, 0>(
-        P, lds, xb, px, py, pz, [&]() { fourier_fragments<CD, HAS_DIR, FRACT>(P, lds, px, py, pz, dx, dy, dz, xb); }, [](int) {});
+        P, lds, xb, px, py, pz, [&]() { fourier_fragments<CD, ACT, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, xb); }, [](int) {});
 }
 
 // the same from the input features `feat` of the current sample, which are advanced to the next sample of the rays

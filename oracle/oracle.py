@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libsrn_oracle.so")
 ACC_HALF, ACC_FLOAT = 0, 1
 ACTIVATIONS = {"ReLU": 0, "Sine": 1, "Snake": 2, "SnakeAlt": 3}
 OUTPUT_MODES = {"density": 0, "density:direct": 1, "rgbo": 2, "rgbo:direct": 3, "densitygrad": 4,
-                "densitygrad:direct": 5, "densitygrad:cubic": 6}
+                "densitygrad:direct": 5, "densitygrad:cubic": 6, "densitycurvature": 7, "densitycurvature:direct": 8}
 TF_NONE, TF_IDENTITY, TF_GAUSSIAN, TF_PIECEWISE, TF_TEXTURE = range(5)
 BLEND_ALPHA, BLEND_BEER_LAMBERT = 0, 1
 
@@ -63,6 +63,8 @@ def lib() -> C.CDLL:
         l = C.CDLL(LIB_PATH)
         l.oracle_eval_points.restype = C.c_int
         l.oracle_eval_points.argtypes = [C.POINTER(_OracleNet), _FP, _FP, C.c_size_t, _FP]
+        l.oracle_eval_points_full.restype = C.c_int
+        l.oracle_eval_points_full.argtypes = [C.POINTER(_OracleNet), _FP, _FP, C.c_size_t, _FP]
         l.oracle_render.restype = C.c_int
         l.oracle_render.argtypes = [C.POINTER(_OracleNet), C.POINTER(_OracleScene), C.c_int, C.c_int, C.c_int, C.c_int,
                                     _FP, C.POINTER(C.c_ulonglong)]
@@ -87,20 +89,24 @@ class OracleNetwork:
         n = _OracleNet()
         keep = []
         F = vn.num_fourier
-        if F <= 0:
-            raise ValueError("the oracle restates the Fourier-feature path only")
         has_grid = vn.has_grid()
+        if F <= 0 and has_grid:
+            raise ValueError("a latent grid needs Fourier features (SceneNetwork::valid, volume_interpolation_network.cpp:952-956)")
         L = vn.layers
         G = 0
         if has_grid:
             tg, eg = vn.time_grids or [], vn.ensemble_grids or []
             G = (tg[0].channels if tg else 0) + (eg[0].channels if eg else 0)
         # getDefines (:1139-1219)
-        Cc = L[0].channels_in - G
         base = 8 if vn.has_direction else 4
-        assert Cc == base + 2 * F, "2*num_fourier+%d == hidden[0].channelsIn must hold" % base
+        if F > 0:
+            Cc = L[0].channels_in - G
+            assert Cc == base + 2 * F, "2*num_fourier+%d == hidden[0].channelsIn must hold" % base
+        else:  # scalar first layer 3|6 -> C (renderer_volume_tensorcores.cuh:810-823)
+            Cc = L[0].channels_out
+            assert L[0].channels_in == (6 if vn.has_direction else 3)
         n.useDirection = (2 if vn.use_direction_in_fourier else 1) if vn.has_direction else 0
-        start_hidden = 1 if has_grid else 0
+        start_hidden = 1 if (has_grid or F <= 0) else 0
         NH = len(L) - start_hidden - 1
         n.C, n.F, n.G, n.NH = Cc, F, G, NH
         n.Cout = L[-1].channels_out
@@ -117,8 +123,8 @@ class OracleNetwork:
             keep.append(a)
             return a.ctypes.data_as(_U16P)
 
-        n.fourier = ptr16(vn.fourier)
-        if has_grid:
+        n.fourier = ptr16(vn.fourier if F > 0 else np.zeros(1, np.uint16))
+        if has_grid or F <= 0:
             n.wFirst = ptr16(L[0].weights)
             n.bFirst = ptr16(L[0].bias)
         hidden = L[start_hidden:len(L) - 1]
@@ -193,6 +199,18 @@ class OracleNetwork:
                                      p.shape[0], out.ctypes.data_as(_FP))
         if r != 0:
             raise RuntimeError("oracle_eval_points failed")
+        return out
+
+
+    def evaluate_full(self, world_positions: np.ndarray, directions: Optional[np.ndarray] = None) -> np.ndarray:
+        """(N,9): value[4], predicted normal[3], predicted curvature[2] -- everything eval<> returns."""
+        p = np.ascontiguousarray(world_positions, dtype=np.float32)
+        d = np.ascontiguousarray(directions, dtype=np.float32) if directions is not None else None
+        out = np.zeros((p.shape[0], 9), np.float32)
+        r = lib().oracle_eval_points_full(C.byref(self._n), p.ctypes.data_as(_FP), d.ctypes.data_as(_FP) if d is not None else None,
+                                          p.shape[0], out.ctypes.data_as(_FP))
+        if r != 0:
+            raise RuntimeError("oracle_eval_points_full failed")
         return out
 
 

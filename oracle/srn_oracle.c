@@ -231,7 +231,7 @@ static float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 static float softplusf_(float x) { return x > 20.f ? x : logf(1.f + expf(x)); }
 
 /* eval<>: world position (+ view direction) -> out[0..3] = value (1 or 4 channels used), nrm[3] = predicted normal */
-static void srn_eval(const OracleNet* n, const float wpos[3], const float dir[3], float out[4], float nrm[3]) {
+static void srn_eval(const OracleNet* n, const float wpos[3], const float dir[3], float out[4], float nrm[3], float curv[2]) {
     const int C = n->C, F = n->F, G = n->G;
     const int base = n->useDirection >= 1 ? 8 : 4; /* fourierOffset :794 */
     float p[3];
@@ -265,6 +265,31 @@ static void srn_eval(const OracleNet* n, const float wpos[3], const float dir[3]
             x[base + F + i] = rh_d(sin(c));
         }
     }
+    if (F == 0) { /* no Fourier features: scalar first layer :810-823, weights [cin][cout], half fma chain */
+        for (int co = 0; co < C; ++co) {
+            float r;
+            if (n->accMode == ORACLE_ACC_HALF) {
+                float c = h2f(n->bFirst[co]);
+                c = hfma(vx, h2f(n->wFirst[co + C * 0]), c);
+                c = hfma(vy, h2f(n->wFirst[co + C * 1]), c);
+                c = hfma(vz, h2f(n->wFirst[co + C * 2]), c);
+                if (n->useDirection >= 1) {
+                    c = hfma(dxh, h2f(n->wFirst[co + C * 3]), c);
+                    c = hfma(dyh, h2f(n->wFirst[co + C * 4]), c);
+                    c = hfma(dzh, h2f(n->wFirst[co + C * 5]), c);
+                }
+                r = act_half(n->activation, c, n->actParam);
+            } else {
+                double c = h2f(n->bFirst[co]);
+                c += (double)vx * h2f(n->wFirst[co + C * 0]) + (double)vy * h2f(n->wFirst[co + C * 1]) + (double)vz * h2f(n->wFirst[co + C * 2]);
+                if (n->useDirection >= 1)
+                    c += (double)dxh * h2f(n->wFirst[co + C * 3]) + (double)dyh * h2f(n->wFirst[co + C * 4]) + (double)dzh * h2f(n->wFirst[co + C * 5]);
+                r = rh(act_float(n->activation, (float)c, n->actParam));
+            }
+            y[co] = r;
+        }
+        memcpy(x, y, sizeof(float) * (size_t)C);
+    }
     /* latent grid layer :839-948 */
     if (G > 0) {
         for (int g = 0; g < G / 16; ++g) grid_features(n, p, g, x + C + 16 * g);
@@ -278,7 +303,7 @@ static void srn_eval(const OracleNet* n, const float wpos[3], const float dir[3]
     }
     /* last layer :1045-1053, :1138-1143; weights stored [cin][cout] */
     const int Co = n->Cout;
-    float o[4] = {0, 0, 0, 0};
+    float o[6] = {0, 0, 0, 0, 0, 0};
     for (int c = 0; c < Co; ++c) {
         if (n->accMode == ORACLE_ACC_HALF) {
             float acc = h2f(n->bLast[c]);
@@ -291,6 +316,7 @@ static void srn_eval(const OracleNet* n, const float wpos[3], const float dir[3]
         }
     }
     nrm[0] = nrm[1] = nrm[2] = 0.f;
+    curv[0] = curv[1] = 0.f;
     out[0] = out[1] = out[2] = out[3] = 0.f;
     switch (n->outputMode) { /* :1054-1158 */
         case ORACLE_OUT_DENSITY: out[0] = sigmoidf_(o[0]); break;
@@ -307,6 +333,12 @@ static void srn_eval(const OracleNet* n, const float wpos[3], const float dir[3]
         case ORACLE_OUT_DENSITY_GRADIENT_CUBIC:
             out[0] = o[0]; nrm[0] = o[1] * o[1] * o[1]; nrm[1] = o[2] * o[2] * o[2]; nrm[2] = o[3] * o[3] * o[3];
             break;
+        case ORACLE_OUT_DENSITY_CURVATURE: /* :1117-1123 */
+            out[0] = sigmoidf_(o[0]); nrm[0] = o[1]; nrm[1] = o[2]; nrm[2] = o[3]; curv[0] = o[4]; curv[1] = o[5];
+            break;
+        case ORACLE_OUT_DENSITY_CURVATURE_DIRECT: /* :1124-1132 */
+            out[0] = o[0]; nrm[0] = o[1]; nrm[1] = o[2]; nrm[2] = o[3]; curv[0] = o[4]; curv[1] = o[5];
+            break;
         default: break;
     }
 }
@@ -316,10 +348,23 @@ int oracle_eval_points(const OracleNet* n, const float* pos, const float* dirs, 
     const int oc = (n->outputMode == ORACLE_OUT_RGBO || n->outputMode == ORACLE_OUT_RGBO_DIRECT) ? 4 : 1;
 #pragma omp parallel for schedule(static)
     for (long long i = 0; i < (long long)count; ++i) {
-        float o[4], nr[3];
+        float o[4], nr[3], cv[2];
         const float zero[3] = {0, 0, 0};
-        srn_eval(n, pos + 3 * i, dirs ? dirs + 3 * i : zero, o, nr);
+        srn_eval(n, pos + 3 * i, dirs ? dirs + 3 * i : zero, o, nr, cv);
         for (int c = 0; c < oc; ++c) out[(size_t)i * oc + c] = o[c];
+    }
+    return 0;
+}
+
+int oracle_eval_points_full(const OracleNet* n, const float* pos, const float* dirs, size_t count, float* out9) {
+    if (!n || n->C > ORACLE_MAX_C || n->G > 64) return -1;
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)count; ++i) {
+        float o[4], nr[3], cv[2];
+        const float zero[3] = {0, 0, 0};
+        srn_eval(n, pos + 3 * i, dirs ? dirs + 3 * i : zero, o, nr, cv);
+        float* r = out9 + (size_t)i * 9;
+        r[0] = o[0]; r[1] = o[1]; r[2] = o[2]; r[3] = o[3]; r[4] = nr[0]; r[5] = nr[1]; r[6] = nr[2]; r[7] = cv[0]; r[8] = cv[1];
     }
     return 0;
 }
@@ -405,8 +450,8 @@ static void render_pixel(const OracleNet* n, const OracleScene* s, int W, int H,
         if (!valid) break; /* later iterations of an invalid lane never blend (:151) and never turn valid again */
         ++cnt;
         const float pos[3] = {eye[0] + dir[0] * t, eye[1] + dir[1] * t, eye[2] + dir[2] * t};
-        float v[4], g[3], c[4] = {0, 0, 0, 0};
-        srn_eval(n, pos, dir, v, g);
+        float v[4], g[3], cv[2], c[4] = {0, 0, 0, 0};
+        srn_eval(n, pos, dir, v, g, cv);
         if (rgbo) {
             c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3] * s->stepsize; /* :104-108 */
         } else {

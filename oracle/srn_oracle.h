@@ -12,7 +12,8 @@ enum { ORACLE_ACC_HALF = 0, ORACLE_ACC_FLOAT = 1 };
 enum { ORACLE_ACT_RELU = 0, ORACLE_ACT_SINE = 1, ORACLE_ACT_SNAKE = 2, ORACLE_ACT_SNAKEALT = 3 };
 enum {
     ORACLE_OUT_DENSITY = 0, ORACLE_OUT_DENSITY_DIRECT = 1, ORACLE_OUT_RGBO = 2, ORACLE_OUT_RGBO_DIRECT = 3,
-    ORACLE_OUT_DENSITY_GRADIENT = 4, ORACLE_OUT_DENSITY_GRADIENT_DIRECT = 5, ORACLE_OUT_DENSITY_GRADIENT_CUBIC = 6
+    ORACLE_OUT_DENSITY_GRADIENT = 4, ORACLE_OUT_DENSITY_GRADIENT_DIRECT = 5, ORACLE_OUT_DENSITY_GRADIENT_CUBIC = 6,
+    ORACLE_OUT_DENSITY_CURVATURE = 7, ORACLE_OUT_DENSITY_CURVATURE_DIRECT = 8
 };
 enum { ORACLE_GRID_FLOAT = 0, ORACLE_GRID_BYTE_LINEAR = 1, ORACLE_GRID_BYTE_GAUSSIAN = 2 };
 enum { ORACLE_TF_NONE = 0, ORACLE_TF_IDENTITY = 1, ORACLE_TF_GAUSSIAN = 2, ORACLE_TF_PIECEWISE = 3, ORACLE_TF_TEXTURE = 4 };
@@ -25,14 +26,14 @@ typedef struct {
     int F;           /* NUM_FOURIER_FEATURES                             */
     int G;           /* latent grid channels (0 = none)                  */
     int NH;          /* NUM_HIDDEN_LAYERS (C x C)                        */
-    int Cout;        /* last layer outputs: 1 or 4                       */
+    int Cout;        /* last layer outputs: 1, 4 or 6 (curvature modes)  */
     int outputMode, activation, gridEncoding, passTime, accMode;
     int useDirection; /* USE_DIRECTION: 0 none, 1 extra inputs, 2 extra inputs + inside the Fourier matrix (6 columns) */
     float actParam;
     float boxMin[3], boxSize[3];
     const uint16_t* fourier; /* cWeightsFourier [3*F], feature-fastest   */
-    const uint16_t* wFirst;  /* cWeightsLatentGrid [C][(C+G)] row-major  */
-    const uint16_t* bFirst;  /* cBiasLatentGrid [C]                      */
+    const uint16_t* wFirst;  /* cWeightsLatentGrid [C][(C+G)] row-major; F == 0: cWeightsFirst [3|6][C] (output fastest) */
+    const uint16_t* bFirst;  /* cBiasLatentGrid [C]; F == 0: cBiasFirst [C] */
     const uint16_t* wHidden; /* cWeightsHidden [NH][C][C] row-major      */
     const uint16_t* bHidden; /* cBiasHidden [NH][C]                      */
     const uint16_t* wLast;   /* cWeightsLast [C][Cout]                   */
@@ -54,6 +55,8 @@ typedef struct {
 } OracleScene;
 
 int oracle_eval_points(const OracleNet* n, const float* worldPos, const float* directions /* or NULL */, size_t count, float* out);
+/* all raw outputs of eval<>: out[count][9] = value[4], normal[3], curvature[2] */
+int oracle_eval_points_full(const OracleNet* n, const float* worldPos, const float* directions /* or NULL */, size_t count, float* out9);
 int oracle_render(const OracleNet* n, const OracleScene* s, int W, int H, int y0, int y1, float* out8,
                   unsigned long long* evaluatedSamples);
 unsigned long long oracle_count_samples(const OracleNet* n, const OracleScene* s, int W, int H, int y0, int y1);

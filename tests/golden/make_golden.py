@@ -94,8 +94,9 @@ def make_network(SRN, *, layers, activation, fouriercount, fourierstd, outputmod
     with torch.no_grad():  # fp16-representable parameters (see module docstring)
         for q in net.parameters():
             q.copy_(q.half().float())
-        B = net._input_parametrization.B
-        B.copy_(B.half().float())
+        if fouriercount > 0:
+            B = net._input_parametrization.B
+            B.copy_(B.half().float())
         # a grid of std 0.01 hardly influences the output; scale it up so grid bugs are visible
         for name in ("_volumetric_latent_space", "_volumetric_latent_space_time", "_volumetric_latent_space_ensemble"):
             if hasattr(net, name):
@@ -133,7 +134,10 @@ def forward(net, pos, time=0.0, ensemble=0.0, half=False, mode="world", directio
 def save_case(name, net, opt, pos, extra_meta=None, times=None, **arrays):
     sd = net.state_dict()
     n_lin = len(opt["layers"].split(":")) + 1
-    data = {"B": sd["_input_parametrization.B"].numpy(), "positions": pos}
+    if ONLY and not any(name.startswith(o) for o in ONLY):
+        return
+    data = {"B": sd["_input_parametrization.B"].numpy() if "_input_parametrization.B" in sd else np.zeros((0, 3), np.float32),
+            "positions": pos}
     for i in range(n_lin):
         data["W%d" % i] = sd["_hidden_layers.linear%d.weight" % i].numpy()
         data["b%d" % i] = sd["_hidden_layers.linear%d.bias" % i].numpy()
@@ -154,7 +158,11 @@ def save_case(name, net, opt, pos, extra_meta=None, times=None, **arrays):
     print("wrote", name, {k: getattr(v, "shape", None) for k, v in data.items() if k not in ("meta",)})
 
 
+ONLY = []  # fixture name prefixes given on the command line: write only those (the others stay byte-identical)
+
+
 def main():
+    ONLY[:] = sys.argv[1:]
     SRN, Raytracing = import_reference()
     N = 1024
 
@@ -214,6 +222,27 @@ def main():
         dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float16).astype(np.float32)
         save_case(name, net, opt, pos, directions=dirs, out_fp32=forward(net, pos, directions=dirs),
                   out_fp16=forward(net, pos, half=True, directions=dirs))
+
+    # ---- G1e: no Fourier features: scalar first layer 3|6 -> C (renderer_volume_tensorcores.cuh:810-823) -------------
+    for name, kw in [
+        ("g1_nofourier_c32l4_snakealt_density", dict(layers="32:32:32", activation="SnakeAlt:1", outputmode="density")),
+        ("g1_nofourier_c64l2_relu_rgbo", dict(layers="64", activation="ReLU", outputmode="rgbo")),  # first + last layer only
+        ("g1_nofourier_c48l3_sine_density-direct", dict(layers="48:48", activation="Sine:1", outputmode="density:direct")),
+        ("g1_nofourier_dir_c32l3_snake_rgbo-direct", dict(layers="32:32", activation="Snake:2", outputmode="rgbo:direct", dir=True)),
+    ]:
+        k += 1
+        net, opt = make_network(SRN, layers=kw["layers"], activation=kw["activation"], fouriercount=0, fourierstd=-1,
+                                outputmode=kw["outputmode"], use_direction=kw.get("dir", False), direction_in_fourier=False,
+                                seed=100 + k)
+        pos = positions(N, 0, k)
+        if kw.get("dir"):
+            rng = np.random.RandomState(1000 + k)
+            dirs = rng.randn(N, 3)
+            dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float16).astype(np.float32)
+            save_case(name, net, opt, pos, directions=dirs, out_fp32=forward(net, pos, directions=dirs),
+                      out_fp16=forward(net, pos, half=True, directions=dirs))
+        else:
+            save_case(name, net, opt, pos, out_fp32=forward(net, pos), out_fp16=forward(net, pos, half=True))
 
     # ---- G2: time-dependent / ensemble latent grids ---------------------------------------------------
     times = [0.0, 0.25, 1.0, 1.75, 2.0]

@@ -151,17 +151,42 @@ def test_invalid_inputs_are_rejected_with_messages():
 
 
 def test_unsupported_variants_fail_loudly():
-    d, meta = util.load_golden("g1_c32l4_snakealt_density")
-    net = capi.Network.create()
-    net.set_input(d["B"])
-    net.set_output_mode("densitycurvature")
     rng = np.random.RandomState(0)
-    net.add_layer(rng.randn(32, 31), rng.randn(32), "ReLU")
-    net.add_layer(rng.randn(6, 32), rng.randn(6), "None")
+    # a hidden width outside the ahead-of-time matrix (32/48/64/96/128)
+    net = capi.Network.create()
+    net.set_input(rng.randn(38, 3).astype(np.float32))
+    net.add_layer(rng.randn(80, 79), rng.randn(80), "ReLU")
+    net.add_layer(rng.randn(1, 80), rng.randn(1), "None")
     assert net.valid()
     with pytest.raises(capi.FvsrnError) as e:
         net.kernel_name()
     assert e.value.code == -4 and "not in the compiled variant set" in str(e.value)
+    # a hidden activation the kernels do not implement
+    d, meta = util.load_golden("g1_c32l4_snakealt_density")
+    net = capi.Network.create()
+    net.set_input(d["B"])
+    net.add_layer(rng.randn(32, 31), rng.randn(32), "Sigmoid")
+    net.add_layer(rng.randn(1, 32), rng.randn(1), "None")
+    assert net.valid()
+    with pytest.raises(capi.FvsrnError) as e:
+        net.kernel_name()
+    assert e.value.code == -4 and "not in the compiled variant set" in str(e.value)
+
+
+def test_curvature_and_no_fourier_networks_select_a_kernel():
+    rng = np.random.RandomState(1)
+    d, meta = util.load_golden("g1_c32l4_snakealt_density")
+    net = capi.Network.create()
+    net.set_input(d["B"])
+    net.set_output_mode("densitycurvature")
+    net.add_layer(rng.randn(32, 31), rng.randn(32), "ReLU")
+    net.add_layer(rng.randn(6, 32), rng.randn(6), "None")
+    assert net.valid() and "render_kernel<2," in net.kernel_name(True)
+    net = capi.Network.create()
+    net.set_input(None)
+    net.add_layer(rng.randn(64, 3), rng.randn(64), "Sine")
+    net.add_layer(rng.randn(1, 64), rng.randn(1), "None")  # first + last layer only
+    assert net.valid() and "render_kernel<4," in net.kernel_name(True)
 
 
 def test_camera_on_a_sphere_all_orientations():
