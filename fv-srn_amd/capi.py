@@ -82,6 +82,8 @@ SYMBOLS = [
     ("fvsrn_render", _I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP]),
     ("fvsrn_stripe_rows", _I, [_I, _I, _I, _I]),
     ("fvsrn_render_stripes", _I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
+    ("fvsrn_extract_color", _I, [_VP, _I, _I, _I, _I, _F, _VP, _VP]),
+    ("fvsrn_extract_color_rgba8", _I, [_VP, _I, _I, _I, _I, _F, _VP, _VP]),
     ("fvsrn_network_kernel_name", _I, [_VP, _I, C.c_char_p, _SZ]),
 ]
 
@@ -349,3 +351,24 @@ def camera_on_a_sphere(orientation: str, center, pitch: float, yaw: float, dista
     eye, right, up = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)()
     _check(lib().fvsrn_camera_on_a_sphere(ORIENTATIONS[orientation], c, pitch, yaw, distance, eye, right, up))
     return np.array(eye, np.float32), np.array(right, np.float32), np.array(up, np.float32)
+
+
+CHANNEL_MASK, CHANNEL_NORMAL, CHANNEL_DEPTH, CHANNEL_COLOR = range(4)
+
+
+def extract_color(raw, channel_mode: int = CHANNEL_COLOR, use_tonemapping: bool = False, max_exposure: float = 1.0,
+                  rgba8: bool = False, stream=None):
+    """IImageEvaluator::ExtractColor on a (1,8,H,W) fp32 CUDA tensor: (1,4,H,W) fp32, or (H,W) int32 words 0xAABBGGRR."""
+    import torch
+    if raw.dim() != 4 or raw.shape[0] != 1 or raw.shape[1] != 8:
+        raise FvsrnError(-1, "raw input must be of shape (1,8,H,W)")
+    H, W = int(raw.shape[2]), int(raw.shape[3])
+    src = _torch_ptr(raw, "torch.float32", "raw input")
+    s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    if rgba8:
+        out = torch.empty((H, W), dtype=torch.int32, device=raw.device)
+        _check(lib().fvsrn_extract_color_rgba8(src, W, H, channel_mode, int(use_tonemapping), max_exposure, out.data_ptr(), s))
+    else:
+        out = torch.empty((1, 4, H, W), dtype=torch.float32, device=raw.device)
+        _check(lib().fvsrn_extract_color(src, W, H, channel_mode, int(use_tonemapping), max_exposure, out.data_ptr(), s))
+    return out

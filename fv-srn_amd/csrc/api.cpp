@@ -787,6 +787,44 @@ int fvsrn_render(fvsrn_scene* scene, fvsrn_network* net, int width, int height, 
     return renderImpl(scene, net, width, height, y0, y1, y1 - y0, 8, 0, 1, 0, d_out8, d_stats, stream);
 }
 
+static int extractImpl(const float* d_raw8, int width, int height, int channel_mode, int use_tonemapping, float max_exposure,
+                       float* d_out4, unsigned int* d_out8, void* stream) {
+    if (!d_raw8 || (!d_out4 && !d_out8)) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null image pointer");
+    if (width <= 0 || height <= 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad image size");
+    if (channel_mode < FVSRN_CHANNEL_MASK || channel_mode > FVSRN_CHANNEL_COLOR) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad channel mode");
+    if (use_tonemapping && !(max_exposure > 0)) return fail(FVSRN_ERR_INVALID_ARGUMENT, "max_exposure must be positive");
+    return guarded([&]() -> int {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+            return fail(FVSRN_ERR_NO_DEVICE, "no HIP device available: the MI355X kernels cannot run (there is no CPU fallback)");
+        // 3 words of scratch for the depth range: one small allocation per thread, reused
+        thread_local DeviceBuffer scratch;
+        try {
+            scratch.ensure(16);
+        } catch (const DeviceError& e) {
+            return fail(FVSRN_ERR_DEVICE, e.what());
+        }
+        ExtractParams p{};
+        p.raw = d_raw8; p.out4 = d_out4; p.out8 = d_out8;
+        p.minmax = static_cast<float*>(scratch.ptr);
+        p.pixels = (unsigned long long)width * (unsigned long long)height;
+        p.mode = channel_mode; p.tonemap = use_tonemapping; p.maxExposure = max_exposure;
+        const hipError_t e = launch_extract_color(p, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("extract_color failed: ") + hipGetErrorString(e));
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_extract_color(const float* d_raw8, int width, int height, int channel_mode, int use_tonemapping, float max_exposure,
+                        float* d_out4, void* stream) {
+    return extractImpl(d_raw8, width, height, channel_mode, use_tonemapping, max_exposure, d_out4, nullptr, stream);
+}
+
+int fvsrn_extract_color_rgba8(const float* d_raw8, int width, int height, int channel_mode, int use_tonemapping,
+                              float max_exposure, unsigned int* d_out, void* stream) {
+    return extractImpl(d_raw8, width, height, channel_mode, use_tonemapping, max_exposure, nullptr, d_out, stream);
+}
+
 int fvsrn_stripe_rows(int height, int stripe_rows, int rank, int world) {
     if (height <= 0 || stripe_rows <= 0 || world <= 0 || rank < 0 || rank >= world) return -1;
     int rows = 0;

@@ -59,6 +59,99 @@ __global__ void grid_blend_kernel(BlendParams p) {
     }
 }
 
+// ---- IImageEvaluator::ExtractColor (renderer/iimage_evaluator.cpp:26-135) --------------------------------------------
+// min / max of the depth plane with the NaN semantics of torch's min()/max() (any NaN -> NaN): per-block reduction,
+// then one atomic per block on an order-preserving integer image of the float; a NaN poisons both results.
+__device__ __forceinline__ unsigned orderedBits(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fromOrderedBits(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// minmaxBits: {min as ordered bits (init 0xffffffff), max (init 0), nan flag}
+__global__ void depth_minmax_kernel(const float* __restrict__ depth, unsigned long long n, unsigned* __restrict__ minmaxBits) {
+    unsigned mn = 0xffffffffu, mx = 0u, nan = 0u;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float v = depth[i];
+        if (v != v) nan = 1u;
+        else { const unsigned k = orderedBits(v); mn = min(mn, k); mx = max(mx, k); }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = min(mn, unsigned(__shfl_xor(int(mn), off)));
+        mx = max(mx, unsigned(__shfl_xor(int(mx), off)));
+        nan |= unsigned(__shfl_xor(int(nan), off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&minmaxBits[0], mn);
+        atomicMax(&minmaxBits[1], mx);
+        if (nan) atomicOr(&minmaxBits[2], 1u);
+    }
+}
+
+__device__ __forceinline__ float tonemap_channel(float v, float maxExposure) {  // iimage_evaluator_cuda.cu:144-165
+    v /= maxExposure;
+    v = (v * (2.51f * v + 0.03f)) / (v * (2.43f * v + 0.59f) + 0.14f);  // ACES filmic curve
+    v = fminf(fmaxf(v, 0.f), 1.f);
+    return powf(v, 1.0f / 2.4f);
+}
+__device__ __forceinline__ unsigned rgba_to_int(float r, float g, float b, float a) {  // renderer_utils.cuh:48-57
+    r = fminf(fmaxf(r * 255.f, 0.f), 255.f);
+    g = fminf(fmaxf(g * 255.f, 0.f), 255.f);
+    b = fminf(fmaxf(b * 255.f, 0.f), 255.f);
+    a = fminf(fmaxf(a * 255.f, 0.f), 255.f);
+    return (unsigned(a) << 24) | (unsigned(b) << 16) | (unsigned(g) << 8) | unsigned(r);
+}
+
+__global__ void extract_color_kernel(ExtractParams p, const unsigned* __restrict__ minmaxBits) {
+    const unsigned long long n = p.pixels;
+    float scaleRGB = 1.f, offsetRGB = 0.f, scaleA = 1.f, offsetA = 0.f;
+    int c0 = 0, c1 = 1, c2 = 2, ca = 3;
+    switch (p.mode) {  // iimage_evaluator.cpp:56-113
+        case FVSRN_CHANNEL_DEPTH: {
+            float mn, mx;
+            if (minmaxBits[2]) { mn = mx = __uint_as_float(0x7fc00000u); }
+            else { mn = fromOrderedBits(minmaxBits[0]); mx = fromOrderedBits(minmaxBits[1]); }
+            c0 = c1 = c2 = 7;
+            scaleRGB = 1.f / (mx - mn);
+            offsetRGB = -mn / (mx - mn);
+            scaleA = 0.f; offsetA = 1.f;
+        } break;
+        case FVSRN_CHANNEL_MASK: c0 = c1 = c2 = 3; scaleA = 0.f; offsetA = 1.f; break;
+        case FVSRN_CHANNEL_NORMAL: c0 = 4; c1 = 5; c2 = 6; scaleRGB = 0.5f; offsetRGB = 0.5f; break;
+        default: break;
+    }
+    const bool tm = p.mode == FVSRN_CHANNEL_COLOR && p.tonemap;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        float r = p.raw[c0 * n + i], g = p.raw[c1 * n + i], b = p.raw[c2 * n + i], a = p.raw[ca * n + i];
+        if (tm) {
+            r = tonemap_channel(r, p.maxExposure); g = tonemap_channel(g, p.maxExposure); b = tonemap_channel(b, p.maxExposure);
+        } else {
+            r = r * scaleRGB + offsetRGB; g = g * scaleRGB + offsetRGB; b = b * scaleRGB + offsetRGB;
+            a = a * scaleA + offsetA;
+        }
+        if (p.out4) { p.out4[i] = r; p.out4[n + i] = g; p.out4[2 * n + i] = b; p.out4[3 * n + i] = a; }
+        else p.out8[i] = rgba_to_int(r, g, b, a);
+    }
+}
+
+hipError_t launch_extract_color(const ExtractParams& p, hipStream_t s) {
+    unsigned* bits = reinterpret_cast<unsigned*>(p.minmax);
+    const unsigned grid = unsigned(std::min<unsigned long long>((p.pixels + 255) / 256, 4096ull));
+    if (p.mode == FVSRN_CHANNEL_DEPTH) {
+        const unsigned init[3] = {0xffffffffu, 0u, 0u};
+        hipError_t e = hipMemcpyAsync(bits, init, sizeof(init), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(depth_minmax_kernel, dim3(grid), dim3(256), 0, s, p.raw + 7 * p.pixels, p.pixels, bits);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(extract_color_kernel, dim3(grid), dim3(256), 0, s, p, bits);
+    return hipGetLastError();
+}
+
 hipError_t launch_grid_blend(const BlendParams& p, hipStream_t s) {
     const unsigned long long n = p.records * (unsigned long long)(2 * (p.Gt + p.Ge));
     if (n == 0) return hipSuccess;

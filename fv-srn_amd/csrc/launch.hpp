@@ -55,6 +55,18 @@ struct BlendParams {
 };
 hipError_t launch_grid_blend(const BlendParams& p, hipStream_t s);
 
+// IImageEvaluator::ExtractColor: raw (8,H,W) -> planar fp32 (4,H,W) or packed RGBA8; d_minmax: 2 floats of scratch
+struct ExtractParams {
+    const float* raw;
+    float* out4;          // or
+    unsigned int* out8;
+    float* minmax;        // device scratch: {min, max} of the depth channel (DEPTH mode)
+    unsigned long long pixels;
+    int mode, tonemap;
+    float maxExposure;
+};
+hipError_t launch_extract_color(const ExtractParams& p, hipStream_t s);
+
 bool kernel_info(const VariantKey& k, KernelInfo* info);
 hipError_t launch_eval(const VariantKey& k, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 hipError_t launch_render(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);

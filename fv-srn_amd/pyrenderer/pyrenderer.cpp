@@ -532,32 +532,17 @@ struct ImageEvaluatorSimple {
         return std::fmax(0.001f, lastMaxExposure * tonemappingShoulder);
     }
 
-    // IImageEvaluator::ExtractColor (renderer/iimage_evaluator.cpp:26-135, kernels iimage_evaluator_cuda.cu:82-101,
-    // 168-262) expressed with tensor ops on the device the input lives on.
+    // IImageEvaluator::ExtractColor (renderer/iimage_evaluator.cpp:26-135): one call into the C ABI per batch entry
     static torch::Tensor extractColorStatic(const torch::Tensor& raw, bool tonemap, float maxExposure, ChannelMode channel) {
         TORCH_CHECK(raw.dim() == 4 && raw.size(1) == 8, "raw input must be of shape (B,8,H,W)");
-        auto ch = [&](int c) { return raw.select(1, c); };
-        switch (channel) {
-            case ChannelColor: {
-                if (!tonemap) return raw.slice(1, 0, 4).clone();
-                torch::Tensor rgb = raw.slice(1, 0, 3) / maxExposure;  // ACES filmic curve + gamma
-                rgb = (rgb * (2.51f * rgb + 0.03f)) / (rgb * (2.43f * rgb + 0.59f) + 0.14f);
-                rgb = rgb.clamp(0, 1).pow(1.0f / 2.4f);
-                return torch::cat({rgb, raw.slice(1, 3, 4)}, 1);
-            }
-            case ChannelDepth: {
-                const float mn = ch(7).min().item<float>(), mx = ch(7).max().item<float>();
-                torch::Tensor v = ch(7) * (1 / (mx - mn)) + (-mn / (mx - mn));
-                return torch::stack({v, v, v, torch::ones_like(v)}, 1);
-            }
-            case ChannelMask: {
-                torch::Tensor a = ch(3);
-                return torch::stack({a, a, a, torch::ones_like(a)}, 1);
-            }
-            case ChannelNormal:
-                return torch::cat({raw.slice(1, 4, 7) * 0.5f + 0.5f, raw.slice(1, 3, 4)}, 1);
-        }
-        raise("unknown channel");
+        TORCH_CHECK(raw.is_cuda() && raw.scalar_type() == torch::kFloat32, "raw input must be a float32 tensor on the GPU");
+        const torch::Tensor in = raw.contiguous();
+        const int B = int(in.size(0)), H = int(in.size(2)), W = int(in.size(3));
+        torch::Tensor out = torch::empty({B, 4, H, W}, in.options());
+        for (int b = 0; b < B; ++b)
+            check(fvsrn_extract_color(in.data_ptr<float>() + size_t(b) * 8 * H * W, W, H, int(channel), tonemap ? 1 : 0, maxExposure,
+                                      out.data_ptr<float>() + size_t(b) * 4 * H * W, currentStream()));
+        return out;
     }
 };
 

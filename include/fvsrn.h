@@ -203,6 +203,22 @@ int fvsrn_stripe_rows(int height, int stripe_rows, int rank, int world);
 int fvsrn_render_stripes(fvsrn_scene* scene, fvsrn_network* net, int width, int height, int stripe_rows, int rank,
                          int world, float* d_out_local, unsigned long long* d_stats, void* stream);
 
+/* IImageEvaluator::ExtractColor (renderer/iimage_evaluator.cpp:26-135): the (1,8,H,W) raw image of fvsrn_render ->
+ * a displayable RGBA image.  channel_mode: ChannelMode of iimage_evaluator.h:19-26.
+ *   COLOR:  rgb, alpha; with use_tonemapping: rgb / max_exposure -> ACES filmic curve -> clamp -> gamma 1/2.4
+ *           (tonemappingFunction, iimage_evaluator_cuda.cu:144-165)
+ *   DEPTH:  (depth - min) / (max - min) of channel 7 over the whole image (min / max found on the device; like the
+ *           reference's tensor min()/max() a NaN depth -- alpha 0 -- makes both NaN), alpha 1
+ *   MASK:   alpha in rgb, alpha 1          NORMAL: 0.5 n + 0.5 of channels 4..6, alpha of channel 3
+ * fvsrn_extract_color writes planar fp32 (4,H,W) (SelectOutputChannelKernel2 / TonemappingKernel2, :82-101, :232-262),
+ * fvsrn_extract_color_rgba8 one packed 0xAABBGGRR word per pixel (the OpenGL-texture overloads, rgbaToInt of
+ * renderer_utils.cuh:48-57).  Device pointers; the image must not alias the output. */
+typedef enum { FVSRN_CHANNEL_MASK = 0, FVSRN_CHANNEL_NORMAL = 1, FVSRN_CHANNEL_DEPTH = 2, FVSRN_CHANNEL_COLOR = 3 } fvsrn_channel_mode;
+int fvsrn_extract_color(const float* d_raw8, int width, int height, int channel_mode, int use_tonemapping,
+                        float max_exposure, float* d_out4, void* stream);
+int fvsrn_extract_color_rgba8(const float* d_raw8, int width, int height, int channel_mode, int use_tonemapping,
+                              float max_exposure, unsigned int* d_out, void* stream);
+
 /* Kernel name + resources of the variant fvsrn_render / fvsrn_evaluate_points would launch for
  * this network (for profiles and bench): writes a 0-terminated string. */
 int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t cap);

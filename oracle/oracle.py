@@ -271,3 +271,43 @@ def camera_on_a_sphere(orientation: str, center, pitch: float, yaw: float, dista
     up = np.cross(right, front)
     up /= np.linalg.norm(up)
     return origin.astype(np.float32), right.astype(np.float32), up.astype(np.float32)
+
+
+# ---- IImageEvaluator::ExtractColor (renderer/iimage_evaluator.cpp:26-135, iimage_evaluator_cuda.cu:82-101,144-165) ----
+CHANNEL_MASK, CHANNEL_NORMAL, CHANNEL_DEPTH, CHANNEL_COLOR = range(4)
+
+
+def extract_color(raw: np.ndarray, channel_mode: int = CHANNEL_COLOR, use_tonemapping: bool = False,
+                  max_exposure: float = 1.0) -> np.ndarray:
+    """raw (8,H,W) fp32 -> (4,H,W) fp32, numpy restatement (test infrastructure)."""
+    raw = np.asarray(raw, np.float32)
+    f = np.float32
+    if channel_mode == CHANNEL_COLOR:
+        if not use_tonemapping:
+            return raw[:4].copy()
+        rgb = raw[:3] / f(max_exposure)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            rgb = (rgb * (f(2.51) * rgb + f(0.03))) / (rgb * (f(2.43) * rgb + f(0.59)) + f(0.14))
+            rgb = np.power(np.clip(rgb, 0, 1), f(1.0 / 2.4)).astype(np.float32)
+        return np.concatenate([rgb, raw[3:4]], axis=0)
+    if channel_mode == CHANNEL_DEPTH:
+        d = raw[7]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            mn, mx = d.min(), d.max()  # numpy, like torch, propagates NaN
+            scale, offset = f(1) / (mx - mn), -mn / (mx - mn)
+            v = d * scale + offset
+        return np.stack([v, v, v, np.ones_like(v)], axis=0).astype(np.float32)
+    if channel_mode == CHANNEL_MASK:
+        a = raw[3]
+        return np.stack([a, a, a, np.ones_like(a)], axis=0)
+    if channel_mode == CHANNEL_NORMAL:
+        return np.concatenate([raw[4:7] * f(0.5) + f(0.5), raw[3:4]], axis=0).astype(np.float32)
+    raise ValueError("unknown channel mode")
+
+
+def rgba_to_int(rgba: np.ndarray) -> np.ndarray:
+    """rgbaToInt (renderer_utils.cuh:48-57) on a (4,H,W) image: uint32 words 0xAABBGGRR."""
+    with np.errstate(invalid="ignore"):
+        q = np.clip(np.asarray(rgba, np.float32) * np.float32(255), 0, 255)
+        q = np.where(np.isnan(q), 0, q).astype(np.uint32)  # fminf(fmaxf(NaN, 0), 255) = 0 on the device
+    return (q[3] << 24) | (q[2] << 16) | (q[1] << 8) | q[0]

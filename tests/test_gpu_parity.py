@@ -368,3 +368,35 @@ def test_render_view_dependent_network(name):
     import torch
     with pytest.raises(capi.FvsrnError, match="direction"):
         net.evaluate(torch.rand(8, 3, device="cuda"))
+
+
+@pytest.mark.parametrize("mode", ["color", "color_tonemapped", "mask", "normal", "depth", "depth_full_coverage"])
+def test_extract_color_matches_restatement(mode):
+    """IImageEvaluator::ExtractColor through the C ABI (planar fp32 and packed RGBA8) against the numpy restatement
+    of iimage_evaluator.cpp:26-135, on a rendered image of a gradient-predicting network (all 8 channels populated)."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode="densitygrad", seed=3, box_min=(-0.5, -0.5, -0.5),
+                             fourier_std=0.4)
+    inside = mode == "depth_full_coverage"  # camera inside the box: every pixel has alpha > 0, so no NaN depth
+    kw = make_scene_kwargs(distance=0.2 if inside else 1.6, tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF, early_out=False)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    raw = capi.Scene(**kw).render(net, 72, 40)
+    if inside:
+        assert not bool(torch.isnan(raw[0, 7]).any())
+    ch = {"color": capi.CHANNEL_COLOR, "color_tonemapped": capi.CHANNEL_COLOR, "mask": capi.CHANNEL_MASK,
+          "normal": capi.CHANNEL_NORMAL, "depth": capi.CHANNEL_DEPTH, "depth_full_coverage": capi.CHANNEL_DEPTH}[mode]
+    tm = mode == "color_tonemapped"
+    exposure = 0.37
+    out = capi.extract_color(raw, ch, tm, exposure).cpu().numpy()[0]
+    packed = capi.extract_color(raw, ch, tm, exposure, rgba8=True).cpu().numpy().view(np.uint32)
+    ref = oracle.extract_color(raw.cpu().numpy()[0], ch, tm, exposure)
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    m = ~np.isnan(ref)
+    # fp32 arithmetic; powf / division differ in the last ulp.  Depth: d * scale + offset cancels (|offset| >> 1 when the
+    # depth range is narrow) and the device fuses the multiply-add
+    assert np.abs(out[m] - ref[m]).max() < (1e-3 if ch == capi.CHANNEL_DEPTH else 2e-6)
+    ref8 = oracle.rgba_to_int(ref)
+    diff = np.abs(((packed[None] >> np.array([0, 8, 16, 24], np.uint32)[:, None, None]) & 255).astype(np.int32) -
+                  ((ref8[None] >> np.array([0, 8, 16, 24], np.uint32)[:, None, None]) & 255).astype(np.int32))
+    assert diff.max() <= 1  # truncation to 8 bits of values that differ by an ulp

@@ -104,8 +104,15 @@ def test_load_from_json_builds_the_module_tree(tmp_path):
         ev.volume.current_network()
 
 
-def test_extract_color_channels_cpu():
-    raw = torch.rand(1, 8, 5, 7)
+def test_extract_color_rejects_host_tensors():
+    # the reference checks CHECK_CUDA(inputTensor) (iimage_evaluator.cpp:29); there is no CPU path here either
+    with pytest.raises(RuntimeError, match="GPU"):
+        pr.ImageEvaluatorSimple.Extract_color(torch.rand(1, 8, 5, 7), False, 1.0, pr.ImageEvaluatorSimple.ChannelMode.Color)
+
+
+@pytest.mark.gpu
+def test_extract_color_channels():
+    raw = torch.rand(2, 8, 5, 7, device="cuda")
     ch = pr.ImageEvaluatorSimple.ChannelMode
     c = pr.ImageEvaluatorSimple.Extract_color(raw, False, 1.0, ch.Color)
     assert torch.equal(c, raw[:, :4])
@@ -113,7 +120,7 @@ def test_extract_color_channels_cpu():
     assert torch.allclose(n[:, :3], raw[:, 4:7] * 0.5 + 0.5) and torch.equal(n[:, 3], raw[:, 3])
     m = pr.ImageEvaluatorSimple.Extract_color(raw, False, 1.0, ch.Mask)
     assert torch.equal(m[:, 0], raw[:, 3]) and bool((m[:, 3] == 1).all())
-    dpt = pr.ImageEvaluatorSimple.Extract_color(raw, False, 1.0, ch.Depth)
+    dpt = pr.ImageEvaluatorSimple.Extract_color(raw[:1], False, 1.0, ch.Depth)
     assert abs(float(dpt[:, 0].min())) < 1e-6 and abs(float(dpt[:, 0].max()) - 1) < 1e-6
     t = pr.ImageEvaluatorSimple.Extract_color(raw, True, 2.0, ch.Color)
     x = raw[:, :3] / 2.0
