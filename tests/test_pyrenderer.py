@@ -162,3 +162,40 @@ def test_render_network_sequence_matches_oracle():
     vn = util.golden_to_volnet(d, meta, box_min=meta["box_min"], box_size=meta["box_size"])
     ref = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos.cpu().numpy() * np.array(meta["box_size"], np.float32) + np.array(meta["box_min"], np.float32))
     assert np.abs(out.cpu().numpy() - ref).max() < 2e-3
+
+
+def test_protocol_png_writer(tmp_path):
+    sys.path.insert(0, os.path.join(util.ROOT, "tools"))
+    import render_protocol
+    img = (np.arange(6 * 5 * 4) % 256).astype(np.uint8).reshape(6, 5, 4)
+    path = str(tmp_path / "a.png")
+    render_protocol.write_png(path, img)
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n" and data[12:16] == b"IHDR"
+    import struct
+    import zlib
+    w, h, depth, ctype = struct.unpack(">IIBB", data[16:26])
+    assert (w, h, depth, ctype) == (5, 6, 8, 6)
+    i = data.index(b"IDAT")
+    n = struct.unpack(">I", data[i - 4:i])[0]
+    raw = zlib.decompress(data[i + 4:i + 4 + n])
+    rows = [raw[y * (1 + 5 * 4) + 1:(y + 1) * (1 + 5 * 4)] for y in range(6)]
+    assert b"".join(rows) == img.tobytes()
+
+
+@pytest.mark.gpu
+def test_reference_timing_protocol_runs(tmp_path):
+    """tools/render_protocol.py = eval_NetworkConfigsGrid.py:100-140 on the drop-in module: loads a .volnet, rotates the
+    camera, times render + extract_color, writes frames and statistics."""
+    sys.path.insert(0, os.path.join(util.ROOT, "tools"))
+    import render_protocol
+    vn = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode="density", seed=2, box_min=(-0.5, -0.5, -0.5))
+    path = str(tmp_path / "net.volnet")
+    open(path, "wb").write(volnet_io.save_volnet(vn))
+    out = str(tmp_path / "out")
+    args = render_protocol.argparse.Namespace(volnet=path, scene=None, out=out, frames=True, width=64, height=48, cameras=4,
+                                              stepsize=1 / 64, timestep=0.0, ensemble=0)
+    stats = render_protocol.run(args)
+    assert stats["num_cameras"] == 4 and stats["ms_mean"] > 0 and stats["num_parameters"] > 3000
+    assert sorted(os.listdir(out)) == ["frame000.png", "frame001.png", "frame002.png", "frame003.png", "stats.json"]
+    assert json.load(open(os.path.join(out, "stats.json")))["width"] == 64
