@@ -753,16 +753,19 @@ __device__ __forceinline__ float4_t srn_layers_kmajor(const NetParams& P, const 
     return out;
 }
 
-template <int CD, int ACT, int GRID, bool HAS_DIR, int NFILL, class Pre, class Fill>
+// MAYBE_NO_LAYERS: the network may consist of first + last layer only (possible without Fourier features)
+template <int CD, int ACT, int GRID, bool HAS_DIR, int NFILL, bool MAYBE_NO_LAYERS, class Pre, class Fill>
 __device__ __forceinline__ float4_t srn_layers(const NetParams& P, const char* lds, half8_t (&xb)[2][2 * mtiles(CD)], float px,
                                                float py, float pz, Pre&& pre, Fill&& fill) {
 #ifndef FVSRN_NO_PIPELINE
     // measured (r01): the pipelined order wins for Fourier-only networks; with a latent grid its extra registers
     // cost more occupancy than the schedule gains
     if constexpr (CD <= 4 && GRID == 0) {
-        if (P.numLayers > 0)  // wave-uniform; 0 = first + last layer only (networks without Fourier features)
-            return srn_layers_pipelined<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill);
-        return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill);
+        if constexpr (MAYBE_NO_LAYERS) {
+            if (P.numLayers == 0)  // wave-uniform
+                return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill);
+        }
+        return srn_layers_pipelined<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill);
     } else
 #endif
         return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill);
@@ -773,7 +776,7 @@ template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE>
 __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* lds, float px, float py, float pz,
                                                 float dx, float dy, float dz) {
     half8_t xb[2][2 * mtiles(CD)];
-    return srn_layers<CD, ACT, GRID, HAS_DIR, 0>(
+    return srn_layers<CD, ACT, GRID, HAS_DIR, 0, FMODE == FM_FIRST_LAYER>(
         P, lds, xb, px, py, pz, [&]() { fourier_fragments<CD, ACT, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, xb); }, [](int) {});
 }
 
@@ -784,7 +787,7 @@ __device__ __forceinline__ float4_t srn_forward_rotating(const NetParams& P, con
     constexpr int NP = 16 * mtiles(CD);  // rotation pieces: half of them cover the LDS latency of the first layer's reads,
     constexpr int NFILL = NP / 2;        // half sit behind MFMAs that have no conversion work of their own
     half8_t xb[2][2 * mtiles(CD)];
-    return srn_layers<CD, ACT, GRID, HAS_DIR, NFILL>(
+    return srn_layers<CD, ACT, GRID, HAS_DIR, NFILL, false>(
         P, lds, xb, px, py, pz,
         [&]() {
             feature_fragments<CD>(feat, xb);
