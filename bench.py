@@ -257,7 +257,14 @@ def main():
         scene = capi.Scene(**build_scene_kwargs(capi, yaw, runner.stepsize, args.early_out))
         full = scene.render(net, runner.W, runner.H)
         torch.cuda.synchronize()
-        frame_check = bool(torch.equal(torch.nan_to_num(full, nan=-1.0), torch.nan_to_num(gathered, nan=-1.0)))
+        # Same samples, but a rank's stripes are a small launch and may be rendered in depth segments (re-associated sums,
+        # other restart points of the feature rotation): compare within the image tolerance of the parity tests, depth
+        # (NaN where alpha == 0) only on pixels that are not within rounding of empty.
+        solid = (full[0, 3] > 1e-4) | (gathered[0, 3] > 1e-4)
+        frame_check = bool(
+            float((full[0, :7] - gathered[0, :7]).abs().max()) < 3e-3
+            and torch.equal(torch.isnan(full[0, 7])[solid], torch.isnan(gathered[0, 7])[solid])
+            and float((torch.nan_to_num(full[0, 7], nan=0.0) - torch.nan_to_num(gathered[0, 7], nan=0.0))[solid].abs().max()) < 3e-2)
         ok = torch.tensor([1 if frame_check else 0], device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         frame_check = bool(ok.item())
@@ -297,7 +304,7 @@ def main():
                          "kernel_ms_avg": 1e3 * kernel_s},
         }
         if frame_check is not None:
-            out["gathered_frame_equals_single_gpu_frame"] = frame_check
+            out["gathered_frame_matches_single_gpu_frame"] = frame_check
         if twin:
             out["twin"] = twin
         if not args.no_cpu_baseline and world == 1:

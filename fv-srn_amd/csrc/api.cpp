@@ -251,14 +251,14 @@ static BoxCenter P_boxCenter(const NetParams& P) {
 struct fvsrn_scene {
     fvsrn_scene_desc desc{};
     std::vector<float> tfTable;
-    DeviceBuffer dTf, dOrder, dCounters;
+    DeviceBuffer dTf, dOrder, dCounters, dPartial;
     unsigned launches = 0;  // parity selects which of the two tile counters a launch uses (the kernel zeroes the other)
     bool tfDirty = true;
     std::mutex mu;
     // cached launch order of the 8x8 pixel tiles
     struct OrderKey { int tilesX = -1, tilesY = -1, cx = 0, cy = 0, y0 = 0, stripeRows = 0, stripeRank = 0, stripeWorld = 0; } orderKey;
     std::vector<int> order;
-    ~fvsrn_scene() { dTf.release(); dOrder.release(); dCounters.release(); }
+    ~fvsrn_scene() { dTf.release(); dOrder.release(); dCounters.release(); dPartial.release(); }
 
     // Two work counters for the persistent render waves.  Launches of one scene must be ordered on one stream
     // (like everything else a scene owns: TF table, tile order).
@@ -753,13 +753,41 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const int tiles = tilesX * tilesY;
             const size_t lds = size_t(a.P.ldsBytes) + tfFloats * 4;
             const int wpb = wavesPerBlockFor(lds);
-            unsigned grid = unsigned((tiles + wpb - 1) / wpb);
-            // persistent waves: no more workgroups than the chip holds at once; the rest of the tiles is handed out by
-            // a device counter (kernels.hpp).  FVSRN_PERSISTENT=0: one tile per wave, hardware dispatch order.
+            const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds);
+            const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));  // workgroups the chip holds at once
+            // Depth segments (kernels.hpp): with fewer tiles than ~4x the resident waves (small images, the stripes of one
+            // rank of a multi-GPU frame) the longest tile dictates the launch time; cut the rays into K step ranges so that
+            // there are enough work units to balance, as long as a segment keeps >= ~48 steps (box diagonal / step size).
+            // Measured r01: 512^2 x 256: 79.8 -> see BASELINE.md.  FVSRN_SEGMENTS=k forces K (1 = off).
+            int K = 1;
+            {
+                const double waves = double(resident) * wpb;
+                const float* bs = a.P.boxSize;
+                const double maxSteps = std::sqrt(double(bs[0]) * bs[0] + double(bs[1]) * bs[1] + double(bs[2]) * bs[2]) / d.stepsize;
+                while (K < 8 && double(tiles) * K < 4.0 * waves && maxSteps / (2 * K) >= 48.0) K *= 2;
+                if (const char* e = std::getenv("FVSRN_SEGMENTS")) {
+                    const int k = std::atoi(e);
+                    if (k >= 1 && k <= 64) K = k;
+                }
+            }
+            S.resyncMask = kFourierResync - 1;
+            if (const char* e = std::getenv("FVSRN_FOURIER_RESYNC")) {  // developer knob: 1 = exact features at every step
+                const int k = std::atoi(e);
+                if (k >= 1 && k <= 4096 && (k & (k - 1)) == 0) S.resyncMask = k - 1;
+            }
+            S.segments = K;
+            S.partial = nullptr;
+            const size_t plane = size_t(width) * size_t(compact ? numLocalRows : height);
+            if (K > 1) {
+                scene->dPartial.ensure(size_t(K) * 8 * plane * sizeof(float));
+                S.partial = static_cast<float*>(scene->dPartial.ptr);
+            }
+            const long long units = (long long)tiles * K;
+            unsigned grid = unsigned((units + wpb - 1) / wpb);
+            // persistent waves: no more workgroups than the chip holds at once; the rest of the units is handed out by
+            // a device counter (kernels.hpp).  FVSRN_PERSISTENT=0: one unit per wave, hardware dispatch order.
             const char* pers = std::getenv("FVSRN_PERSISTENT");
             if (!pers || pers[0] != '0') {
-                const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds);
-                const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));
                 if (perCU > 0 && grid > resident) {
                     grid = resident;
                     if (!scene->tileCounters(s, &S.tileCounter, &S.tileCounterNext))
@@ -773,7 +801,8 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const char* ord = std::getenv("FVSRN_TILE_ORDER");  // "0" / "1" force, unset = heuristic
             const bool useOrder = ord ? ord[0] == '1' : (S.tileCounter == nullptr && (wpb > 1 || net->key.grid != 0));
             S.tileOrder = useOrder ? scene->tileOrder(S, P_boxCenter(a.P), tilesX, tilesY, s) : nullptr;
-            const hipError_t e = launch_render(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
+            hipError_t e = launch_render(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
+            if (e == hipSuccess && K > 1) e = launch_composite(S.partial, d_out8, K, plane, S, s);
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during rendering! ") + hipGetErrorString(e));
             return FVSRN_OK;
         } catch (const DeviceError& e) {

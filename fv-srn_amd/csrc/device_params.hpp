@@ -15,6 +15,7 @@ namespace fvsrn {
 //     next layer" is always readable, see srn_forward_pipelined)
 //   biases: fp32, natural channel order, 32*MT per C->C layer, 32*MT (first 8 rows used) for the last layer
 constexpr int kFragBytes = 1024;
+constexpr int kFourierResync = 64;  // default period of the exact re-derivation of rotated Fourier features (SceneParams::resyncMask)
 
 struct NetParams {
     const void* ldsImage;  // device pointer
@@ -66,6 +67,11 @@ struct SceneParams {
     // launch; null = every wave renders the slots {w, w + totalWaves, ...}
     int* tileCounter;
     int* tileCounterNext;
+    // depth segments (kernels.hpp): every ray is cut into `segments` consecutive step ranges rendered by different waves
+    // into `partial` ([segments][8][rows][width] raw accumulators), composited front to back by composite_kernel
+    int segments;
+    float* partial;
+    int resyncMask;  // feature rotation (srn_device.hpp): exact features every resyncMask + 1 steps (a power of two)
 };
 
 }  // namespace fvsrn

@@ -167,10 +167,22 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     const bool rgboNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
     // networks that predict the gradient (and, in the curvature modes, two curvature values the DVR path has no use for)
     const bool gradNet = P.outputMode >= FVSRN_OUT_DENSITY_GRADIENT && P.outputMode <= FVSRN_OUT_DENSITY_CURVATURE_DIRECT;
-    for (int slot = int(blockIdx.x) * wavesPerBlock + int(threadIdx.x >> 6); slot < numTiles;) {
+    // Depth segments: when a launch has fewer pixel tiles than a few times the wave slots of the chip (small images, one
+    // rank's stripes of a multi-GPU frame) the host cuts every ray into K consecutive step ranges; a work unit is (tile,
+    // segment), the partial results are composited front to back afterwards (blending is associative:
+    // C = C1 + (1 - A1) C2).  The sample positions t = tmin + i * stepsize are the same as without segments.
+#ifdef FVSRN_NO_SEGMENTS
+    constexpr int K = 1;
+#else
+    const int K = S.segments;
+#endif
+    const int numUnits = numTiles * K;
+    for (int slot = int(blockIdx.x) * wavesPerBlock + int(threadIdx.x >> 6); slot < numUnits;) {
+    const int tileSlot = K > 1 ? slot / K : slot;
+    const int seg = slot - tileSlot * K;
     // launch slot -> pixel tile: the host orders tiles by expected ray length (centre of the projected box first), so
     // the long tiles start first and the empty ones fill the tail of the launch
-    const int tile = S.tileOrder ? S.tileOrder[slot] : slot;
+    const int tile = S.tileOrder ? S.tileOrder[tileSlot] : tileSlot;
     const int tx = tile % tilesX, ty = tile / tilesX;
     const int x = tx * 8 + (lane & 7);
     const int lrow = ty * 8 + (lane >> 3);
@@ -199,6 +211,14 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     }
     tmin = fmaxf(tmin, 0.f);  // stepping_dvr.cuh:66-67 (tmax input of the image evaluator is FLT_MAX)
     if (!inImage) tmax = -1.f;  // padding lanes never become valid
+    // this unit's step range [i0, i1) of the ray (the last segment is open: it ends with t <= tmax like the unsegmented loop)
+    int i0 = 0, i1 = 0x7fffffff;
+    if (K > 1) {
+        const float span = tmax - tmin;
+        const int n = span >= 0.f ? int(span / S.stepsize) + 1 : 0;
+        i0 = (n * seg) / K;
+        if (seg + 1 < K) i1 = (n * (seg + 1)) / K;
+    }
 
     // position in unit-box coordinates as a function of t: p = pn0 + dn * t
     // (the reference evaluates ((o + d t) - boxMin) / boxSize, renderer_volume_tensorcores.cuh:746; same value up
@@ -219,8 +239,17 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     floatx16 feat[2][mtiles(CD)], dfeat[2][mtiles(CD)];
 
     for (int i = 0;; ++i) {
-        const float t = tmin + float(i) * S.stepsize;
-        const bool inRange = t <= tmax, notOpaque = ca < S.alphaEarlyOut;
+        float t;
+        bool inRange;
+        if (K > 1) {  // wave-uniform; kept as a branch so that the unsegmented loop does no per-lane index arithmetic
+            const int gi = i0 + i;
+            t = tmin + float(gi) * S.stepsize;
+            inRange = (t <= tmax) & (gi < i1);
+        } else {
+            t = tmin + float(i) * S.stepsize;
+            inRange = t <= tmax;
+        }
+        const bool notOpaque = ca < S.alphaEarlyOut;
         const bool valid = bool(int(inRange) & (int(!S.earlyOut) | int(notOpaque)));  // branch-free
         // wave mask straight from the two v_cmp results (scalar ops only)
         const unsigned long long validMask =
@@ -234,7 +263,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
         if constexpr (kRotate) {
             // Fourier features by rotation (fourier_advance): exact features every kFourierResync steps, the per-step
             // rotation once per ray
-            if ((i & (kFourierResync - 1)) == 0) {  // wave-uniform
+            if ((i & S.resyncMask) == 0) {  // wave-uniform
                 fourier_features<CD, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, feat);
                 if (i == 0)
                     fourier_features<CD, HAS_DIR, FM_COS, true>(P, lds, dnx * S.stepsize, dny * S.stepsize, dnz * S.stepsize, 0.f, 0.f, 0.f, dfeat);
@@ -284,7 +313,14 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
         }
     }
 
-    if (inImage) {  // renderer_image_evaluator_simple.cuh:100-124 with samples == 1
+    if (K > 1) {
+        if (inImage) {  // raw accumulators of this segment; composite_kernel finishes the pixel
+            const size_t plane = size_t(S.width) * (S.compact ? S.numLocalRows : S.height);
+            float* p = S.partial + size_t(seg) * 8 * plane + size_t(S.compact ? lrow : y) * S.width + x;
+            p[0] = cr; p[plane] = cg; p[2 * plane] = cb; p[3 * plane] = ca;
+            p[4 * plane] = nx; p[5 * plane] = ny; p[6 * plane] = nz; p[7 * plane] = depth;
+        }
+    } else if (inImage) {  // renderer_image_evaluator_simple.cuh:100-124 with samples == 1
         const size_t plane = size_t(S.width) * (S.compact ? S.numLocalRows : S.height);
         const size_t o = size_t(S.compact ? lrow : y) * S.width + x;
         out[o] = cr;

@@ -152,6 +152,39 @@ hipError_t launch_extract_color(const ExtractParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- composite of depth segments ---------------------------------------------------------------------------------------
+// Segment s holds sum_j w_j c_j with weights that start from alpha 0; the weight of its samples in the whole ray is
+// (1 - A_before) times that (Blending::eval, renderer_blending.cuh:35-51), so the segments blend like single samples.
+// Rows outside [y0, y1) of a non-compact image are not touched (the render kernel does not write them either).
+__global__ void composite_kernel(const float* __restrict__ partial, float* __restrict__ out, int K, unsigned long long plane, int width,
+                                 int rowBegin, int rowEnd) {
+    const unsigned long long first = (unsigned long long)rowBegin * width, last = (unsigned long long)rowEnd * width;
+    for (unsigned long long o = first + blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; o < last;
+         o += (unsigned long long)gridDim.x * blockDim.x) {
+        float c[3] = {0, 0, 0}, n[3] = {0, 0, 0}, depth = 0, A = 0;
+        for (int s = 0; s < K; ++s) {
+            const float* p = partial + (unsigned long long)s * 8 * plane + o;
+            const float w = 1.f - A;
+            c[0] += w * p[0]; c[1] += w * p[plane]; c[2] += w * p[2 * plane];
+            n[0] += w * p[4 * plane]; n[1] += w * p[5 * plane]; n[2] += w * p[6 * plane];
+            depth += w * p[7 * plane];
+            A += w * p[3 * plane];
+        }
+        out[o] = c[0]; out[plane + o] = c[1]; out[2 * plane + o] = c[2]; out[3 * plane + o] = A;
+        out[4 * plane + o] = n[0] * A; out[5 * plane + o] = n[1] * A; out[6 * plane + o] = n[2] * A;
+        out[7 * plane + o] = depth * A / A;
+    }
+}
+
+hipError_t launch_composite(const float* partial, float* out, int segments, unsigned long long plane, const SceneParams& S,
+                            hipStream_t s) {
+    const int rowBegin = S.compact ? 0 : S.y0, rowEnd = S.compact ? S.numLocalRows : S.y1;
+    const unsigned long long n = (unsigned long long)(rowEnd - rowBegin) * S.width;
+    const unsigned grid = unsigned(std::min<unsigned long long>((n + 255) / 256, 8192ull));
+    hipLaunchKernelGGL(composite_kernel, dim3(std::max(grid, 1u)), dim3(256), 0, s, partial, out, segments, plane, S.width, rowBegin, rowEnd);
+    return hipGetLastError();
+}
+
 hipError_t launch_grid_blend(const BlendParams& p, hipStream_t s) {
     const unsigned long long n = p.records * (unsigned long long)(2 * (p.Gt + p.Ge));
     if (n == 0) return hipSuccess;

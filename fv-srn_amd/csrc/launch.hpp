@@ -67,6 +67,11 @@ struct ExtractParams {
 };
 hipError_t launch_extract_color(const ExtractParams& p, hipStream_t s);
 
+// front-to-back composite of the depth segments of a render (kernels.hpp): partial [K][8][plane] raw accumulators ->
+// out [8][plane] in the layout of ImageEvaluatorSimpleKernel (normal and depth finished like :100-124)
+hipError_t launch_composite(const float* partial, float* out, int segments, unsigned long long plane, const SceneParams& S,
+                            hipStream_t s);
+
 bool kernel_info(const VariantKey& k, KernelInfo* info);
 hipError_t launch_eval(const VariantKey& k, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 hipError_t launch_render(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);

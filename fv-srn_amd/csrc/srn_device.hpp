@@ -489,7 +489,6 @@ __device__ __forceinline__ void feature_fragments(const floatx16 (&f)[2][mtiles(
 // feature instead of two v_cos_f32 (8.3 cycles each, profiles/r01/microbench_issue_model.md) plus the phase MFMA, the
 // position converts and lane exchanges.  Rounding errors grow linearly with the number of rotations (~6e-8 each); the
 // renderer re-derives the features from the positions every kFourierResync steps.
-constexpr int kFourierResync = 64;
 // piece c of the rotation, c in [0, 16 * mtiles(CD)): one register pair (<= 2 VALU instructions)
 template <int CD, bool HAS_DIR>
 __device__ __forceinline__ void fourier_advance_piece(floatx16 (&f)[2][mtiles(CD)], const floatx16 (&d)[2][mtiles(CD)], int c) {
