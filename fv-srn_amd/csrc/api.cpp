@@ -786,8 +786,13 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             unsigned grid = unsigned((units + wpb - 1) / wpb);
             // persistent waves: no more workgroups than the chip holds at once; the rest of the units is handed out by
             // a device counter (kernels.hpp).  FVSRN_PERSISTENT=0: one unit per wave, hardware dispatch order.
+            // A rank of a multi-GPU frame (stripeWorld > 1) launches one workgroup per work unit instead: its frame is
+            // gathered by an RCCL kernel on another stream while the next frame renders, and that kernel only gets onto the
+            // chip when render workgroups retire -- persistent waves would hold every wave slot until their launch ends and
+            // serialise gather and render (the hardware dispatcher hands out the units dynamically either way).
             const char* pers = std::getenv("FVSRN_PERSISTENT");
-            if (!pers || pers[0] != '0') {
+            const bool persistent = pers ? pers[0] != '0' : stripeWorld == 1;
+            if (persistent) {
                 if (perCU > 0 && grid > resident) {
                     grid = resident;
                     if (!scene->tileCounters(s, &S.tileCounter, &S.tileCounterNext))
