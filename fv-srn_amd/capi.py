@@ -48,7 +48,16 @@ class SceneDesc(C.Structure):
                 ("fov_y_radians", C.c_float), ("stepsize", C.c_float), ("density_min", C.c_float),
                 ("density_max", C.c_float), ("early_out", C.c_int), ("blend_mode", C.c_int), ("tf_kind", C.c_int),
                 ("tf_scale_absorption", C.c_float), ("tf_scale_emission", C.c_float),
-                ("tf_table", C.POINTER(C.c_float)), ("tf_rows", C.c_int)]
+                ("tf_table", C.POINTER(C.c_float)), ("tf_rows", C.c_int),
+                ("gradient_mode", C.c_int), ("finite_differences_stepsize", C.c_float),
+                ("brdf_enable_magnitude_scaling", C.c_int), ("brdf_enable_phong", C.c_int),
+                ("brdf_magnitude_scaling", C.c_float), ("brdf_ambient", C.c_float), ("brdf_specular", C.c_float),
+                ("brdf_magnitude_center", C.c_float), ("brdf_magnitude_radius", C.c_float),
+                ("brdf_specular_exponent", C.c_int), ("brdf_light_type", C.c_int), ("brdf_light", C.c_float * 3)]
+
+
+GRADIENT_OFF_OR_DIRECT, GRADIENT_FINITE_DIFFERENCES = 0, 1
+LIGHT_POINT, LIGHT_DIRECTIONAL = 0, 1
 
 
 # every symbol include/fvsrn.h declares: (name, restype, argtypes)
@@ -75,6 +84,8 @@ SYMBOLS = [
     ("fvsrn_network_get_layer", _I, [_VP, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _FP, _U16P, _U16P]),
     ("fvsrn_network_get_fourier", _I, [_VP, _U16P, _I, C.POINTER(_I)]),
     ("fvsrn_evaluate_points", _I, [_VP, _VP, _VP, _SZ, _VP, _I, _VP]),
+    ("fvsrn_scene_desc_size", _SZ, []),
+    ("fvsrn_network_info_size", _SZ, []),
     ("fvsrn_scene_create", _I, [C.POINTER(SceneDesc), C.POINTER(_VP)]),
     ("fvsrn_scene_update", _I, [_VP, C.POINTER(SceneDesc)]),
     ("fvsrn_scene_destroy", None, [_VP]),
@@ -109,6 +120,8 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        if l.fvsrn_scene_desc_size() != C.sizeof(SceneDesc) or l.fvsrn_network_info_size() != C.sizeof(NetworkInfo):
+            raise FvsrnError(-1, "capi.py struct mirrors do not match include/fvsrn.h of the loaded libfvsrn.so")
         _lib = l
     return _lib
 
@@ -277,7 +290,7 @@ class Scene:
 
     def _desc(self, *, eye, right, up, fov_y_radians, stepsize, density_min=0.0, density_max=1.0, early_out=True,
               blend_mode=BLEND_BEER_LAMBERT, tf_kind=TF_IDENTITY, tf_scale_absorption=1.0, tf_scale_emission=1.0,
-              tf_table=None) -> SceneDesc:
+              tf_table=None, gradient_mode=GRADIENT_OFF_OR_DIRECT, finite_differences_stepsize=0.0, brdf=None) -> SceneDesc:
         d = SceneDesc()
         d.cam_eye[:] = [float(v) for v in eye]
         d.cam_right[:] = [float(v) for v in right]
@@ -298,6 +311,20 @@ class Scene:
         else:
             d.tf_table = None
             d.tf_rows = 0
+        d.gradient_mode = gradient_mode
+        d.finite_differences_stepsize = finite_differences_stepsize
+        if brdf:  # BRDFLambert: dict(enable_phong=, enable_magnitude_scaling=, magnitude_scaling=, ambient=, specular=,
+            #                     magnitude_center=, magnitude_radius=, specular_exponent=, light_type=, light=(x,y,z))
+            d.brdf_enable_phong = int(brdf.get("enable_phong", False))
+            d.brdf_enable_magnitude_scaling = int(brdf.get("enable_magnitude_scaling", False))
+            d.brdf_magnitude_scaling = brdf.get("magnitude_scaling", 1.0)
+            d.brdf_ambient = brdf.get("ambient", 0.1)
+            d.brdf_specular = brdf.get("specular", 0.1)
+            d.brdf_magnitude_center = brdf.get("magnitude_center", 0.5)
+            d.brdf_magnitude_radius = brdf.get("magnitude_radius", 0.1)
+            d.brdf_specular_exponent = int(brdf.get("specular_exponent", 16))
+            d.brdf_light_type = int(brdf.get("light_type", LIGHT_POINT))
+            d.brdf_light[:] = [float(v) for v in brdf.get("light", (0.0, 0.0, 1.0))]
         return d
 
     def update(self, **kw):

@@ -113,11 +113,12 @@ struct fvsrn_network {
     // resident workgroups per CU of the render kernel for (blockDim, dynamic LDS); cached
     unsigned long long occKey = 0;
     int occBlocks = 0;
-    int renderBlocksPerCU(unsigned blockDim, size_t ldsBytes) {
-        const unsigned long long k = (static_cast<unsigned long long>(ldsBytes) << 16) | blockDim;
+    int renderBlocksPerCU(unsigned blockDim, size_t ldsBytes, bool shaded) {
+        const unsigned long long k = (static_cast<unsigned long long>(ldsBytes) << 17) | (blockDim << 1) | (shaded ? 1u : 0u);
         if (k != occKey) {
             int n = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kinfoScaled.renderFn, int(blockDim), ldsBytes) != hipSuccess) n = 0;
+            const void* fn = shaded ? kinfo.renderShadedFn : kinfoScaled.renderFn;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, int(blockDim), ldsBytes) != hipSuccess) n = 0;
             occBlocks = n;
             occKey = k;
         }
@@ -195,6 +196,7 @@ struct fvsrn_network {
         const size_t maxLds = packed.ldsImage.size() + 4096 + 256 * 6 * 4;
         HIP_CHECK(hipFuncSetAttribute(kinfo.evalFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         HIP_CHECK(hipFuncSetAttribute(kinfoScaled.renderFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
+        HIP_CHECK(hipFuncSetAttribute(kinfo.renderShadedFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         deviceValid = true;
     }
 
@@ -327,6 +329,8 @@ static int tfCols(int kind) {
 extern "C" {
 
 const char* fvsrn_last_error(void) { return g_lastError.c_str(); }
+size_t fvsrn_scene_desc_size(void) { return sizeof(fvsrn_scene_desc); }
+size_t fvsrn_network_info_size(void) { return sizeof(fvsrn_network_info); }
 const char* fvsrn_version(void) { return "fvsrn 0.1.0 gfx950"; }
 
 int fvsrn_device_count(void) {
@@ -613,6 +617,12 @@ static int sceneValidate(const fvsrn_scene_desc* d) {
     if (tfCols(d->tf_kind) * d->tf_rows > 1024)
         return fail(FVSRN_ERR_INVALID_ARGUMENT, "transfer function table too large (max 1024 floats)");
     if (!(d->stepsize > 0)) return fail(FVSRN_ERR_INVALID_ARGUMENT, "stepsize must be positive");
+    if (d->gradient_mode != FVSRN_GRADIENT_OFF_OR_DIRECT && d->gradient_mode != FVSRN_GRADIENT_FINITE_DIFFERENCES)
+        return fail(FVSRN_ERR_UNSUPPORTED, "gradient mode ADJOINT_METHOD is not in the compiled variant set");
+    if (d->gradient_mode == FVSRN_GRADIENT_FINITE_DIFFERENCES && !(d->finite_differences_stepsize > 0))
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "finite_differences_stepsize must be positive");
+    if (d->brdf_light_type != FVSRN_LIGHT_POINT && d->brdf_light_type != FVSRN_LIGHT_DIRECTIONAL)
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad brdf_light_type");
     if (d->blend_mode != FVSRN_BLEND_ALPHA && d->blend_mode != FVSRN_BLEND_BEER_LAMBERT)
         return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad blend mode");
     return FVSRN_OK;
@@ -721,7 +731,10 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             }
             RenderArgs a{};
             a.P = net->packed.params;
-            if (net->scaledImage) {  // ReLU network: image with activations scaled into [0,1] (pack.cpp)
+            a.shaded = d.gradient_mode == FVSRN_GRADIENT_FINITE_DIFFERENCES || d.brdf_enable_phong || d.brdf_enable_magnitude_scaling;
+            // finite differences also sample up to a step outside the box, where the [0,1] bound of the scaled image does
+            // not hold: the shaded renderer takes the plain image
+            if (net->scaledImage && !a.shaded) {  // ReLU network: image with activations scaled into [0,1] (pack.cpp)
                 a.P.ldsImage = net->scaledImage;
                 a.P.reluClamp = 1;
             }
@@ -739,6 +752,15 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             S.divDensityRange = 1.0f / (d.density_max - d.density_min);
             S.earlyOut = d.early_out;
             S.blendMode = d.blend_mode;
+            S.gradientMode = d.gradient_mode;
+            S.fdStep = d.finite_differences_stepsize;
+            S.brdfMagnitudeScaling = d.brdf_enable_magnitude_scaling;
+            S.brdfPhong = d.brdf_enable_phong;
+            S.brdfLightType = d.brdf_light_type;
+            S.brdfSpecularExponent = d.brdf_specular_exponent;
+            S.brdfMagScale = d.brdf_magnitude_scaling; S.brdfAmbient = d.brdf_ambient; S.brdfSpecular = d.brdf_specular;
+            S.brdfMagCenter = d.brdf_magnitude_center; S.brdfMagRadius = d.brdf_magnitude_radius;
+            for (int i = 0; i < 3; ++i) S.brdfLight[i] = d.brdf_light[i];
             S.tfKind = d.tf_kind;
             S.tfRows = d.tf_rows;
             S.tfScaleAbsorption = d.tf_scale_absorption;
@@ -753,7 +775,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const int tiles = tilesX * tilesY;
             const size_t lds = size_t(a.P.ldsBytes) + tfFloats * 4;
             const int wpb = wavesPerBlockFor(lds);
-            const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds);
+            const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded);
             const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));  // workgroups the chip holds at once
             // Depth segments (kernels.hpp): with fewer tiles than ~4x the resident waves (small images, the stripes of one
             // rank of a multi-GPU frame) the longest tile dictates the launch time; cut the rays into K step ranges so that
@@ -806,7 +828,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const char* ord = std::getenv("FVSRN_TILE_ORDER");  // "0" / "1" force, unset = heuristic
             const bool useOrder = ord ? ord[0] == '1' : (S.tileCounter == nullptr && (wpb > 1 || net->key.grid != 0));
             S.tileOrder = useOrder ? scene->tileOrder(S, P_boxCenter(a.P), tilesX, tilesY, s) : nullptr;
-            hipError_t e = launch_render(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
+            hipError_t e = launch_render(a.shaded ? net->key : net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
             if (e == hipSuccess && K > 1) e = launch_composite(S.partial, d_out8, K, plane, S, s);
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during rendering! ") + hipGetErrorString(e));
             return FVSRN_OK;

@@ -53,6 +53,13 @@ struct SceneParams {
     // DVR (renderer_ray_evaluation_stepping_dvr.cuh:22-30)
     float stepsize, alphaEarlyOut, densityMin, divDensityRange;
     int earlyOut, blendMode;
+    // normals: 0 = from the network if it predicts them, 1 = central differences (6 extra network evaluations)
+    int gradientMode;
+    float fdStep;  // world units
+    // BRDFLambert (renderer_brdf_lambert.cuh:19-103)
+    int brdfMagnitudeScaling, brdfPhong, brdfLightType, brdfSpecularExponent;
+    float brdfMagScale, brdfAmbient, brdfSpecular, brdfMagCenter, brdfMagRadius;
+    float brdfLight[3];
     // TF
     int tfKind, tfRows;
     float tfScaleAbsorption, tfScaleEmission;

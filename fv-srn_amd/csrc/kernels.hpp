@@ -149,7 +149,9 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // depend on the grouping because blending is guarded by isValid).  Stepping is wave-synchronous like
 // the reference's __any_sync loop: all 64 lanes evaluate the network until no lane is valid.
 // ------------------------------------------------------------------------------------------------
-template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE>
+// SHADED: finite-difference normals and the BRDF (magnitude scaling, Phong).  A separate kernel (render_shaded_kernel): the
+// extra network evaluation inside the step loop needs so many registers that it would cost the plain renderer a wave.
+template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, bool SHADED>
 __device__ __forceinline__ void render_body(const NetParams& P, const SceneParams& S, const char* lds, const float* tfLds,
                                             float* __restrict__ out, unsigned long long* __restrict__ stats) {
     const int lane = lane_id();
@@ -234,7 +236,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
 #ifdef FVSRN_NO_ROTATE
     constexpr bool kRotate = false;
 #else
-    constexpr bool kRotate = CD == 2 && GRID == 0 && FMODE != FM_FIRST_LAYER;
+    constexpr bool kRotate = CD == 2 && GRID == 0 && FMODE != FM_FIRST_LAYER && !SHADED;
 #endif
     floatx16 feat[2][mtiles(CD)], dfeat[2][mtiles(CD)];
 
@@ -291,20 +293,69 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             const float value = sigmoidDensity ? sigmoid_f(o[0]) : o[0];
             const float density2 = (value - S.densityMin) * S.divDensityRange;
             const bool requireNormal = valid && (value >= S.densityMin);
-            if (gradNet) {
+            if (SHADED && S.gradientMode == FVSRN_GRADIENT_FINITE_DIFFERENCES) {
+                // evalNormal, GRADIENT_MODE_FINITE_DIFFERENCES (renderer_volume_tensorcores.cuh:1185-1196): central
+                // differences of valueNoClamping with a world-space step, evaluated by the whole wave if ANY lane needs a
+                // normal (stepping_dvr.cuh:122-128); takes precedence over gradients the network predicts
+                if (__builtin_amdgcn_ballot_w64(requireNormal) != 0) {
+                    const float h = S.fdStep;
+                    const float hx = h * P.invBoxSize[0], hy = h * P.invBoxSize[1], hz = h * P.invBoxSize[2];
+                    float v[6];
+#pragma unroll 1
+                    for (int k = 0; k < 6; ++k) {
+                        const float sgn = (k & 1) ? -1.f : 1.f;
+                        const int axis = k >> 1;
+                        const float4_t ok = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE>(
+                            P, lds, px + (axis == 0 ? sgn * hx : 0.f), py + (axis == 1 ? sgn * hy : 0.f), pz + (axis == 2 ? sgn * hz : 0.f), dx, dy, dz);
+                        v[k] = sigmoidDensity ? sigmoid_f(ok[0]) : ok[0];
+                    }
+                    const float inv2h = 1.0f / (2.0f * h);
+                    gx = (v[0] - v[1]) * inv2h; gy = (v[2] - v[3]) * inv2h; gz = (v[4] - v[5]) * inv2h;
+                }
+            } else if (gradNet) {
                 gx = o[1]; gy = o[2]; gz = o[3];
                 if (P.outputMode == FVSRN_OUT_DENSITY_GRADIENT_CUBIC) { gx = gx * gx * gx; gy = gy * gy * gy; gz = gz * gz * gz; }
             }
             if (requireNormal) color = tf_eval(S, tfLds, density2);
         }
-        if (color[3] > 0.f && valid) {  // BRDF Lambert without Phong / magnitude scaling passes through
+        if (SHADED && color[3] > 0.f && (S.brdfMagnitudeScaling | S.brdfPhong)) {
+            // BRDFLambert::eval (renderer_brdf_lambert.cuh:56-103) on the un-normalised gradient; "gradientNorm" is the
+            // reference's rsqrt(|g|^2)
+            const float g2 = gx * gx + gy * gy + gz * gz;
+            if (S.brdfMagnitudeScaling) color[3] *= 1.f - __expf(-S.brdfMagScale * g2);
+            if (S.brdfPhong) {
+                const float gradientNorm = rsqrtf(g2);
+                float nX = gx, nY = gy, nZ = gz;
+                if (g2 >= 1e-8f) { nX *= gradientNorm; nY *= gradientNorm; nZ *= gradientNorm; }  // safeNormalize
+                float lx, ly, lz;
+                if (S.brdfLightType == FVSRN_LIGHT_DIRECTIONAL) { lx = -S.brdfLight[0]; ly = -S.brdfLight[1]; lz = -S.brdfLight[2]; }
+                else {  // point light: towards the light from the world position of the sample
+                    lx = S.brdfLight[0] - (ox + dx * t); ly = S.brdfLight[1] - (oy + dy * t); lz = S.brdfLight[2] - (oz + dz * t);
+                }
+                const float il = rsqrtf(lx * lx + ly * ly + lz * lz);
+                lx *= il; ly *= il; lz *= il;
+                const float lo = S.brdfMagCenter - S.brdfMagRadius, hi = S.brdfMagCenter + S.brdfMagRadius;
+                const float ys = fminf(fmaxf((gradientNorm - lo) / (hi - lo), 0.f), 1.f);
+                const float phongStrength = ys * ys * (3.f - 2.f * ys);                       // smoothstep
+                const float ambientStrength = 1.f + phongStrength * (S.brdfAmbient - 1.f);    // lerp(1, ambient, s)
+                const float ndl = fabsf(nX * lx + nY * ly + nZ * lz);
+                // reflect(lightDirection, -normal) = l - 2 (-n) dot(-n, l) = l - 2 n dot(n, l)
+                const float nl = nX * lx + nY * ly + nZ * lz;
+                const float rx = lx - 2.f * nX * nl, ry = ly - 2.f * nY * nl, rz = lz - 2.f * nZ * nl;
+                const float e = float(S.brdfSpecularExponent);
+                const float spec = (e + 2.f) * 0.159155f * powf(fmaxf(0.f, dx * rx + dy * ry + dz * rz), e);
+                for (int c = 0; c < 3; ++c)
+                    color[c] = ambientStrength * color[c] + (1.f - ambientStrength) * (ndl * color[c] + S.brdfSpecular * spec);
+            }
+        }
+        if (color[3] > 0.f && valid) {
             // Blending::eval (renderer_blending.cuh:35-51)
             const float a = S.blendMode == FVSRN_BLEND_BEER_LAMBERT ? 1.f - __expf(-color[3]) : fminf(1.f, color[3]);
             const float w = (1.f - ca) * a;
             cr += w * color[0]; cg += w * color[1]; cb += w * color[2];
             depth += w * t;
             ca += w;
-            if (gradNet) {  // wave-uniform: only networks that predict gradients carry a normal
+            if (gradNet || (SHADED && S.gradientMode == FVSRN_GRADIENT_FINITE_DIFFERENCES)) {  // wave-uniform: there is a normal
                 // safeNormalize (helper_math.cuh:2443-2448)
                 const float l2 = gx * gx + gy * gy + gz * gz;
                 if (l2 >= 1e-8f) { const float il = rsqrtf(l2); gx *= il; gy *= il; gz *= il; }
@@ -346,9 +397,9 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     }
 }
 
-template <int CD, int ACT, int GRID, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
-                                                               unsigned long long* __restrict__ stats) {
+template <int CD, int ACT, int GRID, bool HAS_DIR, bool SHADED>
+__device__ __forceinline__ void render_entry(const NetParams& P, const SceneParams& S, float* __restrict__ out,
+                                             unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     load_network_to_lds(P, lds);
     // TF table behind the network image
@@ -359,10 +410,23 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void r
         __syncthreads();
     }
     if constexpr (GRID == 0) {
-        if (P.noFourier) return render_body<CD, ACT, GRID, HAS_DIR, FM_FIRST_LAYER>(P, S, lds, tfLds, out, stats);
+        if (P.noFourier) return render_body<CD, ACT, GRID, HAS_DIR, FM_FIRST_LAYER, SHADED>(P, S, lds, tfLds, out, stats);
     }
-    if (P.fourierNeedsFract) render_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS>(P, S, lds, tfLds, out, stats);
-    else render_body<CD, ACT, GRID, HAS_DIR, FM_COS>(P, S, lds, tfLds, out, stats);
+    if (P.fourierNeedsFract) render_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS, SHADED>(P, S, lds, tfLds, out, stats);
+    else render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED>(P, S, lds, tfLds, out, stats);
+}
+
+template <int CD, int ACT, int GRID, bool HAS_DIR>
+__global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+                                                               unsigned long long* __restrict__ stats) {
+    render_entry<CD, ACT, GRID, HAS_DIR, false>(P, S, out, stats);
+}
+
+// finite-difference normals / shading BRDF (SceneParams::gradientMode, brdf*): 7 network evaluations per sample
+template <int CD, int ACT, int GRID, bool HAS_DIR>
+__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : 2)) void render_shaded_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+                                                               unsigned long long* __restrict__ stats) {
+    render_entry<CD, ACT, GRID, HAS_DIR, true>(P, S, out, stats);
 }
 
 }  // namespace fvsrn

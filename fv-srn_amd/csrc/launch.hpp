@@ -22,6 +22,7 @@ struct RenderArgs {
     SceneParams S;
     float* out;
     unsigned long long* stats;
+    bool shaded;  // render_shaded_kernel: finite-difference normals / shading BRDF
 };
 struct VariantKey {
     int CD;    // hidden channels / 16
@@ -32,14 +33,20 @@ struct VariantKey {
 struct KernelInfo {
     const void* evalFn = nullptr;
     const void* renderFn = nullptr;
+    const void* renderShadedFn = nullptr;
     const char* evalName = "";
     const char* renderName = "";
 };
 
-// implemented per CD in kernels_cd*.hip; returns false if the variant is not compiled in
+// implemented per CD in kernels_cd*_eval.hip; returns false if the variant is not compiled in
 template <int CD> bool kernel_info_cd(const VariantKey& k, KernelInfo* info);
 template <int CD> hipError_t launch_eval_cd(const VariantKey& k, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 template <int CD> hipError_t launch_render_cd(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
+// the render kernels live in their own translation units (kernels_cd*_render.hip / _shaded.hip)
+template <int CD> const void* render_fn_cd(const VariantKey& k);
+template <int CD> const void* render_shaded_fn_cd(const VariantKey& k);
+template <int CD> hipError_t launch_render_plain_cd(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
+template <int CD> hipError_t launch_render_shaded_cd(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 
 // decode + A/B time blend of the resident latent key frames into the fp16 working grid (pack.cpp, packLatentGrid)
 struct BlendParams {

@@ -396,8 +396,18 @@ struct TransferFunctionGaussian : TableTF { TransferFunctionGaussian() : TableTF
 struct TransferFunctionPiecewise : TableTF { TransferFunctionPiecewise() : TableTF(FVSRN_TF_PIECEWISE, 5) {} };
 struct TransferFunctionTexture : TableTF { TransferFunctionTexture() : TableTF(FVSRN_TF_TEXTURE, 4) {} };
 
-struct BRDFLambert {  // renderer/brdf.cpp:208-225: only the pass-through configuration is on the compiled path
+struct BRDFLambert {  // renderer/brdf.cpp:208-225 (JSON), :413-508 (constant block, light follows camera)
     bool enableMagnitudeScaling = false, enablePhong = false;
+    std::shared_ptr<Parameter<double>> magnitudeScaling = std::make_shared<Parameter<double>>(Parameter<double>{1.0});
+    std::shared_ptr<Parameter<double>> ambient = std::make_shared<Parameter<double>>(Parameter<double>{0.1});
+    std::shared_ptr<Parameter<double>> specular = std::make_shared<Parameter<double>>(Parameter<double>{0.1});
+    std::shared_ptr<Parameter<double>> magnitudeCenter = std::make_shared<Parameter<double>>(Parameter<double>{0.5});
+    std::shared_ptr<Parameter<double>> magnitudeRadius = std::make_shared<Parameter<double>>(Parameter<double>{0.1});
+    std::shared_ptr<Parameter<int>> specularExponent = std::make_shared<Parameter<int>>(Parameter<int>{16});
+    bool lightFollowsCamera = true;
+    int lightType = FVSRN_LIGHT_DIRECTIONAL;
+    std::shared_ptr<Parameter<double3>> lightPosition = std::make_shared<Parameter<double3>>();
+    std::shared_ptr<Parameter<double3>> lightDirection = std::make_shared<Parameter<double3>>();
 };
 
 struct Blending {
@@ -490,8 +500,7 @@ struct ImageEvaluatorSimple {
         if (!dvr) raise("ImageEvaluatorSimple.ray_evaluator must be a RayEvaluationSteppingDvr");
         if (!camera) raise("no camera selected");
         if (doublePrecision) raise("double precision rendering is not supported by the SRN path");
-        if (dvr->brdf && (dvr->brdf->enablePhong || dvr->brdf->enableMagnitudeScaling))
-            raise("BRDFLambert with Phong shading / magnitude scaling is not in the compiled variant set");
+        if (vol->gradientMode == ADJOINT_METHOD) raise("gradient mode ADJOINT_METHOD is not in the compiled variant set");
         camera->aspectRatio = double(width) / height;
         fvsrn_scene_desc d{};
         std::vector<float> table;
@@ -511,6 +520,28 @@ struct ImageEvaluatorSimple {
             dvr->tf->fill(d, table);
         }
         d.tf_table = table.empty() ? nullptr : table.data();
+        d.gradient_mode = vol->gradientMode == FINITE_DIFFERENCES ? FVSRN_GRADIENT_FINITE_DIFFERENCES : FVSRN_GRADIENT_OFF_OR_DIRECT;
+        d.finite_differences_stepsize = float(vol->finiteDifferencesStepsize);
+        if (dvr->brdf) {  // BRDFLambert::fillConstantMemory, brdf.cpp:413-448
+            BRDFLambert& b = *dvr->brdf;
+            if (b.lightFollowsCamera) {  // updateLightFromCamera :490-508: camera origin / front = cross(up, right)
+                const float* e = d.cam_eye; const float* r = d.cam_right; const float* u = d.cam_up;
+                b.lightPosition->value = double3{e[0], e[1], e[2]};
+                b.lightDirection->value = double3{double(u[1]) * r[2] - double(u[2]) * r[1], double(u[2]) * r[0] - double(u[0]) * r[2],
+                                                  double(u[0]) * r[1] - double(u[1]) * r[0]};
+            }
+            d.brdf_enable_magnitude_scaling = b.enableMagnitudeScaling;
+            d.brdf_enable_phong = b.enablePhong;
+            d.brdf_magnitude_scaling = float(b.magnitudeScaling->value);
+            d.brdf_ambient = float(b.ambient->value);
+            d.brdf_specular = float(b.specular->value);
+            d.brdf_magnitude_center = float(b.magnitudeCenter->value);
+            d.brdf_magnitude_radius = float(b.magnitudeRadius->value);
+            d.brdf_specular_exponent = b.specularExponent->value;
+            d.brdf_light_type = b.lightType;
+            const double3 l = b.lightType == FVSRN_LIGHT_POINT ? b.lightPosition->value : b.lightDirection->value;
+            d.brdf_light[0] = float(l.x); d.brdf_light[1] = float(l.y); d.brdf_light[2] = float(l.z);
+        }
         if (!scene) check(fvsrn_scene_create(&d, &scene));
         else check(fvsrn_scene_update(scene, &d));
         torch::Tensor out = torch::empty({1, 8, height, width}, torch::TensorOptions().dtype(torch::kFloat).device(torch::kCUDA));
@@ -611,8 +642,27 @@ std::shared_ptr<ImageEvaluatorSimple> loadFromJson(const std::string& filename) 
         }
         if (root.contains("brdf") && root["brdf"].cast<py::dict>().contains("Lambert")) {
             py::dict jl = jsub(root, "brdf", "Lambert");
-            dvr->brdf->enablePhong = jget<bool>(jl, "enablePhong", false);
-            dvr->brdf->enableMagnitudeScaling = jget<bool>(jl, "enableMagnitudeScaling", false);
+            BRDFLambert& b = *dvr->brdf;  // BRDFLambert::load, brdf.cpp:208-225
+            b.enableMagnitudeScaling = jget<bool>(jl, "enableMagnitudeScaling", false);
+            b.magnitudeScaling->value = jget<double>(jl, "magnitudeScaling", 1.0);
+            b.enablePhong = jget<bool>(jl, "enablePhong", false);
+            b.ambient->value = jget<double>(jl, "ambient", 1.0);
+            b.specular->value = jget<double>(jl, "specular", 1.0);
+            b.magnitudeCenter->value = jget<double>(jl, "magnitudeCenter", 1.0);
+            b.magnitudeRadius->value = jget<double>(jl, "magnitudeRadius", 1.0);
+            b.specularExponent->value = jget<int>(jl, "specularExponent", 1);
+            b.lightFollowsCamera = jget<bool>(jl, "lightFollowsCamera", true);
+            b.lightType = jget<std::string>(jl, "lightType", "") == "Point" ? FVSRN_LIGHT_POINT : FVSRN_LIGHT_DIRECTIONAL;
+            auto vec3 = [&](const char* key) {
+                double3 v{0, 0, 0};
+                if (jl.contains(key)) {
+                    py::list a = jl[key].cast<py::list>();
+                    if (py::len(a) == 3) v = double3{a[0].cast<double>(), a[1].cast<double>(), a[2].cast<double>()};
+                }
+                return v;
+            };
+            b.lightPosition->value = vec3("lightPosition");
+            b.lightDirection->value = vec3("lightDirection");
         }
         const std::string tfSel = jget<std::string>(jr, "selectedTF", "Identity");
         py::dict jt = jsub(root, "tf", tfSel);
@@ -666,6 +716,8 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def_readwrite("x", &V2<double>::x).def_readwrite("y", &V2<double>::y);
     bindParameter<double3>(m, "Parameter_double3");
     bindParameter<V2<double>>(m, "Parameter_double2");
+    bindParameter<double>(m, "Parameter_double");
+    bindParameter<int>(m, "Parameter_int");
 
     py::class_<GPUTimer>(m, "GPUTimer").def(py::init<>()).def("start", &GPUTimer::start).def("stop", &GPUTimer::stop)
         .def("elapsed_milliseconds", &GPUTimer::elapsed);
@@ -805,7 +857,7 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def_readwrite("only_shared_memory", &VolumeInterpolationNetwork::onlySharedMemory)
         .def_property("gradient_mode", [](VolumeInterpolationNetwork& v) { return v.gradientMode; },
                       [](VolumeInterpolationNetwork& v, GradientMode mode) {
-                          if (mode != OFF_OR_DIRECT) raise("gradient modes FINITE_DIFFERENCES / ADJOINT_METHOD are not part of this build");
+                          if (mode == ADJOINT_METHOD) raise("gradient mode ADJOINT_METHOD is not part of this build");
                           v.gradientMode = mode;
                       })
         .def_readwrite("finite_differences_stepsize", &VolumeInterpolationNetwork::finiteDifferencesStepsize)
@@ -825,10 +877,21 @@ PYBIND11_MODULE(pyrenderer, m) {
     py::class_<TransferFunctionTexture, ITransferFunction, std::shared_ptr<TransferFunctionTexture>>(m, "TransferFunctionTexture")
         .def(py::init<>())
         .def_property("tensor", [](TransferFunctionTexture& t) { return t.tensor; }, &TransferFunctionTexture::setTensor);
-    py::class_<BRDFLambert, std::shared_ptr<BRDFLambert>>(m, "BRDFLambert")
-        .def(py::init<>())
+    py::class_<BRDFLambert, std::shared_ptr<BRDFLambert>> bc(m, "BRDFLambert");  // brdf.cpp:256-273
+    py::enum_<fvsrn_light_type>(bc, "LightType").value("Point", FVSRN_LIGHT_POINT).value("Directional", FVSRN_LIGHT_DIRECTIONAL).export_values();
+    bc.def(py::init<>())
         .def_readwrite("enable_phong", &BRDFLambert::enablePhong)
-        .def_readwrite("enable_magnitude_scaling", &BRDFLambert::enableMagnitudeScaling);
+        .def_readwrite("enable_magnitude_scaling", &BRDFLambert::enableMagnitudeScaling)
+        .def_readonly("magnitude_scaling", &BRDFLambert::magnitudeScaling)
+        .def_readonly("ambient", &BRDFLambert::ambient)
+        .def_readonly("specular", &BRDFLambert::specular)
+        .def_readonly("magnitude_center", &BRDFLambert::magnitudeCenter)
+        .def_readonly("magnitude_radius", &BRDFLambert::magnitudeRadius)
+        .def_readonly("specular_exponent", &BRDFLambert::specularExponent)
+        .def_readwrite("light_follows_camera", &BRDFLambert::lightFollowsCamera)
+        .def_property("light_type", [](BRDFLambert& b) { return fvsrn_light_type(b.lightType); }, [](BRDFLambert& b, fvsrn_light_type t) { b.lightType = t; })
+        .def_readonly("light_position", &BRDFLambert::lightPosition)
+        .def_readonly("light_direction", &BRDFLambert::lightDirection);
     py::class_<Blending, std::shared_ptr<Blending>> bl(m, "Blending");
     py::enum_<fvsrn_blend_mode>(bl, "BlendMode").value("Alpha", FVSRN_BLEND_ALPHA).value("BeerLambert", FVSRN_BLEND_BEER_LAMBERT).export_values();
     bl.def(py::init<>())

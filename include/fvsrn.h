@@ -154,7 +154,7 @@ int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const fl
 
 /* ----------------------------------------------------------------------------------------
  * scene = ImageEvaluatorSimple + CameraOnASphere(->reference frame) + RayEvaluationSteppingDvr
- *         + TF + BRDFLambert(pass-through) + Blending, as ONE POD
+ *         + TF + BRDFLambert + Blending, as ONE POD
  *   renderer/image_evaluator_simple.cpp:198-361, renderer/camera.cpp:458-551,
  *   renderer/ray_evaluation_stepping.cpp:535-623, renderer/transfer_function*.cpp, blending.cpp
  * -------------------------------------------------------------------------------------- */
@@ -173,8 +173,26 @@ typedef struct {
     float tf_scale_absorption, tf_scale_emission; /* Identity */
     const float* tf_table; /* host pointer, (tf_rows, cols(kind)) row-major; copied */
     int tf_rows;
+    /* VolumeInterpolationNetwork gradient mode (renderer_volume_tensorcores.cuh:1166-1201, GRADIENT_MODE):
+     * FVSRN_GRADIENT_OFF_OR_DIRECT: normals only from networks that predict them; FVSRN_GRADIENT_FINITE_DIFFERENCES:
+     * central differences of the (un-clamped) network value, 6 extra evaluations per sample, world step
+     * finite_differences_stepsize.  (ADJOINT_METHOD is not built.) */
+    int gradient_mode;
+    float finite_differences_stepsize;
+    /* BRDFLambert (renderer/renderer_brdf_lambert.cuh:56-103, host renderer/brdf.cpp:413-508); all zero = pass-through */
+    int brdf_enable_magnitude_scaling, brdf_enable_phong;
+    float brdf_magnitude_scaling, brdf_ambient, brdf_specular, brdf_magnitude_center, brdf_magnitude_radius;
+    int brdf_specular_exponent;
+    int brdf_light_type;        /* fvsrn_light_type */
+    float brdf_light[3];        /* light position (POINT) or direction (DIRECTIONAL); "light follows camera" is the
+                                   caller's job: camera origin / front (brdf.cpp:490-508) */
 } fvsrn_scene_desc;
+typedef enum { FVSRN_GRADIENT_OFF_OR_DIRECT = 0, FVSRN_GRADIENT_FINITE_DIFFERENCES = 1 } fvsrn_gradient_mode;
+typedef enum { FVSRN_LIGHT_POINT = 0, FVSRN_LIGHT_DIRECTIONAL = 1 } fvsrn_light_type;
 
+/* sizeof(fvsrn_scene_desc) / sizeof(fvsrn_network_info) of the library: lets an FFI binding verify its struct mirrors */
+size_t fvsrn_scene_desc_size(void);
+size_t fvsrn_network_info_size(void);
 int fvsrn_scene_create(const fvsrn_scene_desc* desc, fvsrn_scene** out);
 int fvsrn_scene_update(fvsrn_scene* scene, const fvsrn_scene_desc* desc);
 void fvsrn_scene_destroy(fvsrn_scene* scene);

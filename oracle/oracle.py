@@ -44,7 +44,12 @@ class _OracleScene(C.Structure):
     _fields_ = [("eye", C.c_float * 3), ("right", C.c_float * 3), ("up", C.c_float * 3), ("fovY", C.c_float),
                 ("stepsize", C.c_float), ("densityMin", C.c_float), ("densityMax", C.c_float),
                 ("earlyOut", C.c_int), ("blendMode", C.c_int), ("tfKind", C.c_int), ("tfRows", C.c_int),
-                ("tfScaleAbsorption", C.c_float), ("tfScaleEmission", C.c_float), ("tfTable", _FP)]
+                ("tfScaleAbsorption", C.c_float), ("tfScaleEmission", C.c_float), ("tfTable", _FP),
+                ("gradientMode", C.c_int), ("fdStep", C.c_float),
+                ("brdfMagnitudeScaling", C.c_int), ("brdfPhong", C.c_int), ("brdfLightType", C.c_int),
+                ("brdfSpecularExponent", C.c_int), ("brdfMagScale", C.c_float), ("brdfAmbient", C.c_float),
+                ("brdfSpecular", C.c_float), ("brdfMagCenter", C.c_float), ("brdfMagRadius", C.c_float),
+                ("brdfLight", C.c_float * 3)]
 
 
 _lib = None
@@ -217,7 +222,7 @@ class OracleNetwork:
 class OracleScene:
     def __init__(self, *, eye, right, up, fov_y_radians, stepsize, density_min=0.0, density_max=1.0, early_out=True,
                  blend_mode=BLEND_BEER_LAMBERT, tf_kind=TF_IDENTITY, tf_scale_absorption=1.0, tf_scale_emission=1.0,
-                 tf_table=None):
+                 tf_table=None, gradient_mode=0, finite_differences_stepsize=0.0, brdf=None):
         s = _OracleScene()
         s.eye[:] = [float(v) for v in eye]
         s.right[:] = [float(v) for v in right]
@@ -232,6 +237,18 @@ class OracleScene:
             self._t = np.ascontiguousarray(tf_table, dtype=np.float32)
             s.tfTable = self._t.ctypes.data_as(_FP)
             s.tfRows = self._t.shape[0]
+        s.gradientMode, s.fdStep = gradient_mode, finite_differences_stepsize
+        if brdf:  # same keys as capi.Scene
+            s.brdfPhong = int(brdf.get("enable_phong", False))
+            s.brdfMagnitudeScaling = int(brdf.get("enable_magnitude_scaling", False))
+            s.brdfMagScale = brdf.get("magnitude_scaling", 1.0)
+            s.brdfAmbient = brdf.get("ambient", 0.1)
+            s.brdfSpecular = brdf.get("specular", 0.1)
+            s.brdfMagCenter = brdf.get("magnitude_center", 0.5)
+            s.brdfMagRadius = brdf.get("magnitude_radius", 0.1)
+            s.brdfSpecularExponent = int(brdf.get("specular_exponent", 16))
+            s.brdfLightType = int(brdf.get("light_type", 0))
+            s.brdfLight[:] = [float(v) for v in brdf.get("light", (0.0, 0.0, 1.0))]
         self._s = s
 
     def render(self, net: OracleNetwork, width: int, height: int, y0: int = 0, y1: Optional[int] = None):

@@ -456,9 +456,45 @@ static void render_pixel(const OracleNet* n, const OracleScene* s, int W, int H,
             c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3] * s->stepsize; /* :104-108 */
         } else {
             const float density2 = (v[0] - s->densityMin) * divRange;
-            if (v[0] >= s->densityMin) tf_eval(s, density2, c); /* :113-133 */
+            if (v[0] >= s->densityMin) {
+                if (s->gradientMode == 1) { /* evalNormal, finite differences of valueNoClamping :1185-1196 */
+                    const float h = s->fdStep;
+                    float vv[6];
+                    for (int k = 0; k < 6; ++k) {
+                        float q[3] = {pos[0], pos[1], pos[2]}, vk[4], gk[3], ck[2];
+                        q[k >> 1] += (k & 1) ? -h : h;
+                        srn_eval(n, q, dir, vk, gk, ck);
+                        vv[k] = vk[0];
+                    }
+                    g[0] = (vv[0] - vv[1]) / (2 * h); g[1] = (vv[2] - vv[3]) / (2 * h); g[2] = (vv[4] - vv[5]) / (2 * h);
+                }
+                tf_eval(s, density2, c); /* :113-133 */
+            }
         }
-        if (c[3] > 0) { /* :138-153, BRDFLambert::eval without its optional defines is the identity */
+        if (c[3] > 0 && (s->brdfMagnitudeScaling || s->brdfPhong)) { /* BRDFLambert::eval, renderer_brdf_lambert.cuh:56-103 */
+            const float g2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+            if (s->brdfMagnitudeScaling) c[3] *= 1.0f - expf(-s->brdfMagScale * g2);
+            if (s->brdfPhong) {
+                const float gradientNorm = 1.0f / sqrtf(g2); /* the reference's rsqrt(gradientNormSqr) */
+                float nn[3] = {g[0], g[1], g[2]};
+                if (g2 >= 1e-8f) { nn[0] *= gradientNorm; nn[1] *= gradientNorm; nn[2] *= gradientNorm; }
+                float l[3];
+                for (int k = 0; k < 3; ++k) l[k] = s->brdfLightType == 1 ? -s->brdfLight[k] : s->brdfLight[k] - pos[k];
+                const float il = 1.0f / sqrtf(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+                l[0] *= il; l[1] *= il; l[2] *= il;
+                const float lo = s->brdfMagCenter - s->brdfMagRadius, hi = s->brdfMagCenter + s->brdfMagRadius;
+                const float y = clamp01((gradientNorm - lo) / (hi - lo));
+                const float phongStrength = y * y * (3.0f - 2.0f * y);
+                const float ambientStrength = 1.0f + phongStrength * (s->brdfAmbient - 1.0f);
+                const float nl = nn[0] * l[0] + nn[1] * l[1] + nn[2] * l[2];
+                const float r[3] = {l[0] - 2 * nn[0] * nl, l[1] - 2 * nn[1] * nl, l[2] - 2 * nn[2] * nl}; /* reflect(l, -n) */
+                const float e = (float)s->brdfSpecularExponent;
+                const float spec = (e + 2.0f) * 0.159155f * powf(fmaxf(0.f, dir[0] * r[0] + dir[1] * r[1] + dir[2] * r[2]), e);
+                for (int k = 0; k < 3; ++k)
+                    c[k] = ambientStrength * c[k] + (1 - ambientStrength) * (fabsf(nl) * c[k] + s->brdfSpecular * spec);
+            }
+        }
+        if (c[3] > 0) { /* :138-153 */
             const float l2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
             if (l2 >= 1e-8f) { const float k = 1.0f / sqrtf(l2); g[0] *= k; g[1] *= k; g[2] *= k; }
             const float a = s->blendMode == ORACLE_BLEND_BEER_LAMBERT ? 1.0f - expf(-c[3]) : fminf(1.0f, c[3]);

@@ -52,6 +52,13 @@ typedef struct {
     int earlyOut, blendMode, tfKind, tfRows;
     float tfScaleAbsorption, tfScaleEmission;
     const float* tfTable;
+    /* GRADIENT_MODE (renderer_volume_tensorcores.cuh:1166-1201): 0 off / direct, 1 finite differences */
+    int gradientMode;
+    float fdStep;
+    /* BRDFLambert (renderer_brdf_lambert.cuh:19-103) */
+    int brdfMagnitudeScaling, brdfPhong, brdfLightType /* 0 point, 1 directional */, brdfSpecularExponent;
+    float brdfMagScale, brdfAmbient, brdfSpecular, brdfMagCenter, brdfMagRadius;
+    float brdfLight[3];
 } OracleScene;
 
 int oracle_eval_points(const OracleNet* n, const float* worldPos, const float* directions /* or NULL */, size_t count, float* out);

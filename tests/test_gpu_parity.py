@@ -243,6 +243,46 @@ def test_feature_rotation_stays_close_to_per_step_features(monkeypatch):
     assert float((exact - rotated).abs().max()) < TOL_IMG
 
 
+PHONG = dict(enable_phong=True, ambient=0.2, specular=0.4, magnitude_center=0.6, magnitude_radius=0.5, specular_exponent=8,
+             light_type=0, light=(1.0, -1.5, 0.8))
+
+
+@pytest.mark.parametrize("case", [
+    # finite-difference normals (6 extra network evaluations per sample) feeding the normal channels
+    dict(net=dict(activation="SnakeAlt", output_mode="density"), fd=True, brdf=None),
+    # ... and Phong shading with a point light
+    dict(net=dict(activation="SnakeAlt", output_mode="density"), fd=True, brdf=PHONG),
+    # directional light + magnitude scaling, ReLU (plain image in the shaded kernel), latent grid, 64 wide
+    dict(net=dict(activation="ReLU", output_mode="density", C=64, layers=3, grid=(16, 8)), fd=True,
+         brdf=dict(PHONG, light_type=1, light=(0.3, 0.5, -1.0), enable_magnitude_scaling=True, magnitude_scaling=5.0)),
+    # shading from predicted gradients (no finite differences)
+    dict(net=dict(activation="Sine", output_mode="densitygrad"), fd=False, brdf=PHONG),
+    # density:direct: differences of the un-clamped value
+    dict(net=dict(activation="Snake", param=2.0, output_mode="density:direct"), fd=True, brdf=PHONG, tf=dict(density_min=-1.0, density_max=1.0)),
+])
+def test_shaded_render_matches_oracle(case):
+    """GRADIENT_MODE_FINITE_DIFFERENCES (renderer_volume_tensorcores.cuh:1185-1196) and
+    BRDFLambert with Phong / magnitude scaling (renderer_brdf_lambert.cuh:56-103) -- render_shaded_kernel vs the oracle."""
+    vn = util.random_network(seed=31, box_min=(-0.5, -0.5, -0.5), fourier_std=0.35, **case["net"])
+    kw = make_scene_kwargs(early_out=True, tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF, brdf=case["brdf"], **case.get("tf", {}))
+    if case["fd"]:
+        kw.update(gradient_mode=1, finite_differences_stepsize=1 / 16)
+    img, ref, stats, count = render_both(vn, kw, 40, 24)
+    assert img[3].max() > 0.05
+    if case["fd"] or case["net"]["output_mode"].startswith("densitygrad"):
+        assert np.abs(ref[4:7]).max() > 0.05, "no normals: the comparison would be vacuous"
+    # central differences amplify the fp16-level differences of two evaluations by 1 / (2h) = 8
+    assert_images_close(img, ref, 4 * TOL_IMG if case["fd"] else TOL_IMG)
+    assert abs(int(stats[0]) - count) <= max(2, count // 1000)
+
+
+def test_adjoint_gradient_mode_fails_loudly():
+    from fvsrn_amd import capi
+    with pytest.raises(capi.FvsrnError) as e:
+        capi.Scene(**make_scene_kwargs(gradient_mode=2, finite_differences_stepsize=0.01))
+    assert e.value.code == -4
+
+
 def test_render_ragged_image_and_row_stripes():
     """W, H not multiples of the 8x8 pixel tile; stripes [y0,y1) compose to the full frame bit-exactly."""
     import torch

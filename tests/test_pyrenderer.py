@@ -164,6 +164,48 @@ def test_render_network_sequence_matches_oracle():
     assert np.abs(out.cpu().numpy() - ref).max() < 2e-3
 
 
+@pytest.mark.gpu
+def test_shaded_configuration_through_the_module_api():
+    """The shaded scene files of the reference (e.g. config-files/ejecta1024-v7-shaded.json) select finite-difference
+    gradients on the volume and Phong shading on the BRDF: same image as the C ABI driven directly, and as the oracle."""
+    from oracle import oracle
+    from fvsrn_amd import capi
+    vn = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode="density", seed=31, box_min=(-0.5, -0.5, -0.5), fourier_std=0.35)
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "shaded_test.volnet")
+    open(path, "wb").write(volnet_io.save_volnet(vn))
+    ev = pr.ImageEvaluatorSimple()
+    vol = pr.VolumeInterpolationNetwork()
+    vol.set_network(pr.SceneNetwork.load(path))
+    vol.gradient_mode = pr.VolumeInterpolationNetwork.GradientMode.FINITE_DIFFERENCES
+    vol.finite_differences_stepsize = 1 / 16
+    ev.volume = vol
+    ev.camera.orientation = pr.CameraOnASphere.Ym
+    ev.camera.pitchYawDistance.value = pr.double3(0.4, 0.7, 1.6)
+    ev.camera.fov_y_radians = float(np.deg2rad(45.0))
+    ev.ray_evaluator.stepsize = 1 / 48
+    tf = pr.TransferFunctionIdentity()
+    tf.absorption_emission.value = pr.double2(20.0, 1.0)
+    ev.ray_evaluator.tf = tf
+    b = ev.ray_evaluator.brdf
+    b.enable_phong = True
+    b.ambient.value, b.specular.value, b.magnitude_center.value, b.magnitude_radius.value = 0.2, 0.4, 0.6, 0.5
+    b.specular_exponent.value = 8
+    b.light_follows_camera = True
+    b.light_type = pr.BRDFLambert.LightType.Point
+    img = ev.render(40, 24).cpu().numpy()[0]
+    eye, right, up = capi.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, 0.7, 1.6)
+    kw = dict(eye=eye, right=right, up=up, fov_y_radians=float(np.deg2rad(45.0)), stepsize=1 / 48, early_out=True,
+              tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=20.0, tf_scale_emission=1.0, gradient_mode=1,
+              finite_differences_stepsize=1 / 16,
+              brdf=dict(enable_phong=True, ambient=0.2, specular=0.4, magnitude_center=0.6, magnitude_radius=0.5, specular_exponent=8,
+                        light_type=0, light=tuple(float(v) for v in eye)))
+    ref, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), 40, 24)
+    assert np.abs(ref[4:7]).max() > 0.05 and img[3].max() > 0.05
+    assert np.abs(img[:7] - ref[:7]).max() < 1.2e-2
+    with pytest.raises(RuntimeError, match="ADJOINT"):
+        vol.gradient_mode = pr.VolumeInterpolationNetwork.GradientMode.ADJOINT_METHOD
+
+
 def test_protocol_png_writer(tmp_path):
     sys.path.insert(0, os.path.join(util.ROOT, "tools"))
     import render_protocol
