@@ -12,6 +12,8 @@
 // iso ray evaluators, implicit / grid volumes, importance sampling, compression bindings, interp1D.
 #include <torch/extension.h>
 
+#include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <fstream>
 #include <memory>
@@ -316,6 +318,16 @@ struct IVolumeInterpolation {
 enum GradientMode { OFF_OR_DIRECT = 0, FINITE_DIFFERENCES = 1, ADJOINT_METHOD = 2 };
 enum Orientation { Xp = 0, Xm = 1, Yp = 2, Ym = 3, Zp = 4, Zm = 5 };
 
+// a volume module this build does not contain ("Grid", "Implicit"): keeps scene files loadable, cannot be rendered
+struct UnsupportedVolume : IVolumeInterpolation {
+    std::string name;
+    explicit UnsupportedVolume(std::string n) : name(std::move(n)) {}
+    int outputChannels() const override { return 1; }
+    torch::Tensor evaluate(const torch::Tensor&, const std::optional<torch::Tensor>&) override {
+        raise("volume '" + name + "' is not part of this build (only the SRN path is): set a VolumeInterpolationNetwork");
+    }
+};
+
 struct VolumeInterpolationNetwork : IVolumeInterpolation {
     std::shared_ptr<SceneNetwork> net;
     bool onlySharedMemory = false;
@@ -495,7 +507,11 @@ struct ImageEvaluatorSimple {
 
     torch::Tensor render(int width, int height) {  // image_evaluator_simple.cpp:198-361
         auto vol = std::dynamic_pointer_cast<VolumeInterpolationNetwork>(volume);
-        if (!vol) raise("ImageEvaluatorSimple.volume must be a VolumeInterpolationNetwork (the SRN path is the only volume of this build)");
+        if (!vol) {
+            auto other = std::dynamic_pointer_cast<UnsupportedVolume>(volume);
+            raise(std::string("ImageEvaluatorSimple.volume must be a VolumeInterpolationNetwork (the SRN path is the only volume of this build)") +
+                  (other ? "; the scene file selected volume '" + other->name + "'" : ""));
+        }
         auto dvr = std::dynamic_pointer_cast<RayEvaluationSteppingDvr>(rayEvaluator);
         if (!dvr) raise("ImageEvaluatorSimple.ray_evaluator must be a RayEvaluationSteppingDvr");
         if (!camera) raise("no camera selected");
@@ -591,6 +607,93 @@ py::dict jsub(const py::dict& root, const std::string& tag, const std::string& n
     return sec[name.c_str()].cast<py::dict>();
 }
 
+// ---- transfer functions from their JSON description (host-side construction of the device tables) ----------------
+struct ColorPoint { double pos; double rgb[3]; };
+std::vector<ColorPoint> colorPointsFromJson(const py::dict& jt) {  // adl_serializer<TFPartPiecewiseColor::Point>, transfer_function.h:403-417
+    std::vector<ColorPoint> pts;
+    for (const auto& v : jt["colorPoints"].cast<std::vector<std::vector<double>>>()) {
+        if (v.size() != 4) raise("colorPoints entries must be [position, r, g, b]");
+        pts.push_back({v[0], {v[1], v[2], v[3]}});
+    }
+    if (pts.empty()) raise("the transfer function has no colour control points");
+    std::stable_sort(pts.begin(), pts.end(), [](const ColorPoint& a, const ColorPoint& b) { return a.pos < b.pos; });  // sortPointsAndUpdateTexture
+    return pts;
+}
+
+// TransferFunctionPiecewiseLinear::computeTensor (renderer/transfer_function_piecewise.cpp:166-282): merged control
+// points (1,R,5) = [r,g,b,absorption*scaling,pos]
+torch::Tensor piecewiseTensor(std::vector<ColorPoint> color, const std::vector<std::vector<double>>& opacityJson, double scaling) {
+    struct OP { double pos, absorption; };
+    std::vector<OP> opacity;
+    for (const auto& v : opacityJson) {
+        if (v.size() != 2) raise("opacityPoints entries must be [position, absorption]");
+        opacity.push_back({v[0], v[1]});
+    }
+    if (opacity.empty()) raise("the transfer function has no opacity control points");
+    std::stable_sort(opacity.begin(), opacity.end(), [](const OP& a, const OP& b) { return a.pos < b.pos; });
+    // control points outside [0,1] (-1 and 2) if the first / last ones are inside (:181-199)
+    if (color.front().pos > 0) color.insert(color.begin(), ColorPoint{-1.0, {color.front().rgb[0], color.front().rgb[1], color.front().rgb[2]}});
+    if (opacity.front().pos > 0) opacity.insert(opacity.begin(), OP{-1.0, opacity.front().absorption});
+    if (color.back().pos < 1) color.push_back(ColorPoint{2.0, {color.back().rgb[0], color.back().rgb[1], color.back().rgb[2]}});
+    if (opacity.back().pos < 1) opacity.push_back(OP{2.0, opacity.back().absorption});
+    struct P { double pos, rgb[3], absorption; };
+    std::vector<P> pts;
+    pts.push_back({color[0].pos <= opacity[0].pos ? color[0].pos : opacity[0].pos, {color[0].rgb[0], color[0].rgb[1], color[0].rgb[2]}, opacity[0].absorption});
+    size_t io = 0, ic = 0;
+    while (io + 1 < opacity.size() && ic + 1 < color.size()) {  // :209-237
+        if (opacity[io + 1].pos < color[ic + 1].pos) {
+            const double f = (opacity[io + 1].pos - color[ic].pos) / (color[ic + 1].pos - color[ic].pos);
+            P q{opacity[io + 1].pos, {0, 0, 0}, opacity[io + 1].absorption};
+            for (int k = 0; k < 3; ++k) q.rgb[k] = color[ic].rgb[k] + f * (color[ic + 1].rgb[k] - color[ic].rgb[k]);
+            pts.push_back(q);
+            ++io;
+        } else {
+            const double f = (color[ic + 1].pos - opacity[io].pos) / (opacity[io + 1].pos - opacity[io].pos);
+            pts.push_back({color[ic + 1].pos, {color[ic + 1].rgb[0], color[ic + 1].rgb[1], color[ic + 1].rgb[2]},
+                           opacity[io].absorption + f * (opacity[io + 1].absorption - opacity[io].absorption)});
+            ++ic;
+        }
+    }
+    const float EPS = 1e-7f;  // purge runs of zero absorption and coincident points (:243-256)
+    for (int64_t i = 0; i < int64_t(pts.size()) - 2;) {
+        if ((pts[i].absorption < EPS && pts[i + 1].absorption < EPS && pts[i + 2].absorption < EPS) || (pts[i + 1].pos - pts[i].pos < EPS))
+            pts.erase(pts.begin() + (i + 1));
+        else
+            ++i;
+    }
+    torch::Tensor t = torch::empty({1, int64_t(pts.size()), 5}, torch::kFloat);
+    for (size_t i = 0; i < pts.size(); ++i) {  // clamp colour, scale opacity (:259-263)
+        float* r = t.data_ptr<float>() + 5 * i;
+        for (int k = 0; k < 3; ++k) r[k] = float(std::min(std::max(pts[i].rgb[k], 0.0), double(1.0f - FLT_EPSILON)));
+        r[3] = float(std::min(std::max(pts[i].absorption, 0.0), 1.0) * scaling);
+        r[4] = float(pts[i].pos);
+    }
+    return t;
+}
+
+// TransferFunctionTexture::computeTexture (renderer/transfer_function_texture.cpp:347-362) with
+// TFPartPiecewiseColor::getAsTexture (transfer_function.cpp:526-551): 256 texels (1,256,4) = [r,g,b,absorptionScaling*plot]
+torch::Tensor textureTensor(const std::vector<ColorPoint>& color, const std::vector<float>& plot, double scaling) {
+    const int R = 256;
+    if (int(plot.size()) != R) raise("opacityPoints of a Texture transfer function must hold 256 values");
+    torch::Tensor t = torch::empty({1, R, 4}, torch::kFloat);
+    const int n = int(color.size());
+    for (int i = 0; i < R; ++i) {
+        const float density = (i + 0.5f) / R;
+        int idx;
+        for (idx = 0; idx < n - 2; ++idx)
+            if (color[size_t(idx) + 1].pos > density) break;
+        const ColorPoint& lo = color[size_t(idx)];
+        const ColorPoint& hi = color[size_t(std::min(idx + 1, n - 1))];
+        const float pLow = float(lo.pos), pHigh = float(hi.pos);
+        const float frac = std::min(std::max((density - pLow) / (pHigh - pLow), 0.0f), 1.0f);
+        float* r = t.data_ptr<float>() + 4 * i;
+        for (int k = 0; k < 3; ++k) r[k] = float((1 - frac) * lo.rgb[k] + frac * hi.rgb[k]);
+        r[3] = float(scaling) * plot[size_t(i)];
+    }
+    return t;
+}
+
 std::shared_ptr<ImageEvaluatorSimple> loadFromJson(const std::string& filename) {
     py::object json = py::module_::import("json");
     py::object io = py::module_::import("io");
@@ -671,6 +774,8 @@ std::shared_ptr<ImageEvaluatorSimple> loadFromJson(const std::string& filename) 
             tf->absorptionEmission->value = {jget<double>(jt, "absorptionScaling", 1.0), jget<double>(jt, "emissionScaling", 1.0)};
             dvr->tf = tf;
         } else if (tfSel == "Gaussian") {  // transfer_function_gaussian.cpp:234-242,340-360
+            if (jget<bool>(jt, "scaleWithGradient", false) || jget<bool>(jt, "usePiecewiseAnalyticIntegration", false))
+                raise("Gaussian transfer functions with scaleWithGradient / usePiecewiseAnalyticIntegration are not in the compiled variant set");
             auto tf = std::make_shared<TransferFunctionGaussian>();
             const double scale = jget<double>(jt, "absorptionScaling", 1.0);
             auto pts = jt["points"].cast<std::vector<std::vector<double>>>();
@@ -682,16 +787,32 @@ std::shared_ptr<ImageEvaluatorSimple> loadFromJson(const std::string& filename) 
             }
             tf->setTensor(t);
             dvr->tf = tf;
+        } else if (tfSel == "Piecewise") {
+            auto tf = std::make_shared<TransferFunctionPiecewise>();
+            tf->setTensor(piecewiseTensor(colorPointsFromJson(jt), jt["opacityPoints"].cast<std::vector<std::vector<double>>>(),
+                                          jget<double>(jt, "absorptionScaling", 1.0)));
+            dvr->tf = tf;
+        } else if (tfSel == "Texture") {
+            const std::string pre = jget<std::string>(jt, "preintegrationMode", "None");
+            if (pre != "None" && pre != "")
+                raise("transfer function 'Texture' with preintegrationMode '" + pre + "' is not in the compiled variant set (None)");
+            auto tf = std::make_shared<TransferFunctionTexture>();
+            tf->setTensor(textureTensor(colorPointsFromJson(jt), jt["opacityPoints"].cast<std::vector<float>>(),
+                                        jget<double>(jt, "absorptionScaling", 1.0)));
+            dvr->tf = tf;
         } else {
-            raise("transfer function '" + tfSel + "' cannot be loaded from JSON yet (Identity, Gaussian)");
+            raise("unknown transfer function '" + tfSel + "' (Identity, Gaussian, Piecewise, Texture)");
         }
         ev->rayEvaluator = dvr;
     }
     // volume: networks are not stored in the JSON (volume_interpolation_network.cpp:1664-1672)
     {
+        // The reference's scene files select the ground-truth volume ("Grid", "Implicit"); its callers then replace it by
+        // the trained network (inference.py:598 `image_evaluator.volume = self._volume_network`).  Those volumes are not
+        // part of this build: the selection is recorded and render() asks for a VolumeInterpolationNetwork.
         const std::string sel = jget<std::string>(je, "selectedVolume", "SRN");
-        if (sel != "SRN") raise("volume '" + sel + "' is not supported by this build (only 'SRN'); attach a VolumeInterpolationNetwork");
-        ev->volume = std::make_shared<VolumeInterpolationNetwork>();
+        if (sel == "SRN") ev->volume = std::make_shared<VolumeInterpolationNetwork>();
+        else ev->volume = std::make_shared<UnsupportedVolume>(sel);
     }
     return ev;
 }
@@ -700,6 +821,7 @@ std::shared_ptr<ImageEvaluatorSimple> loadFromJson(const std::string& filename) 
 
 PYBIND11_MODULE(pyrenderer, m) {
     m.doc() = "MI355X-native drop-in for the SRN/DVR path of fV-SRN's pyrenderer";
+    py::module_::import("torch");  // the Tensor type casters need torch's Python side, whatever the import order of the caller
     // bindings/bindings.cpp:155-171: cache configuration is meaningless for ahead-of-time kernels; kept as no-ops
     m.def("set_cuda_cache_dir", [](const std::string&) {});
     m.def("set_kernel_cache_file", [](const std::string&) {});
@@ -847,6 +969,8 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def("set_box_max", &IVolumeInterpolation::setBoxMax)
         .def("output_channels", &IVolumeInterpolation::outputChannels)
         .def("evaluate", &IVolumeInterpolation::evaluate, py::arg("positions"), py::arg("direction") = std::optional<torch::Tensor>{});
+    py::class_<UnsupportedVolume, IVolumeInterpolation, std::shared_ptr<UnsupportedVolume>>(m, "UnsupportedVolume")
+        .def_readonly("name", &UnsupportedVolume::name);
     py::class_<VolumeInterpolationNetwork, IVolumeInterpolation, std::shared_ptr<VolumeInterpolationNetwork>> vn(m, "VolumeInterpolationNetwork");
     py::enum_<GradientMode>(vn, "GradientMode")
         .value("OFF_OR_DIRECT", OFF_OR_DIRECT).value("FINITE_DIFFERENCES", FINITE_DIFFERENCES).value("ADJOINT_METHOD", ADJOINT_METHOD);

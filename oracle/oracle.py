@@ -328,3 +328,64 @@ def rgba_to_int(rgba: np.ndarray) -> np.ndarray:
         q = np.clip(np.asarray(rgba, np.float32) * np.float32(255), 0, 255)
         q = np.where(np.isnan(q), 0, q).astype(np.uint32)  # fminf(fmaxf(NaN, 0), 255) = 0 on the device
     return (q[3] << 24) | (q[2] << 16) | (q[1] << 8) | q[0]
+
+
+# ---- transfer functions from their scene-file description (host-side table construction of the reference) ----
+def tf_piecewise_table(color_points, opacity_points, absorption_scaling: float) -> np.ndarray:
+    """TransferFunctionPiecewiseLinear::computeTensor (renderer/transfer_function_piecewise.cpp:166-282):
+    colorPoints [[pos,r,g,b]...], opacityPoints [[pos,absorption]...] -> (R,5) rows [r,g,b,absorption*scaling,pos]."""
+    col = sorted(([float(p[0]), np.asarray(p[1:4], np.float64)] for p in color_points), key=lambda p: p[0])
+    opa = sorted(([float(p[0]), float(p[1])] for p in opacity_points), key=lambda p: p[0])
+    if col[0][0] > 0:
+        col.insert(0, [-1.0, col[0][1]])
+    if opa[0][0] > 0:
+        opa.insert(0, [-1.0, opa[0][1]])
+    if col[-1][0] < 1:
+        col.append([2.0, col[-1][1]])
+    if opa[-1][0] < 1:
+        opa.append([2.0, opa[-1][1]])
+    pts = [[min(col[0][0], opa[0][0]) if col[0][0] <= opa[0][0] else opa[0][0], col[0][1], opa[0][1]]]
+    io = ic = 0
+    while io < len(opa) - 1 and ic < len(col) - 1:
+        if opa[io + 1][0] < col[ic + 1][0]:
+            f = (opa[io + 1][0] - col[ic][0]) / (col[ic + 1][0] - col[ic][0])
+            pts.append([opa[io + 1][0], col[ic][1] + f * (col[ic + 1][1] - col[ic][1]), opa[io + 1][1]])
+            io += 1
+        else:
+            f = (col[ic + 1][0] - opa[io][0]) / (opa[io + 1][0] - opa[io][0])
+            pts.append([col[ic + 1][0], col[ic + 1][1], opa[io][1] + f * (opa[io + 1][1] - opa[io][1])])
+            ic += 1
+    eps = float(np.float32(1e-7))
+    i = 0
+    while i < len(pts) - 2:
+        if (pts[i][2] < eps and pts[i + 1][2] < eps and pts[i + 2][2] < eps) or (pts[i + 1][0] - pts[i][0] < eps):
+            del pts[i + 1]
+        else:
+            i += 1
+    out = np.zeros((len(pts), 5), np.float32)
+    for k, (pos, rgb, a) in enumerate(pts):
+        out[k, :3] = np.clip(rgb, 0.0, float(np.float32(1.0) - np.finfo(np.float32).eps))
+        out[k, 3] = min(max(a, 0.0), 1.0) * absorption_scaling
+        out[k, 4] = pos
+    return out
+
+
+def tf_texture_table(color_points, opacity_plot, absorption_scaling: float) -> np.ndarray:
+    """TransferFunctionTexture::computeTexture (renderer/transfer_function_texture.cpp:347-362) +
+    TFPartPiecewiseColor::getAsTexture (transfer_function.cpp:526-551): (256,4) texels [r,g,b,scaling*plot[i]]."""
+    col = sorted(([float(p[0]), np.asarray(p[1:4], np.float64)] for p in color_points), key=lambda p: p[0])
+    R = 256
+    assert len(opacity_plot) == R
+    out = np.zeros((R, 4), np.float32)
+    n = len(col)
+    for i in range(R):
+        density = np.float32((i + np.float32(0.5)) / np.float32(R))
+        idx = 0
+        while idx < n - 2 and not (col[idx + 1][0] > density):
+            idx += 1
+        lo, hi = col[idx], col[min(idx + 1, n - 1)]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            frac = np.clip(np.float32((density - np.float32(lo[0])) / (np.float32(hi[0]) - np.float32(lo[0]))), 0, 1)
+        out[i, :3] = (1 - frac) * lo[1] + frac * hi[1]
+        out[i, 3] = np.float32(absorption_scaling) * np.float32(opacity_plot[i])
+    return out

@@ -104,6 +104,83 @@ def test_load_from_json_builds_the_module_tree(tmp_path):
         ev.volume.current_network()
 
 
+def _scene_json(tf_name, tf_body, brdf=None, volume="Grid"):
+    return {"version": 1, "root": "Simple",
+            "ImageEvaluator": {"Simple": {"selectedCamera": "Sphere", "selectedVolume": volume, "selectedRayEvaluator": "DVR",
+                                          "samplesPerIterationLog2": 0, "useTonemapping": False}},
+            "camera": {"Sphere": {"orientation": "Ym", "center": [0, 0, 0], "pitch": 0.4, "yaw": 0.7, "distance": 1.6, "fovY": 0.7853981633974483}},
+            "RayEvaluation": {"DVR": {"stepsize": 1 / 48, "stepsizeIsObjectSpace": False, "minDensity": 0.0, "maxDensity": 1.0,
+                                      "earlyOut": True, "selectedTF": tf_name, "selectedBRDF": "Lambert"}},
+            "tf": {tf_name: tf_body}, "brdf": {"Lambert": brdf or {"enablePhong": False}},
+            "blending": {"blending": {"blending": "BeerLambert"}}, "volume": {"Grid": {}}}
+
+
+PIECEWISE_JSON = {"absorptionScaling": 25.0, "colorPoints": [[0.0033, 1e-6, 1e-6, 1e-6], [0.44, 1.0, 0.04, 0.04], [0.7558, 0.9167, 0.9167, 0.1168]],
+                  "opacityPoints": [[0.0568, 0.0], [0.3645, 0.66], [0.7, 0.0], [0.75, 0.0], [0.8, 0.0], [1.0, 0.9]]}
+TEXTURE_JSON = {"absorptionScaling": 40.0, "preintegrationMode": "None",
+                "colorPoints": [[0.1, 0.2, 0.1, 0.9], [0.5, 1.0, 0.5, 0.0], [0.9, 1.0, 1.0, 1.0]],
+                "opacityPoints": [float(0.5 + 0.5 * np.sin(i / 40.0)) for i in range(256)]}
+
+
+def test_scene_files_with_piecewise_and_texture_tfs_load(tmp_path):
+    """Scene files of the reference select the ground-truth volume and a Piecewise / Texture / Gaussian TF; the device
+    tables must equal the restatement of TransferFunctionPiecewiseLinear::computeTensor / TransferFunctionTexture::computeTexture."""
+    from oracle import oracle
+    p = tmp_path / "pw.json"
+    p.write_text(json.dumps(_scene_json("Piecewise", PIECEWISE_JSON)))
+    ev = pr.load_from_json(str(p))
+    assert isinstance(ev.volume, pr.UnsupportedVolume) and ev.volume.name == "Grid"
+    t = ev.ray_evaluator.tf.tensor.numpy()[0]
+    ref = oracle.tf_piecewise_table(PIECEWISE_JSON["colorPoints"], PIECEWISE_JSON["opacityPoints"], 25.0)
+    assert t.shape == ref.shape and np.abs(t - ref).max() < 1e-6
+    assert ref[0, 4] == -1.0 and ref.shape[0] < 3 + 6 + 2  # sentinel at -1, a run of zero-absorption points was purged
+    p = tmp_path / "tex.json"
+    p.write_text(json.dumps(_scene_json("Texture", TEXTURE_JSON)))
+    t = pr.load_from_json(str(p)).ray_evaluator.tf.tensor.numpy()[0]
+    ref = oracle.tf_texture_table(TEXTURE_JSON["colorPoints"], TEXTURE_JSON["opacityPoints"], 40.0)
+    assert t.shape == (256, 4) and np.abs(t - ref).max() < 1e-6
+    bad = dict(TEXTURE_JSON, preintegrationMode="Preintegrate2D")
+    p.write_text(json.dumps(_scene_json("Texture", bad)))
+    with pytest.raises(RuntimeError, match="preintegrationMode"):
+        pr.load_from_json(str(p))
+
+
+REFERENCE_SCENES = "/root/reference/applications/config-files"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_SCENES), reason="reference checkout not present (it is not on the GPU box)")
+def test_reference_scene_files_load_unchanged():
+    """Every DVR scene file the reference ships loads; the ones outside this build fail with a precise message."""
+    import glob
+    from oracle import oracle
+    loaded = 0
+    for f in sorted(glob.glob(os.path.join(REFERENCE_SCENES, "*.json"))):
+        d = json.load(open(f))
+        sel = d["ImageEvaluator"]["Simple"].get("selectedRayEvaluator", "DVR")
+        tfsel = d["RayEvaluation"].get("DVR", {}).get("selectedTF")
+        jt = d.get("tf", {}).get(tfsel, {})
+        expect_error = None
+        if sel != "DVR":
+            expect_error = "ray evaluator"
+        elif tfsel == "Texture" and jt.get("preintegrationMode", "None") not in ("None", ""):
+            expect_error = "preintegrationMode"
+        if expect_error:
+            with pytest.raises(RuntimeError, match=expect_error):
+                pr.load_from_json(f)
+            continue
+        ev = pr.load_from_json(f)
+        loaded += 1
+        if tfsel == "Piecewise":
+            ref = oracle.tf_piecewise_table(jt["colorPoints"], jt["opacityPoints"], jt["absorptionScaling"])
+            assert np.abs(ev.ray_evaluator.tf.tensor.numpy()[0] - ref).max() < 1e-5, f
+        elif tfsel == "Texture":
+            ref = oracle.tf_texture_table(jt["colorPoints"], jt["opacityPoints"], jt["absorptionScaling"])
+            assert np.abs(ev.ray_evaluator.tf.tensor.numpy()[0] - ref).max() < 1e-5, f
+        b = d.get("brdf", {}).get("Lambert", {})
+        assert ev.ray_evaluator.brdf.enable_phong == b.get("enablePhong", False), f
+    assert loaded >= 19
+
+
 def test_extract_color_rejects_host_tensors():
     # the reference checks CHECK_CUDA(inputTensor) (iimage_evaluator.cpp:29); there is no CPU path here either
     with pytest.raises(RuntimeError, match="GPU"):
@@ -204,6 +281,41 @@ def test_shaded_configuration_through_the_module_api():
     assert np.abs(img[:7] - ref[:7]).max() < 1.2e-2
     with pytest.raises(RuntimeError, match="ADJOINT"):
         vol.gradient_mode = pr.VolumeInterpolationNetwork.GradientMode.ADJOINT_METHOD
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tf_name", ["Piecewise", "Texture"])
+def test_scene_file_render_matches_oracle(tmp_path, tf_name):
+    """A scene file in the reference's format (ground-truth volume selected, Piecewise / Texture TF, Phong-shaded BRDF with
+    a light that follows the camera) + a .volnet: load_from_json, attach the network like inference.py:598, render."""
+    from oracle import oracle
+    from fvsrn_amd import capi
+    brdf = {"enablePhong": True, "enableMagnitudeScaling": False, "ambient": 0.3, "specular": 0.5, "magnitudeCenter": 0.6,
+            "magnitudeRadius": 0.5, "specularExponent": 4, "lightFollowsCamera": True, "lightType": "Directional"}
+    body = PIECEWISE_JSON if tf_name == "Piecewise" else TEXTURE_JSON
+    p = tmp_path / "scene.json"
+    p.write_text(json.dumps(_scene_json(tf_name, body, brdf)))
+    vn = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode="densitygrad", seed=8, box_min=(-0.5, -0.5, -0.5), fourier_std=0.35)
+    path = str(tmp_path / "net.volnet")
+    open(path, "wb").write(volnet_io.save_volnet(vn))
+    ev = pr.load_from_json(str(p))
+    with pytest.raises(RuntimeError, match="VolumeInterpolationNetwork"):
+        ev.render(40, 24)  # the ground-truth grid volume is not part of this build
+    vol = pr.VolumeInterpolationNetwork()
+    vol.set_network(pr.SceneNetwork.load(path))
+    ev.volume = vol
+    img = ev.render(40, 24).cpu().numpy()[0]
+    eye, right, up = capi.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, 0.7, 1.6)
+    front = np.cross(up, right)
+    table = (oracle.tf_piecewise_table(body["colorPoints"], body["opacityPoints"], body["absorptionScaling"]) if tf_name == "Piecewise"
+             else oracle.tf_texture_table(body["colorPoints"], body["opacityPoints"], body["absorptionScaling"]))
+    kw = dict(eye=eye, right=right, up=up, fov_y_radians=0.7853981633974483, stepsize=1 / 48, early_out=True,
+              tf_kind=oracle.TF_PIECEWISE if tf_name == "Piecewise" else oracle.TF_TEXTURE, tf_table=table,
+              brdf=dict(enable_phong=True, ambient=0.3, specular=0.5, magnitude_center=0.6, magnitude_radius=0.5, specular_exponent=4,
+                        light_type=1, light=tuple(float(v) for v in front)))
+    ref, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), 40, 24)
+    assert img[3].max() > 0.05
+    assert np.abs(img[:7] - ref[:7]).max() < 3e-3
 
 
 def test_protocol_png_writer(tmp_path):
