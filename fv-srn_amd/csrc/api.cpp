@@ -253,14 +253,16 @@ static BoxCenter P_boxCenter(const NetParams& P) {
 struct fvsrn_scene {
     fvsrn_scene_desc desc{};
     std::vector<float> tfTable;
-    DeviceBuffer dTf, dOrder, dCounters, dPartial;
+    DeviceBuffer dTf, dOrder, dCounters, dPartial, dPreint;
+    int preintMode = 0;          // what dPreint holds
+    float preintStepsize = -1.f;
     unsigned launches = 0;  // parity selects which of the two tile counters a launch uses (the kernel zeroes the other)
     bool tfDirty = true;
     std::mutex mu;
     // cached launch order of the 8x8 pixel tiles
     struct OrderKey { int tilesX = -1, tilesY = -1, cx = 0, cy = 0, y0 = 0, stripeRows = 0, stripeRank = 0, stripeWorld = 0; } orderKey;
     std::vector<int> order;
-    ~fvsrn_scene() { dTf.release(); dOrder.release(); dCounters.release(); dPartial.release(); }
+    ~fvsrn_scene() { dTf.release(); dOrder.release(); dCounters.release(); dPartial.release(); dPreint.release(); }
 
     // Two work counters for the persistent render waves.  Launches of one scene must be ordered on one stream
     // (like everything else a scene owns: TF table, tile order).
@@ -623,6 +625,10 @@ static int sceneValidate(const fvsrn_scene_desc* d) {
         return fail(FVSRN_ERR_INVALID_ARGUMENT, "finite_differences_stepsize must be positive");
     if (d->brdf_light_type != FVSRN_LIGHT_POINT && d->brdf_light_type != FVSRN_LIGHT_DIRECTIONAL)
         return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad brdf_light_type");
+    if (d->tf_preintegration < FVSRN_PREINTEGRATE_NONE || d->tf_preintegration > FVSRN_PREINTEGRATE_2D)
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad tf_preintegration");
+    if (d->tf_preintegration != FVSRN_PREINTEGRATE_NONE && d->tf_kind != FVSRN_TF_TEXTURE)
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "pre-integration is a mode of the Texture transfer function");
     if (d->blend_mode != FVSRN_BLEND_ALPHA && d->blend_mode != FVSRN_BLEND_BEER_LAMBERT)
         return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad blend mode");
     return FVSRN_OK;
@@ -722,6 +728,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             if (numLocalRows == 0) return FVSRN_OK;
 
             const size_t tfFloats = scene->tfTable.size();
+            const bool tfChanged = scene->tfDirty;
             if (scene->tfDirty) {
                 if (tfFloats) {
                     scene->dTf.ensure(tfFloats * 4);
@@ -729,9 +736,23 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 }
                 scene->tfDirty = false;
             }
+            // TransferFunctionTexture::updatePreintegrationTable (transfer_function_texture.cpp:364-379): rebuilt when the
+            // texture or (2D) the step size changed
+            if (d.tf_preintegration != FVSRN_PREINTEGRATE_NONE &&
+                (tfChanged || scene->preintMode != d.tf_preintegration ||
+                 (d.tf_preintegration == FVSRN_PREINTEGRATE_2D && scene->preintStepsize != d.stepsize))) {
+                const int R = d.tf_rows;
+                scene->dPreint.ensure(size_t(d.tf_preintegration == FVSRN_PREINTEGRATE_2D ? R : 1) * R * 4 * sizeof(float));
+                const hipError_t e = launch_tf_preintegration(static_cast<const float*>(scene->dTf.ptr), static_cast<float*>(scene->dPreint.ptr), R,
+                                                              d.tf_preintegration, d.stepsize, 256, s);
+                if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("pre-integration failed: ") + hipGetErrorString(e));
+                scene->preintMode = d.tf_preintegration;
+                scene->preintStepsize = d.stepsize;
+            }
             RenderArgs a{};
             a.P = net->packed.params;
-            a.shaded = d.gradient_mode == FVSRN_GRADIENT_FINITE_DIFFERENCES || d.brdf_enable_phong || d.brdf_enable_magnitude_scaling;
+            a.shaded = d.gradient_mode == FVSRN_GRADIENT_FINITE_DIFFERENCES || d.brdf_enable_phong || d.brdf_enable_magnitude_scaling ||
+                       d.tf_preintegration != FVSRN_PREINTEGRATE_NONE;
             // finite differences also sample up to a step outside the box, where the [0,1] bound of the scaled image does
             // not hold: the shaded renderer takes the plain image
             if (net->scaledImage && !a.shaded) {  // ReLU network: image with activations scaled into [0,1] (pack.cpp)
@@ -766,6 +787,8 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             S.tfScaleAbsorption = d.tf_scale_absorption;
             S.tfScaleEmission = d.tf_scale_emission;
             S.tfTable = static_cast<const float*>(scene->dTf.ptr);
+            S.tfPreintegration = d.tf_preintegration;
+            S.tfPreintegrated = static_cast<const float*>(scene->dPreint.ptr);
             S.width = width; S.height = height; S.y0 = y0; S.y1 = y1;
             S.numLocalRows = numLocalRows; S.stripeRows = stripeRows; S.stripeRank = stripeRank;
             S.stripeWorld = stripeWorld; S.compact = compact;
@@ -786,10 +809,11 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 const double waves = double(resident) * wpb;
                 const float* bs = a.P.boxSize;
                 const double maxSteps = std::sqrt(double(bs[0]) * bs[0] + double(bs[1]) * bs[1] + double(bs[2]) * bs[2]) / d.stepsize;
-                while (K < 8 && double(tiles) * K < 4.0 * waves && maxSteps / (2 * K) >= 48.0) K *= 2;
+                // (a pre-integrated TF looks at the previous sample of the ray: no cuts)
+                while (d.tf_preintegration == FVSRN_PREINTEGRATE_NONE && K < 8 && double(tiles) * K < 4.0 * waves && maxSteps / (2 * K) >= 48.0) K *= 2;
                 if (const char* e = std::getenv("FVSRN_SEGMENTS")) {
                     const int k = std::atoi(e);
-                    if (k >= 1 && k <= 64) K = k;
+                    if (k >= 1 && k <= 64 && d.tf_preintegration == FVSRN_PREINTEGRATE_NONE) K = k;
                 }
             }
             S.resyncMask = kFourierResync - 1;

@@ -64,6 +64,8 @@ struct SceneParams {
     int tfKind, tfRows;
     float tfScaleAbsorption, tfScaleEmission;
     const float* tfTable;  // device pointer
+    int tfPreintegration;          // 0 none, 1: tfPreintegrated = [R][4] running integral, 2: [R][R][4] (previous, current density)
+    const float* tfPreintegrated;  // device pointer (global memory: 1 MiB in 2D mode), R = tfRows
     // image: the launch covers `numLocalRows` rows; local row l is image row
     //   y = y0 + ((l / stripeRows) * stripeWorld + stripeRank) * stripeRows + l % stripeRows   (y < y1)
     // (stripeWorld == 1: the contiguous range [y0,y1)); compact != 0 writes a [8][numLocalRows][width] image

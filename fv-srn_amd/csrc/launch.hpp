@@ -79,6 +79,10 @@ hipError_t launch_extract_color(const ExtractParams& p, hipStream_t s);
 hipError_t launch_composite(const float* partial, float* out, int segments, unsigned long long plane, const SceneParams& S,
                             hipStream_t s);
 
+// pre-integration tables of a Texture TF (transfer_function_texture_cuda.cu:9-90): tex = device [R][4] texels,
+// mode 1 -> out [R][4], mode 2 -> out [R][R][4] (row = current density index, column = previous density index)
+hipError_t launch_tf_preintegration(const float* tex, float* out, int R, int mode, float stepsize, int quadratureSteps, hipStream_t s);
+
 bool kernel_info(const VariantKey& k, KernelInfo* info);
 hipError_t launch_eval(const VariantKey& k, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 hipError_t launch_render(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);

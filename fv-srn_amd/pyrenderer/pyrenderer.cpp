@@ -406,7 +406,14 @@ struct TableTF : ITransferFunction {
 };
 struct TransferFunctionGaussian : TableTF { TransferFunctionGaussian() : TableTF(FVSRN_TF_GAUSSIAN, 6) {} };
 struct TransferFunctionPiecewise : TableTF { TransferFunctionPiecewise() : TableTF(FVSRN_TF_PIECEWISE, 5) {} };
-struct TransferFunctionTexture : TableTF { TransferFunctionTexture() : TableTF(FVSRN_TF_TEXTURE, 4) {} };
+struct TransferFunctionTexture : TableTF {
+    int preintegrationMode = FVSRN_PREINTEGRATE_NONE;  // TransferFunctionTexture::PreintegrationMode
+    TransferFunctionTexture() : TableTF(FVSRN_TF_TEXTURE, 4) {}
+    void fill(fvsrn_scene_desc& d, std::vector<float>& table) const override {
+        TableTF::fill(d, table);
+        d.tf_preintegration = preintegrationMode;
+    }
+};
 
 struct BRDFLambert {  // renderer/brdf.cpp:208-225 (JSON), :413-508 (constant block, light follows camera)
     bool enableMagnitudeScaling = false, enablePhong = false;
@@ -793,10 +800,10 @@ std::shared_ptr<ImageEvaluatorSimple> loadFromJson(const std::string& filename) 
                                           jget<double>(jt, "absorptionScaling", 1.0)));
             dvr->tf = tf;
         } else if (tfSel == "Texture") {
-            const std::string pre = jget<std::string>(jt, "preintegrationMode", "None");
-            if (pre != "None" && pre != "")
-                raise("transfer function 'Texture' with preintegrationMode '" + pre + "' is not in the compiled variant set (None)");
+            const std::string pre = jget<std::string>(jt, "preintegrationMode", "None");  // magic_enum names, transfer_function_texture.cpp:222
             auto tf = std::make_shared<TransferFunctionTexture>();
+            if (pre == "Preintegrate1D") tf->preintegrationMode = FVSRN_PREINTEGRATE_1D;
+            else if (pre == "Preintegrate2D") tf->preintegrationMode = FVSRN_PREINTEGRATE_2D;
             tf->setTensor(textureTensor(colorPointsFromJson(jt), jt["opacityPoints"].cast<std::vector<float>>(),
                                         jget<double>(jt, "absorptionScaling", 1.0)));
             dvr->tf = tf;
@@ -998,8 +1005,12 @@ PYBIND11_MODULE(pyrenderer, m) {
     py::class_<TransferFunctionPiecewise, ITransferFunction, std::shared_ptr<TransferFunctionPiecewise>>(m, "TransferFunctionPiecewise")
         .def(py::init<>())
         .def_property("tensor", [](TransferFunctionPiecewise& t) { return t.tensor; }, &TransferFunctionPiecewise::setTensor);
-    py::class_<TransferFunctionTexture, ITransferFunction, std::shared_ptr<TransferFunctionTexture>>(m, "TransferFunctionTexture")
-        .def(py::init<>())
+    py::class_<TransferFunctionTexture, ITransferFunction, std::shared_ptr<TransferFunctionTexture>> ttex(m, "TransferFunctionTexture");
+    py::enum_<fvsrn_tf_preintegration>(ttex, "PreintegrationMode")  // transfer_function_texture.cpp:246-250
+        .value("Off", FVSRN_PREINTEGRATE_NONE).value("Preintegrate1D", FVSRN_PREINTEGRATE_1D).value("Preintegrate2D", FVSRN_PREINTEGRATE_2D).export_values();
+    ttex.def(py::init<>())
+        .def_property("preintegration_mode", [](TransferFunctionTexture& t) { return fvsrn_tf_preintegration(t.preintegrationMode); },
+                      [](TransferFunctionTexture& t, fvsrn_tf_preintegration v) { t.preintegrationMode = v; })
         .def_property("tensor", [](TransferFunctionTexture& t) { return t.tensor; }, &TransferFunctionTexture::setTensor);
     py::class_<BRDFLambert, std::shared_ptr<BRDFLambert>> bc(m, "BRDFLambert");  // brdf.cpp:256-273
     py::enum_<fvsrn_light_type>(bc, "LightType").value("Point", FVSRN_LIGHT_POINT).value("Directional", FVSRN_LIGHT_DIRECTIONAL).export_values();

@@ -186,7 +186,12 @@ typedef struct {
     int brdf_light_type;        /* fvsrn_light_type */
     float brdf_light[3];        /* light position (POINT) or direction (DIRECTIONAL); "light follows camera" is the
                                    caller's job: camera origin / front (brdf.cpp:490-508) */
+    /* TransferFunctionTexture::PreintegrationMode (transfer_function.h, device renderer_tf_texture.cuh:55-93): only with
+     * FVSRN_TF_TEXTURE and a 256-texel table; the tables are built on the device (transfer_function_texture_cuda.cu:9-90,
+     * 256 entries / 256 x 256 entries with 256 quadrature steps) whenever the table or the step size changes */
+    int tf_preintegration;      /* fvsrn_tf_preintegration */
 } fvsrn_scene_desc;
+typedef enum { FVSRN_PREINTEGRATE_NONE = 0, FVSRN_PREINTEGRATE_1D = 1, FVSRN_PREINTEGRATE_2D = 2 } fvsrn_tf_preintegration;
 typedef enum { FVSRN_GRADIENT_OFF_OR_DIRECT = 0, FVSRN_GRADIENT_FINITE_DIFFERENCES = 1 } fvsrn_gradient_mode;
 typedef enum { FVSRN_LIGHT_POINT = 0, FVSRN_LIGHT_DIRECTIONAL = 1 } fvsrn_light_type;
 

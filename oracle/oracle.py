@@ -49,7 +49,7 @@ class _OracleScene(C.Structure):
                 ("brdfMagnitudeScaling", C.c_int), ("brdfPhong", C.c_int), ("brdfLightType", C.c_int),
                 ("brdfSpecularExponent", C.c_int), ("brdfMagScale", C.c_float), ("brdfAmbient", C.c_float),
                 ("brdfSpecular", C.c_float), ("brdfMagCenter", C.c_float), ("brdfMagRadius", C.c_float),
-                ("brdfLight", C.c_float * 3)]
+                ("brdfLight", C.c_float * 3), ("tfPreintegration", C.c_int), ("tfPreintegrated", _FP)]
 
 
 _lib = None
@@ -68,6 +68,8 @@ def lib() -> C.CDLL:
         l = C.CDLL(LIB_PATH)
         l.oracle_eval_points.restype = C.c_int
         l.oracle_eval_points.argtypes = [C.POINTER(_OracleNet), _FP, _FP, C.c_size_t, _FP]
+        l.oracle_tf_preintegrate.restype = None
+        l.oracle_tf_preintegrate.argtypes = [_FP, C.c_int, C.c_int, C.c_float, C.c_int, _FP]
         l.oracle_eval_points_full.restype = C.c_int
         l.oracle_eval_points_full.argtypes = [C.POINTER(_OracleNet), _FP, _FP, C.c_size_t, _FP]
         l.oracle_render.restype = C.c_int
@@ -222,7 +224,7 @@ class OracleNetwork:
 class OracleScene:
     def __init__(self, *, eye, right, up, fov_y_radians, stepsize, density_min=0.0, density_max=1.0, early_out=True,
                  blend_mode=BLEND_BEER_LAMBERT, tf_kind=TF_IDENTITY, tf_scale_absorption=1.0, tf_scale_emission=1.0,
-                 tf_table=None, gradient_mode=0, finite_differences_stepsize=0.0, brdf=None):
+                 tf_table=None, gradient_mode=0, finite_differences_stepsize=0.0, brdf=None, tf_preintegration=0):
         s = _OracleScene()
         s.eye[:] = [float(v) for v in eye]
         s.right[:] = [float(v) for v in right]
@@ -237,6 +239,13 @@ class OracleScene:
             self._t = np.ascontiguousarray(tf_table, dtype=np.float32)
             s.tfTable = self._t.ctypes.data_as(_FP)
             s.tfRows = self._t.shape[0]
+        self._p = None
+        if tf_preintegration:
+            R = self._t.shape[0]
+            self._p = np.zeros((R, 4) if tf_preintegration == 1 else (R, R, 4), np.float32)
+            lib().oracle_tf_preintegrate(self._t.ctypes.data_as(_FP), R, tf_preintegration, stepsize, 256, self._p.ctypes.data_as(_FP))
+            s.tfPreintegration = tf_preintegration
+            s.tfPreintegrated = self._p.ctypes.data_as(_FP)
         s.gradientMode, s.fdStep = gradient_mode, finite_differences_stepsize
         if brdf:  # same keys as capi.Scene
             s.brdfPhong = int(brdf.get("enable_phong", False))

@@ -372,6 +372,87 @@ int oracle_eval_points_full(const OracleNet* n, const float* pos, const float* d
 /* ------------------------------------------------------------------------------------------- TFs */
 static float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
 
+/* tex1D<float4> with linear filtering, normalized coordinates, clamp addressing (exact fp32 weights; the hardware filter of
+ * the reference has 8 fractional bits) */
+static void tex1d(const float* tex, int R, float x, float o[4]) {
+    const float d = x * R - 0.5f;
+    const int di = (int)floorf(d);
+    const float f = d - di;
+    const int i0 = di < 0 ? 0 : (di > R - 1 ? R - 1 : di), i1 = di + 1 < 0 ? 0 : (di + 1 > R - 1 ? R - 1 : di + 1);
+    for (int k = 0; k < 4; ++k) o[k] = tex[4 * i0 + k] + f * (tex[4 * i1 + k] - tex[4 * i0 + k]);
+}
+static void tex2d(const float* tex, int R, float x, float y, float o[4]) {
+    const float dx = x * R - 0.5f, dy = y * R - 0.5f;
+    const int ix = (int)floorf(dx), iy = (int)floorf(dy);
+    const float fx = dx - ix, fy = dy - iy;
+#define CL(v) ((v) < 0 ? 0 : ((v) > R - 1 ? R - 1 : (v)))
+    const int x0 = CL(ix), x1 = CL(ix + 1), y0 = CL(iy), y1 = CL(iy + 1);
+#undef CL
+    for (int k = 0; k < 4; ++k) {
+        const float a = tex[4 * ((size_t)y0 * R + x0) + k], b = tex[4 * ((size_t)y0 * R + x1) + k];
+        const float c = tex[4 * ((size_t)y1 * R + x0) + k], d = tex[4 * ((size_t)y1 * R + x1) + k];
+        const float lo = a + fx * (b - a), hi = c + fx * (d - c);
+        o[k] = lo + fy * (hi - lo);
+    }
+}
+
+void oracle_tf_preintegrate(const float* tex, int R, int mode, float stepsize, int N, float* out) {
+    if (mode == 1) { /* Compute1DPreintegrationTableKernel :9-36 */
+        float integral[4] = {0, 0, 0, 0}, last[4], v[4];
+        float lastDensity = 0.f;
+        tex1d(tex, R, lastDensity, last);
+        for (int i = 0; i < R; ++i) {
+            const float cur = ((float)i + 0.5f) / (float)R;
+            tex1d(tex, R, cur, v);
+            const float w = cur - lastDensity;
+            for (int k = 0; k < 3; ++k) integral[k] += w * 0.5f * (last[k] * last[3] + v[k] * v[3]);
+            integral[3] += w * 0.5f * (last[3] + v[3]);
+            for (int k = 0; k < 4; ++k) { out[4 * i + k] = integral[k]; last[k] = v[k]; }
+            lastDensity = cur;
+        }
+        return;
+    }
+#pragma omp parallel for schedule(static)
+    for (int iend = 0; iend < R; ++iend) /* Compute2DPreintegrationTableKernel :50-79 */
+        for (int istart = 0; istart < R; ++istart) {
+            const float dstart = ((float)istart + 0.5f) / (float)R, dend = ((float)iend + 0.5f) / (float)R;
+            float rgb[3] = {0, 0, 0}, alphaSum = 0, v[4];
+            const float h = 1.0f / (float)N;
+            for (int i = 1; i <= N; ++i) {
+                const float omega = i * h;
+                tex1d(tex, R, (1 - omega) * dstart + omega * dend, v);
+                alphaSum += v[3] * h * stepsize;
+                const float k = h * v[3] * stepsize * expf(-alphaSum);
+                rgb[0] += k * v[0]; rgb[1] += k * v[1]; rgb[2] += k * v[2];
+            }
+            float* o = out + 4 * ((size_t)iend * R + istart);
+            o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2]; o[3] = 1 - expf(-alphaSum);
+        }
+}
+
+/* TransferFunctionTexture::eval with pre-integration, renderer_tf_texture.cuh:55-93; density is clamped */
+static void tf_eval_preintegrated(const OracleScene* s, float density, float previousDensity, float c[4]) {
+    density = density < 0 ? 0 : (density > 1 ? 1 : density);
+    if (previousDensity < 0) previousDensity = density;
+    if (s->tfPreintegration == 1) {
+        if (fabsf(previousDensity - density) < 1e-3f) {
+            tex1d(s->tfTable, s->tfRows, density, c);
+            c[3] *= s->stepsize;
+        } else {
+            float f[4], b[4];
+            tex1d(s->tfPreintegrated, s->tfRows, previousDensity, f);
+            tex1d(s->tfPreintegrated, s->tfRows, density, b);
+            const float inv = 1.0f / (density - previousDensity);
+            for (int k = 0; k < 3; ++k) c[k] = s->stepsize * (b[k] - f[k]) * inv;
+            c[3] = 1 - expf(-s->stepsize * (b[3] - f[3]) * inv);
+            if (c[3] > 1e-5f) { c[0] /= c[3]; c[1] /= c[3]; c[2] /= c[3]; }
+        }
+    } else {
+        tex2d(s->tfPreintegrated, s->tfRows, previousDensity, density, c);
+        if (c[3] > 1e-5f) { c[0] /= c[3]; c[1] /= c[3]; c[2] /= c[3]; }
+    }
+}
+
 static void tf_eval(const OracleScene* s, float density, float c[4]) {
     density = clamp01(density);
     c[0] = c[1] = c[2] = c[3] = 0.f;
@@ -443,6 +524,7 @@ static void render_pixel(const OracleNet* n, const OracleScene* s, int W, int H,
     const float divRange = 1.0f / (s->densityMax - s->densityMin);
     const int rgbo = n->outputMode == ORACLE_OUT_RGBO || n->outputMode == ORACLE_OUT_RGBO_DIRECT;
     float col[4] = {0, 0, 0, 0}, nacc[3] = {0, 0, 0}, depth = 0;
+    float previousDensity = -1.f; /* :81 */
     unsigned long long cnt = 0;
     for (int i = 0;; ++i) { /* :84-154, per-lane view of the warp-synchronous loop */
         const float t = tmin + (float)i * s->stepsize;
@@ -468,8 +550,10 @@ static void render_pixel(const OracleNet* n, const OracleScene* s, int W, int H,
                     }
                     g[0] = (vv[0] - vv[1]) / (2 * h); g[1] = (vv[2] - vv[3]) / (2 * h); g[2] = (vv[4] - vv[5]) / (2 * h);
                 }
-                tf_eval(s, density2, c); /* :113-133 */
+                if (s->tfPreintegration) tf_eval_preintegrated(s, density2, previousDensity, c);
+                else tf_eval(s, density2, c); /* :113-133 */
             }
+            previousDensity = density2; /* :135 */
         }
         if (c[3] > 0 && (s->brdfMagnitudeScaling || s->brdfPhong)) { /* BRDFLambert::eval, renderer_brdf_lambert.cuh:56-103 */
             const float g2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];

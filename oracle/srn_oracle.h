@@ -59,7 +59,13 @@ typedef struct {
     int brdfMagnitudeScaling, brdfPhong, brdfLightType /* 0 point, 1 directional */, brdfSpecularExponent;
     float brdfMagScale, brdfAmbient, brdfSpecular, brdfMagCenter, brdfMagRadius;
     float brdfLight[3];
+    /* TransferFunctionTexture pre-integration (renderer_tf_texture.cuh:55-93): 0 none, 1: table [R][4], 2: [R][R][4];
+     * built by oracle_tf_preintegrate (transfer_function_texture_cuda.cu:9-90) */
+    int tfPreintegration;
+    const float* tfPreintegrated;
 } OracleScene;
+/* tex [R][4] -> out [R][4] (mode 1) or [R][R][4] (mode 2, N quadrature steps, world step size) */
+void oracle_tf_preintegrate(const float* tex, int R, int mode, float stepsize, int N, float* out);
 
 int oracle_eval_points(const OracleNet* n, const float* worldPos, const float* directions /* or NULL */, size_t count, float* out);
 /* all raw outputs of eval<>: out[count][9] = value[4], normal[3], curvature[2] */

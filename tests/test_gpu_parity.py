@@ -276,6 +276,27 @@ def test_shaded_render_matches_oracle(case):
     assert abs(int(stats[0]) - count) <= max(2, count // 1000)
 
 
+TEX256 = np.stack([0.5 + 0.5 * np.sin(np.arange(256) / 20.0), np.linspace(0, 1, 256), np.linspace(1, 0, 256) ** 2,
+                   60.0 * (0.5 + 0.5 * np.cos(np.arange(256) / 33.0))], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("act", ["SnakeAlt", "ReLU"])
+def test_preintegrated_texture_tf_matches_oracle(mode, act):
+    """TransferFunctionTexture with Preintegrate1D / Preintegrate2D (renderer_tf_texture.cuh:55-93): tables built on the
+    device like transfer_function_texture_cuda.cu:9-90, previous-density state per ray."""
+    vn = util.random_network(C=32, layers=4, activation=act, output_mode="density", seed=41, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4)
+    kw = make_scene_kwargs(early_out=True, tf_kind=oracle.TF_TEXTURE, tf_table=TEX256, tf_preintegration=mode)
+    img, ref, stats, count = render_both(vn, kw, 40, 24)
+    assert img[3].max() > 0.05
+    assert_images_close(img, ref, TOL_IMG)
+    assert abs(int(stats[0]) - count) <= max(2, count // 1000)
+    # another step size rebuilds the 2D table
+    kw2 = make_scene_kwargs(stepsize=1 / 30, early_out=True, tf_kind=oracle.TF_TEXTURE, tf_table=TEX256, tf_preintegration=mode)
+    img2, ref2, _, _ = render_both(vn, kw2, 40, 24)
+    assert_images_close(img2, ref2, TOL_IMG)
+
+
 def test_adjoint_gradient_mode_fails_loudly():
     from fvsrn_amd import capi
     with pytest.raises(capi.FvsrnError) as e:

@@ -139,10 +139,9 @@ def test_scene_files_with_piecewise_and_texture_tfs_load(tmp_path):
     t = pr.load_from_json(str(p)).ray_evaluator.tf.tensor.numpy()[0]
     ref = oracle.tf_texture_table(TEXTURE_JSON["colorPoints"], TEXTURE_JSON["opacityPoints"], 40.0)
     assert t.shape == (256, 4) and np.abs(t - ref).max() < 1e-6
-    bad = dict(TEXTURE_JSON, preintegrationMode="Preintegrate2D")
-    p.write_text(json.dumps(_scene_json("Texture", bad)))
-    with pytest.raises(RuntimeError, match="preintegrationMode"):
-        pr.load_from_json(str(p))
+    pre = dict(TEXTURE_JSON, preintegrationMode="Preintegrate2D")
+    p.write_text(json.dumps(_scene_json("Texture", pre)))
+    assert pr.load_from_json(str(p)).ray_evaluator.tf.preintegration_mode == pr.TransferFunctionTexture.PreintegrationMode.Preintegrate2D
 
 
 REFERENCE_SCENES = "/root/reference/applications/config-files"
@@ -162,8 +161,6 @@ def test_reference_scene_files_load_unchanged():
         expect_error = None
         if sel != "DVR":
             expect_error = "ray evaluator"
-        elif tfsel == "Texture" and jt.get("preintegrationMode", "None") not in ("None", ""):
-            expect_error = "preintegrationMode"
         if expect_error:
             with pytest.raises(RuntimeError, match=expect_error):
                 pr.load_from_json(f)
@@ -178,7 +175,7 @@ def test_reference_scene_files_load_unchanged():
             assert np.abs(ev.ray_evaluator.tf.tensor.numpy()[0] - ref).max() < 1e-5, f
         b = d.get("brdf", {}).get("Lambert", {})
         assert ev.ray_evaluator.brdf.enable_phong == b.get("enablePhong", False), f
-    assert loaded >= 19
+    assert loaded >= 22
 
 
 def test_extract_color_rejects_host_tensors():
