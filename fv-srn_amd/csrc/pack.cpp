@@ -291,7 +291,13 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
                 }
             for (int r = 0; r < C; ++r) bias[size_t(l) * 32 * MT + r] = std::ldexp(half_bits_to_float(L.bias[size_t(r)]), kB);
         }
-        // last layer: outputs replicated on rows 0..3 and 4..7 so both lane halves see them
+        // Last layer (C -> 1|4): one v_mfma_f32_16x16x32_f16 per K step and tile -- 16 output rows instead of 32 halve
+        // the padding of a 1..4-row matrix.  That instruction reads the SAME B registers differently: lane l supplies
+        // column n = l % 16 and K slots 8*(l / 16) .. +7, so column n sees the two samples n (lane groups 0, 2: channel
+        // slots 0-7 / 8-15 of the K step) and n + 16 (lane groups 1, 3).  Rows 4g + o of the fragment carry output o for
+        // the lanes 16g .. 16g+15 that will read it (D rows 4*(l/16) + r live in lane l): rows of even g take the
+        // weights on the K slots of sample n, rows of odd g on those of sample n + 16.  A fragment: lane l = row l % 16,
+        // K slots 8*(l / 16) .. +7.
         const Layer& L = net.hidden.back();
         if (L.channelsIn != C || L.channelsOut != Cout) throw InvalidNetwork("last layer shape mismatch");
         const bool transposed = L.channelsIn < 16 || L.channelsOut < 16;  // addLayer stores [in][out]
@@ -299,9 +305,11 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
         for (int s = 0; s < KS; ++s) {
             Frag f{};
             for (int lane = 0; lane < 64; ++lane) {
-                const int row = lane & 31, h = lane >> 5;
-                if (row >= 8 || (row & 3) >= Cout) continue;  // outputs 0..3 (curvature outputs 4,5 have no consumer on this path)
-                const int o = row & 3;
+                const int m = lane & 15, kg = lane >> 4;  // row, K group
+                const int o = m & 3, g = m >> 2;          // output, consumer lane group
+                if (o >= Cout) continue;                  // outputs 0..3 (curvature outputs 4,5 have no consumer on this path)
+                if ((kg & 1) != (g & 1)) continue;        // K groups 0,2 belong to sample n, 1,3 to sample n + 16
+                const int h = kg >> 1;                    // lane half of the data: channel slots 8h .. 8h+7
                 for (int j = 0; j < 8; ++j) {
                     const int col = chiOfSlot(16 * s + 8 * h + j);
                     f.v[lane][j] = scaleHalf(transposed ? L.weights[size_t(col) * Cout + o] : L.weights[size_t(o) * C + col], kL);
@@ -310,7 +318,7 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
             putFrag(img, size_t(np.offLast) + size_t(s) * kFragBytes, f);
         }
         float* bl = bias + size_t(NL) * 32 * MT;
-        for (int o = 0; o < std::min(Cout, 4); ++o) bl[o] = bl[4 + o] = half_bits_to_float(L.bias[size_t(o)]);
+        for (int o = 0; o < std::min(Cout, 4); ++o) bl[o] = half_bits_to_float(L.bias[size_t(o)]);  // C operand rows 4g + o, any g
     };
     packLayers(P.ldsImage, nullptr);
 
@@ -379,7 +387,8 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
         np.boxSize[i] = net.boxSize[i];
         np.invBoxSize[i] = 1.0f / net.boxSize[i];
     }
-    P.mfmaFlopsPerSample = 1024.0 * (MT + (NL > 0 ? double(MT) * KS0 : 0.0) + double(std::max(NL - 1, 0)) * MT * KS + KS);
+    // 32x32x16: 32768 FLOP per 32 samples; the last layer runs 16x16x32 MFMAs (16384 FLOP per 32 samples)
+    P.mfmaFlopsPerSample = 1024.0 * (MT + (NL > 0 ? double(MT) * KS0 : 0.0) + double(std::max(NL - 1, 0)) * MT * KS + 0.5 * KS);
     return P;
 }
 

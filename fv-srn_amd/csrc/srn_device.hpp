@@ -11,8 +11,8 @@
 //     B operand of layer l+1 -- weights were permuted on the host for that (pack.cpp); the
 //     reference round-trips activations through shared memory every layer (:1019-1023)
 //   * biases enter as the MFMA C operand (fp32), accumulation is fp32 (reference: half, :965)
-//   * the last (C -> 1|4) layer is one more MFMA whose rows are replicated for both lane halves,
-//     replacing the per-lane hfma loop :1138-1143
+//   * the last (C -> 1|4) layer is a v_mfma_f32_16x16x32_f16 per K step and tile on the same B fragments (its weight
+//     fragment routes every output to the lane that owns the sample, pack.cpp), replacing the per-lane hfma loop :1138-1143
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -515,8 +515,8 @@ __device__ __forceinline__ void fourier_advance_piece(floatx16 (&f)[2][mtiles(CD
 //     l+1 -- weights were permuted on the host for that (pack.cpp); the reference round-trips activations through shared
 //     memory every layer (renderer_volume_tensorcores.cuh:1019-1023)
 //   * biases enter as the MFMA C operand (fp32), accumulation is fp32 (reference: half, :965)
-//   * the last (C -> 1|4) layer is one more MFMA whose rows are replicated for both lane halves, replacing the per-lane
-//     hfma loop :1138-1143
+//   * the last (C -> 1|4) layer is a v_mfma_f32_16x16x32_f16 per K step and tile on the same B fragments (its weight
+//     fragment routes every output to the lane that owns the sample, pack.cpp), replacing the per-lane hfma loop :1138-1143
 //
 // Schedule (Fourier-only networks up to 64 wide).  The two sample tiles t0,t1 of the wave run half a layer apart:
 //     A_l: MFMAs of layer l for t0   ||  activation+convert of layer l-1 for t1, bias(l)   -> accumulators of t1
@@ -659,23 +659,23 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
         slot(T1{}, Yes{}, P.offBias + (l + 1) * kBiasLayer, l + 1 < NL ? P.offHidden + l * NM * kFragBytes : P.offLast);
     }
 
-    // ---- last layer (rows replicated for both lane halves; its fragments are a[0..KS-1], its bias is in place) ----
-    interleave<KS, NV>([&](int s) { acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], xb[0][s], acc[0][0], 0, 0, 0); },
+    // ---- last layer: 16x16x32 MFMAs (pack.cpp) on the same B fragments; its weight fragments are a[0..KS-1]; output r of
+    // this lane's tile-(lane>>5) sample lands in register r ----------------------------------------------------------------
+    const float4_t biasLast = *reinterpret_cast<const float4_t*>(lds + P.offBias + NL * kBiasLayer);
+    float4_t o0 = biasLast, o1 = biasLast;
+    interleave<KS, NV>([&](int s) { o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s], xb[0][s], o0, 0, 0, 0); },
                        [&](int j) {
                            const int m = j / 4, q = j % 4;
                            act_pack_quarter<ACT>(acc[1][m], q, actA, actB, xb[1][2 * m], xb[1][2 * m + 1]);
-                           if (j == 3) acc[1][0] = bias(P.offBias + NL * kBiasLayer);
                        });
-    interleave<KS, NFILL - NF0>([&](int s) { acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], xb[1][s], acc[1][0], 0, 0, 0); },
+    interleave<KS, NFILL - NF0>([&](int s) { o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s], xb[1][s], o1, 0, 0, 0); },
                                 [&](int j) { fill(NF0 + j); });
-
-    // rows 0..3 (lane half 0) and rows 4..7 (lane half 1) both carry outputs 0..3 of sample c of the tile
     float4_t out = {0, 0, 0, 0};
-    out[0] = h ? acc[1][0][0] : acc[0][0][0];
+    out[0] = h ? o1[0] : o0[0];
     if (P.outputMode >= FVSRN_OUT_RGBO) {  // wave-uniform: only colour / gradient networks have outputs 1..3
-        out[1] = h ? acc[1][0][1] : acc[0][0][1];
-        out[2] = h ? acc[1][0][2] : acc[0][0][2];
-        out[3] = h ? acc[1][0][3] : acc[0][0][3];
+        out[1] = h ? o1[1] : o0[1];
+        out[2] = h ? o1[2] : o0[2];
+        out[3] = h ? o1[3] : o0[3];
     }
     return out;
 }
@@ -732,16 +732,15 @@ __device__ __forceinline__ float4_t srn_layers_kmajor(const NetParams& P, const 
             for (int m = 0; m < MT; ++m) act_pack<ACT>(acc[t][m], actA, actB, xb[t][2 * m], xb[t][2 * m + 1]);
     }
 
-    // ---- last layer ----------------------------------------------------------------------------------------
-    const floatx16 biasL = lds_bias(lds, P.offBias + NL * 32 * MT * 4, 0);  // rows 0..7 hold the (replicated) bias
-    floatx16 o0 = biasL, o1 = biasL;
+    // ---- last layer: 16x16x32 MFMAs (pack.cpp); output r of this lane's tile-(lane>>5) sample lands in register r ------
+    const float4_t biasLast = *reinterpret_cast<const float4_t*>(lds + P.offBias + NL * 32 * MT * 4);
+    float4_t o0 = biasLast, o1 = biasLast;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const half8_t a = lds_frag(lds, P.offLast + s * kFragBytes, lane);
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[0][s], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[1][s], o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[0][s], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[1][s], o1, 0, 0, 0);
     }
-    // rows 0..3 (lane half 0) and rows 4..7 (lane half 1) both carry outputs 0..3 of sample c of the tile
     float4_t out = {0, 0, 0, 0};
     out[0] = h ? o1[0] : o0[0];
     if (P.outputMode >= FVSRN_OUT_RGBO) {  // wave-uniform: only colour / gradient networks have outputs 1..3
