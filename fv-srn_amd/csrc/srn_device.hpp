@@ -559,14 +559,20 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[t][m] = bias(P.offBias + m * 128);
     const int offGridW = P.offLayer0 + NM * kFragBytes;  // [g][m] fragments of the latent K steps
+    // (the latent-step fragments are only prefetched where registers allow: at 64 wide it would spill)
+    constexpr bool PREFETCH_AG = MT == 1;
+    // first latent chunk fetched ahead and reduced behind the first layer's MFMAs: only where its 32 registers fit
+    constexpr bool GRID_AHEAD = GRID == 1 && MT == 1;
     half8_t ag[MT];
     GridTap gt[2];
     GridRaw raw;
     if constexpr (GRID != 0) {
+        if constexpr (PREFETCH_AG) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) ag[m] = frag(offGridW + m * kFragBytes);
+            for (int m = 0; m < MT; ++m) ag[m] = frag(offGridW + m * kFragBytes);
+        }
         grid_tap_bcast<GRID == 2>(grid_tap(P, px, py, pz), gt[0], gt[1]);
-        if constexpr (GRID == 1) grid_load(P.grid, gt[0], 0, h, raw);
+        if constexpr (GRID_AHEAD) grid_load(P.grid, gt[0], 0, h, raw);
     }
     __builtin_amdgcn_sched_barrier(0);
     pre();
@@ -577,7 +583,7 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
     constexpr int NF0 = NFILL / 2;
     // ---- first layer, tile 0 -------------------------------------------------------------------------------------
     half8_t gf;
-    if constexpr (GRID == 1) {
+    if constexpr (GRID_AHEAD) {
         float gacc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) gacc[j] = 0.f;
@@ -595,10 +601,10 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
     }
     if constexpr (GRID != 0) {
         for (int g = 0; g < P.gridK; ++g) {
-            if (GRID == 2 || g > 0) gf = grid_features<GRID>(P, gt[0], g, h);
+            if (!GRID_AHEAD || g > 0) gf = grid_features<GRID>(P, gt[0], g, h);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const half8_t w = g == 0 ? ag[m] : frag(offGridW + (g * MT + m) * kFragBytes);
+                const half8_t w = (PREFETCH_AG && g == 0) ? ag[m] : frag(offGridW + (g * MT + m) * kFragBytes);
                 acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, gf, acc[0][m], 0, 0, 0);
             }
         }
@@ -630,7 +636,7 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
     slot(T1{}, Yes{}, P.offBias + kBiasLayer, NL > 1 ? P.offHidden : P.offLast);
     if constexpr (GRID != 0) {
         for (int g = 0; g < P.gridK; ++g) {
-            if (GRID == 1 && g == 0) {
+            if (GRID_AHEAD && g == 0) {
                 float gacc[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) gacc[j] = 0.f;
@@ -642,7 +648,7 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const half8_t w = g == 0 ? ag[m] : frag(offGridW + (g * MT + m) * kFragBytes);
+                const half8_t w = (PREFETCH_AG && g == 0) ? ag[m] : frag(offGridW + (g * MT + m) * kFragBytes);
                 acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, gf, acc[1][m], 0, 0, 0);
             }
         }
