@@ -97,6 +97,8 @@ SYMBOLS = [
     ("fvsrn_render_stripes", _I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     ("fvsrn_extract_color", _I, [_VP, _I, _I, _I, _I, _F, _VP, _VP]),
     ("fvsrn_extract_color_rgba8", _I, [_VP, _I, _I, _I, _I, _F, _VP, _VP]),
+    ("fvsrn_generate_rays", _I, [_FP, _FP, _FP, _F, _I, _I, _VP, _VP, _VP]),
+    ("fvsrn_scene_evaluate_tf", _I, [_VP, _VP, _VP, _SZ, _F, _F, _F, _VP, _VP]),
     ("fvsrn_network_kernel_name", _I, [_VP, _I, C.c_char_p, _SZ]),
 ]
 
@@ -331,6 +333,17 @@ class Scene:
             d.brdf_light[:] = [float(v) for v in brdf.get("light", (0.0, 0.0, 1.0))]
         return d
 
+    def evaluate_tf(self, densities, density_min: float, density_max: float, previous=None, stepsize: float = 1.0, stream=None):
+        """ITransferFunction::evaluate / evaluate_with_previous on a (B,1) fp32 CUDA tensor -> (B,4)."""
+        import torch
+        n = int(densities.shape[0])
+        out = torch.empty((n, 4), dtype=torch.float32, device=densities.device)
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _check(lib().fvsrn_scene_evaluate_tf(self._h, _torch_ptr(densities, "torch.float32", "densities"),
+                                             _torch_ptr(previous, "torch.float32", "previous densities") if previous is not None else None,
+                                             n, density_min, density_max, stepsize, out.data_ptr(), s))
+        return out
+
     def update(self, **kw):
         d = self._desc(**kw)
         _check(lib().fvsrn_scene_update(self._h, C.byref(d)))
@@ -403,3 +416,14 @@ def extract_color(raw, channel_mode: int = CHANNEL_COLOR, use_tonemapping: bool 
         out = torch.empty((1, 4, H, W), dtype=torch.float32, device=raw.device)
         _check(lib().fvsrn_extract_color(src, W, H, channel_mode, int(use_tonemapping), max_exposure, out.data_ptr(), s))
     return out
+
+
+def generate_rays(eye, right, up, fov_y_radians: float, width: int, height: int, stream=None):
+    """ICamera::generateRays: (ray_start, ray_dir), each (1,H,W,3) fp32 on the GPU."""
+    import torch
+    start = torch.empty((1, height, width, 3), dtype=torch.float32, device="cuda")
+    direction = torch.empty_like(start)
+    e, r, u = (np.ascontiguousarray(v, np.float32) for v in (eye, right, up))
+    s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    _check(lib().fvsrn_generate_rays(_fptr(e), _fptr(r), _fptr(u), fov_y_radians, width, height, start.data_ptr(), direction.data_ptr(), s))
+    return start, direction

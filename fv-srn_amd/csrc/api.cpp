@@ -264,6 +264,37 @@ struct fvsrn_scene {
     std::vector<int> order;
     ~fvsrn_scene() { dTf.release(); dOrder.release(); dCounters.release(); dPartial.release(); dPreint.release(); }
 
+    // TF table (and, for pre-integrated Texture TFs, its tables) on the device, for step size `stepsize`
+    int uploadTf(float stepsize, hipStream_t s) {
+        const fvsrn_scene_desc& d = desc;
+        const size_t tfFloats = tfTable.size();
+        const bool tfChanged = tfDirty;
+        try {
+            if (tfDirty) {
+                if (tfFloats) {
+                    dTf.ensure(tfFloats * 4);
+                    HIP_CHECK(hipMemcpyAsync(dTf.ptr, tfTable.data(), tfFloats * 4, hipMemcpyHostToDevice, s));
+                }
+                tfDirty = false;
+            }
+            // TransferFunctionTexture::updatePreintegrationTable (transfer_function_texture.cpp:364-379): rebuilt when the
+            // texture or (2D) the step size changed
+            if (d.tf_preintegration != FVSRN_PREINTEGRATE_NONE &&
+                (tfChanged || preintMode != d.tf_preintegration || (d.tf_preintegration == FVSRN_PREINTEGRATE_2D && preintStepsize != stepsize))) {
+                const int R = d.tf_rows;
+                dPreint.ensure(size_t(d.tf_preintegration == FVSRN_PREINTEGRATE_2D ? R : 1) * R * 4 * sizeof(float));
+                const hipError_t e = launch_tf_preintegration(static_cast<const float*>(dTf.ptr), static_cast<float*>(dPreint.ptr), R,
+                                                              d.tf_preintegration, stepsize, 256, s);
+                if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("pre-integration failed: ") + hipGetErrorString(e));
+                preintMode = d.tf_preintegration;
+                preintStepsize = stepsize;
+            }
+        } catch (const DeviceError& e) {
+            return fail(FVSRN_ERR_DEVICE, e.what());
+        }
+        return FVSRN_OK;
+    }
+
     // Two work counters for the persistent render waves.  Launches of one scene must be ordered on one stream
     // (like everything else a scene owns: TF table, tile order).
     bool tileCounters(hipStream_t stream, int** cur, int** next) {
@@ -728,27 +759,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             if (numLocalRows == 0) return FVSRN_OK;
 
             const size_t tfFloats = scene->tfTable.size();
-            const bool tfChanged = scene->tfDirty;
-            if (scene->tfDirty) {
-                if (tfFloats) {
-                    scene->dTf.ensure(tfFloats * 4);
-                    HIP_CHECK(hipMemcpyAsync(scene->dTf.ptr, scene->tfTable.data(), tfFloats * 4, hipMemcpyHostToDevice, s));
-                }
-                scene->tfDirty = false;
-            }
-            // TransferFunctionTexture::updatePreintegrationTable (transfer_function_texture.cpp:364-379): rebuilt when the
-            // texture or (2D) the step size changed
-            if (d.tf_preintegration != FVSRN_PREINTEGRATE_NONE &&
-                (tfChanged || scene->preintMode != d.tf_preintegration ||
-                 (d.tf_preintegration == FVSRN_PREINTEGRATE_2D && scene->preintStepsize != d.stepsize))) {
-                const int R = d.tf_rows;
-                scene->dPreint.ensure(size_t(d.tf_preintegration == FVSRN_PREINTEGRATE_2D ? R : 1) * R * 4 * sizeof(float));
-                const hipError_t e = launch_tf_preintegration(static_cast<const float*>(scene->dTf.ptr), static_cast<float*>(scene->dPreint.ptr), R,
-                                                              d.tf_preintegration, d.stepsize, 256, s);
-                if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("pre-integration failed: ") + hipGetErrorString(e));
-                scene->preintMode = d.tf_preintegration;
-                scene->preintStepsize = d.stepsize;
-            }
+            if (const int rc = scene->uploadTf(d.stepsize, s)) return rc;
             RenderArgs a{};
             a.P = net->packed.params;
             a.shaded = d.gradient_mode == FVSRN_GRADIENT_FINITE_DIFFERENCES || d.brdf_enable_phong || d.brdf_enable_magnitude_scaling ||
@@ -903,6 +914,58 @@ int fvsrn_extract_color(const float* d_raw8, int width, int height, int channel_
 int fvsrn_extract_color_rgba8(const float* d_raw8, int width, int height, int channel_mode, int use_tonemapping,
                               float max_exposure, unsigned int* d_out, void* stream) {
     return extractImpl(d_raw8, width, height, channel_mode, use_tonemapping, max_exposure, nullptr, d_out, stream);
+}
+
+int fvsrn_generate_rays(const float eye[3], const float right[3], const float up[3], float fov_y_radians, int width, int height,
+                        float* d_ray_start, float* d_ray_dir, void* stream) {
+    if (!eye || !right || !up || !d_ray_start || !d_ray_dir) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null pointer");
+    if (width <= 0 || height <= 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad image size");
+    return guarded([&]() -> int {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+            return fail(FVSRN_ERR_NO_DEVICE, "no HIP device available: the MI355X kernels cannot run (there is no CPU fallback)");
+        SceneParams S{};
+        for (int i = 0; i < 3; ++i) { S.eye[i] = eye[i]; S.right[i] = right[i]; S.up[i] = up[i]; }
+        S.front[0] = S.up[1] * S.right[2] - S.up[2] * S.right[1];  // cross(up, right), renderer_camera.cuh:47
+        S.front[1] = S.up[2] * S.right[0] - S.up[0] * S.right[2];
+        S.front[2] = S.up[0] * S.right[1] - S.up[1] * S.right[0];
+        S.tanFovY = std::tan(fov_y_radians / 2);
+        S.tanFovX = S.tanFovY * (float(width) / float(height));
+        S.width = width; S.height = height;
+        const hipError_t e = launch_generate_rays(S, d_ray_start, d_ray_dir, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("generate_rays failed: ") + hipGetErrorString(e));
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_scene_evaluate_tf(fvsrn_scene* scene, const float* d_density, const float* d_previous_density, size_t n, float density_min,
+                            float density_max, float stepsize, float* d_colors, void* stream) {
+    if (!scene || !d_density || !d_colors) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null pointer");
+    return guarded([&]() -> int {
+        std::lock_guard<std::mutex> lock(scene->mu);
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+            return fail(FVSRN_ERR_NO_DEVICE, "no HIP device available: the MI355X kernels cannot run (there is no CPU fallback)");
+        const fvsrn_scene_desc& d = scene->desc;
+        if (d.tf_kind == FVSRN_TF_NONE) return fail(FVSRN_ERR_INVALID_ARGUMENT, "the scene has no transfer function");
+        if (n == 0) return FVSRN_OK;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        // evaluate(): no previous density, step size 1; evaluate_with_previous(): the caller's step size
+        const float step = d_previous_density ? stepsize : 1.0f;
+        if (const int rc = scene->uploadTf(step, s)) return rc;
+        SceneParams S{};
+        S.stepsize = step;
+        S.densityMin = density_min;
+        S.divDensityRange = 1.0f / (density_max - density_min);
+        S.tfKind = d.tf_kind; S.tfRows = d.tf_rows;
+        S.tfScaleAbsorption = d.tf_scale_absorption; S.tfScaleEmission = d.tf_scale_emission;
+        S.tfTable = static_cast<const float*>(scene->dTf.ptr);
+        S.tfPreintegration = d.tf_preintegration;
+        S.tfPreintegrated = static_cast<const float*>(scene->dPreint.ptr);
+        const hipError_t e = launch_evaluate_tf(S, d_density, d_previous_density, n, d_colors, s);
+        if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("evaluate_tf failed: ") + hipGetErrorString(e));
+        return FVSRN_OK;
+    });
 }
 
 int fvsrn_stripe_rows(int height, int stripe_rows, int rank, int world) {

@@ -1,5 +1,7 @@
 #include "launch.hpp"
 
+#include "kernels.hpp"
+
 #include <algorithm>
 
 namespace fvsrn {
@@ -235,6 +237,52 @@ __global__ void tf_preintegrate_2d_kernel(const float* __restrict__ tex, float* 
 hipError_t launch_tf_preintegration(const float* tex, float* out, int R, int mode, float stepsize, int quadratureSteps, hipStream_t s) {
     if (mode == 1) hipLaunchKernelGGL(tf_preintegrate_1d_kernel, dim3(1), dim3(64), 0, s, tex, out, R);
     else hipLaunchKernelGGL(tf_preintegrate_2d_kernel, dim3((R + 63) / 64, R), dim3(64), 0, s, tex, out, R, stepsize, quadratureSteps);
+    return hipGetLastError();
+}
+
+// ---- tensor APIs of the camera and the transfer functions ------------------------------------------------------------------
+// CameraGenerateRayKernel (renderer_camera_kernels.cuh:12-43) with CameraReferenceFrame::eval (renderer_camera.cuh:33-52)
+__global__ void generate_rays_kernel(SceneParams S, float* __restrict__ rayStart, float* __restrict__ rayDir) {
+    const size_t n = size_t(S.width) * S.height;
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const int x = int(i % size_t(S.width)), y = int(i / size_t(S.width));
+        const float ndcx = 2.f * (float(x) + 0.5f) / float(S.width) - 1.f;
+        const float ndcy = 2.f * (float(y) + 0.5f) / float(S.height) - 1.f;
+        float dx = S.front[0] + ndcx * S.tanFovX * S.right[0] + ndcy * S.tanFovY * S.up[0];
+        float dy = S.front[1] + ndcx * S.tanFovX * S.right[1] + ndcy * S.tanFovY * S.up[1];
+        float dz = S.front[2] + ndcx * S.tanFovX * S.right[2] + ndcy * S.tanFovY * S.up[2];
+        const float invLen = rsqrtf(dx * dx + dy * dy + dz * dz);
+        rayStart[3 * i + 0] = S.eye[0]; rayStart[3 * i + 1] = S.eye[1]; rayStart[3 * i + 2] = S.eye[2];
+        rayDir[3 * i + 0] = dx * invLen; rayDir[3 * i + 1] = dy * invLen; rayDir[3 * i + 2] = dz * invLen;
+    }
+}
+hipError_t launch_generate_rays(const SceneParams& S, float* rayStart, float* rayDir, hipStream_t s) {
+    const size_t n = size_t(S.width) * S.height;
+    hipLaunchKernelGGL(generate_rays_kernel, dim3(unsigned(std::min<size_t>((n + 255) / 256, 8192))), dim3(256), 0, s, S, rayStart, rayDir);
+    return hipGetLastError();
+}
+
+// EvaluateTF / EvaluateTFWithPrevious (renderer_tf_kernels.cuh:11-70); S.stepsize is the step size the TF multiplies in
+__global__ void evaluate_tf_kernel(SceneParams S, const float* __restrict__ density, const float* __restrict__ previous, size_t n,
+                                   float* __restrict__ colors) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        const float d = density[i];
+        float4_t c = {0, 0, 0, 0};
+        if (d >= S.densityMin) {
+            const float d2 = (d - S.densityMin) * S.divDensityRange;
+            if (S.tfPreintegration != FVSRN_PREINTEGRATE_NONE) {
+                const float p = previous ? previous[i] : -1.f;
+                const float p2 = p >= 0.f ? (p - S.densityMin) * S.divDensityRange : -1.f;
+                c = tf_eval_preintegrated(S, S.tfTable, fminf(fmaxf(d2, 0.f), 1.f), p2);
+            } else {
+                c = tf_eval(S, S.tfTable, d2);
+            }
+        }
+        colors[4 * i + 0] = c[0]; colors[4 * i + 1] = c[1]; colors[4 * i + 2] = c[2]; colors[4 * i + 3] = c[3];
+    }
+}
+hipError_t launch_evaluate_tf(const SceneParams& S, const float* density, const float* previous, size_t n, float* colors, hipStream_t s) {
+    hipLaunchKernelGGL(evaluate_tf_kernel, dim3(unsigned(std::min<size_t>((n + 255) / 256, 8192))), dim3(256), 0, s, S, density, previous, n, colors);
     return hipGetLastError();
 }
 

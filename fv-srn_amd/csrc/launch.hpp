@@ -83,6 +83,10 @@ hipError_t launch_composite(const float* partial, float* out, int segments, unsi
 // mode 1 -> out [R][4], mode 2 -> out [R][R][4] (row = current density index, column = previous density index)
 hipError_t launch_tf_preintegration(const float* tex, float* out, int R, int mode, float stepsize, int quadratureSteps, hipStream_t s);
 
+// ICamera::generateRays / ITransferFunction::evaluate tensor APIs (launch.hip)
+hipError_t launch_generate_rays(const SceneParams& S, float* rayStart, float* rayDir, hipStream_t s);
+hipError_t launch_evaluate_tf(const SceneParams& S, const float* density, const float* previous, size_t n, float* colors, hipStream_t s);
+
 bool kernel_info(const VariantKey& k, KernelInfo* info);
 hipError_t launch_eval(const VariantKey& k, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 hipError_t launch_render(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);

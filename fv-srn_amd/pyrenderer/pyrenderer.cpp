@@ -378,6 +378,32 @@ struct VolumeInterpolationNetwork : IVolumeInterpolation {
 struct ITransferFunction {
     virtual ~ITransferFunction() = default;
     virtual void fill(fvsrn_scene_desc& d, std::vector<float>& table) const = 0;
+    // ITransferFunction::evaluate / evaluate_with_previous (transfer_function.cpp:132-145): densities (B,1) -> colours (B,4)
+    torch::Tensor evaluate(const torch::Tensor& densities, double densityMin, double densityMax, const std::optional<torch::Tensor>& previous,
+                           double stepsize) const {
+        TORCH_CHECK(densities.dim() == 2 && densities.size(1) == 1, "densities must be of shape (B,1)");
+        TORCH_CHECK(densities.is_cuda() && densities.scalar_type() == torch::kFloat32, "densities must be a float32 tensor on the GPU");
+        fvsrn_scene_desc d{};
+        std::vector<float> table;
+        fill(d, table);
+        d.tf_table = table.empty() ? nullptr : table.data();
+        d.cam_right[0] = 1; d.cam_up[1] = 1; d.fov_y_radians = 1; d.stepsize = 1; d.density_max = 1;  // a valid (unused) rest of the scene
+        fvsrn_scene* sc = nullptr;
+        check(fvsrn_scene_create(&d, &sc));
+        const torch::Tensor in = densities.contiguous();
+        torch::Tensor prev;
+        if (previous) {
+            TORCH_CHECK(previous->sizes() == densities.sizes() && previous->is_cuda() && previous->scalar_type() == torch::kFloat32,
+                        "previous_density must match densities");
+            prev = previous->contiguous();
+        }
+        torch::Tensor out = torch::empty({in.size(0), 4}, in.options());
+        const int rc = fvsrn_scene_evaluate_tf(sc, in.data_ptr<float>(), previous ? prev.data_ptr<float>() : nullptr, size_t(in.size(0)),
+                                               float(densityMin), float(densityMax), float(stepsize), out.data_ptr<float>(), currentStream());
+        fvsrn_scene_destroy(sc);
+        check(rc);
+        return out;
+    }
 };
 struct TransferFunctionIdentity : ITransferFunction {
     // transfer_function_identity.cpp:34-38: absorption_emission = (scaleAbsorption, scaleEmission)
@@ -995,7 +1021,18 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def_readwrite("adjoint_latent_grid_central_differences_stepsize_scale", &VolumeInterpolationNetwork::adjointScale);
 
     // ---- transfer functions, BRDF, blending
-    py::class_<ITransferFunction, std::shared_ptr<ITransferFunction>>(m, "ITransferFunction");
+    py::class_<ITransferFunction, std::shared_ptr<ITransferFunction>>(m, "ITransferFunction")
+        .def("evaluate", [](ITransferFunction& t, const torch::Tensor& densities, double mn, double mx, const std::optional<torch::Tensor>& gradients) {
+                 if (gradients) raise("transfer functions that use the gradient are not in the compiled variant set");
+                 return t.evaluate(densities, mn, mx, std::nullopt, 1.0);
+             }, py::arg("densities"), py::arg("min_density"), py::arg("max_density"), py::arg("gradients") = std::optional<torch::Tensor>())
+        .def("evaluate_with_previous", [](ITransferFunction& t, const torch::Tensor& densities, double mn, double mx, const torch::Tensor& previous,
+                                          double stepsize, const std::optional<torch::Tensor>& gradients) {
+                 if (gradients) raise("transfer functions that use the gradient are not in the compiled variant set");
+                 return t.evaluate(densities, mn, mx, previous, stepsize);
+             }, py::arg("densities"), py::arg("min_density"), py::arg("max_density"), py::arg("previous_density"), py::arg("stepsize"),
+             py::arg("gradients") = std::optional<torch::Tensor>())
+        .def("requires_gradients", [](ITransferFunction&) { return false; });
     py::class_<TransferFunctionIdentity, ITransferFunction, std::shared_ptr<TransferFunctionIdentity>>(m, "TransferFunctionIdentity")
         .def(py::init<>())
         .def_readonly("absorption_emission", &TransferFunctionIdentity::absorptionEmission);
@@ -1059,7 +1096,17 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def("get_origin", &CameraOnASphere::getOrigin, py::arg("batch") = 0)
         .def("get_front", &CameraOnASphere::getFront, py::arg("batch") = 0)
         .def("get_parameters", &CameraOnASphere::getParameters)
-        .def("set_parameters", &CameraOnASphere::setParameters);
+        .def("set_parameters", &CameraOnASphere::setParameters)
+        .def("generate_rays", [](CameraOnASphere& c, int width, int height, bool doublePrecision) {  // camera.cpp:204-208
+                 if (doublePrecision) raise("double precision rays are not supported by this build");
+                 c.aspectRatio = double(width) / height;
+                 float e[3], r[3], u[3];
+                 c.frame(e, r, u);
+                 auto opt = torch::TensorOptions().dtype(torch::kFloat).device(torch::kCUDA);
+                 torch::Tensor start = torch::empty({1, height, width, 3}, opt), dir = torch::empty({1, height, width, 3}, opt);
+                 check(fvsrn_generate_rays(e, r, u, float(c.fovYRadians), width, height, start.data_ptr<float>(), dir.data_ptr<float>(), currentStream()));
+                 return std::make_tuple(start, dir);
+             }, py::arg("width"), py::arg("height"), py::arg("double_precision") = false);
 
     // ---- image evaluators (iimage_evaluator.cpp:325-358, image_evaluator_simple.cpp:427-475)
     py::class_<ImageEvaluatorSimple, std::shared_ptr<ImageEvaluatorSimple>> ie(m, "ImageEvaluatorSimple");

@@ -242,6 +242,19 @@ int fvsrn_extract_color(const float* d_raw8, int width, int height, int channel_
 int fvsrn_extract_color_rgba8(const float* d_raw8, int width, int height, int channel_mode, int use_tonemapping,
                               float max_exposure, unsigned int* d_out, void* stream);
 
+/* ICamera::generateRays (renderer/camera.cpp:37-98, kernel CameraGenerateRayKernel renderer_camera_kernels.cuh:12-43):
+ * ray start / direction of every pixel centre of a width x height image for a camera reference frame (eye, right, up as
+ * in fvsrn_scene_desc), written as [height][width][3] fp32 each (the reference's (1,H,W,3) tensors). */
+int fvsrn_generate_rays(const float eye[3], const float right[3], const float up[3], float fov_y_radians, int width,
+                        int height, float* d_ray_start, float* d_ray_dir, void* stream);
+
+/* ITransferFunction::evaluate / evaluate_with_previous (renderer/transfer_function.cpp:132-145, kernels EvaluateTF /
+ * EvaluateTFWithPrevious renderer_tf_kernels.cuh:11-70): the scene's transfer function on n densities ->
+ * colours [n][4] (rgb, absorption).  d_previous_density == NULL: evaluate() (no previous density, step size 1);
+ * otherwise evaluate_with_previous() with the given step size (a negative previous density means "none"). */
+int fvsrn_scene_evaluate_tf(fvsrn_scene* scene, const float* d_density, const float* d_previous_density, size_t n,
+                            float density_min, float density_max, float stepsize, float* d_colors, void* stream);
+
 /* Kernel name + resources of the variant fvsrn_render / fvsrn_evaluate_points would launch for
  * this network (for profiles and bench): writes a 0-terminated string. */
 int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t cap);

@@ -68,6 +68,8 @@ def lib() -> C.CDLL:
         l = C.CDLL(LIB_PATH)
         l.oracle_eval_points.restype = C.c_int
         l.oracle_eval_points.argtypes = [C.POINTER(_OracleNet), _FP, _FP, C.c_size_t, _FP]
+        l.oracle_tf_evaluate.restype = None
+        l.oracle_tf_evaluate.argtypes = [C.POINTER(_OracleScene), _FP, _FP, C.c_size_t, _FP]
         l.oracle_tf_preintegrate.restype = None
         l.oracle_tf_preintegrate.argtypes = [_FP, C.c_int, C.c_int, C.c_float, C.c_int, _FP]
         l.oracle_eval_points_full.restype = C.c_int
@@ -270,6 +272,15 @@ class OracleScene:
         if r != 0:
             raise RuntimeError("oracle_render failed")
         return out, cnt.value
+
+    def evaluate_tf(self, densities: np.ndarray, previous: Optional[np.ndarray] = None) -> np.ndarray:
+        """EvaluateTF / EvaluateTFWithPrevious with this scene's TF, density range and step size: (n,) -> (n,4)."""
+        d = np.ascontiguousarray(densities, np.float32).reshape(-1)
+        p = np.ascontiguousarray(previous, np.float32).reshape(-1) if previous is not None else None
+        out = np.zeros((d.size, 4), np.float32)
+        lib().oracle_tf_evaluate(C.byref(self._s), d.ctypes.data_as(_FP), p.ctypes.data_as(_FP) if p is not None else None, d.size,
+                                 out.ctypes.data_as(_FP))
+        return out
 
     def count_samples(self, net: OracleNetwork, width: int, height: int, y0: int = 0, y1: Optional[int] = None) -> int:
         if y1 is None:

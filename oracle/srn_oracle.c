@@ -495,6 +495,24 @@ static void tf_eval(const OracleScene* s, float density, float c[4]) {
     }
 }
 
+void oracle_tf_evaluate(const OracleScene* s, const float* density, const float* previous, size_t n, float* out4) {
+    const float divRange = 1.0f / (s->densityMax - s->densityMin);
+    for (size_t i = 0; i < n; ++i) {
+        float c[4] = {0, 0, 0, 0};
+        const float d = density[i];
+        if (d >= s->densityMin) {
+            const float d2 = (d - s->densityMin) * divRange;
+            if (s->tfPreintegration) {
+                const float p = previous ? previous[i] : -1.f;
+                tf_eval_preintegrated(s, d2, p >= 0 ? (p - s->densityMin) * divRange : -1.f, c);
+            } else {
+                tf_eval(s, d2, c);
+            }
+        }
+        for (int k = 0; k < 4; ++k) out4[4 * i + k] = c[k];
+    }
+}
+
 /* ------------------------------------------------------------------------------------------- DVR */
 static void render_pixel(const OracleNet* n, const OracleScene* s, int W, int H, int x, int y, float px8[8],
                          unsigned long long* samples) {

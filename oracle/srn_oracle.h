@@ -65,6 +65,9 @@ typedef struct {
     const float* tfPreintegrated;
 } OracleScene;
 /* tex [R][4] -> out [R][4] (mode 1) or [R][R][4] (mode 2, N quadrature steps, world step size) */
+/* EvaluateTF / EvaluateTFWithPrevious (renderer_tf_kernels.cuh:11-70) with the scene's TF, density range and step size;
+ * previous == NULL: no previous density */
+void oracle_tf_evaluate(const OracleScene* s, const float* density, const float* previous, size_t n, float* out4);
 void oracle_tf_preintegrate(const float* tex, int R, int mode, float stepsize, int N, float* out);
 
 int oracle_eval_points(const OracleNet* n, const float* worldPos, const float* directions /* or NULL */, size_t count, float* out);

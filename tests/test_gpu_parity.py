@@ -513,3 +513,49 @@ def test_extract_color_matches_restatement(mode):
     diff = np.abs(((packed[None] >> np.array([0, 8, 16, 24], np.uint32)[:, None, None]) & 255).astype(np.int32) -
                   ((ref8[None] >> np.array([0, 8, 16, 24], np.uint32)[:, None, None]) & 255).astype(np.int32))
     assert diff.max() <= 1  # truncation to 8 bits of values that differ by an ulp
+
+
+def test_generate_rays_matches_camera_restatement():
+    """ICamera::generateRays through the C ABI vs CameraReferenceFrame::eval restated in numpy (renderer_camera.cuh:33-52)."""
+    from fvsrn_amd import capi
+    eye, right, up = oracle.camera_on_a_sphere("Zp", (0.1, -0.2, 0.3), 0.3, 1.9, 2.2)
+    W, H, fov = 50, 30, float(np.deg2rad(40.0))
+    start, direction = capi.generate_rays(eye, right, up, fov, W, H)
+    start, direction = start.cpu().numpy()[0], direction.cpu().numpy()[0]
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    ndcx, ndcy = 2 * (xs + 0.5) / W - 1, 2 * (ys + 0.5) / H - 1
+    front = np.cross(up, right)
+    ty = np.tan(fov / 2)
+    d = front[None, None] + (ndcx * ty * W / H)[..., None] * right[None, None] + (ndcy * ty)[..., None] * up[None, None]
+    d = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    assert np.abs(start - eye[None, None]).max() == 0
+    assert np.abs(direction - d).max() < 2e-6
+
+
+@pytest.mark.parametrize("tf", ["identity", "gaussian", "piecewise", "texture", "texture_pre1d", "texture_pre2d"])
+def test_evaluate_tf_matches_restatement(tf):
+    """ITransferFunction::evaluate / evaluate_with_previous (EvaluateTF kernels, renderer_tf_kernels.cuh:11-70)."""
+    import torch
+    from fvsrn_amd import capi
+    kw = dict(identity=dict(tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=12.0, tf_scale_emission=0.7),
+              gaussian=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF), piecewise=dict(tf_kind=oracle.TF_PIECEWISE, tf_table=PIECE_TF),
+              texture=dict(tf_kind=oracle.TF_TEXTURE, tf_table=TEX256),
+              texture_pre1d=dict(tf_kind=oracle.TF_TEXTURE, tf_table=TEX256, tf_preintegration=1),
+              texture_pre2d=dict(tf_kind=oracle.TF_TEXTURE, tf_table=TEX256, tf_preintegration=2))[tf]
+    rng = np.random.RandomState(3)
+    dens = rng.uniform(-0.2, 1.3, 5000).astype(np.float32)
+    prev = np.where(rng.rand(5000) < 0.2, -1.0, dens + rng.uniform(-0.05, 0.05, 5000)).astype(np.float32)
+    dmin, dmax, step = 0.1, 0.9, 1 / 40
+    # pre-integrated tables: 256-step sums with the device's exp / division, then a division by a small alpha
+    tol = 5e-4 if "pre" in tf else 2e-5
+    scene = capi.Scene(**make_scene_kwargs(stepsize=step, density_min=dmin, density_max=dmax, **kw))
+    d_t = torch.from_numpy(dens).cuda().reshape(-1, 1)
+    # evaluate(): step size 1, no previous density
+    out = scene.evaluate_tf(d_t, dmin, dmax).cpu().numpy()
+    ref = oracle.OracleScene(**make_scene_kwargs(stepsize=1.0, density_min=dmin, density_max=dmax, **kw)).evaluate_tf(dens)
+    assert np.abs(out - ref).max() < tol * max(1.0, np.abs(ref).max())
+    assert (out[dens < dmin] == 0).all()
+    # evaluate_with_previous()
+    out = scene.evaluate_tf(d_t, dmin, dmax, previous=torch.from_numpy(prev).cuda().reshape(-1, 1), stepsize=step).cpu().numpy()
+    ref = oracle.OracleScene(**make_scene_kwargs(stepsize=step, density_min=dmin, density_max=dmax, **kw)).evaluate_tf(dens, prev)
+    assert np.abs(out - ref).max() < tol * max(1.0, np.abs(ref).max())

@@ -315,6 +315,29 @@ def test_scene_file_render_matches_oracle(tmp_path, tf_name):
     assert np.abs(img[:7] - ref[:7]).max() < 3e-3
 
 
+@pytest.mark.gpu
+def test_tensor_apis_generate_rays_and_tf_evaluate():
+    """camera.generate_rays + tf.evaluate: the calls the reference's Python ray tracer makes (raytracing.py:206-224, :286-297)."""
+    from oracle import oracle
+    cam = pr.CameraOnASphere()
+    cam.orientation = pr.CameraOnASphere.Ym
+    cam.pitchYawDistance.value = pr.double3(0.4, 0.7, 1.6)
+    start, direction = cam.generate_rays(48, 32)
+    assert tuple(start.shape) == (1, 32, 48, 3) and tuple(direction.shape) == (1, 32, 48, 3)
+    assert torch.allclose(direction.norm(dim=-1), torch.ones(1, 32, 48, device="cuda"), atol=1e-6)
+    origin = cam.get_origin()
+    assert torch.allclose(start[0, 5, 7].cpu(), torch.tensor([origin.x, origin.y, origin.z], dtype=torch.float32))
+    tf = pr.TransferFunctionGaussian()
+    table = np.array([[0.9, 0.1, 0.1, 30.0, 0.25, 0.08], [0.1, 0.9, 0.2, 60.0, 0.5, 0.05]], np.float32)
+    tf.tensor = torch.from_numpy(table[None])
+    dens = torch.rand(1000, 1, device="cuda")
+    out = tf.evaluate(dens, 0.1, 0.9).cpu().numpy()
+    eye, right, up = oracle.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, 0.7, 1.6)
+    ref = oracle.OracleScene(eye=eye, right=right, up=up, fov_y_radians=0.78, stepsize=1.0, density_min=0.1, density_max=0.9,
+                             tf_kind=oracle.TF_GAUSSIAN, tf_table=table).evaluate_tf(dens.cpu().numpy())
+    assert np.abs(out - ref).max() < 2e-5 * np.abs(ref).max()
+
+
 def test_protocol_png_writer(tmp_path):
     sys.path.insert(0, os.path.join(util.ROOT, "tools"))
     import render_protocol
