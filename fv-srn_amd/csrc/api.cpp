@@ -808,7 +808,12 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const int tilesX = (width + 7) / 8, tilesY = (numLocalRows + 7) / 8;
             const int tiles = tilesX * tilesY;
             const size_t lds = size_t(a.P.ldsBytes) + tfFloats * 4;
-            const int wpb = wavesPerBlockFor(lds);
+            // A rank of a multi-GPU frame (stripeWorld > 1) launches one workgroup per few work units instead of persistent
+            // waves (see below); four waves per workgroup then share the copy of the network into LDS, which would
+            // otherwise cost every one-wave workgroup ~5 us against ~30 us of rendering.
+            const char* pers = std::getenv("FVSRN_PERSISTENT");
+            const bool persistent = pers ? pers[0] != '0' : stripeWorld == 1;
+            const int wpb = persistent ? wavesPerBlockFor(lds) : std::max(wavesPerBlockFor(lds), std::getenv("FVSRN_WAVES_PER_BLOCK") ? 1 : 4);
             const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded);
             const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));  // workgroups the chip holds at once
             // Depth segments (kernels.hpp): with fewer tiles than ~4x the resident waves (small images, the stripes of one
@@ -847,11 +852,24 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             // gathered by an RCCL kernel on another stream while the next frame renders, and that kernel only gets onto the
             // chip when render workgroups retire -- persistent waves would hold every wave slot until their launch ends and
             // serialise gather and render (the hardware dispatcher hands out the units dynamically either way).
-            const char* pers = std::getenv("FVSRN_PERSISTENT");
-            const bool persistent = pers ? pers[0] != '0' : stripeWorld == 1;
+            S.unitQuota = 0;
             if (persistent) {
                 if (perCU > 0 && grid > resident) {
                     grid = resident;
+                    if (!scene->tileCounters(s, &S.tileCounter, &S.tileCounterNext))
+                        return fail(FVSRN_ERR_DEVICE, "could not set up the tile counters");
+                }
+            } else {
+                // Bounded waves for the stripes of a latent-grid network: every wave takes two units from the counter in raster
+                // order (neighbouring tiles share grid lines in L2) and retires, so the launch still turns its workgroups over
+                // for the gather kernel but copies the network into LDS half as often.  Measured r01 on one rank's share
+                // of 1024^2 x 512, 64x6 + grid (tools/stripe_efficiency.py): 75 / 76 / 84 % of frame_time / world at
+                // world 2 / 4 / 8 without, 85 / 87 / 85 % with; no gain for Fourier-only networks (small LDS image).
+                const char* q = std::getenv("FVSRN_UNIT_QUOTA");
+                const int quota = q ? std::atoi(q) : (stripeWorld > 1 && net->key.grid != 0 ? 2 : 0);
+                if (quota > 1 && perCU > 0 && grid > resident) {
+                    grid = unsigned((units + (long long)wpb * quota - 1) / ((long long)wpb * quota));
+                    S.unitQuota = quota;
                     if (!scene->tileCounters(s, &S.tileCounter, &S.tileCounterNext))
                         return fail(FVSRN_ERR_DEVICE, "could not set up the tile counters");
                 }

@@ -76,6 +76,9 @@ struct SceneParams {
     // launch; null = every wave renders the slots {w, w + totalWaves, ...}
     int* tileCounter;
     int* tileCounterNext;
+    // > 0: a wave retires after this many work units (all of them taken from the counter) and the launch holds more
+    // workgroups than fit on the chip at once -- used for the stripes of a multi-GPU frame, see api.cpp
+    int unitQuota;
     // depth segments (kernels.hpp): every ray is cut into `segments` consecutive step ranges rendered by different waves
     // into `partial` ([segments][8][rows][width] raw accumulators), composited front to back by composite_kernel
     int segments;

@@ -224,7 +224,14 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     const int K = S.segments;
 #endif
     const int numUnits = numTiles * K;
-    for (int slot = int(blockIdx.x) * wavesPerBlock + int(threadIdx.x >> 6); slot < numUnits;) {
+    int slot = int(blockIdx.x) * wavesPerBlock + int(threadIdx.x >> 6);
+    int quota = S.unitQuota;  // wave-uniform
+    if (quota > 0) {  // bounded waves: every unit comes from the counter
+        int first = 0;
+        if (lane == 0) first = atomicAdd(S.tileCounter, 1);
+        slot = __builtin_amdgcn_readfirstlane(first);
+    }
+    for (; slot < numUnits;) {
     const int tileSlot = K > 1 ? slot / K : slot;
     const int seg = slot - tileSlot * K;
     // launch slot -> pixel tile: the host orders tiles by expected ray length (centre of the projected box first), so
@@ -435,7 +442,12 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
         out[6 * plane + o] = nz * ca;
         out[7 * plane + o] = depth * ca / ca;  // (depth*alpha)/alpha, NaN for alpha == 0 like the reference
     }
-    if (S.tileCounter) {
+    if (S.unitQuota > 0) {
+        if (--quota == 0) break;
+        int next = 0;
+        if (lane == 0) next = atomicAdd(S.tileCounter, 1);
+        slot = __builtin_amdgcn_readfirstlane(next);
+    } else if (S.tileCounter) {
         int next = 0;
         if (lane == 0) next = atomicAdd(S.tileCounter, 1);
         slot = totalWaves + __builtin_amdgcn_readfirstlane(next);
