@@ -119,6 +119,10 @@ struct fvsrn_network {
             int n = 0;
             const void* fn = shaded ? kinfo.renderShadedFn : kinfoScaled.renderFn;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, int(blockDim), ldsBytes) != hipSuccess) n = 0;
+            if (const char* e = std::getenv("FVSRN_MAX_BLOCKS_PER_CU")) {  // developer knob: occupancy experiments
+                const int m = std::atoi(e);
+                if (m >= 1 && m < n) n = m;
+            }
             occBlocks = n;
             occKey = k;
         }

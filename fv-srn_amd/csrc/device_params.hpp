@@ -17,7 +17,28 @@ namespace fvsrn {
 constexpr int kFragBytes = 1024;
 constexpr int kFourierResync = 64;  // default period of the exact re-derivation of rotated Fourier features (SceneParams::resyncMask)
 
+// Developer build (-DFVSRN_PROF_SECTIONS, tools/section_profile.py): cycle counter marks inside the render loop; the sums
+// go to stats[2 + k].  Marks wait for outstanding LDS reads (s_memtime is a scalar memory read), i.e. they perturb the
+// schedule they measure: a coarse split of the wave step, not a profile of the shipped kernel.
+#ifdef FVSRN_PROF_SECTIONS
+#define FVSRN_MARK(P, k)                                                  \
+    do {                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                \
+        const unsigned long long now_ = __builtin_readcyclecounter();     \
+        (P).prof[k] += now_ - (P).profLast;                               \
+        (P).profLast = now_;                                              \
+        __builtin_amdgcn_sched_barrier(0);                                \
+    } while (0)
+#else
+#define FVSRN_MARK(P, k) do { } while (0)
+#endif
+constexpr int kProfSections = 8;
+
 struct NetParams {
+#ifdef FVSRN_PROF_SECTIONS
+    mutable unsigned long long prof[kProfSections];
+    mutable unsigned long long profLast;
+#endif
     const void* ldsImage;  // device pointer
     int ldsBytes;          // multiple of 16
     int numLayers;         // NL: number of C->C Linear layers, the first one consumes Fourier(+grid) features; 0 only with noFourier

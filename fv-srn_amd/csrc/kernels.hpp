@@ -196,7 +196,14 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // ------------------------------------------------------------------------------------------------
 // SHADED: finite-difference normals and the BRDF (magnitude scaling, Phong).  A separate kernel (render_shaded_kernel): the
 // extra network evaluation inside the step loop needs so many registers that it would cost the plain renderer a wave.
-template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, bool SHADED>
+// TAIL: what follows the network inside the step loop.  TAIL_GENERIC handles every output mode / transfer function /
+// blend mode / early-out setting through wave-uniform branches (~20 scalar branches, exec-mask regions and scalar spills
+// per step: ~1000 cycles of latency for a lone wave, r01 tools/section_profile.py, more than the network itself).
+// TAIL_SCALAR_TABLE is the common case -- a scalar density network (density | density:direct) with an Identity or
+// Texture transfer function -- as straight-line predicated code with two wave-uniform branches (sigmoid, texture).
+enum { TAIL_GENERIC = 0, TAIL_SCALAR_TABLE = 1 };
+
+template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, bool SHADED, int TAIL = TAIL_GENERIC>
 __device__ __forceinline__ void render_body(const NetParams& P, const SceneParams& S, const char* lds, const float* tfLds,
                                             float* __restrict__ out, unsigned long long* __restrict__ stats) {
     const int lane = lane_id();
@@ -211,6 +218,9 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     const int totalWaves = int(gridDim.x) * wavesPerBlock;
     if (S.tileCounterNext && blockIdx.x == 0 && threadIdx.x == 0) *S.tileCounterNext = 0;
     unsigned nValid = 0, nSteps = 0;  // wave-uniform (scalar registers): lane-exact samples / executed wave steps
+#ifdef FVSRN_PROF_SECTIONS
+    for (int k = 0; k < kProfSections; ++k) P.prof[k] = 0;
+#endif
     const bool rgboNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
     // networks that predict the gradient (and, in the curvature modes, two curvature values the DVR path has no use for)
     const bool gradNet = P.outputMode >= FVSRN_OUT_DENSITY_GRADIENT && P.outputMode <= FVSRN_OUT_DENSITY_CURVATURE_DIRECT;
@@ -224,6 +234,11 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     const int K = S.segments;
 #endif
     const int numUnits = numTiles * K;
+    // TAIL_SCALAR_TABLE: loop-invariant scalars
+    const float alphaLimit = S.earlyOut ? S.alphaEarlyOut : __builtin_inff();
+    const bool sigmoidNet = P.outputMode == FVSRN_OUT_DENSITY;
+    const bool textureTf = S.tfKind == FVSRN_TF_TEXTURE;
+    const bool beerLambert = S.blendMode == FVSRN_BLEND_BEER_LAMBERT;
     int slot = int(blockIdx.x) * wavesPerBlock + int(threadIdx.x >> 6);
     int quota = S.unitQuota;  // wave-uniform
     if (quota > 0) {  // bounded waves: every unit comes from the counter
@@ -293,22 +308,34 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
 #endif
     floatx16 feat[2][mtiles(CD)], dfeat[2][mtiles(CD)];
 
+#ifdef FVSRN_PROF_SECTIONS
+    P.profLast = __builtin_readcyclecounter();
+#endif
     for (int i = 0;; ++i) {
+        FVSRN_MARK(P, 0);  // tail of the previous step: output parametrization, TF, blending
         float t;
-        bool inRange;
-        if (K > 1) {  // wave-uniform; kept as a branch so that the unsegmented loop does no per-lane index arithmetic
+        bool inRange, valid;
+        unsigned long long validMask;
+        if constexpr (TAIL == TAIL_SCALAR_TABLE) {  // straight-line: i0 = 0, i1 = INT_MAX without segments
             const int gi = i0 + i;
             t = tmin + float(gi) * S.stepsize;
             inRange = (t <= tmax) & (gi < i1);
+            valid = inRange & (ca < alphaLimit);
+            validMask = __builtin_amdgcn_ballot_w64(valid);
         } else {
-            t = tmin + float(i) * S.stepsize;
-            inRange = t <= tmax;
+            if (K > 1) {  // wave-uniform; kept as a branch so that the unsegmented loop does no per-lane index arithmetic
+                const int gi = i0 + i;
+                t = tmin + float(gi) * S.stepsize;
+                inRange = (t <= tmax) & (gi < i1);
+            } else {
+                t = tmin + float(i) * S.stepsize;
+                inRange = t <= tmax;
+            }
+            const bool notOpaque = ca < S.alphaEarlyOut;
+            valid = bool(int(inRange) & (int(!S.earlyOut) | int(notOpaque)));  // branch-free
+            // wave mask straight from the two v_cmp results (scalar ops only)
+            validMask = __builtin_amdgcn_ballot_w64(inRange) & (S.earlyOut ? __builtin_amdgcn_ballot_w64(notOpaque) : ~0ull);
         }
-        const bool notOpaque = ca < S.alphaEarlyOut;
-        const bool valid = bool(int(inRange) & (int(!S.earlyOut) | int(notOpaque)));  // branch-free
-        // wave mask straight from the two v_cmp results (scalar ops only)
-        const unsigned long long validMask =
-            __builtin_amdgcn_ballot_w64(inRange) & (S.earlyOut ? __builtin_amdgcn_ballot_w64(notOpaque) : ~0ull);
         if (validMask == 0) break;  // wave-uniform: no lane of the wave is valid any more
         ++nSteps;
         nValid += unsigned(__builtin_popcountll(validMask));
@@ -328,10 +355,42 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz);
         }
 
+        FVSRN_MARK(P, 5);  // last layer (+ the other half of the rotation)
 #ifdef FVSRN_ABL_NOTAIL  // ablation build (tools/ablate.sh): no output parametrization / TF / blending
         cr += o[0] * 1e-30f;
         continue;
 #endif
+        if constexpr (TAIL == TAIL_SCALAR_TABLE) {
+            // stepping_dvr.cuh:110-150 for a scalar density network, Identity | Texture TF, no normals: predicated, no
+            // exec-mask regions.  Same operations in the same order as the generic tail below.
+            float value = o[0];
+            if (sigmoidNet) value = sigmoid_f(value);  // wave-uniform
+            const float density = fminf(fmaxf((value - S.densityMin) * S.divDensityRange, 0.f), 1.f);  // tf_eval clamps
+            float c0, c1, c2, c3;
+            if (textureTf) {  // wave-uniform; renderer_tf_texture.cuh:46-55
+                const int R = S.tfRows;
+                const float d = density * R - 0.5f;
+                const float fl = floorf(d);
+                const int di = int(fl);
+                const float df = d - fl;
+                const float4_t a = *reinterpret_cast<const float4_t*>(tfLds + 4 * min(max(di, 0), R - 1));
+                const float4_t b = *reinterpret_cast<const float4_t*>(tfLds + 4 * min(max(di + 1, 0), R - 1));
+                c0 = a[0] + df * (b[0] - a[0]); c1 = a[1] + df * (b[1] - a[1]); c2 = a[2] + df * (b[2] - a[2]);
+                c3 = (a[3] + df * (b[3] - a[3])) * S.stepsize;
+            } else {  // renderer_tf_identity.cuh:36-54
+                c0 = c1 = c2 = density * S.tfScaleEmission;
+                c3 = density * S.tfScaleAbsorption * S.stepsize;
+            }
+            // Blending::eval (renderer_blending.cuh:35-51) where the sample counts: valid, value >= densityMin, absorption > 0
+            const float aBeer = 1.f - __expf(-c3), aAlpha = fminf(1.f, c3);
+            const float a = beerLambert ? aBeer : aAlpha;
+            const bool counts = valid & (value >= S.densityMin) & (c3 > 0.f);
+            const float w = counts ? (1.f - ca) * a : 0.f;
+            cr += w * c0; cg += w * c1; cb += w * c2;
+            depth += w * t;
+            ca += w;
+            continue;
+        }
         float4_t color = {0, 0, 0, 0};
         float gx = 0, gy = 0, gz = 0;
         if (rgboNet) {  // stepping_dvr.cuh:104-109
@@ -458,6 +517,9 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     if (stats && lane == 0) {
         atomicAdd(&stats[0], (unsigned long long)nValid);
         atomicAdd(&stats[1], (unsigned long long)nSteps * 64ull);
+#ifdef FVSRN_PROF_SECTIONS
+        for (int k = 0; k < kProfSections; ++k) atomicAdd(&stats[2 + k], P.prof[k]);
+#endif
     }
 }
 
@@ -476,8 +538,13 @@ __device__ __forceinline__ void render_entry(const NetParams& P, const ScenePara
     if constexpr (GRID == 0) {
         if (P.noFourier) return render_body<CD, ACT, GRID, HAS_DIR, FM_FIRST_LAYER, SHADED>(P, S, lds, tfLds, out, stats);
     }
-    if (P.fourierNeedsFract) render_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS, SHADED>(P, S, lds, tfLds, out, stats);
-    else render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED>(P, S, lds, tfLds, out, stats);
+    if (P.fourierNeedsFract) return render_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS, SHADED>(P, S, lds, tfLds, out, stats);
+    if constexpr (!SHADED) {
+        const bool scalarNet = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
+        if (scalarNet && (S.tfKind == FVSRN_TF_IDENTITY || S.tfKind == FVSRN_TF_TEXTURE))
+            return render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_SCALAR_TABLE>(P, S, lds, tfLds, out, stats);
+    }
+    render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED>(P, S, lds, tfLds, out, stats);
 }
 
 template <int CD, int ACT, int GRID, bool HAS_DIR>

@@ -575,8 +575,10 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
         if constexpr (GRID_AHEAD) grid_load(P.grid, gt[0], 0, h, raw);
     }
     __builtin_amdgcn_sched_barrier(0);
+    FVSRN_MARK(P, 1);  // loop head, LDS reads of the first layer issued
     pre();
     __builtin_amdgcn_sched_barrier(0);
+    FVSRN_MARK(P, 2);  // pre(): B fragments of the first layer (+ half of the rotation)
 
     const int NL = P.numLayers;
     constexpr int kBiasLayer = 32 * MT * 4;
@@ -613,19 +615,37 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
 
     // One half-layer slot: MFMAs of tile T over the fragments in a[] || activation+convert of the other tile, whose
     // accumulators then take the bias block at `biasOff`; RELOAD: a[i] <- fragment i at `nextW` right after its use.
+    // The bias block of the converted tile lands in its accumulator registers as soon as they are free: 16-byte block g
+    // (registers 4g..4g+3) after the quarters {0,1} (g = 0, 2) resp. {2,3} (g = 1, 3) are converted.  The conversion items
+    // are front-loaded (kSlotItems per MFMA) so that the slot's remaining MFMAs cover the LDS latency of those reads: the
+    // next slot starts with an MFMA that takes them as its C operand.
+#ifndef FVSRN_SLOT_ITEMS
+#define FVSRN_SLOT_ITEMS 2
+#endif
+    constexpr int kSlotItems = FVSRN_SLOT_ITEMS;
     auto slot = [&](auto tileTag, auto reloadTag, int biasOff, int nextW) {
         constexpr int T = decltype(tileTag)::value, O = 1 - T;
         constexpr bool RELOAD = decltype(reloadTag)::value;
-        interleave<NM, NV>(
-            [&](int i) {
-                acc[T][i / KS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], xb[T][i % KS], acc[T][i / KS], 0, 0, 0);
-                if constexpr (RELOAD) a[i] = frag(nextW + i * kFragBytes);
-            },
-            [&](int j) {
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            acc[T][i / KS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], xb[T][i % KS], acc[T][i / KS], 0, 0, 0);
+            if constexpr (RELOAD) a[i] = frag(nextW + i * kFragBytes);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = i * kSlotItems; j < (i + 1) * kSlotItems && j < NV; ++j) {
                 const int m = j / 4, q = j % 4;
                 act_pack_quarter<ACT>(acc[O][m], q, actA, actB, xb[O][2 * m], xb[O][2 * m + 1]);
-                if (q == 3) acc[O][m] = bias(biasOff + m * 128);
-            });
+                if (q & 1) {
+                    const float4_t* p = reinterpret_cast<const float4_t*>(ldsB + biasOff + m * 128);
+#pragma unroll
+                    for (int g = q >> 1; g < 4; g += 2) {
+                        const float4_t v = p[2 * g];
+                        acc[O][m][4 * g + 0] = v[0]; acc[O][m][4 * g + 1] = v[1]; acc[O][m][4 * g + 2] = v[2]; acc[O][m][4 * g + 3] = v[3];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     using T0 = std::integral_constant<int, 0>;
     using T1 = std::integral_constant<int, 1>;
@@ -655,6 +675,7 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    FVSRN_MARK(P, 3);  // first layer
     // ---- layers 1 .. NL-1 -----------------------------------------------------------------------------------------------
 #ifdef FVSRN_ABL_NOHIDDEN
     for (int l = 1; l < NL; l += 1000) {
@@ -665,6 +686,7 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
         slot(T1{}, Yes{}, P.offBias + (l + 1) * kBiasLayer, l + 1 < NL ? P.offHidden + l * NM * kFragBytes : P.offLast);
     }
 
+    FVSRN_MARK(P, 4);  // hidden layers
     // ---- last layer: 16x16x32 MFMAs (pack.cpp) on the same B fragments; its weight fragments are a[0..KS-1]; output r of
     // this lane's tile-(lane>>5) sample lands in register r ----------------------------------------------------------------
     const float4_t biasLast = *reinterpret_cast<const float4_t*>(lds + P.offBias + NL * kBiasLayer);
