@@ -113,11 +113,12 @@ struct fvsrn_network {
     // resident workgroups per CU of the render kernel for (blockDim, dynamic LDS); cached
     unsigned long long occKey = 0;
     int occBlocks = 0;
-    int renderBlocksPerCU(unsigned blockDim, size_t ldsBytes, bool shaded) {
-        const unsigned long long k = (static_cast<unsigned long long>(ldsBytes) << 17) | (blockDim << 1) | (shaded ? 1u : 0u);
+    // smallFn: render_small_kernel variant to use instead of render_kernel (nullptr = none)
+    int renderBlocksPerCU(unsigned blockDim, size_t ldsBytes, bool shaded, const void* smallFn = nullptr) {
+        const unsigned long long k = (static_cast<unsigned long long>(ldsBytes) << 18) | (blockDim << 2) | (smallFn ? 2u : 0u) | (shaded ? 1u : 0u);
         if (k != occKey) {
             int n = 0;
-            const void* fn = shaded ? kinfo.renderShadedFn : kinfoScaled.renderFn;
+            const void* fn = smallFn ? smallFn : (shaded ? kinfo.renderShadedFn : kinfoScaled.renderFn);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, int(blockDim), ldsBytes) != hipSuccess) n = 0;
             if (const char* e = std::getenv("FVSRN_MAX_BLOCKS_PER_CU")) {  // developer knob: occupancy experiments
                 const int m = std::atoi(e);
@@ -798,7 +799,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             S.brdfMagCenter = d.brdf_magnitude_center; S.brdfMagRadius = d.brdf_magnitude_radius;
             for (int i = 0; i < 3; ++i) S.brdfLight[i] = d.brdf_light[i];
             S.tfKind = d.tf_kind;
-            S.tfRows = d.tf_rows;
+            S.tfRows = d.tf_rows; S.tfRowsF = float(d.tf_rows);
             S.tfScaleAbsorption = d.tf_scale_absorption;
             S.tfScaleEmission = d.tf_scale_emission;
             S.tfTable = static_cast<const float*>(scene->dTf.ptr);
@@ -818,7 +819,18 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const char* pers = std::getenv("FVSRN_PERSISTENT");
             const bool persistent = pers ? pers[0] != '0' : stripeWorld == 1;
             const int wpb = persistent ? wavesPerBlockFor(lds) : std::max(wavesPerBlockFor(lds), std::getenv("FVSRN_WAVES_PER_BLOCK") ? 1 : 4);
-            const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded);
+            // Small networks in registers (render_small_kernel, kernels.hpp): 32-wide Fourier-only scalar network with at most
+            // three C->C layers, phases inside the v_cos domain, Identity or Texture TF, no shading.  FVSRN_SMALL_KERNEL=0: off.
+            const void* smallFn = nullptr;
+            {
+                const char* e = std::getenv("FVSRN_SMALL_KERNEL");
+                const VariantKey& k = net->keyScaled;
+                const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
+                if (!(e && e[0] == '0') && !a.shaded && k.CD == 2 && k.grid == 0 && !a.P.noFourier && !a.P.fourierNeedsFract &&
+                    a.P.numLayers >= 1 && a.P.numLayers <= 3 && scalarNet && (d.tf_kind == FVSRN_TF_IDENTITY || d.tf_kind == FVSRN_TF_TEXTURE))
+                    smallFn = render_small_fn(k.act, k.dir, a.P.numLayers);
+            }
+            const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded, smallFn);
             const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));  // workgroups the chip holds at once
             // Depth segments (kernels.hpp): with fewer tiles than ~4x the resident waves (small images, the stripes of one
             // rank of a multi-GPU frame) the longest tile dictates the launch time; cut the rays into K step ranges so that
@@ -885,7 +897,8 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const char* ord = std::getenv("FVSRN_TILE_ORDER");  // "0" / "1" force, unset = heuristic
             const bool useOrder = ord ? ord[0] == '1' : (S.tileCounter == nullptr && (wpb > 1 || net->key.grid != 0));
             S.tileOrder = useOrder ? scene->tileOrder(S, P_boxCenter(a.P), tilesX, tilesY, s) : nullptr;
-            hipError_t e = launch_render(a.shaded ? net->key : net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
+            hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, a, grid, unsigned(64 * wpb), lds, s)
+                                   : launch_render(a.shaded ? net->key : net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
             if (e == hipSuccess && K > 1) e = launch_composite(S.partial, d_out8, K, plane, S, s);
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during rendering! ") + hipGetErrorString(e));
             return FVSRN_OK;
@@ -979,7 +992,7 @@ int fvsrn_scene_evaluate_tf(fvsrn_scene* scene, const float* d_density, const fl
         S.stepsize = step;
         S.densityMin = density_min;
         S.divDensityRange = 1.0f / (density_max - density_min);
-        S.tfKind = d.tf_kind; S.tfRows = d.tf_rows;
+        S.tfKind = d.tf_kind; S.tfRows = d.tf_rows; S.tfRowsF = float(d.tf_rows);
         S.tfScaleAbsorption = d.tf_scale_absorption; S.tfScaleEmission = d.tf_scale_emission;
         S.tfTable = static_cast<const float*>(scene->dTf.ptr);
         S.tfPreintegration = d.tf_preintegration;

@@ -83,6 +83,7 @@ struct SceneParams {
     float brdfLight[3];
     // TF
     int tfKind, tfRows;
+    float tfRowsF;  // float(tfRows): a scalar operand of the texture lookup instead of a per-lane convert
     float tfScaleAbsorption, tfScaleEmission;
     const float* tfTable;  // device pointer
     int tfPreintegration;          // 0 none, 1: tfPreintegrated = [R][4] running integral, 2: [R][R][4] (previous, current density)

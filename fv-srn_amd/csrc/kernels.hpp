@@ -203,7 +203,8 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // Texture transfer function -- as straight-line predicated code with two wave-uniform branches (sigmoid, texture).
 enum { TAIL_GENERIC = 0, TAIL_SCALAR_TABLE = 1 };
 
-template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, bool SHADED, int TAIL = TAIL_GENERIC>
+// NLC > 0 (render_small_kernel): the network stays in registers (ResidentNet, srn_device.hpp); CD = 2, GRID = 0, rotation path
+template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, bool SHADED, int TAIL = TAIL_GENERIC, int NLC = 0>
 __device__ __forceinline__ void render_body(const NetParams& P, const SceneParams& S, const char* lds, const float* tfLds,
                                             float* __restrict__ out, unsigned long long* __restrict__ stats) {
     const int lane = lane_id();
@@ -234,6 +235,8 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     const int K = S.segments;
 #endif
     const int numUnits = numTiles * K;
+    ResidentNet<(NLC > 0 ? NLC : 1)> resident;
+    if constexpr (NLC > 0) load_resident(P, lds, resident);
     // TAIL_SCALAR_TABLE: loop-invariant scalars
     const float alphaLimit = S.earlyOut ? S.alphaEarlyOut : __builtin_inff();
     const bool sigmoidNet = P.outputMode == FVSRN_OUT_DENSITY;
@@ -320,8 +323,9 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             const int gi = i0 + i;
             t = tmin + float(gi) * S.stepsize;
             inRange = (t <= tmax) & (gi < i1);
-            valid = inRange & (ca < alphaLimit);
-            validMask = __builtin_amdgcn_ballot_w64(valid);
+            const bool notOpaque = ca < alphaLimit;
+            valid = inRange & notOpaque;
+            validMask = __builtin_amdgcn_ballot_w64(inRange) & __builtin_amdgcn_ballot_w64(notOpaque);  // scalar ops only
         } else {
             if (K > 1) {  // wave-uniform; kept as a branch so that the unsegmented loop does no per-lane index arithmetic
                 const int gi = i0 + i;
@@ -350,7 +354,8 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
                 if (i == 0)
                     fourier_features<CD, HAS_DIR, FM_COS, true>(P, lds, dnx * S.stepsize, dny * S.stepsize, dnz * S.stepsize, 0.f, 0.f, 0.f, dfeat);
             }
-            o = srn_forward_rotating<CD, ACT, GRID, HAS_DIR>(P, lds, feat, dfeat, px, py, pz);
+            if constexpr (NLC > 0) o[0] = srn_forward_rotating_resident<ACT, HAS_DIR, NLC>(P, resident, feat, dfeat);
+            else o = srn_forward_rotating<CD, ACT, GRID, HAS_DIR>(P, lds, feat, dfeat, px, py, pz);
         } else {
             o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz);
         }
@@ -364,12 +369,15 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             // stepping_dvr.cuh:110-150 for a scalar density network, Identity | Texture TF, no normals: predicated, no
             // exec-mask regions.  Same operations in the same order as the generic tail below.
             float value = o[0];
-            if (sigmoidNet) value = sigmoid_f(value);  // wave-uniform
+            if (sigmoidNet) {  // wave-uniform; the empty asm keeps hipcc from turning the branch into a select (2 transcendentals)
+                asm volatile("");
+                value = sigmoid_f(value);
+            }
             const float density = fminf(fmaxf((value - S.densityMin) * S.divDensityRange, 0.f), 1.f);  // tf_eval clamps
             float c0, c1, c2, c3;
             if (textureTf) {  // wave-uniform; renderer_tf_texture.cuh:46-55
                 const int R = S.tfRows;
-                const float d = density * R - 0.5f;
+                const float d = density * S.tfRowsF - 0.5f;
                 const float fl = floorf(d);
                 const int di = int(fl);
                 const float df = d - fl;
@@ -523,18 +531,21 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     }
 }
 
+// network image + TF table (behind it) -> LDS
+__device__ __forceinline__ float* render_prologue(const NetParams& P, const SceneParams& S, char* lds) {
+    load_network_to_lds(P, lds);
+    float* tfLds = reinterpret_cast<float*>(lds + P.ldsBytes);
+    const int cols = S.tfKind == FVSRN_TF_GAUSSIAN ? 6 : (S.tfKind == FVSRN_TF_PIECEWISE ? 5 : (S.tfKind == FVSRN_TF_TEXTURE ? 4 : 0));
+    for (int i = threadIdx.x; i < cols * S.tfRows; i += int(blockDim.x)) tfLds[i] = S.tfTable[i];
+    __syncthreads();
+    return tfLds;
+}
+
 template <int CD, int ACT, int GRID, bool HAS_DIR, bool SHADED>
 __device__ __forceinline__ void render_entry(const NetParams& P, const SceneParams& S, float* __restrict__ out,
                                              unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    load_network_to_lds(P, lds);
-    // TF table behind the network image
-    float* tfLds = reinterpret_cast<float*>(lds + P.ldsBytes);
-    {
-        const int cols = S.tfKind == FVSRN_TF_GAUSSIAN ? 6 : (S.tfKind == FVSRN_TF_PIECEWISE ? 5 : (S.tfKind == FVSRN_TF_TEXTURE ? 4 : 0));
-        for (int i = threadIdx.x; i < cols * S.tfRows; i += int(blockDim.x)) tfLds[i] = S.tfTable[i];
-        __syncthreads();
-    }
+    float* tfLds = render_prologue(P, S, lds);
     if constexpr (GRID == 0) {
         if (P.noFourier) return render_body<CD, ACT, GRID, HAS_DIR, FM_FIRST_LAYER, SHADED>(P, S, lds, tfLds, out, stats);
     }
@@ -551,6 +562,16 @@ template <int CD, int ACT, int GRID, bool HAS_DIR>
 __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                unsigned long long* __restrict__ stats) {
     render_entry<CD, ACT, GRID, HAS_DIR, false>(P, S, out, stats);
+}
+
+// 32-wide Fourier-only scalar networks with NLC <= 3 C->C layers, Identity | Texture TF, phases inside the v_cos domain
+// (the host checks all of that, api.cpp): weights and biases in registers, 2 waves per SIMD (256 registers)
+template <int ACT, bool HAS_DIR, int NLC>
+__global__ __launch_bounds__(kBlockThreads, 2) void render_small_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+                                                                      unsigned long long* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* tfLds = render_prologue(P, S, lds);
+    render_body<2, ACT, 0, HAS_DIR, FM_COS, false, TAIL_SCALAR_TABLE, NLC>(P, S, lds, tfLds, out, stats);
 }
 
 // finite-difference normals / shading BRDF (SceneParams::gradientMode, brdf*): 7 network evaluations per sample

@@ -537,13 +537,21 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
     const float actA = P.actA, actB = P.actB;
     const char* ldsA = lds + 16 * lane;  // A fragments are lane-linear
     const char* ldsB = lds + 16 * h;     // bias blocks: this lane half's rows 8g + 4h .. +3 at 32g bytes
+#ifdef FVSRN_ABL_NOLDS  // ablation build (tools/ablate.sh): the layer loop without its LDS reads (registers left undefined)
+    auto frag = [&](int) { half8_t v; asm volatile("" : "=v"(v)); return v; };
+#else
     auto frag = [&](int byteOff) { return *reinterpret_cast<const half8_t*>(ldsA + byteOff); };
+#endif
     auto bias = [&](int byteOff) {
         floatx16 c;
         const float4_t* p = reinterpret_cast<const float4_t*>(ldsB + byteOff);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+#ifdef FVSRN_ABL_NOLDS
+            float4_t v; asm volatile("" : "=v"(v));
+#else
             const float4_t v = p[2 * g];
+#endif
             c[4 * g + 0] = v[0]; c[4 * g + 1] = v[1]; c[4 * g + 2] = v[2]; c[4 * g + 3] = v[3];
         }
         return c;
@@ -639,7 +647,11 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
                     const float4_t* p = reinterpret_cast<const float4_t*>(ldsB + biasOff + m * 128);
 #pragma unroll
                     for (int g = q >> 1; g < 4; g += 2) {
+#ifdef FVSRN_ABL_NOLDS
+                        float4_t v; asm volatile("" : "=v"(v)); (void)p;
+#else
                         const float4_t v = p[2 * g];
+#endif
                         acc[O][m][4 * g + 0] = v[0]; acc[O][m][4 * g + 1] = v[1]; acc[O][m][4 * g + 2] = v[2]; acc[O][m][4 * g + 3] = v[3];
                     }
                 }
@@ -689,7 +701,11 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
     FVSRN_MARK(P, 4);  // hidden layers
     // ---- last layer: 16x16x32 MFMAs (pack.cpp) on the same B fragments; its weight fragments are a[0..KS-1]; output r of
     // this lane's tile-(lane>>5) sample lands in register r ----------------------------------------------------------------
+#ifdef FVSRN_ABL_NOLDS
+    float4_t biasLast; asm volatile("" : "=v"(biasLast));
+#else
     const float4_t biasLast = *reinterpret_cast<const float4_t*>(lds + P.offBias + NL * kBiasLayer);
+#endif
     float4_t o0 = biasLast, o1 = biasLast;
     interleave<KS, NV>([&](int s) { o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s], xb[0][s], o0, 0, 0, 0); },
                        [&](int j) {
@@ -822,6 +838,93 @@ __device__ __forceinline__ float4_t srn_forward_rotating(const NetParams& P, con
             for (int c = 0; c < NP - NFILL; ++c) fourier_advance_piece<CD, HAS_DIR>(feat, dfeat, c);
         },
         [&](int j) { fourier_advance_piece<CD, HAS_DIR>(feat, dfeat, NP - NFILL + j); });
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Small networks entirely in registers (render_small_kernel): a 32-wide Fourier-only network with NLC <= 3 C->C layers has
+// 2 (NLC + 1) weight fragments (4 registers each) and NLC bias blocks (16 registers): 80 registers at NLC = 3.  With the 256
+// registers of a 2-waves-per-SIMD kernel they stay resident for the whole launch, and the sample loop has no LDS access at
+// all: the same schedule as srn_layers_pipelined without its 33 ds_read_b128 per wave step (8 weight fragments, 6 x 4 bias
+// blocks), their address arithmetic and their waits, and the bias block enters as the C operand of each tile's first MFMA
+// instead of passing through the accumulator registers.  Measured r01 on the headline frame with the LDS reads of the
+// 3-wave kernel ablated: 126.7 -> 145.6 Gsamples/s at 3 waves, 140.6 at 2 waves (what fits), tools/ablate.sh.
+template <int NLC>
+struct ResidentNet {
+    half8_t w[2 * (NLC + 1)];  // [layer 0 | hidden 1..NLC-1 | last][K step]
+    floatx16 b[NLC];           // bias rows of this lane half, layers 0..NLC-1
+    float4_t bLast;
+};
+
+template <int NLC>
+__device__ __forceinline__ void load_resident(const NetParams& P, const char* lds, ResidentNet<NLC>& R) {
+    const int lane = lane_id();
+    const char* ldsA = lds + 16 * lane;
+    const char* ldsB = lds + 16 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) R.w[i] = *reinterpret_cast<const half8_t*>(ldsA + P.offLayer0 + i * kFragBytes);
+#pragma unroll
+    for (int i = 0; i < 2 * (NLC - 1); ++i) R.w[2 + i] = *reinterpret_cast<const half8_t*>(ldsA + P.offHidden + i * kFragBytes);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) R.w[2 * NLC + i] = *reinterpret_cast<const half8_t*>(ldsA + P.offLast + i * kFragBytes);
+#pragma unroll
+    for (int l = 0; l < NLC; ++l) {
+        const float4_t* p = reinterpret_cast<const float4_t*>(ldsB + P.offBias + l * 128);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4_t v = p[2 * g];
+            R.b[l][4 * g + 0] = v[0]; R.b[l][4 * g + 1] = v[1]; R.b[l][4 * g + 2] = v[2]; R.b[l][4 * g + 3] = v[3];
+        }
+    }
+    R.bLast = *reinterpret_cast<const float4_t*>(lds + P.offBias + NLC * 128);
+}
+
+// srn_layers_pipelined for CD = 2, GRID = 0 on a ResidentNet; returns output 0 of this lane's sample (scalar networks)
+template <int ACT, int NLC, int NFILL, class Pre, class Fill>
+__device__ __forceinline__ float srn_layers_resident(const NetParams& P, const ResidentNet<NLC>& R, half8_t (&xb)[2][2], Pre&& pre, Fill&& fill) {
+    const float actA = P.actA, actB = P.actB;
+    constexpr int NF0 = NFILL / 2;
+    floatx16 acc[2];
+    __builtin_amdgcn_sched_barrier(0);
+    pre();
+    __builtin_amdgcn_sched_barrier(0);
+    // first layer, tile 0 (its MFMAs carry rotation pieces)
+    interleave<2, NF0>([&](int i) { acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.w[i], xb[0][i], i == 0 ? R.b[0] : acc[0], 0, 0, 0); },
+                       [&](int j) { fill(j); });
+    // half-layer slot: layer l for tile T || activation + convert of the other tile
+    auto slot = [&](auto tileTag, auto layerTag) {
+        constexpr int T = decltype(tileTag)::value, O = 1 - T, L = decltype(layerTag)::value;
+        interleave<2, 4>([&](int i) { acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.w[2 * L + i], xb[T][i], i == 0 ? R.b[L] : acc[T], 0, 0, 0); },
+                         [&](int q) { act_pack_quarter<ACT>(acc[O], q, actA, actB, xb[O][0], xb[O][1]); });
+    };
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+    slot(T1{}, std::integral_constant<int, 0>{});
+    if constexpr (NLC > 1) { slot(T0{}, std::integral_constant<int, 1>{}); slot(T1{}, std::integral_constant<int, 1>{}); }
+    if constexpr (NLC > 2) { slot(T0{}, std::integral_constant<int, 2>{}); slot(T1{}, std::integral_constant<int, 2>{}); }
+    static_assert(NLC >= 1 && NLC <= 3, "resident networks: 1..3 C->C layers");
+    // last layer (16x16x32, see srn_layers_pipelined)
+    float4_t o0 = R.bLast, o1 = R.bLast;
+    interleave<2, 4>([&](int s) { o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(R.w[2 * NLC + s], xb[0][s], o0, 0, 0, 0); },
+                     [&](int q) { act_pack_quarter<ACT>(acc[1], q, actA, actB, xb[1][0], xb[1][1]); });
+    interleave<2, NFILL - NF0>([&](int s) { o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(R.w[2 * NLC + s], xb[1][s], o1, 0, 0, 0); },
+                               [&](int j) { fill(NF0 + j); });
+    return (lane_id() >> 5) ? o1[0] : o0[0];
+}
+
+// srn_forward_rotating on a ResidentNet
+template <int ACT, bool HAS_DIR, int NLC>
+__device__ __forceinline__ float srn_forward_rotating_resident(const NetParams& P, const ResidentNet<NLC>& R, floatx16 (&feat)[2][1],
+                                                               const floatx16 (&dfeat)[2][1]) {
+    constexpr int NP = 16, NFILL = NP / 2;
+    half8_t xb[2][2];
+    return srn_layers_resident<ACT, NLC, NFILL>(
+        P, R, xb,
+        [&]() {
+            feature_fragments<2>(feat, xb);
+#pragma unroll
+            for (int c = 0; c < NP - NFILL; ++c) fourier_advance_piece<2, HAS_DIR>(feat, dfeat, c);
+        },
+        [&](int j) { fourier_advance_piece<2, HAS_DIR>(feat, dfeat, NP - NFILL + j); });
 }
 
 // output parametrization, renderer_volume_tensorcores.cuh:1054-1158. The reference rounds the

@@ -243,6 +243,36 @@ def test_feature_rotation_stays_close_to_per_step_features(monkeypatch):
     assert float((exact - rotated).abs().max()) < TOL_IMG
 
 
+@pytest.mark.parametrize("layers,activation,output_mode,tf", [
+    (4, "ReLU", "density:direct", "identity"), (3, "SnakeAlt", "density", "texture"), (2, "Sine", "density", "identity"),
+])
+def test_register_resident_kernel_matches_lds_kernel(monkeypatch, layers, activation, output_mode, tf):
+    """render_small_kernel (32-wide Fourier-only scalar networks with <= 3 C->C layers: weights and biases resident in
+    registers, no LDS access in the sample loop) runs the same schedule as render_kernel (FVSRN_SMALL_KERNEL=0): images
+    agree to rounding (measured <= 1e-4: hipcc contracts the fp32 tail differently in the two kernels), both match the oracle."""
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=32, layers=layers, activation=activation, output_mode=output_mode, seed=77, box_min=(-0.5, -0.5, -0.5))
+    kw = make_scene_kwargs(stepsize=1 / 128, early_out=True, tf_scale_absorption=10.0, density_min=-1.0, density_max=1.0)
+    if tf == "texture":
+        rng = np.random.RandomState(5)
+        tab = rng.uniform(0.0, 1.0, (64, 4)).astype(np.float32)
+        tab[:, 3] *= 20.0
+        kw.update(tf_kind=oracle.TF_TEXTURE, tf_table=tab)
+    else:
+        kw.update(tf_kind=oracle.TF_IDENTITY)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    W = H = 96
+    small = capi.Scene(**kw).render(net, W, H)[0].clone()
+    monkeypatch.setenv("FVSRN_SMALL_KERNEL", "0")
+    plain = capi.Scene(**kw).render(net, W, H)[0].clone()
+    assert small[3].max() > 0.2
+    import torch
+    diff = float((torch.nan_to_num(small, nan=-7.0) - torch.nan_to_num(plain, nan=-7.0)).abs().max())
+    assert diff < 5e-4, diff
+    ref, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), W, H, 0, H)
+    assert np.abs(small[:4].cpu().numpy() - ref[:4]).max() < TOL_IMG
+
+
 PHONG = dict(enable_phong=True, ambient=0.2, specular=0.4, magnitude_center=0.6, magnitude_radius=0.5, specular_exponent=8,
              light_type=0, light=(1.0, -1.5, 0.8))
 
