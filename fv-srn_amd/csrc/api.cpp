@@ -608,8 +608,18 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
         if (!net || !buf || cap == 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
         std::lock_guard<std::mutex> lock(net->mu);
         net->pack();
-        const char* name = render ? net->kinfoScaled.renderName : net->kinfo.evalName;
-        std::strncpy(buf, name, cap - 1);
+        std::string name = render ? net->kinfoScaled.renderName : net->kinfo.evalName;
+        if (render) {  // the register-resident kernel takes over for scenes with an Identity / Texture TF and no shading (renderImpl)
+            const NetParams& P = net->packed.params;
+            const VariantKey& k = net->keyScaled;
+            const char* e = std::getenv("FVSRN_SMALL_KERNEL");
+            const bool scalarNet = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
+            if (!(e && e[0] == '0') && k.CD == 2 && k.grid == 0 && !P.noFourier && !P.fourierNeedsFract && scalarNet &&
+                render_small_fn(k.act, k.dir, P.numLayers))
+                name = "render_small_kernel<act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "," + std::to_string(P.numLayers) +
+                       "> (Identity/Texture TF, unshaded; else " + name + ")";
+        }
+        std::strncpy(buf, name.c_str(), cap - 1);
         buf[cap - 1] = 0;
         return FVSRN_OK;
     });

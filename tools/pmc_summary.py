@@ -12,9 +12,10 @@ for d in sorted(glob.glob(root + "/pmc*")):
         acc = collections.defaultdict(lambda: collections.defaultdict(float))
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            if "render_kernel" not in k:
+            name = next((n for n in ("render_small_kernel", "render_shaded_kernel", "render_kernel") if n in k), None)
+            if name is None:
                 continue
-            k = k[k.index("render_kernel"):].split("(")[0]
+            k = k[k.index(name):].split("(")[0]
             acc[(k, row["Counter_Name"])][row["Dispatch_Id"]] += float(row["Counter_Value"])
         for (k, c), per in sorted(acc.items()):
             print("%s,\"%s\",%s,%d,%.1f" % (d.split("/")[-1], k, c, len(per), sum(per.values()) / len(per)))
