@@ -823,12 +823,9 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const int tilesX = (width + 7) / 8, tilesY = (numLocalRows + 7) / 8;
             const int tiles = tilesX * tilesY;
             const size_t lds = size_t(a.P.ldsBytes) + tfFloats * 4;
-            // A rank of a multi-GPU frame (stripeWorld > 1) launches one workgroup per few work units instead of persistent
-            // waves (see below); four waves per workgroup then share the copy of the network into LDS, which would
-            // otherwise cost every one-wave workgroup ~5 us against ~30 us of rendering.
             const char* pers = std::getenv("FVSRN_PERSISTENT");
             const bool persistent = pers ? pers[0] != '0' : stripeWorld == 1;
-            const int wpb = persistent ? wavesPerBlockFor(lds) : std::max(wavesPerBlockFor(lds), std::getenv("FVSRN_WAVES_PER_BLOCK") ? 1 : 4);
+            const int wpb = wavesPerBlockFor(lds);
             // Small networks in registers (render_small_kernel, kernels.hpp): 32-wide Fourier-only scalar network with at most
             // three C->C layers, phases inside the v_cos domain, Identity or Texture TF, no shading.  FVSRN_SMALL_KERNEL=0: off.
             const void* smallFn = nullptr;
