@@ -77,10 +77,14 @@ class Runner:
         self.stats = torch.zeros(2, dtype=torch.int64, device="cuda")
         # N > 1: frames alternate between two scenes on two streams, so that the launch tail of frame i (its last waves, the
         # composite of its depth segments) overlaps the start of frame i + 1.  Not with time-dependent grids: a time change
-        # rewrites the working grid the previous frame may still read.
-        self.pipelined = world > 1 and time_keys == 1
+        # rewrites the working grid the previous frame may still read.  At N = 1 the same trick is worth +4 % (r01: 152.7 ->
+        # 159.0 Gsamples/s, FVSRN_BENCH_PIPELINE=1), but the default keeps one launch at a time there so that the HIP-event
+        # duration of the kernel, the rocprofv3 kernel trace and the frame period are the same number.
+        pipe = os.environ.get("FVSRN_BENCH_PIPELINE")
+        self.pipelined = time_keys == 1 and (pipe == "1" if pipe is not None else world > 1)
         if world == 1:
-            self.out = torch.zeros((1, 8, self.H, self.W), dtype=torch.float32, device="cuda")
+            self.outs = [torch.zeros((1, 8, self.H, self.W), dtype=torch.float32, device="cuda") for _ in range(2)]
+            self.out = self.outs[0]
         else:
             assert self.H % (STRIPE * world) == 0, "image height must be a multiple of stripe*world"
             rows = capi.stripe_rows(self.H, STRIPE, rank, world)
@@ -89,11 +93,11 @@ class Runner:
             self.comm_stream = torch.cuda.Stream()
             self.render_done = [torch.cuda.Event() for _ in range(2)]
             self.gather_done = [torch.cuda.Event() for _ in range(2)]
-            if self.pipelined:
-                self.scenes = [self.scene, capi.Scene(**build_scene_kwargs(capi, 0.0, self.stepsize, early_out))]
-                self.render_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-                for st in self.render_streams:
-                    st.wait_stream(torch.cuda.current_stream())
+        if self.pipelined:
+            self.scenes = [self.scene, capi.Scene(**build_scene_kwargs(capi, 0.0, self.stepsize, early_out))]
+            self.render_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            for st in self.render_streams:
+                st.wait_stream(torch.cuda.current_stream())
         self.kernel_events = []
 
     def frame(self, index, record=False):
@@ -110,7 +114,7 @@ class Runner:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             if self.world == 1:
-                scene.render(self.net, self.W, self.H, out=self.out, stats=self.stats)
+                scene.render(self.net, self.W, self.H, out=self.outs[b], stats=self.stats)
             else:
                 stream.wait_event(self.gather_done[b])  # buffer b free again
                 self.capi.render_stripes(scene, self.net, self.W, self.H, STRIPE, self.rank, self.world,
@@ -126,10 +130,10 @@ class Runner:
                 self.gather_done[b].record()
 
     def finish(self):
+        if self.pipelined:
+            for st in self.render_streams:
+                torch.cuda.current_stream().wait_stream(st)
         if self.world > 1:
-            if self.pipelined:
-                for st in self.render_streams:
-                    torch.cuda.current_stream().wait_stream(st)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def assemble(self, b=0):
