@@ -100,6 +100,13 @@ SYMBOLS = [
     ("fvsrn_generate_rays", _I, [_FP, _FP, _FP, _F, _I, _I, _VP, _VP, _VP]),
     ("fvsrn_scene_evaluate_tf", _I, [_VP, _VP, _VP, _SZ, _F, _F, _F, _VP, _VP]),
     ("fvsrn_network_kernel_name", _I, [_VP, _I, C.c_char_p, _SZ]),
+    ("fvsrn_volume_create", _I, [_VP, _I, _I, _I, _I, _I, _FP, _FP, C.POINTER(_VP)]),
+    ("fvsrn_volume_destroy", _I, [_VP]),
+    ("fvsrn_volume_load_cvol", _I, [C.c_char_p, _I, C.POINTER(_VP)]),
+    ("fvsrn_volume_save_cvol", _I, [C.c_char_p, C.c_char_p, _VP, _I, _I, _I, _I, _F, _F, _F]),
+    ("fvsrn_volume_info", _I, [_VP, C.POINTER(_I), _FP, _FP]),
+    ("fvsrn_volume_evaluate_points", _I, [_VP, _I, _I, _I, _VP, _SZ, _VP, _VP]),
+    ("fvsrn_render_volume", _I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
 ]
 
 _lib = None
@@ -373,6 +380,85 @@ class Scene:
 
 def stripe_rows(height: int, stripe: int, rank: int, world: int) -> int:
     return lib().fvsrn_stripe_rows(height, stripe, rank, world)
+
+
+VOLUME_U8, VOLUME_U16, VOLUME_F32 = range(3)
+VOLUME_NEAREST, VOLUME_TRILINEAR, VOLUME_TRICUBIC = range(3)
+VOLUME_SOURCE_TEXTURE, VOLUME_SOURCE_TENSOR = range(2)
+_VOLUME_DTYPES = {"uint8": VOLUME_U8, "uint16": VOLUME_U16, "float32": VOLUME_F32}
+
+
+class Volume:
+    """One scalar feature of a grid volume (renderer/volume.h) for ``VolumeInterpolationGrid``: fvsrn_volume_* of the C ABI."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_array(cls, data_xyz, box_min=None, box_size=None) -> "Volume":
+        """(X,Y,Z) uint8 / uint16 / float32 array.  Default box: [-s/2, s/2] with s = res / max(res), like
+        VolumeInterpolationGrid::setSource(tensor) (volume_interpolation_grid.cpp:200-224)."""
+        a = np.ascontiguousarray(data_xyz)
+        if a.ndim != 3 or a.dtype.name not in _VOLUME_DTYPES:
+            raise ValueError("expected a (X,Y,Z) uint8 / uint16 / float32 array")
+        if box_size is None:
+            box_size = [n / max(a.shape) for n in a.shape]
+        if box_min is None:
+            box_min = [-0.5 * b for b in box_size]
+        h = _VP()
+        _check(lib().fvsrn_volume_create(a.ctypes.data_as(_VP), _VOLUME_DTYPES[a.dtype.name], a.shape[0], a.shape[1], a.shape[2], 0,
+                                         (C.c_float * 3)(*[float(v) for v in box_min]), (C.c_float * 3)(*[float(v) for v in box_size]),
+                                         C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load(cls, path: str, feature_index: int = 0) -> "Volume":
+        """Uncompressed .cvol (Volume::Volume(filename), volume.cpp:685-740); box = [-world/2, world/2]."""
+        h = _VP()
+        _check(lib().fvsrn_volume_load_cvol(os.fsencode(path), feature_index, C.byref(h)))
+        return cls(h)
+
+    @staticmethod
+    def save_cvol(path: str, data_xyz, world_size=(1.0, 1.0, 1.0), feature_name: str = "density") -> None:
+        a = np.asarray(data_xyz)
+        if a.ndim != 3 or a.dtype.name not in _VOLUME_DTYPES:
+            raise ValueError("expected a (X,Y,Z) uint8 / uint16 / float32 array")
+        xfast = np.ascontiguousarray(a.transpose(2, 1, 0))  # file order: x fastest, z slowest
+        _check(lib().fvsrn_volume_save_cvol(os.fsencode(path), feature_name.encode(), xfast.ctypes.data_as(_VP), _VOLUME_DTYPES[a.dtype.name],
+                                            a.shape[0], a.shape[1], a.shape[2], *[float(w) for w in world_size]))
+
+    def info(self):
+        res, bmin, bsize = (_I * 3)(), (C.c_float * 3)(), (C.c_float * 3)()
+        _check(lib().fvsrn_volume_info(self._h, res, bmin, bsize))
+        return tuple(res), np.array(bmin, np.float32), np.array(bsize, np.float32)
+
+    def evaluate(self, positions, interpolation=VOLUME_TRILINEAR, source=VOLUME_SOURCE_TEXTURE, new_behavior=False, stream=None):
+        """IVolumeInterpolation::evaluate: (N,3) fp32 CUDA world positions -> (N,1)."""
+        import torch
+        pp = _torch_ptr(positions, "torch.float32", "positions")
+        out = torch.empty((positions.shape[0], 1), dtype=torch.float32, device=positions.device)
+        _check(lib().fvsrn_volume_evaluate_points(self._h, source, interpolation, int(new_behavior), pp, positions.shape[0],
+                                                  _torch_ptr(out, "torch.float32", "out"), _current_stream() if stream is None else stream))
+        return out
+
+    def render(self, scene: "Scene", width: int, height: int, interpolation=VOLUME_TRILINEAR, source=VOLUME_SOURCE_TEXTURE,
+               new_behavior=False, out=None, stats=None, stream=None):
+        """ImageEvaluatorSimple.render with this volume: (1,8,H,W) fp32."""
+        import torch
+        if out is None:
+            out = torch.zeros((1, 8, height, width), dtype=torch.float32, device="cuda")
+        sp = _torch_ptr(stats, "torch.int64", "stats") if stats is not None else None
+        _check(lib().fvsrn_render_volume(scene._h, self._h, source, interpolation, int(new_behavior), width, height,
+                                         _torch_ptr(out, "torch.float32", "out"), sp, _current_stream() if stream is None else stream))
+        return out
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().fvsrn_volume_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 def render_stripes(scene: Scene, net: Network, width: int, height: int, stripe: int, rank: int, world: int, out=None,

@@ -14,6 +14,9 @@
 #include "srn_device_enums.hpp"
 #include "pack.hpp"
 #include "scene_network.hpp"
+#include "grid_volume.hpp"
+#include <fstream>
+#include <vector>
 
 using namespace fvsrn;
 
@@ -750,6 +753,39 @@ int fvsrn_camera_on_a_sphere(int orientation, const double center[3], double pit
     });
 }
 
+// camera, ray stepping, TF and BRDF constants of a scene (device tables must be uploaded: fvsrn_scene::uploadTf)
+static void fillSceneParams(fvsrn_scene* scene, const fvsrn_scene_desc& d, int width, int height, SceneParams& S) {
+    for (int i = 0; i < 3; ++i) { S.eye[i] = d.cam_eye[i]; S.right[i] = d.cam_right[i]; S.up[i] = d.cam_up[i]; }
+    // front = cross(up, right), renderer_camera.cuh:47
+    S.front[0] = S.up[1] * S.right[2] - S.up[2] * S.right[1];
+    S.front[1] = S.up[2] * S.right[0] - S.up[0] * S.right[2];
+    S.front[2] = S.up[0] * S.right[1] - S.up[1] * S.right[0];
+    S.tanFovY = std::tan(d.fov_y_radians / 2);
+    S.tanFovX = S.tanFovY * (float(width) / float(height));  // setAspectRatio, image_evaluator_simple.cpp:204
+    S.stepsize = d.stepsize;
+    S.alphaEarlyOut = 1.0f - 1e-5f;  // ray_evaluation_stepping.cpp:536
+    S.densityMin = d.density_min;
+    S.divDensityRange = 1.0f / (d.density_max - d.density_min);
+    S.earlyOut = d.early_out;
+    S.blendMode = d.blend_mode;
+    S.gradientMode = d.gradient_mode;
+    S.fdStep = d.finite_differences_stepsize;
+    S.brdfMagnitudeScaling = d.brdf_enable_magnitude_scaling;
+    S.brdfPhong = d.brdf_enable_phong;
+    S.brdfLightType = d.brdf_light_type;
+    S.brdfSpecularExponent = d.brdf_specular_exponent;
+    S.brdfMagScale = d.brdf_magnitude_scaling; S.brdfAmbient = d.brdf_ambient; S.brdfSpecular = d.brdf_specular;
+    S.brdfMagCenter = d.brdf_magnitude_center; S.brdfMagRadius = d.brdf_magnitude_radius;
+    for (int i = 0; i < 3; ++i) S.brdfLight[i] = d.brdf_light[i];
+    S.tfKind = d.tf_kind;
+    S.tfRows = d.tf_rows; S.tfRowsF = float(d.tf_rows);
+    S.tfScaleAbsorption = d.tf_scale_absorption;
+    S.tfScaleEmission = d.tf_scale_emission;
+    S.tfTable = static_cast<const float*>(scene->dTf.ptr);
+    S.tfPreintegration = d.tf_preintegration;
+    S.tfPreintegrated = static_cast<const float*>(scene->dPreint.ptr);
+}
+
 static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int height, int y0, int y1, int numLocalRows,
                       int stripeRows, int stripeRank, int stripeWorld, int compact, float* d_out8,
                       unsigned long long* d_stats, void* stream) {
@@ -786,35 +822,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 a.P.reluClamp = 1;
             }
             SceneParams& S = a.S;
-            for (int i = 0; i < 3; ++i) { S.eye[i] = d.cam_eye[i]; S.right[i] = d.cam_right[i]; S.up[i] = d.cam_up[i]; }
-            // front = cross(up, right), renderer_camera.cuh:47
-            S.front[0] = S.up[1] * S.right[2] - S.up[2] * S.right[1];
-            S.front[1] = S.up[2] * S.right[0] - S.up[0] * S.right[2];
-            S.front[2] = S.up[0] * S.right[1] - S.up[1] * S.right[0];
-            S.tanFovY = std::tan(d.fov_y_radians / 2);
-            S.tanFovX = S.tanFovY * (float(width) / float(height));  // setAspectRatio, image_evaluator_simple.cpp:204
-            S.stepsize = d.stepsize;
-            S.alphaEarlyOut = 1.0f - 1e-5f;  // ray_evaluation_stepping.cpp:536
-            S.densityMin = d.density_min;
-            S.divDensityRange = 1.0f / (d.density_max - d.density_min);
-            S.earlyOut = d.early_out;
-            S.blendMode = d.blend_mode;
-            S.gradientMode = d.gradient_mode;
-            S.fdStep = d.finite_differences_stepsize;
-            S.brdfMagnitudeScaling = d.brdf_enable_magnitude_scaling;
-            S.brdfPhong = d.brdf_enable_phong;
-            S.brdfLightType = d.brdf_light_type;
-            S.brdfSpecularExponent = d.brdf_specular_exponent;
-            S.brdfMagScale = d.brdf_magnitude_scaling; S.brdfAmbient = d.brdf_ambient; S.brdfSpecular = d.brdf_specular;
-            S.brdfMagCenter = d.brdf_magnitude_center; S.brdfMagRadius = d.brdf_magnitude_radius;
-            for (int i = 0; i < 3; ++i) S.brdfLight[i] = d.brdf_light[i];
-            S.tfKind = d.tf_kind;
-            S.tfRows = d.tf_rows; S.tfRowsF = float(d.tf_rows);
-            S.tfScaleAbsorption = d.tf_scale_absorption;
-            S.tfScaleEmission = d.tf_scale_emission;
-            S.tfTable = static_cast<const float*>(scene->dTf.ptr);
-            S.tfPreintegration = d.tf_preintegration;
-            S.tfPreintegrated = static_cast<const float*>(scene->dPreint.ptr);
+            fillSceneParams(scene, d, width, height, S);
             S.width = width; S.height = height; S.y0 = y0; S.y1 = y1;
             S.numLocalRows = numLocalRows; S.stripeRows = stripeRows; S.stripeRank = stripeRank;
             S.stripeWorld = stripeWorld; S.compact = compact;
@@ -1024,6 +1032,224 @@ int fvsrn_render_stripes(fvsrn_scene* scene, fvsrn_network* net, int width, int 
     // local rows are laid out stripe after stripe; a short last stripe only ever is the LAST local stripe
     const int rows = fvsrn_stripe_rows(height, stripe_rows, rank, world);
     return renderImpl(scene, net, width, height, 0, height, rows, stripe_rows, rank, world, 1, d_out_local, d_stats, stream);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ dense grid volumes
+struct fvsrn_volume {
+    std::mutex mu;
+    std::vector<float> host;  // x fastest: x + X (y + Y z), like Volume::MipmapLevel::idx (volume.h:126-132)
+    int res[3] = {0, 0, 0};
+    float boxMin[3] = {0, 0, 0}, boxSize[3] = {1, 1, 1};
+    DeviceBuffer dData;
+    bool deviceValid = false;
+    ~fvsrn_volume() { dData.release(); }
+    void ensureDevice(hipStream_t s) {
+        if (deviceValid) return;
+        dData.ensure(host.size() * sizeof(float));
+        HIP_CHECK(hipMemcpyAsync(dData.ptr, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        deviceValid = true;
+    }
+    VolumeParams params(int source, int interpolation, int newBehavior) const {
+        VolumeParams V{};
+        V.data = static_cast<const float*>(dData.ptr);
+        for (int i = 0; i < 3; ++i) { V.res[i] = res[i]; V.boxMin[i] = boxMin[i]; V.boxSize[i] = boxSize[i]; }
+        V.stride[0] = 1; V.stride[1] = res[0]; V.stride[2] = (long long)res[0] * res[1];
+        V.source = source; V.interpolation = interpolation; V.newBehavior = newBehavior;
+        return V;
+    }
+};
+
+namespace {
+// u8 / u16 voxels are read as normalised floats like the reference's textures (cudaReadModeNormalizedFloat, volume.cpp:109-167)
+void convertVoxels(const void* src, int dtype, size_t n, float* dst) {
+    switch (dtype) {
+        case FVSRN_VOLUME_U8: { const unsigned char* p = static_cast<const unsigned char*>(src); for (size_t i = 0; i < n; ++i) dst[i] = float(p[i]) / 255.0f; } break;
+        case FVSRN_VOLUME_U16: { const unsigned short* p = static_cast<const unsigned short*>(src); for (size_t i = 0; i < n; ++i) dst[i] = float(p[i]) / 65535.0f; } break;
+        default: std::memcpy(dst, src, n * sizeof(float)); break;
+    }
+}
+int checkVolumeModes(int source, int interpolation) {
+    if (source != FVSRN_VOLUME_SOURCE_TEXTURE && source != FVSRN_VOLUME_SOURCE_TENSOR) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad volume source");
+    if (interpolation < FVSRN_VOLUME_NEAREST || interpolation > FVSRN_VOLUME_TRICUBIC) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad volume interpolation");
+    return FVSRN_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int fvsrn_volume_create(const void* host_data, int dtype, int sx, int sy, int sz, int x_fastest, const float box_min[3],
+                        const float box_size[3], fvsrn_volume** out) {
+    return guarded([&] {
+        if (!host_data || !out || !box_min || !box_size) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        if (sx <= 0 || sy <= 0 || sz <= 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad volume resolution");
+        if (dtype < FVSRN_VOLUME_U8 || dtype > FVSRN_VOLUME_F32) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad volume data type");
+        for (int i = 0; i < 3; ++i)
+            if (!(box_size[i] > 0)) return fail(FVSRN_ERR_INVALID_ARGUMENT, "box size must be positive");
+        auto v = std::make_unique<fvsrn_volume>();
+        const size_t n = size_t(sx) * sy * sz;
+        v->host.resize(n);
+        if (x_fastest) {
+            convertVoxels(host_data, dtype, n, v->host.data());
+        } else {  // contiguous (X,Y,Z) tensor: z fastest
+            std::vector<float> tmp(n);
+            convertVoxels(host_data, dtype, n, tmp.data());
+            for (int x = 0; x < sx; ++x)
+                for (int y = 0; y < sy; ++y)
+                    for (int z = 0; z < sz; ++z) v->host[size_t(x) + size_t(sx) * (size_t(y) + size_t(sy) * z)] = tmp[(size_t(x) * sy + y) * sz + z];
+        }
+        v->res[0] = sx; v->res[1] = sy; v->res[2] = sz;
+        for (int i = 0; i < 3; ++i) { v->boxMin[i] = box_min[i]; v->boxSize[i] = box_size[i]; }
+        *out = v.release();
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_volume_destroy(fvsrn_volume* volume) {
+    delete volume;
+    return FVSRN_OK;
+}
+
+int fvsrn_volume_info(fvsrn_volume* volume, int resolution[3], float box_min[3], float box_size[3]) {
+    if (!volume) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+    for (int i = 0; i < 3; ++i) {
+        if (resolution) resolution[i] = volume->res[i];
+        if (box_min) box_min[i] = volume->boxMin[i];
+        if (box_size) box_size[i] = volume->boxSize[i];
+    }
+    return FVSRN_OK;
+}
+
+// Volume::save / Volume::Volume(filename) (volume.cpp:623-668, 685-740), Feature::save / load (:278-332, 346-385)
+int fvsrn_volume_save_cvol(const char* path, const char* feature_name, const void* host_data, int dtype, int sx, int sy, int sz,
+                           float world_x, float world_y, float world_z) {
+    return guarded([&] {
+        if (!path || !feature_name || !host_data) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        if (sx <= 0 || sy <= 0 || sz <= 0 || dtype < FVSRN_VOLUME_U8 || dtype > FVSRN_VOLUME_F32) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad volume");
+        std::ofstream f(path, std::ios::binary);
+        if (!f) return fail(FVSRN_ERR_IO, std::string("cannot write ") + path);
+        const int version = 1, numFeatures = 1, flags = 0, channels = 1;
+        const char pad[4] = {0, 0, 0, 0};
+        f.write("CVOL", 4);
+        f.write(reinterpret_cast<const char*>(&version), 4);
+        f.write(reinterpret_cast<const char*>(&world_x), 4);
+        f.write(reinterpret_cast<const char*>(&world_y), 4);
+        f.write(reinterpret_cast<const char*>(&world_z), 4);
+        f.write(reinterpret_cast<const char*>(&numFeatures), 4);
+        f.write(reinterpret_cast<const char*>(&flags), 4);
+        f.write(pad, 4);
+        const int lenName = int(std::strlen(feature_name));
+        const unsigned long long X = sx, Y = sy, Z = sz;
+        f.write(reinterpret_cast<const char*>(&lenName), 4);
+        f.write(feature_name, lenName);
+        f.write(reinterpret_cast<const char*>(&X), 8);
+        f.write(reinterpret_cast<const char*>(&Y), 8);
+        f.write(reinterpret_cast<const char*>(&Z), 8);
+        f.write(reinterpret_cast<const char*>(&channels), 4);
+        f.write(reinterpret_cast<const char*>(&dtype), 4);
+        static const size_t bytesPerType[3] = {1, 2, 4};
+        f.write(static_cast<const char*>(host_data), std::streamsize(bytesPerType[dtype] * X * Y * Z));
+        if (!f) return fail(FVSRN_ERR_IO, std::string("error while writing ") + path);
+        return FVSRN_OK;
+    });
+}
+
+int fvsrn_volume_load_cvol(const char* path, int feature_index, fvsrn_volume** out) {
+    return guarded([&] {
+        if (!path || !out) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        std::ifstream f(path, std::ios::binary);
+        if (!f) return fail(FVSRN_ERR_IO, std::string("Unable to open file ") + path);
+        char magic[4];
+        int version = 0, numFeatures = 0, flags = 0;
+        float world[3];
+        f.read(magic, 4);
+        if (!f || std::memcmp(magic, "CVOL", 4) != 0)
+            return fail(FVSRN_ERR_FORMAT, std::memcmp(magic, "cvol", 4) == 0 ? "legacy 'cvol' files (density only, volume.cpp:741-793) are not supported"
+                                                                               : "Illegal magic number");
+        f.read(reinterpret_cast<char*>(&version), 4);
+        if (version != 1) return fail(FVSRN_ERR_FORMAT, "Unknown file version!");
+        f.read(reinterpret_cast<char*>(world), 12);
+        f.read(reinterpret_cast<char*>(&numFeatures), 4);
+        f.read(reinterpret_cast<char*>(&flags), 4);
+        f.ignore(4);
+        if (flags & 1) return fail(FVSRN_ERR_UNSUPPORTED, "LZ4-compressed .cvol files are not supported (save the volume with compression 0)");
+        if (feature_index < 0 || feature_index >= numFeatures) return fail(FVSRN_ERR_INVALID_ARGUMENT, "no such feature in the volume");
+        static const size_t bytesPerType[3] = {1, 2, 4};
+        for (int i = 0; i <= feature_index; ++i) {
+            int lenName = 0, channels = 0, type = 0;
+            unsigned long long X = 0, Y = 0, Z = 0;
+            f.read(reinterpret_cast<char*>(&lenName), 4);
+            if (!f || lenName < 0 || lenName > 4096) return fail(FVSRN_ERR_FORMAT, "corrupt feature header");
+            std::string name(size_t(lenName), ' ');
+            f.read(name.data(), lenName);
+            f.read(reinterpret_cast<char*>(&X), 8);
+            f.read(reinterpret_cast<char*>(&Y), 8);
+            f.read(reinterpret_cast<char*>(&Z), 8);
+            f.read(reinterpret_cast<char*>(&channels), 4);
+            f.read(reinterpret_cast<char*>(&type), 4);
+            if (!f || type < 0 || type > 2 || channels <= 0 || X == 0 || Y == 0 || Z == 0 || X > 65536 || Y > 65536 || Z > 65536)
+                return fail(FVSRN_ERR_FORMAT, "corrupt feature header");
+            const size_t bytes = bytesPerType[type] * X * Y * Z * size_t(channels);
+            if (i < feature_index) { f.ignore(std::streamsize(bytes)); continue; }
+            if (channels != 1) return fail(FVSRN_ERR_UNSUPPORTED, "only scalar (1-channel) features can be rendered as densities");
+            std::vector<char> raw(bytes);
+            f.read(raw.data(), std::streamsize(bytes));
+            if (!f) return fail(FVSRN_ERR_FORMAT, "unexpected end of file");
+            const float boxMin[3] = {-world[0] / 2, -world[1] / 2, -world[2] / 2};  // VolumeInterpolationGrid::setSource, :193-198
+            return fvsrn_volume_create(raw.data(), type, int(X), int(Y), int(Z), 1, boxMin, world, out);
+        }
+        return fail(FVSRN_ERR_FORMAT, "feature not found");
+    });
+}
+
+int fvsrn_volume_evaluate_points(fvsrn_volume* volume, int source, int interpolation, int grid_resolution_new_behavior,
+                                 const float* d_positions, size_t n, float* d_out, void* stream) {
+    return guarded([&] {
+        if (!volume || (n > 0 && (!d_positions || !d_out))) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        if (const int rc = checkVolumeModes(source, interpolation)) return rc;
+        std::lock_guard<std::mutex> lock(volume->mu);
+        try {
+            hipStream_t s = static_cast<hipStream_t>(stream);
+            volume->ensureDevice(s);
+            const hipError_t e = launch_volume_evaluate(volume->params(source, interpolation, grid_resolution_new_behavior), d_positions, n, d_out, s);
+            if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during evaluation! ") + hipGetErrorString(e));
+            return FVSRN_OK;
+        } catch (const DeviceError& e) {
+            return fail(fvsrn_device_count() == 0 ? FVSRN_ERR_NO_DEVICE : FVSRN_ERR_DEVICE, e.what());
+        }
+    });
+}
+
+int fvsrn_render_volume(fvsrn_scene* scene, fvsrn_volume* volume, int source, int interpolation, int grid_resolution_new_behavior,
+                        int width, int height, float* d_out8, unsigned long long* d_stats, void* stream) {
+    return guarded([&] {
+        if (!scene || !volume || !d_out8) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        if (width <= 0 || height <= 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad image size");
+        if (const int rc = checkVolumeModes(source, interpolation)) return rc;
+        std::lock_guard<std::mutex> lockV(volume->mu);
+        std::lock_guard<std::mutex> lockS(scene->mu);
+        try {
+            hipStream_t s = static_cast<hipStream_t>(stream);
+            const fvsrn_scene_desc& d = scene->desc;
+            if (d.tf_kind == FVSRN_TF_NONE) return fail(FVSRN_ERR_INVALID_ARGUMENT, "a grid volume holds densities; the scene needs a transfer function");
+            if (d.gradient_mode != FVSRN_GRADIENT_OFF_OR_DIRECT || d.brdf_enable_phong || d.brdf_enable_magnitude_scaling ||
+                d.tf_preintegration != FVSRN_PREINTEGRATE_NONE)
+                return fail(FVSRN_ERR_UNSUPPORTED, "grid volumes are rendered without normals: no shading BRDF, finite differences or pre-integrated TF");
+            volume->ensureDevice(s);
+            const size_t tfFloats = scene->tfTable.size();
+            if (const int rc = scene->uploadTf(d.stepsize, s)) return rc;
+            SceneParams S{};
+            fillSceneParams(scene, d, width, height, S);
+            S.width = width; S.height = height; S.y0 = 0; S.y1 = height;
+            const hipError_t e = launch_volume_render(volume->params(source, interpolation, grid_resolution_new_behavior), S, d_out8, d_stats, tfFloats, s);
+            if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during rendering! ") + hipGetErrorString(e));
+            return FVSRN_OK;
+        } catch (const DeviceError& e) {
+            return fail(fvsrn_device_count() == 0 ? FVSRN_ERR_NO_DEVICE : FVSRN_ERR_DEVICE, e.what());
+        }
+    });
 }
 
 }  // extern "C"

@@ -1,0 +1,104 @@
+// DVR of a dense grid volume: ImageEvaluatorSimpleKernel + RayEvaluationSteppingDvr with kernel::VolumeInterpolationGrid as
+// the volume (reference renderer_image_evaluator_simple.cuh:36-127, renderer_ray_evaluation_stepping_dvr.cuh:48-157,
+// renderer_volume_grid.cuh).  One thread per pixel, 8x8 pixel tiles per wave (neighbouring rays read neighbouring voxels);
+// the kernel is bound by the voxel gathers (8 per trilinear sample, L2/HBM), not by arithmetic.
+#include "kernels.hpp"
+#include "grid_volume.hpp"
+
+namespace fvsrn {
+
+__global__ __launch_bounds__(256) void volume_evaluate_kernel(VolumeParams V, const float* __restrict__ pos, size_t n,
+                                                             float* __restrict__ out) {
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x)
+        out[i] = vol_eval(V, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+}
+
+__global__ __launch_bounds__(256) void volume_render_kernel(VolumeParams V, SceneParams S, float* __restrict__ out,
+                                                           unsigned long long* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float tfLds[];
+    {
+        const int cols = S.tfKind == FVSRN_TF_GAUSSIAN ? 6 : (S.tfKind == FVSRN_TF_PIECEWISE ? 5 : (S.tfKind == FVSRN_TF_TEXTURE ? 4 : 0));
+        for (int i = threadIdx.x; i < cols * S.tfRows; i += int(blockDim.x)) tfLds[i] = S.tfTable[i];
+        __syncthreads();
+    }
+    // 256 threads = 4 waves, each an 8x8 pixel tile of a 16x16 block
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tilesX = (S.width + 15) >> 4;
+    const int bx = blockIdx.x % tilesX, by = blockIdx.x / tilesX;
+    const int x = bx * 16 + (wave & 1) * 8 + (lane & 7), y = by * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool inImage = x < S.width && y < S.height;
+
+    const float ndcx = 2.f * (float(x) + 0.5f) / float(S.width) - 1.f;
+    const float ndcy = 2.f * (float(y) + 0.5f) / float(S.height) - 1.f;
+    float dx = S.front[0] + ndcx * S.tanFovX * S.right[0] + ndcy * S.tanFovY * S.up[0];
+    float dy = S.front[1] + ndcx * S.tanFovX * S.right[1] + ndcy * S.tanFovY * S.up[1];
+    float dz = S.front[2] + ndcx * S.tanFovX * S.right[2] + ndcy * S.tanFovY * S.up[2];
+    const float invLen = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    dx *= invLen; dy *= invLen; dz *= invLen;
+    const float ox = S.eye[0], oy = S.eye[1], oz = S.eye[2];
+    float tmin, tmax;
+    {
+        const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+        const float t1 = (V.boxMin[0] - ox) * ix, t2 = (V.boxMin[0] + V.boxSize[0] - ox) * ix;
+        const float t3 = (V.boxMin[1] - oy) * iy, t4 = (V.boxMin[1] + V.boxSize[1] - oy) * iy;
+        const float t5 = (V.boxMin[2] - oz) * iz, t6 = (V.boxMin[2] + V.boxSize[2] - oz) * iz;
+        tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+        tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    }
+    tmin = fmaxf(tmin, 0.f);
+    if (!inImage) tmax = -1.f;
+
+    float cr = 0, cg = 0, cb = 0, ca = 0, depth = 0;
+    unsigned count = 0;
+    for (int i = 0;; ++i) {
+        const float t = tmin + float(i) * S.stepsize;
+        const bool valid = (t <= tmax) && (!S.earlyOut || ca < S.alphaEarlyOut);
+        if (!valid) break;  // per-lane view of the reference's warp-synchronous loop: an invalid lane never blends again
+        ++count;
+        const float value = vol_eval(V, ox + dx * t, oy + dy * t, oz + dz * t);
+        if (value >= S.densityMin) {  // stepping_dvr.cuh:110-135
+            const float4_t color = tf_eval(S, tfLds, (value - S.densityMin) * S.divDensityRange);
+            if (color[3] > 0.f) {  // Blending::eval
+                const float a = S.blendMode == FVSRN_BLEND_BEER_LAMBERT ? 1.f - __expf(-color[3]) : fminf(1.f, color[3]);
+                const float w = (1.f - ca) * a;
+                cr += w * color[0]; cg += w * color[1]; cb += w * color[2];
+                depth += w * t;
+                ca += w;
+            }
+        }
+    }
+    if (inImage) {
+        const size_t plane = size_t(S.width) * S.height, o = size_t(y) * S.width + x;
+        out[o] = cr; out[plane + o] = cg; out[2 * plane + o] = cb; out[3 * plane + o] = ca;
+        out[4 * plane + o] = 0.f; out[5 * plane + o] = 0.f; out[6 * plane + o] = 0.f;  // no normals requested from the grid
+        out[7 * plane + o] = depth * ca / ca;
+    }
+    if (stats) {
+        unsigned sum = count, mx = count;
+        for (int off = 32; off > 0; off >>= 1) {
+            sum += __shfl_down(sum, off);
+            const unsigned other = __shfl_down(mx, off);
+            mx = other > mx ? other : mx;
+        }
+        if (lane == 0) {
+            atomicAdd(&stats[0], (unsigned long long)sum);
+            atomicAdd(&stats[1], (unsigned long long)mx * 64ull);
+        }
+    }
+}
+
+hipError_t launch_volume_evaluate(const VolumeParams& V, const float* pos, size_t n, float* out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const unsigned grid = unsigned(std::min<size_t>((n + 255) / 256, 256 * 32));
+    hipLaunchKernelGGL(volume_evaluate_kernel, dim3(grid), dim3(256), 0, s, V, pos, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_volume_render(const VolumeParams& V, const SceneParams& S, float* out, unsigned long long* stats, size_t tfFloats,
+                                hipStream_t s) {
+    const unsigned grid = unsigned(((S.width + 15) / 16) * ((S.height + 15) / 16));
+    hipLaunchKernelGGL(volume_render_kernel, dim3(grid), dim3(256), tfFloats * 4, s, V, S, out, stats);
+    return hipGetLastError();
+}
+
+}  // namespace fvsrn

@@ -33,6 +33,7 @@ extern "C" {
 #define FVSRN_ERR_UNSUPPORTED (-4)      /* outside the ahead-of-time compiled variant set  */
 #define FVSRN_ERR_DEVICE (-5)           /* HIP runtime error                               */
 #define FVSRN_ERR_NO_DEVICE (-6)        /* no GPU / kernels not usable                     */
+#define FVSRN_ERR_IO (-7)               /* file cannot be opened / written                   */
 
 /* activation of the hidden layers: renderer/volume_interpolation_network.cpp:223-230 */
 typedef enum {
@@ -254,6 +255,38 @@ int fvsrn_generate_rays(const float eye[3], const float right[3], const float up
  * otherwise evaluate_with_previous() with the given step size (a negative previous density means "none"). */
 int fvsrn_scene_evaluate_tf(fvsrn_scene* scene, const float* d_density, const float* d_previous_density, size_t n,
                             float density_min, float density_max, float stepsize, float* d_colors, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Dense grid volumes: VolumeInterpolationGrid (renderer/volume_interpolation_grid.cpp, device code
+ * renderer/renderer_volume_grid.cuh:89-232) behind the same DVR ray loop -- BASELINE.json configs[0], the ground-truth
+ * renders of the reference's evaluation scripts.  A volume is one scalar feature of a `Volume` (renderer/volume.h) or a
+ * (X,Y,Z) tensor; it is stored as fp32 in HBM (u8 / u16 data are read as normalised floats like the reference's textures,
+ * volume.cpp:109-167). */
+typedef struct fvsrn_volume fvsrn_volume;
+typedef enum { FVSRN_VOLUME_U8 = 0, FVSRN_VOLUME_U16 = 1, FVSRN_VOLUME_F32 = 2 } fvsrn_volume_dtype;          /* volume.h:43-47 */
+typedef enum { FVSRN_VOLUME_NEAREST = 0, FVSRN_VOLUME_TRILINEAR = 1, FVSRN_VOLUME_TRICUBIC = 2 } fvsrn_volume_interpolation;
+/* VolumeSource (volume_interpolation_grid.h): VOLUME samples like a CUDA texture (un-normalised coordinates, texel centres at
+ * +0.5, 8-bit filter weights), TORCH_TENSOR like the tensor branch of sampleLinear (nodes at integer coordinates) */
+typedef enum { FVSRN_VOLUME_SOURCE_TEXTURE = 0, FVSRN_VOLUME_SOURCE_TENSOR = 1 } fvsrn_volume_source;
+
+/* host_data: sx*sy*sz values; x_fastest != 0: index x + sx*(y + sy*z) (Volume::idx, volume.h:128-134), else the layout of a
+ * contiguous (X,Y,Z) tensor.  The box is the world-space extent the volume is rendered into. */
+int fvsrn_volume_create(const void* host_data, int dtype, int sx, int sy, int sz, int x_fastest, const float box_min[3],
+                        const float box_size[3], fvsrn_volume** out);
+int fvsrn_volume_destroy(fvsrn_volume* volume);
+/* .cvol files, version 1, uncompressed (volume.cpp:278-332,685-740); LZ4-compressed files are rejected (the reference's LZ4
+ * wrapper is an empty submodule).  load: feature `feature_index` at mipmap level 0, box = [-world/2, world/2] like
+ * VolumeInterpolationGrid::setSource. */
+int fvsrn_volume_load_cvol(const char* path, int feature_index, fvsrn_volume** out);
+int fvsrn_volume_save_cvol(const char* path, const char* feature_name, const void* host_data, int dtype, int sx, int sy, int sz,
+                           float world_x, float world_y, float world_z);
+int fvsrn_volume_info(fvsrn_volume* volume, int resolution[3], float box_min[3], float box_size[3]);
+/* IVolumeInterpolation::evaluate for a grid volume: world positions [n][3] -> values [n] (device pointers) */
+int fvsrn_volume_evaluate_points(fvsrn_volume* volume, int source, int interpolation, int grid_resolution_new_behavior,
+                                 const float* d_positions, size_t n, float* d_out, void* stream);
+/* fvsrn_render with a grid volume instead of a network: same scene, same (8,H,W) output, same counters */
+int fvsrn_render_volume(fvsrn_scene* scene, fvsrn_volume* volume, int source, int interpolation, int grid_resolution_new_behavior,
+                        int width, int height, float* d_out8, unsigned long long* d_stats, void* stream);
 
 /* Kernel name + resources of the variant fvsrn_render / fvsrn_evaluate_points would launch for
  * this network (for profiles and bench): writes a 0-terminated string. */

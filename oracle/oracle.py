@@ -60,6 +60,15 @@ def build() -> None:
     subprocess.check_call(["make", "-C", _HERE, "-s"])
 
 
+VOLUME_NEAREST, VOLUME_TRILINEAR, VOLUME_TRICUBIC = range(3)
+VOLUME_SOURCE_TEXTURE, VOLUME_SOURCE_TENSOR = range(2)
+
+
+class _OracleVolume(C.Structure):
+    _fields_ = [("data", _FP), ("res", C.c_int * 3), ("boxMin", C.c_float * 3), ("boxSize", C.c_float * 3),
+                ("interpolation", C.c_int), ("source", C.c_int), ("newBehavior", C.c_int)]
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -79,6 +88,10 @@ def lib() -> C.CDLL:
                                     _FP, C.POINTER(C.c_ulonglong)]
         l.oracle_count_samples.restype = C.c_ulonglong
         l.oracle_count_samples.argtypes = [C.POINTER(_OracleNet), C.POINTER(_OracleScene), C.c_int, C.c_int, C.c_int, C.c_int]
+        l.oracle_volume_eval_points.restype = None
+        l.oracle_volume_eval_points.argtypes = [C.POINTER(_OracleVolume), _FP, C.c_size_t, _FP]
+        l.oracle_render_volume.restype = C.c_int
+        l.oracle_render_volume.argtypes = [C.POINTER(_OracleVolume), C.POINTER(_OracleScene), C.c_int, C.c_int, _FP, C.POINTER(C.c_ulonglong)]
         l.oracle_float_to_half.restype = C.c_uint16
         l.oracle_float_to_half.argtypes = [C.c_float]
         l.oracle_half_to_float.restype = C.c_float
@@ -221,6 +234,40 @@ class OracleNetwork:
         if r != 0:
             raise RuntimeError("oracle_eval_points_full failed")
         return out
+
+
+class OracleVolume:
+    """kernel::VolumeInterpolationGrid on a dense (X,Y,Z) array (renderer/renderer_volume_grid.cuh); u8 / u16 arrays are read as
+    normalised floats like the reference's textures."""
+
+    def __init__(self, data_xyz: np.ndarray, box_min, box_size, interpolation=VOLUME_TRILINEAR, source=VOLUME_SOURCE_TEXTURE,
+                 new_behavior=False):
+        a = np.asarray(data_xyz)
+        if a.dtype == np.uint8:
+            a = a.astype(np.float32) / np.float32(255.0)
+        elif a.dtype == np.uint16:
+            a = a.astype(np.float32) / np.float32(65535.0)
+        self._d = np.ascontiguousarray(a.astype(np.float32).transpose(2, 1, 0))  # [z][y][x]: x fastest
+        v = _OracleVolume()
+        v.data = self._d.ctypes.data_as(_FP)
+        v.res[:] = [int(n) for n in a.shape]
+        v.boxMin[:] = [float(x) for x in box_min]
+        v.boxSize[:] = [float(x) for x in box_size]
+        v.interpolation, v.source, v.newBehavior = int(interpolation), int(source), int(new_behavior)
+        self._v = v
+
+    def evaluate(self, positions: np.ndarray) -> np.ndarray:
+        p = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        out = np.zeros(p.shape[0], np.float32)
+        lib().oracle_volume_eval_points(C.byref(self._v), p.ctypes.data_as(_FP), p.shape[0], out.ctypes.data_as(_FP))
+        return out
+
+    def render(self, scene: "OracleScene", width: int, height: int):
+        out = np.zeros((8, height, width), np.float32)
+        cnt = C.c_ulonglong(0)
+        if lib().oracle_render_volume(C.byref(self._v), C.byref(scene._s), width, height, out.ctypes.data_as(_FP), C.byref(cnt)) != 0:
+            raise RuntimeError("oracle_render_volume failed")
+        return out, cnt.value
 
 
 class OracleScene:

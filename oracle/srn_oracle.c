@@ -660,5 +660,153 @@ unsigned long long oracle_count_samples(const OracleNet* n, const OracleScene* s
     return total;
 }
 
+/* --------------------------------------------------------------------------- dense grid volumes
+ * kernel::VolumeInterpolationGrid, renderer/renderer_volume_grid.cuh */
+static float vol_fetch(const OracleVolume* v, int x, int y, int z) {
+    x = clampi(x, 0, v->res[0] - 1); y = clampi(y, 0, v->res[1] - 1); z = clampi(z, 0, v->res[2] - 1);
+    return v->data[(size_t)x + (size_t)v->res[0] * ((size_t)y + (size_t)v->res[1] * (size_t)z)];
+}
+static float lerpf_(float a, float b, float t) { return a + t * (b - a); } /* helper_math.cuh lerp */
+
+/* sampleLinear, :102-139 */
+static float vol_linear(const OracleVolume* v, float x, float y, float z) {
+    if (v->source == 1) { /* tensor branch: ipos = make_int3(posObject) truncates, nodes at integer coordinates */
+        const int ix = (int)x, iy = (int)y, iz = (int)z;
+        const float fx = x - (float)ix, fy = y - (float)iy, fz = z - (float)iz;
+        const float d000 = vol_fetch(v, ix, iy, iz), d001 = vol_fetch(v, ix, iy, iz + 1);
+        const float d010 = vol_fetch(v, ix, iy + 1, iz), d011 = vol_fetch(v, ix, iy + 1, iz + 1);
+        const float d100 = vol_fetch(v, ix + 1, iy, iz), d101 = vol_fetch(v, ix + 1, iy, iz + 1);
+        const float d110 = vol_fetch(v, ix + 1, iy + 1, iz), d111 = vol_fetch(v, ix + 1, iy + 1, iz + 1);
+        return lerpf_(lerpf_(lerpf_(d000, d100, fx), lerpf_(d010, d110, fx), fy),
+                      lerpf_(lerpf_(d001, d101, fx), lerpf_(d011, d111, fx), fy), fz);
+    }
+    /* tex3D with cudaFilterModeLinear, un-normalised coordinates, clamp addressing (CUDA programming guide, linear
+     * filtering): xB = x - 0.5, i = floor(xB), alpha = frac(xB) stored in 1.8 fixed point */
+    const float xb = x - 0.5f, yb = y - 0.5f, zb = z - 0.5f;
+    const float fxi = floorf(xb), fyi = floorf(yb), fzi = floorf(zb);
+    const float a = rintf((xb - fxi) * 256.f) * (1.f / 256.f), b = rintf((yb - fyi) * 256.f) * (1.f / 256.f),
+                c = rintf((zb - fzi) * 256.f) * (1.f / 256.f);
+    const int i = (int)fxi, j = (int)fyi, k = (int)fzi;
+    return (1 - a) * (1 - b) * (1 - c) * vol_fetch(v, i, j, k) + a * (1 - b) * (1 - c) * vol_fetch(v, i + 1, j, k) +
+           (1 - a) * b * (1 - c) * vol_fetch(v, i, j + 1, k) + a * b * (1 - c) * vol_fetch(v, i + 1, j + 1, k) +
+           (1 - a) * (1 - b) * c * vol_fetch(v, i, j, k + 1) + a * (1 - b) * c * vol_fetch(v, i + 1, j, k + 1) +
+           (1 - a) * b * c * vol_fetch(v, i, j + 1, k + 1) + a * b * c * vol_fetch(v, i + 1, j + 1, k + 1);
+}
+
+/* bspline_weights + sampleCubic, :141-186 */
+static float vol_cubic(const OracleVolume* v, float x, float y, float z) {
+    const float c[3] = {x - 0.5f, y - 0.5f, z - 0.5f};
+    float g0[3], g1[3], h0[3], h1[3];
+    for (int d = 0; d < 3; ++d) {
+        const float index = floorf(c[d]), f = c[d] - index;
+        const float one_frac = 1.0f - f, squared = f * f, one_sqd = one_frac * one_frac;
+        const float w0 = 1.0f / 6.0f * one_sqd * one_frac;
+        const float w1 = 2.0f / 3.0f - 0.5f * squared * (2.0f - f);
+        const float w2 = 2.0f / 3.0f - 0.5f * one_sqd * (2.0f - one_frac);
+        const float w3 = 1.0f / 6.0f * squared * f;
+        g0[d] = w0 + w1;
+        g1[d] = w2 + w3;
+        h0[d] = (w1 / g0[d]) - 0.5f + index;
+        h1[d] = (w3 / g1[d]) + 1.5f + index;
+    }
+    float tex000 = vol_linear(v, h0[0], h0[1], h0[2]);
+    const float tex100 = vol_linear(v, h1[0], h0[1], h0[2]);
+    tex000 = g0[0] * tex000 + g1[0] * tex100;
+    float tex010 = vol_linear(v, h0[0], h1[1], h0[2]);
+    const float tex110 = vol_linear(v, h1[0], h1[1], h0[2]);
+    tex010 = g0[0] * tex010 + g1[0] * tex110;
+    tex000 = g0[1] * tex000 + g1[1] * tex010;
+    float tex001 = vol_linear(v, h0[0], h0[1], h1[2]);
+    const float tex101 = vol_linear(v, h1[0], h0[1], h1[2]);
+    tex001 = g0[0] * tex001 + g1[0] * tex101;
+    float tex011 = vol_linear(v, h0[0], h1[1], h1[2]);
+    const float tex111 = vol_linear(v, h1[0], h1[1], h1[2]);
+    tex011 = g0[0] * tex011 + g1[0] * tex111;
+    tex001 = g0[1] * tex001 + g1[1] * tex011;
+    return g0[2] * tex000 + g1[2] * tex001;
+}
+
+/* eval, :193-232 */
+static float vol_eval(const OracleVolume* v, const float w[3]) {
+    float p[3];
+    for (int d = 0; d < 3; ++d) {
+        const float scale = (float)(v->newBehavior ? v->res[d] : v->res[d] - 1);
+        p[d] = (w[d] - v->boxMin[d]) / v->boxSize[d] * scale;
+    }
+    if (v->interpolation == 0) return vol_fetch(v, (int)roundf(p[0]), (int)roundf(p[1]), (int)roundf(p[2])); /* :88-101,189 */
+    if (v->interpolation == 1) return vol_linear(v, p[0], p[1], p[2]);
+    return vol_cubic(v, p[0], p[1], p[2]);
+}
+
+void oracle_volume_eval_points(const OracleVolume* v, const float* pos, size_t count, float* out) {
+    for (size_t i = 0; i < count; ++i) out[i] = vol_eval(v, pos + 3 * i);
+}
+
+/* render_pixel with the grid as the volume: no normals, no BRDF (the DVR loop ignores isInside like for networks) */
+static void render_pixel_volume(const OracleVolume* v, const OracleScene* s, int W, int H, int x, int y, float px8[8],
+                                unsigned long long* samples) {
+    const float ndcx = 2 * ((float)x + 0.5f) / (float)W - 1, ndcy = 2 * ((float)y + 0.5f) / (float)H - 1;
+    const float tanFovY = tanf(s->fovY / 2), tanFovX = tanFovY * ((float)W / (float)H);
+    const float* eye = s->eye; const float* right = s->right; const float* up = s->up;
+    const float front[3] = {up[1] * right[2] - up[2] * right[1], up[2] * right[0] - up[0] * right[2],
+                            up[0] * right[1] - up[1] * right[0]};
+    float dir[3];
+    for (int i = 0; i < 3; ++i) dir[i] = front[i] + ndcx * tanFovX * right[i] + ndcy * tanFovY * up[i];
+    const float il = 1.0f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    for (int i = 0; i < 3; ++i) dir[i] *= il;
+    float tlo[3], thi[3];
+    for (int i = 0; i < 3; ++i) {
+        const float inv = 1.0f / dir[i];
+        const float ta = (v->boxMin[i] - eye[i]) * inv, tb = (v->boxMin[i] + v->boxSize[i] - eye[i]) * inv;
+        tlo[i] = fminf(ta, tb);
+        thi[i] = fmaxf(ta, tb);
+    }
+    float tmin = fmaxf(fmaxf(tlo[0], tlo[1]), tlo[2]);
+    const float tmax = fminf(fminf(thi[0], thi[1]), thi[2]);
+    tmin = fmaxf(tmin, 0.f);
+    const float alphaEarlyOut = 1.0f - 1e-5f;
+    const float divRange = 1.0f / (s->densityMax - s->densityMin);
+    float col[4] = {0, 0, 0, 0}, depth = 0;
+    unsigned long long cnt = 0;
+    for (int i = 0;; ++i) {
+        const float t = tmin + (float)i * s->stepsize;
+        const int valid = (t <= tmax) && (!s->earlyOut || col[3] < alphaEarlyOut);
+        if (!valid) break;
+        ++cnt;
+        const float pos[3] = {eye[0] + dir[0] * t, eye[1] + dir[1] * t, eye[2] + dir[2] * t};
+        const float value = vol_eval(v, pos);
+        float c[4] = {0, 0, 0, 0};
+        if (value >= s->densityMin) tf_eval(s, (value - s->densityMin) * divRange, c);
+        if (c[3] > 0) {
+            const float a = s->blendMode == ORACLE_BLEND_BEER_LAMBERT ? 1.0f - expf(-c[3]) : fminf(1.0f, c[3]);
+            const float w = (1 - col[3]) * a;
+            for (int k = 0; k < 3; ++k) col[k] += w * c[k];
+            depth += w * t;
+            col[3] += w;
+        }
+    }
+    px8[0] = col[0]; px8[1] = col[1]; px8[2] = col[2]; px8[3] = col[3];
+    px8[4] = px8[5] = px8[6] = 0.f;
+    px8[7] = depth * col[3] / col[3];
+    *samples = cnt;
+}
+
+int oracle_render_volume(const OracleVolume* v, const OracleScene* s, int W, int H, float* out8, unsigned long long* evaluatedSamples) {
+    if (!v || !s || !v->data || W <= 0 || H <= 0) return -1;
+    unsigned long long total = 0;
+    const size_t plane = (size_t)W * H;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float p[8];
+            unsigned long long c;
+            render_pixel_volume(v, s, W, H, x, y, p, &c);
+            total += c;
+            for (int k = 0; k < 8; ++k) out8[k * plane + (size_t)y * W + x] = p[k];
+        }
+    if (evaluatedSamples) *evaluatedSamples = total;
+    return 0;
+}
+
 uint16_t oracle_float_to_half(float f) { return f2h(f); }
 float oracle_half_to_float(uint16_t h) { return h2f(h); }

@@ -76,6 +76,19 @@ int oracle_eval_points_full(const OracleNet* n, const float* worldPos, const flo
 int oracle_render(const OracleNet* n, const OracleScene* s, int W, int H, int y0, int y1, float* out8,
                   unsigned long long* evaluatedSamples);
 unsigned long long oracle_count_samples(const OracleNet* n, const OracleScene* s, int W, int H, int y0, int y1);
+/* Dense grid volumes: kernel::VolumeInterpolationGrid (renderer/renderer_volume_grid.cuh:89-232) behind the same DVR loop.
+ * data: fp32, index x + X (y + Y z) (Volume::MipmapLevel::idx, volume.h:126-132). */
+typedef struct {
+    const float* data;
+    int res[3];
+    float boxMin[3], boxSize[3];
+    int interpolation; /* 0 nearest, 1 trilinear, 2 tricubic (VOLUME_INTERPOLATION_GRID__INTERPOLATION) */
+    int source;        /* 0: CUDA texture addressing (VolumeSource::VOLUME), 1: tensor accessor (VolumeSource::TORCH_TENSOR) */
+    int newBehavior;   /* !VOLUME_INTERPOLATION_GRID__GRID_RESOLUTION_OLD_BEHAVIOR */
+} OracleVolume;
+void oracle_volume_eval_points(const OracleVolume* v, const float* worldPos, size_t count, float* out);
+int oracle_render_volume(const OracleVolume* v, const OracleScene* s, int W, int H, float* out8, unsigned long long* evaluatedSamples);
+
 uint16_t oracle_float_to_half(float f);
 float oracle_half_to_float(uint16_t h);
 

@@ -1,0 +1,191 @@
+"""Dense grid volumes (BASELINE.json configs[0]): VolumeInterpolationGrid behind the DVR loop.
+
+CPU: the C restatement (oracle/srn_oracle.c, vol_*) against hand-computed properties of renderer_volume_grid.cuh:89-232 and
+the .cvol container (volume.cpp:623-740).  GPU: fvsrn_volume_evaluate_points / fvsrn_render_volume against the restatement.
+Parity of this row is restatement-pinned only: the reference evaluates grids in CUDA / its CPU kernels, none of which can be
+built here."""
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle  # noqa: E402
+
+BOX_MIN, BOX_SIZE = (-0.5, -0.4, -0.3), (1.0, 0.8, 0.6)
+
+
+def make_volume(shape=(12, 10, 8), seed=3, dtype=np.float32):
+    rng = np.random.RandomState(seed)
+    x, y, z = np.meshgrid(*[np.linspace(-1, 1, n) for n in shape], indexing="ij")
+    v = np.exp(-3 * (x * x + y * y + z * z)) + 0.15 * rng.rand(*shape)
+    v = np.clip(v / v.max(), 0, 1)
+    if dtype == np.uint8:
+        return np.round(v * 255).astype(np.uint8)
+    if dtype == np.uint16:
+        return np.round(v * 65535).astype(np.uint16)
+    return v.astype(np.float32)
+
+
+def node_positions(shape, scale_minus_one=True):
+    """world positions of the grid nodes under the old behaviour (object coordinate = index)"""
+    idx = np.stack(np.meshgrid(*[np.arange(n) for n in shape], indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    den = np.array([n - 1 if scale_minus_one else n for n in shape], np.float32)
+    return np.array(BOX_MIN, np.float32) + idx / den * np.array(BOX_SIZE, np.float32), idx.astype(int)
+
+
+def test_tensor_source_interpolates_the_nodes():
+    data = make_volume()
+    pos, idx = node_positions(data.shape)
+    for interp in (oracle.VOLUME_NEAREST, oracle.VOLUME_TRILINEAR):
+        v = oracle.OracleVolume(data, BOX_MIN, BOX_SIZE, interp, oracle.VOLUME_SOURCE_TENSOR)
+        got = v.evaluate(pos)
+        assert np.abs(got - data[idx[:, 0], idx[:, 1], idx[:, 2]]).max() < 2e-5  # positions are rounded to fp32
+
+
+def test_texture_source_is_shifted_by_half_a_voxel():
+    """tex3D filters around texel centres at +0.5 and the reference applies no offset: object coordinate
+    i + 0.5 returns node i, the tensor branch returns the midpoint of nodes i and i + 1."""
+    data = make_volume()
+    X = data.shape[0]
+    p = np.array([[BOX_MIN[0] + (3 + 0.5) / (X - 1) * BOX_SIZE[0], BOX_MIN[1], BOX_MIN[2]]], np.float32)
+    tex = oracle.OracleVolume(data, BOX_MIN, BOX_SIZE, oracle.VOLUME_TRILINEAR, oracle.VOLUME_SOURCE_TEXTURE).evaluate(p)[0]
+    ten = oracle.OracleVolume(data, BOX_MIN, BOX_SIZE, oracle.VOLUME_TRILINEAR, oracle.VOLUME_SOURCE_TENSOR).evaluate(p)[0]
+    assert abs(tex - data[3, 0, 0]) < 5e-3   # 8-bit filter weights
+    assert abs(ten - 0.5 * (data[3, 0, 0] + data[4, 0, 0])) < 1e-4
+
+
+def test_cubic_reproduces_constants_and_is_smooth():
+    const = np.full((6, 7, 8), 0.37, np.float32)
+    rng = np.random.RandomState(1)
+    pos = (np.array(BOX_MIN) + rng.rand(64, 3) * np.array(BOX_SIZE)).astype(np.float32)
+    for src in (oracle.VOLUME_SOURCE_TEXTURE, oracle.VOLUME_SOURCE_TENSOR):
+        got = oracle.OracleVolume(const, BOX_MIN, BOX_SIZE, oracle.VOLUME_TRICUBIC, src).evaluate(pos)
+        assert np.abs(got - 0.37).max() < 1e-5
+    data = make_volume()
+    v = oracle.OracleVolume(data, BOX_MIN, BOX_SIZE, oracle.VOLUME_TRICUBIC, oracle.VOLUME_SOURCE_TENSOR).evaluate(pos)
+    assert data.min() - 0.05 <= v.min() and v.max() <= data.max() + 0.05  # B-spline smoothing stays inside the data range
+
+
+def test_new_behaviour_scales_by_the_resolution():
+    data = make_volume()
+    pos, idx = node_positions(data.shape, scale_minus_one=False)
+    got = oracle.OracleVolume(data, BOX_MIN, BOX_SIZE, oracle.VOLUME_NEAREST, oracle.VOLUME_SOURCE_TENSOR, new_behavior=True).evaluate(pos)
+    assert np.abs(got - data[idx[:, 0], idx[:, 1], idx[:, 2]]).max() < 1e-6
+
+
+def test_cvol_round_trip(tmp_path):
+    """Volume::save / Volume::Volume(filename), uncompressed (volume.cpp:623-740): header layout and x-fastest voxel order."""
+    from fvsrn_amd import capi
+    for dtype in (np.uint8, np.uint16, np.float32):
+        data = make_volume(dtype=dtype)
+        path = str(tmp_path / ("v_%s.cvol" % np.dtype(dtype).name))
+        capi.Volume.save_cvol(path, data, world_size=(1.0, 0.8, 0.6), feature_name="density")
+        raw = open(path, "rb").read()
+        assert raw[:4] == b"CVOL" and struct.unpack("<i", raw[4:8])[0] == 1
+        assert struct.unpack("<3f", raw[8:20]) == pytest.approx((1.0, 0.8, 0.6))
+        nfeat, flags = struct.unpack("<2i", raw[20:28])
+        assert (nfeat, flags) == (1, 0)
+        ln = struct.unpack("<i", raw[32:36])[0]
+        assert raw[36:36 + ln] == b"density"
+        X, Y, Z = struct.unpack("<3Q", raw[36 + ln:60 + ln])
+        assert (X, Y, Z) == data.shape
+        ch, ty = struct.unpack("<2i", raw[60 + ln:68 + ln])
+        assert (ch, ty) == (1, {np.uint8: 0, np.uint16: 1, np.float32: 2}[dtype])
+        body = np.frombuffer(raw[68 + ln:], dtype).reshape(Z, Y, X)
+        assert np.array_equal(body.transpose(2, 1, 0), data)
+        vol = capi.Volume.load(path)
+        res, bmin, bsize = vol.info()
+        assert res == data.shape
+        assert np.allclose(bmin, (-0.5, -0.4, -0.3)) and np.allclose(bsize, (1.0, 0.8, 0.6))
+
+
+def test_cvol_errors(tmp_path):
+    from fvsrn_amd import capi
+    bad = tmp_path / "bad.cvol"
+    bad.write_bytes(b"XXXX" + b"\0" * 64)
+    with pytest.raises(capi.FvsrnError, match="magic"):
+        capi.Volume.load(str(bad))
+    lz4 = tmp_path / "lz4.cvol"
+    lz4.write_bytes(b"CVOL" + struct.pack("<i3f3i", 1, 1, 1, 1, 1, 1, 0))
+    with pytest.raises(capi.FvsrnError, match="LZ4"):
+        capi.Volume.load(str(lz4))
+    with pytest.raises(capi.FvsrnError, match="open"):
+        capi.Volume.load(str(tmp_path / "missing.cvol"))
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def scene_kwargs(**kw):
+    eye, right, up = oracle.camera_on_a_sphere("Ym", (0, 0, 0), 0.5, 0.8, 1.7)
+    d = dict(eye=eye, right=right, up=up, fov_y_radians=float(np.deg2rad(45.0)), stepsize=1 / 96, early_out=True,
+             tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=30.0, tf_scale_emission=1.0, density_min=0.1, density_max=0.9)
+    d.update(kw)
+    return d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("source", [oracle.VOLUME_SOURCE_TEXTURE, oracle.VOLUME_SOURCE_TENSOR])
+@pytest.mark.parametrize("interp", [oracle.VOLUME_NEAREST, oracle.VOLUME_TRILINEAR, oracle.VOLUME_TRICUBIC])
+@pytest.mark.parametrize("new_behavior", [False, True])
+def test_evaluate_points_matches_restatement(source, interp, new_behavior):
+    import torch
+    from fvsrn_amd import capi
+    data = make_volume(shape=(17, 13, 9))
+    rng = np.random.RandomState(9)
+    pos = (np.array(BOX_MIN) - 0.1 + rng.rand(4099, 3) * (np.array(BOX_SIZE) + 0.2)).astype(np.float32)  # also outside the box
+    ref = oracle.OracleVolume(data, BOX_MIN, BOX_SIZE, interp, source, new_behavior).evaluate(pos)
+    vol = capi.Volume.from_array(data, BOX_MIN, BOX_SIZE)
+    got = vol.evaluate(torch.from_numpy(pos).cuda(), interp, source, new_behavior).cpu().numpy()[:, 0]
+    # same fp32 operations; hipcc may contract a*b+c into fma where gcc does not: a few ulp
+    assert np.abs(got - ref).max() < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    dict(dtype=np.float32, interp=oracle.VOLUME_TRILINEAR, source=oracle.VOLUME_SOURCE_TEXTURE, tf="identity"),
+    dict(dtype=np.uint8, interp=oracle.VOLUME_TRILINEAR, source=oracle.VOLUME_SOURCE_TEXTURE, tf="texture"),
+    dict(dtype=np.uint16, interp=oracle.VOLUME_TRICUBIC, source=oracle.VOLUME_SOURCE_TENSOR, tf="identity"),
+    dict(dtype=np.float32, interp=oracle.VOLUME_NEAREST, source=oracle.VOLUME_SOURCE_TENSOR, tf="identity", new_behavior=True,
+         early_out=False, blend_mode=oracle.BLEND_ALPHA),
+])
+def test_render_volume_matches_restatement(case):
+    import torch
+    from fvsrn_amd import capi
+    data = make_volume(shape=(24, 20, 16), dtype=case["dtype"])
+    kw = scene_kwargs(early_out=case.get("early_out", True), blend_mode=case.get("blend_mode", oracle.BLEND_BEER_LAMBERT))
+    if case["tf"] == "texture":
+        rng = np.random.RandomState(5)
+        tab = rng.uniform(0.0, 1.0, (32, 4)).astype(np.float32)
+        tab[:, 3] *= 40.0
+        kw.update(tf_kind=oracle.TF_TEXTURE, tf_table=tab)
+    W, H = 72, 56  # not multiples of the 16x16 pixel blocks
+    nb = case.get("new_behavior", False)
+    ref, count = oracle.OracleVolume(data, BOX_MIN, BOX_SIZE, case["interp"], case["source"], nb).render(oracle.OracleScene(**kw), W, H)
+    vol = capi.Volume.from_array(data, BOX_MIN, BOX_SIZE)
+    stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+    img = vol.render(capi.Scene(**kw), W, H, case["interp"], case["source"], nb, stats=stats)[0].cpu().numpy()
+    assert ref[3].max() > 0.5
+    assert np.array_equal(np.isnan(img[7]), np.isnan(ref[7]))
+    # nearest-neighbour lookups flip voxels where a coordinate rounds differently by one ulp: compare all but a few pixels there
+    diff = np.abs(img[:4] - ref[:4]).max(axis=0)
+    if case["interp"] == oracle.VOLUME_NEAREST:
+        assert (diff > 1e-4).mean() < 0.01
+    elif case["source"] == oracle.VOLUME_SOURCE_TEXTURE:
+        # the 8-bit filter weights of the texture model jump by 1/256 where a coordinate differs by one ulp (the compilers
+        # contract eye + dir * t differently): a random 32-entry TF turns that into <= 1e-3 of colour
+        assert diff.max() < 3e-3 and (diff > 1e-4).mean() < 0.02
+    else:
+        assert diff.max() < 1e-4
+    st = stats.cpu().numpy()
+    assert abs(int(st[0]) - count) <= max(8, count // 10000)
+
+
+@pytest.mark.gpu
+def test_render_volume_rejects_shading():
+    from fvsrn_amd import capi
+    vol = capi.Volume.from_array(make_volume())
+    with pytest.raises(capi.FvsrnError, match="normals"):
+        vol.render(capi.Scene(**scene_kwargs(gradient_mode=1, finite_differences_stepsize=0.01)), 16, 16)
