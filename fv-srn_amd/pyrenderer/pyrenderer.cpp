@@ -374,6 +374,202 @@ struct VolumeInterpolationNetwork : IVolumeInterpolation {
     }
 };
 
+// --------------------------------------------------------------------------------------------------- grid volumes
+// Volume (renderer/volume.h, volume.cpp:1244-1400): host container of named features; .cvol version 1, uncompressed.
+struct Volume {
+    enum DataType { TypeUChar = 0, TypeUShort = 1, TypeFloat = 2 };
+    struct Feature {
+        std::string name_;
+        DataType type_ = TypeFloat;
+        int channels_ = 1;
+        int sx = 0, sy = 0, sz = 0;
+        std::vector<char> data;  // channel fastest, then x, y, z (MipmapLevel::idx, volume.h:126-132)
+        std::string name() const { return name_; }
+        DataType type() const { return type_; }
+        int channels() const { return channels_; }
+        std::tuple<int, int, int> baseResolution() const { return {sx, sy, sz}; }
+    };
+    float worldX = 1, worldY = 1, worldZ = 1;
+    std::vector<std::shared_ptr<Feature>> features;
+    static size_t bytesPerType(DataType t) { return t == TypeUChar ? 1 : (t == TypeUShort ? 2 : 4); }
+
+    Volume() = default;
+    explicit Volume(const std::string& filename) {  // Volume::Volume(filename), volume.cpp:685-740 + Feature::load :278-332
+        std::ifstream f(filename, std::ios::binary);
+        if (!f) raise("Unable to open file " + filename);
+        char magic[4];
+        int version = 0, numFeatures = 0, flags = 0;
+        f.read(magic, 4);
+        if (!f || std::memcmp(magic, "CVOL", 4) != 0) raise("Illegal magic number");
+        f.read(reinterpret_cast<char*>(&version), 4);
+        if (version != 1) raise("Unknown file version!");
+        f.read(reinterpret_cast<char*>(&worldX), 4);
+        f.read(reinterpret_cast<char*>(&worldY), 4);
+        f.read(reinterpret_cast<char*>(&worldZ), 4);
+        f.read(reinterpret_cast<char*>(&numFeatures), 4);
+        f.read(reinterpret_cast<char*>(&flags), 4);
+        f.ignore(4);
+        if (flags & 1) raise("LZ4-compressed .cvol files are not supported by this build (save the volume with compression 0)");
+        if (!f || numFeatures < 0 || numFeatures > 1024) raise("corrupt .cvol header");
+        for (int i = 0; i < numFeatures; ++i) {
+            auto ft = std::make_shared<Feature>();
+            int lenName = 0, type = 0;
+            unsigned long long X = 0, Y = 0, Z = 0;
+            f.read(reinterpret_cast<char*>(&lenName), 4);
+            if (!f || lenName < 0 || lenName > 4096) raise("corrupt feature header");
+            ft->name_.resize(size_t(lenName));
+            f.read(ft->name_.data(), lenName);
+            f.read(reinterpret_cast<char*>(&X), 8);
+            f.read(reinterpret_cast<char*>(&Y), 8);
+            f.read(reinterpret_cast<char*>(&Z), 8);
+            f.read(reinterpret_cast<char*>(&ft->channels_), 4);
+            f.read(reinterpret_cast<char*>(&type), 4);
+            if (!f || type < 0 || type > 2 || ft->channels_ <= 0 || X == 0 || Y == 0 || Z == 0 || X > 65536 || Y > 65536 || Z > 65536)
+                raise("corrupt feature header");
+            ft->type_ = DataType(type);
+            ft->sx = int(X); ft->sy = int(Y); ft->sz = int(Z);
+            ft->data.resize(bytesPerType(ft->type_) * X * Y * Z * size_t(ft->channels_));
+            f.read(ft->data.data(), std::streamsize(ft->data.size()));
+            if (!f) raise("unexpected end of file in " + filename);
+            features.push_back(ft);
+        }
+    }
+    void save(const std::string& filename, int compression) const {  // Volume::save, volume.cpp:623-668
+        if (compression != 0) raise("this build writes uncompressed .cvol files only (compression=0)");
+        std::ofstream f(filename, std::ios::binary);
+        if (!f) raise("cannot write " + filename);
+        const int version = 1, numFeatures = int(features.size()), flags = 0;
+        const char pad[4] = {0, 0, 0, 0};
+        f.write("CVOL", 4);
+        f.write(reinterpret_cast<const char*>(&version), 4);
+        f.write(reinterpret_cast<const char*>(&worldX), 4);
+        f.write(reinterpret_cast<const char*>(&worldY), 4);
+        f.write(reinterpret_cast<const char*>(&worldZ), 4);
+        f.write(reinterpret_cast<const char*>(&numFeatures), 4);
+        f.write(reinterpret_cast<const char*>(&flags), 4);
+        f.write(pad, 4);
+        for (const auto& ft : features) {
+            const int lenName = int(ft->name_.size()), type = int(ft->type_);
+            const unsigned long long X = ft->sx, Y = ft->sy, Z = ft->sz;
+            f.write(reinterpret_cast<const char*>(&lenName), 4);
+            f.write(ft->name_.data(), lenName);
+            f.write(reinterpret_cast<const char*>(&X), 8);
+            f.write(reinterpret_cast<const char*>(&Y), 8);
+            f.write(reinterpret_cast<const char*>(&Z), 8);
+            f.write(reinterpret_cast<const char*>(&ft->channels_), 4);
+            f.write(reinterpret_cast<const char*>(&type), 4);
+            f.write(ft->data.data(), std::streamsize(ft->data.size()));
+        }
+        if (!f) raise("error while writing " + filename);
+    }
+    std::shared_ptr<Feature> getFeature(int index) const {
+        if (index < 0 || index >= int(features.size())) raise("feature index out of bounds");
+        return features[size_t(index)];
+    }
+    std::shared_ptr<Feature> getFeatureByName(const std::string& name) const {
+        for (const auto& f : features)
+            if (f->name_ == name) return f;
+        return nullptr;
+    }
+    // addFeatureFromBuffer (volume.cpp): (C,X,Y,Z) float tensor on the CPU -> float feature
+    std::shared_ptr<Feature> addFeatureFromTensor(const std::string& name, const torch::Tensor& t) {
+        if (t.scalar_type() != torch::kFloat32) raise("Incompatible format: expected a float array!");
+        if (!t.device().is_cpu()) raise("Incompatible format, expected the tensor to reside in CPU memory");
+        if (t.dim() != 4) raise("Incompatible buffer dimension, expected a 4D array!");
+        auto ft = std::make_shared<Feature>();
+        ft->name_ = name;
+        ft->type_ = TypeFloat;
+        ft->channels_ = int(t.size(0));
+        ft->sx = int(t.size(1)); ft->sy = int(t.size(2)); ft->sz = int(t.size(3));
+        const torch::Tensor zyxc = t.permute({3, 2, 1, 0}).contiguous();  // z slowest ... channel fastest
+        ft->data.resize(size_t(zyxc.numel()) * 4);
+        std::memcpy(ft->data.data(), zyxc.data_ptr<float>(), ft->data.size());
+        features.push_back(ft);
+        return ft;
+    }
+};
+
+// VolumeInterpolationGrid (renderer/volume_interpolation_grid.cpp): a Volume feature (texture addressing) or a (1,X,Y,Z)
+// tensor (accessor addressing) as the density volume of the renderer
+struct VolumeInterpolationGrid : IVolumeInterpolation {
+    enum VolumeSource { SourceVolume = 0, SourceTorchTensor = 1, SourceEmpty = 2 };
+    VolumeSource source_ = SourceEmpty;
+    int interpolation_ = FVSRN_VOLUME_TRILINEAR;
+    bool newBehavior = false;
+    std::shared_ptr<Volume> volume_;
+    int mipmapLevel_ = 0;
+    torch::Tensor tensor_;
+    float minDensity_ = 0, maxDensity_ = 1;
+    fvsrn_volume* h = nullptr;
+    ~VolumeInterpolationGrid() override { fvsrn_volume_destroy(h); }
+
+    void rebuild(const void* data, int dtype, int sx, int sy, int sz, bool xFastest) {
+        fvsrn_volume_destroy(h);
+        h = nullptr;
+        const double3 s = boxSize();
+        const float bmin[3] = {float(boxMin_.x), float(boxMin_.y), float(boxMin_.z)}, bsize[3] = {float(s.x), float(s.y), float(s.z)};
+        check(fvsrn_volume_create(data, dtype, sx, sy, sz, xFastest ? 1 : 0, bmin, bsize, &h));
+    }
+    void setSourceVolume(std::shared_ptr<Volume> v, int mipmap) {  // :136-199
+        if (mipmap != 0) raise("mipmap levels are not supported by this build");
+        if (!v) { source_ = SourceEmpty; volume_ = nullptr; return; }
+        std::shared_ptr<Volume::Feature> density;
+        for (const auto& f : v->features)
+            if (f->channels_ == 1) { density = f; break; }
+        if (!density) raise("Selected volume does not contain any scalar features. Can't render!");
+        source_ = SourceVolume;
+        volume_ = std::move(v);
+        tensor_ = torch::Tensor();
+        boxMin_ = {-volume_->worldX / 2.0, -volume_->worldY / 2.0, -volume_->worldZ / 2.0};
+        boxMax_ = {volume_->worldX / 2.0, volume_->worldY / 2.0, volume_->worldZ / 2.0};
+        rebuild(density->data.data(), int(density->type_), density->sx, density->sy, density->sz, true);
+        minDensity_ = 0; maxDensity_ = 1;
+    }
+    void setSourceTensor(const torch::Tensor& t) {  // :200-224
+        TORCH_CHECK(t.dim() == 4, "expected a 4D tensor (B,X,Y,Z)");
+        TORCH_CHECK(t.scalar_type() == torch::kFloat32 || t.scalar_type() == torch::kFloat64, "tensor must be of type float or double, but is ", t.dtype());
+        TORCH_CHECK(t.size(0) == 1, "batched grids are not supported by this build");
+        source_ = SourceTorchTensor;
+        volume_ = nullptr;
+        mipmapLevel_ = 0;
+        tensor_ = t;
+        const torch::Tensor host = t.detach().to(torch::kCPU, torch::kFloat32).contiguous();
+        minDensity_ = host.min().item<float>();
+        maxDensity_ = host.max().item<float>();
+        const int X = int(t.size(1)), Y = int(t.size(2)), Z = int(t.size(3));
+        const double voxel = 1.0 / std::max({X, Y, Z});
+        boxMin_ = {-X * voxel / 2.0, -Y * voxel / 2.0, -Z * voxel / 2.0};
+        boxMax_ = {X * voxel / 2.0, Y * voxel / 2.0, Z * voxel / 2.0};
+        rebuild(host.data_ptr<float>(), FVSRN_VOLUME_F32, X, Y, Z, false);
+    }
+    void pushBox() {  // the C ABI volume carries its box: re-create it from the current source
+        if (source_ == SourceTorchTensor && tensor_.defined()) {
+            const torch::Tensor host = tensor_.detach().to(torch::kCPU, torch::kFloat32).contiguous();
+            rebuild(host.data_ptr<float>(), FVSRN_VOLUME_F32, int(host.size(1)), int(host.size(2)), int(host.size(3)), false);
+        } else if (source_ == SourceVolume && volume_) {
+            for (const auto& f : volume_->features)
+                if (f->channels_ == 1) { rebuild(f->data.data(), int(f->type_), f->sx, f->sy, f->sz, true); break; }
+        }
+    }
+    void setBoxMin(double3 v) override { boxMin_ = v; pushBox(); }
+    void setBoxMax(double3 v) override { boxMax_ = v; pushBox(); }
+    int outputChannels() const override { return 1; }
+    fvsrn_volume* handle() const {
+        if (source_ == SourceEmpty || !h) raise("No volume specified, can't render!");
+        return h;
+    }
+    int sourceMode() const { return source_ == SourceTorchTensor ? FVSRN_VOLUME_SOURCE_TENSOR : FVSRN_VOLUME_SOURCE_TEXTURE; }
+    torch::Tensor evaluate(const torch::Tensor& positions, const std::optional<torch::Tensor>&) override {
+        TORCH_CHECK(positions.is_cuda(), "positions must reside on the GPU");
+        TORCH_CHECK(positions.dim() == 2 && positions.size(1) == 3, "positions must be of shape (N,3)");
+        const torch::Tensor p = positions.to(c10::kFloat).contiguous();
+        torch::Tensor out = torch::empty({p.size(0), 1}, p.options());
+        check(fvsrn_volume_evaluate_points(handle(), sourceMode(), interpolation_, newBehavior ? 1 : 0, p.data_ptr<float>(), size_t(p.size(0)),
+                                           out.data_ptr<float>(), currentStream()));
+        return out.to(positions.scalar_type());
+    }
+};
+
 // ----------------------------------------------------------------------------------------------- TF / BRDF
 struct ITransferFunction {
     virtual ~ITransferFunction() = default;
@@ -540,16 +736,17 @@ struct ImageEvaluatorSimple {
 
     torch::Tensor render(int width, int height) {  // image_evaluator_simple.cpp:198-361
         auto vol = std::dynamic_pointer_cast<VolumeInterpolationNetwork>(volume);
-        if (!vol) {
+        auto grid = std::dynamic_pointer_cast<VolumeInterpolationGrid>(volume);
+        if (!vol && !grid) {
             auto other = std::dynamic_pointer_cast<UnsupportedVolume>(volume);
-            raise(std::string("ImageEvaluatorSimple.volume must be a VolumeInterpolationNetwork (the SRN path is the only volume of this build)") +
+            raise(std::string("ImageEvaluatorSimple.volume must be a VolumeInterpolationNetwork or a VolumeInterpolationGrid") +
                   (other ? "; the scene file selected volume '" + other->name + "'" : ""));
         }
         auto dvr = std::dynamic_pointer_cast<RayEvaluationSteppingDvr>(rayEvaluator);
         if (!dvr) raise("ImageEvaluatorSimple.ray_evaluator must be a RayEvaluationSteppingDvr");
         if (!camera) raise("no camera selected");
         if (doublePrecision) raise("double precision rendering is not supported by the SRN path");
-        if (vol->gradientMode == ADJOINT_METHOD) raise("gradient mode ADJOINT_METHOD is not in the compiled variant set");
+        if (vol && vol->gradientMode == ADJOINT_METHOD) raise("gradient mode ADJOINT_METHOD is not in the compiled variant set");
         camera->aspectRatio = double(width) / height;
         fvsrn_scene_desc d{};
         std::vector<float> table;
@@ -560,8 +757,11 @@ struct ImageEvaluatorSimple {
         d.density_max = float(dvr->maxDensity);
         d.early_out = dvr->enableEarlyOut;
         d.blend_mode = dvr->blending ? dvr->blending->blendMode : FVSRN_BLEND_BEER_LAMBERT;
-        const fvsrn_network_info info = vol->currentNetwork()->info();
-        const bool rgbo = info.output_mode == FVSRN_OUT_RGBO || info.output_mode == FVSRN_OUT_RGBO_DIRECT;
+        bool rgbo = false;
+        if (vol) {
+            const fvsrn_network_info info = vol->currentNetwork()->info();
+            rgbo = info.output_mode == FVSRN_OUT_RGBO || info.output_mode == FVSRN_OUT_RGBO_DIRECT;
+        }
         if (rgbo) {
             d.tf_kind = FVSRN_TF_NONE;  // ray_evaluation_stepping.cpp:560-601: colour volumes skip the TF
         } else {
@@ -569,8 +769,8 @@ struct ImageEvaluatorSimple {
             dvr->tf->fill(d, table);
         }
         d.tf_table = table.empty() ? nullptr : table.data();
-        d.gradient_mode = vol->gradientMode == FINITE_DIFFERENCES ? FVSRN_GRADIENT_FINITE_DIFFERENCES : FVSRN_GRADIENT_OFF_OR_DIRECT;
-        d.finite_differences_stepsize = float(vol->finiteDifferencesStepsize);
+        d.gradient_mode = vol && vol->gradientMode == FINITE_DIFFERENCES ? FVSRN_GRADIENT_FINITE_DIFFERENCES : FVSRN_GRADIENT_OFF_OR_DIRECT;
+        d.finite_differences_stepsize = vol ? float(vol->finiteDifferencesStepsize) : 0.f;
         if (dvr->brdf) {  // BRDFLambert::fillConstantMemory, brdf.cpp:413-448
             BRDFLambert& b = *dvr->brdf;
             if (b.lightFollowsCamera) {  // updateLightFromCamera :490-508: camera origin / front = cross(up, right)
@@ -594,7 +794,11 @@ struct ImageEvaluatorSimple {
         if (!scene) check(fvsrn_scene_create(&d, &scene));
         else check(fvsrn_scene_update(scene, &d));
         torch::Tensor out = torch::empty({1, 8, height, width}, torch::TensorOptions().dtype(torch::kFloat).device(torch::kCUDA));
-        check(fvsrn_render(scene, vol->currentNetwork()->h, width, height, 0, height, out.data_ptr<float>(), nullptr, currentStream()));
+        if (vol)
+            check(fvsrn_render(scene, vol->currentNetwork()->h, width, height, 0, height, out.data_ptr<float>(), nullptr, currentStream()));
+        else
+            check(fvsrn_render_volume(scene, grid->handle(), grid->sourceMode(), grid->interpolation_, grid->newBehavior ? 1 : 0, width, height,
+                                      out.data_ptr<float>(), nullptr, currentStream()));
         lastRender = out;
         exposureStale = true;
         return out;
@@ -840,12 +1044,38 @@ std::shared_ptr<ImageEvaluatorSimple> loadFromJson(const std::string& filename) 
     }
     // volume: networks are not stored in the JSON (volume_interpolation_network.cpp:1664-1672)
     {
-        // The reference's scene files select the ground-truth volume ("Grid", "Implicit"); its callers then replace it by
-        // the trained network (inference.py:598 `image_evaluator.volume = self._volume_network`).  Those volumes are not
-        // part of this build: the selection is recorded and render() asks for a VolumeInterpolationNetwork.
+        // The reference's scene files select the ground-truth volume ("Grid", "Implicit"); its callers usually replace it by
+        // the trained network (inference.py:598 `image_evaluator.volume = self._volume_network`).  "Grid" is loaded like
+        // VolumeInterpolationGrid::load (volume_interpolation_grid.cpp:772-812): the .cvol next to the scene file if it
+        // exists, otherwise an empty source; "Implicit" is recorded only.
         const std::string sel = jget<std::string>(je, "selectedVolume", "SRN");
-        if (sel == "SRN") ev->volume = std::make_shared<VolumeInterpolationNetwork>();
-        else ev->volume = std::make_shared<UnsupportedVolume>(sel);
+        if (sel == "SRN") {
+            ev->volume = std::make_shared<VolumeInterpolationNetwork>();
+        } else if (sel == "Grid") {
+            auto grid = std::make_shared<VolumeInterpolationGrid>();
+            if (root.contains("volume") && root["volume"].cast<py::dict>().contains("Grid")) {
+                py::dict jg = jsub(root, "volume", "Grid");
+                const std::string ip = jget<std::string>(jg, "interpolation", "TRILINEAR");
+                grid->interpolation_ = ip == "NEAREST_NEIGHBOR" ? FVSRN_VOLUME_NEAREST : (ip == "TRICUBIC" ? FVSRN_VOLUME_TRICUBIC : FVSRN_VOLUME_TRILINEAR);
+                const std::string src = jget<std::string>(jg, "source", "");
+                std::string path = jget<std::string>(jg, "volumePath", "");
+                if (src == "VOLUME" && !path.empty() && jget<int>(jg, "mipmapLevel", 0) == 0) {
+                    py::object os = py::module_::import("os.path");
+                    if (!os.attr("isabs")(path).cast<bool>())
+                        path = os.attr("normpath")(os.attr("join")(os.attr("dirname")(os.attr("abspath")(filename)), path)).cast<std::string>();
+                    if (path.size() > 5 && path.substr(path.size() - 5) == ".cvol" && os.attr("exists")(path).cast<bool>()) {
+                        try {
+                            grid->setSourceVolume(std::make_shared<Volume>(path), 0);
+                        } catch (const std::exception& e) {  // the reference prints and leaves the source empty
+                            py::print("Unable to load volume, is the file valid?", path, e.what());
+                        }
+                    }
+                }
+            }
+            ev->volume = grid;
+        } else {
+            ev->volume = std::make_shared<UnsupportedVolume>(sel);
+        }
     }
     return ev;
 }
@@ -1004,6 +1234,46 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def("evaluate", &IVolumeInterpolation::evaluate, py::arg("positions"), py::arg("direction") = std::optional<torch::Tensor>{});
     py::class_<UnsupportedVolume, IVolumeInterpolation, std::shared_ptr<UnsupportedVolume>>(m, "UnsupportedVolume")
         .def_readonly("name", &UnsupportedVolume::name);
+    // ---- grid volumes (volume.cpp:1244-1400, volume_interpolation_grid.cpp:851-897)
+    py::class_<Volume, std::shared_ptr<Volume>> vol(m, "Volume");
+    py::enum_<Volume::DataType>(vol, "DataType")
+        .value("TypeUChar", Volume::TypeUChar).value("TypeUShort", Volume::TypeUShort).value("TypeFloat", Volume::TypeFloat);
+    vol.def_static("bytes_per_type", [](Volume::DataType t) { return int(Volume::bytesPerType(t)); });
+    py::class_<Volume::Feature, std::shared_ptr<Volume::Feature>>(vol, "Feature")
+        .def("name", &Volume::Feature::name)
+        .def("type", &Volume::Feature::type)
+        .def("channels", &Volume::Feature::channels)
+        .def("base_resolution", &Volume::Feature::baseResolution, py::doc("The resolution of mipmap level 0"));
+    vol.def(py::init<>(), py::doc("Creates a new, empty volume"))
+        .def(py::init<const std::string&>(), py::doc("Loads the volume from the given .cvol file"))
+        .def("save", &Volume::save, py::arg("filename"), py::arg("compression") = 0)
+        .def_readwrite("worldX", &Volume::worldX)
+        .def_readwrite("worldY", &Volume::worldY)
+        .def_readwrite("worldZ", &Volume::worldZ)
+        .def("num_features", [](const Volume& v) { return int(v.features.size()); })
+        .def("get_feature", &Volume::getFeature, py::arg("index"))
+        .def("get_feature", &Volume::getFeatureByName, py::arg("name"))
+        .def("add_feature_from_tensor", &Volume::addFeatureFromTensor, py::arg("name"), py::arg("buffer"),
+             py::doc("Adds a new feature with the given name from the given CPU-float tensor, a 4D array with the dimensions Channel,X,Y,Z."));
+    py::class_<VolumeInterpolationGrid, IVolumeInterpolation, std::shared_ptr<VolumeInterpolationGrid>> vg(m, "VolumeInterpolationGrid");
+    py::enum_<VolumeInterpolationGrid::VolumeSource>(vg, "VolumeSource")
+        .value("Volume", VolumeInterpolationGrid::SourceVolume).value("TorchTensor", VolumeInterpolationGrid::SourceTorchTensor)
+        .value("Empty", VolumeInterpolationGrid::SourceEmpty).export_values();
+    py::enum_<fvsrn_volume_interpolation>(vg, "VolumeInterpolation")
+        .value("NearestNeighbor", FVSRN_VOLUME_NEAREST).value("Trilinear", FVSRN_VOLUME_TRILINEAR).value("Tricubic", FVSRN_VOLUME_TRICUBIC)
+        .export_values();
+    vg.def(py::init<>())
+        .def("source", [](VolumeInterpolationGrid& g) { return g.source_; })
+        .def("interpolation", [](VolumeInterpolationGrid& g) { return fvsrn_volume_interpolation(g.interpolation_); })
+        .def("setInterpolation", [](VolumeInterpolationGrid& g, fvsrn_volume_interpolation i) { g.interpolation_ = int(i); })
+        .def("minDensity", [](VolumeInterpolationGrid& g) { return g.minDensity_; })
+        .def("maxDensity", [](VolumeInterpolationGrid& g) { return g.maxDensity_; })
+        .def("volume", [](VolumeInterpolationGrid& g) { return g.volume_; })
+        .def("mipmap_level", [](VolumeInterpolationGrid& g) { return g.mipmapLevel_; })
+        .def("tensor", [](VolumeInterpolationGrid& g) { return g.tensor_; })
+        .def("setSource", &VolumeInterpolationGrid::setSourceVolume, py::arg("volume"), py::arg("mipmap") = 0)
+        .def("setSource", &VolumeInterpolationGrid::setSourceTensor, py::arg("tensor"))
+        .def_readwrite("grid_resolution_new_behavior", &VolumeInterpolationGrid::newBehavior);
     py::class_<VolumeInterpolationNetwork, IVolumeInterpolation, std::shared_ptr<VolumeInterpolationNetwork>> vn(m, "VolumeInterpolationNetwork");
     py::enum_<GradientMode>(vn, "GradientMode")
         .value("OFF_OR_DIRECT", OFF_OR_DIRECT).value("FINITE_DIFFERENCES", FINITE_DIFFERENCES).value("ADJOINT_METHOD", ADJOINT_METHOD);

@@ -129,7 +129,7 @@ def test_scene_files_with_piecewise_and_texture_tfs_load(tmp_path):
     p = tmp_path / "pw.json"
     p.write_text(json.dumps(_scene_json("Piecewise", PIECEWISE_JSON)))
     ev = pr.load_from_json(str(p))
-    assert isinstance(ev.volume, pr.UnsupportedVolume) and ev.volume.name == "Grid"
+    assert isinstance(ev.volume, pr.VolumeInterpolationGrid) and ev.volume.source() == pr.VolumeInterpolationGrid.Empty
     t = ev.ray_evaluator.tf.tensor.numpy()[0]
     ref = oracle.tf_piecewise_table(PIECEWISE_JSON["colorPoints"], PIECEWISE_JSON["opacityPoints"], 25.0)
     assert t.shape == ref.shape and np.abs(t - ref).max() < 1e-6
@@ -296,8 +296,8 @@ def test_scene_file_render_matches_oracle(tmp_path, tf_name):
     path = str(tmp_path / "net.volnet")
     open(path, "wb").write(volnet_io.save_volnet(vn))
     ev = pr.load_from_json(str(p))
-    with pytest.raises(RuntimeError, match="VolumeInterpolationNetwork"):
-        ev.render(40, 24)  # the ground-truth grid volume is not part of this build
+    with pytest.raises(RuntimeError, match="No volume specified"):
+        ev.render(40, 24)  # the scene's ground-truth grid volume (.cvol) is not on disk: empty source, like the reference
     vol = pr.VolumeInterpolationNetwork()
     vol.set_network(pr.SceneNetwork.load(path))
     ev.volume = vol
@@ -373,3 +373,79 @@ def test_reference_timing_protocol_runs(tmp_path):
     assert stats["num_cameras"] == 4 and stats["ms_mean"] > 0 and stats["num_parameters"] > 3000
     assert sorted(os.listdir(out)) == ["frame000.png", "frame001.png", "frame002.png", "frame003.png", "stats.json"]
     assert json.load(open(os.path.join(out, "stats.json")))["width"] == 64
+
+
+# ------------------------------------------------------------------------------------------------ grid volumes
+def _test_volume(shape=(20, 16, 12)):
+    x, y, z = np.meshgrid(*[np.linspace(-1, 1, n) for n in shape], indexing="ij")
+    return np.clip(np.exp(-3 * (x * x + y * y + z * z)) + 0.1 * np.sin(7 * x) * np.cos(5 * y), 0, 1).astype(np.float32)
+
+
+def test_volume_container_round_trip(tmp_path):
+    """pyrenderer.Volume (renderer/volume.cpp:1244-1400): features from tensors, .cvol save / load (uncompressed)."""
+    data = _test_volume()
+    v = pr.Volume()
+    v.worldX, v.worldY, v.worldZ = 1.0, 0.8, 0.6
+    f = v.add_feature_from_tensor("density", torch.from_numpy(data)[None])
+    assert f.name() == "density" and f.channels() == 1 and f.base_resolution() == data.shape and f.type() == pr.Volume.DataType.TypeFloat
+    v.add_feature_from_tensor("velocity", torch.zeros(3, *data.shape))
+    path = str(tmp_path / "vol.cvol")
+    v.save(path)
+    w = pr.Volume(path)
+    assert w.num_features() == 2 and (w.worldX, w.worldY, w.worldZ) == pytest.approx((1.0, 0.8, 0.6))
+    assert w.get_feature(0).name() == "density" and w.get_feature("velocity").channels() == 3 and w.get_feature("nope") is None
+    with pytest.raises(RuntimeError, match="compression"):
+        v.save(path, 5)
+    # the same file through the C ABI loader
+    from fvsrn_amd import capi
+    res, bmin, bsize = capi.Volume.load(path).info()
+    assert res == data.shape and np.allclose(bsize, (1.0, 0.8, 0.6))
+    g = pr.VolumeInterpolationGrid()
+    assert g.source() == pr.VolumeInterpolationGrid.Empty and g.interpolation() == pr.VolumeInterpolationGrid.Trilinear
+    g.setSource(w)
+    assert g.source() == pr.VolumeInterpolationGrid.Volume and g.box_min().x == pytest.approx(-0.5) and g.box_size().z == pytest.approx(0.6)
+    g.setSource(torch.from_numpy(data)[None])
+    assert g.source() == pr.VolumeInterpolationGrid.TorchTensor and g.maxDensity() == pytest.approx(float(data.max()))
+    assert g.box_size().x == pytest.approx(1.0) and g.box_size().y == pytest.approx(0.8)  # res / max(res)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("source", ["volume", "tensor"])
+def test_grid_volume_renders_like_the_restatement(tmp_path, source):
+    """ImageEvaluatorSimple with a VolumeInterpolationGrid (BASELINE.json configs[0]: grid DVR) against oracle_render_volume."""
+    from oracle import oracle
+    data = _test_volume()
+    grid = pr.VolumeInterpolationGrid()
+    if source == "volume":
+        v = pr.Volume()
+        v.worldX, v.worldY, v.worldZ = 1.0, 0.8, 0.6
+        v.add_feature_from_tensor("density", torch.from_numpy(data)[None])
+        grid.setSource(v)
+        osrc = oracle.VOLUME_SOURCE_TEXTURE
+    else:
+        grid.setSource(torch.from_numpy(data)[None])
+        osrc = oracle.VOLUME_SOURCE_TENSOR
+    grid.setInterpolation(pr.VolumeInterpolationGrid.Tricubic)
+    ev = pr.ImageEvaluatorSimple()
+    ev.volume = grid
+    ev.camera.orientation = pr.CameraOnASphere.Ym
+    ev.camera.pitchYawDistance.value = pr.double3(0.5, 0.8, 1.7)
+    ev.camera.fov_y_radians = float(np.deg2rad(45.0))
+    tf = pr.TransferFunctionIdentity()
+    tf.absorption_emission.value = pr.double2(30.0, 1.0)
+    ev.ray_evaluator.tf = tf
+    ev.ray_evaluator.stepsize = 1 / 96
+    ev.ray_evaluator.min_density, ev.ray_evaluator.max_density = 0.1, 0.9
+    W, H = 64, 48
+    img = ev.render(W, H)[0].cpu().numpy()
+    eye, right, up = oracle.camera_on_a_sphere("Ym", (0, 0, 0), 0.5, 0.8, 1.7)
+    scene = oracle.OracleScene(eye=eye, right=right, up=up, fov_y_radians=float(np.deg2rad(45.0)), stepsize=1 / 96, early_out=True,
+                               tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=30.0, tf_scale_emission=1.0, density_min=0.1, density_max=0.9)
+    bmin, bsize = (-0.5, -0.4, -0.3), (1.0, 0.8, 0.6)
+    ref, _ = oracle.OracleVolume(data, bmin, bsize, oracle.VOLUME_TRICUBIC, osrc).render(scene, W, H)
+    assert ref[3].max() > 0.5
+    assert np.abs(img[:4] - ref[:4]).max() < (3e-3 if source == "volume" else 2e-4)
+    pos = torch.rand(1000, 3, device="cuda") - 0.5
+    got = grid.evaluate(pos).cpu().numpy()[:, 0]
+    want = oracle.OracleVolume(data, bmin, bsize, oracle.VOLUME_TRICUBIC, osrc).evaluate(pos.cpu().numpy())
+    assert np.abs(got - want).max() < 1e-5
