@@ -513,6 +513,18 @@ def test_render_view_dependent_network(name):
         net.evaluate(torch.rand(8, 3, device="cuda"))
 
 
+def test_register_resident_kernel_with_view_direction():
+    """The direction-input variant of render_small_kernel (scalar 32x4 network with USE_DIRECTION 2, Identity TF) vs the oracle."""
+    d, meta = util.load_golden("g1_dir2_c32l4_relu_density")
+    vn = util.golden_to_volnet(d, meta, box_min=(-0.5, -0.5, -0.5))
+    kw = make_scene_kwargs(stepsize=1 / 64, tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=20.0, early_out=False)
+    from fvsrn_amd import capi, volnet_io
+    assert "render_small_kernel" in capi.Network.from_volnet(volnet_io.save_volnet(vn)).kernel_name(True)
+    img, ref, stats, count = render_both(vn, kw, 48, 40)
+    assert_images_close(img, ref, TOL_IMG)
+    assert stats[0] == count and img[3].max() > 0.2
+
+
 @pytest.mark.parametrize("mode", ["color", "color_tonemapped", "mask", "normal", "depth", "depth_full_coverage"])
 def test_extract_color_matches_restatement(mode):
     """IImageEvaluator::ExtractColor through the C ABI (planar fp32 and packed RGBA8) against the numpy restatement
