@@ -100,7 +100,7 @@ class Runner:
                 st.wait_stream(torch.cuda.current_stream())
         self.kernel_events = []
 
-    def frame(self, index, record=False):
+    def frame(self, index, record=False, gather=True):
         import torch.distributed as dist
         yaw = 2 * math.pi * (index % 64) / 64
         b = index & 1
@@ -123,7 +123,7 @@ class Runner:
             if record:
                 e1.record()
                 self.kernel_events.append((e0, e1))
-        if self.world > 1:
+        if self.world > 1 and gather:
             with torch.cuda.stream(self.comm_stream):  # gather(frame i) overlaps render(frame i+1)
                 self.comm_stream.wait_event(self.render_done[b])
                 dist.all_gather_into_tensor(self.gathered[b].view(self.world * 8, -1, self.W), self.local[b])
@@ -145,8 +145,25 @@ class Runner:
         return g.view(R, 8, rows // STRIPE, STRIPE, W).permute(1, 2, 0, 3, 4).reshape(1, 8, self.H, W)
 
 
-def timed_run(runner, steps, warmup, distributed):
+def timed_run(runner, steps, warmup, distributed, spinup_ms=0.0):
     import torch.distributed as dist
+    # Clock spin-up (untimed, before the W warm-up steps): the shader clock of an idle MI355X needs a few hundred ms of load to
+    # settle (r01: the same 32 timed frames read 1.5 % lower after 4 warm-up frames than after 150, 8 timed frames 5 % lower), and
+    # at N GPUs the timed region shrinks to 32 x 0.3 ms.  Every rank spins for the same wall time, rendering only (the number of
+    # frames differs between ranks, so no collective is called here).
+    if distributed and spinup_ms > 0:  # one untimed frame with its gather on every rank: RCCL sets its communicator up lazily
+        runner.frame(0)
+        runner.finish()
+        torch.cuda.synchronize()
+        dist.barrier()
+    t_end = time.perf_counter() + 1e-3 * spinup_ms
+    i = 0
+    while time.perf_counter() < t_end:
+        runner.frame(i, gather=False)
+        i += 1
+        if i % 8 == 0:
+            runner.finish()
+            torch.cuda.synchronize()
     for i in range(warmup):
         runner.frame(i)
     runner.finish()
@@ -223,6 +240,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--spinup-ms", type=float, default=250.0, help="untimed clock spin-up before the warm-up steps (0 = off)")
     ap.add_argument("--config", default="c32l4_fourier_1024x512", choices=sorted(CONFIGS))
     ap.add_argument("--activation", default="ReLU", choices=["ReLU", "SnakeAlt", "Snake", "Sine"])
     ap.add_argument("--early-out", action="store_true", help="as-shipped DVR with alpha early-out")
@@ -259,7 +277,7 @@ def main():
     vn, net = make_network(util, volnet_io, capi, cfg, args.activation, time_keys)
     info = net.info()
     runner = Runner(capi, net, cfg, rank, world, args.early_out, time_keys)
-    dt, kernel_ms, evaluated, executed = timed_run(runner, args.steps, args.warmup, distributed)
+    dt, kernel_ms, evaluated, executed = timed_run(runner, args.steps, args.warmup, distributed, args.spinup_ms)
     if distributed:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -308,7 +326,7 @@ def main():
         achieved = flops_per_launch / kernel_s / 1e12
         out = {
             "metric": "srn_samples_per_s", "value": evaluated / dt, "unit": "samples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "steps": args.steps, "warmup": args.warmup, "spinup_ms": args.spinup_ms, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "%s: %dx%d, %d steps/ray, %d-wide x %d-layer fp16 SRN%s, %s, density:direct + Identity TF, "
                                    "early-out %s" % (args.config, W, H, steps, cfg[0], cfg[1],
