@@ -664,6 +664,7 @@ struct RayEvaluationSteppingDvr : IRayEvaluation {
     std::shared_ptr<Blending> blending = std::make_shared<Blending>();
     std::shared_ptr<ITransferFunction> tf = std::make_shared<TransferFunctionIdentity>();
     std::shared_ptr<BRDFLambert> brdf = std::make_shared<BRDFLambert>();
+    void convertToTextureTF();  // ray_evaluation_stepping.cpp:767-779
 };
 
 // ----------------------------------------------------------------------------------------------------- camera
@@ -929,6 +930,64 @@ torch::Tensor textureTensor(const std::vector<ColorPoint>& color, const std::vec
         r[3] = float(scaling) * plot[size_t(i)];
     }
     return t;
+}
+
+// RayEvaluationSteppingDvr::convertToTextureTF (ray_evaluation_stepping.cpp:767-779) = TransferFunctionTexture::doPaste
+// (transfer_function_texture.cpp:412-437): the current TF is sampled on the host at the 256 texel centres
+// (ITransferFunction::evaluate(double): transfer_function_identity.cpp:140-150, _gaussian.cpp:335-338,376-385,
+// _piecewise.cpp:283-287 = sampleTF of renderer_tf_piecewise.cuh:31-52), colours become colour control points, absorption the
+// opacity plot relative to the scaling (10, raised to the maximum absorption if that is larger), then computeTexture.
+void RayEvaluationSteppingDvr::convertToTextureTF() {
+    if (!tf) return;
+    if (std::dynamic_pointer_cast<TransferFunctionTexture>(tf)) return;  // already a texture TF
+    const int R = 256;
+    std::vector<ColorPoint> colorPoints;
+    std::vector<float> plot(R);
+    double scaling = 10.0, maxW = 0.0;
+    auto ident = std::dynamic_pointer_cast<TransferFunctionIdentity>(tf);
+    auto table = std::dynamic_pointer_cast<TableTF>(tf);
+    if (table && !table->tensor.defined()) raise("the transfer function has no control points");
+    for (int i = 0; i < R; ++i) {
+        const double d = (i + 0.5) / R;
+        double rgba[4] = {0, 0, 0, 0};
+        if (ident) {
+            rgba[0] = rgba[1] = rgba[2] = d * ident->absorptionEmission->value.y;
+            rgba[3] = d * ident->absorptionEmission->value.x;
+        } else if (table && table->kind == FVSRN_TF_GAUSSIAN) {
+            const float* t = table->tensor.data_ptr<float>();
+            for (int64_t k = 0; k < table->tensor.size(1); ++k) {
+                const float* r = t + 6 * k;
+                const float x = float(d);
+                const double ni = std::exp(-(x - r[4]) * (x - r[4]) / (r[5] * r[5]));  // gaussian(float, float, float), expf
+                for (int c = 0; c < 4; ++c) rgba[c] += double(r[c]) * double(float(ni));
+            }
+        } else if (table && table->kind == FVSRN_TF_PIECEWISE) {
+            const float* t = table->tensor.data_ptr<float>();
+            const int n = int(table->tensor.size(1));
+            float density = float(d);
+            int k;
+            for (k = 0; k < n - 2; ++k)
+                if (t[5 * (k + 1) + 4] > density) break;
+            const float* a = t + 5 * k;
+            const float* b = t + 5 * (k + 1);
+            density = std::min(std::max(density, a[4]), b[4]);
+            const float frac = (density - a[4]) / (b[4] - a[4]);
+            for (int c = 0; c < 4; ++c) rgba[c] = a[c] + frac * (b[c] - a[c]);
+        } else {
+            raise("Copying to texture TF not supported from source TF");
+        }
+        colorPoints.push_back({d, {rgba[0], rgba[1], rgba[2]}});
+        plot[size_t(i)] = float(rgba[3] / scaling);
+        maxW = std::max(maxW, rgba[3]);
+    }
+    if (maxW > scaling) {
+        const double f = scaling / maxW;
+        scaling = maxW;
+        for (float& p : plot) p = float(p * f);
+    }
+    auto tex = std::make_shared<TransferFunctionTexture>();
+    tex->setTensor(textureTensor(colorPoints, plot, scaling));
+    tf = tex;
 }
 
 std::shared_ptr<ImageEvaluatorSimple> loadFromJson(const std::string& filename) {
@@ -1349,7 +1408,8 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def_readwrite("early_out", &RayEvaluationSteppingDvr::enableEarlyOut)
         .def_readonly("blending", &RayEvaluationSteppingDvr::blending)
         .def_readwrite("tf", &RayEvaluationSteppingDvr::tf)
-        .def_readwrite("brdf", &RayEvaluationSteppingDvr::brdf);
+        .def_readwrite("brdf", &RayEvaluationSteppingDvr::brdf)
+        .def("convert_to_texture_tf", &RayEvaluationSteppingDvr::convertToTextureTF);
 
     // ---- cameras (camera.cpp:184-224,375-397)
     py::class_<ICamera, std::shared_ptr<ICamera>>(m, "ICamera")

@@ -449,3 +449,65 @@ def test_grid_volume_renders_like_the_restatement(tmp_path, source):
     got = grid.evaluate(pos).cpu().numpy()[:, 0]
     want = oracle.OracleVolume(data, bmin, bsize, oracle.VOLUME_TRICUBIC, osrc).evaluate(pos.cpu().numpy())
     assert np.abs(got - want).max() < 1e-5
+
+
+def test_convert_to_texture_tf(tmp_path):
+    """RayEvaluationSteppingDvr.convert_to_texture_tf (ray_evaluation_stepping.cpp:767-779, what inference.py:335 calls before it
+    times a network): the TF sampled at the 256 texel centres becomes a TransferFunctionTexture."""
+    from oracle import oracle
+    p = tmp_path / "pw.json"
+    p.write_text(json.dumps(_scene_json("Piecewise", PIECEWISE_JSON)))
+    ev = pr.load_from_json(str(p))
+    table = ev.ray_evaluator.tf.tensor.numpy()[0]  # (R,5): r,g,b,absorption,pos
+    ev.ray_evaluator.convert_to_texture_tf()
+    assert isinstance(ev.ray_evaluator.tf, pr.TransferFunctionTexture)
+    tex = ev.ray_evaluator.tf.tensor.numpy()[0]
+    assert tex.shape == (256, 4)
+    d = ((np.arange(256) + 0.5) / 256).astype(np.float32)
+    want = np.zeros((256, 4), np.float32)
+    for i, x in enumerate(d):  # sampleTF, renderer_tf_piecewise.cuh:31-52
+        k = 0
+        while k < table.shape[0] - 2 and not table[k + 1, 4] > x:
+            k += 1
+        a, b = table[k], table[k + 1]
+        f = (min(max(x, a[4]), b[4]) - a[4]) / (b[4] - a[4])
+        want[i] = a[:4] + f * (b[:4] - a[:4])
+    assert np.abs(tex[:, :3] - want[:, :3]).max() < 1e-6
+    assert np.abs(tex[:, 3] - want[:, 3]).max() < 1e-5 * max(1.0, want[:, 3].max())
+    before = ev.ray_evaluator.tf
+    ev.ray_evaluator.convert_to_texture_tf()  # already a texture TF: unchanged
+    assert ev.ray_evaluator.tf is before
+    # Identity and Gaussian sources
+    re = pr.RayEvaluationSteppingDvr()
+    re.tf.absorption_emission.value = pr.double2(25.0, 0.5)
+    re.convert_to_texture_tf()
+    t = re.tf.tensor.numpy()[0]
+    assert np.allclose(t[:, 0], d * 0.5, atol=1e-6) and np.allclose(t[:, 3], d * 25.0, rtol=1e-5)
+    p = tmp_path / "g.json"
+    gaussian_json = {"absorptionScaling": 2.0, "points": [[1, 0, 0, 10, 0.3, 0.1], [0, 1, 0, 20, 0.7, 0.05]]}
+    p.write_text(json.dumps(_scene_json("Gaussian", gaussian_json)))
+    ev = pr.load_from_json(str(p))
+    g = ev.ray_evaluator.tf.tensor.numpy()[0]
+    ev.ray_evaluator.convert_to_texture_tf()
+    t = ev.ray_evaluator.tf.tensor.numpy()[0]
+    want = sum(np.outer(np.exp(-(d - r[4]) ** 2 / r[5] ** 2), r[:4]) for r in g)
+    assert np.abs(t - want).max() < 2e-5 * max(1.0, want.max())
+
+
+@pytest.mark.gpu
+def test_render_with_converted_texture_tf_stays_close(tmp_path):
+    """inference.py:335: the renders with the piecewise TF and with its 256-texel texture agree to the resolution of the texture."""
+    p = tmp_path / "pw.json"
+    p.write_text(json.dumps(_scene_json("Piecewise", PIECEWISE_JSON)))
+    vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density", seed=8, box_min=(-0.5, -0.5, -0.5))
+    path = str(tmp_path / "net.volnet")
+    open(path, "wb").write(volnet_io.save_volnet(vn))
+    ev = pr.load_from_json(str(p))
+    vol = pr.VolumeInterpolationNetwork()
+    vol.set_network(pr.SceneNetwork.load(path))
+    ev.volume = vol
+    a = ev.render(64, 48).clone()
+    ev.ray_evaluator.convert_to_texture_tf()
+    b = ev.render(64, 48)
+    assert float(a[0, 3].max()) > 0.2
+    assert float((a[0, :4] - b[0, :4]).abs().max()) < 2e-2

@@ -76,6 +76,8 @@ def run(args) -> dict:
     vol.set_network(net)
     ev.volume = vol
     ev.ray_evaluator.stepsize = args.stepsize  # world step size (render_network :603-606)
+    if getattr(args, "texture_tf", False):  # LoadedModel.enable_preintegration(..., convert_to_texture=True), inference.py:332-336
+        ev.ray_evaluator.convert_to_texture_tf()
     net.set_time_and_ensemble(args.timestep, args.ensemble)
 
     pyd = ev.camera.pitchYawDistance.value
@@ -124,6 +126,7 @@ def main(argv=None):
     p.add_argument("--stepsize", type=float, default=1.0 / 256)
     p.add_argument("--timestep", type=float, default=0.0)
     p.add_argument("--ensemble", type=int, default=0)
+    p.add_argument("--texture-tf", action="store_true", help="convert the scene's TF to a 256-texel texture TF first (convert_to_texture_tf)")
     args = p.parse_args(argv)
     print(json.dumps(run(args)))
 
