@@ -311,8 +311,35 @@ struct IVolumeInterpolation {
     virtual void setBoxMin(double3 v) { boxMin_ = v; }
     virtual void setBoxMax(double3 v) { boxMax_ = v; }
     double3 boxSize() const { return {boxMax_.x - boxMin_.x, boxMax_.y - boxMin_.y, boxMax_.z - boxMin_.z}; }
+    int objectResolution_[3] = {256, 256, 256};  // volume_interpolation.h:39 (networks: the resolution the scene file carries)
+    double3 voxelSize() const {  // volume_interpolation.cpp:21-24
+        const double3 s = boxSize();
+        return {s.x / (objectResolution_[0] - 1), s.y / (objectResolution_[1] - 1), s.z / (objectResolution_[2] - 1)};
+    }
     virtual int outputChannels() const = 0;
+    // positions in UNIT-BOX coordinates: the reference sets the box to [0,1]^3 for these calls (volume_interpolation.cpp:46-49,154-157)
     virtual torch::Tensor evaluate(const torch::Tensor& positions, const std::optional<torch::Tensor>& direction) = 0;
+    // world-space step of the central differences behind evaluate_with_gradients, per axis; {0,0,0}: no gradient available
+    virtual double3 gradientStep() const = 0;
+    // IVolumeInterpolation::evaluateWithGradient (:128-243, kernel EvaluateNoBatchesWithGradient): densities (N,1) and
+    // gradients (N,3) by central differences of evaluate() -- what evalNormal computes for grids (renderer_volume_grid.cuh:234-283:
+    // one voxel to either side, scaled by 0.5 / voxel size) and for networks in GRADIENT_MODE_FINITE_DIFFERENCES
+    // (renderer_volume_tensorcores.cuh:1185-1196)
+    std::tuple<torch::Tensor, torch::Tensor> evaluateWithGradients(const torch::Tensor& positions, const std::optional<torch::Tensor>& direction) {
+        if (outputChannels() != 1) raise("evaluateWithGradient can only be called for scalar volumes");
+        const double3 h = gradientStep();
+        if (!(h.x > 0 && h.y > 0 && h.z > 0)) raise("this volume provides no gradients in its current gradient mode (use FINITE_DIFFERENCES)");
+        const torch::Tensor densities = evaluate(positions, direction);
+        torch::Tensor gradients = torch::empty({positions.size(0), 3}, densities.options());
+        const double hs[3] = {h.x, h.y, h.z};
+        for (int k = 0; k < 3; ++k) {
+            torch::Tensor offset = torch::zeros({1, 3}, positions.options());
+            offset.select(1, k).fill_(hs[k]);
+            const torch::Tensor hi = evaluate(positions + offset, direction), lo = evaluate(positions - offset, direction);
+            gradients.select(1, k).copy_(((hi - lo) * (0.5 / hs[k])).select(1, 0));
+        }
+        return {densities, gradients};
+    }
 };
 
 enum GradientMode { OFF_OR_DIRECT = 0, FINITE_DIFFERENCES = 1, ADJOINT_METHOD = 2 };
@@ -323,6 +350,7 @@ struct UnsupportedVolume : IVolumeInterpolation {
     std::string name;
     explicit UnsupportedVolume(std::string n) : name(std::move(n)) {}
     int outputChannels() const override { return 1; }
+    double3 gradientStep() const override { return {0, 0, 0}; }
     torch::Tensor evaluate(const torch::Tensor&, const std::optional<torch::Tensor>&) override {
         raise("volume '" + name + "' is not part of this build (only the SRN path is): set a VolumeInterpolationNetwork");
     }
@@ -354,6 +382,11 @@ struct VolumeInterpolationNetwork : IVolumeInterpolation {
     void setBoxMin(double3 v) override { boxMin_ = v; pushBox(); }
     void setBoxMax(double3 v) override { boxMax_ = v; pushBox(); }
     int outputChannels() const override { return currentNetwork()->info().output_channels; }
+    double3 gradientStep() const override {  // unit-box coordinates (see evaluate)
+        if (gradientMode == ADJOINT_METHOD) raise("gradient mode ADJOINT_METHOD is not in the compiled variant set");
+        if (gradientMode != FINITE_DIFFERENCES) return {0, 0, 0};
+        return {finiteDifferencesStepsize, finiteDifferencesStepsize, finiteDifferencesStepsize};
+    }
     void setTimeAndEnsemble(float t, int e) { check(fvsrn_network_set_time_and_ensemble(currentNetwork()->h, t, e)); }
 
     torch::Tensor evaluate(const torch::Tensor& positions, const std::optional<torch::Tensor>& direction) override {
@@ -559,10 +592,20 @@ struct VolumeInterpolationGrid : IVolumeInterpolation {
         return h;
     }
     int sourceMode() const { return source_ == SourceTorchTensor ? FVSRN_VOLUME_SOURCE_TENSOR : FVSRN_VOLUME_SOURCE_TEXTURE; }
+    double3 gradientStep() const override {  // one voxel (normalStep = 1, normalScale = 0.5 / voxelSize, :1097-1104), in unit-box units
+        int res[3];
+        check(fvsrn_volume_info(handle(), res, nullptr, nullptr));
+        const int m = newBehavior ? 0 : 1;
+        return {1.0 / (res[0] - m), 1.0 / (res[1] - m), 1.0 / (res[2] - m)};
+    }
     torch::Tensor evaluate(const torch::Tensor& positions, const std::optional<torch::Tensor>&) override {
         TORCH_CHECK(positions.is_cuda(), "positions must reside on the GPU");
         TORCH_CHECK(positions.dim() == 2 && positions.size(1) == 3, "positions must be of shape (N,3)");
-        const torch::Tensor p = positions.to(c10::kFloat).contiguous();
+        // unit-box positions (the reference evaluates with the box set to [0,1]^3) -> the world box of the C ABI volume
+        const double3 bs = boxSize();
+        const torch::Tensor scale = torch::tensor({float(bs.x), float(bs.y), float(bs.z)}, positions.options().dtype(c10::kFloat));
+        const torch::Tensor shift = torch::tensor({float(boxMin_.x), float(boxMin_.y), float(boxMin_.z)}, positions.options().dtype(c10::kFloat));
+        const torch::Tensor p = (positions.to(c10::kFloat) * scale + shift).contiguous();
         torch::Tensor out = torch::empty({p.size(0), 1}, p.options());
         check(fvsrn_volume_evaluate_points(handle(), sourceMode(), interpolation_, newBehavior ? 1 : 0, p.data_ptr<float>(), size_t(p.size(0)),
                                            out.data_ptr<float>(), currentStream()));
@@ -802,7 +845,32 @@ struct ImageEvaluatorSimple {
                                       out.data_ptr<float>(), nullptr, currentStream()));
         lastRender = out;
         exposureStale = true;
+        refiningCounter = 0;
         return out;
+    }
+    // IImageEvaluator::refine = render(..., refine = true, previous) (image_evaluator_simple.cpp:288-356): a new frame blended into
+    // the previous one with weight 1 / refiningCounter (the DVR ray evaluator is deterministic: the average converges at once)
+    int refiningCounter = 0;
+    torch::Tensor refine(int width, int height, const torch::Tensor& previous) {
+        TORCH_CHECK(previous.dim() == 4 && previous.size(0) == 1 && previous.size(1) == 8 && previous.size(2) == height && previous.size(3) == width,
+                    "previous must be a (1,8,H,W) render of the same size");
+        const int counter = refiningCounter;
+        const torch::Tensor t = render(width, height);
+        refiningCounter = counter + 1;
+        torch::Tensor out = previous + (t - previous) * (1.0 / refiningCounter);
+        lastRender = out;
+        exposureStale = true;
+        return out;
+    }
+    py::object moduleForTag(const std::string& tag) const {  // IImageEvaluator::getSelectedModuleForTag
+        if (tag == "camera") return py::cast(camera);
+        if (tag == "volume") return py::cast(volume);
+        if (tag == "RayEvaluation") return py::cast(rayEvaluator);
+        auto dvr = std::dynamic_pointer_cast<RayEvaluationSteppingDvr>(rayEvaluator);
+        if (dvr && tag == "tf") return py::cast(dvr->tf);
+        if (dvr && tag == "brdf") return py::cast(dvr->brdf);
+        if (dvr && tag == "blending") return py::cast(dvr->blending);
+        raise("no module for tag '" + tag + "' (camera, volume, RayEvaluation, tf, brdf, blending)");
     }
     torch::Tensor lastRender;
     bool exposureStale = false;
@@ -1218,6 +1286,9 @@ PYBIND11_MODULE(pyrenderer, m) {
                 if (s == names[i]) return fvsrn_activation(i);
             raise("No output mode found matching string " + s);
         })
+        .def("valid", [](const Layer& l, bool isOutputLayer) {  // Layer::valid, volume_interpolation_network.cpp:241-246 (sizes always match here)
+                 return l.channelsIn > 0 && l.channelsOut > 0 && (isOutputLayer || l.channelsOut % 4 == 0);
+             }, py::arg("is_output_layer"))
         .def_readonly("channels_in", &Layer::channelsIn)
         .def_readonly("channels_out", &Layer::channelsOut);
 
@@ -1290,7 +1361,15 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def("set_box_min", &IVolumeInterpolation::setBoxMin)
         .def("set_box_max", &IVolumeInterpolation::setBoxMax)
         .def("output_channels", &IVolumeInterpolation::outputChannels)
-        .def("evaluate", &IVolumeInterpolation::evaluate, py::arg("positions"), py::arg("direction") = std::optional<torch::Tensor>{});
+        .def("voxel_size", &IVolumeInterpolation::voxelSize)
+        .def("object_resolution", [](IVolumeInterpolation& v) { return int3{v.objectResolution_[0], v.objectResolution_[1], v.objectResolution_[2]}; })
+        .def("evaluate", &IVolumeInterpolation::evaluate, py::arg("positions"), py::arg("direction") = std::optional<torch::Tensor>{},
+             py::doc("Evaluates the volume on the given position array of shape (B,3) and returns the interpolated densities of shape (B,1)"))
+        .def("evaluate_with_gradients", &IVolumeInterpolation::evaluateWithGradients, py::arg("positions"), py::arg("direction") = std::optional<torch::Tensor>{},
+             py::doc("Densities of shape (B,1) and gradients of shape (B,3)"))
+        .def("evaluate_with_gradients_and_curvature", [](IVolumeInterpolation&, const torch::Tensor&, const std::optional<torch::Tensor>&) -> py::object {
+                 raise("curvature evaluation is not in the compiled variant set");
+             }, py::arg("positions"), py::arg("direction") = std::optional<torch::Tensor>{});
     py::class_<UnsupportedVolume, IVolumeInterpolation, std::shared_ptr<UnsupportedVolume>>(m, "UnsupportedVolume")
         .def_readonly("name", &UnsupportedVolume::name);
     // ---- grid volumes (volume.cpp:1244-1400, volume_interpolation_grid.cpp:851-897)
@@ -1436,7 +1515,28 @@ PYBIND11_MODULE(pyrenderer, m) {
                  torch::Tensor start = torch::empty({1, height, width, 3}, opt), dir = torch::empty({1, height, width, 3}, opt);
                  check(fvsrn_generate_rays(e, r, u, float(c.fovYRadians), width, height, start.data_ptr<float>(), dir.data_ptr<float>(), currentStream()));
                  return std::make_tuple(start, dir);
-             }, py::arg("width"), py::arg("height"), py::arg("double_precision") = false);
+             }, py::arg("width"), py::arg("height"), py::arg("double_precision") = false)
+        // ICamera::generateRaysMultisampling (camera.cpp:100-164, CameraGenerateRayMultisamplingKernel): num_samples rays per pixel
+        // through uniformly jittered positions inside the pixel, batch dimension = sample.  The reference seeds its device
+        // sampler with (42, time); here torch's generator is seeded with 42 + time: same distribution, another sequence.
+        .def("generate_rays_multisampling", [](CameraOnASphere& c, int width, int height, int numSamples, unsigned time, bool doublePrecision) {
+                 if (doublePrecision) raise("double precision rays are not supported by this build");
+                 if (numSamples <= 0) raise("num_samples must be positive");
+                 c.aspectRatio = double(width) / height;
+                 float e[3], r[3], u[3];
+                 c.frame(e, r, u);
+                 auto opt = torch::TensorOptions().dtype(torch::kFloat).device(torch::kCUDA);
+                 auto gen = at::detail::createCPUGenerator(42 + uint64_t(time));
+                 const torch::Tensor jitter = (torch::rand({numSamples, height, width, 2}, gen, torch::TensorOptions().dtype(torch::kFloat)) - 0.5).to(torch::kCUDA);
+                 const torch::Tensor xs = torch::arange(width, opt).view({1, 1, width}), ys = torch::arange(height, opt).view({1, height, 1});
+                 const torch::Tensor ndcx = 2 * (xs + jitter.select(3, 0) + 0.5) / width - 1, ndcy = 2 * (ys + jitter.select(3, 1) + 0.5) / height - 1;
+                 const torch::Tensor E = torch::tensor({e[0], e[1], e[2]}, opt), R = torch::tensor({r[0], r[1], r[2]}, opt), U = torch::tensor({u[0], u[1], u[2]}, opt);
+                 const torch::Tensor F = torch::cross(U, R, 0);  // front = cross(up, right), renderer_camera.cuh:47
+                 const float tanY = std::tan(float(c.fovYRadians) / 2), tanX = tanY * float(width) / float(height);
+                 torch::Tensor dir = F.view({1, 1, 1, 3}) + (ndcx * tanX).unsqueeze(3) * R.view({1, 1, 1, 3}) + (ndcy * tanY).unsqueeze(3) * U.view({1, 1, 1, 3});
+                 dir = dir / dir.norm(2, 3, true);
+                 return std::make_tuple(E.view({1, 1, 1, 3}).expand({numSamples, height, width, 3}).contiguous(), dir.contiguous());
+             }, py::arg("width"), py::arg("height"), py::arg("num_samples"), py::arg("time") = 0, py::arg("double_precision") = false);
 
     // ---- image evaluators (iimage_evaluator.cpp:325-358, image_evaluator_simple.cpp:427-475)
     py::class_<ImageEvaluatorSimple, std::shared_ptr<ImageEvaluatorSimple>> ie(m, "ImageEvaluatorSimple");
@@ -1447,6 +1547,8 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def_readwrite("selected_channel", &ImageEvaluatorSimple::selectedChannel)
         .def_readwrite("double_precision", &ImageEvaluatorSimple::doublePrecision)
         .def("render", &ImageEvaluatorSimple::render, py::arg("width"), py::arg("height"))
+        .def("refine", &ImageEvaluatorSimple::refine, py::arg("width"), py::arg("height"), py::arg("previous"))
+        .def("get_module_for_tag", &ImageEvaluatorSimple::moduleForTag, py::arg("tag"))
         .def("compute_batch_count", [](ImageEvaluatorSimple&) { return 1; })
         .def("is_iterative_refining", [](ImageEvaluatorSimple&) { return false; })
         .def("get_supported_tags", [](ImageEvaluatorSimple&) { return std::vector<std::string>{"camera", "volume", "RayEvaluation"}; })

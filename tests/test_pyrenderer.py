@@ -445,10 +445,28 @@ def test_grid_volume_renders_like_the_restatement(tmp_path, source):
     ref, _ = oracle.OracleVolume(data, bmin, bsize, oracle.VOLUME_TRICUBIC, osrc).render(scene, W, H)
     assert ref[3].max() > 0.5
     assert np.abs(img[:4] - ref[:4]).max() < (3e-3 if source == "volume" else 2e-4)
-    pos = torch.rand(1000, 3, device="cuda") - 0.5
+    # IVolumeInterpolation::evaluate takes unit-box positions (the reference sets the box to [0,1]^3, volume_interpolation.cpp:46-49)
+    pos = torch.rand(1000, 3, device="cuda")
+    world = np.array(bmin, np.float32) + pos.cpu().numpy() * np.array(bsize, np.float32)
+    ov = oracle.OracleVolume(data, bmin, bsize, oracle.VOLUME_TRICUBIC, osrc)
     got = grid.evaluate(pos).cpu().numpy()[:, 0]
-    want = oracle.OracleVolume(data, bmin, bsize, oracle.VOLUME_TRICUBIC, osrc).evaluate(pos.cpu().numpy())
-    assert np.abs(got - want).max() < 1e-5
+    assert np.abs(got - ov.evaluate(world)).max() < 2e-5
+    # evaluate_with_gradients: evalNormal of the grid = central differences one voxel to either side (renderer_volume_grid.cuh:234-283)
+    dens, grad = grid.evaluate_with_gradients(pos)
+    assert dens.shape == (1000, 1) and grad.shape == (1000, 3)
+    for k in range(3):
+        h = 1.0 / (data.shape[k] - 1)
+        off = np.zeros(3, np.float32)
+        off[k] = h * bsize[k]
+        want = (ov.evaluate(world + off) - ov.evaluate(world - off)) * (0.5 / h)
+        assert np.abs(grad[:, k].cpu().numpy() - want).max() < 2e-3 * max(1.0, np.abs(want).max())
+    # refine (image_evaluator_simple.cpp:351-356): the DVR is deterministic, the running average equals the render
+    img2 = ev.refine(W, H, ev.render(W, H))
+    img3 = ev.refine(W, H, img2)
+    assert float((img3[0, :4].cpu() - torch.from_numpy(img[:4])).abs().max()) < 1e-6
+    assert ev.get_module_for_tag("volume") is grid and ev.get_module_for_tag("tf") is tf
+    with pytest.raises(RuntimeError, match="no module"):
+        ev.get_module_for_tag("nope")
 
 
 def test_convert_to_texture_tf(tmp_path):
@@ -511,3 +529,42 @@ def test_render_with_converted_texture_tf_stays_close(tmp_path):
     b = ev.render(64, 48)
     assert float(a[0, 3].max()) > 0.2
     assert float((a[0, :4] - b[0, :4]).abs().max()) < 2e-2
+
+
+@pytest.mark.gpu
+def test_network_evaluate_with_gradients_and_ray_multisampling(tmp_path):
+    """IVolumeInterpolation.evaluate_with_gradients for a network in FINITE_DIFFERENCES mode (central differences of evaluate, unit box)
+    and ICamera.generate_rays_multisampling (jittered rays, batch = sample)."""
+    vn = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode="density", seed=3, box_min=(-0.5, -0.5, -0.5))
+    path = str(tmp_path / "net.volnet")
+    open(path, "wb").write(volnet_io.save_volnet(vn))
+    vol = pr.VolumeInterpolationNetwork()
+    vol.set_network(pr.SceneNetwork.load(path))
+    pos = torch.rand(512, 3, device="cuda") * 0.8 + 0.1
+    with pytest.raises(RuntimeError, match="gradient"):
+        vol.evaluate_with_gradients(pos)  # OFF_OR_DIRECT: a density network predicts no gradient
+    vol.gradient_mode = pr.VolumeInterpolationNetwork.GradientMode.FINITE_DIFFERENCES
+    vol.finite_differences_stepsize = 1 / 64
+    dens, grad = vol.evaluate_with_gradients(pos)
+    assert torch.equal(dens, vol.evaluate(pos))
+    h = 1 / 64
+    for k in range(3):
+        off = torch.zeros(1, 3, device="cuda")
+        off[0, k] = h
+        want = (vol.evaluate(pos + off) - vol.evaluate(pos - off))[:, 0] / (2 * h)
+        assert float((grad[:, k] - want).abs().max()) < 1e-5
+    assert float(grad.abs().max()) > 1e-3
+    layer = vol.current_network().get_layer(0)
+    assert layer.valid(False) and vol.object_resolution().x == 256 and vol.voxel_size().x == pytest.approx(1 / 255)
+    cam = pr.CameraOnASphere()
+    cam.pitchYawDistance.value = pr.double3(0.4, 0.7, 1.6)
+    start, direction = cam.generate_rays_multisampling(24, 16, 5)
+    c_start, c_dir = cam.generate_rays(24, 16)
+    assert start.shape == (5, 16, 24, 3) and direction.shape == (5, 16, 24, 3)
+    assert float((start - c_start).abs().max()) < 1e-6
+    assert float((direction.norm(dim=3) - 1).abs().max()) < 1e-5
+    # jitter stays inside the pixel: directions differ from the pixel-centre ray by less than one pixel's angle, and differ between samples
+    assert float((direction - c_dir).abs().max()) < 2 * float((c_dir[0, 0, 1] - c_dir[0, 0, 0]).abs().max())
+    assert float((direction[0] - direction[1]).abs().max()) > 0
+    again, _ = cam.generate_rays_multisampling(24, 16, 5), None
+    assert torch.equal(again[1], direction)  # seeded like the reference: (42, time)
