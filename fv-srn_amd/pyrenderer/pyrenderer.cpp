@@ -669,7 +669,15 @@ struct TableTF : ITransferFunction {
         table.assign(tensor.data_ptr<float>(), tensor.data_ptr<float>() + tensor.numel());
     }
 };
-struct TransferFunctionGaussian : TableTF { TransferFunctionGaussian() : TableTF(FVSRN_TF_GAUSSIAN, 6) {} };
+struct TransferFunctionGaussian : TableTF {
+    double absorptionScaling = 1.0;            // transfer_function_gaussian.cpp:264 (the tensor rows already carry opacity * scaling)
+    bool piecewiseAnalyticIntegration = false;  // :265; only the non-analytic evaluation is compiled in
+    TransferFunctionGaussian() : TableTF(FVSRN_TF_GAUSSIAN, 6) {}
+    void fill(fvsrn_scene_desc& d, std::vector<float>& table) const override {
+        if (piecewiseAnalyticIntegration) raise("piecewise analytic integration of Gaussian transfer functions is not in the compiled variant set");
+        TableTF::fill(d, table);
+    }
+};
 struct TransferFunctionPiecewise : TableTF { TransferFunctionPiecewise() : TableTF(FVSRN_TF_PIECEWISE, 5) {} };
 struct TransferFunctionTexture : TableTF {
     int preintegrationMode = FVSRN_PREINTEGRATE_NONE;  // TransferFunctionTexture::PreintegrationMode
@@ -680,7 +688,8 @@ struct TransferFunctionTexture : TableTF {
     }
 };
 
-struct BRDFLambert {  // renderer/brdf.cpp:208-225 (JSON), :413-508 (constant block, light follows camera)
+struct IBRDF { virtual ~IBRDF() = default; };
+struct BRDFLambert : IBRDF {  // renderer/brdf.cpp:208-225 (JSON), :413-508 (constant block, light follows camera)
     bool enableMagnitudeScaling = false, enablePhong = false;
     std::shared_ptr<Parameter<double>> magnitudeScaling = std::make_shared<Parameter<double>>(Parameter<double>{1.0});
     std::shared_ptr<Parameter<double>> ambient = std::make_shared<Parameter<double>>(Parameter<double>{0.1});
@@ -700,8 +709,10 @@ struct Blending {
 
 // ---------------------------------------------------------------------------------------------- ray evaluator
 struct IRayEvaluation { virtual ~IRayEvaluation() = default; };
-struct RayEvaluationSteppingDvr : IRayEvaluation {
+struct IRayEvaluationStepping : IRayEvaluation {  // ray_evaluation_stepping.cpp:80-93
     double stepsize = 0.005;
+};
+struct RayEvaluationSteppingDvr : IRayEvaluationStepping {
     double minDensity = 0.0, maxDensity = 1.0;
     bool enableEarlyOut = true;
     std::shared_ptr<Blending> blending = std::make_shared<Blending>();
@@ -1440,16 +1451,29 @@ PYBIND11_MODULE(pyrenderer, m) {
                  return t.evaluate(densities, mn, mx, previous, stepsize);
              }, py::arg("densities"), py::arg("min_density"), py::arg("max_density"), py::arg("previous_density"), py::arg("stepsize"),
              py::arg("gradients") = std::optional<torch::Tensor>())
-        .def("requires_gradients", [](ITransferFunction&) { return false; });
+        .def("requires_gradients", [](ITransferFunction&) { return false; })
+        .def("get_max_absorption", [](ITransferFunction& t) {  // ITransferFunction::getMaxAbsorption: per unit step size
+                 fvsrn_scene_desc d{};
+                 std::vector<float> table;
+                 t.fill(d, table);
+                 if (d.tf_kind == FVSRN_TF_IDENTITY) return double(d.tf_scale_absorption);
+                 const int cols = d.tf_kind == FVSRN_TF_GAUSSIAN ? 6 : (d.tf_kind == FVSRN_TF_PIECEWISE ? 5 : 4);
+                 double m = 0;  // the table rows carry absorption * absorptionScaling in column 3
+                 for (size_t i = 3; i < table.size(); i += size_t(cols)) m = std::max(m, double(table[i]));
+                 return m;
+             });
     py::class_<TransferFunctionIdentity, ITransferFunction, std::shared_ptr<TransferFunctionIdentity>>(m, "TransferFunctionIdentity")
         .def(py::init<>())
         .def_readonly("absorption_emission", &TransferFunctionIdentity::absorptionEmission);
     py::class_<TransferFunctionGaussian, ITransferFunction, std::shared_ptr<TransferFunctionGaussian>>(m, "TransferFunctionGaussian")
         .def(py::init<>())
-        .def_property("tensor", [](TransferFunctionGaussian& t) { return t.tensor; }, &TransferFunctionGaussian::setTensor);
-    py::class_<TransferFunctionPiecewise, ITransferFunction, std::shared_ptr<TransferFunctionPiecewise>>(m, "TransferFunctionPiecewise")
+        .def_property("tensor", [](TransferFunctionGaussian& t) { return t.tensor; }, &TransferFunctionGaussian::setTensor)
+        .def_readwrite("absorption_scaling", &TransferFunctionGaussian::absorptionScaling)
+        .def_readwrite("piecewise_analytic_integraton", &TransferFunctionGaussian::piecewiseAnalyticIntegration);
+    py::class_<TransferFunctionPiecewise, ITransferFunction, std::shared_ptr<TransferFunctionPiecewise>>(m, "TransferFunctionPiecewiseLinear")
         .def(py::init<>())
         .def_property("tensor", [](TransferFunctionPiecewise& t) { return t.tensor; }, &TransferFunctionPiecewise::setTensor);
+    m.attr("TransferFunctionPiecewise") = m.attr("TransferFunctionPiecewiseLinear");  // earlier name of this build
     py::class_<TransferFunctionTexture, ITransferFunction, std::shared_ptr<TransferFunctionTexture>> ttex(m, "TransferFunctionTexture");
     py::enum_<fvsrn_tf_preintegration>(ttex, "PreintegrationMode")  // transfer_function_texture.cpp:246-250
         .value("Off", FVSRN_PREINTEGRATE_NONE).value("Preintegrate1D", FVSRN_PREINTEGRATE_1D).value("Preintegrate2D", FVSRN_PREINTEGRATE_2D).export_values();
@@ -1457,7 +1481,8 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def_property("preintegration_mode", [](TransferFunctionTexture& t) { return fvsrn_tf_preintegration(t.preintegrationMode); },
                       [](TransferFunctionTexture& t, fvsrn_tf_preintegration v) { t.preintegrationMode = v; })
         .def_property("tensor", [](TransferFunctionTexture& t) { return t.tensor; }, &TransferFunctionTexture::setTensor);
-    py::class_<BRDFLambert, std::shared_ptr<BRDFLambert>> bc(m, "BRDFLambert");  // brdf.cpp:256-273
+    py::class_<IBRDF, std::shared_ptr<IBRDF>>(m, "IBRDF");  // brdf.cpp:107 (its tensor evaluate() is not part of this build)
+    py::class_<BRDFLambert, IBRDF, std::shared_ptr<BRDFLambert>> bc(m, "BRDFLambert");  // brdf.cpp:256-273
     py::enum_<fvsrn_light_type>(bc, "LightType").value("Point", FVSRN_LIGHT_POINT).value("Directional", FVSRN_LIGHT_DIRECTIONAL).export_values();
     bc.def(py::init<>())
         .def_readwrite("enable_phong", &BRDFLambert::enablePhong)
@@ -1478,10 +1503,11 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def_property("blendMode", [](Blending& b) { return fvsrn_blend_mode(b.blendMode); }, [](Blending& b, fvsrn_blend_mode v) { b.blendMode = v; });
 
     // ---- ray evaluators (ray_evaluation_stepping.cpp:80-93,781-801)
-    py::class_<IRayEvaluation, std::shared_ptr<IRayEvaluation>>(m, "IRayEvaluation");
-    py::class_<RayEvaluationSteppingDvr, IRayEvaluation, std::shared_ptr<RayEvaluationSteppingDvr>>(m, "RayEvaluationSteppingDvr")
+    py::class_<IRayEvaluation, std::shared_ptr<IRayEvaluation>>(m, "IRayEvaluation", py::dynamic_attr());
+    py::class_<IRayEvaluationStepping, IRayEvaluation, std::shared_ptr<IRayEvaluationStepping>>(m, "IRayEvaluationStepping")
+        .def_readwrite("stepsize", &IRayEvaluationStepping::stepsize);
+    py::class_<RayEvaluationSteppingDvr, IRayEvaluationStepping, std::shared_ptr<RayEvaluationSteppingDvr>>(m, "RayEvaluationSteppingDvr")
         .def(py::init<>())
-        .def_readwrite("stepsize", &RayEvaluationSteppingDvr::stepsize)
         .def_readwrite("min_density", &RayEvaluationSteppingDvr::minDensity)
         .def_readwrite("max_density", &RayEvaluationSteppingDvr::maxDensity)
         .def_readwrite("early_out", &RayEvaluationSteppingDvr::enableEarlyOut)
