@@ -106,7 +106,7 @@ SYMBOLS = [
     ("fvsrn_volume_save_cvol", _I, [C.c_char_p, C.c_char_p, _VP, _I, _I, _I, _I, _F, _F, _F]),
     ("fvsrn_volume_info", _I, [_VP, C.POINTER(_I), _FP, _FP]),
     ("fvsrn_volume_evaluate_points", _I, [_VP, _I, _I, _I, _VP, _SZ, _VP, _VP]),
-    ("fvsrn_render_volume", _I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
+    ("fvsrn_render_volume", _I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
 ]
 
 _lib = None
@@ -442,13 +442,13 @@ class Volume:
         return out
 
     def render(self, scene: "Scene", width: int, height: int, interpolation=VOLUME_TRILINEAR, source=VOLUME_SOURCE_TEXTURE,
-               new_behavior=False, out=None, stats=None, stream=None):
+               new_behavior=False, out=None, stats=None, stream=None, provide_normals=False):
         """ImageEvaluatorSimple.render with this volume: (1,8,H,W) fp32."""
         import torch
         if out is None:
             out = torch.zeros((1, 8, height, width), dtype=torch.float32, device="cuda")
         sp = _torch_ptr(stats, "torch.int64", "stats") if stats is not None else None
-        _check(lib().fvsrn_render_volume(scene._h, self._h, source, interpolation, int(new_behavior), width, height,
+        _check(lib().fvsrn_render_volume(scene._h, self._h, source, interpolation, int(new_behavior), int(provide_normals), width, height,
                                          _torch_ptr(out, "torch.float32", "out"), sp, _current_stream() if stream is None else stream))
         return out
 

@@ -1052,12 +1052,12 @@ struct fvsrn_volume {
         HIP_CHECK(hipStreamSynchronize(s));
         deviceValid = true;
     }
-    VolumeParams params(int source, int interpolation, int newBehavior) const {
+    VolumeParams params(int source, int interpolation, int newBehavior, int provideNormals = 0) const {
         VolumeParams V{};
         V.data = static_cast<const float*>(dData.ptr);
         for (int i = 0; i < 3; ++i) { V.res[i] = res[i]; V.boxMin[i] = boxMin[i]; V.boxSize[i] = boxSize[i]; }
         V.stride[0] = 1; V.stride[1] = res[0]; V.stride[2] = (long long)res[0] * res[1];
-        V.source = source; V.interpolation = interpolation; V.newBehavior = newBehavior;
+        V.source = source; V.interpolation = interpolation; V.newBehavior = newBehavior; V.provideNormals = provideNormals;
         return V;
     }
 };
@@ -1223,7 +1223,7 @@ int fvsrn_volume_evaluate_points(fvsrn_volume* volume, int source, int interpola
 }
 
 int fvsrn_render_volume(fvsrn_scene* scene, fvsrn_volume* volume, int source, int interpolation, int grid_resolution_new_behavior,
-                        int width, int height, float* d_out8, unsigned long long* d_stats, void* stream) {
+                        int provide_normals, int width, int height, float* d_out8, unsigned long long* d_stats, void* stream) {
     return guarded([&] {
         if (!scene || !volume || !d_out8) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
         if (width <= 0 || height <= 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad image size");
@@ -1234,16 +1234,15 @@ int fvsrn_render_volume(fvsrn_scene* scene, fvsrn_volume* volume, int source, in
             hipStream_t s = static_cast<hipStream_t>(stream);
             const fvsrn_scene_desc& d = scene->desc;
             if (d.tf_kind == FVSRN_TF_NONE) return fail(FVSRN_ERR_INVALID_ARGUMENT, "a grid volume holds densities; the scene needs a transfer function");
-            if (d.gradient_mode != FVSRN_GRADIENT_OFF_OR_DIRECT || d.brdf_enable_phong || d.brdf_enable_magnitude_scaling ||
-                d.tf_preintegration != FVSRN_PREINTEGRATE_NONE)
-                return fail(FVSRN_ERR_UNSUPPORTED, "grid volumes are rendered without normals: no shading BRDF, finite differences or pre-integrated TF");
+            // (fvsrn_scene_desc::gradient_mode configures network volumes; a grid always differentiates by central differences)
+            const int normals = provide_normals || d.brdf_enable_phong || d.brdf_enable_magnitude_scaling;  // brdf.cpp:40,279
             volume->ensureDevice(s);
             const size_t tfFloats = scene->tfTable.size();
             if (const int rc = scene->uploadTf(d.stepsize, s)) return rc;
             SceneParams S{};
             fillSceneParams(scene, d, width, height, S);
             S.width = width; S.height = height; S.y0 = 0; S.y1 = height;
-            const hipError_t e = launch_volume_render(volume->params(source, interpolation, grid_resolution_new_behavior), S, d_out8, d_stats, tfFloats, s);
+            const hipError_t e = launch_volume_render(volume->params(source, interpolation, grid_resolution_new_behavior, normals), S, d_out8, d_stats, tfFloats, s);
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during rendering! ") + hipGetErrorString(e));
             return FVSRN_OK;
         } catch (const DeviceError& e) {

@@ -48,29 +48,66 @@ __global__ __launch_bounds__(256) void volume_render_kernel(VolumeParams V, Scen
     tmin = fmaxf(tmin, 0.f);
     if (!inImage) tmax = -1.f;
 
-    float cr = 0, cg = 0, cb = 0, ca = 0, depth = 0;
+    float cr = 0, cg = 0, cb = 0, ca = 0, depth = 0, nx = 0, ny = 0, nz = 0;
+    float previousDensity = -1.f;  // pre-integrated transfer functions, stepping_dvr.cuh:81
     unsigned count = 0;
     for (int i = 0;; ++i) {
         const float t = tmin + float(i) * S.stepsize;
         const bool valid = (t <= tmax) && (!S.earlyOut || ca < S.alphaEarlyOut);
         if (!valid) break;  // per-lane view of the reference's warp-synchronous loop: an invalid lane never blends again
         ++count;
-        const float value = vol_eval(V, ox + dx * t, oy + dy * t, oz + dz * t);
-        if (value >= S.densityMin) {  // stepping_dvr.cuh:110-135
-            const float4_t color = tf_eval(S, tfLds, (value - S.densityMin) * S.divDensityRange);
+        const float wx = ox + dx * t, wy = oy + dy * t, wz = oz + dz * t;
+        const float value = vol_eval(V, wx, wy, wz);
+        const float density2 = (value - S.densityMin) * S.divDensityRange;
+        const float prev = previousDensity;
+        previousDensity = density2;  // stepping_dvr.cuh:135
+        if (value >= S.densityMin) {  // :110-135
+            float4_t color = S.tfPreintegration != FVSRN_PREINTEGRATE_NONE ? tf_eval_preintegrated(S, tfLds, fminf(fmaxf(density2, 0.f), 1.f), prev)
+                                                                         : tf_eval(S, tfLds, density2);
+            float g[3] = {0.f, 0.f, 0.f};
+            if (V.provideNormals) vol_normal(V, wx, wy, wz, g);  // :122-128 (requireNormal)
+            if (color[3] > 0.f && (S.brdfMagnitudeScaling | S.brdfPhong)) {  // BRDFLambert::eval, renderer_brdf_lambert.cuh:56-103
+                const float g2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+                if (S.brdfMagnitudeScaling) color[3] *= 1.f - __expf(-S.brdfMagScale * g2);
+                if (S.brdfPhong) {
+                    const float gradientNorm = rsqrtf(g2);
+                    float nX = g[0], nY = g[1], nZ = g[2];
+                    if (g2 >= 1e-8f) { nX *= gradientNorm; nY *= gradientNorm; nZ *= gradientNorm; }
+                    float lx, ly, lz;
+                    if (S.brdfLightType == FVSRN_LIGHT_DIRECTIONAL) { lx = -S.brdfLight[0]; ly = -S.brdfLight[1]; lz = -S.brdfLight[2]; }
+                    else { lx = S.brdfLight[0] - wx; ly = S.brdfLight[1] - wy; lz = S.brdfLight[2] - wz; }
+                    const float il = rsqrtf(lx * lx + ly * ly + lz * lz);
+                    lx *= il; ly *= il; lz *= il;
+                    const float lo = S.brdfMagCenter - S.brdfMagRadius, hi = S.brdfMagCenter + S.brdfMagRadius;
+                    const float ys = fminf(fmaxf((gradientNorm - lo) / (hi - lo), 0.f), 1.f);
+                    const float phongStrength = ys * ys * (3.f - 2.f * ys);
+                    const float ambientStrength = 1.f + phongStrength * (S.brdfAmbient - 1.f);
+                    const float nl = nX * lx + nY * ly + nZ * lz;
+                    const float rx = lx - 2.f * nX * nl, ry = ly - 2.f * nY * nl, rz = lz - 2.f * nZ * nl;
+                    const float e = float(S.brdfSpecularExponent);
+                    const float spec = (e + 2.f) * 0.159155f * powf(fmaxf(0.f, dx * rx + dy * ry + dz * rz), e);
+                    for (int c = 0; c < 3; ++c)
+                        color[c] = ambientStrength * color[c] + (1.f - ambientStrength) * (fabsf(nl) * color[c] + S.brdfSpecular * spec);
+                }
+            }
             if (color[3] > 0.f) {  // Blending::eval
                 const float a = S.blendMode == FVSRN_BLEND_BEER_LAMBERT ? 1.f - __expf(-color[3]) : fminf(1.f, color[3]);
                 const float w = (1.f - ca) * a;
                 cr += w * color[0]; cg += w * color[1]; cb += w * color[2];
                 depth += w * t;
                 ca += w;
+                if (V.provideNormals) {
+                    const float l2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+                    if (l2 >= 1e-8f) { const float il = rsqrtf(l2); g[0] *= il; g[1] *= il; g[2] *= il; }  // safeNormalize
+                    nx += w * g[0]; ny += w * g[1]; nz += w * g[2];
+                }
             }
         }
     }
     if (inImage) {
         const size_t plane = size_t(S.width) * S.height, o = size_t(y) * S.width + x;
         out[o] = cr; out[plane + o] = cg; out[2 * plane + o] = cb; out[3 * plane + o] = ca;
-        out[4 * plane + o] = 0.f; out[5 * plane + o] = 0.f; out[6 * plane + o] = 0.f;  // no normals requested from the grid
+        out[4 * plane + o] = nx * ca; out[5 * plane + o] = ny * ca; out[6 * plane + o] = nz * ca;
         out[7 * plane + o] = depth * ca / ca;
     }
     if (stats) {

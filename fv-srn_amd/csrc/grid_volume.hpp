@@ -16,6 +16,7 @@ struct VolumeParams {
     int interpolation;        // fvsrn_volume_interpolation
     int source;               // fvsrn_volume_source
     int newBehavior;          // grid_resolution_new_behavior: world -> object scale = resolution instead of resolution - 1
+    int provideNormals;       // volumeShouldProvideNormals (shading BRDF, normal channel): central-difference gradients
 };
 
 __device__ __forceinline__ int vol_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -94,16 +95,36 @@ __device__ __forceinline__ float vol_sample_cubic(const VolumeParams& V, float x
 }
 
 // eval (:193-232): world position -> object coordinates [0, res-1] (old behaviour) or [0, res] (new), then sample()
-__device__ __forceinline__ float vol_eval(const VolumeParams& V, float wx, float wy, float wz) {
+__device__ __forceinline__ void vol_to_object(const VolumeParams& V, float wx, float wy, float wz, float p[3]) {
     const float w[3] = {wx, wy, wz};
-    float p[3];
     for (int d = 0; d < 3; ++d) {
         const float scale = float(V.newBehavior ? V.res[d] : V.res[d] - 1);
         p[d] = (w[d] - V.boxMin[d]) / V.boxSize[d] * scale;
     }
-    if (V.interpolation == 0) return vol_sample_nearest(V, p[0], p[1], p[2]);
-    if (V.interpolation == 1) return vol_sample_linear(V, p[0], p[1], p[2]);
-    return vol_sample_cubic(V, p[0], p[1], p[2]);
+}
+__device__ __forceinline__ float vol_sample(const VolumeParams& V, float x, float y, float z) {
+    if (V.interpolation == 0) return vol_sample_nearest(V, x, y, z);
+    if (V.interpolation == 1) return vol_sample_linear(V, x, y, z);
+    return vol_sample_cubic(V, x, y, z);
+}
+__device__ __forceinline__ float vol_eval(const VolumeParams& V, float wx, float wy, float wz) {
+    float p[3];
+    vol_to_object(V, wx, wy, wz, p);
+    return vol_sample(V, p[0], p[1], p[2]);
+}
+// evalNormalImpl (:234-283): central differences one voxel to either side (normalStep = 1), scaled by 0.5 / voxelSize with
+// voxelSize = boxSize / (resolution - 1 | resolution) (volume_interpolation_grid.cpp:1097-1104)
+__device__ __forceinline__ void vol_normal(const VolumeParams& V, float wx, float wy, float wz, float n[3]) {
+    float p[3];
+    vol_to_object(V, wx, wy, wz, p);
+    for (int d = 0; d < 3; ++d) {
+        const float voxel = V.boxSize[d] / float(V.newBehavior ? V.res[d] : V.res[d] - 1);
+        const float scale = 0.5f / voxel;
+        float a[3] = {p[0], p[1], p[2]}, b[3] = {p[0], p[1], p[2]};
+        a[d] += 1.f;
+        b[d] -= 1.f;
+        n[d] = scale * (vol_sample(V, a[0], a[1], a[2]) - vol_sample(V, b[0], b[1], b[2]));
+    }
 }
 
 hipError_t launch_volume_evaluate(const VolumeParams& V, const float* pos, size_t n, float* out, hipStream_t s);

@@ -852,7 +852,8 @@ struct ImageEvaluatorSimple {
         if (vol)
             check(fvsrn_render(scene, vol->currentNetwork()->h, width, height, 0, height, out.data_ptr<float>(), nullptr, currentStream()));
         else
-            check(fvsrn_render_volume(scene, grid->handle(), grid->sourceMode(), grid->interpolation_, grid->newBehavior ? 1 : 0, width, height,
+            check(fvsrn_render_volume(scene, grid->handle(), grid->sourceMode(), grid->interpolation_, grid->newBehavior ? 1 : 0,
+                                      selectedChannel == ChannelNormal ? 1 : 0 /* image_evaluator_simple.cpp:249-252 */, width, height,
                                       out.data_ptr<float>(), nullptr, currentStream()));
         lastRender = out;
         exposureStale = true;

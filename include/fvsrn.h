@@ -284,9 +284,11 @@ int fvsrn_volume_info(fvsrn_volume* volume, int resolution[3], float box_min[3],
 /* IVolumeInterpolation::evaluate for a grid volume: world positions [n][3] -> values [n] (device pointers) */
 int fvsrn_volume_evaluate_points(fvsrn_volume* volume, int source, int interpolation, int grid_resolution_new_behavior,
                                  const float* d_positions, size_t n, float* d_out, void* stream);
-/* fvsrn_render with a grid volume instead of a network: same scene, same (8,H,W) output, same counters */
+/* fvsrn_render with a grid volume instead of a network: same scene, same (8,H,W) output, same counters.  provide_normals:
+ * central-difference gradients one voxel to either side (evalNormalImpl, renderer_volume_grid.cuh:234-283) for the normal
+ * channels; implied by a shading BRDF (brdf_enable_phong / _magnitude_scaling).  fvsrn_scene_desc::gradient_mode is ignored. */
 int fvsrn_render_volume(fvsrn_scene* scene, fvsrn_volume* volume, int source, int interpolation, int grid_resolution_new_behavior,
-                        int width, int height, float* d_out8, unsigned long long* d_stats, void* stream);
+                        int provide_normals, int width, int height, float* d_out8, unsigned long long* d_stats, void* stream);
 
 /* Kernel name + resources of the variant fvsrn_render / fvsrn_evaluate_points would launch for
  * this network (for profiles and bench): writes a 0-terminated string. */

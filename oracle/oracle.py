@@ -66,7 +66,7 @@ VOLUME_SOURCE_TEXTURE, VOLUME_SOURCE_TENSOR = range(2)
 
 class _OracleVolume(C.Structure):
     _fields_ = [("data", _FP), ("res", C.c_int * 3), ("boxMin", C.c_float * 3), ("boxSize", C.c_float * 3),
-                ("interpolation", C.c_int), ("source", C.c_int), ("newBehavior", C.c_int)]
+                ("interpolation", C.c_int), ("source", C.c_int), ("newBehavior", C.c_int), ("provideNormals", C.c_int)]
 
 
 def lib() -> C.CDLL:
@@ -241,7 +241,7 @@ class OracleVolume:
     normalised floats like the reference's textures."""
 
     def __init__(self, data_xyz: np.ndarray, box_min, box_size, interpolation=VOLUME_TRILINEAR, source=VOLUME_SOURCE_TEXTURE,
-                 new_behavior=False):
+                 new_behavior=False, provide_normals=False):
         a = np.asarray(data_xyz)
         if a.dtype == np.uint8:
             a = a.astype(np.float32) / np.float32(255.0)
@@ -254,6 +254,7 @@ class OracleVolume:
         v.boxMin[:] = [float(x) for x in box_min]
         v.boxSize[:] = [float(x) for x in box_size]
         v.interpolation, v.source, v.newBehavior = int(interpolation), int(source), int(new_behavior)
+        v.provideNormals = int(provide_normals)
         self._v = v
 
     def evaluate(self, positions: np.ndarray) -> np.ndarray:

@@ -727,15 +727,34 @@ static float vol_cubic(const OracleVolume* v, float x, float y, float z) {
 }
 
 /* eval, :193-232 */
-static float vol_eval(const OracleVolume* v, const float w[3]) {
-    float p[3];
+static void vol_to_object(const OracleVolume* v, const float w[3], float p[3]) {
     for (int d = 0; d < 3; ++d) {
         const float scale = (float)(v->newBehavior ? v->res[d] : v->res[d] - 1);
         p[d] = (w[d] - v->boxMin[d]) / v->boxSize[d] * scale;
     }
-    if (v->interpolation == 0) return vol_fetch(v, (int)roundf(p[0]), (int)roundf(p[1]), (int)roundf(p[2])); /* :88-101,189 */
-    if (v->interpolation == 1) return vol_linear(v, p[0], p[1], p[2]);
-    return vol_cubic(v, p[0], p[1], p[2]);
+}
+static float vol_sample(const OracleVolume* v, float x, float y, float z) {
+    if (v->interpolation == 0) return vol_fetch(v, (int)roundf(x), (int)roundf(y), (int)roundf(z)); /* :88-101,189 */
+    if (v->interpolation == 1) return vol_linear(v, x, y, z);
+    return vol_cubic(v, x, y, z);
+}
+static float vol_eval(const OracleVolume* v, const float w[3]) {
+    float p[3];
+    vol_to_object(v, w, p);
+    return vol_sample(v, p[0], p[1], p[2]);
+}
+/* evalNormalImpl, :234-283: normalStep = 1 voxel, normalScale = 0.5 / voxelSize (volume_interpolation_grid.cpp:1097-1104) */
+static void vol_normal(const OracleVolume* v, const float w[3], float n[3]) {
+    float p[3];
+    vol_to_object(v, w, p);
+    for (int d = 0; d < 3; ++d) {
+        const float voxel = v->boxSize[d] / (float)(v->newBehavior ? v->res[d] : v->res[d] - 1);
+        const float scale = 0.5f / voxel;
+        float a[3] = {p[0], p[1], p[2]}, b[3] = {p[0], p[1], p[2]};
+        a[d] += 1.f;
+        b[d] -= 1.f;
+        n[d] = scale * (vol_sample(v, a[0], a[1], a[2]) - vol_sample(v, b[0], b[1], b[2]));
+    }
 }
 
 void oracle_volume_eval_points(const OracleVolume* v, const float* pos, size_t count, float* out) {
@@ -766,7 +785,9 @@ static void render_pixel_volume(const OracleVolume* v, const OracleScene* s, int
     tmin = fmaxf(tmin, 0.f);
     const float alphaEarlyOut = 1.0f - 1e-5f;
     const float divRange = 1.0f / (s->densityMax - s->densityMin);
-    float col[4] = {0, 0, 0, 0}, depth = 0;
+    float col[4] = {0, 0, 0, 0}, nacc[3] = {0, 0, 0}, depth = 0;
+    float previousDensity = -1.f;
+    const int normals = v->provideNormals || s->brdfPhong || s->brdfMagnitudeScaling;
     unsigned long long cnt = 0;
     for (int i = 0;; ++i) {
         const float t = tmin + (float)i * s->stepsize;
@@ -775,18 +796,49 @@ static void render_pixel_volume(const OracleVolume* v, const OracleScene* s, int
         ++cnt;
         const float pos[3] = {eye[0] + dir[0] * t, eye[1] + dir[1] * t, eye[2] + dir[2] * t};
         const float value = vol_eval(v, pos);
-        float c[4] = {0, 0, 0, 0};
-        if (value >= s->densityMin) tf_eval(s, (value - s->densityMin) * divRange, c);
+        const float density2 = (value - s->densityMin) * divRange;
+        float c[4] = {0, 0, 0, 0}, g[3] = {0, 0, 0};
+        if (value >= s->densityMin) {
+            if (normals) vol_normal(v, pos, g);
+            if (s->tfPreintegration) tf_eval_preintegrated(s, density2, previousDensity, c);
+            else tf_eval(s, density2, c);
+        }
+        previousDensity = density2;
+        if (c[3] > 0 && (s->brdfMagnitudeScaling || s->brdfPhong)) { /* BRDFLambert::eval, as in render_pixel */
+            const float g2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+            if (s->brdfMagnitudeScaling) c[3] *= 1.0f - expf(-s->brdfMagScale * g2);
+            if (s->brdfPhong) {
+                const float gradientNorm = 1.0f / sqrtf(g2);
+                float nn[3] = {g[0], g[1], g[2]};
+                if (g2 >= 1e-8f) { nn[0] *= gradientNorm; nn[1] *= gradientNorm; nn[2] *= gradientNorm; }
+                float l[3];
+                for (int k = 0; k < 3; ++k) l[k] = s->brdfLightType == 1 ? -s->brdfLight[k] : s->brdfLight[k] - pos[k];
+                const float ill = 1.0f / sqrtf(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+                l[0] *= ill; l[1] *= ill; l[2] *= ill;
+                const float lo = s->brdfMagCenter - s->brdfMagRadius, hi = s->brdfMagCenter + s->brdfMagRadius;
+                const float yy = clamp01((gradientNorm - lo) / (hi - lo));
+                const float phongStrength = yy * yy * (3.0f - 2.0f * yy);
+                const float ambientStrength = 1.0f + phongStrength * (s->brdfAmbient - 1.0f);
+                const float nl = nn[0] * l[0] + nn[1] * l[1] + nn[2] * l[2];
+                const float r[3] = {l[0] - 2 * nn[0] * nl, l[1] - 2 * nn[1] * nl, l[2] - 2 * nn[2] * nl};
+                const float e = (float)s->brdfSpecularExponent;
+                const float spec = (e + 2.0f) * 0.159155f * powf(fmaxf(0.f, dir[0] * r[0] + dir[1] * r[1] + dir[2] * r[2]), e);
+                for (int k = 0; k < 3; ++k)
+                    c[k] = ambientStrength * c[k] + (1 - ambientStrength) * (fabsf(nl) * c[k] + s->brdfSpecular * spec);
+            }
+        }
         if (c[3] > 0) {
+            const float l2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+            if (l2 >= 1e-8f) { const float k = 1.0f / sqrtf(l2); g[0] *= k; g[1] *= k; g[2] *= k; }
             const float a = s->blendMode == ORACLE_BLEND_BEER_LAMBERT ? 1.0f - expf(-c[3]) : fminf(1.0f, c[3]);
             const float w = (1 - col[3]) * a;
-            for (int k = 0; k < 3; ++k) col[k] += w * c[k];
+            for (int k = 0; k < 3; ++k) { col[k] += w * c[k]; nacc[k] += w * g[k]; }
             depth += w * t;
             col[3] += w;
         }
     }
     px8[0] = col[0]; px8[1] = col[1]; px8[2] = col[2]; px8[3] = col[3];
-    px8[4] = px8[5] = px8[6] = 0.f;
+    for (int k = 0; k < 3; ++k) px8[4 + k] = nacc[k] * col[3];
     px8[7] = depth * col[3] / col[3];
     *samples = cnt;
 }

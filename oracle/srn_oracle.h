@@ -85,6 +85,7 @@ typedef struct {
     int interpolation; /* 0 nearest, 1 trilinear, 2 tricubic (VOLUME_INTERPOLATION_GRID__INTERPOLATION) */
     int source;        /* 0: CUDA texture addressing (VolumeSource::VOLUME), 1: tensor accessor (VolumeSource::TORCH_TENSOR) */
     int newBehavior;   /* !VOLUME_INTERPOLATION_GRID__GRID_RESOLUTION_OLD_BEHAVIOR */
+    int provideNormals; /* VOLUME_INTERPOLATION_GRID__REQUIRES_NORMAL (shading BRDF, normal channel) */
 } OracleVolume;
 void oracle_volume_eval_points(const OracleVolume* v, const float* worldPos, size_t count, float* out);
 int oracle_render_volume(const OracleVolume* v, const OracleScene* s, int W, int H, float* out8, unsigned long long* evaluatedSamples);

@@ -183,9 +183,38 @@ def test_render_volume_matches_restatement(case):
     assert abs(int(st[0]) - count) <= max(8, count // 10000)
 
 
+PHONG = dict(enable_phong=True, ambient=0.2, specular=0.4, magnitude_center=0.6, magnitude_radius=0.5, specular_exponent=8,
+             light_type=1, light=(0.3, 0.5, -1.0), enable_magnitude_scaling=True, magnitude_scaling=3.0)
+
+
 @pytest.mark.gpu
-def test_render_volume_rejects_shading():
+@pytest.mark.parametrize("case", [
+    dict(brdf=None, normals=True, preint=0),      # normal channel only (ChannelNormal)
+    dict(brdf=PHONG, normals=False, preint=0),    # Phong + magnitude scaling from the grid's central-difference gradients
+    # pre-integrated Texture TF, 2D table (looks at the previous sample of the ray; the 1D mode switches formulas at
+    # |d - d_prev| = 1e-3, where one ulp of density flips isolated pixels by a few percent)
+    dict(brdf=None, normals=False, preint=2),
+])
+def test_render_volume_normals_shading_preintegration(case):
+    """evalNormalImpl (renderer_volume_grid.cuh:234-283) feeding BRDFLambert and the normal channels; pre-integrated TFs."""
+    import torch
     from fvsrn_amd import capi
-    vol = capi.Volume.from_array(make_volume())
-    with pytest.raises(capi.FvsrnError, match="normals"):
-        vol.render(capi.Scene(**scene_kwargs(gradient_mode=1, finite_differences_stepsize=0.01)), 16, 16)
+    data = make_volume(shape=(24, 20, 16))
+    kw = scene_kwargs(brdf=case["brdf"])
+    if case["preint"]:
+        rng = np.random.RandomState(5)
+        tab = rng.uniform(0.0, 1.0, (64, 4)).astype(np.float32)
+        tab[:, 3] *= 40.0
+        kw.update(tf_kind=oracle.TF_TEXTURE, tf_table=tab, tf_preintegration=case["preint"])
+    W, H = 64, 48
+    ov = oracle.OracleVolume(data, BOX_MIN, BOX_SIZE, oracle.VOLUME_TRILINEAR, oracle.VOLUME_SOURCE_TENSOR, provide_normals=case["normals"])
+    ref, _ = ov.render(oracle.OracleScene(**kw), W, H)
+    vol = capi.Volume.from_array(data, BOX_MIN, BOX_SIZE)
+    img = vol.render(capi.Scene(**kw), W, H, oracle.VOLUME_TRILINEAR, oracle.VOLUME_SOURCE_TENSOR, provide_normals=case["normals"])[0].cpu().numpy()
+    assert ref[3].max() > 0.5
+    # Phong: rsqrt / powf / exp of the device vs libm on gradients of ~10/unit: looser, like the shaded network renders
+    assert np.abs(img[:4] - ref[:4]).max() < (5e-3 if case["brdf"] else 5e-4)
+    if case["normals"] or case["brdf"]:
+        assert np.abs(ref[4:7]).max() > 0.1 and np.abs(img[4:7] - ref[4:7]).max() < (5e-3 if case["brdf"] else 2e-3)
+    else:
+        assert np.abs(img[4:7]).max() == 0.0
