@@ -115,10 +115,13 @@ struct fvsrn_network {
 
     // resident workgroups per CU of the render kernel for (blockDim, dynamic LDS); cached
     unsigned long long occKey = 0;
+    const void* occFn = nullptr;
     int occBlocks = 0;
     // smallFn: render_small_kernel variant to use instead of render_kernel (nullptr = none)
     int renderBlocksPerCU(unsigned blockDim, size_t ldsBytes, bool shaded, const void* smallFn = nullptr) {
         const unsigned long long k = (static_cast<unsigned long long>(ldsBytes) << 18) | (blockDim << 2) | (smallFn ? 2u : 0u) | (shaded ? 1u : 0u);
+        if (smallFn != occFn) occKey = 0;  // another render_small_kernel variant
+        occFn = smallFn;
         if (k != occKey) {
             int n = 0;
             const void* fn = smallFn ? smallFn : (shaded ? kinfo.renderShadedFn : kinfoScaled.renderFn);
@@ -618,9 +621,9 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
             const char* e = std::getenv("FVSRN_SMALL_KERNEL");
             const bool scalarNet = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
             if (!(e && e[0] == '0') && k.CD == 2 && k.grid == 0 && !P.noFourier && !P.fourierNeedsFract && scalarNet &&
-                render_small_fn(k.act, k.dir, P.numLayers))
+                render_small_fn(k.act, k.dir, P.numLayers, false))
                 name = "render_small_kernel<act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "," + std::to_string(P.numLayers) +
-                       "> (Identity/Texture TF, unshaded; else " + name + ")";
+                       "> (unshaded; else " + name + ")";
         }
         std::strncpy(buf, name.c_str(), cap - 1);
         buf[cap - 1] = 0;
@@ -835,15 +838,16 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const bool persistent = pers ? pers[0] != '0' : stripeWorld == 1;
             const int wpb = wavesPerBlockFor(lds);
             // Small networks in registers (render_small_kernel, kernels.hpp): 32-wide Fourier-only scalar network with at most
-            // three C->C layers, phases inside the v_cos domain, Identity or Texture TF, no shading.  FVSRN_SMALL_KERNEL=0: off.
+            // three C->C layers, phases inside the v_cos domain, a transfer function, no shading.  FVSRN_SMALL_KERNEL=0: off.
             const void* smallFn = nullptr;
+            const bool loopTf = d.tf_kind == FVSRN_TF_PIECEWISE || d.tf_kind == FVSRN_TF_GAUSSIAN;
             {
                 const char* e = std::getenv("FVSRN_SMALL_KERNEL");
                 const VariantKey& k = net->keyScaled;
                 const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
                 if (!(e && e[0] == '0') && !a.shaded && k.CD == 2 && k.grid == 0 && !a.P.noFourier && !a.P.fourierNeedsFract &&
-                    a.P.numLayers >= 1 && a.P.numLayers <= 3 && scalarNet && (d.tf_kind == FVSRN_TF_IDENTITY || d.tf_kind == FVSRN_TF_TEXTURE))
-                    smallFn = render_small_fn(k.act, k.dir, a.P.numLayers);
+                    a.P.numLayers >= 1 && a.P.numLayers <= 3 && scalarNet && d.tf_kind != FVSRN_TF_NONE)
+                    smallFn = render_small_fn(k.act, k.dir, a.P.numLayers, loopTf);
             }
             const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded, smallFn);
             const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));  // workgroups the chip holds at once
@@ -912,7 +916,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const char* ord = std::getenv("FVSRN_TILE_ORDER");  // "0" / "1" force, unset = heuristic
             const bool useOrder = ord ? ord[0] == '1' : (S.tileCounter == nullptr && (wpb > 1 || net->key.grid != 0));
             S.tileOrder = useOrder ? scene->tileOrder(S, P_boxCenter(a.P), tilesX, tilesY, s) : nullptr;
-            hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, a, grid, unsigned(64 * wpb), lds, s)
+            hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, loopTf, a, grid, unsigned(64 * wpb), lds, s)
                                    : launch_render(a.shaded ? net->key : net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
             if (e == hipSuccess && K > 1) e = launch_composite(S.partial, d_out8, K, plane, S, s);
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during rendering! ") + hipGetErrorString(e));

@@ -201,7 +201,9 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // per step: ~1000 cycles of latency for a lone wave, r01 tools/section_profile.py, more than the network itself).
 // TAIL_SCALAR_TABLE is the common case -- a scalar density network (density | density:direct) with an Identity or
 // Texture transfer function -- as straight-line predicated code with two wave-uniform branches (sigmoid, texture).
-enum { TAIL_GENERIC = 0, TAIL_SCALAR_TABLE = 1 };
+// TAIL_SCALAR_LOOP: the same frame around Piecewise / Gaussian TFs, which loop over their control points (a separate
+// instantiation: inside TAIL_SCALAR_TABLE the extra code cost the Identity path 4 %, r01).
+enum { TAIL_GENERIC = 0, TAIL_SCALAR_TABLE = 1, TAIL_SCALAR_LOOP = 2 };
 
 // NLC > 0 (render_small_kernel): the network stays in registers (ResidentNet, srn_device.hpp); CD = 2, GRID = 0, rotation path
 template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, bool SHADED, int TAIL = TAIL_GENERIC, int NLC = 0>
@@ -319,7 +321,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
         float t;
         bool inRange, valid;
         unsigned long long validMask;
-        if constexpr (TAIL == TAIL_SCALAR_TABLE) {  // straight-line: i0 = 0, i1 = INT_MAX without segments
+        if constexpr (TAIL != TAIL_GENERIC) {  // straight-line: i0 = 0, i1 = INT_MAX without segments
             const int gi = i0 + i;
             t = tmin + float(gi) * S.stepsize;
             inRange = (t <= tmax) & (gi < i1);
@@ -365,7 +367,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
         cr += o[0] * 1e-30f;
         continue;
 #endif
-        if constexpr (TAIL == TAIL_SCALAR_TABLE) {
+        if constexpr (TAIL != TAIL_GENERIC) {
             // stepping_dvr.cuh:110-150 for a scalar density network, Identity | Texture TF, no normals: predicated, no
             // exec-mask regions.  Same operations in the same order as the generic tail below.
             float value = o[0];
@@ -375,7 +377,10 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             }
             const float density = fminf(fmaxf((value - S.densityMin) * S.divDensityRange, 0.f), 1.f);  // tf_eval clamps
             float c0, c1, c2, c3;
-            if (textureTf) {  // wave-uniform; renderer_tf_texture.cuh:46-55
+            if constexpr (TAIL == TAIL_SCALAR_LOOP) {  // Piecewise / Gaussian: per-lane loops over the control points
+                const float4_t c = tf_eval(S, tfLds, density);
+                c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3];
+            } else if (textureTf) {  // wave-uniform; renderer_tf_texture.cuh:46-55
                 const int R = S.tfRows;
                 const float d = density * S.tfRowsF - 0.5f;
                 const float fl = floorf(d);
@@ -564,14 +569,15 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void r
     render_entry<CD, ACT, GRID, HAS_DIR, false>(P, S, out, stats);
 }
 
-// 32-wide Fourier-only scalar networks with NLC <= 3 C->C layers, Identity | Texture TF, phases inside the v_cos domain
+// 32-wide Fourier-only scalar networks with NLC <= 3 C->C layers behind a transfer function, phases inside the v_cos domain
 // (the host checks all of that, api.cpp): weights and biases in registers, 2 waves per SIMD (256 registers)
-template <int ACT, bool HAS_DIR, int NLC>
+// LOOP_TF: Piecewise / Gaussian transfer function (TAIL_SCALAR_LOOP) instead of Identity / Texture (TAIL_SCALAR_TABLE)
+template <int ACT, bool HAS_DIR, int NLC, bool LOOP_TF>
 __global__ __launch_bounds__(kBlockThreads, 2) void render_small_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                       unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* tfLds = render_prologue(P, S, lds);
-    render_body<2, ACT, 0, HAS_DIR, FM_COS, false, TAIL_SCALAR_TABLE, NLC>(P, S, lds, tfLds, out, stats);
+    render_body<2, ACT, 0, HAS_DIR, FM_COS, false, LOOP_TF ? TAIL_SCALAR_LOOP : TAIL_SCALAR_TABLE, NLC>(P, S, lds, tfLds, out, stats);
 }
 
 // finite-difference normals / shading BRDF (SceneParams::gradientMode, brdf*): 7 network evaluations per sample
