@@ -620,8 +620,9 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
             const VariantKey& k = net->keyScaled;
             const char* e = std::getenv("FVSRN_SMALL_KERNEL");
             const bool scalarNet = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
-            if (!(e && e[0] == '0') && k.CD == 2 && k.grid == 0 && !P.noFourier && !P.fourierNeedsFract && scalarNet &&
-                render_small_fn(k.act, k.dir, P.numLayers, false))
+            const bool colourNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
+            if (!(e && e[0] == '0') && k.CD == 2 && k.grid == 0 && !P.noFourier && !P.fourierNeedsFract && (scalarNet || colourNet) &&
+                render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1))
                 name = "render_small_kernel<act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "," + std::to_string(P.numLayers) +
                        "> (unshaded; else " + name + ")";
         }
@@ -840,14 +841,14 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             // Small networks in registers (render_small_kernel, kernels.hpp): 32-wide Fourier-only scalar network with at most
             // three C->C layers, phases inside the v_cos domain, a transfer function, no shading.  FVSRN_SMALL_KERNEL=0: off.
             const void* smallFn = nullptr;
-            const bool loopTf = d.tf_kind == FVSRN_TF_PIECEWISE || d.tf_kind == FVSRN_TF_GAUSSIAN;
+            const int smallTail = rgbo ? 3 : (d.tf_kind == FVSRN_TF_PIECEWISE || d.tf_kind == FVSRN_TF_GAUSSIAN ? 2 : 1);  // kernels.hpp TAIL_*
             {
                 const char* e = std::getenv("FVSRN_SMALL_KERNEL");
                 const VariantKey& k = net->keyScaled;
                 const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
                 if (!(e && e[0] == '0') && !a.shaded && k.CD == 2 && k.grid == 0 && !a.P.noFourier && !a.P.fourierNeedsFract &&
-                    a.P.numLayers >= 1 && a.P.numLayers <= 3 && scalarNet && d.tf_kind != FVSRN_TF_NONE)
-                    smallFn = render_small_fn(k.act, k.dir, a.P.numLayers, loopTf);
+                    a.P.numLayers >= 1 && a.P.numLayers <= 3 && (rgbo || (scalarNet && d.tf_kind != FVSRN_TF_NONE)))
+                    smallFn = render_small_fn(k.act, k.dir, a.P.numLayers, smallTail);
             }
             const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded, smallFn);
             const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));  // workgroups the chip holds at once
@@ -916,7 +917,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const char* ord = std::getenv("FVSRN_TILE_ORDER");  // "0" / "1" force, unset = heuristic
             const bool useOrder = ord ? ord[0] == '1' : (S.tileCounter == nullptr && (wpb > 1 || net->key.grid != 0));
             S.tileOrder = useOrder ? scene->tileOrder(S, P_boxCenter(a.P), tilesX, tilesY, s) : nullptr;
-            hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, loopTf, a, grid, unsigned(64 * wpb), lds, s)
+            hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, a, grid, unsigned(64 * wpb), lds, s)
                                    : launch_render(a.shaded ? net->key : net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
             if (e == hipSuccess && K > 1) e = launch_composite(S.partial, d_out8, K, plane, S, s);
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during rendering! ") + hipGetErrorString(e));

@@ -202,8 +202,9 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // TAIL_SCALAR_TABLE is the common case -- a scalar density network (density | density:direct) with an Identity or
 // Texture transfer function -- as straight-line predicated code with two wave-uniform branches (sigmoid, texture).
 // TAIL_SCALAR_LOOP: the same frame around Piecewise / Gaussian TFs, which loop over their control points (a separate
-// instantiation: inside TAIL_SCALAR_TABLE the extra code cost the Identity path 4 %, r01).
-enum { TAIL_GENERIC = 0, TAIL_SCALAR_TABLE = 1, TAIL_SCALAR_LOOP = 2 };
+// instantiation: inside TAIL_SCALAR_TABLE the extra code cost the Identity path 4 %, r01).  TAIL_RGBO: colour networks (rgbo |
+// rgbo:direct, no transfer function) in the same frame.
+enum { TAIL_GENERIC = 0, TAIL_SCALAR_TABLE = 1, TAIL_SCALAR_LOOP = 2, TAIL_RGBO = 3 };
 
 // NLC > 0 (render_small_kernel): the network stays in registers (ResidentNet, srn_device.hpp); CD = 2, GRID = 0, rotation path
 template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, bool SHADED, int TAIL = TAIL_GENERIC, int NLC = 0>
@@ -356,7 +357,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
                 if (i == 0)
                     fourier_features<CD, HAS_DIR, FM_COS, true>(P, lds, dnx * S.stepsize, dny * S.stepsize, dnz * S.stepsize, 0.f, 0.f, 0.f, dfeat);
             }
-            if constexpr (NLC > 0) o[0] = srn_forward_rotating_resident<ACT, HAS_DIR, NLC>(P, resident, feat, dfeat);
+            if constexpr (NLC > 0) o = srn_forward_rotating_resident<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeat);
             else o = srn_forward_rotating<CD, ACT, GRID, HAS_DIR>(P, lds, feat, dfeat, px, py, pz);
         } else {
             o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz);
@@ -367,6 +368,23 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
         cr += o[0] * 1e-30f;
         continue;
 #endif
+        if constexpr (TAIL == TAIL_RGBO) {  // stepping_dvr.cuh:104-109, 138-150: the network's colour, no TF, no normals
+            float c0, c1, c2, c3;
+            if (P.outputMode == FVSRN_OUT_RGBO) {  // wave-uniform
+                asm volatile("");
+                c0 = sigmoid_f(o[0]); c1 = sigmoid_f(o[1]); c2 = sigmoid_f(o[2]); c3 = softplus_f(o[3]);
+            } else {
+                c0 = fminf(fmaxf(o[0], 0.f), 1.f); c1 = fminf(fmaxf(o[1], 0.f), 1.f); c2 = fminf(fmaxf(o[2], 0.f), 1.f); c3 = fmaxf(o[3], 0.f);
+            }
+            c3 *= S.stepsize;
+            const float aBeer = 1.f - __expf(-c3), aAlpha = fminf(1.f, c3);
+            const float a = beerLambert ? aBeer : aAlpha;
+            const float w = (valid & (c3 > 0.f)) ? (1.f - ca) * a : 0.f;
+            cr += w * c0; cg += w * c1; cb += w * c2;
+            depth += w * t;
+            ca += w;
+            continue;
+        }
         if constexpr (TAIL != TAIL_GENERIC) {
             // stepping_dvr.cuh:110-150 for a scalar density network, Identity | Texture TF, no normals: predicated, no
             // exec-mask regions.  Same operations in the same order as the generic tail below.
@@ -571,13 +589,13 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void r
 
 // 32-wide Fourier-only scalar networks with NLC <= 3 C->C layers behind a transfer function, phases inside the v_cos domain
 // (the host checks all of that, api.cpp): weights and biases in registers, 2 waves per SIMD (256 registers)
-// LOOP_TF: Piecewise / Gaussian transfer function (TAIL_SCALAR_LOOP) instead of Identity / Texture (TAIL_SCALAR_TABLE)
-template <int ACT, bool HAS_DIR, int NLC, bool LOOP_TF>
+// TAILK: TAIL_SCALAR_TABLE (Identity / Texture TF), TAIL_SCALAR_LOOP (Piecewise / Gaussian TF) or TAIL_RGBO (colour network)
+template <int ACT, bool HAS_DIR, int NLC, int TAILK>
 __global__ __launch_bounds__(kBlockThreads, 2) void render_small_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                       unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* tfLds = render_prologue(P, S, lds);
-    render_body<2, ACT, 0, HAS_DIR, FM_COS, false, LOOP_TF ? TAIL_SCALAR_LOOP : TAIL_SCALAR_TABLE, NLC>(P, S, lds, tfLds, out, stats);
+    render_body<2, ACT, 0, HAS_DIR, FM_COS, false, TAILK, NLC>(P, S, lds, tfLds, out, stats);
 }
 
 // finite-difference normals / shading BRDF (SceneParams::gradientMode, brdf*): 7 network evaluations per sample

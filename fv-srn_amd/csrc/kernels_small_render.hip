@@ -7,19 +7,20 @@ namespace fvsrn {
 #define FVSRN_SMALL_VARIANTS(X) \
     X(ACT_RELU01, false) X(ACT_RELU01, true) X(ACT_SINE, false) X(ACT_SINE, true) \
     X(ACT_SNAKE, false) X(ACT_SNAKE, true) X(ACT_SNAKEALT, false) X(ACT_SNAKEALT, true)
-#define FVSRN_SMALL_LAYERS(A, D) Y(A, D, 1, false) Y(A, D, 2, false) Y(A, D, 3, false) Y(A, D, 1, true) Y(A, D, 2, true) Y(A, D, 3, true)
+#define FVSRN_SMALL_LAYERS(A, D) \
+    Y(A, D, 1, 1) Y(A, D, 2, 1) Y(A, D, 3, 1) Y(A, D, 1, 2) Y(A, D, 2, 2) Y(A, D, 3, 2) Y(A, D, 1, 3) Y(A, D, 2, 3) Y(A, D, 3, 3)
 
-const void* render_small_fn(int act, bool dir, int numLayers, bool loopTf) {
+const void* render_small_fn(int act, bool dir, int numLayers, int tail) {
 #define Y(A, D, N, L) \
-    if (act == A && dir == D && numLayers == N && loopTf == L) return reinterpret_cast<const void*>(&render_small_kernel<A, D, N, L>);
+    if (act == A && dir == D && numLayers == N && tail == L) return reinterpret_cast<const void*>(&render_small_kernel<A, D, N, L>);
     FVSRN_SMALL_VARIANTS(FVSRN_SMALL_LAYERS)
 #undef Y
     return nullptr;
 }
 
-hipError_t launch_render_small(int act, bool dir, int numLayers, bool loopTf, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s) {
+hipError_t launch_render_small(int act, bool dir, int numLayers, int tail, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s) {
 #define Y(A, D, N, L)                                                                                         \
-    if (act == A && dir == D && numLayers == N && loopTf == L) {                                              \
+    if (act == A && dir == D && numLayers == N && tail == L) {                                                \
         hipLaunchKernelGGL((render_small_kernel<A, D, N, L>), dim3(gridDim), dim3(blockDim), ldsBytes, s, a.P, a.S, a.out, a.stats); \
         return hipGetLastError();                                                                             \
     }

@@ -88,8 +88,8 @@ hipError_t launch_generate_rays(const SceneParams& S, float* rayStart, float* ra
 hipError_t launch_evaluate_tf(const SceneParams& S, const float* density, const float* previous, size_t n, float* colors, hipStream_t s);
 
 // render_small_kernel (kernels_small_render.hip): nullptr / hipErrorInvalidDeviceFunction if that variant is not compiled in
-const void* render_small_fn(int act, bool dir, int numLayers, bool loopTf);  // loopTf: Piecewise / Gaussian TF
-hipError_t launch_render_small(int act, bool dir, int numLayers, bool loopTf, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
+const void* render_small_fn(int act, bool dir, int numLayers, int tail);  // tail: 1 Identity/Texture TF, 2 Piecewise/Gaussian TF, 3 colour network
+hipError_t launch_render_small(int act, bool dir, int numLayers, int tail, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 
 bool kernel_info(const VariantKey& k, KernelInfo* info);
 hipError_t launch_eval(const VariantKey& k, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);

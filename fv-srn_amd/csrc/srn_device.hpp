@@ -878,9 +878,10 @@ __device__ __forceinline__ void load_resident(const NetParams& P, const char* ld
     R.bLast = *reinterpret_cast<const float4_t*>(lds + P.offBias + NLC * 128);
 }
 
-// srn_layers_pipelined for CD = 2, GRID = 0 on a ResidentNet; returns output 0 of this lane's sample (scalar networks)
-template <int ACT, int NLC, int NFILL, class Pre, class Fill>
-__device__ __forceinline__ float srn_layers_resident(const NetParams& P, const ResidentNet<NLC>& R, half8_t (&xb)[2][2], Pre&& pre, Fill&& fill) {
+// srn_layers_pipelined for CD = 2, GRID = 0 on a ResidentNet; returns the raw outputs of this lane's sample (ALL4: all four,
+// colour networks; otherwise only output 0)
+template <int ACT, int NLC, int NFILL, bool ALL4, class Pre, class Fill>
+__device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, const ResidentNet<NLC>& R, half8_t (&xb)[2][2], Pre&& pre, Fill&& fill) {
     const float actA = P.actA, actB = P.actB;
     constexpr int NF0 = NFILL / 2;
     floatx16 acc[2];
@@ -914,16 +915,19 @@ __device__ __forceinline__ float srn_layers_resident(const NetParams& P, const R
                                [&](int j) { fill(NF0 + j); });
     __builtin_amdgcn_s_setprio(3);
     __builtin_amdgcn_sched_barrier(0);
-    return (lane_id() >> 5) ? o1[0] : o0[0];
+    const bool h = (lane_id() >> 5) != 0;
+    float4_t out = {h ? o1[0] : o0[0], 0.f, 0.f, 0.f};
+    if constexpr (ALL4) { out[1] = h ? o1[1] : o0[1]; out[2] = h ? o1[2] : o0[2]; out[3] = h ? o1[3] : o0[3]; }
+    return out;
 }
 
 // srn_forward_rotating on a ResidentNet
-template <int ACT, bool HAS_DIR, int NLC>
-__device__ __forceinline__ float srn_forward_rotating_resident(const NetParams& P, const ResidentNet<NLC>& R, floatx16 (&feat)[2][1],
+template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
+__device__ __forceinline__ float4_t srn_forward_rotating_resident(const NetParams& P, const ResidentNet<NLC>& R, floatx16 (&feat)[2][1],
                                                                const floatx16 (&dfeat)[2][1]) {
     constexpr int NP = 16, NFILL = NP / 2;
     half8_t xb[2][2];
-    return srn_layers_resident<ACT, NLC, NFILL>(
+    return srn_layers_resident<ACT, NLC, NFILL, ALL4>(
         P, R, xb,
         [&]() {
             feature_fragments<2>(feat, xb);
