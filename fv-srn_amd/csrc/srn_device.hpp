@@ -925,7 +925,12 @@ __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, cons
 template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
 __device__ __forceinline__ float4_t srn_forward_rotating_resident(const NetParams& P, const ResidentNet<NLC>& R, floatx16 (&feat)[2][1],
                                                                const floatx16 (&dfeat)[2][1]) {
-    constexpr int NP = 16, NFILL = NP / 2;
+#ifndef FVSRN_SMALL_NFILL
+#define FVSRN_SMALL_NFILL 0
+#endif
+    // rotation pieces behind MFMAs; the rest runs in pre().  r01: 0 / 4 / 8 / 12 / 16 pieces behind MFMAs -> 157.4 / 155.1 / 154.1 /
+    // 154.4 / 155.1 Gsamples/s: the whole rotation belongs to the high-priority vector phase of the step
+    constexpr int NP = 16, NFILL = FVSRN_SMALL_NFILL;
     half8_t xb[2][2];
     return srn_layers_resident<ACT, NLC, NFILL, ALL4>(
         P, R, xb,
