@@ -215,6 +215,62 @@ def cpu_baseline(util, cfg, activation):
                       % (W, H, steps, r["samples"], r["seconds"])}
 
 
+def grid_volume_bench(res, size, interpolation, frames, with_cpu):
+    """BASELINE.json configs[0] on the GPU: DVR of a dense grid volume (VolumeInterpolationGrid) next to the C restatement on the
+    host cores (the cpu_baseline leg).  The reference's example-volume.cvol is not in the repository snapshot
+    (.MISSING_LARGE_BLOBS): a synthetic res^3 float volume stands in.  Prints one JSON line."""
+    import fvsrn_amd  # noqa: F401
+    from fvsrn_amd import capi
+    n = res
+    ax = np.linspace(-1, 1, n, dtype=np.float32)
+    x, y, z = np.meshgrid(ax, ax, ax, indexing="ij")
+    data = np.clip(np.exp(-3 * (x * x + y * y + z * z)) + 0.1 * np.sin(9 * x) * np.cos(7 * y) * np.sin(5 * z), 0, 1).astype(np.float32)
+    vol = capi.Volume.from_array(data, (-0.5, -0.5, -0.5), (1, 1, 1))
+    stepsize = 1.0 / n
+
+    def kwargs(yaw):
+        eye, right, up = capi.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, yaw, 1.6)
+        return dict(eye=eye, right=right, up=up, fov_y_radians=float(np.deg2rad(45.0)), stepsize=stepsize, early_out=False,
+                    tf_kind=capi.TF_IDENTITY, tf_scale_absorption=10.0, tf_scale_emission=1.0)
+
+    scene = capi.Scene(**kwargs(0.0))
+    out = torch.zeros((1, 8, size, size), dtype=torch.float32, device="cuda")
+    stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+    t_end = time.perf_counter() + 0.25  # clock spin-up, see timed_run
+    while time.perf_counter() < t_end:
+        vol.render(scene, size, size, interpolation, out=out)
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(frames):
+        scene.update(**kwargs(2 * np.pi * i / 64))
+        vol.render(scene, size, size, interpolation, out=out, stats=stats)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / frames
+    samples = int(stats.cpu()[0]) / frames
+    taps = {0: 1, 1: 8, 2: 64}[interpolation]
+    res_ = {"workload": "grid_dvr: %d^3 fp32 volume, %dx%d, step 1/%d, interpolation %d, Identity TF, early-out off" % (n, size, size, n, interpolation),
+            "ms_per_frame": ms, "frames_per_s": 1e3 / ms, "samples_per_s": samples / (ms * 1e-3), "samples_per_frame": samples,
+            "voxel_reads_per_s": taps * samples / (ms * 1e-3), "voxel_read_GBps_algorithmic": 4 * taps * samples / (ms * 1e-3) / 1e9,
+            "volume_MB": data.nbytes / 1e6}
+    if with_cpu:
+        from oracle import oracle
+        ov = oracle.OracleVolume(data, (-0.5, -0.5, -0.5), (1, 1, 1), interpolation, oracle.VOLUME_SOURCE_TEXTURE)
+        kw = kwargs(0.0)
+        kw.pop("tf_kind")
+        sc = oracle.OracleScene(tf_kind=oracle.TF_IDENTITY, **kw)
+        t0 = time.perf_counter()
+        ref, cnt = ov.render(sc, size, size)
+        dt = time.perf_counter() - t0
+        res_["cpu_baseline"] = {"value": cnt / dt, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+                                "sample": "oracle_render_volume (C restatement, OpenMP) of the same frame, %.2f s" % dt}
+        scene.update(**kwargs(0.0))
+        img = vol.render(scene, size, size, interpolation)[0].cpu().numpy()
+        res_["max_abs_diff_vs_cpu"] = float(np.abs(img[:4] - ref[:4]).max())
+    print(json.dumps(res_))
+
+
 def pmc_traffic(workload):
     """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC summary of this workload
     (profiles/r*/<workload>_*_pmc.csv, written by tools/pmc_profile.sh: separate --pmc passes; WRITE_SIZE is exact,
@@ -246,7 +302,16 @@ def main():
     ap.add_argument("--early-out", action="store_true", help="as-shipped DVR with alpha early-out")
     ap.add_argument("--no-twin", action="store_true", help="skip the second-activation twin run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grid-volume", action="store_true",
+                    help="side benchmark (not the headline metric): DVR of a dense grid volume, BASELINE.json configs[0]; one JSON line")
+    ap.add_argument("--grid-res", type=int, default=256)
+    ap.add_argument("--grid-size", type=int, default=256)
+    ap.add_argument("--grid-interpolation", type=int, default=1, help="0 nearest, 1 trilinear, 2 tricubic")
     args = ap.parse_args()
+    if args.grid_volume:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP kernels have no CPU fallback")
+        return grid_volume_bench(args.grid_res, args.grid_size, args.grid_interpolation, 64, not args.no_cpu_baseline)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
