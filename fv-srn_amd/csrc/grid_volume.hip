@@ -13,6 +13,8 @@ __global__ __launch_bounds__(256) void volume_evaluate_kernel(VolumeParams V, co
         out[i] = vol_eval(V, pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
 }
 
+// SHADE: normals from the grid, shading BRDF, pre-integrated TFs (compiled out of the plain renderer: -11 % otherwise, r01)
+template <bool SHADE>
 __global__ __launch_bounds__(256) void volume_render_kernel(VolumeParams V, SceneParams S, float* __restrict__ out,
                                                            unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) float tfLds[];
@@ -62,11 +64,11 @@ __global__ __launch_bounds__(256) void volume_render_kernel(VolumeParams V, Scen
         const float prev = previousDensity;
         previousDensity = density2;  // stepping_dvr.cuh:135
         if (value >= S.densityMin) {  // :110-135
-            float4_t color = S.tfPreintegration != FVSRN_PREINTEGRATE_NONE ? tf_eval_preintegrated(S, tfLds, fminf(fmaxf(density2, 0.f), 1.f), prev)
-                                                                         : tf_eval(S, tfLds, density2);
+            float4_t color = SHADE && S.tfPreintegration != FVSRN_PREINTEGRATE_NONE ? tf_eval_preintegrated(S, tfLds, fminf(fmaxf(density2, 0.f), 1.f), prev)
+                                                                                  : tf_eval(S, tfLds, density2);
             float g[3] = {0.f, 0.f, 0.f};
-            if (V.provideNormals) vol_normal(V, wx, wy, wz, g);  // :122-128 (requireNormal)
-            if (color[3] > 0.f && (S.brdfMagnitudeScaling | S.brdfPhong)) {  // BRDFLambert::eval, renderer_brdf_lambert.cuh:56-103
+            if (SHADE && V.provideNormals) vol_normal(V, wx, wy, wz, g);  // :122-128 (requireNormal)
+            if (SHADE && color[3] > 0.f && (S.brdfMagnitudeScaling | S.brdfPhong)) {  // BRDFLambert::eval, renderer_brdf_lambert.cuh:56-103
                 const float g2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
                 if (S.brdfMagnitudeScaling) color[3] *= 1.f - __expf(-S.brdfMagScale * g2);
                 if (S.brdfPhong) {
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void volume_render_kernel(VolumeParams V, Scen
                 cr += w * color[0]; cg += w * color[1]; cb += w * color[2];
                 depth += w * t;
                 ca += w;
-                if (V.provideNormals) {
+                if (SHADE && V.provideNormals) {
                     const float l2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
                     if (l2 >= 1e-8f) { const float il = rsqrtf(l2); g[0] *= il; g[1] *= il; g[2] *= il; }  // safeNormalize
                     nx += w * g[0]; ny += w * g[1]; nz += w * g[2];
@@ -134,7 +136,9 @@ hipError_t launch_volume_evaluate(const VolumeParams& V, const float* pos, size_
 hipError_t launch_volume_render(const VolumeParams& V, const SceneParams& S, float* out, unsigned long long* stats, size_t tfFloats,
                                 hipStream_t s) {
     const unsigned grid = unsigned(((S.width + 15) / 16) * ((S.height + 15) / 16));
-    hipLaunchKernelGGL(volume_render_kernel, dim3(grid), dim3(256), tfFloats * 4, s, V, S, out, stats);
+    const bool shade = V.provideNormals || S.brdfMagnitudeScaling || S.brdfPhong || S.tfPreintegration != FVSRN_PREINTEGRATE_NONE;
+    if (shade) hipLaunchKernelGGL(volume_render_kernel<true>, dim3(grid), dim3(256), tfFloats * 4, s, V, S, out, stats);
+    else hipLaunchKernelGGL(volume_render_kernel<false>, dim3(grid), dim3(256), tfFloats * 4, s, V, S, out, stats);
     return hipGetLastError();
 }
 
