@@ -827,8 +827,10 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
 template <int CD, int ACT, int GRID, bool HAS_DIR>
 __device__ __forceinline__ float4_t srn_forward_rotating(const NetParams& P, const char* lds, floatx16 (&feat)[2][mtiles(CD)],
                                                          const floatx16 (&dfeat)[2][mtiles(CD)], float px, float py, float pz) {
-    constexpr int NP = 16 * mtiles(CD);  // rotation pieces: half of them cover the LDS latency of the first layer's reads,
-    constexpr int NFILL = NP / 2;        // half sit behind MFMAs that have no conversion work of their own
+    // rotation pieces behind MFMAs without conversion work of their own (NFILL) vs in pre(), where they also cover the LDS
+    // latency of the first layer's reads: all of them in pre() is fastest (r01: NFILL = NP/2 -> 0: 132 -> 137 Gsamples/s)
+    constexpr int NP = 16 * mtiles(CD);
+    constexpr int NFILL = 0;
     half8_t xb[2][2 * mtiles(CD)];
     return srn_layers<CD, ACT, GRID, HAS_DIR, NFILL, false>(
         P, lds, xb, px, py, pz,
