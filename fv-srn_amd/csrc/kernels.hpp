@@ -202,7 +202,7 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // TAIL_SCALAR_TABLE is the common case -- a scalar density network (density | density:direct) with an Identity or
 // Texture transfer function -- as straight-line predicated code with two wave-uniform branches (sigmoid, texture).
 // TAIL_SCALAR_LOOP: the same frame around Piecewise / Gaussian TFs, which loop over their control points (a separate
-// instantiation: inside TAIL_SCALAR_TABLE the extra code cost the Identity path 4 %, r01).  TAIL_RGBO: colour networks (rgbo |
+// instantiation, so that the loops stay out of the Identity / Texture instruction stream).  TAIL_RGBO: colour networks (rgbo |
 // rgbo:direct, no transfer function) in the same frame.
 enum { TAIL_GENERIC = 0, TAIL_SCALAR_TABLE = 1, TAIL_SCALAR_LOOP = 2, TAIL_RGBO = 3 };
 
@@ -386,7 +386,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             continue;
         }
         if constexpr (TAIL != TAIL_GENERIC) {
-            // stepping_dvr.cuh:110-150 for a scalar density network, Identity | Texture TF, no normals: predicated, no
+            // stepping_dvr.cuh:110-150 for a scalar density network behind a transfer function, no normals: predicated, no
             // exec-mask regions.  Same operations in the same order as the generic tail below.
             float value = o[0];
             if (sigmoidNet) {  // wave-uniform; the empty asm keeps hipcc from turning the branch into a select (2 transcendentals)
