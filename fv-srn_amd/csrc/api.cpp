@@ -92,6 +92,7 @@ int actIndex(fvsrn_activation a) {
         case FVSRN_ACT_SINE: return 1;
         case FVSRN_ACT_SNAKE: return 2;
         case FVSRN_ACT_SNAKEALT: return 3;
+        case FVSRN_ACT_SIGMOID: return 5;  // ACT_SIGMOID (4 is the scaled-ReLU image)
         default: return -1;
     }
 }

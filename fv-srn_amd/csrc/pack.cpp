@@ -378,9 +378,10 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
         case FVSRN_ACT_SINE: np.actA = float(p / (2 * pi)); np.actB = 0; break;
         case FVSRN_ACT_SNAKE: np.actA = float(p / pi); np.actB = float(1.0 / (2 * p)); break;
         case FVSRN_ACT_SNAKEALT: np.actA = float(p / pi); np.actB = float(1.0 / (2 * p)); break;
+        case FVSRN_ACT_SIGMOID: np.actA = -1.4426950408889634f; np.actB = 0; break;  // exp(-x) = exp2(-log2(e) x)
         default:
             throw Unsupported(std::string("hidden activation ") + activationName(c.activation) +
-                              " is not in the compiled variant set (ReLU, Sine, Snake, SnakeAlt)");
+                              " is not in the compiled variant set (ReLU, Sine, Snake, SnakeAlt, Sigmoid)");
     }
     for (int i = 0; i < 3; ++i) {
         np.boxMin[i] = net.boxMin[i];

@@ -51,6 +51,8 @@ __device__ __forceinline__ float act_f32(float x, float a, float b) {
     } else if constexpr (ACT == ACT_SNAKE) {  // x + sin^2(p x)/p = x + (1 - cos(2 p x))/(2p), a = p/pi, b = 1/(2p)
         const float c = __builtin_amdgcn_cosf(x * a);
         return fmaf(-c, b, x + b);
+    } else if constexpr (ACT == ACT_SIGMOID) {  // 1 / (1 + exp(-x)), a = -log2(e)
+        return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * a));
     } else {  // SnakeAlt: (x + 1 - cos(2 p x)) / (2p)
         const float c = __builtin_amdgcn_cosf(x * a);
         return fmaf(x - c, b, b);
@@ -72,6 +74,9 @@ __device__ __forceinline__ float2_t act_f32x2(float2_t x, float a, float b) {
         const float2_t c = {__builtin_amdgcn_cosf(t[0]), __builtin_amdgcn_cosf(t[1])};
         const float2_t bb = {b, b};
         return __builtin_elementwise_fma(x - c, bb, bb);
+    } else if constexpr (ACT == ACT_SIGMOID) {  // renderer_activations.cuh:152-179: 1 / (1 + exp(-x)); a = -log2(e)
+        const float2_t t = x * a;
+        return float2_t{__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[0])), __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[1]))};
     } else {
         return float2_t{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
     }

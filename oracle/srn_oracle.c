@@ -103,7 +103,7 @@ static float hcosf(float a) { return rh_d(cos((double)a)); }
 static float hsinf(float a) { return rh_d(sin((double)a)); }
 
 /* ------------------------------------------------------------------------------------ activations */
-/* half versions: renderer_activations.cuh (ReLU :40-60, Sine :97-120, Snake :263-285, SnakeAlt :329-358) */
+/* half versions: renderer_activations.cuh (ReLU :40-60, Sine :97-120, Sigmoid :152-179, Snake :263-285, SnakeAlt :329-358) */
 static float act_half(int act, float v, float param) {
     switch (act) {
         case ORACLE_ACT_RELU: return v > 0.f ? v : 0.f;
@@ -119,6 +119,8 @@ static float act_half(int act, float v, float param) {
             const float x1 = hsub(hadd(v, 1.0f), x0);
             return hdivf(x1, f2);
         }
+        case ORACLE_ACT_SIGMOID: /* :152-160: __hdiv(ONE, __hadd(ONE, hexp(__hneg(v)))) */
+            return hdivf(1.0f, hadd(1.0f, rh_d(exp(-(double)v))));
         default: return v;
     }
 }
@@ -129,6 +131,7 @@ static float act_float(int act, float v, float param) {
         case ORACLE_ACT_SINE: return (float)sin((double)v * param);
         case ORACLE_ACT_SNAKE: { const double s = sin((double)param * v); return (float)(v + s * s / param); }
         case ORACLE_ACT_SNAKEALT: return (float)(((double)v + 1.0 - cos(2.0 * param * v)) / (2.0 * param));
+        case ORACLE_ACT_SIGMOID: return (float)(1.0 / (1.0 + exp(-(double)v)));
         default: return v;
     }
 }

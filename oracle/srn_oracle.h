@@ -9,7 +9,7 @@ extern "C" {
 #endif
 
 enum { ORACLE_ACC_HALF = 0, ORACLE_ACC_FLOAT = 1 };
-enum { ORACLE_ACT_RELU = 0, ORACLE_ACT_SINE = 1, ORACLE_ACT_SNAKE = 2, ORACLE_ACT_SNAKEALT = 3 };
+enum { ORACLE_ACT_RELU = 0, ORACLE_ACT_SINE = 1, ORACLE_ACT_SNAKE = 2, ORACLE_ACT_SNAKEALT = 3, ORACLE_ACT_SIGMOID = 4 };
 enum {
     ORACLE_OUT_DENSITY = 0, ORACLE_OUT_DENSITY_DIRECT = 1, ORACLE_OUT_RGBO = 2, ORACLE_OUT_RGBO_DIRECT = 3,
     ORACLE_OUT_DENSITY_GRADIENT = 4, ORACLE_OUT_DENSITY_GRADIENT_DIRECT = 5, ORACLE_OUT_DENSITY_GRADIENT_CUBIC = 6,

@@ -178,6 +178,16 @@ def main():
             save_case("g1_c32l4_%s_%s" % (act.split(":")[0].lower(), om.replace(":", "-")), net, opt, pos,
                       out_fp32=forward(net, pos), out_fp16=forward(net, pos, half=True))
 
+    # ---- G1f: Sigmoid hidden activation (torch.nn.Sigmoid -> Layer::Activation::Sigmoid) -----------------------
+    for name, kw in [
+        ("g1_sigmoid_c32l4_density", dict(layers="32:32:32", outputmode="density", F=14, std=-1)),
+        ("g1_sigmoid_c64l3_grid16r8_rgbo-direct", dict(layers="64:64", outputmode="rgbo:direct", F=30, std=0.6, gc=16, gr=8)),
+    ]:
+        net, opt = make_network(SRN, layers=kw["layers"], activation="Sigmoid", fouriercount=kw["F"], fourierstd=kw["std"],
+                                outputmode=kw["outputmode"], grid_channels=kw.get("gc", 0), grid_res=kw.get("gr", 0), seed=700 + len(name))
+        pos = positions(N, 0, 70)
+        save_case(name, net, opt, pos, out_fp32=forward(net, pos), out_fp16=forward(net, pos, half=True))
+
     # ---- G1b: latent grids ------------------------------------------------------------------------
     for name, kw in [
         ("g1_c32l4_grid16r8_relu_density", dict(layers="32:32:32", activation="ReLU", outputmode="density", gc=16, gr=8)),
