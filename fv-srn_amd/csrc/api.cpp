@@ -647,6 +647,12 @@ int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const fl
             if (net->key.dir && !d_directions)
                 return fail(FVSRN_ERR_INVALID_ARGUMENT, "the network uses the view direction, but no directions were given");
             EvalArgs a{net->packed.params, d_positions, d_directions, n, d_out, net->net->outputChannels()};
+            if (flags & FVSRN_EVAL_WITH_PREDICTED_GRADIENT) {
+                const int om = a.P.outputMode;
+                if (om < FVSRN_OUT_DENSITY_GRADIENT || om > FVSRN_OUT_DENSITY_CURVATURE_DIRECT)
+                    return fail(FVSRN_ERR_INVALID_ARGUMENT, "the network does not predict gradients (output mode densitygrad* / densitycurvature*)");
+                a.outChannels = 4;
+            }
             if (!(flags & FVSRN_EVAL_WORLD_POSITIONS))  // volume_interpolation.cpp:46-49: box := [0,1]^3
                 for (int i = 0; i < 3; ++i) { a.P.boxMin[i] = 0.f; a.P.boxSize[i] = 1.f; a.P.invBoxSize[i] = 1.f; }
             const size_t batches = (n + 63) / 64;

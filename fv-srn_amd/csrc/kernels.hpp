@@ -74,6 +74,10 @@ __device__ __forceinline__ void evaluate_body(const NetParams& P, const char* ld
                     out[i * outChannels] = o[0];
                     break;
             }
+            if (outChannels == 4 && P.outputMode >= FVSRN_OUT_DENSITY_GRADIENT) {  // FVSRN_EVAL_WITH_PREDICTED_GRADIENT
+                const bool cubic = P.outputMode == FVSRN_OUT_DENSITY_GRADIENT_CUBIC;  // evalNormal :1166-1183
+                for (int k = 1; k < 4; ++k) out[i * 4 + k] = cubic ? o[k] * o[k] * o[k] : o[k];
+            }
         }
     }
 }

@@ -325,7 +325,7 @@ struct IVolumeInterpolation {
     // gradients (N,3) by central differences of evaluate() -- what evalNormal computes for grids (renderer_volume_grid.cuh:234-283:
     // one voxel to either side, scaled by 0.5 / voxel size) and for networks in GRADIENT_MODE_FINITE_DIFFERENCES
     // (renderer_volume_tensorcores.cuh:1185-1196)
-    std::tuple<torch::Tensor, torch::Tensor> evaluateWithGradients(const torch::Tensor& positions, const std::optional<torch::Tensor>& direction) {
+    virtual std::tuple<torch::Tensor, torch::Tensor> evaluateWithGradients(const torch::Tensor& positions, const std::optional<torch::Tensor>& direction) {
         if (outputChannels() != 1) raise("evaluateWithGradient can only be called for scalar volumes");
         const double3 h = gradientStep();
         if (!(h.x > 0 && h.y > 0 && h.z > 0)) raise("this volume provides no gradients in its current gradient mode (use FINITE_DIFFERENCES)");
@@ -388,6 +388,21 @@ struct VolumeInterpolationNetwork : IVolumeInterpolation {
         return {finiteDifferencesStepsize, finiteDifferencesStepsize, finiteDifferencesStepsize};
     }
     void setTimeAndEnsemble(float t, int e) { check(fvsrn_network_set_time_and_ensemble(currentNetwork()->h, t, e)); }
+    // GRADIENT_MODE_OFF_OR_DIRECT on a gradient-predicting network: the network's own gradient outputs (evalNormal,
+    // renderer_volume_tensorcores.cuh:1166-1183); otherwise central differences like the base class
+    std::tuple<torch::Tensor, torch::Tensor> evaluateWithGradients(const torch::Tensor& positions, const std::optional<torch::Tensor>& direction) override {
+        const int om = currentNetwork()->info().output_mode;
+        const bool predicts = om >= FVSRN_OUT_DENSITY_GRADIENT && om <= FVSRN_OUT_DENSITY_CURVATURE_DIRECT;
+        if (gradientMode != OFF_OR_DIRECT || !predicts) return IVolumeInterpolation::evaluateWithGradients(positions, direction);
+        TORCH_CHECK(positions.is_cuda() && positions.dim() == 2 && positions.size(1) == 3, "positions must be a CUDA tensor of shape (N,3)");
+        const torch::Tensor p = positions.to(c10::kFloat).contiguous();
+        torch::Tensor d;
+        if (direction.has_value() && direction->defined()) d = direction->to(c10::kFloat).contiguous();
+        torch::Tensor out = torch::empty({p.size(0), 4}, p.options());
+        check(fvsrn_evaluate_points(currentNetwork()->h, p.data_ptr<float>(), d.defined() ? d.data_ptr<float>() : nullptr, size_t(p.size(0)),
+                                    out.data_ptr<float>(), FVSRN_EVAL_WITH_PREDICTED_GRADIENT, currentStream()));
+        return {out.slice(1, 0, 1).to(positions.scalar_type()).contiguous(), out.slice(1, 1, 4).to(positions.scalar_type()).contiguous()};
+    }
 
     torch::Tensor evaluate(const torch::Tensor& positions, const std::optional<torch::Tensor>& direction) override {
         // IVolumeInterpolation::evaluate, renderer/volume_interpolation.cpp:26-127

@@ -150,6 +150,10 @@ int fvsrn_network_get_fourier(const fvsrn_network* net, uint16_t* matrix, int ca
  * positions and mapped through the network's box_min / box_size as the renderer does.
  * -------------------------------------------------------------------------------------- */
 #define FVSRN_EVAL_WORLD_POSITIONS 1
+/* gradient-predicting networks (densitygrad, densitygrad:direct, densitygrad:cubic; also the curvature modes): d_out is (n,4) =
+ * value + the predicted gradient, i.e. eval() + evalNormal() in GRADIENT_MODE_OFF_OR_DIRECT
+ * (renderer_volume_tensorcores.cuh:1166-1183; IVolumeInterpolation::evaluateWithGradient, volume_interpolation.cpp:128-243) */
+#define FVSRN_EVAL_WITH_PREDICTED_GRADIENT 2
 int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const float* d_directions,
                           size_t n, float* d_out, int flags, void* stream);
 

@@ -568,3 +568,23 @@ def test_network_evaluate_with_gradients_and_ray_multisampling(tmp_path):
     assert float((direction[0] - direction[1]).abs().max()) > 0
     again, _ = cam.generate_rays_multisampling(24, 16, 5), None
     assert torch.equal(again[1], direction)  # seeded like the reference: (42, time)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["densitygrad", "densitygrad:cubic"])
+def test_evaluate_with_gradients_of_a_gradient_predicting_network(tmp_path, mode):
+    """GRADIENT_MODE_OFF_OR_DIRECT on a densitygrad network: evaluate_with_gradients returns the network's own gradient outputs
+    (evalNormal, renderer_volume_tensorcores.cuh:1166-1183; cubed in densitygrad:cubic) -- against oracle_eval_points_full."""
+    from oracle import oracle
+    vn = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode=mode, seed=5, fourier_std=0.4)
+    path = str(tmp_path / "net.volnet")
+    open(path, "wb").write(volnet_io.save_volnet(vn))
+    vol = pr.VolumeInterpolationNetwork()
+    vol.set_network(pr.SceneNetwork.load(path))
+    pos = torch.rand(777, 3, device="cuda")
+    dens, grad = vol.evaluate_with_gradients(pos)
+    full = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate_full(pos.cpu().numpy())  # value[4], normal[3], curvature[2]
+    assert dens.shape == (777, 1) and grad.shape == (777, 3)
+    assert np.abs(dens.cpu().numpy()[:, 0] - full[:, 0]).max() < 2e-3
+    assert np.abs(grad.cpu().numpy() - full[:, 4:7]).max() < 2e-3 * max(1.0, np.abs(full[:, 4:7]).max())
+    assert np.abs(full[:, 4:7]).max() > 1e-3
