@@ -77,21 +77,18 @@ __device__ __forceinline__ float vol_sample_cubic(const VolumeParams& V, float x
         h0[d] = (w1 / g0[d]) - 0.5f + index;
         h1[d] = (w3 / g1[d]) + 1.5f + index;
     }
-    float tex000 = vol_sample_linear(V, h0[0], h0[1], h0[2]);
-    const float tex100 = vol_sample_linear(V, h1[0], h0[1], h0[2]);
-    tex000 = g0[0] * tex000 + g1[0] * tex100;
-    float tex010 = vol_sample_linear(V, h0[0], h1[1], h0[2]);
-    const float tex110 = vol_sample_linear(V, h1[0], h1[1], h0[2]);
-    tex010 = g0[0] * tex010 + g1[0] * tex110;
-    tex000 = g0[1] * tex000 + g1[1] * tex010;
-    float tex001 = vol_sample_linear(V, h0[0], h0[1], h1[2]);
-    const float tex101 = vol_sample_linear(V, h1[0], h0[1], h1[2]);
-    tex001 = g0[0] * tex001 + g1[0] * tex101;
-    float tex011 = vol_sample_linear(V, h0[0], h1[1], h1[2]);
-    const float tex111 = vol_sample_linear(V, h1[0], h1[1], h1[2]);
-    tex011 = g0[0] * tex011 + g1[0] * tex111;
-    tex001 = g0[1] * tex001 + g1[1] * tex011;
-    return g0[2] * tex000 + g1[2] * tex001;
+    // eight linear fetches, weighted along x, then y, then z (the order of the reference's sums)
+    float alongZ[2];
+    for (int kz = 0; kz < 2; ++kz) {
+        const float z = kz ? h1[2] : h0[2];
+        float alongY[2];
+        for (int ky = 0; ky < 2; ++ky) {
+            const float y = ky ? h1[1] : h0[1];
+            alongY[ky] = g0[0] * vol_sample_linear(V, h0[0], y, z) + g1[0] * vol_sample_linear(V, h1[0], y, z);
+        }
+        alongZ[kz] = g0[1] * alongY[0] + g1[1] * alongY[1];
+    }
+    return g0[2] * alongZ[0] + g1[2] * alongZ[1];
 }
 
 // eval (:193-232): world position -> object coordinates [0, res-1] (old behaviour) or [0, res] (new), then sample()
