@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer tool: cycle split of the render loop's wave step from a -DFVSRN_PROF_SECTIONS build
 (tools/ablate.sh "-DFVSRN_PROF_SECTIONS", then FVSRN_LIBRARY=fv-srn_amd/ablate/libfvsrn__DFVSRN_PROF_SECTIONS.so).
-usage: tools/section_profile.py [config]     (FVSRN_MAX_BLOCKS_PER_CU=4 -> one wave per SIMD: pure latencies)"""
+usage: tools/section_profile.py [config]     (FVSRN_MAX_BLOCKS_PER_CU=4 -> one wave per SIMD: pure latencies)
+The marks sit in render_kernel's pipelined layer loop: run with FVSRN_SMALL_KERNEL=0 for networks the register-resident kernel would take."""
 import importlib.util
 import os
 import sys
