@@ -317,6 +317,8 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     constexpr bool kRotate = CD == 2 && GRID == 0 && FMODE != FM_FIRST_LAYER && !SHADED;
 #endif
     floatx16 feat[2][mtiles(CD)], dfeat[2][mtiles(CD)];
+    float stepIndex = float(i0);
+    const float stepEnd = float(i1);  // INT_MAX -> 2^31: never reached
 
 #ifdef FVSRN_PROF_SECTIONS
     P.profLast = __builtin_readcyclecounter();
@@ -327,9 +329,10 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
         bool inRange, valid;
         unsigned long long validMask;
         if constexpr (TAIL != TAIL_GENERIC) {  // straight-line: i0 = 0, i1 = INT_MAX without segments
-            const int gi = i0 + i;
-            t = tmin + float(gi) * S.stepsize;
-            inRange = (t <= tmax) & (gi < i1);
+            // the global step index i0 + i as a float counter (exact below 2^24): one add per step instead of add + convert
+            t = tmin + stepIndex * S.stepsize;
+            inRange = (t <= tmax) & (stepIndex < stepEnd);
+            stepIndex += 1.f;
             const bool notOpaque = ca < alphaLimit;
             valid = inRange & notOpaque;
             validMask = __builtin_amdgcn_ballot_w64(inRange) & __builtin_amdgcn_ballot_w64(notOpaque);  // scalar ops only
