@@ -1057,10 +1057,18 @@ struct fvsrn_volume {
     DeviceBuffer dData;
     bool deviceValid = false;
     ~fvsrn_volume() { dData.release(); }
-    void ensureDevice(hipStream_t s) {
+    void ensureDevice(hipStream_t s) {  // upload in 4x4x4 bricks (grid_volume.hpp)
         if (deviceValid) return;
-        dData.ensure(host.size() * sizeof(float));
-        HIP_CHECK(hipMemcpyAsync(dData.ptr, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        const size_t bx = size_t(res[0] + 3) / 4, by = size_t(res[1] + 3) / 4, bz = size_t(res[2] + 3) / 4;
+        std::vector<float> bricked(bx * by * bz * 64, 0.f);
+        for (int z = 0; z < res[2]; ++z)
+            for (int y = 0; y < res[1]; ++y) {
+                const float* row = host.data() + size_t(res[0]) * (size_t(y) + size_t(res[1]) * size_t(z));
+                const size_t base = ((size_t(z >> 2) * by + size_t(y >> 2)) * bx) * 64 + size_t(((z & 3) << 4) | ((y & 3) << 2));
+                for (int x = 0; x < res[0]; ++x) bricked[base + size_t(x >> 2) * 64 + size_t(x & 3)] = row[x];
+            }
+        dData.ensure(bricked.size() * sizeof(float));
+        HIP_CHECK(hipMemcpyAsync(dData.ptr, bricked.data(), bricked.size() * sizeof(float), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipStreamSynchronize(s));
         deviceValid = true;
     }
@@ -1068,7 +1076,7 @@ struct fvsrn_volume {
         VolumeParams V{};
         V.data = static_cast<const float*>(dData.ptr);
         for (int i = 0; i < 3; ++i) { V.res[i] = res[i]; V.boxMin[i] = boxMin[i]; V.boxSize[i] = boxSize[i]; }
-        V.stride[0] = 1; V.stride[1] = res[0]; V.stride[2] = (long long)res[0] * res[1];
+        V.bricks[0] = (res[0] + 3) / 4; V.bricks[1] = (res[1] + 3) / 4;
         V.source = source; V.interpolation = interpolation; V.newBehavior = newBehavior; V.provideNormals = provideNormals;
         return V;
     }

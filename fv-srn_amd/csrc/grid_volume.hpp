@@ -9,9 +9,12 @@
 namespace fvsrn {
 
 struct VolumeParams {
-    const float* data;        // fp32 voxels in HBM
+    const float* data;        // fp32 voxels in HBM, in 4x4x4 bricks (256 bytes = two cache lines): brick (x>>2, y>>2, z>>2) in
+                              // x-fastest order, voxel (x&3) + 4 (y&3) + 16 (z&3) inside -- a trilinear footprint touches one brick
+                              // most of the time whatever the direction of the ray (an x-fastest array is fast only along x:
+                              // 2.0 .. 5.3 ms per 1024^2 frame of a 512^3 volume depending on the view, r01)
     int res[3];               // X, Y, Z
-    long long stride[3];      // element strides of x, y, z
+    int bricks[2];            // bricks along x and y
     float boxMin[3], boxSize[3];
     int interpolation;        // fvsrn_volume_interpolation
     int source;               // fvsrn_volume_source
@@ -22,7 +25,8 @@ struct VolumeParams {
 __device__ __forceinline__ int vol_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ float vol_fetch(const VolumeParams& V, int x, int y, int z) {
     x = vol_clampi(x, 0, V.res[0] - 1); y = vol_clampi(y, 0, V.res[1] - 1); z = vol_clampi(z, 0, V.res[2] - 1);
-    return V.data[x * V.stride[0] + y * V.stride[1] + z * V.stride[2]];
+    const size_t brick = (size_t(z >> 2) * size_t(V.bricks[1]) + size_t(y >> 2)) * size_t(V.bricks[0]) + size_t(x >> 2);
+    return V.data[brick * 64 + size_t(((z & 3) << 4) | ((y & 3) << 2) | (x & 3))];
 }
 __device__ __forceinline__ float vol_lerp(float a, float b, float t) { return a + t * (b - a); }  // helper_math.cuh lerp
 
