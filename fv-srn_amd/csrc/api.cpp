@@ -1262,7 +1262,33 @@ int fvsrn_render_volume(fvsrn_scene* scene, fvsrn_volume* volume, int source, in
             SceneParams S{};
             fillSceneParams(scene, d, width, height, S);
             S.width = width; S.height = height; S.y0 = 0; S.y1 = height;
-            const hipError_t e = launch_volume_render(volume->params(source, interpolation, grid_resolution_new_behavior, normals), S, d_out8, d_stats, tfFloats, s);
+            // depth segments (see renderImpl): enough waves to cover the gather latency of small images, >= 48 steps per segment
+            // (early-out then works per segment; not with a pre-integrated TF, which looks at the previous sample)
+            int K = 1;
+            {
+                static int numCUs = 0;  // hipGetDeviceProperties costs ~0.1 ms: once
+                if (numCUs == 0) {
+                    hipDeviceProp_t prop;
+                    int dev = 0;
+                    numCUs = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+                }
+                const double waves = double(((width + 15) / 16) * ((height + 15) / 16)) * 4.0, slots = double(numCUs) * 32.0;
+                const float* bs = volume->boxSize;
+                const double maxSteps = std::sqrt(double(bs[0]) * bs[0] + double(bs[1]) * bs[1] + double(bs[2]) * bs[2]) / d.stepsize;
+                while (d.tf_preintegration == FVSRN_PREINTEGRATE_NONE && K < 8 && waves * K < slots / 2 && maxSteps / (2 * K) >= 48.0) K *= 2;  // r01, 256^2: K = 1 / 2 / 4 / 8 -> 0.34 / 0.19 / 0.17 / 0.24 ms
+                if (const char* e = std::getenv("FVSRN_SEGMENTS")) {
+                    const int k = std::atoi(e);
+                    if (k >= 1 && k <= 64 && d.tf_preintegration == FVSRN_PREINTEGRATE_NONE) K = k;
+                }
+            }
+            S.segments = K;
+            const size_t plane = size_t(width) * size_t(height);
+            if (K > 1) {
+                scene->dPartial.ensure(size_t(K) * 8 * plane * sizeof(float));
+                S.partial = static_cast<float*>(scene->dPartial.ptr);
+            }
+            hipError_t e = launch_volume_render(volume->params(source, interpolation, grid_resolution_new_behavior, normals), S, d_out8, d_stats, tfFloats, s);
+            if (e == hipSuccess && K > 1) e = launch_composite(S.partial, d_out8, K, plane, S, s);
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during rendering! ") + hipGetErrorString(e));
             return FVSRN_OK;
         } catch (const DeviceError& e) {

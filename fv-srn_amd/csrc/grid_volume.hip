@@ -27,6 +27,10 @@ __global__ __launch_bounds__(256) void volume_render_kernel(VolumeParams V, Scen
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tilesX = (S.width + 15) >> 4;
     const int bx = blockIdx.x % tilesX, by = blockIdx.x / tilesX;
+    // depth segments like render_body (kernels.hpp): blockIdx.y = segment of the ray's step range, partial results composited
+    // front to back by composite_kernel; a small image (BASELINE configs[0]: 256^2 = one wave per SIMD) is bound by the latency of
+    // its serial gathers otherwise
+    const int K = S.segments, seg = int(blockIdx.y);
     const int x = bx * 16 + (wave & 1) * 8 + (lane & 7), y = by * 16 + (wave >> 1) * 8 + (lane >> 3);
     const bool inImage = x < S.width && y < S.height;
 
@@ -53,9 +57,16 @@ __global__ __launch_bounds__(256) void volume_render_kernel(VolumeParams V, Scen
     float cr = 0, cg = 0, cb = 0, ca = 0, depth = 0, nx = 0, ny = 0, nz = 0;
     float previousDensity = -1.f;  // pre-integrated transfer functions, stepping_dvr.cuh:81
     unsigned count = 0;
-    for (int i = 0;; ++i) {
+    int i0 = 0, i1 = 0x7fffffff;
+    if (K > 1) {
+        const float span = tmax - tmin;
+        const int n = span >= 0.f ? int(span / S.stepsize) + 1 : 0;
+        i0 = (n * seg) / K;
+        if (seg + 1 < K) i1 = (n * (seg + 1)) / K;
+    }
+    for (int i = i0;; ++i) {
         const float t = tmin + float(i) * S.stepsize;
-        const bool valid = (t <= tmax) && (!S.earlyOut || ca < S.alphaEarlyOut);
+        const bool valid = (t <= tmax) && (i < i1) && (!S.earlyOut || ca < S.alphaEarlyOut);
         if (!valid) break;  // per-lane view of the reference's warp-synchronous loop: an invalid lane never blends again
         ++count;
         const float wx = ox + dx * t, wy = oy + dy * t, wz = oz + dz * t;
@@ -106,7 +117,12 @@ __global__ __launch_bounds__(256) void volume_render_kernel(VolumeParams V, Scen
             }
         }
     }
-    if (inImage) {
+    if (inImage && K > 1) {  // raw accumulators of this segment
+        const size_t plane = size_t(S.width) * S.height;
+        float* p = S.partial + size_t(seg) * 8 * plane + size_t(y) * S.width + x;
+        p[0] = cr; p[plane] = cg; p[2 * plane] = cb; p[3 * plane] = ca;
+        p[4 * plane] = nx; p[5 * plane] = ny; p[6 * plane] = nz; p[7 * plane] = depth;
+    } else if (inImage) {
         const size_t plane = size_t(S.width) * S.height, o = size_t(y) * S.width + x;
         out[o] = cr; out[plane + o] = cg; out[2 * plane + o] = cb; out[3 * plane + o] = ca;
         out[4 * plane + o] = nx * ca; out[5 * plane + o] = ny * ca; out[6 * plane + o] = nz * ca;
@@ -135,10 +151,10 @@ hipError_t launch_volume_evaluate(const VolumeParams& V, const float* pos, size_
 
 hipError_t launch_volume_render(const VolumeParams& V, const SceneParams& S, float* out, unsigned long long* stats, size_t tfFloats,
                                 hipStream_t s) {
-    const unsigned grid = unsigned(((S.width + 15) / 16) * ((S.height + 15) / 16));
+    const dim3 grid(unsigned(((S.width + 15) / 16) * ((S.height + 15) / 16)), unsigned(std::max(S.segments, 1)));
     const bool shade = V.provideNormals || S.brdfMagnitudeScaling || S.brdfPhong || S.tfPreintegration != FVSRN_PREINTEGRATE_NONE;
-    if (shade) hipLaunchKernelGGL(volume_render_kernel<true>, dim3(grid), dim3(256), tfFloats * 4, s, V, S, out, stats);
-    else hipLaunchKernelGGL(volume_render_kernel<false>, dim3(grid), dim3(256), tfFloats * 4, s, V, S, out, stats);
+    if (shade) hipLaunchKernelGGL(volume_render_kernel<true>, grid, dim3(256), tfFloats * 4, s, V, S, out, stats);
+    else hipLaunchKernelGGL(volume_render_kernel<false>, grid, dim3(256), tfFloats * 4, s, V, S, out, stats);
     return hipGetLastError();
 }
 

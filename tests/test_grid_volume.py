@@ -180,7 +180,10 @@ def test_render_volume_matches_restatement(case):
     else:
         assert diff.max() < 1e-4
     st = stats.cpu().numpy()
-    assert abs(int(st[0]) - count) <= max(8, count // 10000)
+    if case.get("early_out", True):  # depth segments (small images) stop early per segment: a few more samples than the single loop
+        assert count <= int(st[0]) <= 1.5 * count
+    else:
+        assert abs(int(st[0]) - count) <= max(8, count // 10000)
 
 
 PHONG = dict(enable_phong=True, ambient=0.2, specular=0.4, magnitude_center=0.6, magnitude_radius=0.5, specular_exponent=8,
