@@ -11,7 +11,7 @@ What it reproduces (reference files):
     `extract_color`)
   * LoadedModel.convert_image (:627-631) + imageio.imwrite -> PNG frames (written here with zlib, imageio is not installed)
 
-Inputs: a `.volnet` file (the reference's own export format, loaded unchanged) and optionally a scene JSON of the
+Inputs: a `.volnet` file (the reference's own export format, loaded unchanged) -- or an uncompressed `.cvol` grid volume for the ground truth -- and optionally a scene JSON of the
 reference (`pyrenderer.load_from_json`); without one a default DVR scene (Identity TF) is used.
 
   python tools/render_protocol.py net.volnet [--scene scene.json] [--out outdir] [--width 512 --height 512]
@@ -71,14 +71,20 @@ def run(args) -> dict:
     if not torch.cuda.is_available():
         raise SystemExit("no GPU: the renderer has no CPU path")
     ev = pr.load_from_json(args.scene) if args.scene else default_evaluator(pr)
-    net = pr.SceneNetwork.load(args.volnet)
-    vol = pr.VolumeInterpolationNetwork()
-    vol.set_network(net)
+    if args.volnet.endswith(".cvol"):  # ground truth: the grid volume itself (the scene files' own "Grid" volume)
+        net = None
+        vol = pr.VolumeInterpolationGrid()
+        vol.setSource(pr.Volume(args.volnet))
+    else:
+        net = pr.SceneNetwork.load(args.volnet)
+        vol = pr.VolumeInterpolationNetwork()
+        vol.set_network(net)
     ev.volume = vol
     ev.ray_evaluator.stepsize = args.stepsize  # world step size (render_network :603-606)
     if getattr(args, "texture_tf", False):  # LoadedModel.enable_preintegration(..., convert_to_texture=True), inference.py:332-336
         ev.ray_evaluator.convert_to_texture_tf()
-    net.set_time_and_ensemble(args.timestep, args.ensemble)
+    if net is not None:
+        net.set_time_and_ensemble(args.timestep, args.ensemble)
 
     pyd = ev.camera.pitchYawDistance.value
     pitch, yaw, dist = pyd.x, pyd.y, pyd.z
@@ -105,7 +111,7 @@ def run(args) -> dict:
     stats = {"protocol": "eval_NetworkConfigsGrid.py:100-140 (rotation cameras, GPUTimer around render + extract_color, "
                          "first frame discarded)",
              "volnet": os.path.basename(args.volnet), "width": args.width, "height": args.height, "stepsize": args.stepsize,
-             "num_cameras": args.cameras, "num_parameters": net.num_parameters(),
+             "num_cameras": args.cameras, "num_parameters": net.num_parameters() if net is not None else None,
              "ms_mean": float(t.mean()) if len(t) else None, "ms_std": float(t.std()) if len(t) else None,
              "fps": float(1000.0 / t.mean()) if len(t) else None}
     if args.out:
