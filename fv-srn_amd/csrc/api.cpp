@@ -659,7 +659,19 @@ int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const fl
             const size_t wpb = size_t(wavesPerBlockFor(size_t(net->packed.params.ldsBytes)));
             const size_t blocks = (batches + wpb - 1) / wpb;
             const unsigned grid = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 32 / wpb));
-            const hipError_t e = launch_eval(net->key, a, grid, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
+            // small networks in registers (evaluate_small_kernel): see renderImpl; the plain weight image, any output mode
+            hipError_t e = hipErrorInvalidDeviceFunction;
+            {
+                const char* env = std::getenv("FVSRN_SMALL_KERNEL");
+                const VariantKey& k = net->key;
+                if (!(env && env[0] == '0') && k.CD == 2 && k.grid == 0 && !a.P.noFourier && !a.P.fourierNeedsFractEval && a.P.numLayers >= 1 &&
+                    a.P.numLayers <= 3) {
+                    const unsigned gridSmall = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 8 / wpb));  // 2 waves per SIMD
+                    e = launch_eval_small(k.act, k.dir, a.P.numLayers, a, gridSmall, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
+                }
+            }
+            if (e == hipErrorInvalidDeviceFunction)
+                e = launch_eval(net->key, a, grid, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during evaluation! ") + hipGetErrorString(e));
             return FVSRN_OK;
         } catch (const DeviceError& e) {

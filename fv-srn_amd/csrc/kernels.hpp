@@ -28,6 +28,36 @@ __device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* ld
     __syncthreads();
 }
 
+// output parametrization of IVolumeInterpolation::evaluate for point i (renderer_volume_tensorcores.cuh:1054-1158)
+__device__ __forceinline__ void write_eval_outputs(const NetParams& P, const float4_t& o, float* __restrict__ out, size_t i, int outChannels) {
+    switch (P.outputMode) {
+        case FVSRN_OUT_DENSITY:
+        case FVSRN_OUT_DENSITY_GRADIENT:
+        case FVSRN_OUT_DENSITY_CURVATURE:
+            out[i * outChannels] = sigmoid_f(o[0]);
+            break;
+        case FVSRN_OUT_RGBO:
+            out[i * 4 + 0] = sigmoid_f(o[0]);
+            out[i * 4 + 1] = sigmoid_f(o[1]);
+            out[i * 4 + 2] = sigmoid_f(o[2]);
+            out[i * 4 + 3] = softplus_f(o[3]);
+            break;
+        case FVSRN_OUT_RGBO_DIRECT:
+            out[i * 4 + 0] = fminf(fmaxf(o[0], 0.f), 1.f);
+            out[i * 4 + 1] = fminf(fmaxf(o[1], 0.f), 1.f);
+            out[i * 4 + 2] = fminf(fmaxf(o[2], 0.f), 1.f);
+            out[i * 4 + 3] = fmaxf(o[3], 0.f);
+            break;
+        default:  // density:direct and the direct gradient modes: un-clamped
+            out[i * outChannels] = o[0];
+            break;
+    }
+    if (outChannels == 4 && P.outputMode >= FVSRN_OUT_DENSITY_GRADIENT) {  // FVSRN_EVAL_WITH_PREDICTED_GRADIENT
+        const bool cubic = P.outputMode == FVSRN_OUT_DENSITY_GRADIENT_CUBIC;  // evalNormal :1166-1183
+        for (int k = 1; k < 4; ++k) out[i * 4 + k] = cubic ? o[k] * o[k] * o[k] : o[k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // EvaluateNoBatches (reference renderer/renderer_volume_kernels1.cuh:15): positions -> network value
 // ------------------------------------------------------------------------------------------------
@@ -51,34 +81,7 @@ __device__ __forceinline__ void evaluate_body(const NetParams& P, const char* ld
         py = (py - P.boxMin[1]) * P.invBoxSize[1];
         pz = (pz - P.boxMin[2]) * P.invBoxSize[2];
         const float4_t o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz);
-        if (valid) {
-            switch (P.outputMode) {
-                case FVSRN_OUT_DENSITY:
-                case FVSRN_OUT_DENSITY_GRADIENT:
-                case FVSRN_OUT_DENSITY_CURVATURE:
-                    out[i * outChannels] = sigmoid_f(o[0]);
-                    break;
-                case FVSRN_OUT_RGBO:
-                    out[i * 4 + 0] = sigmoid_f(o[0]);
-                    out[i * 4 + 1] = sigmoid_f(o[1]);
-                    out[i * 4 + 2] = sigmoid_f(o[2]);
-                    out[i * 4 + 3] = softplus_f(o[3]);
-                    break;
-                case FVSRN_OUT_RGBO_DIRECT:
-                    out[i * 4 + 0] = fminf(fmaxf(o[0], 0.f), 1.f);
-                    out[i * 4 + 1] = fminf(fmaxf(o[1], 0.f), 1.f);
-                    out[i * 4 + 2] = fminf(fmaxf(o[2], 0.f), 1.f);
-                    out[i * 4 + 3] = fmaxf(o[3], 0.f);
-                    break;
-                default:  // density:direct and the direct gradient modes: un-clamped
-                    out[i * outChannels] = o[0];
-                    break;
-            }
-            if (outChannels == 4 && P.outputMode >= FVSRN_OUT_DENSITY_GRADIENT) {  // FVSRN_EVAL_WITH_PREDICTED_GRADIENT
-                const bool cubic = P.outputMode == FVSRN_OUT_DENSITY_GRADIENT_CUBIC;  // evalNormal :1166-1183
-                for (int k = 1; k < 4; ++k) out[i * 4 + k] = cubic ? o[k] * o[k] * o[k] : o[k];
-            }
-        }
+        if (valid) write_eval_outputs(P, o, out, i, outChannels);
     }
 }
 
@@ -96,6 +99,37 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void e
     }
     if (P.fourierNeedsFractEval) evaluate_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS>(P, lds, pos, dir, n, out, outChannels);
     else evaluate_body<CD, ACT, GRID, HAS_DIR, FM_COS>(P, lds, pos, dir, n, out, outChannels);
+}
+
+// evaluate_kernel for 32-wide Fourier-only networks with NLC <= 3 C->C layers: weights and biases in registers (ResidentNet,
+// srn_device.hpp), 2 waves per SIMD; the phase fragments of the Fourier stage are the only LDS reads of a batch
+template <int ACT, bool HAS_DIR, int NLC>
+__global__ __launch_bounds__(kBlockThreads, 2) void evaluate_small_kernel(NetParams P, const float* __restrict__ pos, const float* __restrict__ dir,
+                                                                        size_t n, float* __restrict__ out, int outChannels) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    load_network_to_lds(P, lds);
+    ResidentNet<NLC> R;
+    load_resident(P, lds, R);
+    const int lane = lane_id();
+    const size_t wavesPerBlock = blockDim.x >> 6;
+    const size_t wave = size_t(blockIdx.x) * wavesPerBlock + (threadIdx.x >> 6);
+    const size_t numWaves = size_t(gridDim.x) * wavesPerBlock;
+    const size_t batches = (n + 63) / 64;
+    for (size_t b = wave; b < batches; b += numWaves) {
+        const size_t i = b * 64 + lane;
+        const bool valid = i < n;
+        const size_t j = valid ? i : 0;
+        float px = pos[3 * j + 0], py = pos[3 * j + 1], pz = pos[3 * j + 2];
+        float dx = 0, dy = 0, dz = 0;
+        if constexpr (HAS_DIR) { dx = dir[3 * j + 0]; dy = dir[3 * j + 1]; dz = dir[3 * j + 2]; }
+        px = (px - P.boxMin[0]) * P.invBoxSize[0];
+        py = (py - P.boxMin[1]) * P.invBoxSize[1];
+        pz = (pz - P.boxMin[2]) * P.invBoxSize[2];
+        half8_t xb[2][2];
+        const float4_t o = srn_layers_resident<ACT, NLC, 0, true>(
+            P, R, xb, [&]() { fourier_fragments<2, ACT, HAS_DIR, FM_COS>(P, lds, px, py, pz, dx, dy, dz, xb); }, [](int) {});
+        if (valid) write_eval_outputs(P, o, out, i, outChannels);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -91,6 +91,9 @@ hipError_t launch_evaluate_tf(const SceneParams& S, const float* density, const 
 const void* render_small_fn(int act, bool dir, int numLayers, int tail);  // tail: 1 Identity/Texture TF, 2 Piecewise/Gaussian TF, 3 colour network
 hipError_t launch_render_small(int act, bool dir, int numLayers, int tail, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 
+// evaluate_small_kernel: hipErrorInvalidDeviceFunction if that variant is not compiled in
+hipError_t launch_eval_small(int act, bool dir, int numLayers, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
+
 bool kernel_info(const VariantKey& k, KernelInfo* info);
 hipError_t launch_eval(const VariantKey& k, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 hipError_t launch_render(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
