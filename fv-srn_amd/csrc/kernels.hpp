@@ -28,6 +28,18 @@ __device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* ld
     __syncthreads();
 }
 
+// positions (and directions) of batch b for this lane; lanes beyond n read point 0.  The next batch is fetched before the
+// current one is evaluated: with 2-3 waves per SIMD the ~1 us of a dependent global load is otherwise exposed once per batch.
+template <bool HAS_DIR>
+__device__ __forceinline__ void load_eval_point(const float* __restrict__ pos, const float* __restrict__ dir, size_t n, size_t b, int lane,
+                                                float (&p)[3], float (&d)[3]) {
+    const size_t i = b * 64 + lane;
+    const size_t j = i < n ? i : 0;
+    p[0] = pos[3 * j + 0]; p[1] = pos[3 * j + 1]; p[2] = pos[3 * j + 2];
+    if constexpr (HAS_DIR) { d[0] = dir[3 * j + 0]; d[1] = dir[3 * j + 1]; d[2] = dir[3 * j + 2]; }
+    else { d[0] = d[1] = d[2] = 0.f; }
+}
+
 // output parametrization of IVolumeInterpolation::evaluate for point i (renderer_volume_tensorcores.cuh:1054-1158)
 __device__ __forceinline__ void write_eval_outputs(const NetParams& P, const float4_t& o, float* __restrict__ out, size_t i, int outChannels) {
     switch (P.outputMode) {
@@ -72,10 +84,10 @@ __device__ __forceinline__ void evaluate_body(const NetParams& P, const char* ld
     for (size_t b = wave; b < batches; b += numWaves) {  // wave-uniform trip count: EXEC stays full
         const size_t i = b * 64 + lane;
         const bool valid = i < n;
-        const size_t j = valid ? i : 0;
-        float px = pos[3 * j + 0], py = pos[3 * j + 1], pz = pos[3 * j + 2];
-        float dx = 0, dy = 0, dz = 0;
-        if constexpr (HAS_DIR) { dx = dir[3 * j + 0]; dy = dir[3 * j + 1]; dz = dir[3 * j + 2]; }
+        float np_[3], nd_[3];  // (no prefetch of the next batch here: its six registers cost the 64-wide kernel 26 %, r01)
+        load_eval_point<HAS_DIR>(pos, dir, n, b, lane, np_, nd_);
+        float px = np_[0], py = np_[1], pz = np_[2];
+        const float dx = nd_[0], dy = nd_[1], dz = nd_[2];
         // renderer_volume_tensorcores.cuh:744-746
         px = (px - P.boxMin[0]) * P.invBoxSize[0];
         py = (py - P.boxMin[1]) * P.invBoxSize[1];
@@ -115,13 +127,14 @@ __global__ __launch_bounds__(kBlockThreads, 2) void evaluate_small_kernel(NetPar
     const size_t wave = size_t(blockIdx.x) * wavesPerBlock + (threadIdx.x >> 6);
     const size_t numWaves = size_t(gridDim.x) * wavesPerBlock;
     const size_t batches = (n + 63) / 64;
+    float np_[3], nd_[3];
+    if (wave < batches) load_eval_point<HAS_DIR>(pos, dir, n, wave, lane, np_, nd_);
     for (size_t b = wave; b < batches; b += numWaves) {
         const size_t i = b * 64 + lane;
         const bool valid = i < n;
-        const size_t j = valid ? i : 0;
-        float px = pos[3 * j + 0], py = pos[3 * j + 1], pz = pos[3 * j + 2];
-        float dx = 0, dy = 0, dz = 0;
-        if constexpr (HAS_DIR) { dx = dir[3 * j + 0]; dy = dir[3 * j + 1]; dz = dir[3 * j + 2]; }
+        float px = np_[0], py = np_[1], pz = np_[2];
+        const float dx = nd_[0], dy = nd_[1], dz = nd_[2];
+        if (b + numWaves < batches) load_eval_point<HAS_DIR>(pos, dir, n, b + numWaves, lane, np_, nd_);
         px = (px - P.boxMin[0]) * P.invBoxSize[0];
         py = (py - P.boxMin[1]) * P.invBoxSize[1];
         pz = (pz - P.boxMin[2]) * P.invBoxSize[2];
