@@ -84,7 +84,7 @@ __device__ __forceinline__ void evaluate_body(const NetParams& P, const char* ld
     for (size_t b = wave; b < batches; b += numWaves) {  // wave-uniform trip count: EXEC stays full
         const size_t i = b * 64 + lane;
         const bool valid = i < n;
-        float np_[3], nd_[3];  // (no prefetch of the next batch here: its six registers cost the 64-wide kernel 26 %, r01)
+        float np_[3], nd_[3];  // (the next batch is not fetched ahead here: six more live registers for the wide kernels, +3 % at 32 wide)
         load_eval_point<HAS_DIR>(pos, dir, n, b, lane, np_, nd_);
         float px = np_[0], py = np_[1], pz = np_[2];
         const float dx = nd_[0], dy = nd_[1], dz = nd_[2];
