@@ -15,7 +15,8 @@ synthetic inputs already resident in HBM:
 metric: SRN samples/s, counting lane-exact EVALUATED samples (the loop bound of
 renderer_ray_evaluation_stepping_dvr.cuh:84-90 summed over all rays), read from the kernel's own counter.
 
-N > 1 (launched with torch.distributed.run): the SAME frame is split into round-robin 16-row stripes, one
+N > 1 (`python bench.py --gpus N` starts the N rank processes itself; under torch.distributed.run it takes the launcher's
+RANK / WORLD_SIZE instead): the SAME frame is split into round-robin 16-row stripes, one
 process per GPU, each rank renders its stripes and one RCCL all-gather assembles the frame ("strong" scaling;
 the gather of frame i overlaps the render of frame i+1 on a side stream, and consecutive frames alternate between two render
 streams so that the tail of one launch overlaps the start of the next).
@@ -26,12 +27,13 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -57,10 +59,17 @@ def build_scene_kwargs(capi, yaw, stepsize, early_out):
                 early_out=early_out, tf_kind=capi.TF_IDENTITY, tf_scale_absorption=10.0, tf_scale_emission=1.0)
 
 
-def make_network(util, volnet_io, capi, cfg, activation, time_keys=1):
+def bench_network(C, layers, grid, activation, time_keys=1):
+    """The synthetic network of a workload: seed 1234, nn.Linear-style init, NeRF ladder, density:direct,
+    latent grid randn * 0.01.  tests/test_gpu_parity.py renders the same networks against the oracle."""
+    from fvsrn_amd import synthetic
+    return synthetic.random_network(C=C, layers=layers, activation=activation, param=1.0, output_mode="density:direct",
+                                    grid=grid, seed=1234, box_min=(-0.5, -0.5, -0.5), grid_scale=0.01, time_grids=time_keys)
+
+
+def make_network(volnet_io, capi, cfg, activation, time_keys=1):
     C, layers, grid, *_ = cfg
-    vn = util.random_network(C=C, layers=layers, activation=activation, param=1.0, output_mode="density:direct",
-                             grid=grid, seed=1234, box_min=(-0.5, -0.5, -0.5), grid_scale=0.01, time_grids=time_keys)
+    vn = bench_network(C, layers, grid, activation, time_keys)
     return vn, capi.Network.from_volnet(volnet_io.save_volnet(vn))
 
 
@@ -95,6 +104,13 @@ class Runner:
             self.gather_done = [torch.cuda.Event() for _ in range(2)]
         if self.pipelined:
             self.scenes = [self.scene, capi.Scene(**build_scene_kwargs(capi, 0.0, self.stepsize, early_out))]
+            # First use of a network handle (upload of the LDS image and the key frames, include/fvsrn.h) is ordered on the
+            # stream of the call that triggers it only: do it once here, untimed, and let both render streams start behind it.
+            if world == 1:
+                self.scene.render(net, self.W, self.H, out=self.outs[0])
+            else:
+                capi.render_stripes(self.scene, net, self.W, self.H, STRIPE, rank, world, out=self.local[0])
+            torch.cuda.synchronize()
             self.render_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
             for st in self.render_streams:
                 st.wait_stream(torch.cuda.current_stream())
@@ -186,7 +202,7 @@ def timed_run(runner, steps, warmup, distributed, spinup_ms=0.0):
     return dt, kernel_ms, int(st[0]), int(st[1])
 
 
-def cpu_baseline(util, cfg, activation):
+def cpu_baseline(cfg, activation):
     """The reference's PyTorch path (port: oracle/torch_port.py) on the host cores, bounded sample."""
     from oracle import torch_port
     from fvsrn_amd import capi
@@ -291,6 +307,48 @@ def pmc_traffic(workload):
     return 1024.0 * (vals["WRITE_SIZE"] + 2.0 * vals["FETCH_SIZE"])  # bytes per launch
 
 
+def dist_world_size(distributed):
+    if not distributed:
+        return 1
+    import torch.distributed as dist
+    return dist.get_world_size()
+
+
+def launch_ranks(n, argv, child=None):
+    """`python bench.py --gpus N` without a launcher around it: start N rank processes (fresh interpreters, one per GPU, RCCL
+    rendezvous on 127.0.0.1), relay rank 0's JSON line and return the worst exit code.  This process never initialises a GPU
+    (torch.cuda.device_count() does not, on this image).  Fewer than N visible GPUs is an error, not a silent 1-GPU run --
+    unless FVSRN_BENCH_BACKEND=gloo, the test mode in which all ranks share the visible GPU(s).
+    child: command prefix of a rank process (tests substitute a stand-in); default = this script."""
+    backend = os.environ.get("FVSRN_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        print("bench.py --gpus %d: only %d GPU(s) visible, one per rank is required" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = list(child) if child else [sys.executable, os.path.abspath(__file__)]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:  # rank 0 is gone and this one hangs in a collective: end exactly this process
+            p.kill()
+            rcs.append(p.wait())
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    return 0 if not bad else (bad[0] if bad[0] > 0 else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,15 +371,22 @@ def main():
             raise SystemExit("bench.py needs a GPU: the HIP kernels have no CPU fallback")
         return grid_volume_bench(args.grid_res, args.grid_size, args.grid_interpolation, 64, not args.no_cpu_baseline)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started plainly with --gpus N: this process becomes the launcher of N rank processes and never touches a GPU itself
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP kernels have no CPU fallback")
     # FVSRN_BENCH_BACKEND=gloo lets the N>1 orchestration be exercised on a box with ONE GPU (all ranks share it);
     # the driver's multi-GPU runs use the default "nccl" (= RCCL over xGMI), one rank per GPU.
     backend = os.environ.get("FVSRN_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible, one per rank is required" % (world, torch.cuda.device_count()))
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
     if distributed:
@@ -331,15 +396,14 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend=backend)
-    assert world == args.gpus or not distributed, "--gpus must equal WORLD_SIZE"
+        assert dist.get_world_size() == args.gpus
 
-    import util
     import fvsrn_amd  # noqa: F401
     from fvsrn_amd import capi, volnet_io
 
     cfg = CONFIGS[args.config]
     time_keys = TIME_KEYS.get(args.config, 1)
-    vn, net = make_network(util, volnet_io, capi, cfg, args.activation, time_keys)
+    vn, net = make_network(volnet_io, capi, cfg, args.activation, time_keys)
     info = net.info()
     runner = Runner(capi, net, cfg, rank, world, args.early_out, time_keys)
     dt, kernel_ms, evaluated, executed = timed_run(runner, args.steps, args.warmup, distributed, args.spinup_ms)
@@ -375,10 +439,10 @@ def main():
     twin = None
     if not args.no_twin and not distributed:
         other = "SnakeAlt" if args.activation == "ReLU" else "ReLU"
-        _, net2 = make_network(util, volnet_io, capi, cfg, other, time_keys)
+        _, net2 = make_network(volnet_io, capi, cfg, other, time_keys)
         r2 = Runner(capi, net2, cfg, rank, world, args.early_out, time_keys)
-        dt2, k2, ev2, ex2 = timed_run(r2, max(4, args.steps // 4), 2, False)
-        twin = {"activation": other, "value": ev2 / dt2, "unit": "samples/s", "ms_per_step": 1e3 * dt2 / max(4, args.steps // 4),
+        dt2, k2, ev2, ex2 = timed_run(r2, args.steps, args.warmup, False)  # the same step counts as the primary
+        twin = {"activation": other, "value": ev2 / dt2, "unit": "samples/s", "ms_per_step": 1e3 * dt2 / args.steps, "steps": args.steps,
                 "kernel": net2.kernel_name(True),
                 "mfma_frac": (ev2 * info.flops_per_sample / (sum(k2) * 1e-3)) / (MFMA_F16_PEAK_TFLOPS * 1e12)}
 
@@ -391,6 +455,7 @@ def main():
         achieved = flops_per_launch / kernel_s / 1e12
         out = {
             "metric": "srn_samples_per_s", "value": evaluated / dt, "unit": "samples/s", "n_gpus": world,
+            "world_size": dist_world_size(distributed), "backend": backend if distributed else None,
             "steps": args.steps, "warmup": args.warmup, "spinup_ms": args.spinup_ms, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "%s: %dx%d, %d steps/ray, %d-wide x %d-layer fp16 SRN%s, %s, density:direct + Identity TF, "
@@ -413,7 +478,7 @@ def main():
         if twin:
             out["twin"] = twin
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(util, cfg, args.activation)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.activation)
         print(json.dumps(out))
     if distributed:
         import torch.distributed as dist

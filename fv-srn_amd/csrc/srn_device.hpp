@@ -59,8 +59,19 @@ __device__ __forceinline__ float act_f32(float x, float a, float b) {
     }
 }
 
+// Two activations.  Measured on MI355X (tools/microbench/r02_issue.hip, profiles/r02/microbench_issue_model_r02.md): packed
+// fp32 instructions (v_pk_mul/add/fma_f32) do not run beside the SIMD's matrix pipe -- one of them behind an MFMA costs ~7.5
+// cycles, and a partner wave issues 0.25 of them per MFMA of this wave against 2 - 4 scalar fp32 instructions -- so the hot loops
+// use the scalar forms (FVSRN_PK_F32=1 restores the packed ones: 2 values per instruction, fewer issue slots without MFMAs around).
+#ifndef FVSRN_PK_F32
+#define FVSRN_PK_F32 0
+#endif
 template <int ACT>
 __device__ __forceinline__ float2_t act_f32x2(float2_t x, float a, float b) {
+#if !FVSRN_PK_F32
+    if constexpr (ACT == ACT_RELU || ACT == ACT_RELU01) return float2_t{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+    else return float2_t{act_f32<ACT>(x[0], a, b), act_f32<ACT>(x[1], a, b)};
+#else
     if constexpr (ACT == ACT_SINE) {
         const float2_t t = x * a;
         return float2_t{__builtin_amdgcn_sinf(t[0]), __builtin_amdgcn_sinf(t[1])};
@@ -80,6 +91,7 @@ __device__ __forceinline__ float2_t act_f32x2(float2_t x, float a, float b) {
     } else {
         return float2_t{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
     }
+#endif
 }
 
 // 16 fp32 accumulator values of one M tile -> two B fragments (K steps 2m, 2m+1) with activation
@@ -500,6 +512,25 @@ __device__ __forceinline__ void fourier_advance_piece(floatx16 (&f)[2][mtiles(CD
     constexpr int MT = mtiles(CD);
     constexpr int NPASS = HAS_DIR ? 4 : 2;
     const int t = c / (8 * MT), m = (c / 8) % MT, k = c % 8;
+#if !FVSRN_PK_F32
+    // scalar fp32 (see act_f32x2): c' = c cd - s sd, s' = s cd + c sd as 2 v_mul + 2 v_fma; pinned with asm so that hipcc's
+    // SLP vectorizer does not fuse them back into v_pk_*_f32
+    float cs_ = f[t][m][2 * k], sn = f[t][m][2 * k + 1];
+    const float cd = d[t][m][2 * k], sd = d[t][m][2 * k + 1];
+    if (m == 0 && 2 * k < NPASS) {
+        asm("v_add_f32 %0, %1, %2" : "=v"(cs_) : "v"(cs_), "v"(cd));
+        asm("v_add_f32 %0, %1, %2" : "=v"(sn) : "v"(sn), "v"(sd));
+    } else {
+        float t0, t1;
+        asm("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(cs_), "v"(cd));
+        asm("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(sn), "v"(cd));
+        asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(t0) : "v"(sn), "v"(sd), "v"(t0));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(cs_), "v"(sd), "v"(t1));
+        cs_ = t0; sn = t1;
+    }
+    f[t][m][2 * k] = cs_;
+    f[t][m][2 * k + 1] = sn;
+#else
     float2_t cs = {f[t][m][2 * k], f[t][m][2 * k + 1]};
     const float2_t dd = {d[t][m][2 * k], d[t][m][2 * k + 1]};
     if (m == 0 && 2 * k < NPASS) {
@@ -512,6 +543,7 @@ __device__ __forceinline__ void fourier_advance_piece(floatx16 (&f)[2][mtiles(CD
     }
     f[t][m][2 * k] = cs[0];
     f[t][m][2 * k + 1] = cs[1];
+#endif
 }
 
 // The network behind the input features, for the 64 samples of this wave: returns the raw last-layer outputs (before
@@ -855,6 +887,9 @@ __device__ __forceinline__ float4_t srn_forward_rotating(const NetParams& P, con
 // blocks), their address arithmetic and their waits, and the bias block enters as the C operand of each tile's first MFMA
 // instead of passing through the accumulator registers.  Measured r01 on the headline frame with the LDS reads of the
 // 3-wave kernel ablated: 126.7 -> 145.6 Gsamples/s at 3 waves, 140.6 at 2 waves (what fits), tools/ablate.sh.
+#ifndef FVSRN_SLOT_ORDER
+#define FVSRN_SLOT_ORDER 0
+#endif
 template <int NLC>
 struct ResidentNet {
     half8_t w[2 * (NLC + 1)];  // [layer 0 | hidden 1..NLC-1 | last][K step]
@@ -905,8 +940,20 @@ __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, cons
     // half-layer slot: layer l for tile T || activation + convert of the other tile
     auto slot = [&](auto tileTag, auto layerTag) {
         constexpr int T = decltype(tileTag)::value, O = 1 - T, L = decltype(layerTag)::value;
+#if FVSRN_SLOT_ORDER == 1
+        // both MFMAs of the slot first: the other tile's accumulators (its last MFMA was issued just before this slot) are
+        // complete by the time the converts start, and the converts run in the shadow of this slot's second MFMA
+        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.w[2 * L], xb[T][0], R.b[L], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.w[2 * L + 1], xb[T][1], acc[T], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) act_pack_quarter<ACT>(acc[O], q, actA, actB, xb[O][0], xb[O][1]);
+        __builtin_amdgcn_sched_barrier(0);
+#else
         interleave<2, 4>([&](int i) { acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.w[2 * L + i], xb[T][i], i == 0 ? R.b[L] : acc[T], 0, 0, 0); },
                          [&](int q) { act_pack_quarter<ACT>(acc[O], q, actA, actB, xb[O][0], xb[O][1]); });
+#endif
     };
     using T0 = std::integral_constant<int, 0>;
     using T1 = std::integral_constant<int, 1>;

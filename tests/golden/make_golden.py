@@ -160,134 +160,54 @@ def save_case(name, net, opt, pos, extra_meta=None, times=None, **arrays):
 
 ONLY = []  # fixture name prefixes given on the command line: write only those (the others stay byte-identical)
 
+# Every fixture is seeded from its NAME, never from its place in this script, so that adding a fixture cannot change
+# another one: new fixtures take crc32(name); the fixtures of round 1 keep the seeds they were generated with (they came
+# from a running counter then, which is frozen into this table).  `make_golden.py --check` regenerates everything into a
+# temporary directory and compares it with the committed files (tests/test_golden_reproducible.py runs that where
+# /root/reference exists).
+_R1 = {}
+_g1a = ["g1_c32l4_%s_%s" % (a, m) for a in ("relu", "snakealt", "sine", "snake") for m in ("density", "density-direct", "rgbo", "rgbo-direct")]
+_g1rest = ["g1_c32l4_grid16r8_relu_density", "g1_c32l4_grid16r8_snakealt_rgbo", "g1_c32l4_grid16r16_snakealt_density-direct",
+           "g1_c32l3_grid32r8_sine_density", "g1_c64l6_grid16r8_snakealt_density-direct", "g1_c48l3_grid16r8_snake_rgbo-direct",
+           "g1_c64l6_relu_density", "g1_c48l4_snakealt_density-direct", "g1_c64l2_sine_rgbo",
+           "g1_dir1_c32l4_snakealt_rgbo", "g1_dir2_c32l4_relu_density", "g1_dir2_c64l3_grid16r8_sine_rgbo-direct",
+           "g1_nofourier_c32l4_snakealt_density", "g1_nofourier_c64l2_relu_rgbo", "g1_nofourier_c48l3_sine_density-direct",
+           "g1_nofourier_dir_c32l3_snake_rgbo-direct"]
+for _i, _n in enumerate(_g1a + _g1rest):
+    _R1[_n] = _i + 1
+# generated before the no-Fourier section existed: their counter values then
+_R1.update({"g2_time3_c32l4_grid16r8": 29, "g2_time3_ens2_c32l4_grid32r8": 30, "g2_time3_passtime_c32l4_grid16r8": 31,
+            "g3_trace_rgbo_32x32": 32})
+_R1_SIGMOID = {"g1_sigmoid_c32l4_density": 700 + len("g1_sigmoid_c32l4_density"),
+               "g1_sigmoid_c64l3_grid16r8_rgbo-direct": 700 + len("g1_sigmoid_c64l3_grid16r8_rgbo-direct")}
 
-def main():
-    ONLY[:] = sys.argv[1:]
-    SRN, Raytracing = import_reference()
-    N = 1024
 
-    # ---- G1a: 32x4 Fourier-only, all activations x output modes ------------------------------------
-    k = 0
-    for act in ["ReLU", "SnakeAlt:1", "Sine:1", "Snake:2"]:
-        for om in ["density", "density:direct", "rgbo", "rgbo:direct"]:
-            k += 1
-            std = -1 if k % 2 else 0.6  # alternate NeRF block-identity and random gaussian matrices
-            net, opt = make_network(SRN, layers="32:32:32", activation=act, fouriercount=14, fourierstd=std,
-                                    outputmode=om, seed=100 + k)
-            pos = positions(N, 0, k)
-            save_case("g1_c32l4_%s_%s" % (act.split(":")[0].lower(), om.replace(":", "-")), net, opt, pos,
-                      out_fp32=forward(net, pos), out_fp16=forward(net, pos, half=True))
+def seeds(name):
+    """(network seed, position seed, direction seed) of fixture `name`"""
+    if name in _R1:
+        k = _R1[name]
+        return 100 + k, k, 1000 + k
+    if name in _R1_SIGMOID:
+        return _R1_SIGMOID[name], 70, 0
+    import zlib
+    c = zlib.crc32(name.encode())
+    return c & 0x7fffffff, (c >> 3) & 0x7fffffff, (c >> 7) & 0x7fffffff
 
-    # ---- G1f: Sigmoid hidden activation (torch.nn.Sigmoid -> Layer::Activation::Sigmoid) -----------------------
-    for name, kw in [
-        ("g1_sigmoid_c32l4_density", dict(layers="32:32:32", outputmode="density", F=14, std=-1)),
-        ("g1_sigmoid_c64l3_grid16r8_rgbo-direct", dict(layers="64:64", outputmode="rgbo:direct", F=30, std=0.6, gc=16, gr=8)),
-    ]:
-        net, opt = make_network(SRN, layers=kw["layers"], activation="Sigmoid", fouriercount=kw["F"], fourierstd=kw["std"],
-                                outputmode=kw["outputmode"], grid_channels=kw.get("gc", 0), grid_res=kw.get("gr", 0), seed=700 + len(name))
-        pos = positions(N, 0, 70)
-        save_case(name, net, opt, pos, out_fp32=forward(net, pos), out_fp16=forward(net, pos, half=True))
 
-    # ---- G1b: latent grids ------------------------------------------------------------------------
-    for name, kw in [
-        ("g1_c32l4_grid16r8_relu_density", dict(layers="32:32:32", activation="ReLU", outputmode="density", gc=16, gr=8)),
-        ("g1_c32l4_grid16r8_snakealt_rgbo", dict(layers="32:32:32", activation="SnakeAlt:1", outputmode="rgbo", gc=16, gr=8)),
-        ("g1_c32l4_grid16r16_snakealt_density-direct", dict(layers="32:32:32", activation="SnakeAlt:1", outputmode="density:direct", gc=16, gr=16)),
-        ("g1_c32l3_grid32r8_sine_density", dict(layers="32:32", activation="Sine:1", outputmode="density", gc=32, gr=8)),
-        ("g1_c64l6_grid16r8_snakealt_density-direct", dict(layers="64:64:64:64:64", activation="SnakeAlt:1", outputmode="density:direct", gc=16, gr=8, F=30)),
-        ("g1_c48l3_grid16r8_snake_rgbo-direct", dict(layers="48:48", activation="Snake:2", outputmode="rgbo:direct", gc=16, gr=8, F=22)),
-    ]:
-        k += 1
-        net, opt = make_network(SRN, layers=kw["layers"], activation=kw["activation"], fouriercount=kw.get("F", 14),
-                                fourierstd=-1, outputmode=kw["outputmode"], grid_channels=kw["gc"], grid_res=kw["gr"],
-                                seed=100 + k)
-        pos = positions(N, kw["gr"], k)
-        save_case(name, net, opt, pos, out_fp32=forward(net, pos), out_fp16=forward(net, pos, half=True))
+def rand_dirs(n, seed):
+    rng = np.random.RandomState(seed)
+    dirs = rng.randn(n, 3)
+    return (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float16).astype(np.float32)
 
-    # ---- G1c: wider / deeper without grid -------------------------------------------------------------
-    for name, kw in [
-        ("g1_c64l6_relu_density", dict(layers="64:64:64:64:64", activation="ReLU", outputmode="density", F=30)),
-        ("g1_c48l4_snakealt_density-direct", dict(layers="48:48:48", activation="SnakeAlt:1", outputmode="density:direct", F=22)),
-        ("g1_c64l2_sine_rgbo", dict(layers="64", activation="Sine:1", outputmode="rgbo", F=30)),
-    ]:
-        k += 1
-        net, opt = make_network(SRN, layers=kw["layers"], activation=kw["activation"], fouriercount=kw["F"],
-                                fourierstd=0.5, outputmode=kw["outputmode"], seed=100 + k)
-        pos = positions(N, 0, k)
-        save_case(name, net, opt, pos, out_fp32=forward(net, pos), out_fp16=forward(net, pos, half=True))
 
-    # ---- G1d: view direction as network input (USE_DIRECTION 1 and 2) ---------------------------------------
-    for name, kw in [
-        ("g1_dir1_c32l4_snakealt_rgbo", dict(layers="32:32:32", activation="SnakeAlt:1", outputmode="rgbo", F=12, dif=False)),
-        ("g1_dir2_c32l4_relu_density", dict(layers="32:32:32", activation="ReLU", outputmode="density", F=12, dif=True)),
-        ("g1_dir2_c64l3_grid16r8_sine_rgbo-direct", dict(layers="64:64", activation="Sine:1", outputmode="rgbo:direct", F=28, dif=True, gc=16, gr=8)),
-    ]:
-        k += 1
-        net, opt = make_network(SRN, layers=kw["layers"], activation=kw["activation"], fouriercount=kw["F"], fourierstd=0.5,
-                                outputmode=kw["outputmode"], grid_channels=kw.get("gc", 0), grid_res=kw.get("gr", 0),
-                                use_direction=True, direction_in_fourier=kw["dif"], seed=100 + k)
-        pos = positions(N, kw.get("gr", 0), k)
-        rng = np.random.RandomState(1000 + k)
-        dirs = rng.randn(N, 3)
-        dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float16).astype(np.float32)
-        save_case(name, net, opt, pos, directions=dirs, out_fp32=forward(net, pos, directions=dirs),
-                  out_fp16=forward(net, pos, half=True, directions=dirs))
-
-    # ---- G1e: no Fourier features: scalar first layer 3|6 -> C (renderer_volume_tensorcores.cuh:810-823) -------------
-    for name, kw in [
-        ("g1_nofourier_c32l4_snakealt_density", dict(layers="32:32:32", activation="SnakeAlt:1", outputmode="density")),
-        ("g1_nofourier_c64l2_relu_rgbo", dict(layers="64", activation="ReLU", outputmode="rgbo")),  # first + last layer only
-        ("g1_nofourier_c48l3_sine_density-direct", dict(layers="48:48", activation="Sine:1", outputmode="density:direct")),
-        ("g1_nofourier_dir_c32l3_snake_rgbo-direct", dict(layers="32:32", activation="Snake:2", outputmode="rgbo:direct", dir=True)),
-    ]:
-        k += 1
-        net, opt = make_network(SRN, layers=kw["layers"], activation=kw["activation"], fouriercount=0, fourierstd=-1,
-                                outputmode=kw["outputmode"], use_direction=kw.get("dir", False), direction_in_fourier=False,
-                                seed=100 + k)
-        pos = positions(N, 0, k)
-        if kw.get("dir"):
-            rng = np.random.RandomState(1000 + k)
-            dirs = rng.randn(N, 3)
-            dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float16).astype(np.float32)
-            save_case(name, net, opt, pos, directions=dirs, out_fp32=forward(net, pos, directions=dirs),
-                      out_fp16=forward(net, pos, half=True, directions=dirs))
-        else:
-            save_case(name, net, opt, pos, out_fp32=forward(net, pos), out_fp16=forward(net, pos, half=True))
-
-    # ---- G2: time-dependent / ensemble latent grids ---------------------------------------------------
-    times = [0.0, 0.25, 1.0, 1.75, 2.0]
-    k += 1
-    net, opt = make_network(SRN, layers="32:32:32", activation="SnakeAlt:1", fouriercount=14, fourierstd=-1,
-                            outputmode="density:direct", grid_channels=16, grid_res=8, time_dependent=True,
-                            time_features=16, ensemble_features=0, num_time=3, seed=100 + k)
-    pos = positions(512, 8, k)
-    save_case("g2_time3_c32l4_grid16r8", net, opt, pos, extra_meta={"times": times},
-              out_fp32=np.stack([forward(net, pos, time=t) for t in times]))
-    k += 1
-    net, opt = make_network(SRN, layers="32:32:32", activation="ReLU", fouriercount=14, fourierstd=-1,
-                            outputmode="density", grid_channels=32, grid_res=8, time_dependent=True,
-                            time_features=16, ensemble_features=16, num_time=3, num_ens=2, seed=100 + k)
-    pos = positions(512, 8, k)
-    te = [(0.5, 0), (1.5, 1), (2.0, 1)]
-    save_case("g2_time3_ens2_c32l4_grid32r8", net, opt, pos, extra_meta={"time_ensemble": te},
-              out_fp32=np.stack([forward(net, pos, time=t, ensemble=e) for t, e in te]))
-    k += 1
-    net, opt = make_network(SRN, layers="32:32:32", activation="SnakeAlt:1", fouriercount=14, fourierstd=-1,
-                            outputmode="density:direct", grid_channels=16, grid_res=8, time_dependent=True,
-                            time_features=16, ensemble_features=0, num_time=3, use_time_direct=True, seed=100 + k)
-    pos = positions(512, 8, k)
-    save_case("g2_time3_passtime_c32l4_grid16r8", net, opt, pos, extra_meta={"times": times},
-              out_fp32=np.stack([forward(net, pos, time=t) for t in times]))
-
-    # ---- G3: rgbo ray march with explicit rays (Raytracing._full_trace_forward) ------------------------
-    k += 1
-    net, opt = make_network(SRN, layers="32:32:32", activation="SnakeAlt:1", fouriercount=14, fourierstd=0.35,
-                            outputmode="rgbo", seed=100 + k)
-    W = H = 32
-    stepsize = 1.0 / 48
+def trace_case(SRN, Raytracing, name, *, activation, fourierstd, W, H, stepsize, pitch=0.4, yaw=0.7, distance=1.6):
+    """rgbo ray march with explicit rays through Raytracing._full_trace_forward (raytracing.py:275-329)."""
+    ns, _, _ = seeds(name)
+    net, opt = make_network(SRN, layers="32:32:32", activation=activation, fouriercount=14, fourierstd=fourierstd,
+                            outputmode="rgbo", seed=ns)
     box_min, box_size = np.array([-0.5, -0.5, -0.5], np.float32), np.array([1, 1, 1], np.float32)
-    # CameraOnASphere(Ym, center 0, pitch 0.4, yaw 0.7, distance 1.6), fovY 45 deg -- computed here in numpy
-    eye, right, up = camera_frame(pitch=0.4, yaw=0.7, distance=1.6)
+    # CameraOnASphere(Ym, center 0), fovY 45 deg -- computed here in numpy
+    eye, right, up = camera_frame(pitch=pitch, yaw=yaw, distance=distance)
     fov = np.deg2rad(45.0)
     ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
     ndcx = (2 * (xs + 0.5) / W - 1).astype(np.float32)
@@ -314,10 +234,180 @@ def main():
     with torch.no_grad():
         img = rt._full_trace_forward(net, torch.from_numpy(start)[None], torch.from_numpy(d)[None], None, False, True,
                                      [z, z, z, "screen"])
-    save_case("g3_trace_rgbo_32x32", net, opt, np.zeros((1, 3), np.float32),
-              extra_meta={"W": W, "H": H, "stepsize": stepsize, "fov_y": float(fov), "pitch": 0.4, "yaw": 0.7,
-                          "distance": 1.6, "orientation": "Ym", "box_min": box_min.tolist(), "box_size": box_size.tolist()},
+    save_case(name, net, opt, np.zeros((1, 3), np.float32),
+              extra_meta={"W": W, "H": H, "stepsize": stepsize, "fov_y": float(fov), "pitch": pitch, "yaw": yaw,
+                          "distance": distance, "orientation": "Ym", "box_min": box_min.tolist(), "box_size": box_size.tolist()},
               ray_start=start, ray_dir=d, image=img.numpy()[0], eye=eye, right=right, up=up)
+
+
+def main():
+    global OUT
+    args = sys.argv[1:]
+    if args and args[0] == "--check":
+        return check(args[1:])
+    ONLY[:] = args
+    generate()
+
+
+def check(only):
+    """Regenerates every fixture into a temporary directory and compares it, array by array, with the committed file."""
+    global OUT
+    import glob
+    import tempfile
+    committed = OUT
+    ONLY[:] = only
+    with tempfile.TemporaryDirectory() as tmp:
+        OUT = tmp
+        generate()
+        OUT = committed
+        bad = []
+        made = sorted(os.path.basename(f) for f in glob.glob(os.path.join(tmp, "*.npz")))
+        have = sorted(os.path.basename(f) for f in glob.glob(os.path.join(committed, "*.npz")) if not only or any(
+            os.path.basename(f).startswith(o) for o in only))
+        if made != have:
+            bad.append("fixture sets differ: generated %s, committed %s" % (sorted(set(made) - set(have)), sorted(set(have) - set(made))))
+        for f in made:
+            if f not in have:
+                continue
+            a, b = dict(np.load(os.path.join(tmp, f))), dict(np.load(os.path.join(committed, f)))
+            ma, mb = json.loads(bytes(a.pop("meta")).decode()), json.loads(bytes(b.pop("meta")).decode())
+            ma.pop("torch", None), mb.pop("torch", None)
+            if ma != mb:
+                bad.append("%s: meta differs" % f)
+            if sorted(a) != sorted(b):
+                bad.append("%s: arrays %s vs %s" % (f, sorted(a), sorted(b)))
+                continue
+            for k in a:
+                if a[k].shape != b[k].shape or not np.array_equal(a[k], b[k], equal_nan=True):
+                    bad.append("%s: array %s differs" % (f, k))
+    if bad:
+        print("\n".join(bad))
+        raise SystemExit("make_golden.py --check: %d difference(s)" % len(bad))
+    print("make_golden.py --check: %d fixtures reproduce bit for bit" % len(made))
+
+
+def generate():
+    SRN, Raytracing = import_reference()
+    N = 1024
+
+    def simple(name, *, layers, activation, outputmode, F, std, gc=0, gr=0, **kw):
+        ns, ps, ds = seeds(name)
+        net, opt = make_network(SRN, layers=layers, activation=activation, fouriercount=F, fourierstd=std, outputmode=outputmode,
+                                grid_channels=gc, grid_res=gr, seed=ns, **kw)
+        pos = positions(N, gr if kw.get("pos_grid", True) else 0, ps)
+        if kw.get("use_direction"):
+            dirs = rand_dirs(N, ds)
+            save_case(name, net, opt, pos, directions=dirs, out_fp32=forward(net, pos, directions=dirs),
+                      out_fp16=forward(net, pos, half=True, directions=dirs))
+        else:
+            save_case(name, net, opt, pos, out_fp32=forward(net, pos), out_fp16=forward(net, pos, half=True))
+
+    # ---- G1a: 32x4 Fourier-only, all activations x output modes ------------------------------------
+    k = 0
+    for act in ["ReLU", "SnakeAlt:1", "Sine:1", "Snake:2"]:
+        for om in ["density", "density:direct", "rgbo", "rgbo:direct"]:
+            k += 1
+            std = -1 if k % 2 else 0.6  # alternate NeRF block-identity and random gaussian matrices
+            simple("g1_c32l4_%s_%s" % (act.split(":")[0].lower(), om.replace(":", "-")), layers="32:32:32", activation=act,
+                   outputmode=om, F=14, std=std)
+
+    # ---- G1f: Sigmoid hidden activation (torch.nn.Sigmoid -> Layer::Activation::Sigmoid) -----------------------
+    for name, kw in [
+        ("g1_sigmoid_c32l4_density", dict(layers="32:32:32", outputmode="density", F=14, std=-1)),
+        ("g1_sigmoid_c64l3_grid16r8_rgbo-direct", dict(layers="64:64", outputmode="rgbo:direct", F=30, std=0.6, gc=16, gr=8)),
+    ]:
+        ns, ps, _ = seeds(name)
+        net, opt = make_network(SRN, layers=kw["layers"], activation="Sigmoid", fouriercount=kw["F"], fourierstd=kw["std"],
+                                outputmode=kw["outputmode"], grid_channels=kw.get("gc", 0), grid_res=kw.get("gr", 0), seed=ns)
+        pos = positions(N, 0, ps)
+        save_case(name, net, opt, pos, out_fp32=forward(net, pos), out_fp16=forward(net, pos, half=True))
+
+    # ---- G1b: latent grids ------------------------------------------------------------------------
+    for name, kw in [
+        ("g1_c32l4_grid16r8_relu_density", dict(layers="32:32:32", activation="ReLU", outputmode="density", gc=16, gr=8)),
+        ("g1_c32l4_grid16r8_snakealt_rgbo", dict(layers="32:32:32", activation="SnakeAlt:1", outputmode="rgbo", gc=16, gr=8)),
+        ("g1_c32l4_grid16r16_snakealt_density-direct", dict(layers="32:32:32", activation="SnakeAlt:1", outputmode="density:direct", gc=16, gr=16)),
+        ("g1_c32l3_grid32r8_sine_density", dict(layers="32:32", activation="Sine:1", outputmode="density", gc=32, gr=8)),
+        ("g1_c64l6_grid16r8_snakealt_density-direct", dict(layers="64:64:64:64:64", activation="SnakeAlt:1", outputmode="density:direct", gc=16, gr=8, F=30)),
+        ("g1_c48l3_grid16r8_snake_rgbo-direct", dict(layers="48:48", activation="Snake:2", outputmode="rgbo:direct", gc=16, gr=8, F=22)),
+        # round 2: the grid size of BASELINE.json configs[3] / [4] (64-wide x 6 layers, 16 channels at 32^3)
+        ("g1_c64l6_grid16r32_relu_density-direct", dict(layers="64:64:64:64:64", activation="ReLU", outputmode="density:direct", gc=16, gr=32, F=30)),
+    ]:
+        simple(name, layers=kw["layers"], activation=kw["activation"], outputmode=kw["outputmode"], F=kw.get("F", 14), std=-1,
+               gc=kw["gc"], gr=kw["gr"])
+
+    # ---- G1c: wider / deeper without grid -------------------------------------------------------------
+    for name, kw in [
+        ("g1_c64l6_relu_density", dict(layers="64:64:64:64:64", activation="ReLU", outputmode="density", F=30)),
+        ("g1_c48l4_snakealt_density-direct", dict(layers="48:48:48", activation="SnakeAlt:1", outputmode="density:direct", F=22)),
+        ("g1_c64l2_sine_rgbo", dict(layers="64", activation="Sine:1", outputmode="rgbo", F=30)),
+    ]:
+        simple(name, layers=kw["layers"], activation=kw["activation"], outputmode=kw["outputmode"], F=kw["F"], std=0.5)
+
+    # ---- G1d: view direction as network input (USE_DIRECTION 1 and 2) ---------------------------------------
+    for name, kw in [
+        ("g1_dir1_c32l4_snakealt_rgbo", dict(layers="32:32:32", activation="SnakeAlt:1", outputmode="rgbo", F=12, dif=False)),
+        ("g1_dir2_c32l4_relu_density", dict(layers="32:32:32", activation="ReLU", outputmode="density", F=12, dif=True)),
+        ("g1_dir2_c64l3_grid16r8_sine_rgbo-direct", dict(layers="64:64", activation="Sine:1", outputmode="rgbo:direct", F=28, dif=True, gc=16, gr=8)),
+    ]:
+        simple(name, layers=kw["layers"], activation=kw["activation"], outputmode=kw["outputmode"], F=kw["F"], std=0.5,
+               gc=kw.get("gc", 0), gr=kw.get("gr", 0), use_direction=True, direction_in_fourier=kw["dif"])
+
+    # ---- G1e: no Fourier features: scalar first layer 3|6 -> C (renderer_volume_tensorcores.cuh:810-823) -------------
+    for name, kw in [
+        ("g1_nofourier_c32l4_snakealt_density", dict(layers="32:32:32", activation="SnakeAlt:1", outputmode="density")),
+        ("g1_nofourier_c64l2_relu_rgbo", dict(layers="64", activation="ReLU", outputmode="rgbo")),  # first + last layer only
+        ("g1_nofourier_c48l3_sine_density-direct", dict(layers="48:48", activation="Sine:1", outputmode="density:direct")),
+        ("g1_nofourier_dir_c32l3_snake_rgbo-direct", dict(layers="32:32", activation="Snake:2", outputmode="rgbo:direct", dir=True)),
+    ]:
+        simple(name, layers=kw["layers"], activation=kw["activation"], outputmode=kw["outputmode"], F=0, std=-1,
+               use_direction=kw.get("dir", False), direction_in_fourier=False)
+
+    # ---- G2: time-dependent / ensemble latent grids ---------------------------------------------------
+    times = [0.0, 0.25, 1.0, 1.75, 2.0]
+    name = "g2_time3_c32l4_grid16r8"
+    ns, ps, _ = seeds(name)
+    net, opt = make_network(SRN, layers="32:32:32", activation="SnakeAlt:1", fouriercount=14, fourierstd=-1,
+                            outputmode="density:direct", grid_channels=16, grid_res=8, time_dependent=True,
+                            time_features=16, ensemble_features=0, num_time=3, seed=ns)
+    pos = positions(512, 8, ps)
+    save_case(name, net, opt, pos, extra_meta={"times": times},
+              out_fp32=np.stack([forward(net, pos, time=t) for t in times]))
+    name = "g2_time3_ens2_c32l4_grid32r8"
+    ns, ps, _ = seeds(name)
+    net, opt = make_network(SRN, layers="32:32:32", activation="ReLU", fouriercount=14, fourierstd=-1,
+                            outputmode="density", grid_channels=32, grid_res=8, time_dependent=True,
+                            time_features=16, ensemble_features=16, num_time=3, num_ens=2, seed=ns)
+    pos = positions(512, 8, ps)
+    te = [(0.5, 0), (1.5, 1), (2.0, 1)]
+    save_case(name, net, opt, pos, extra_meta={"time_ensemble": te},
+              out_fp32=np.stack([forward(net, pos, time=t, ensemble=e) for t, e in te]))
+    name = "g2_time3_passtime_c32l4_grid16r8"
+    ns, ps, _ = seeds(name)
+    net, opt = make_network(SRN, layers="32:32:32", activation="SnakeAlt:1", fouriercount=14, fourierstd=-1,
+                            outputmode="density:direct", grid_channels=16, grid_res=8, time_dependent=True,
+                            time_features=16, ensemble_features=0, num_time=3, use_time_direct=True, seed=ns)
+    pos = positions(512, 8, ps)
+    save_case(name, net, opt, pos, extra_meta={"times": times},
+              out_fp32=np.stack([forward(net, pos, time=t) for t in times]))
+    # round 2: the key-frame count of BASELINE.json configs[4] (16 time key frames, 64-wide x 6 layers)
+    name = "g2_time16_c64l6_grid16r8"
+    times16 = [0.0, 0.25, 3.5, 7.75, 14.25, 15.0]
+    ns, ps, _ = seeds(name)
+    net, opt = make_network(SRN, layers="64:64:64:64:64", activation="ReLU", fouriercount=30, fourierstd=-1,
+                            outputmode="density:direct", grid_channels=16, grid_res=8, time_dependent=True,
+                            time_features=16, ensemble_features=0, num_time=16, seed=ns)
+    pos = positions(512, 8, ps)
+    save_case(name, net, opt, pos, extra_meta={"times": times16},
+              out_fp32=np.stack([forward(net, pos, time=t) for t in times16]))
+
+    # ---- G3: rgbo ray march with explicit rays (Raytracing._full_trace_forward) ------------------------
+    trace_case(SRN, Raytracing, "g3_trace_rgbo_32x32", activation="SnakeAlt:1", fourierstd=0.35, W=32, H=32, stepsize=1.0 / 48)
+    # round 2 (g3b): step 1/512 through the unit box with the NeRF ladder (--fourierstd -1), i.e. the sampling of the
+    # headline benchmark: rays of up to ~800 steps, which the HIP renderer's feature rotation follows across >= 8 exact
+    # re-derivations (srn_device.hpp, fourier_advance_piece)
+    trace_case(SRN, Raytracing, "g3b_trace_rgbo_64x64_s512_snakealt", activation="SnakeAlt:1", fourierstd=-1, W=64, H=64, stepsize=1.0 / 512)
+    trace_case(SRN, Raytracing, "g3b_trace_rgbo_64x64_s512_relu", activation="ReLU", fourierstd=-1, W=64, H=64, stepsize=1.0 / 512)
 
 
 def camera_frame(pitch, yaw, distance):

@@ -23,13 +23,12 @@ def draw_case(seed):
     act = str(rng.choice(["ReLU", "SnakeAlt", "Sine", "Snake", "Sigmoid"]))
     out = str(rng.choice(["density", "density:direct", "rgbo", "rgbo:direct", "densitygrad"]))
     grid = (16, int(rng.choice([4, 8]))) if rng.rand() < 0.35 else None
-    # Random weights behind a NeRF frequency ladder (2 pi 2^k) and a periodic activation are chaotic in the position: the fp16
-    # rounding of the positions (which the reference applies and the rotation path of the kernels does not)
-    # then moves colours by percents, in the oracle's own fp16 model by 0.14.  Periodic activations get the smooth random Fourier
-    # matrix and parameter 1 here; the ladder is drawn for the others.
-    periodic = act in ("Sine", "Snake", "SnakeAlt")
+    # NeRF frequency ladder (2 pi 2^k, network.py:55-63) or a smooth random Fourier matrix, for every activation.  Random weights
+    # behind the ladder and a periodic activation are sensitive to the position at the 1e-4 level: there the reference's own
+    # fp16 arithmetic (phases in half, renderer_volume_tensorcores.cuh:797-806) moves colours by percents against an fp32
+    # evaluation of the same network, see the tolerance in test_random_scene_matches_oracle.
     net = dict(C=C, layers=layers, activation=act, param=1.0, output_mode=out, grid=grid, seed=int(rng.randint(1 << 20)),
-               box_min=(-0.5, -0.5, -0.5), fourier_std=0.4 if periodic or rng.rand() < 0.5 else None)
+               box_min=(-0.5, -0.5, -0.5), fourier_std=0.4 if rng.rand() < 0.5 else None)
     eye, right, up = oracle.camera_on_a_sphere(str(rng.choice(["Ym", "Zp", "Xm"])), (0, 0, 0), float(rng.uniform(-0.6, 0.6)),
                                                float(rng.uniform(0, 6.28)), float(rng.uniform(1.2, 2.2)))
     scene = dict(eye=eye, right=right, up=up, fov_y_radians=float(rng.uniform(0.5, 1.0)), stepsize=float(1.0 / rng.choice([24, 48, 160])),
@@ -62,8 +61,9 @@ def draw_case(seed):
     return net, scene, W, H
 
 
-@pytest.mark.parametrize("seed", range(24))
-def test_random_scene_matches_oracle(seed):
+def compare_case(seed):
+    """-> (max |rgba+normal| difference GPU vs oracle fp32-accumulate model, the same between the oracle's fp16-accumulate
+    (reference CUDA arithmetic) and fp32-accumulate models, info string, img, ref, stats, count)"""
     import torch
     from fvsrn_amd import capi, volnet_io
     net_kw, scene_kw, W, H = draw_case(seed)
@@ -72,11 +72,31 @@ def test_random_scene_matches_oracle(seed):
     stats = torch.zeros(2, dtype=torch.int64, device="cuda")
     img = capi.Scene(**scene_kw).render(net, W, H, stats=stats)[0].cpu().numpy()
     ref, count = oracle.OracleScene(**scene_kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), W, H)
-    info = "%s | %s" % ({k: v for k, v in net_kw.items() if k != "box_min"}, {k: v for k, v in scene_kw.items() if k not in ("eye", "right", "up", "tf_table")})
+    ref_h, _ = oracle.OracleScene(**scene_kw).render(oracle.OracleNetwork(vn, oracle.ACC_HALF), W, H)
+    info = "%s | %s | %s" % ({k: v for k, v in net_kw.items() if k != "box_min"},
+                             {k: v for k, v in scene_kw.items() if k not in ("eye", "right", "up", "tf_table")}, net.kernel_name(True)[:32])
+    return float(np.abs(img[:7] - ref[:7]).max()), float(np.abs(ref_h[:7] - ref[:7]).max()), info, img, ref, stats.cpu().numpy(), count, scene_kw
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_scene_matches_oracle(seed):
+    """Tolerance: the image tolerance of test_gpu_parity.py (3e-3), or -- for networks on which the reference's own two arithmetic
+    models disagree by more than twice that -- half of the distance between the oracle's fp16-accumulate model (the reference's CUDA
+    arithmetic) and its fp32-accumulate model on this very image: the HIP path must sit closer to the fp32 evaluation of the network
+    than the reference's renderer does.  (The one modelled difference: between two exact re-derivations the register-resident
+    kernel's rotated Fourier features follow the un-rounded ray position, the reference rounds every position to fp16.)"""
+    err, spread, info, img, ref, stats, count, scene_kw = compare_case(seed)
     solid = ref[3] > 1e-4
-    assert np.abs(img[:7] - ref[:7]).max() < TOL_IMG, info
-    assert np.array_equal(np.isnan(img[7])[solid], np.isnan(ref[7])[solid]), info
-    if solid.any():
-        assert np.nanmax(np.abs(img[7] - ref[7])[solid]) < 3e-2, info
+    assert err < max(TOL_IMG, 0.5 * spread), "%s: |gpu - oracle| %.2e, oracle fp16 vs fp32 model %.2e" % (info, err, spread)
+    if err < TOL_IMG:
+        assert np.array_equal(np.isnan(img[7])[solid], np.isnan(ref[7])[solid]), info
+        if solid.any():
+            assert np.nanmax(np.abs(img[7] - ref[7])[solid]) < 3e-2, info
     if not scene_kw["early_out"]:
-        assert int(stats.cpu()[0]) == count, info  # lane-exact evaluated samples (early-out may stop a step apart at the threshold)
+        assert int(stats[0]) == count, info  # lane-exact evaluated samples (early-out may stop a step apart at the threshold)
+
+
+if __name__ == "__main__":  # developer report: python tests/test_fuzz_parity.py [n]  (GPU box)
+    for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 32):
+        err, spread, info, *_ = compare_case(seed)
+        print("%2d  gpu-oracle %.2e  fp16-vs-fp32 models %.2e  %s  %s" % (seed, err, spread, "OK" if err < max(TOL_IMG, 0.5 * spread) else "FAIL", info))

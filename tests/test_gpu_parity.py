@@ -127,8 +127,14 @@ def assert_images_close(img, ref, tol, y0=0, y1=None):
         assert np.abs(a[7][m] - b[7][m]).max() < 10 * tol
 
 
-def test_render_golden_trace_rgbo():
-    d, meta = util.load_golden("g3_trace_rgbo_32x32")
+@pytest.mark.parametrize("name", ["g3_trace_rgbo_32x32", "g3b_trace_rgbo_64x64_s512_snakealt", "g3b_trace_rgbo_64x64_s512_relu"])
+def test_render_golden_trace_rgbo(name):
+    """Reference-Python ray march (Raytracing._full_trace_forward, tests/golden/make_golden.py).  The g3b fixtures sample the
+    unit box at step 1/512 with the NeRF ladder -- the sampling of the headline benchmark: rays of up to ~800 steps, so the
+    register-resident kernel's feature rotation (srn_device.hpp, fourier_advance_piece) is followed across >= 8 exact
+    re-derivations and compared with the reference itself, not only with the restatement."""
+    from fvsrn_amd import capi, volnet_io
+    d, meta = util.load_golden(name)
     vn = util.golden_to_volnet(d, meta, box_min=meta["box_min"], box_size=meta["box_size"])
     kw = dict(eye=d["eye"], right=d["right"], up=d["up"], fov_y_radians=meta["fov_y"], stepsize=meta["stepsize"],
               early_out=False, tf_kind=oracle.TF_NONE)
@@ -138,6 +144,53 @@ def test_render_golden_trace_rgbo():
     assert diff.max() < TOL_IMG       # vs the reference's Python ray marcher
     assert_images_close(img, ref, TOL_IMG)
     assert stats[0] == count
+    if name.startswith("g3b"):
+        assert count > 64 * 64 * 256, "rays are too short to cross several resynchronisations"
+        assert "render_small_kernel" in capi.Network.from_volnet(volnet_io.save_volnet(vn)).kernel_name(True)
+
+
+@pytest.mark.parametrize("activation", ["ReLU", "SnakeAlt"])
+@pytest.mark.parametrize("config", ["c32l4_fourier", "c32l4_grid16", "c64l6_grid16r32"])
+def test_bench_networks_match_oracle_at_512_steps(config, activation):
+    """The exact networks bench.py times (seed 1234, NeRF ladder, density:direct + Identity TF, absorption 10, early-out off;
+    BASELINE.json configs[1..3]) at the benchmark's step size 1/512 against the oracle's fp32-accumulate model: 128 x 128 pixels
+    for the 32-wide networks, 64 x 64 for 64 x 6 + 32^3 grid.  c32l4_fourier takes the register-resident kernel with the
+    feature rotation, the grid networks the LDS kernel."""
+    import bench
+    from fvsrn_amd import capi, volnet_io
+    cfg = {"c32l4_fourier": (32, 4, None), "c32l4_grid16": (32, 4, (16, 16)), "c64l6_grid16r32": (64, 6, (16, 32))}[config]
+    vn = bench.bench_network(cfg[0], cfg[1], cfg[2], activation)
+    kw = bench.build_scene_kwargs(oracle, 0.0, 1.0 / 512, False)
+    size = 64 if cfg[0] == 64 else 128
+    img, ref, stats, count = render_both(vn, kw, size, size)
+    assert_images_close(img, ref, TOL_IMG)
+    assert stats[0] == count
+    assert img[3].max() > 0.25, "scene is empty, the comparison would be vacuous"
+    if config == "c32l4_fourier":
+        assert "render_small_kernel" in capi.Network.from_volnet(volnet_io.save_volnet(vn)).kernel_name(True)
+
+
+def test_bench_time_dependent_network_matches_oracle_at_three_times():
+    """BASELINE.json configs[4]: 64 x 6 network, 16 latent key frames of 16 channels at 32^3; bench.py advances the time by
+    0.25 key frames per frame.  ONE live network handle, three times (inside the first, a middle and the last key-frame
+    interval), 64 x 64 pixels at step 1/512, against the oracle."""
+    import torch
+    import bench
+    from fvsrn_amd import capi, volnet_io
+    vn = bench.bench_network(64, 6, (16, 32), "ReLU", time_keys=16)
+    kw = bench.build_scene_kwargs(oracle, 0.0, 1.0 / 512, False)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    scene = capi.Scene(**kw)
+    imgs = []
+    for t in (0.25, 7.5, 14.75):
+        net.set_time_and_ensemble(t, 0)
+        stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+        img = scene.render(net, 64, 64, stats=stats)[0].cpu().numpy()
+        ref, count = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT, time=t), 64, 64)
+        assert_images_close(img, ref, TOL_IMG)
+        assert int(stats.cpu()[0]) == count
+        imgs.append(img)
+    assert np.abs(imgs[0][:4] - imgs[1][:4]).max() > 1e-4 and np.abs(imgs[1][:4] - imgs[2][:4]).max() > 1e-4, "time has no effect"
 
 
 GAUSS_TF = np.array([[0.9, 0.1, 0.1, 30.0, 0.25, 0.08], [0.1, 0.9, 0.2, 60.0, 0.5, 0.05], [0.2, 0.3, 0.95, 90.0, 0.8, 0.1]], np.float32)
@@ -366,18 +419,24 @@ def test_render_camera_inside_box_and_missing_rays():
     assert stats[0] == count
 
 
-def test_full_size_properties_1024x512steps():
-    """BASELINE size (1024^2, 512 steps): properties that need no oracle run.
-    (a) evaluated sample counter == host count of the loop bound, (b) two row stripes == full frame,
-    (c) alpha in [0,1], finite colour."""
+@pytest.mark.parametrize("config", ["c32l4_fourier", "c32l4_grid16", "c64l6_grid16r32", "c64l6_grid16r32_time16"])
+def test_full_size_properties_1024x512steps(config):
+    """Every BASELINE.json configuration at its full size (1024^2, 512 steps, bench.py's network and scene): properties that need
+    no oracle run.  (a) evaluated sample counter == host count of the loop bound, (b) two row stripes == full frame,
+    (c) alpha in [0,1], finite colour; (d) time-dependent: the frame changes with the time, and returns when the time does."""
     import torch
+    import bench
     from fvsrn_amd import capi, volnet_io
-    vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density:direct", seed=1234, box_min=(-0.5, -0.5, -0.5))
-    kw = make_scene_kwargs(stepsize=1 / 512, early_out=False, tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=10.0)
+    C, layers, grid, keys = {"c32l4_fourier": (32, 4, None, 1), "c32l4_grid16": (32, 4, (16, 16), 1), "c64l6_grid16r32": (64, 6, (16, 32), 1),
+                            "c64l6_grid16r32_time16": (64, 6, (16, 32), 16)}[config]
+    vn = bench.bench_network(C, layers, grid, "ReLU", time_keys=keys)
+    kw = bench.build_scene_kwargs(oracle, 0.7, 1.0 / 512, False)
     net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
     scene = capi.Scene(**kw)
     stats = torch.zeros(2, dtype=torch.int64, device="cuda")
-    full = scene.render(net, 1024, 1024, stats=stats)
+    if keys > 1:
+        net.set_time_and_ensemble(3.25, 0)
+    full = scene.render(net, 1024, 1024, stats=stats).clone()
     halves = torch.zeros_like(full)
     scene.render(net, 1024, 1024, 0, 512, out=halves)
     scene.render(net, 1024, 1024, 512, 1024, out=halves)
@@ -398,6 +457,15 @@ def test_full_size_properties_1024x512steps():
     assert float((torch.nan_to_num(full[0, 7], nan=0.0) - torch.nan_to_num(halves[0, 7], nan=0.0))[solid].abs().max()) < 10 * TOL_IMG
     rgba = full[0, :4]
     assert torch.isfinite(rgba).all() and rgba[3].min() >= 0 and rgba[3].max() <= 1.0 + 1e-6
+    assert rgba[3].max() > 0.25
+    if keys > 1:
+        net.set_time_and_ensemble(11.5, 0)
+        other = scene.render(net, 1024, 1024).clone()
+        net.set_time_and_ensemble(3.25, 0)
+        back = scene.render(net, 1024, 1024)
+        torch.cuda.synchronize()
+        assert float((other[0, :4] - full[0, :4]).abs().max()) > 1e-4
+        assert torch.equal(torch.nan_to_num(back, nan=-1.0), torch.nan_to_num(full, nan=-1.0))
 
 
 def test_errors_are_reported():

@@ -47,35 +47,4 @@ def golden_to_volnet(d, meta, *, encoding=volnet_io.ENC_FLOAT, box_min=(0.0, 0.0
         has_time=meta.get("use_time_direct", False), has_direction=meta.get("use_direction", False))
 
 
-def random_network(*, C=32, layers=4, activation="SnakeAlt", param=1.0, output_mode="density:direct", grid=None,
-                   fourier_std=None, seed=0, box_min=(0.0, 0.0, 0.0), box_size=(1.0, 1.0, 1.0), encoding=volnet_io.ENC_FLOAT,
-                   grid_scale=0.3, time_grids=1, no_fourier=False):
-    """Seeded random SRN in the reference's shape conventions: nn.Linear default init U(+-1/sqrt(in)),
-    NeRF block-identity Fourier matrix (network.py:55-63) unless fourier_std is given; grid = (channels, res)."""
-    rng = np.random.RandomState(seed)
-    F = 0 if no_fourier else (C - 4) // 2
-    if no_fourier:
-        B = np.zeros((0, 3), np.float32)
-    elif fourier_std is None:
-        blocks = [(2.0 ** i) * np.eye(3) for i in range((F + 2) // 3)]
-        B = (np.concatenate(blocks, axis=0)[:F] * 2 * np.pi).astype(np.float32)
-    else:
-        B = (rng.randn(F, 3) * fourier_std * 2 * np.pi).astype(np.float32)
-    G = grid[0] if grid else 0
-    cout = 6 if output_mode.startswith("densitycurvature") else (
-        4 if output_mode.startswith("rgbo") or output_mode.startswith("densitygrad") else 1)
-    dims = [3 + 2 * F + G] + [C] * (layers - 1) + [cout]
-    weights, biases = [], []
-    for i in range(layers):
-        k = 1.0 / np.sqrt(dims[i])
-        weights.append(rng.uniform(-k, k, (dims[i + 1], dims[i])).astype(np.float32))
-        biases.append(rng.uniform(-k, k, dims[i + 1]).astype(np.float32))
-    if output_mode.startswith("rgbo"):  # reference network.py:404-405: positive rgba bias "to see something"
-        biases[-1] = np.abs(biases[-1]) + 1.0
-    tg = None
-    if grid:
-        tg = [(rng.randn(G, grid[1], grid[1], grid[1]) * grid_scale).astype(np.float32) for _ in range(time_grids)]
-    vn = volnet_io.build_volnet(fourier_B=B, weights=weights, biases=biases, activation=activation, activation_param=param,
-                                output_mode=output_mode, box_min=box_min, box_size=box_size, time_grids=tg,
-                                grid_encoding=encoding)
-    return vn
+from fvsrn_amd.synthetic import random_network  # noqa: E402,F401  (lives in the package: bench.py uses it too)

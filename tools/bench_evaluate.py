@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import util  # noqa: E402
+from fvsrn_amd import synthetic as util  # noqa: E402
 from fvsrn_amd import capi, volnet_io  # noqa: E402
 
 

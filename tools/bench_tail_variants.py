@@ -1,7 +1,9 @@
 import os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np, torch, util
+import numpy as np, torch
+import fvsrn_amd
+from fvsrn_amd import synthetic as util
 from fvsrn_amd import capi, volnet_io
 def run(mode, act, tf_kind, tf_table=None):
     vn = util.random_network(C=32, layers=4, activation=act, param=1.0, output_mode=mode, seed=1234, box_min=(-0.5, -0.5, -0.5))

@@ -4,13 +4,14 @@ import importlib.util, os, sys, time, types
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py")); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
-import torch, util
+import torch
+from fvsrn_amd import synthetic as util
 import torch.distributed as dist
 from fvsrn_amd import capi, volnet_io
 name = sys.argv[1] if len(sys.argv) > 1 else "c32l4_fourier_1024x512"
 cfg = b.CONFIGS[name]
 print(name)
-vn, net = b.make_network(util, volnet_io, capi, cfg, "ReLU")
+vn, net = b.make_network(volnet_io, capi, cfg, "ReLU")
 dist.all_gather_into_tensor = lambda out, inp: None   # host cost of the collective call itself is not in this number
 for world in (1, 2, 4, 8):
     r = b.Runner(capi, net, cfg, 0, world, False)

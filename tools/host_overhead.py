@@ -13,11 +13,11 @@ spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench
 b = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(b)
 import torch  # noqa: E402
-import util  # noqa: E402
+from fvsrn_amd import synthetic as util  # noqa: E402
 from fvsrn_amd import capi, volnet_io  # noqa: E402
 
 cfg = (32, 4, None, 64, 64, 64)
-vn, net = b.make_network(util, volnet_io, capi, cfg, "ReLU")
+vn, net = b.make_network(volnet_io, capi, cfg, "ReLU")
 r = b.Runner(capi, net, cfg, 0, 1, False)
 for i in range(20):
     r.frame(i)

@@ -14,12 +14,12 @@ spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench
 b = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(b)
 import torch  # noqa: E402
-import util  # noqa: E402
+from fvsrn_amd import synthetic as util  # noqa: E402
 from fvsrn_amd import capi, volnet_io  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c32l4_fourier_1024x512"
 cfg = b.CONFIGS[name]
-vn, net = b.make_network(util, volnet_io, capi, cfg, "ReLU")
+vn, net = b.make_network(volnet_io, capi, cfg, "ReLU")
 _, _, _, W, H, steps = cfg
 scene = capi.Scene(**b.build_scene_kwargs(capi, 0.3, 1.0 / steps, False))
 out = torch.zeros((1, 8, H, W), dtype=torch.float32, device="cuda")
