@@ -57,6 +57,11 @@ class SceneDesc(C.Structure):
                 ("tf_preintegration", C.c_int)]
 
 
+# fvsrn_option (include/fvsrn.h): tuning / developer switches of a handle
+OPTIONS = {"small_kernel": 0, "persistent": 1, "depth_segments": 2, "fourier_resync": 3, "unit_quota": 4, "tile_order": 5,
+           "waves_per_block": 6, "max_blocks_per_cu": 7, "relu_clamp": 8}
+ERR_WRONG_DEVICE = -8
+
 GRADIENT_OFF_OR_DIRECT, GRADIENT_FINITE_DIFFERENCES = 0, 1
 LIGHT_POINT, LIGHT_DIRECTIONAL = 0, 1
 PREINTEGRATE_NONE, PREINTEGRATE_1D, PREINTEGRATE_2D = 0, 1, 2
@@ -100,6 +105,10 @@ SYMBOLS = [
     ("fvsrn_generate_rays", _I, [_FP, _FP, _FP, _F, _I, _I, _VP, _VP, _VP]),
     ("fvsrn_scene_evaluate_tf", _I, [_VP, _VP, _VP, _SZ, _F, _F, _F, _VP, _VP]),
     ("fvsrn_network_kernel_name", _I, [_VP, _I, C.c_char_p, _SZ]),
+    ("fvsrn_network_set_option", _I, [_VP, _I, _I]),
+    ("fvsrn_network_get_option", _I, [_VP, _I, C.POINTER(_I)]),
+    ("fvsrn_scene_set_option", _I, [_VP, _I, _I]),
+    ("fvsrn_scene_get_option", _I, [_VP, _I, C.POINTER(_I)]),
     ("fvsrn_volume_create", _I, [_VP, _I, _I, _I, _I, _I, _FP, _FP, C.POINTER(_VP)]),
     ("fvsrn_volume_destroy", _I, [_VP]),
     ("fvsrn_volume_load_cvol", _I, [C.c_char_p, _I, C.POINTER(_VP)]),
@@ -269,6 +278,15 @@ class Network:
     def set_time_and_ensemble(self, time: float, ensemble: int = 0):
         _check(lib().fvsrn_network_set_time_and_ensemble(self._h, float(time), int(ensemble)))
 
+    def set_option(self, name: str, value: int):
+        _check(lib().fvsrn_network_set_option(self._h, OPTIONS[name], int(value)))
+        self._info = None
+
+    def get_option(self, name: str) -> int:
+        v = _I()
+        _check(lib().fvsrn_network_get_option(self._h, OPTIONS[name], C.byref(v)))
+        return v.value
+
     def clear_gpu_resources(self):
         _check(lib().fvsrn_network_clear_gpu_resources(self._h))
 
@@ -354,6 +372,15 @@ class Scene:
     def update(self, **kw):
         d = self._desc(**kw)
         _check(lib().fvsrn_scene_update(self._h, C.byref(d)))
+
+    def set_option(self, name: str, value: int):
+        _check(lib().fvsrn_scene_set_option(self._h, OPTIONS[name], int(value)))
+        return self
+
+    def get_option(self, name: str) -> int:
+        v = _I()
+        _check(lib().fvsrn_scene_get_option(self._h, OPTIONS[name], C.byref(v)))
+        return v.value
 
     def __del__(self):
         try:

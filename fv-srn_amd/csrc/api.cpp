@@ -20,14 +20,58 @@
 
 using namespace fvsrn;
 
+// Tuning / developer switches of a handle (include/fvsrn.h, fvsrn_option).  Every new handle starts from the process defaults,
+// which are read from the environment ONCE (FVSRN_SMALL_KERNEL, FVSRN_PERSISTENT, FVSRN_SEGMENTS, FVSRN_FOURIER_RESYNC,
+// FVSRN_UNIT_QUOTA, FVSRN_TILE_ORDER, FVSRN_WAVES_PER_BLOCK, FVSRN_MAX_BLOCKS_PER_CU, FVSRN_DISABLE_RELU_CLAMP); nothing on the
+// per-frame path calls getenv.
+struct Options {
+    int v[FVSRN_OPT_COUNT_];
+    Options() {
+        v[FVSRN_OPT_SMALL_KERNEL] = -1; v[FVSRN_OPT_PERSISTENT] = -1; v[FVSRN_OPT_DEPTH_SEGMENTS] = 0; v[FVSRN_OPT_FOURIER_RESYNC] = 0;
+        v[FVSRN_OPT_UNIT_QUOTA] = -1; v[FVSRN_OPT_TILE_ORDER] = -1; v[FVSRN_OPT_WAVES_PER_BLOCK] = 0; v[FVSRN_OPT_MAX_BLOCKS_PER_CU] = 0;
+        v[FVSRN_OPT_RELU_CLAMP] = 1;
+    }
+    int operator[](int i) const { return v[i]; }
+    // empty string = valid
+    static std::string check(int opt, int value) {
+        switch (opt) {
+            case FVSRN_OPT_SMALL_KERNEL: case FVSRN_OPT_PERSISTENT: case FVSRN_OPT_TILE_ORDER:
+                return value >= -1 && value <= 1 ? "" : "value must be -1 (automatic), 0 or 1";
+            case FVSRN_OPT_DEPTH_SEGMENTS: return value >= 0 && value <= 64 ? "" : "segments must be 0 (automatic) .. 64";
+            case FVSRN_OPT_FOURIER_RESYNC:
+                return value == 0 || (value >= 1 && value <= 4096 && (value & (value - 1)) == 0) ? "" : "resync period must be 0 (default) or a power of two <= 4096";
+            case FVSRN_OPT_UNIT_QUOTA: return value >= -1 && value <= 1024 ? "" : "unit quota must be -1 (automatic) .. 1024";
+            case FVSRN_OPT_WAVES_PER_BLOCK: return value == 0 || value == 1 || value == 2 || value == 4 ? "" : "waves per workgroup must be 0 (automatic), 1, 2 or 4";
+            case FVSRN_OPT_MAX_BLOCKS_PER_CU: return value >= 0 && value <= 32 ? "" : "workgroups per CU must be 0 (no limit) .. 32";
+            case FVSRN_OPT_RELU_CLAMP: return value == 0 || value == 1 ? "" : "value must be 0 or 1";
+            default: return "unknown option";
+        }
+    }
+};
+
+static const Options& defaultOptions() {
+    static const Options defaults = [] {
+        Options o;
+        static const struct { const char* name; int opt; } kEnv[] = {
+            {"FVSRN_SMALL_KERNEL", FVSRN_OPT_SMALL_KERNEL}, {"FVSRN_PERSISTENT", FVSRN_OPT_PERSISTENT}, {"FVSRN_SEGMENTS", FVSRN_OPT_DEPTH_SEGMENTS},
+            {"FVSRN_FOURIER_RESYNC", FVSRN_OPT_FOURIER_RESYNC}, {"FVSRN_UNIT_QUOTA", FVSRN_OPT_UNIT_QUOTA}, {"FVSRN_TILE_ORDER", FVSRN_OPT_TILE_ORDER},
+            {"FVSRN_WAVES_PER_BLOCK", FVSRN_OPT_WAVES_PER_BLOCK}, {"FVSRN_MAX_BLOCKS_PER_CU", FVSRN_OPT_MAX_BLOCKS_PER_CU}};
+        for (const auto& e : kEnv)
+            if (const char* t = std::getenv(e.name)) {
+                const int val = std::atoi(t);
+                if (Options::check(e.opt, val).empty()) o.v[e.opt] = val;
+            }
+        if (std::getenv("FVSRN_DISABLE_RELU_CLAMP")) o.v[FVSRN_OPT_RELU_CLAMP] = 0;
+        return o;
+    }();
+    return defaults;
+}
+
 // Waves per workgroup: as few as the LDS budget allows.  16 waves per CU (4 per SIMD) must fit their network copies
 // into the 160 KiB of LDS; a workgroup's slot is only recycled when its slowest wave is done, so fewer waves per
 // workgroup = better balance between long and empty pixel tiles (measured r01: 1 wave 110.8, 4 waves 92.3 Gsamples/s).
-static int wavesPerBlockFor(size_t ldsBytesPerBlock) {
-    if (const char* e = std::getenv("FVSRN_WAVES_PER_BLOCK")) {
-        const int w = std::atoi(e);
-        if (w == 1 || w == 2 || w == 4) return w;
-    }
+static int wavesPerBlockFor(size_t ldsBytesPerBlock, const Options& o) {
+    if (o[FVSRN_OPT_WAVES_PER_BLOCK]) return o[FVSRN_OPT_WAVES_PER_BLOCK];
     const size_t budget = 160 * 1024;
     for (int w : {1, 2, 4})
         if (size_t(16 / w) * ldsBytesPerBlock <= budget) return w;
@@ -42,6 +86,8 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+struct WrongDeviceBase : std::runtime_error { using std::runtime_error::runtime_error; };
+
 template <class F>
 int guarded(F&& f) {
     try {
@@ -53,6 +99,8 @@ int guarded(F&& f) {
         return fail(FVSRN_ERR_INVALID_NETWORK, e.what());
     } catch (const Unsupported& e) {
         return fail(FVSRN_ERR_UNSUPPORTED, e.what());
+    } catch (const WrongDeviceBase& e) {
+        return fail(FVSRN_ERR_WRONG_DEVICE, e.what());
     } catch (const std::bad_alloc&) {
         return fail(FVSRN_ERR_INVALID_ARGUMENT, "out of host memory");
     } catch (const std::exception& e) {
@@ -86,6 +134,17 @@ struct DeviceBuffer {
     }
 };
 
+struct WrongDevice : WrongDeviceBase { using WrongDeviceBase::WrongDeviceBase; };
+// A handle's device state lives on the device that was current at its first use; every later call must run there.
+void bindOrCheckDevice(int& bound, const char* what) {
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (bound < 0) bound = dev;
+    else if (bound != dev)
+        throw WrongDevice(std::string(what) + " holds resources on HIP device " + std::to_string(bound) + ", but the current device is " +
+                          std::to_string(dev) + " (hipSetDevice before the call, or use one handle per device)");
+}
+
 int actIndex(fvsrn_activation a) {
     switch (a) {
         case FVSRN_ACT_RELU: return 0;
@@ -110,27 +169,30 @@ struct fvsrn_network {
     VariantKey keyScaled{};  // ReLU networks: [0,1]-scaled image (render only)
     KernelInfo kinfo{}, kinfoScaled{};
     int numCUs = 0;
-    std::mutex mu;
+    int device = -1;  // HIP device of the buffers above (-1: none yet)
+    Options opts = defaultOptions();
+    mutable std::mutex mu;
+    // fvsrn_network_get_info is called per frame by bindings (output channels, FLOP counts): computed once per network state
+    mutable bool infoValid = false;
+    mutable fvsrn_network_info info{};
 
-    void invalidate() { deviceValid = false; occKey = 0; }
+    void invalidate() { deviceValid = false; occKey = 0; infoValid = false; }
 
     // resident workgroups per CU of the render kernel for (blockDim, dynamic LDS); cached
     unsigned long long occKey = 0;
     const void* occFn = nullptr;
     int occBlocks = 0;
     // smallFn: render_small_kernel variant to use instead of render_kernel (nullptr = none)
-    int renderBlocksPerCU(unsigned blockDim, size_t ldsBytes, bool shaded, const void* smallFn = nullptr) {
-        const unsigned long long k = (static_cast<unsigned long long>(ldsBytes) << 18) | (blockDim << 2) | (smallFn ? 2u : 0u) | (shaded ? 1u : 0u);
+    int renderBlocksPerCU(unsigned blockDim, size_t ldsBytes, bool shaded, const void* smallFn, int maxBlocks) {
+        const unsigned long long k = (static_cast<unsigned long long>(ldsBytes) << 24) | (static_cast<unsigned long long>(maxBlocks) << 18) | (blockDim << 2) |
+                                     (smallFn ? 2u : 0u) | (shaded ? 1u : 0u);
         if (smallFn != occFn) occKey = 0;  // another render_small_kernel variant
         occFn = smallFn;
         if (k != occKey) {
             int n = 0;
             const void* fn = smallFn ? smallFn : (shaded ? kinfo.renderShadedFn : kinfoScaled.renderFn);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, int(blockDim), ldsBytes) != hipSuccess) n = 0;
-            if (const char* e = std::getenv("FVSRN_MAX_BLOCKS_PER_CU")) {  // developer knob: occupancy experiments
-                const int m = std::atoi(e);
-                if (m >= 1 && m < n) n = m;
-            }
+            if (maxBlocks >= 1 && maxBlocks < n) n = maxBlocks;  // FVSRN_OPT_MAX_BLOCKS_PER_CU: occupancy experiments
             occBlocks = n;
             occKey = k;
         }
@@ -149,22 +211,22 @@ struct fvsrn_network {
                               (key.dir ? ", with view direction" : "") + " (compiled: widths 32/48/64/96/128)");
         keyScaled = key;
         kinfoScaled = kinfo;
-        if (!packed.ldsImageScaled.empty() && !std::getenv("FVSRN_DISABLE_RELU_CLAMP")) {
+        if (!packed.ldsImageScaled.empty() && opts[FVSRN_OPT_RELU_CLAMP]) {
             keyScaled.act = ACT_RELU01;
             if (!kernel_info(keyScaled, &kinfoScaled)) throw Unsupported("scaled-ReLU kernel variant missing");
         }
     }
 
     void ensureDevice(hipStream_t stream) {
-        if (deviceValid) return;
+        if (deviceValid) return bindOrCheckDevice(device, "the network");
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
             throw DeviceError("no HIP device available: the MI355X kernels cannot run (there is no CPU fallback)");
+        if (!dLds.ptr) device = -1;  // nothing resident (new handle or after clear_gpu_resources): bind to the current device
+        bindOrCheckDevice(device, "the network");
         pack();
-        int dev = 0;
-        HIP_CHECK(hipGetDevice(&dev));
         hipDeviceProp_t prop;
-        HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
         numCUs = prop.multiProcessorCount;
         dLds.ensure(packed.ldsImage.size());
         HIP_CHECK(hipMemcpyAsync(dLds.ptr, packed.ldsImage.data(), packed.ldsImage.size(), hipMemcpyHostToDevice, stream));
@@ -270,6 +332,8 @@ struct fvsrn_scene {
     float preintStepsize = -1.f;
     unsigned launches = 0;  // parity selects which of the two tile counters a launch uses (the kernel zeroes the other)
     bool tfDirty = true;
+    int device = -1;  // HIP device of the buffers above (-1: none yet)
+    Options opts = defaultOptions();
     std::mutex mu;
     // cached launch order of the 8x8 pixel tiles
     struct OrderKey { int tilesX = -1, tilesY = -1, cx = 0, cy = 0, y0 = 0, stripeRows = 0, stripeRank = 0, stripeWorld = 0; } orderKey;
@@ -278,6 +342,7 @@ struct fvsrn_scene {
 
     // TF table (and, for pre-integrated Texture TFs, its tables) on the device, for step size `stepsize`
     int uploadTf(float stepsize, hipStream_t s) {
+        bindOrCheckDevice(device, "the scene");
         const fvsrn_scene_desc& d = desc;
         const size_t tfFloats = tfTable.size();
         const bool tfChanged = tfDirty;
@@ -542,6 +607,11 @@ int fvsrn_network_clear_gpu_resources(fvsrn_network* net) {
 int fvsrn_network_get_info(const fvsrn_network* netc, fvsrn_network_info* info) {
     return guarded([&] {
         if (!netc || !info) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        std::lock_guard<std::mutex> lock(netc->mu);
+        if (netc->infoValid) {  // bindings ask per frame (output channels, FLOP counts): nothing is recomputed until the network changes
+            *info = netc->info;
+            return FVSRN_OK;
+        }
         const SceneNetwork& n = *netc->net;
         std::memset(info, 0, sizeof(*info));
         info->num_layers = int(n.hidden.size());
@@ -551,32 +621,39 @@ int fvsrn_network_get_info(const fvsrn_network* netc, fvsrn_network_info* info) 
         info->use_direction_in_fourier = n.input.useDirectionInFourierFeatures;
         info->output_mode = int(n.outputMode);
         info->output_channels = n.outputChannels();
-        if (n.latentGrid) {
+        std::string why;
+        // a network under construction may hold unset grids (fvsrn_network_set_latent_grid_layout before the grids): no grid data
+        if (n.latentGrid && n.latentGrid->isValid(&why)) {
             info->grid_channels = n.latentGrid->totalChannels();
             info->grid_encoding = int(n.latentGrid->commonEncoding());
             const LatentGrid* g = n.latentGrid->hasTimeGrids() ? n.latentGrid->timeGrids[0].get()
                                                                : (n.latentGrid->hasEnsembleGrids() ? n.latentGrid->ensembleGrids[0].get() : nullptr);
             if (g) { info->grid_res[0] = g->gridSizeX; info->grid_res[1] = g->gridSizeY; info->grid_res[2] = g->gridSizeZ; }
+        }
+        if (n.latentGrid) {
             info->time_num = n.latentGrid->timeNum;
             info->ensemble_num = n.latentGrid->ensembleNum;
         }
-        info->num_parameters = n.numParameters();
-        info->max_warps_shared = n.computeMaxWarps(true, false);
-        info->max_warps_mixed = n.computeMaxWarps(false, false);
         for (int i = 0; i < 3; ++i) { info->box_min[i] = n.boxMin[i]; info->box_size[i] = n.boxSize[i]; }
-        std::string why;
         if (n.valid(&why)) {
-            const NetworkConfig c = n.config();
-            info->hidden_channels = c.hiddenChannels;
-            info->activation = int(c.activation);
-            info->activation_param = c.activationParam;
-            info->flops_per_sample = n.flopsPerSample();
-            try {
-                info->mfma_flops_per_sample = packNetwork(n).mfmaFlopsPerSample;
+            try {  // getDefines-level checks (uniform activation parameter, layer shapes) are stricter than valid(): fields stay 0
+                info->num_parameters = n.numParameters();
+                info->max_warps_shared = n.computeMaxWarps(true, false);
+                info->max_warps_mixed = n.computeMaxWarps(false, false);
+                const NetworkConfig c = n.config();
+                info->hidden_channels = c.hiddenChannels;
+                info->activation = int(c.activation);
+                info->activation_param = c.activationParam;
+                info->flops_per_sample = n.flopsPerSample();
+                info->mfma_flops_per_sample = mfmaFlopsPerSample(c, int(n.hidden.size()));  // no packing: bindings call this once per frame
             } catch (const Unsupported&) {
                 info->mfma_flops_per_sample = 0;
+            } catch (const InvalidNetwork&) {
+                info->hidden_channels = 0;
             }
         }
+        netc->info = *info;
+        netc->infoValid = true;
         return FVSRN_OK;
     });
 }
@@ -619,10 +696,9 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
         if (render) {  // the register-resident kernel takes over for scenes with an Identity / Texture TF and no shading (renderImpl)
             const NetParams& P = net->packed.params;
             const VariantKey& k = net->keyScaled;
-            const char* e = std::getenv("FVSRN_SMALL_KERNEL");
             const bool scalarNet = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
             const bool colourNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
-            if (!(e && e[0] == '0') && k.CD == 2 && k.grid == 0 && !P.noFourier && !P.fourierNeedsFract && (scalarNet || colourNet) &&
+            if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && k.grid == 0 && !P.noFourier && !P.fourierNeedsFract && (scalarNet || colourNet) &&
                 render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1))
                 name = "render_small_kernel<act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "," + std::to_string(P.numLayers) +
                        "> (unshaded; else " + name + ")";
@@ -631,6 +707,48 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
         buf[cap - 1] = 0;
         return FVSRN_OK;
     });
+}
+
+// --------------------------------------------------------------------------------------------- options
+static int setOption(Options& o, int option, int value) {
+    if (option < 0 || option >= FVSRN_OPT_COUNT_) return fail(FVSRN_ERR_INVALID_ARGUMENT, "unknown option");
+    const std::string why = Options::check(option, value);
+    if (!why.empty()) return fail(FVSRN_ERR_INVALID_ARGUMENT, "option " + std::to_string(option) + ": " + why);
+    o.v[option] = value;
+    return FVSRN_OK;
+}
+
+int fvsrn_network_set_option(fvsrn_network* net, int option, int value) {
+    return guarded([&] {
+        if (!net) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null network");
+        std::lock_guard<std::mutex> lock(net->mu);
+        const int old = option >= 0 && option < FVSRN_OPT_COUNT_ ? net->opts[option] : 0;
+        const int rc = setOption(net->opts, option, value);
+        if (rc == FVSRN_OK && option == FVSRN_OPT_RELU_CLAMP && old != value) net->invalidate();  // selects the weight image
+        return rc;
+    });
+}
+
+int fvsrn_scene_set_option(fvsrn_scene* scene, int option, int value) {
+    return guarded([&] {
+        if (!scene) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null scene");
+        std::lock_guard<std::mutex> lock(scene->mu);
+        return setOption(scene->opts, option, value);
+    });
+}
+
+int fvsrn_network_get_option(const fvsrn_network* net, int option, int* value) {
+    if (!net || !value || option < 0 || option >= FVSRN_OPT_COUNT_) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad option query");
+    std::lock_guard<std::mutex> lock(net->mu);
+    *value = net->opts[option];
+    return FVSRN_OK;
+}
+
+int fvsrn_scene_get_option(fvsrn_scene* scene, int option, int* value) {
+    if (!scene || !value || option < 0 || option >= FVSRN_OPT_COUNT_) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad option query");
+    std::lock_guard<std::mutex> lock(scene->mu);
+    *value = scene->opts[option];
+    return FVSRN_OK;
 }
 
 // ------------------------------------------------------------------------------------------- evaluation
@@ -656,15 +774,14 @@ int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const fl
             if (!(flags & FVSRN_EVAL_WORLD_POSITIONS))  // volume_interpolation.cpp:46-49: box := [0,1]^3
                 for (int i = 0; i < 3; ++i) { a.P.boxMin[i] = 0.f; a.P.boxSize[i] = 1.f; a.P.invBoxSize[i] = 1.f; }
             const size_t batches = (n + 63) / 64;
-            const size_t wpb = size_t(wavesPerBlockFor(size_t(net->packed.params.ldsBytes)));
+            const size_t wpb = size_t(wavesPerBlockFor(size_t(net->packed.params.ldsBytes), net->opts));
             const size_t blocks = (batches + wpb - 1) / wpb;
             const unsigned grid = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 32 / wpb));
             // small networks in registers (evaluate_small_kernel): see renderImpl; the plain weight image, any output mode
             hipError_t e = hipErrorInvalidDeviceFunction;
             {
-                const char* env = std::getenv("FVSRN_SMALL_KERNEL");
                 const VariantKey& k = net->key;
-                if (!(env && env[0] == '0') && k.CD == 2 && k.grid == 0 && !a.P.noFourier && !a.P.fourierNeedsFractEval && a.P.numLayers >= 1 &&
+                if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && k.grid == 0 && !a.P.noFourier && !a.P.fourierNeedsFractEval && a.P.numLayers >= 1 &&
                     a.P.numLayers <= 3) {
                     const unsigned gridSmall = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 8 / wpb));  // 2 waves per SIMD
                     e = launch_eval_small(k.act, k.dir, a.P.numLayers, a, gridSmall, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
@@ -854,22 +971,21 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const int tilesX = (width + 7) / 8, tilesY = (numLocalRows + 7) / 8;
             const int tiles = tilesX * tilesY;
             const size_t lds = size_t(a.P.ldsBytes) + tfFloats * 4;
-            const char* pers = std::getenv("FVSRN_PERSISTENT");
-            const bool persistent = pers ? pers[0] != '0' : stripeWorld == 1;
-            const int wpb = wavesPerBlockFor(lds);
+            const Options& O = scene->opts;
+            const bool persistent = O[FVSRN_OPT_PERSISTENT] >= 0 ? O[FVSRN_OPT_PERSISTENT] != 0 : stripeWorld == 1;
+            const int wpb = wavesPerBlockFor(lds, O);
             // Small networks in registers (render_small_kernel, kernels.hpp): 32-wide Fourier-only scalar network with at most
             // three C->C layers, phases inside the v_cos domain, a transfer function, no shading.  FVSRN_SMALL_KERNEL=0: off.
             const void* smallFn = nullptr;
             const int smallTail = rgbo ? 3 : (d.tf_kind == FVSRN_TF_PIECEWISE || d.tf_kind == FVSRN_TF_GAUSSIAN ? 2 : 1);  // kernels.hpp TAIL_*
             {
-                const char* e = std::getenv("FVSRN_SMALL_KERNEL");
                 const VariantKey& k = net->keyScaled;
                 const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
-                if (!(e && e[0] == '0') && !a.shaded && k.CD == 2 && k.grid == 0 && !a.P.noFourier && !a.P.fourierNeedsFract &&
+                if (O[FVSRN_OPT_SMALL_KERNEL] != 0 && net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && !a.shaded && k.CD == 2 && k.grid == 0 && !a.P.noFourier && !a.P.fourierNeedsFract &&
                     a.P.numLayers >= 1 && a.P.numLayers <= 3 && (rgbo || (scalarNet && d.tf_kind != FVSRN_TF_NONE)))
                     smallFn = render_small_fn(k.act, k.dir, a.P.numLayers, smallTail);
             }
-            const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded, smallFn);
+            const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded, smallFn, O[FVSRN_OPT_MAX_BLOCKS_PER_CU]);
             const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));  // workgroups the chip holds at once
             // Depth segments (kernels.hpp): with fewer tiles than ~4x the resident waves (small images, the stripes of one
             // rank of a multi-GPU frame) the longest tile dictates the launch time; cut the rays into K step ranges so that
@@ -882,16 +998,10 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 const double maxSteps = std::sqrt(double(bs[0]) * bs[0] + double(bs[1]) * bs[1] + double(bs[2]) * bs[2]) / d.stepsize;
                 // (a pre-integrated TF looks at the previous sample of the ray: no cuts)
                 while (d.tf_preintegration == FVSRN_PREINTEGRATE_NONE && K < 8 && double(tiles) * K < 4.0 * waves && maxSteps / (2 * K) >= 48.0) K *= 2;
-                if (const char* e = std::getenv("FVSRN_SEGMENTS")) {
-                    const int k = std::atoi(e);
-                    if (k >= 1 && k <= 64 && d.tf_preintegration == FVSRN_PREINTEGRATE_NONE) K = k;
-                }
+                if (O[FVSRN_OPT_DEPTH_SEGMENTS] >= 1 && d.tf_preintegration == FVSRN_PREINTEGRATE_NONE) K = O[FVSRN_OPT_DEPTH_SEGMENTS];
             }
-            S.resyncMask = kFourierResync - 1;
-            if (const char* e = std::getenv("FVSRN_FOURIER_RESYNC")) {  // developer knob: 1 = exact features at every step
-                const int k = std::atoi(e);
-                if (k >= 1 && k <= 4096 && (k & (k - 1)) == 0) S.resyncMask = k - 1;
-            }
+            // FVSRN_OPT_FOURIER_RESYNC: 1 = exact Fourier features at every step (the reference's arithmetic), default every 64 steps
+            S.resyncMask = (O[FVSRN_OPT_FOURIER_RESYNC] ? O[FVSRN_OPT_FOURIER_RESYNC] : kFourierResync) - 1;
             S.segments = K;
             S.partial = nullptr;
             const size_t plane = size_t(width) * size_t(compact ? numLocalRows : height);
@@ -920,8 +1030,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 // for the gather kernel but copies the network into LDS half as often.  Measured r01 on one rank's share
                 // of 1024^2 x 512, 64x6 + grid (tools/stripe_efficiency.py): 75 / 76 / 84 % of frame_time / world at
                 // world 2 / 4 / 8 without, 85 / 87 / 85 % with; no gain for Fourier-only networks (small LDS image).
-                const char* q = std::getenv("FVSRN_UNIT_QUOTA");
-                const int quota = q ? std::atoi(q) : (stripeWorld > 1 && net->key.grid != 0 ? 2 : 0);
+                const int quota = O[FVSRN_OPT_UNIT_QUOTA] >= 0 ? O[FVSRN_OPT_UNIT_QUOTA] : (stripeWorld > 1 && net->key.grid != 0 ? 2 : 0);
                 if (quota > 1 && perCU > 0 && grid > resident) {
                     grid = unsigned((units + (long long)wpb * quota - 1) / ((long long)wpb * quota));
                     S.unitQuota = quota;
@@ -933,8 +1042,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             // order (neighbouring tiles share latent-grid lines in L1/L2: 64x6+grid 22.1 centre-first vs 23.2 raster
             // Gsamples/s, r01).  Without them (FVSRN_PERSISTENT=0, or a launch that fits on the chip at once) centre-first
             // starts the long rays first, which pays whenever a workgroup holds several waves or waits on memory.
-            const char* ord = std::getenv("FVSRN_TILE_ORDER");  // "0" / "1" force, unset = heuristic
-            const bool useOrder = ord ? ord[0] == '1' : (S.tileCounter == nullptr && (wpb > 1 || net->key.grid != 0));
+            const bool useOrder = O[FVSRN_OPT_TILE_ORDER] >= 0 ? O[FVSRN_OPT_TILE_ORDER] == 1 : (S.tileCounter == nullptr && (wpb > 1 || net->key.grid != 0));
             S.tileOrder = useOrder ? scene->tileOrder(S, P_boxCenter(a.P), tilesX, tilesY, s) : nullptr;
             hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, a, grid, unsigned(64 * wpb), lds, s)
                                    : launch_render(a.shaded ? net->key : net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
@@ -1288,10 +1396,7 @@ int fvsrn_render_volume(fvsrn_scene* scene, fvsrn_volume* volume, int source, in
                 const float* bs = volume->boxSize;
                 const double maxSteps = std::sqrt(double(bs[0]) * bs[0] + double(bs[1]) * bs[1] + double(bs[2]) * bs[2]) / d.stepsize;
                 while (d.tf_preintegration == FVSRN_PREINTEGRATE_NONE && K < 8 && waves * K < slots / 2 && maxSteps / (2 * K) >= 48.0) K *= 2;  // r01, 256^2: K = 1 / 2 / 4 / 8 -> 0.34 / 0.19 / 0.17 / 0.24 ms
-                if (const char* e = std::getenv("FVSRN_SEGMENTS")) {
-                    const int k = std::atoi(e);
-                    if (k >= 1 && k <= 64 && d.tf_preintegration == FVSRN_PREINTEGRATE_NONE) K = k;
-                }
+                if (scene->opts[FVSRN_OPT_DEPTH_SEGMENTS] >= 1 && d.tf_preintegration == FVSRN_PREINTEGRATE_NONE) K = scene->opts[FVSRN_OPT_DEPTH_SEGMENTS];
             }
             S.segments = K;
             const size_t plane = size_t(width) * size_t(height);

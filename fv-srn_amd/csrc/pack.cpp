@@ -59,7 +59,8 @@ GridSelection selectGrid(const SceneNetwork& net) {
     if (!net.latentGrid) return g;
     const LatentGridTimeAndEnsemble& lg = *net.latentGrid;
     if (lg.hasTimeGrids()) {
-        const float time = lg.interpolateTime(net.currentTime);
+        float time = lg.interpolateTime(net.currentTime);
+        if (!(time >= 0.f)) time = 0.f;  // NaN-safe (a NaN time would index key frame INT_MIN)
         g.timeIndex = time;
         g.lo = std::min(int(time), lg.timeNum - 1);
         g.hi = std::min(g.lo + 1, lg.timeNum - 1);
@@ -127,9 +128,10 @@ void packLatentGrid(const SceneNetwork& net, PackedNetwork& out) {
                         // previous key frame's coefficients, which is what a blend with this frame as "B" uses
                         float m;
                         if (enc == FVSRN_GRID_BYTE_GAUSSIAN) {
-                            // |mean| + std * sqrt2 * erfinv(0.99995) bounds every decoded value
-                            m = std::fabs(off[k * Gc + c]) + 3.9f * std::fabs(scale[k * Gc + c]);
-                            if (timeQuirk && k > 0) m = std::max(m, std::fabs(off[(k - 1) * Gc + c]) + 3.9f * std::fabs(scale[(k - 1) * Gc + c]));
+                            // |mean| + std * sqrt2 * erfinv(0.99995) bounds every decoded value (bytes 0 / 255: 4.056)
+                            constexpr float kMaxGaussian = 4.06f;
+                            m = std::fabs(off[k * Gc + c]) + kMaxGaussian * std::fabs(scale[k * Gc + c]);
+                            if (timeQuirk && k > 0) m = std::max(m, std::fabs(off[(k - 1) * Gc + c]) + kMaxGaussian * std::fabs(scale[(k - 1) * Gc + c]));
                         } else {
                             m = std::fabs(off[k * Gc + c] + r * scale[k * Gc + c]);
                             if (timeQuirk && k > 0) m = std::max(m, std::fabs(off[(k - 1) * Gc + c] + r * scale[(k - 1) * Gc + c]));
@@ -388,9 +390,19 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
         np.boxSize[i] = net.boxSize[i];
         np.invBoxSize[i] = 1.0f / net.boxSize[i];
     }
-    // 32x32x16: 32768 FLOP per 32 samples; the last layer runs 16x16x32 MFMAs (16384 FLOP per 32 samples)
-    P.mfmaFlopsPerSample = 1024.0 * (MT + (NL > 0 ? double(MT) * KS0 : 0.0) + double(std::max(NL - 1, 0)) * MT * KS + 0.5 * KS);
+    P.mfmaFlopsPerSample = mfmaFlopsPerSample(c, int(net.hidden.size()));
     return P;
+}
+
+// padded FLOPs per sample that the kernels issue to the matrix cores, from the tiling alone (no packing)
+double mfmaFlopsPerSample(const NetworkConfig& c, int numLinearLayers) {
+    const int C = c.hiddenChannels;
+    if (C != 32 && C != 48 && C != 64 && C != 96 && C != 128)
+        throw Unsupported("hidden width " + std::to_string(C) + " is not in the compiled variant set (32,48,64,96,128)");
+    const int MT = (C + 31) / 32, KS = C / 16, KG = c.gridChannels / 16, KS0 = KS + KG;
+    const int NL = numLinearLayers - 1 - (c.hasFourier ? 0 : 1);
+    // 32x32x16: 32768 FLOP per 32 samples; the last layer runs 16x16x32 MFMAs (16384 FLOP per 32 samples)
+    return 1024.0 * (MT + (NL > 0 ? double(MT) * KS0 : 0.0) + double(std::max(NL - 1, 0)) * MT * KS + 0.5 * KS);
 }
 
 }  // namespace fvsrn

@@ -43,6 +43,8 @@ inline int chiOfSlot(int k) {
 
 // Throws Unsupported for networks outside the compiled variant set, InvalidNetwork like getDefines.
 PackedNetwork packNetwork(const SceneNetwork& net);
+// PackedNetwork::mfmaFlopsPerSample from the configuration alone; numLinearLayers = SceneNetwork::hidden.size()
+double mfmaFlopsPerSample(const NetworkConfig& c, int numLinearLayers);
 void packLatentGrid(const SceneNetwork& net, PackedNetwork& out);
 
 }  // namespace fvsrn

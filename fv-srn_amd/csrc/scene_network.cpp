@@ -376,6 +376,7 @@ static std::shared_ptr<LatentGridTimeAndEnsemble> loadGridTE(Reader& r) {
     g->ensembleNum = r.i32();
     if (g->timeNum < 0 || g->ensembleNum < 0 || g->timeNum > 65536 || g->ensembleNum > 65536)
         throw FormatError("bad grid counts in .volnet data");
+    if (g->timeStep == 0) throw FormatError("latent grid time step is 0 in .volnet data");  // interpolateTime divides by it
     for (int i = 0; i < g->timeNum; ++i) g->timeGrids.push_back(loadGrid(r));
     for (int i = 0; i < g->ensembleNum; ++i) g->ensembleGrids.push_back(loadGrid(r));
     return g;

@@ -59,12 +59,13 @@ __device__ __forceinline__ float act_f32(float x, float a, float b) {
     }
 }
 
-// Two activations.  Measured on MI355X (tools/microbench/r02_issue.hip, profiles/r02/microbench_issue_model_r02.md): packed
-// fp32 instructions (v_pk_mul/add/fma_f32) do not run beside the SIMD's matrix pipe -- one of them behind an MFMA costs ~7.5
-// cycles, and a partner wave issues 0.25 of them per MFMA of this wave against 2 - 4 scalar fp32 instructions -- so the hot loops
-// use the scalar forms (FVSRN_PK_F32=1 restores the packed ones: 2 values per instruction, fewer issue slots without MFMAs around).
+// Two activations.  Packed fp32 instructions (v_pk_mul/add/fma_f32) are the default.  Measured on MI355X (r02,
+// tools/microbench/r02_issue.hip, profiles/r02/microbench_issue_model_r02.md): one of them placed BEHIND an MFMA of the same
+// wave costs ~7.5 cycles and a partner wave issues only 0.25 of them per MFMA of this wave (against 2 - 4 scalar fp32
+// instructions) -- but in the vector phase of the step, where they sit, the halved instruction count wins: scalar forms
+// (FVSRN_PK_F32=0) 153.5 -> 145.5 Gsamples/s (32x4 ReLU), 63.4 -> 55.0 (SnakeAlt).
 #ifndef FVSRN_PK_F32
-#define FVSRN_PK_F32 0
+#define FVSRN_PK_F32 1
 #endif
 template <int ACT>
 __device__ __forceinline__ float2_t act_f32x2(float2_t x, float a, float b) {
@@ -513,8 +514,8 @@ __device__ __forceinline__ void fourier_advance_piece(floatx16 (&f)[2][mtiles(CD
     constexpr int NPASS = HAS_DIR ? 4 : 2;
     const int t = c / (8 * MT), m = (c / 8) % MT, k = c % 8;
 #if !FVSRN_PK_F32
-    // scalar fp32 (see act_f32x2): c' = c cd - s sd, s' = s cd + c sd as 2 v_mul + 2 v_fma; pinned with asm so that hipcc's
-    // SLP vectorizer does not fuse them back into v_pk_*_f32
+    // scalar fp32 (experiment, see act_f32x2): c' = c cd - s sd, s' = s cd + c sd as 2 v_mul + 2 v_fma; pinned with asm so
+    // that hipcc's SLP vectorizer does not fuse them back into v_pk_*_f32
     float cs_ = f[t][m][2 * k], sn = f[t][m][2 * k + 1];
     const float cd = d[t][m][2 * k], sd = d[t][m][2 * k + 1];
     if (m == 0 && 2 * k < NPASS) {

@@ -1396,7 +1396,14 @@ PYBIND11_MODULE(pyrenderer, m) {
              py::doc("Densities of shape (B,1) and gradients of shape (B,3)"))
         .def("evaluate_with_gradients_and_curvature", [](IVolumeInterpolation&, const torch::Tensor&, const std::optional<torch::Tensor>&) -> py::object {
                  raise("curvature evaluation is not in the compiled variant set");
-             }, py::arg("positions"), py::arg("direction") = std::optional<torch::Tensor>{});
+             }, py::arg("positions"), py::arg("direction") = std::optional<torch::Tensor>{})
+        // volume_interpolation.cpp:651-695: training-data samplers, not on the inference path (out of scope): present, and raise
+        .def("importance_sampling", [](IVolumeInterpolation&, py::args, py::kwargs) -> py::object {
+                 raise("importance_sampling is not part of this build (training-data sampler, outside the inference hot path)");
+             })
+        .def("importance_sampling_with_probability_grid", [](IVolumeInterpolation&, py::args, py::kwargs) -> py::object {
+                 raise("importance_sampling_with_probability_grid is not part of this build (training-data sampler, outside the inference hot path)");
+             });
     py::class_<UnsupportedVolume, IVolumeInterpolation, std::shared_ptr<UnsupportedVolume>>(m, "UnsupportedVolume")
         .def_readonly("name", &UnsupportedVolume::name);
     // ---- grid volumes (volume.cpp:1244-1400, volume_interpolation_grid.cpp:851-897)
@@ -1535,7 +1542,11 @@ PYBIND11_MODULE(pyrenderer, m) {
     // ---- cameras (camera.cpp:184-224,375-397)
     py::class_<ICamera, std::shared_ptr<ICamera>>(m, "ICamera")
         .def_readonly("aspect_ratio", &ICamera::aspectRatio)
-        .def_readwrite("fov_y_radians", &ICamera::fovYRadians);
+        .def_readwrite("fov_y_radians", &ICamera::fovYRadians)
+        // camera.cpp:166-182: projects through the OpenGL matrices of the rasterisation path, which is not part of this build
+        .def("world2screen", [](ICamera&, py::args, py::kwargs) -> py::object {
+                 raise("world2screen is not part of this build (OpenGL view / projection matrices of the rasterisation path)");
+             });
     py::class_<CameraOnASphere, ICamera, std::shared_ptr<CameraOnASphere>> cs(m, "CameraOnASphere");
     py::enum_<Orientation>(cs, "Orientation")
         .value("Xp", Xp).value("Xm", Xm).value("Yp", Yp).value("Ym", Ym).value("Zp", Zp).value("Zm", Zm).export_values();

@@ -15,6 +15,12 @@
  *     enqueued asynchronously on it, like the reference uses the current torch stream
  *     (renderer/iimage_evaluator.cpp:167-170)
  *   - handles are re-entrant per object; distinct objects may be used from distinct threads
+ *   - a handle's device state (weight image, latent key frames, TF tables) is created at its first use on the HIP device
+ *     that is current then; every later call must run with that device current (FVSRN_ERR_WRONG_DEVICE otherwise) --
+ *     one handle per device, the reference's "one renderer per CUDA context".  First use and time changes of a network
+ *     are ordered on the stream of the call that triggers them: callers that render one network from several streams
+ *     synchronise those streams behind the first call / a time change themselves
+ *   - nothing on a per-frame path reads the process environment; the FVSRN_* variables only seed the option defaults once
  */
 #ifndef FVSRN_H_
 #define FVSRN_H_
@@ -34,6 +40,7 @@ extern "C" {
 #define FVSRN_ERR_DEVICE (-5)           /* HIP runtime error                               */
 #define FVSRN_ERR_NO_DEVICE (-6)        /* no GPU / kernels not usable                     */
 #define FVSRN_ERR_IO (-7)               /* file cannot be opened / written                   */
+#define FVSRN_ERR_WRONG_DEVICE (-8)     /* the handle's device state lives on another HIP device than the current one */
 
 /* activation of the hidden layers: renderer/volume_interpolation_network.cpp:223-230 */
 typedef enum {
@@ -140,6 +147,29 @@ int fvsrn_network_get_layer(const fvsrn_network* net, int index, int* channels_o
                             int* activation, float* act_param, uint16_t* weights, uint16_t* bias);
 /* Fourier matrix as stored (half bits, feature-fastest [cin*F + f]); returns F*cols entries */
 int fvsrn_network_get_fourier(const fvsrn_network* net, uint16_t* matrix, int cap, int* count);
+
+/* ----------------------------------------------------------------------------------------
+ * Tuning / developer options of a handle.  No reference counterpart (the reference takes its kernel choices from NVRTC
+ * #defines); they replace what used to be FVSRN_* environment variables read on every call.  A new handle starts from the
+ * process defaults, which are read from the environment ONCE (variable named per option below).
+ * -------------------------------------------------------------------------------------- */
+typedef enum {
+    FVSRN_OPT_SMALL_KERNEL = 0,      /* network + scene: 0 = never take the register-resident kernels, -1 auto  [FVSRN_SMALL_KERNEL]  */
+    FVSRN_OPT_PERSISTENT = 1,        /* scene: persistent render waves 0 / 1, -1 auto                          [FVSRN_PERSISTENT]    */
+    FVSRN_OPT_DEPTH_SEGMENTS = 2,    /* scene: cut rays into k step ranges composited afterwards, 0 auto       [FVSRN_SEGMENTS]      */
+    FVSRN_OPT_FOURIER_RESYNC = 3,    /* scene: exact Fourier features every k steps (power of two), 0 = 64; 1 = the reference's
+                                        per-step arithmetic (fp16 position at every sample), no feature rotation [FVSRN_FOURIER_RESYNC] */
+    FVSRN_OPT_UNIT_QUOTA = 4,        /* scene: work units per bounded wave of a stripe launch, -1 auto          [FVSRN_UNIT_QUOTA]    */
+    FVSRN_OPT_TILE_ORDER = 5,        /* scene: 1 = centre-first tile order, 0 = raster, -1 auto                 [FVSRN_TILE_ORDER]    */
+    FVSRN_OPT_WAVES_PER_BLOCK = 6,   /* network (evaluate) + scene (render): 1 / 2 / 4, 0 auto                  [FVSRN_WAVES_PER_BLOCK] */
+    FVSRN_OPT_MAX_BLOCKS_PER_CU = 7, /* scene: occupancy cap for experiments, 0 = none                          [FVSRN_MAX_BLOCKS_PER_CU] */
+    FVSRN_OPT_RELU_CLAMP = 8,        /* network: 0 = do not use the [0,1]-scaled ReLU weight image              [FVSRN_DISABLE_RELU_CLAMP] */
+    FVSRN_OPT_COUNT_ = 9
+} fvsrn_option;
+int fvsrn_network_set_option(fvsrn_network* net, int option, int value);
+int fvsrn_network_get_option(const fvsrn_network* net, int option, int* value);
+int fvsrn_scene_set_option(fvsrn_scene* scene, int option, int value);
+int fvsrn_scene_get_option(fvsrn_scene* scene, int option, int* value);
 
 /* ----------------------------------------------------------------------------------------
  * IVolumeInterpolation::evaluate   (renderer/volume_interpolation.cpp:26-127, kernel

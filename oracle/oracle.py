@@ -17,7 +17,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrn_oracle.so")
+LIB_PATH = os.environ.get("FVSRN_ORACLE_LIBRARY") or os.path.join(_HERE, "libsrn_oracle.so")  # override: the sanitizer build (tools/run_asan.sh)
 
 ACC_HALF, ACC_FLOAT = 0, 1
 ACTIVATIONS = {"ReLU": 0, "Sine": 1, "Snake": 2, "SnakeAlt": 3, "Sigmoid": 4}

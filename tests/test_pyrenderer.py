@@ -78,6 +78,21 @@ def test_value_types_and_enums():
     assert lg.interpolate_time(5.0) == 1.5 and lg.interpolate_time(99) == 2 and lg.interpolate_ensemble(0) == 0
 
 
+def test_entries_outside_the_hot_path_exist_and_raise():
+    """world2screen (OpenGL matrices), importance_sampling* (training-data samplers) and the curvature
+    evaluation are present on the surface and raise a RuntimeError, rather than being absent attributes."""
+    cam = pr.CameraOnASphere()
+    with pytest.raises(RuntimeError, match="world2screen"):
+        cam.world2screen(64, 64, [])
+    vol = pr.VolumeInterpolationNetwork()
+    with pytest.raises(RuntimeError, match="importance_sampling"):
+        vol.importance_sampling(10, None, 0.1, 1, 0, 0.0, 1.0, "float")
+    with pytest.raises(RuntimeError, match="importance_sampling_with_probability_grid"):
+        vol.importance_sampling_with_probability_grid(10, None, None, 1.0, 0.1, 1, 0, 0.0, 1.0)
+    with pytest.raises(RuntimeError, match="curvature"):
+        vol.evaluate_with_gradients_and_curvature(torch.zeros(1, 3))
+
+
 def test_load_from_json_builds_the_module_tree(tmp_path):
     scene = {"version": 1, "root": "Simple",
              "ImageEvaluator": {"Simple": {"selectedCamera": "Sphere", "selectedVolume": "SRN", "selectedRayEvaluator": "DVR",

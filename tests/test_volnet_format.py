@@ -194,3 +194,50 @@ def test_camera_on_a_sphere_all_orientations():
             b = oracle.camera_on_a_sphere(o, (0.1, -0.2, 0.3), pitch, yaw, dist)
             for x, y in zip(a, b):
                 assert np.allclose(x, y, atol=1e-6)
+
+
+def test_handle_options_replace_environment_switches():
+    """include/fvsrn.h fvsrn_option: per-handle values, validated, readable back; no GPU involved."""
+    from fvsrn_amd import capi
+    net = capi.Network.from_volnet(volnet_io.save_volnet(util.random_network(seed=3)))
+    assert net.get_option("small_kernel") == -1 and net.get_option("relu_clamp") == 1
+    net.set_option("relu_clamp", 0)
+    assert net.get_option("relu_clamp") == 0
+    eye, right, up = capi.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, 0.7, 1.6)
+    scene = capi.Scene(eye=eye, right=right, up=up, fov_y_radians=0.8, stepsize=0.01, tf_kind=capi.TF_IDENTITY)
+    assert scene.get_option("fourier_resync") == 0 and scene.get_option("depth_segments") == 0
+    scene.set_option("fourier_resync", 1).set_option("depth_segments", 4).set_option("persistent", 0)
+    assert (scene.get_option("fourier_resync"), scene.get_option("depth_segments"), scene.get_option("persistent")) == (1, 4, 0)
+    for name, bad in (("fourier_resync", 3), ("depth_segments", 65), ("persistent", 2), ("waves_per_block", 3), ("relu_clamp", 2)):
+        with pytest.raises(capi.FvsrnError):
+            scene.set_option(name, bad)
+    with pytest.raises(capi.FvsrnError):
+        capi._check(capi.lib().fvsrn_scene_set_option(scene._h, 99, 0))
+
+
+def test_info_of_a_network_under_construction_does_not_crash():
+    """fvsrn_network_get_info between set_latent_grid_layout and the grids (unset grid pointers): an answer, not a segfault."""
+    from fvsrn_amd import capi
+    net = capi.Network.create()
+    net.set_latent_grid_layout(0, 3, 1, 0, 0)
+    i = net.info()
+    assert i.time_num == 3 and i.grid_channels == 0
+    assert not net.valid()
+
+
+def test_volnet_with_zero_time_step_is_rejected():
+    """A latent grid block with timeStep == 0 would make interpolateTime compute 0/0: FormatError at load."""
+    from fvsrn_amd import capi
+    vn = util.random_network(grid=(16, 4), seed=2)
+    data = bytearray(volnet_io.save_volnet(vn))
+    good = capi.Network.from_volnet(bytes(data))
+    assert good.valid()
+    # LatentGridTimeAndEnsemble header: version, timeMin, timeNum, timeStep, ensembleMin, ensembleNum (int32 each); find it by its
+    # values (1, 0, 1, 1, 0, 0) and zero the time step
+    import struct
+    pat = struct.pack("<6i", 1, 0, 1, 1, 0, 0)
+    at = bytes(data).find(pat)
+    assert at > 0
+    data[at + 12:at + 16] = struct.pack("<i", 0)
+    with pytest.raises(capi.FvsrnError, match="time step"):
+        capi.Network.from_volnet(bytes(data))
