@@ -59,7 +59,7 @@ class SceneDesc(C.Structure):
 
 # fvsrn_option (include/fvsrn.h): tuning / developer switches of a handle
 OPTIONS = {"small_kernel": 0, "persistent": 1, "depth_segments": 2, "fourier_resync": 3, "unit_quota": 4, "tile_order": 5,
-           "waves_per_block": 6, "max_blocks_per_cu": 7, "relu_clamp": 8}
+           "waves_per_block": 6, "max_blocks_per_cu": 7, "relu_clamp": 8, "keyframe_slots": 9}
 ERR_WRONG_DEVICE = -8
 
 GRADIENT_OFF_OR_DIRECT, GRADIENT_FINITE_DIFFERENCES = 0, 1
@@ -109,6 +109,7 @@ SYMBOLS = [
     ("fvsrn_network_get_option", _I, [_VP, _I, C.POINTER(_I)]),
     ("fvsrn_scene_set_option", _I, [_VP, _I, _I]),
     ("fvsrn_scene_get_option", _I, [_VP, _I, C.POINTER(_I)]),
+    ("fvsrn_network_keyframe_stats", _I, [_VP, C.POINTER(C.c_ulonglong)]),
     ("fvsrn_volume_create", _I, [_VP, _I, _I, _I, _I, _I, _FP, _FP, C.POINTER(_VP)]),
     ("fvsrn_volume_destroy", _I, [_VP]),
     ("fvsrn_volume_load_cvol", _I, [C.c_char_p, _I, C.POINTER(_VP)]),
@@ -286,6 +287,11 @@ class Network:
         v = _I()
         _check(lib().fvsrn_network_get_option(self._h, OPTIONS[name], C.byref(v)))
         return v.value
+
+    def keyframe_stats(self) -> dict:
+        a = (C.c_ulonglong * 6)()
+        _check(lib().fvsrn_network_keyframe_stats(self._h, a))
+        return dict(zip(("key_frames", "slots", "uploads", "on_demand", "prefetched", "bytes"), [int(v) for v in a]))
 
     def clear_gpu_resources(self):
         _check(lib().fvsrn_network_clear_gpu_resources(self._h))

@@ -29,7 +29,7 @@ struct Options {
     Options() {
         v[FVSRN_OPT_SMALL_KERNEL] = -1; v[FVSRN_OPT_PERSISTENT] = -1; v[FVSRN_OPT_DEPTH_SEGMENTS] = 0; v[FVSRN_OPT_FOURIER_RESYNC] = 0;
         v[FVSRN_OPT_UNIT_QUOTA] = -1; v[FVSRN_OPT_TILE_ORDER] = -1; v[FVSRN_OPT_WAVES_PER_BLOCK] = 0; v[FVSRN_OPT_MAX_BLOCKS_PER_CU] = 0;
-        v[FVSRN_OPT_RELU_CLAMP] = 1;
+        v[FVSRN_OPT_RELU_CLAMP] = 1; v[FVSRN_OPT_KEYFRAME_SLOTS] = 0;
     }
     int operator[](int i) const { return v[i]; }
     // empty string = valid
@@ -44,6 +44,7 @@ struct Options {
             case FVSRN_OPT_WAVES_PER_BLOCK: return value == 0 || value == 1 || value == 2 || value == 4 ? "" : "waves per workgroup must be 0 (automatic), 1, 2 or 4";
             case FVSRN_OPT_MAX_BLOCKS_PER_CU: return value >= 0 && value <= 32 ? "" : "workgroups per CU must be 0 (no limit) .. 32";
             case FVSRN_OPT_RELU_CLAMP: return value == 0 || value == 1 ? "" : "value must be 0 or 1";
+            case FVSRN_OPT_KEYFRAME_SLOTS: return value == 0 || (value >= 2 && value <= 65536) ? "" : "key-frame slots must be 0 (all resident) or >= 2";
             default: return "unknown option";
         }
     }
@@ -55,7 +56,8 @@ static const Options& defaultOptions() {
         static const struct { const char* name; int opt; } kEnv[] = {
             {"FVSRN_SMALL_KERNEL", FVSRN_OPT_SMALL_KERNEL}, {"FVSRN_PERSISTENT", FVSRN_OPT_PERSISTENT}, {"FVSRN_SEGMENTS", FVSRN_OPT_DEPTH_SEGMENTS},
             {"FVSRN_FOURIER_RESYNC", FVSRN_OPT_FOURIER_RESYNC}, {"FVSRN_UNIT_QUOTA", FVSRN_OPT_UNIT_QUOTA}, {"FVSRN_TILE_ORDER", FVSRN_OPT_TILE_ORDER},
-            {"FVSRN_WAVES_PER_BLOCK", FVSRN_OPT_WAVES_PER_BLOCK}, {"FVSRN_MAX_BLOCKS_PER_CU", FVSRN_OPT_MAX_BLOCKS_PER_CU}};
+            {"FVSRN_WAVES_PER_BLOCK", FVSRN_OPT_WAVES_PER_BLOCK}, {"FVSRN_MAX_BLOCKS_PER_CU", FVSRN_OPT_MAX_BLOCKS_PER_CU},
+            {"FVSRN_KEYFRAME_SLOTS", FVSRN_OPT_KEYFRAME_SLOTS}};
         for (const auto& e : kEnv)
             if (const char* t = std::getenv(e.name)) {
                 const int val = std::atoi(t);
@@ -157,12 +159,123 @@ int actIndex(fvsrn_activation a) {
 }
 }  // namespace
 
+// Time key frames of a latent grid on the device (BASELINE.json configs[4]; reference: LatentGrid textures uploaded lazily by a
+// synchronous cudaMemcpy3D at first use and kept forever, volume_interpolation_network.cpp:482-488,524-535,1308-1315).
+// Here every key frame sits in PINNED host memory in device layout and `slots` of them are resident in HBM (all of them by
+// default, FVSRN_OPT_KEYFRAME_SLOTS bounds it; >= 2).  Uploads run on a copy stream of the store: a slot is overwritten once the
+// last blend kernel that read it is done (event), the blend of a frame waits for the uploads it needs (event) -- and for nothing
+// else, so the copy of frame i+1's key frame overlaps the render of frame i (the render kernel reads the blended working grid,
+// not the key frames).  With >= 3 slots the key frame the time is moving towards is prefetched one interval ahead.
+struct KeyframeStore {
+    char* pinned = nullptr;      // [numKeys][bytesPerKey]
+    size_t bytesPerKey = 0;
+    int numKeys = 0, slots = 0;
+    DeviceBuffer dSlots;         // [slots][bytesPerKey]
+    std::vector<int> keyOfSlot, slotOfKey;
+    std::vector<unsigned long long> lastUse;
+    std::vector<hipEvent_t> readDone, uploadDone;
+    std::vector<char> readRecorded;
+    hipStream_t copyStream = nullptr;
+    unsigned long long tick = 0;
+    float lastTime = -1.f;
+    unsigned long long stats[4] = {0, 0, 0, 0};  // uploads, of which on demand (a blend waited for them), prefetched, bytes
+
+    bool active() const { return numKeys > 0; }
+    void release() {
+        for (hipEvent_t e : readDone) (void)hipEventDestroy(e);
+        for (hipEvent_t e : uploadDone) (void)hipEventDestroy(e);
+        readDone.clear(); uploadDone.clear();
+        if (copyStream) { (void)hipStreamSynchronize(copyStream); (void)hipStreamDestroy(copyStream); copyStream = nullptr; }
+        if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; }
+        dSlots.release();
+        numKeys = slots = 0;
+    }
+    // host data of all key frames -> pinned memory; `budget` = 0 (all resident) or the number of device slots
+    void init(const std::vector<char>& data, int keys, int budget) {
+        release();
+        if (keys <= 0 || data.empty()) return;
+        numKeys = keys;
+        bytesPerKey = data.size() / size_t(keys);
+        slots = budget <= 0 ? keys : std::min(keys, std::max(budget, 2));
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&pinned), data.size(), hipHostMallocDefault));
+        std::memcpy(pinned, data.data(), data.size());
+        dSlots.ensure(size_t(slots) * bytesPerKey);
+        HIP_CHECK(hipStreamCreateWithFlags(&copyStream, hipStreamNonBlocking));
+        keyOfSlot.assign(size_t(slots), -1);
+        slotOfKey.assign(size_t(keys), -1);
+        lastUse.assign(size_t(slots), 0);
+        readRecorded.assign(size_t(slots), 0);
+        readDone.resize(size_t(slots));
+        uploadDone.resize(size_t(slots));
+        for (int i = 0; i < slots; ++i) {
+            HIP_CHECK(hipEventCreateWithFlags(&readDone[size_t(i)], hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&uploadDone[size_t(i)], hipEventDisableTiming));
+        }
+        tick = 0;
+        lastTime = -1.f;
+        if (slots == keys)  // everything resident: upload now, asynchronously, the first blend waits for what it needs
+            for (int k = 0; k < keys; ++k) upload(k, k, false);
+    }
+    const char* slotPtr(int slot) const { return static_cast<const char*>(dSlots.ptr) + size_t(slot) * bytesPerKey; }
+    void upload(int key, int slot, bool prefetch) {
+        if (readRecorded[size_t(slot)]) HIP_CHECK(hipStreamWaitEvent(copyStream, readDone[size_t(slot)], 0));  // last reader of the old content
+        HIP_CHECK(hipMemcpyAsync(const_cast<char*>(slotPtr(slot)), pinned + size_t(key) * bytesPerKey, bytesPerKey, hipMemcpyHostToDevice, copyStream));
+        HIP_CHECK(hipEventRecord(uploadDone[size_t(slot)], copyStream));
+        if (keyOfSlot[size_t(slot)] >= 0) slotOfKey[size_t(keyOfSlot[size_t(slot)])] = -1;
+        keyOfSlot[size_t(slot)] = key;
+        slotOfKey[size_t(key)] = slot;
+        ++stats[0];
+        ++stats[prefetch ? 2 : 1];
+        stats[3] += bytesPerKey;
+    }
+    int victim(int keepA, int keepB) const {  // least recently used slot that holds neither key
+        int best = -1;
+        for (int i = 0; i < slots; ++i) {
+            const int k = keyOfSlot[size_t(i)];
+            if (k >= 0 && (k == keepA || k == keepB)) continue;
+            if (k < 0) return i;
+            if (best < 0 || lastUse[size_t(i)] < lastUse[size_t(best)]) best = i;
+        }
+        return best;
+    }
+    // device pointers of key frames lo / hi for a blend enqueued on `stream` (which is made to wait for their uploads)
+    void acquire(int lo, int hi, float time, hipStream_t stream, const void** pLo, const void** pHi) {
+        ++tick;
+        for (int key : {lo, hi}) {
+            if (slotOfKey[size_t(key)] < 0) upload(key, victim(lo, hi), false);
+            const int s = slotOfKey[size_t(key)];
+            lastUse[size_t(s)] = tick;
+            HIP_CHECK(hipStreamWaitEvent(stream, uploadDone[size_t(s)], 0));
+        }
+        *pLo = slotPtr(slotOfKey[size_t(lo)]);
+        *pHi = slotPtr(slotOfKey[size_t(hi)]);
+        // prefetch the key frame the time is moving towards, if a slot is free of this frame's two
+        if (slots >= 3 && slots < numKeys && lastTime >= 0.f && time != lastTime) {
+            const int next = time > lastTime ? hi + 1 : lo - 1;
+            if (next >= 0 && next < numKeys && slotOfKey[size_t(next)] < 0) {
+                const int v = victim(lo, hi);
+                if (v >= 0) upload(next, v, true);
+            }
+        }
+        lastTime = time;
+    }
+    // call after the blend kernel has been enqueued on `stream`
+    void released(int lo, int hi, hipStream_t stream) {
+        for (int key : {lo, hi}) {
+            const int s = slotOfKey[size_t(key)];
+            HIP_CHECK(hipEventRecord(readDone[size_t(s)], stream));
+            readRecorded[size_t(s)] = 1;
+        }
+    }
+};
+
 struct fvsrn_network {
     std::shared_ptr<SceneNetwork> net = std::make_shared<SceneNetwork>();
     // device image (lazy; invalidated by any mutation)
     bool deviceValid = false;
     PackedNetwork packed;
-    DeviceBuffer dLds, dLdsScaled, dGrid, dGridB, dKeysTime, dKeysEns, dCoeffs;
+    DeviceBuffer dLds, dLdsScaled, dGrid, dGridB, dKeysEns, dCoeffs;
+    KeyframeStore keyStore;  // time key frames
     const void* scaledImage = nullptr;
     bool timeDirty = true;  // working grid / time slot do not match net->currentTime yet
     VariantKey key{};       // plain image
@@ -241,10 +354,7 @@ struct fvsrn_network {
         // latent key frames: uploaded once and kept resident; the working grid is blended from them on the device
         const GridKeyframes& K = packed.keys;
         if (K.records) {
-            if (!K.timeData.empty()) {
-                dKeysTime.ensure(K.timeData.size());
-                HIP_CHECK(hipMemcpyAsync(dKeysTime.ptr, K.timeData.data(), K.timeData.size(), hipMemcpyHostToDevice, stream));
-            }
+            keyStore.init(K.timeData, K.timeNum, opts[FVSRN_OPT_KEYFRAME_SLOTS]);
             if (!K.ensData.empty()) {
                 dKeysEns.ensure(K.ensData.size());
                 HIP_CHECK(hipMemcpyAsync(dKeysEns.ptr, K.ensData.data(), K.ensData.size(), hipMemcpyHostToDevice, stream));
@@ -284,13 +394,15 @@ struct fvsrn_network {
         if (K.records) {
             const GridSelection g = selectGrid(*net);
             BlendParams b{};
-            b.timeData = dKeysTime.ptr; b.ensData = dKeysEns.ptr;
+            b.ensData = dKeysEns.ptr;
+            if (keyStore.active()) keyStore.acquire(g.lo, g.hi, g.timeIndex, stream, &b.timeLo, &b.timeHi);
             const float* c = static_cast<const float*>(dCoeffs.ptr);
             b.timeOffset = c; b.timeScale = c + K.timeOffset.size();
             b.ensOffset = c + 2 * K.timeOffset.size(); b.ensScale = b.ensOffset + K.ensOffset.size();
             b.out = dGrid.ptr; b.outB = dGridB.ptr; b.records = K.records; b.enc = int(K.enc); b.Gt = K.Gt; b.Ge = K.Ge;
             b.lo = g.lo; b.hi = g.hi; b.ens = g.ens; b.frac = g.frac;
             HIP_CHECK(launch_grid_blend(b, stream));
+            if (keyStore.active()) keyStore.released(g.lo, g.hi, stream);
             // decode coefficients of the selected key frames (BYTE_GAUSSIAN decodes inside the render kernel)
             packed.params.gridFrac = g.frac;
             packed.params.gridMeanTime = b.timeOffset + size_t(g.lo) * K.Gt;
@@ -313,7 +425,7 @@ struct fvsrn_network {
         dLdsScaled.release();
         dGrid.release();
         dGridB.release();
-        dKeysTime.release();
+        keyStore.release();
         dKeysEns.release();
         dCoeffs.release();
     }
@@ -597,7 +709,7 @@ int fvsrn_network_clear_gpu_resources(fvsrn_network* net) {
         net->dLdsScaled.release();
         net->dGrid.release();
         net->dGridB.release();
-        net->dKeysTime.release();
+        net->keyStore.release();
         net->dKeysEns.release();
         net->dCoeffs.release();
         return FVSRN_OK;
@@ -691,7 +803,7 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
     return guarded([&] {
         if (!net || !buf || cap == 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
         std::lock_guard<std::mutex> lock(net->mu);
-        net->pack();
+        if (!net->deviceValid) net->pack();  // (a live network keeps its packed state: it carries the device pointers)
         std::string name = render ? net->kinfoScaled.renderName : net->kinfo.evalName;
         if (render) {  // the register-resident kernel takes over for scenes with an Identity / Texture TF and no shading (renderImpl)
             const NetParams& P = net->packed.params;
@@ -724,7 +836,8 @@ int fvsrn_network_set_option(fvsrn_network* net, int option, int value) {
         std::lock_guard<std::mutex> lock(net->mu);
         const int old = option >= 0 && option < FVSRN_OPT_COUNT_ ? net->opts[option] : 0;
         const int rc = setOption(net->opts, option, value);
-        if (rc == FVSRN_OK && option == FVSRN_OPT_RELU_CLAMP && old != value) net->invalidate();  // selects the weight image
+        // the weight image / the key-frame residency are part of the device state
+        if (rc == FVSRN_OK && (option == FVSRN_OPT_RELU_CLAMP || option == FVSRN_OPT_KEYFRAME_SLOTS) && old != value) net->invalidate();
         return rc;
     });
 }
@@ -741,6 +854,15 @@ int fvsrn_network_get_option(const fvsrn_network* net, int option, int* value) {
     if (!net || !value || option < 0 || option >= FVSRN_OPT_COUNT_) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad option query");
     std::lock_guard<std::mutex> lock(net->mu);
     *value = net->opts[option];
+    return FVSRN_OK;
+}
+
+int fvsrn_network_keyframe_stats(const fvsrn_network* net, unsigned long long out[6]) {
+    if (!net || !out) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(net->mu);
+    const KeyframeStore& k = net->keyStore;
+    out[0] = (unsigned long long)k.numKeys; out[1] = (unsigned long long)k.slots;
+    for (int i = 0; i < 4; ++i) out[2 + i] = k.stats[i];
     return FVSRN_OK;
 }
 

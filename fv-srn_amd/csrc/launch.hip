@@ -21,10 +21,9 @@ __global__ void grid_blend_kernel(BlendParams p) {
         if (p.enc == FVSRN_GRID_BYTE_GAUSSIAN) {  // no decode, no blend: byte values of A and B for the render kernel
             float a, b;
             if (c < p.Gt) {
-                const unsigned long long per = p.records * (unsigned long long)(2 * p.Gt);
                 const unsigned long long idx = rec * (unsigned)(2 * p.Gt) + (unsigned)(2 * c + pp);
-                a = float(static_cast<const unsigned char*>(p.timeData)[p.lo * per + idx]);
-                b = float(static_cast<const unsigned char*>(p.timeData)[p.hi * per + idx]);
+                a = float(static_cast<const unsigned char*>(p.timeLo)[idx]);
+                b = float(static_cast<const unsigned char*>(p.timeHi)[idx]);
             } else {
                 const int ce = c - p.Gt;
                 const unsigned long long per = p.records * (unsigned long long)(2 * p.Ge);
@@ -35,16 +34,15 @@ __global__ void grid_blend_kernel(BlendParams p) {
             continue;
         }
         if (c < p.Gt) {
-            const unsigned long long per = p.records * (unsigned long long)(2 * p.Gt);
             const unsigned long long idx = rec * (unsigned)(2 * p.Gt) + (unsigned)(2 * c + pp);
             float a, b;
             if (p.enc == FVSRN_GRID_FLOAT) {
-                a = static_cast<const float*>(p.timeData)[p.lo * per + idx];
-                b = static_cast<const float*>(p.timeData)[p.hi * per + idx];
-            } else {
+                a = static_cast<const float*>(p.timeLo)[idx];
+                b = static_cast<const float*>(p.timeHi)[idx];
+            } else {  // key frame B is decoded with A's coefficients (renderer_volume_tensorcores.cuh:586-587)
                 const float off = p.timeOffset[p.lo * p.Gt + c], sc = p.timeScale[p.lo * p.Gt + c];
-                a = off + (static_cast<const unsigned char*>(p.timeData)[p.lo * per + idx] / 255.0f) * sc;
-                b = off + (static_cast<const unsigned char*>(p.timeData)[p.hi * per + idx] / 255.0f) * sc;
+                a = off + (static_cast<const unsigned char*>(p.timeLo)[idx] / 255.0f) * sc;
+                b = off + (static_cast<const unsigned char*>(p.timeHi)[idx] / 255.0f) * sc;
             }
             v = a + p.frac * (b - a);
         } else {

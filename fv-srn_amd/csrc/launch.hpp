@@ -50,7 +50,8 @@ template <int CD> hipError_t launch_render_shaded_cd(const VariantKey& k, const 
 
 // decode + A/B time blend of the resident latent key frames into the fp16 working grid (pack.cpp, packLatentGrid)
 struct BlendParams {
-    const void* timeData;  // [timeNum][records][Gt][2] fp32 | uint8
+    const void* timeLo;    // time key frames lo / hi of this blend: [records][Gt][2] fp32 | uint8 each (api.cpp, KeyframeStore)
+    const void* timeHi;
     const void* ensData;   // [ensNum][records][Ge][2]
     const float* timeOffset; const float* timeScale;  // [timeNum][Gt]
     const float* ensOffset; const float* ensScale;    // [ensNum][Ge]

@@ -164,12 +164,18 @@ typedef enum {
     FVSRN_OPT_WAVES_PER_BLOCK = 6,   /* network (evaluate) + scene (render): 1 / 2 / 4, 0 auto                  [FVSRN_WAVES_PER_BLOCK] */
     FVSRN_OPT_MAX_BLOCKS_PER_CU = 7, /* scene: occupancy cap for experiments, 0 = none                          [FVSRN_MAX_BLOCKS_PER_CU] */
     FVSRN_OPT_RELU_CLAMP = 8,        /* network: 0 = do not use the [0,1]-scaled ReLU weight image              [FVSRN_DISABLE_RELU_CLAMP] */
-    FVSRN_OPT_COUNT_ = 9
+    FVSRN_OPT_KEYFRAME_SLOTS = 9,    /* network: time key frames of the latent grid resident in HBM; 0 = all, k >= 2 = at most k, the
+                                        others are streamed from pinned host memory on a copy stream, overlapped with rendering
+                                        (k >= 3: prefetched one key-frame interval ahead)                      [FVSRN_KEYFRAME_SLOTS] */
+    FVSRN_OPT_COUNT_ = 10
 } fvsrn_option;
 int fvsrn_network_set_option(fvsrn_network* net, int option, int value);
 int fvsrn_network_get_option(const fvsrn_network* net, int option, int* value);
 int fvsrn_scene_set_option(fvsrn_scene* scene, int option, int value);
 int fvsrn_scene_get_option(fvsrn_scene* scene, int option, int* value);
+/* time key frames of a network's latent grid: out = { key frames, device slots, uploads, of which a blend had to wait for
+ * (on demand), prefetched ahead of need, bytes uploaded } since the device state was created */
+int fvsrn_network_keyframe_stats(const fvsrn_network* net, unsigned long long out[6]);
 
 /* ----------------------------------------------------------------------------------------
  * IVolumeInterpolation::evaluate   (renderer/volume_interpolation.cpp:26-127, kernel

@@ -469,6 +469,27 @@ def test_full_size_properties_1024x512steps(config):
         assert torch.equal(torch.nan_to_num(back, nan=-1.0), torch.nan_to_num(full, nan=-1.0))
 
 
+def test_handles_are_bound_to_their_device():
+    """A network / scene holds device state on the HIP device of its first use; a call with another device current returns
+    FVSRN_ERR_WRONG_DEVICE instead of reading foreign pointers (needs two GPUs)."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density", seed=1)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    scene = capi.Scene(**make_scene_kwargs(tf_kind=oracle.TF_IDENTITY))
+    with torch.cuda.device(0):
+        scene.render(net, 16, 16)
+        torch.cuda.synchronize()
+    with torch.cuda.device(1):
+        with pytest.raises(capi.FvsrnError) as e:
+            scene.render(net, 16, 16, out=torch.zeros((1, 8, 16, 16), device="cuda:1"))
+        assert e.value.code == capi.ERR_WRONG_DEVICE
+    with torch.cuda.device(0):
+        scene.render(net, 16, 16)
+
+
 def test_errors_are_reported():
     import torch
     from fvsrn_amd import capi, volnet_io
