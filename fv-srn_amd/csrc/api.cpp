@@ -324,9 +324,9 @@ struct fvsrn_network {
                               (key.dir ? ", with view direction" : "") + " (compiled: widths 32/48/64/96/128)");
         keyScaled = key;
         kinfoScaled = kinfo;
-        if (!packed.ldsImageScaled.empty() && opts[FVSRN_OPT_RELU_CLAMP]) {
-            keyScaled.act = ACT_RELU01;
-            if (!kernel_info(keyScaled, &kinfoScaled)) throw Unsupported("scaled-ReLU kernel variant missing");
+        if (!packed.ldsImageScaled.empty() && opts[FVSRN_OPT_RELU_CLAMP]) {  // ACT_RELU01 / ACT_SNAKEALT0 image (pack.cpp)
+            keyScaled.act = packed.scaledAct;
+            if (!kernel_info(keyScaled, &kinfoScaled)) throw Unsupported("kernel variant of the re-scaled weight image missing");
         }
     }
 
@@ -346,7 +346,7 @@ struct fvsrn_network {
         packed.params.ldsImage = dLds.ptr;
         packed.params.reluClamp = 0;
         scaledImage = nullptr;
-        if (keyScaled.act == ACT_RELU01) {
+        if (keyScaled.act != key.act) {
             dLdsScaled.ensure(packed.ldsImageScaled.size());
             HIP_CHECK(hipMemcpyAsync(dLdsScaled.ptr, packed.ldsImageScaled.data(), packed.ldsImageScaled.size(), hipMemcpyHostToDevice, stream));
             scaledImage = dLdsScaled.ptr;
@@ -930,8 +930,9 @@ static int sceneValidate(const fvsrn_scene_desc* d) {
     if (tfCols(d->tf_kind) * d->tf_rows > 1024)
         return fail(FVSRN_ERR_INVALID_ARGUMENT, "transfer function table too large (max 1024 floats)");
     if (!(d->stepsize > 0)) return fail(FVSRN_ERR_INVALID_ARGUMENT, "stepsize must be positive");
-    if (d->gradient_mode != FVSRN_GRADIENT_OFF_OR_DIRECT && d->gradient_mode != FVSRN_GRADIENT_FINITE_DIFFERENCES)
-        return fail(FVSRN_ERR_UNSUPPORTED, "gradient mode ADJOINT_METHOD is not in the compiled variant set");
+    if (d->gradient_mode < FVSRN_GRADIENT_OFF_OR_DIRECT || d->gradient_mode > FVSRN_GRADIENT_ADJOINT_METHOD)
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad gradient mode");
+    if (!(d->adjoint_grid_stepsize >= 0)) return fail(FVSRN_ERR_INVALID_ARGUMENT, "adjoint_grid_stepsize must not be negative");
     if (d->gradient_mode == FVSRN_GRADIENT_FINITE_DIFFERENCES && !(d->finite_differences_stepsize > 0))
         return fail(FVSRN_ERR_INVALID_ARGUMENT, "finite_differences_stepsize must be positive");
     if (d->brdf_light_type != FVSRN_LIGHT_POINT && d->brdf_light_type != FVSRN_LIGHT_DIRECTIONAL)
@@ -1032,6 +1033,7 @@ static void fillSceneParams(fvsrn_scene* scene, const fvsrn_scene_desc& d, int w
     S.blendMode = d.blend_mode;
     S.gradientMode = d.gradient_mode;
     S.fdStep = d.finite_differences_stepsize;
+    S.gridDiffStep = d.adjoint_grid_stepsize;
     S.brdfMagnitudeScaling = d.brdf_enable_magnitude_scaling;
     S.brdfPhong = d.brdf_enable_phong;
     S.brdfLightType = d.brdf_light_type;
@@ -1075,16 +1077,20 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             if (const int rc = scene->uploadTf(d.stepsize, s)) return rc;
             RenderArgs a{};
             a.P = net->packed.params;
-            a.shaded = d.gradient_mode == FVSRN_GRADIENT_FINITE_DIFFERENCES || d.brdf_enable_phong || d.brdf_enable_magnitude_scaling ||
+            a.shaded = d.gradient_mode != FVSRN_GRADIENT_OFF_OR_DIRECT || d.brdf_enable_phong || d.brdf_enable_magnitude_scaling ||
                        d.tf_preintegration != FVSRN_PREINTEGRATE_NONE;
             // finite differences also sample up to a step outside the box, where the [0,1] bound of the scaled image does
             // not hold: the shaded renderer takes the plain image
             if (net->scaledImage && !a.shaded) {  // ReLU network: image with activations scaled into [0,1] (pack.cpp)
                 a.P.ldsImage = net->scaledImage;
-                a.P.reluClamp = 1;
+                a.P.reluClamp = net->keyScaled.act == ACT_RELU01 ? 1 : 0;
             }
             SceneParams& S = a.S;
             fillSceneParams(scene, d, width, height, S);
+            // colour networks have no gradient mode (SceneNetwork::getDefines, volume_interpolation_network.cpp:1148)
+            if (rgbo) S.gradientMode = FVSRN_GRADIENT_OFF_OR_DIRECT;
+            // latentGridDifferencesStepSize of the adjoint mode (VolumeInterpolationNetwork::fillConstantMemory :1808-1812)
+            if (S.gridDiffStep <= 0.f) S.gridDiffStep = 1.0f / (float(std::max(1, a.P.gridX)) * 4.0f);
             S.width = width; S.height = height; S.y0 = y0; S.y1 = y1;
             S.numLocalRows = numLocalRows; S.stripeRows = stripeRows; S.stripeRank = stripeRank;
             S.stripeWorld = stripeWorld; S.compact = compact;

@@ -77,6 +77,7 @@ struct SceneParams {
     // normals: 0 = from the network if it predicts them, 1 = central differences (6 extra network evaluations)
     int gradientMode;
     float fdStep;  // world units
+    float gridDiffStep;  // adjoint mode: central-difference step of the latent grid, unit-box coordinates (1 / (resolution * 4))
     // BRDFLambert (renderer_brdf_lambert.cuh:19-103)
     int brdfMagnitudeScaling, brdfPhong, brdfLightType, brdfSpecularExponent;
     float brdfMagScale, brdfAmbient, brdfSpecular, brdfMagCenter, brdfMagRadius;

@@ -1,6 +1,7 @@
 // Kernel templates: point evaluation and the fused DVR ray-marching renderer.
 #pragma once
 #include "srn_device.hpp"
+#include "srn_gradient.hpp"
 
 namespace fvsrn {
 
@@ -509,6 +510,13 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
                     const float inv2h = 1.0f / (2.0f * h);
                     gx = (v[0] - v[1]) * inv2h; gy = (v[2] - v[3]) * inv2h; gz = (v[4] - v[5]) * inv2h;
                 }
+            } else if (SHADED && S.gradientMode == FVSRN_GRADIENT_ADJOINT_METHOD) {
+                // evalNormal, GRADIENT_MODE_ADJOINT_METHOD (renderer_volume_tensorcores.cuh:1198-1540): the analytic gradient w.r.t.
+                // the normalized position, by the whole wave if ANY lane needs a normal; forward mode, see srn_gradient.hpp
+                if constexpr (SHADED) {
+                    if (__builtin_amdgcn_ballot_w64(requireNormal) != 0)
+                        (void)srn_forward_gradient<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, S.gridDiffStep, gx, gy, gz);
+                }
             } else if (gradNet) {
                 gx = o[1]; gy = o[2]; gz = o[3];
                 if (P.outputMode == FVSRN_OUT_DENSITY_GRADIENT_CUBIC) { gx = gx * gx * gx; gy = gy * gy * gy; gz = gz * gz * gz; }
@@ -558,7 +566,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             cr += w * color[0]; cg += w * color[1]; cb += w * color[2];
             depth += w * t;
             ca += w;
-            if (gradNet || (SHADED && S.gradientMode == FVSRN_GRADIENT_FINITE_DIFFERENCES)) {  // wave-uniform: there is a normal
+            if (gradNet || (SHADED && S.gradientMode != FVSRN_GRADIENT_OFF_OR_DIRECT)) {  // wave-uniform: there is a normal
                 // safeNormalize (helper_math.cuh:2443-2448)
                 const float l2 = gx * gx + gy * gy + gz * gz;
                 if (l2 >= 1e-8f) { const float il = rsqrtf(l2); gx *= il; gy *= il; gz *= il; }

@@ -6,7 +6,8 @@ namespace fvsrn {
 
 #define FVSRN_SMALL_VARIANTS(X) \
     X(ACT_RELU01, false) X(ACT_RELU01, true) X(ACT_SINE, false) X(ACT_SINE, true) \
-    X(ACT_SNAKE, false) X(ACT_SNAKE, true) X(ACT_SNAKEALT, false) X(ACT_SNAKEALT, true) X(ACT_SIGMOID, false) X(ACT_SIGMOID, true)
+    X(ACT_SNAKE, false) X(ACT_SNAKE, true) X(ACT_SNAKEALT, false) X(ACT_SNAKEALT, true) X(ACT_SIGMOID, false) X(ACT_SIGMOID, true) \
+    X(ACT_SNAKEALT0, false) X(ACT_SNAKEALT0, true)
 #define FVSRN_SMALL_LAYERS(A, D) \
     Y(A, D, 1, 1) Y(A, D, 2, 1) Y(A, D, 3, 1) Y(A, D, 1, 2) Y(A, D, 2, 2) Y(A, D, 3, 2) Y(A, D, 1, 3) Y(A, D, 2, 3) Y(A, D, 3, 3)
 

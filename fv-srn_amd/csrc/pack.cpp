@@ -7,6 +7,7 @@
 // host into the exact per-lane order v_mfma_f32_32x32x16_f16 wants, so that the accumulator of
 // layer l is directly the B operand of layer l+1 (no LDS round trip for activations).
 #include "pack.hpp"
+#include "srn_device_enums.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -262,14 +263,18 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
     auto scaleHalf = [](uint16_t bits, int k) {
         return k == 0 ? bits : float_to_half_bits(std::ldexp(half_bits_to_float(bits), k));
     };
-    auto packLayers = [&](std::vector<char>& img, const std::vector<int>* exps) {
+    // foldExp != INT_MIN (SnakeAlt with b = 1/(2p) = 2^foldExp, see ACT_SNAKEALT0): every layer behind an activation takes
+    // W' = b W and b' = bias + b * sum_j W_j (fp32), the activation itself leaves out its affine part
+    constexpr int kNoFold = -1000;
+    auto packLayers = [&](std::vector<char>& img, const std::vector<int>* exps, int foldExp = kNoFold) {
         float* bias = reinterpret_cast<float*>(img.data() + np.offBias);
         for (int l = 0; l < NL; ++l) {
             const Layer& L = net.hidden[size_t(L0 + l)];
             const int ks = l == 0 ? KS0 : KS;
             const size_t baseOff = l == 0 ? size_t(np.offLayer0) : size_t(np.offHidden) + size_t(l - 1) * MT * KS * kFragBytes;
             if (L.channelsOut != C) throw InvalidNetwork("hidden layer width mismatch");
-            const int kW = exps ? (l > 0 ? (*exps)[size_t(l - 1)] : 0) - (*exps)[size_t(l)] : 0;
+            const bool fold = foldExp != kNoFold && l > 0;
+            const int kW = exps ? (l > 0 ? (*exps)[size_t(l - 1)] : 0) - (*exps)[size_t(l)] : (fold ? foldExp : 0);
             const int kB = exps ? -(*exps)[size_t(l)] : 0;
             for (int m = 0; m < MT; ++m)
                 for (int s = 0; s < ks; ++s) {
@@ -291,7 +296,15 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
                     const size_t fragIndex = s < KS ? size_t(m) * KS + s : size_t(MT) * KS + size_t(s - KS) * MT + m;
                     putFrag(img, baseOff + fragIndex * kFragBytes, f);
                 }
-            for (int r = 0; r < C; ++r) bias[size_t(l) * 32 * MT + r] = std::ldexp(half_bits_to_float(L.bias[size_t(r)]), kB);
+            for (int r = 0; r < C; ++r) {
+                double b = std::ldexp(double(half_bits_to_float(L.bias[size_t(r)])), kB);
+                if (fold) {
+                    double sum = 0;
+                    for (int j = 0; j < L.channelsIn; ++j) sum += double(half_bits_to_float(L.weights[size_t(r) * L.channelsIn + j]));
+                    b += std::ldexp(sum, foldExp);
+                }
+                bias[size_t(l) * 32 * MT + r] = float(b);
+            }
         }
         // Last layer (C -> 1|4): one v_mfma_f32_16x16x32_f16 per K step and tile -- 16 output rows instead of 32 halve
         // the padding of a 1..4-row matrix.  That instruction reads the SAME B registers differently: lane l supplies
@@ -303,7 +316,8 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
         const Layer& L = net.hidden.back();
         if (L.channelsIn != C || L.channelsOut != Cout) throw InvalidNetwork("last layer shape mismatch");
         const bool transposed = L.channelsIn < 16 || L.channelsOut < 16;  // addLayer stores [in][out]
-        const int kL = exps && NL > 0 ? (*exps)[size_t(NL - 1)] : 0;
+        const bool foldLast = foldExp != kNoFold && NL > 0;
+        const int kL = exps && NL > 0 ? (*exps)[size_t(NL - 1)] : (foldLast ? foldExp : 0);
         for (int s = 0; s < KS; ++s) {
             Frag f{};
             for (int lane = 0; lane < 64; ++lane) {
@@ -320,7 +334,15 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
             putFrag(img, size_t(np.offLast) + size_t(s) * kFragBytes, f);
         }
         float* bl = bias + size_t(NL) * 32 * MT;
-        for (int o = 0; o < std::min(Cout, 4); ++o) bl[o] = half_bits_to_float(L.bias[size_t(o)]);  // C operand rows 4g + o, any g
+        for (int o = 0; o < std::min(Cout, 4); ++o) {  // C operand rows 4g + o, any g
+            double b = double(half_bits_to_float(L.bias[size_t(o)]));
+            if (foldLast) {
+                double sum = 0;
+                for (int col = 0; col < C; ++col) sum += double(half_bits_to_float(transposed ? L.weights[size_t(col) * Cout + o] : L.weights[size_t(o) * C + col]));
+                b += std::ldexp(sum, foldExp);
+            }
+            bl[o] = float(b);
+        }
     };
     packLayers(P.ldsImage, nullptr);
 
@@ -333,6 +355,27 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
     // latent features by the grid's range), which is what the renderer evaluates; evaluate_points keeps the
     // plain image because callers may pass positions outside the box.
     P.ldsImageScaled.clear();
+    P.scaledAct = -1;
+    // ---- SnakeAlt with a power-of-two parameter: the affine part of the activation moves into the next layer (ACT_SNAKEALT0) ----
+    if (c.activation == FVSRN_ACT_SNAKEALT && c.hasFourier && NL > 0 && c.activationParam > 0) {
+        int e2 = 0;
+        const double mant = std::frexp(1.0 / (2.0 * double(c.activationParam)), &e2);  // b = mant * 2^e2
+        bool ok = mant == 0.5;
+        const int foldExp = e2 - 1;
+        // exact up to fp16 subnormals (like the scaled ReLU image): a weight below 2^-14 may lose its last bit, an error of at most
+        // 2^-25 per weight; a scaled weight must not overflow
+        for (int l = 1; l <= NL && ok; ++l)
+            for (uint16_t wbits : net.hidden[size_t(L0 + l)].weights) {
+                const float w = half_bits_to_float(wbits);
+                const float ws = half_bits_to_float(scaleHalf(wbits, foldExp));
+                if (!std::isfinite(ws) || std::fabs(double(ws) - std::ldexp(double(w), foldExp)) > std::ldexp(1.0, -25)) { ok = false; break; }
+            }
+        if (ok) {
+            P.ldsImageScaled = P.ldsImage;  // phase fragments, first layer: shared
+            packLayers(P.ldsImageScaled, nullptr, foldExp);
+            P.scaledAct = ACT_SNAKEALT0;
+        }
+    }
     if (c.activation == FVSRN_ACT_RELU && c.hasFourier) {
         std::vector<double> bound(size_t(C + c.gridChannels), 1.0005);  // stored input order of layer 0
         if (c.passTime && net.latentGrid) bound[3] = double(std::max(net.latentGrid->timeNum - 1, 0)) + 1e-3;  // any time index
@@ -369,6 +412,7 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
             P.ldsImageScaled = P.ldsImage;  // phase fragments are shared
             packLayers(P.ldsImageScaled, &exps);
             P.reluExponents = exps;
+            P.scaledAct = ACT_RELU01;
         }
     }
 

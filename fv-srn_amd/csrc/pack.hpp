@@ -25,7 +25,9 @@ struct PackedNetwork {
     NetworkConfig cfg;
     int MT = 0, KS = 0, KS0 = 0, NL = 0;
     std::vector<char> ldsImage;  // see device_params.hpp
-    std::vector<char> ldsImageScaled;  // ReLU networks: activations scaled into [0,1] (empty if not applicable)
+    std::vector<char> ldsImageScaled;  // second image for the renderer (empty if not applicable): ReLU networks with activations scaled
+                                       // into [0,1], SnakeAlt networks with the 1/(2p) factor folded into the next layer
+    int scaledAct = -1;                // ACT_RELU01 / ACT_SNAKEALT0: the kernel variant that goes with ldsImageScaled
     std::vector<int> reluExponents;    // e_l of the scaled image
     std::vector<float> gridMaxAbs;     // per latent channel
     NetParams params{};          // pointers left null (filled by the device layer)

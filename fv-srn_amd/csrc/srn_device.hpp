@@ -53,6 +53,8 @@ __device__ __forceinline__ float act_f32(float x, float a, float b) {
         return fmaf(-c, b, x + b);
     } else if constexpr (ACT == ACT_SIGMOID) {  // 1 / (1 + exp(-x)), a = -log2(e)
         return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * a));
+    } else if constexpr (ACT == ACT_SNAKEALT0) {  // x - cos(2 p x): the rest of SnakeAlt sits in the next layer (pack.cpp)
+        return x - __builtin_amdgcn_cosf(x * a);
     } else {  // SnakeAlt: (x + 1 - cos(2 p x)) / (2p)
         const float c = __builtin_amdgcn_cosf(x * a);
         return fmaf(x - c, b, b);
@@ -86,6 +88,10 @@ __device__ __forceinline__ float2_t act_f32x2(float2_t x, float a, float b) {
         const float2_t c = {__builtin_amdgcn_cosf(t[0]), __builtin_amdgcn_cosf(t[1])};
         const float2_t bb = {b, b};
         return __builtin_elementwise_fma(x - c, bb, bb);
+    } else if constexpr (ACT == ACT_SNAKEALT0) {
+        const float2_t t = x * a;
+        const float2_t c = {__builtin_amdgcn_cosf(t[0]), __builtin_amdgcn_cosf(t[1])};
+        return x - c;
     } else if constexpr (ACT == ACT_SIGMOID) {  // renderer_activations.cuh:152-179: 1 / (1 + exp(-x)); a = -log2(e)
         const float2_t t = x * a;
         return float2_t{__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[0])), __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t[1]))};
@@ -465,31 +471,36 @@ __device__ __forceinline__ void fourier_features(const NetParams& P, const char*
 }
 
 // the same features as fp16 B fragments of the first layer, tile by tile (few live registers)
+// one tile: b0 = its phase operand (phase_operands)
 template <int CD, int ACT, bool HAS_DIR, int FMODE>
-__device__ __forceinline__ void fourier_fragments(const NetParams& P, const char* lds, float px, float py, float pz, float dx,
-                                                  float dy, float dz, half8_t (&xb)[2][2 * mtiles(CD)]) {
+__device__ __forceinline__ void fourier_fragments_tile(const NetParams& P, const char* lds, const half8_t& b0, half8_t (&xbt)[2 * mtiles(CD)]) {
     constexpr int MT = mtiles(CD);
     constexpr int NPASS = HAS_DIR ? 4 : 2;
     const int lane = lane_id();
-    const int h = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        floatx16 d = {0};
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(lds, P.offPhase + m * kFragBytes, lane), b0, d, 0, 0, 0);
+        if constexpr (FMODE == FM_FIRST_LAYER) {
+            constexpr int A = (ACT == ACT_RELU01) ? ACT_RELU : (ACT == ACT_SNAKEALT0 ? ACT_SNAKEALT : ACT);  // no re-scaled image without Fourier features
+#pragma unroll
+            for (int q = 0; q < 4; ++q) act_pack_quarter<A>(d, q, P.actA, P.actB, xbt[2 * m], xbt[2 * m + 1]);
+        } else {
+            phase_cos<FMODE>(d, m == 0 ? NPASS : 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d, q, 0.f, 0.f, xbt[2 * m], xbt[2 * m + 1]);
+        }
+    }
+}
+
+template <int CD, int ACT, bool HAS_DIR, int FMODE>
+__device__ __forceinline__ void fourier_fragments(const NetParams& P, const char* lds, float px, float py, float pz, float dx,
+                                                  float dy, float dz, half8_t (&xb)[2][2 * mtiles(CD)]) {
+    const int h = lane_id() >> 5;
     half8_t b0[2];
     phase_operands<HAS_DIR, true>(px, py, pz, dx, dy, dz, h, b0);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            floatx16 d = {0};
-            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(lds, P.offPhase + m * kFragBytes, lane), b0[t], d, 0, 0, 0);
-            if constexpr (FMODE == FM_FIRST_LAYER) {
-                constexpr int A = ACT == ACT_RELU01 ? ACT_RELU : ACT;  // no scaled image without Fourier features
-#pragma unroll
-                for (int q = 0; q < 4; ++q) act_pack_quarter<A>(d, q, P.actA, P.actB, xb[t][2 * m], xb[t][2 * m + 1]);
-            } else {
-                phase_cos<FMODE>(d, m == 0 ? NPASS : 0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d, q, 0.f, 0.f, xb[t][2 * m], xb[t][2 * m + 1]);
-            }
-        }
+    fourier_fragments_tile<CD, ACT, HAS_DIR, FMODE>(P, lds, b0[0], xb[0]);
+    fourier_fragments_tile<CD, ACT, HAS_DIR, FMODE>(P, lds, b0[1], xb[1]);
 }
 
 template <int CD>
@@ -566,9 +577,19 @@ __device__ __forceinline__ void fourier_advance_piece(floatx16 (&f)[2][mtiles(CD
 //   pre():    produces xb (the first layer's B fragments); called after the first layer's LDS reads are issued
 //   fill(j):  NFILL pieces of independent VALU work for the MFMAs that have none of their own (first layer of tile 0,
 //             last layer of tile 1)
+// Latent-grid work a caller has done ahead of the layers (srn_forward): the taps of both sample tiles and -- valid != 0 -- the
+// fetched first 16-channel chunk of both tiles as B fragments.  Measured r02: fetching inside the layer loop leaves the L1 / L2
+// latency of every tile's 8 gathers exposed once per tile and wave step (the real 32x4 + grid kernel ran 32 % below its own
+// instruction skeleton, tools/microbench/r02_issue.hip part 6); srn_forward issues them in front of the tile's Fourier work.
+struct GridPre {
+    GridTap gt[2];
+    half8_t gf[2];
+    int valid;
+};
+
 template <int CD, int ACT, int GRID, bool HAS_DIR, int NFILL, class Pre, class Fill>
 __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, const char* lds, half8_t (&xb)[2][2 * mtiles(CD)],
-                                                         float px, float py, float pz, Pre&& pre, Fill&& fill) {
+                                                         float px, float py, float pz, Pre&& pre, Fill&& fill, const GridPre* gpre = nullptr) {
     constexpr int MT = mtiles(CD), KS = CD, NM = MT * KS, NV = 4 * MT;
     const int lane = lane_id();
     const int h = lane >> 5;
@@ -617,9 +638,11 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
 #pragma unroll
             for (int m = 0; m < MT; ++m) ag[m] = frag(offGridW + m * kFragBytes);
         }
-        grid_tap_bcast<GRID == 2>(grid_tap(P, px, py, pz), gt[0], gt[1]);
+        if (gpre) { gt[0] = gpre->gt[0]; gt[1] = gpre->gt[1]; }
+        else grid_tap_bcast<GRID == 2>(grid_tap(P, px, py, pz), gt[0], gt[1]);
         if constexpr (GRID_AHEAD) grid_load(P.grid, gt[0], 0, h, raw);
     }
+    const bool havePre = GRID == 1 && gpre && gpre->valid;
     __builtin_amdgcn_sched_barrier(0);
     FVSRN_MARK(P, 1);  // loop head, LDS reads of the first layer issued
     pre();
@@ -649,7 +672,8 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
     }
     if constexpr (GRID != 0) {
         for (int g = 0; g < P.gridK; ++g) {
-            if (!GRID_AHEAD || g > 0) gf = grid_features<GRID>(P, gt[0], g, h);
+            if (havePre && g == 0) gf = gpre->gf[0];
+            else if (!GRID_AHEAD || g > 0) gf = grid_features<GRID>(P, gt[0], g, h);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const half8_t w = (PREFETCH_AG && g == 0) ? ag[m] : frag(offGridW + (g * MT + m) * kFragBytes);
@@ -713,6 +737,8 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
 #pragma unroll
                 for (int k = 0; k < 4; ++k) grid_reduce_record<false>(raw, gt[1], k, gacc);
                 gf = grid_pack(gacc);
+            } else if (havePre && g == 0) {
+                gf = gpre->gf[1];
             } else {
                 gf = grid_features<GRID>(P, gt[1], g, h);
             }
@@ -767,13 +793,17 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
 // networks (measured r01: there the extra registers of the pipelined order cost more occupancy than the schedule gains).
 template <int CD, int ACT, int GRID, bool HAS_DIR, int NFILL, class Pre, class Fill>
 __device__ __forceinline__ float4_t srn_layers_kmajor(const NetParams& P, const char* lds, half8_t (&xb)[2][2 * mtiles(CD)],
-                                                      float px, float py, float pz, Pre&& pre, Fill&& fill) {
+                                                      float px, float py, float pz, Pre&& pre, Fill&& fill, const GridPre* gpre = nullptr) {
     constexpr int MT = mtiles(CD), KS = CD;
     const int lane = lane_id();
     const int h = lane >> 5;
     const float actA = P.actA, actB = P.actB;
     GridTap gt[2];
-    if constexpr (GRID != 0) grid_tap_bcast<GRID == 2>(grid_tap(P, px, py, pz), gt[0], gt[1]);
+    if constexpr (GRID != 0) {
+        if (gpre) { gt[0] = gpre->gt[0]; gt[1] = gpre->gt[1]; }
+        else grid_tap_bcast<GRID == 2>(grid_tap(P, px, py, pz), gt[0], gt[1]);
+    }
+    const bool havePre = GRID == 1 && gpre && gpre->valid;
     pre();
 #pragma unroll
     for (int j = 0; j < NFILL; ++j) fill(j);
@@ -797,8 +827,8 @@ __device__ __forceinline__ float4_t srn_layers_kmajor(const NetParams& P, const 
         if constexpr (GRID != 0) {
             if (l == 0) {
                 for (int g = 0; g < P.gridK; ++g) {
-                    const half8_t g0 = grid_features<GRID>(P, gt[0], g, h);
-                    const half8_t g1 = grid_features<GRID>(P, gt[1], g, h);
+                    const half8_t g0 = (havePre && g == 0) ? gpre->gf[0] : grid_features<GRID>(P, gt[0], g, h);
+                    const half8_t g1 = (havePre && g == 0) ? gpre->gf[1] : grid_features<GRID>(P, gt[1], g, h);
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const half8_t a = lds_frag(lds, wOff + (MT * KS + g * MT + m) * kFragBytes, lane);
@@ -836,7 +866,7 @@ __device__ __forceinline__ float4_t srn_layers_kmajor(const NetParams& P, const 
 // MAYBE_NO_LAYERS: the network may consist of first + last layer only (possible without Fourier features)
 template <int CD, int ACT, int GRID, bool HAS_DIR, int NFILL, bool MAYBE_NO_LAYERS, class Pre, class Fill>
 __device__ __forceinline__ float4_t srn_layers(const NetParams& P, const char* lds, half8_t (&xb)[2][2 * mtiles(CD)], float px,
-                                               float py, float pz, Pre&& pre, Fill&& fill) {
+                                               float py, float pz, Pre&& pre, Fill&& fill, const GridPre* gpre = nullptr) {
 #ifndef FVSRN_NO_PIPELINE
     // measured (r01, 1024^2 x 512): the pipelined order wins for Fourier-only networks (32x4: 106.7 -> 110.3 Gsamples/s) and
     // for 64-wide latent-grid networks (23.1 -> 23.9); for 32-wide ones with a grid its extra registers cost more
@@ -844,21 +874,62 @@ __device__ __forceinline__ float4_t srn_layers(const NetParams& P, const char* l
     if constexpr (CD <= 4 && (GRID == 0 || CD >= 3)) {
         if constexpr (MAYBE_NO_LAYERS) {
             if (P.numLayers == 0)  // wave-uniform
-                return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill);
+                return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill, gpre);
         }
-        return srn_layers_pipelined<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill);
+        return srn_layers_pipelined<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill, gpre);
     } else
 #endif
-        return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill);
+        return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill, gpre);
 }
 
 // positions -> raw network outputs (evaluate_points, and render steps of networks without the rotation shortcut)
+#ifndef FVSRN_GRID_PRE
+#define FVSRN_GRID_PRE 1
+#endif
 template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE>
 __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* lds, float px, float py, float pz,
                                                 float dx, float dy, float dz) {
     half8_t xb[2][2 * mtiles(CD)];
-    return srn_layers<CD, ACT, GRID, HAS_DIR, 0, FMODE == FM_FIRST_LAYER>(
-        P, lds, xb, px, py, pz, [&]() { fourier_fragments<CD, ACT, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, xb); }, [](int) {});
+    if constexpr (GRID == 1 && FVSRN_GRID_PRE) {
+        // Latent grid with decoded working values: the 8 gathers of a tile's first 16-channel chunk are issued in FRONT of that
+        // tile's Fourier work (phase MFMA, v_cos, converts), which covers their L1 / L2 latency; one 32-register buffer serves
+        // both tiles in turn (see GridPre).
+        const int h = lane_id() >> 5;
+        GridPre G;
+        grid_tap_bcast<false>(grid_tap(P, px, py, pz), G.gt[0], G.gt[1]);
+        G.valid = 1;
+        GridRaw raw;
+        grid_load(P.grid, G.gt[0], 0, h, raw);
+        half8_t b0[2];
+        phase_operands<HAS_DIR, true>(px, py, pz, dx, dy, dz, h, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        fourier_fragments_tile<CD, ACT, HAS_DIR, FMODE>(P, lds, b0[0], xb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) grid_reduce_record<false>(raw, G.gt[0], k, acc);
+            G.gf[0] = grid_pack(acc);
+        }
+        grid_load(P.grid, G.gt[1], 0, h, raw);
+        __builtin_amdgcn_sched_barrier(0);
+        fourier_fragments_tile<CD, ACT, HAS_DIR, FMODE>(P, lds, b0[1], xb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) grid_reduce_record<false>(raw, G.gt[1], k, acc);
+            G.gf[1] = grid_pack(acc);
+        }
+        return srn_layers<CD, ACT, GRID, HAS_DIR, 0, false>(P, lds, xb, px, py, pz, []() {}, [](int) {}, &G);
+    } else {
+        return srn_layers<CD, ACT, GRID, HAS_DIR, 0, FMODE == FM_FIRST_LAYER>(
+            P, lds, xb, px, py, pz, [&]() { fourier_fragments<CD, ACT, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, xb); }, [](int) {});
+    }
 }
 
 // the same from the input features `feat` of the current sample, which are advanced to the next sample of the rays

@@ -383,8 +383,9 @@ struct VolumeInterpolationNetwork : IVolumeInterpolation {
     void setBoxMax(double3 v) override { boxMax_ = v; pushBox(); }
     int outputChannels() const override { return currentNetwork()->info().output_channels; }
     double3 gradientStep() const override {  // unit-box coordinates (see evaluate)
-        if (gradientMode == ADJOINT_METHOD) raise("gradient mode ADJOINT_METHOD is not in the compiled variant set");
-        if (gradientMode != FINITE_DIFFERENCES) return {0, 0, 0};
+        // (tensor API evaluate_with_gradients: the adjoint mode is a renderer mode here, the tensor API differentiates by central
+        // differences for it like IVolumeInterpolation's base implementation does)
+        if (gradientMode == OFF_OR_DIRECT) return {0, 0, 0};
         return {finiteDifferencesStepsize, finiteDifferencesStepsize, finiteDifferencesStepsize};
     }
     void setTimeAndEnsemble(float t, int e) { check(fvsrn_network_set_time_and_ensemble(currentNetwork()->h, t, e)); }
@@ -816,7 +817,6 @@ struct ImageEvaluatorSimple {
         if (!dvr) raise("ImageEvaluatorSimple.ray_evaluator must be a RayEvaluationSteppingDvr");
         if (!camera) raise("no camera selected");
         if (doublePrecision) raise("double precision rendering is not supported by the SRN path");
-        if (vol && vol->gradientMode == ADJOINT_METHOD) raise("gradient mode ADJOINT_METHOD is not in the compiled variant set");
         camera->aspectRatio = double(width) / height;
         fvsrn_scene_desc d{};
         std::vector<float> table;
@@ -839,8 +839,14 @@ struct ImageEvaluatorSimple {
             dvr->tf->fill(d, table);
         }
         d.tf_table = table.empty() ? nullptr : table.data();
-        d.gradient_mode = vol && vol->gradientMode == FINITE_DIFFERENCES ? FVSRN_GRADIENT_FINITE_DIFFERENCES : FVSRN_GRADIENT_OFF_OR_DIRECT;
+        d.gradient_mode = !vol ? FVSRN_GRADIENT_OFF_OR_DIRECT
+                               : (vol->gradientMode == FINITE_DIFFERENCES ? FVSRN_GRADIENT_FINITE_DIFFERENCES
+                                  : (vol->gradientMode == ADJOINT_METHOD ? FVSRN_GRADIENT_ADJOINT_METHOD : FVSRN_GRADIENT_OFF_OR_DIRECT));
         d.finite_differences_stepsize = vol ? float(vol->finiteDifferencesStepsize) : 0.f;
+        if (vol && vol->gradientMode == ADJOINT_METHOD) {  // VolumeInterpolationNetwork::fillConstantMemory :1808-1812
+            const fvsrn_network_info info = vol->currentNetwork()->info();
+            d.adjoint_grid_stepsize = 1.0f / (float(std::max(info.grid_res[0], 1)) * float(vol->adjointScale));
+        }
         if (dvr->brdf) {  // BRDFLambert::fillConstantMemory, brdf.cpp:413-448
             BRDFLambert& b = *dvr->brdf;
             if (b.lightFollowsCamera) {  // updateLightFromCamera :490-508: camera origin / front = cross(up, right)
@@ -1371,9 +1377,15 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def_static("load", &SceneNetwork::load)
         .def("num_parameters", [](SceneNetwork& n) { return n.info().num_parameters; })
         .def("compute_max_warps", [](SceneNetwork& n, bool onlyShared, bool adjoint) {
-            if (adjoint) raise("the adjoint method is not part of this build");
+            // SceneNetwork::computeMaxWarps(.., adjoint) :987-1041: the reference's shared-memory budget with one more C-wide
+            // row of halfs per layer and thread; informational here (the HIP path keeps no activation store, srn_gradient.hpp)
             const fvsrn_network_info i = n.info();
-            return onlyShared ? i.max_warps_shared : i.max_warps_mixed;
+            const int plain = onlyShared ? i.max_warps_shared : i.max_warps_mixed;
+            if (!adjoint || plain <= 0) return plain;
+            const int maxCh = std::max(i.hidden_channels + i.grid_channels, 1);
+            const int freeBytes = plain * maxCh * 2 * 32;  // (48 KiB - weights) rounded down to whole warps
+            const int w = freeBytes / (maxCh * i.num_layers * 2 * 32);
+            return w > 0 ? w : -1;
         }, py::arg("only_shared_memory"), py::arg("adjoint") = false)
         .def("clear_gpu_resources", [](SceneNetwork& n) { check(fvsrn_network_clear_gpu_resources(n.h)); })
         .def("set_time_and_ensemble", [](SceneNetwork& n, float t, int e) { check(fvsrn_network_set_time_and_ensemble(n.h, t, e)); },
@@ -1455,10 +1467,7 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def("set_time_and_ensemble", &VolumeInterpolationNetwork::setTimeAndEnsemble)
         .def_readwrite("only_shared_memory", &VolumeInterpolationNetwork::onlySharedMemory)
         .def_property("gradient_mode", [](VolumeInterpolationNetwork& v) { return v.gradientMode; },
-                      [](VolumeInterpolationNetwork& v, GradientMode mode) {
-                          if (mode == ADJOINT_METHOD) raise("gradient mode ADJOINT_METHOD is not part of this build");
-                          v.gradientMode = mode;
-                      })
+                      [](VolumeInterpolationNetwork& v, GradientMode mode) { v.gradientMode = mode; })
         .def_readwrite("finite_differences_stepsize", &VolumeInterpolationNetwork::finiteDifferencesStepsize)
         .def_readwrite("adjoint_latent_grid_central_differences_stepsize_scale", &VolumeInterpolationNetwork::adjointScale);
 

@@ -217,7 +217,10 @@ typedef struct {
     /* VolumeInterpolationNetwork gradient mode (renderer_volume_tensorcores.cuh:1166-1201, GRADIENT_MODE):
      * FVSRN_GRADIENT_OFF_OR_DIRECT: normals only from networks that predict them; FVSRN_GRADIENT_FINITE_DIFFERENCES:
      * central differences of the (un-clamped) network value, 6 extra evaluations per sample, world step
-     * finite_differences_stepsize.  (ADJOINT_METHOD is not built.) */
+     * finite_differences_stepsize.  FVSRN_GRADIENT_ADJOINT_METHOD (:1198-1540): the analytic gradient w.r.t. the NORMALIZED
+     * position of density networks (colour networks: none, like the reference); computed in forward mode in the same MFMA pass
+     * (fv-srn_amd/csrc/srn_gradient.hpp), the latent grid by central differences with step adjoint_grid_stepsize in unit-box
+     * coordinates (0 = the reference's default 1 / (grid resolution * 4), volume_interpolation_network.cpp:1809-1812). */
     int gradient_mode;
     float finite_differences_stepsize;
     /* BRDFLambert (renderer/renderer_brdf_lambert.cuh:56-103, host renderer/brdf.cpp:413-508); all zero = pass-through */
@@ -231,9 +234,10 @@ typedef struct {
      * FVSRN_TF_TEXTURE and a 256-texel table; the tables are built on the device (transfer_function_texture_cuda.cu:9-90,
      * 256 entries / 256 x 256 entries with 256 quadrature steps) whenever the table or the step size changes */
     int tf_preintegration;      /* fvsrn_tf_preintegration */
+    float adjoint_grid_stepsize; /* FVSRN_GRADIENT_ADJOINT_METHOD: see gradient_mode */
 } fvsrn_scene_desc;
 typedef enum { FVSRN_PREINTEGRATE_NONE = 0, FVSRN_PREINTEGRATE_1D = 1, FVSRN_PREINTEGRATE_2D = 2 } fvsrn_tf_preintegration;
-typedef enum { FVSRN_GRADIENT_OFF_OR_DIRECT = 0, FVSRN_GRADIENT_FINITE_DIFFERENCES = 1 } fvsrn_gradient_mode;
+typedef enum { FVSRN_GRADIENT_OFF_OR_DIRECT = 0, FVSRN_GRADIENT_FINITE_DIFFERENCES = 1, FVSRN_GRADIENT_ADJOINT_METHOD = 2 } fvsrn_gradient_mode;
 typedef enum { FVSRN_LIGHT_POINT = 0, FVSRN_LIGHT_DIRECTIONAL = 1 } fvsrn_light_type;
 
 /* sizeof(fvsrn_scene_desc) / sizeof(fvsrn_network_info) of the library: lets an FFI binding verify its struct mirrors */

@@ -45,7 +45,7 @@ class _OracleScene(C.Structure):
                 ("stepsize", C.c_float), ("densityMin", C.c_float), ("densityMax", C.c_float),
                 ("earlyOut", C.c_int), ("blendMode", C.c_int), ("tfKind", C.c_int), ("tfRows", C.c_int),
                 ("tfScaleAbsorption", C.c_float), ("tfScaleEmission", C.c_float), ("tfTable", _FP),
-                ("gradientMode", C.c_int), ("fdStep", C.c_float),
+                ("gradientMode", C.c_int), ("fdStep", C.c_float), ("gridDiffStep", C.c_float),
                 ("brdfMagnitudeScaling", C.c_int), ("brdfPhong", C.c_int), ("brdfLightType", C.c_int),
                 ("brdfSpecularExponent", C.c_int), ("brdfMagScale", C.c_float), ("brdfAmbient", C.c_float),
                 ("brdfSpecular", C.c_float), ("brdfMagCenter", C.c_float), ("brdfMagRadius", C.c_float),
@@ -77,6 +77,8 @@ def lib() -> C.CDLL:
         l = C.CDLL(LIB_PATH)
         l.oracle_eval_points.restype = C.c_int
         l.oracle_eval_points.argtypes = [C.POINTER(_OracleNet), _FP, _FP, C.c_size_t, _FP]
+        l.oracle_eval_adjoint.restype = C.c_int
+        l.oracle_eval_adjoint.argtypes = [C.POINTER(_OracleNet), _FP, _FP, C.c_size_t, C.c_float, _FP]
         l.oracle_tf_evaluate.restype = None
         l.oracle_tf_evaluate.argtypes = [C.POINTER(_OracleScene), _FP, _FP, C.c_size_t, _FP]
         l.oracle_tf_preintegrate.restype = None
@@ -224,6 +226,20 @@ class OracleNetwork:
         return out
 
 
+    def adjoint_gradient(self, world_positions: np.ndarray, directions: Optional[np.ndarray] = None, grid_step: float = 0.0) -> np.ndarray:
+        """_evalNormalAdjoint (renderer_volume_tensorcores.cuh:1198-1540): (n,3) gradients of the un-clamped density w.r.t. the
+        NORMALIZED position; grid_step = 0: the reference's default 1 / (grid resolution * 4)."""
+        p = np.ascontiguousarray(world_positions, dtype=np.float32)
+        d = np.ascontiguousarray(directions, dtype=np.float32) if directions is not None else None
+        if grid_step <= 0:
+            grid_step = 1.0 / (max(int(self._n.gridX), 1) * 4.0)
+        out = np.zeros((p.shape[0], 3), np.float32)
+        r = lib().oracle_eval_adjoint(C.byref(self._n), p.ctypes.data_as(_FP), d.ctypes.data_as(_FP) if d is not None else None,
+                                      p.shape[0], grid_step, out.ctypes.data_as(_FP))
+        if r != 0:
+            raise RuntimeError("oracle_eval_adjoint failed")
+        return out
+
     def evaluate_full(self, world_positions: np.ndarray, directions: Optional[np.ndarray] = None) -> np.ndarray:
         """(N,9): value[4], predicted normal[3], predicted curvature[2] -- everything eval<> returns."""
         p = np.ascontiguousarray(world_positions, dtype=np.float32)
@@ -274,7 +290,8 @@ class OracleVolume:
 class OracleScene:
     def __init__(self, *, eye, right, up, fov_y_radians, stepsize, density_min=0.0, density_max=1.0, early_out=True,
                  blend_mode=BLEND_BEER_LAMBERT, tf_kind=TF_IDENTITY, tf_scale_absorption=1.0, tf_scale_emission=1.0,
-                 tf_table=None, gradient_mode=0, finite_differences_stepsize=0.0, brdf=None, tf_preintegration=0):
+                 tf_table=None, gradient_mode=0, finite_differences_stepsize=0.0, brdf=None, tf_preintegration=0,
+                 adjoint_grid_stepsize=0.0):
         s = _OracleScene()
         s.eye[:] = [float(v) for v in eye]
         s.right[:] = [float(v) for v in right]
@@ -297,6 +314,7 @@ class OracleScene:
             s.tfPreintegration = tf_preintegration
             s.tfPreintegrated = self._p.ctypes.data_as(_FP)
         s.gradientMode, s.fdStep = gradient_mode, finite_differences_stepsize
+        self._adjoint_grid_stepsize = adjoint_grid_stepsize
         if brdf:  # same keys as capi.Scene
             s.brdfPhong = int(brdf.get("enable_phong", False))
             s.brdfMagnitudeScaling = int(brdf.get("enable_magnitude_scaling", False))
@@ -316,6 +334,8 @@ class OracleScene:
             y1 = height
         out = np.zeros((8, height, width), np.float32)
         cnt = C.c_ulonglong(0)
+        # latentGridDifferencesStepSize of the adjoint mode: 1 / (grid resolution * 4) unless given (volume_interpolation_network.cpp:1808-1812)
+        self._s.gridDiffStep = self._adjoint_grid_stepsize if self._adjoint_grid_stepsize > 0 else 1.0 / (max(int(net._n.gridX), 1) * 4.0)
         r = lib().oracle_render(C.byref(net._n), C.byref(self._s), width, height, y0, y1, out.ctypes.data_as(_FP), C.byref(cnt))
         if r != 0:
             raise RuntimeError("oracle_render failed")

@@ -207,9 +207,10 @@ static void grid_features(const OracleNet* n, const float p[3], int chunk, float
 /* ---------------------------------------------------------------------------------------- network */
 #define ORACLE_MAX_C 256
 
-/* one WMMA-style layer: y = act(W x + b), W row-major [cout][cin] */
-static void dense_layer(const OracleNet* n, const uint16_t* W, const uint16_t* b, int cin, int cout, const float* x,
-                        float* y) {
+/* one WMMA-style layer: y = act(W x + b), W row-major [cout][cin]; pre (optional): the pre-activations, as the adjoint pass
+ * finds them (HALF: the half accumulator, sStorageForAdjointHidden :1000-1010; FLOAT: the fp32 sum) */
+static void dense_layer_tape(const OracleNet* n, const uint16_t* W, const uint16_t* b, int cin, int cout, const float* x,
+                             float* y, float* pre) {
     for (int o = 0; o < cout; ++o) {
         const uint16_t* w = W + (size_t)o * cin;
         float r;
@@ -220,14 +221,19 @@ static void dense_layer(const OracleNet* n, const uint16_t* W, const uint16_t* b
                 for (int k = k0; k < k0 + 16 && k < cin; ++k) s += (double)h2f(w[k]) * (double)x[k];
                 acc = rh_d((double)acc + s);
             }
+            if (pre) pre[o] = acc;
             r = act_half(n->activation, acc, n->actParam);
         } else {
             double s = h2f(b[o]);
             for (int k = 0; k < cin; ++k) s += (double)h2f(w[k]) * (double)x[k];
+            if (pre) pre[o] = (float)s;
             r = rh(act_float(n->activation, (float)s, n->actParam));
         }
         y[o] = r;
     }
+}
+static void dense_layer(const OracleNet* n, const uint16_t* W, const uint16_t* b, int cin, int cout, const float* x, float* y) {
+    dense_layer_tape(n, W, b, cin, cout, x, y, NULL);
 }
 
 static float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -344,6 +350,209 @@ static void srn_eval(const OracleNet* n, const float wpos[3], const float dir[3]
             break;
         default: break;
     }
+}
+
+/* ------------------------------------------------------------------------------------ adjoint method */
+/* activations::*::adjoint (renderer_activations.cuh): vAdj = act'(v) * zAdj.  HALF: the half overloads (ReLU: the intended
+ * v > 0 ? zAdj : 0 of the float / pre-sm_80 forms -- the sm_80 half branch :70 returns v instead of zAdj); FLOAT: fp32 */
+static float act_adjoint(const OracleNet* n, float v, float zAdj) {
+    const float p = n->actParam;
+    if (n->accMode == ORACLE_ACC_HALF) {
+        switch (n->activation) {
+            case ORACLE_ACT_RELU: return v > 0.f ? zAdj : 0.f;
+            case ORACLE_ACT_SINE: return hmul(zAdj, hmul(rh(p), hcosf(hmul(v, rh(p)))));
+            case ORACLE_ACT_SNAKE: return hmul(zAdj, hadd(1.0f, hsinf(hmul(rh(2 * p), v))));
+            case ORACLE_ACT_SNAKEALT: return hmul(zAdj, hadd(hsinf(hmul(rh(2 * p), v)), rh(1 / (2 * p))));
+            case ORACLE_ACT_SIGMOID: { const float ev = rh_d(exp((double)v)), ev1 = hadd(1.0f, ev); return hmul(zAdj, hdivf(ev, hmul(ev1, ev1))); }
+            default: return zAdj;
+        }
+    }
+    switch (n->activation) {
+        case ORACLE_ACT_RELU: return v > 0.f ? zAdj : 0.f;
+        case ORACLE_ACT_SINE: return (float)((double)zAdj * p * cos((double)v * p));
+        case ORACLE_ACT_SNAKE: return (float)((double)zAdj * (1.0 + sin(2.0 * p * v)));
+        case ORACLE_ACT_SNAKEALT: return (float)((double)zAdj * (sin(2.0 * p * v) + 1.0 / (2.0 * p)));
+        case ORACLE_ACT_SIGMOID: { const double ev = exp((double)v); return (float)((double)zAdj * ev / ((ev + 1) * (ev + 1))); }
+        default: return zAdj;
+    }
+}
+
+/* adjIn[cin] = sum_cout W[cout][c0 + cin] * z[cout] for cin in [0, ncin): the transposed product :1285-1335 (HALF: half
+ * accumulators of the 16-wide WMMA tiles; FLOAT: fp32) */
+static void dense_transposed(const OracleNet* n, const uint16_t* W, int stride, int c0, int ncin, int cout, const float* z, float* adjIn) {
+    for (int i = 0; i < ncin; ++i) {
+        if (n->accMode == ORACLE_ACC_HALF) {
+            float acc = 0.f;
+            for (int k0 = 0; k0 < cout; k0 += 16) {
+                double s = 0;
+                for (int k = k0; k < k0 + 16 && k < cout; ++k) s += (double)h2f(W[(size_t)k * stride + c0 + i]) * (double)z[k];
+                acc = rh_d((double)acc + s);
+            }
+            adjIn[i] = acc;
+        } else {
+            double s = 0;
+            for (int k = 0; k < cout; ++k) s += (double)h2f(W[(size_t)k * stride + c0 + i]) * (double)z[k];
+            adjIn[i] = (float)s;
+        }
+    }
+}
+
+/* one decoded, time-blended texel group of the latent grid at p (4 channels of texture t), fp32: LoadVolumetricFeaturesAdjoint :662-676 */
+static void grid_value4(const OracleNet* n, int t, float px, float py, float pz, float out[4]) {
+    float a[4], b[4];
+    tex3d(n, n->gridTexA[t], px, py, pz, a);
+    tex3d(n, n->gridTexB[t], px, py, pz, b);
+    const float time = n->gridInterpolation[t];
+    const float f = time - floorf(time);
+    for (int c = 0; c < 4; ++c) {
+        const float va = decode_grid(n, a[c], 4 * t + c), vb = decode_grid(n, b[c], 4 * t + c);
+        out[c] = va + f * (vb - va);
+    }
+}
+
+/* _evalNormalAdjoint (renderer_volume_tensorcores.cuh:1198-1540): d(density before clamping) / d(NORMALIZED position).
+ * gridStep = latentGridDifferencesStepSize.  Colour networks: zero (the reference asserts). */
+static void srn_adjoint(const OracleNet* n, const float wpos[3], const float dir[3], float gridStep, float grad[3]) {
+    const int C = n->C, F = n->F, G = n->G, NH = n->NH;
+    const int base = n->useDirection >= 1 ? 8 : 4;
+    const int half = n->accMode == ORACLE_ACC_HALF;
+    grad[0] = grad[1] = grad[2] = 0.f;
+    if (n->outputMode == ORACLE_OUT_RGBO || n->outputMode == ORACLE_OUT_RGBO_DIRECT) return;
+    float p[3];
+    for (int i = 0; i < 3; ++i) p[i] = (wpos[i] - n->boxMin[i]) / n->boxSize[i];
+    /* ---- forward pass with the pre-activations kept (the reference stores them in shared memory as halves) ---- */
+    static _Thread_local float x[ORACLE_MAX_C + 64], y[ORACLE_MAX_C], pre[16][ORACLE_MAX_C], adj[ORACLE_MAX_C + 64], z[ORACLE_MAX_C];
+    const float vx = rh(p[0]), vy = rh(p[1]), vz = rh(p[2]);
+    float dxh = 0, dyh = 0, dzh = 0;
+    if (n->useDirection >= 1) { dxh = rh(dir[0]); dyh = rh(dir[1]); dzh = rh(dir[2]); }
+    float phase[ORACLE_MAX_C];
+    x[0] = vx; x[1] = vy; x[2] = vz; x[3] = n->passTime ? rh(n->gridInterpolation[0]) : 0.f;
+    if (n->useDirection >= 1) { x[4] = dxh; x[5] = dyh; x[6] = dzh; x[7] = 0.f; }
+    const int d6 = n->useDirection == 2;
+    for (int i = 0; i < F; ++i) {
+        const float f0 = h2f(n->fourier[i]), f1 = h2f(n->fourier[i + F]), f2 = h2f(n->fourier[i + 2 * F]);
+        const float f3 = d6 ? h2f(n->fourier[i + 3 * F]) : 0.f, f4 = d6 ? h2f(n->fourier[i + 4 * F]) : 0.f, f5 = d6 ? h2f(n->fourier[i + 5 * F]) : 0.f;
+        if (half) {
+            float c = hmul(vx, f0);
+            c = hfma(vy, f1, c); c = hfma(vz, f2, c);
+            if (d6) { c = hfma(dxh, f3, c); c = hfma(dyh, f4, c); c = hfma(dzh, f5, c); }
+            phase[i] = c;
+            x[base + i] = hcosf(c); x[base + F + i] = hsinf(c);
+        } else {
+            double c = (double)vx * f0 + (double)vy * f1 + (double)vz * f2;
+            if (d6) c += (double)dxh * f3 + (double)dyh * f4 + (double)dzh * f5;
+            phase[i] = (float)c; /* (only its cos / sin are used below, from the double) */
+            x[base + i] = rh_d(cos(c)); x[base + F + i] = rh_d(sin(c));
+        }
+    }
+    float preFirst[ORACLE_MAX_C];
+    if (F == 0) { /* scalar first layer :810-823 */
+        for (int co = 0; co < C; ++co) {
+            float c;
+            if (half) {
+                c = h2f(n->bFirst[co]);
+                c = hfma(vx, h2f(n->wFirst[co + C * 0]), c); c = hfma(vy, h2f(n->wFirst[co + C * 1]), c); c = hfma(vz, h2f(n->wFirst[co + C * 2]), c);
+                if (n->useDirection >= 1) { c = hfma(dxh, h2f(n->wFirst[co + C * 3]), c); c = hfma(dyh, h2f(n->wFirst[co + C * 4]), c); c = hfma(dzh, h2f(n->wFirst[co + C * 5]), c); }
+                y[co] = act_half(n->activation, c, n->actParam);
+            } else {
+                double cd = h2f(n->bFirst[co]);
+                cd += (double)vx * h2f(n->wFirst[co + C * 0]) + (double)vy * h2f(n->wFirst[co + C * 1]) + (double)vz * h2f(n->wFirst[co + C * 2]);
+                if (n->useDirection >= 1) cd += (double)dxh * h2f(n->wFirst[co + C * 3]) + (double)dyh * h2f(n->wFirst[co + C * 4]) + (double)dzh * h2f(n->wFirst[co + C * 5]);
+                c = (float)cd;
+                y[co] = rh(act_float(n->activation, c, n->actParam));
+            }
+            preFirst[co] = c;
+        }
+        memcpy(x, y, sizeof(float) * (size_t)C);
+    }
+    float preGrid[ORACLE_MAX_C];
+    if (G > 0) {
+        for (int g = 0; g < G / 16; ++g) grid_features(n, p, g, x + C + 16 * g);
+        dense_layer_tape(n, n->wFirst, n->bFirst, C + G, C, x, y, preGrid);
+        memcpy(x, y, sizeof(float) * (size_t)C);
+    }
+    for (int l = 0; l < NH; ++l) {
+        dense_layer_tape(n, n->wHidden + (size_t)l * C * C, n->bHidden + (size_t)l * C, C, C, x, y, pre[l]);
+        memcpy(x, y, sizeof(float) * (size_t)C);
+    }
+    const int Co = n->Cout;
+    float out0;
+    if (half) {
+        float acc = h2f(n->bLast[0]);
+        for (int k = 0; k < C; ++k) acc = hfma(x[k], h2f(n->wLast[(size_t)k * Co]), acc);
+        out0 = acc;
+    } else {
+        double s = h2f(n->bLast[0]);
+        for (int k = 0; k < C; ++k) s += (double)x[k] * (double)h2f(n->wLast[(size_t)k * Co]);
+        out0 = (float)s;
+    }
+    /* ---- adjoint of the output parametrization :1225-1262 ---- */
+    float adjOut = 1.f;
+    if (n->outputMode == ORACLE_OUT_DENSITY || n->outputMode == ORACLE_OUT_DENSITY_GRADIENT || n->outputMode == ORACLE_OUT_DENSITY_CURVATURE) {
+        const double ev = half ? (double)expf(out0) : exp((double)out0); /* Sigmoid::adjoint(float) :204-209 */
+        adjOut = (float)(ev / ((ev + 1) * (ev + 1)));
+    }
+    if (half) adjOut = rh(adjOut);
+    for (int cin = 0; cin < C; ++cin) adj[cin] = half ? hmul(h2f(n->wLast[(size_t)cin * Co]), adjOut) : rh(h2f(n->wLast[(size_t)cin * Co]) * adjOut);
+    /* ---- hidden layers, last to first :1269-1336 ---- */
+    for (int l = NH - 1; l >= 0; --l) {
+        for (int co = 0; co < C; ++co) { const float a = act_adjoint(n, pre[l][co], adj[co]); z[co] = half ? a : rh(a); }
+        dense_transposed(n, n->wHidden + (size_t)l * C * C, C, 0, C, C, z, adj);
+        if (half) for (int i = 0; i < C; ++i) adj[i] = rh(adj[i]); /* store_matrix_sync of half accumulators: already half */
+    }
+    /* ---- latent grid layer :1342-1460 ---- */
+    if (G > 0) {
+        for (int co = 0; co < C; ++co) { const float a = act_adjoint(n, preGrid[co], adj[co]); z[co] = half ? a : rh(a); }
+        const float s2 = 1.0f / (2.0f * gridStep);
+        for (int g = 0; g < G / 16; ++g) {
+            float adjG[16];
+            dense_transposed(n, n->wFirst, C + G, C + 16 * g, 16, C, z, adjG);
+            for (int i = 0; i < 4; ++i) { /* LoadVolumetricFeaturesAdjoint :609-735: central differences, fp32 */
+                const int t = 4 * g + i;
+                for (int axis = 0; axis < 3; ++axis) {
+                    float hi[4], lo[4];
+                    float q[3] = {p[0], p[1], p[2]};
+                    q[axis] = p[axis] + gridStep; grid_value4(n, t, q[0], q[1], q[2], hi);
+                    q[axis] = p[axis] - gridStep; grid_value4(n, t, q[0], q[1], q[2], lo);
+                    for (int c = 0; c < 4; ++c) grad[axis] += adjG[4 * i + c] * (s2 * (hi[c] - lo[c]));
+                }
+            }
+        }
+        dense_transposed(n, n->wFirst, C + G, 0, C, C, z, adj);
+    }
+    /* ---- first layer :1466-1531 ---- */
+    if (F > 0) {
+        grad[0] += adj[0]; grad[1] += adj[1]; grad[2] += adj[2];
+        for (int i = 0; i < F; ++i) {
+            const float f0 = h2f(n->fourier[i]), f1 = h2f(n->fourier[i + F]), f2 = h2f(n->fourier[i + 2 * F]);
+            if (half) {
+                const float c = phase[i];
+                const float adjC = hsub(hmul(rh(adj[base + F + i]), hcosf(c)), hmul(rh(adj[base + i]), hsinf(c)));
+                grad[0] += hmul(f0, adjC); grad[1] += hmul(f1, adjC); grad[2] += hmul(f2, adjC);
+            } else {
+                double c = (double)vx * f0 + (double)vy * f1 + (double)vz * f2;
+                if (d6) c += (double)dxh * h2f(n->fourier[i + 3 * F]) + (double)dyh * h2f(n->fourier[i + 4 * F]) + (double)dzh * h2f(n->fourier[i + 5 * F]);
+                const double adjC = (double)adj[base + F + i] * cos(c) - (double)adj[base + i] * sin(c);
+                grad[0] += (float)(f0 * adjC); grad[1] += (float)(f1 * adjC); grad[2] += (float)(f2 * adjC);
+            }
+        }
+    } else {
+        for (int co = 0; co < C; ++co) {
+            const float a1 = act_adjoint(n, preFirst[co], adj[co]);
+            for (int axis = 0; axis < 3; ++axis) {
+                const float w = h2f(n->wFirst[co + C * axis]);
+                grad[axis] += half ? hmul(w, a1) : w * a1;
+            }
+        }
+    }
+}
+
+int oracle_eval_adjoint(const OracleNet* n, const float* pos, const float* dirs, size_t count, float gridStep, float* out3) {
+    if (!n || !pos || !out3 || n->C > ORACLE_MAX_C || n->NH > 16) return -1;
+    static const float zero[3] = {0, 0, 0};
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)count; ++i) srn_adjoint(n, pos + 3 * i, dirs ? dirs + 3 * i : zero, gridStep, out3 + 3 * i);
+    return 0;
 }
 
 int oracle_eval_points(const OracleNet* n, const float* pos, const float* dirs, size_t count, float* out) {
@@ -570,6 +779,8 @@ static void render_pixel(const OracleNet* n, const OracleScene* s, int W, int H,
                         vv[k] = vk[0];
                     }
                     g[0] = (vv[0] - vv[1]) / (2 * h); g[1] = (vv[2] - vv[3]) / (2 * h); g[2] = (vv[4] - vv[5]) / (2 * h);
+                } else if (s->gradientMode == 2) { /* GRADIENT_MODE_ADJOINT_METHOD :1198-1540 */
+                    srn_adjoint(n, pos, dir, s->gridDiffStep, g);
                 }
                 if (s->tfPreintegration) tf_eval_preintegrated(s, density2, previousDensity, c);
                 else tf_eval(s, density2, c); /* :113-133 */

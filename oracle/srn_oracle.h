@@ -52,9 +52,10 @@ typedef struct {
     int earlyOut, blendMode, tfKind, tfRows;
     float tfScaleAbsorption, tfScaleEmission;
     const float* tfTable;
-    /* GRADIENT_MODE (renderer_volume_tensorcores.cuh:1166-1201): 0 off / direct, 1 finite differences */
+    /* GRADIENT_MODE (renderer_volume_tensorcores.cuh:1166-1201): 0 off / direct, 1 finite differences, 2 adjoint method */
     int gradientMode;
     float fdStep;
+    float gridDiffStep; /* adjoint: latentGridDifferencesStepSize, normalized coordinates */
     /* BRDFLambert (renderer_brdf_lambert.cuh:19-103) */
     int brdfMagnitudeScaling, brdfPhong, brdfLightType /* 0 point, 1 directional */, brdfSpecularExponent;
     float brdfMagScale, brdfAmbient, brdfSpecular, brdfMagCenter, brdfMagRadius;
@@ -73,6 +74,8 @@ void oracle_tf_preintegrate(const float* tex, int R, int mode, float stepsize, i
 int oracle_eval_points(const OracleNet* n, const float* worldPos, const float* directions /* or NULL */, size_t count, float* out);
 /* all raw outputs of eval<>: out[count][9] = value[4], normal[3], curvature[2] */
 int oracle_eval_points_full(const OracleNet* n, const float* worldPos, const float* directions /* or NULL */, size_t count, float* out9);
+/* _evalNormalAdjoint (:1198-1540): out3[count][3] = d(un-clamped density) / d(normalized position) */
+int oracle_eval_adjoint(const OracleNet* n, const float* worldPos, const float* directions /* or NULL */, size_t count, float gridStep, float* out3);
 int oracle_render(const OracleNet* n, const OracleScene* s, int W, int H, int y0, int y1, float* out8,
                   unsigned long long* evaluatedSamples);
 unsigned long long oracle_count_samples(const OracleNet* n, const OracleScene* s, int W, int H, int y0, int y1);

@@ -381,11 +381,53 @@ def test_preintegrated_texture_tf_matches_oracle(mode, act):
     assert_images_close(img2, ref2, TOL_IMG)
 
 
-def test_adjoint_gradient_mode_fails_loudly():
-    from fvsrn_amd import capi
-    with pytest.raises(capi.FvsrnError) as e:
-        capi.Scene(**make_scene_kwargs(gradient_mode=2, finite_differences_stepsize=0.01))
-    assert e.value.code == -4
+ADJOINT_CASES = [
+    dict(net=dict(activation="SnakeAlt", output_mode="density"), brdf=None),
+    dict(net=dict(activation="ReLU", output_mode="density:direct"), brdf=PHONG, tf=dict(density_min=-1.0, density_max=1.0)),
+    dict(net=dict(activation="Sine", output_mode="density", C=64, layers=3, grid=(16, 8)), brdf=dict(PHONG, light_type=1, light=(0.3, 0.5, -1.0), enable_magnitude_scaling=True, magnitude_scaling=5.0)),
+    dict(net=dict(activation="Snake", param=2.0, output_mode="densitygrad:direct", grid=(16, 8)), brdf=PHONG, tf=dict(density_min=-1.0, density_max=1.0)),
+    dict(net=dict(activation="Sigmoid", output_mode="density", C=48, layers=3), brdf=PHONG),
+    dict(net=dict(activation="SnakeAlt", output_mode="density", no_fourier=True), brdf=PHONG),
+    dict(net=dict(activation="ReLU", output_mode="density", C=96, layers=3), brdf=PHONG),   # three passes of one tangent each
+    dict(net=dict(activation="SnakeAlt", output_mode="density", grid=(16, 8), encoding=2), brdf=PHONG),  # BYTE_GAUSSIAN grid
+]
+
+
+@pytest.mark.parametrize("case", ADJOINT_CASES)
+def test_adjoint_gradient_mode_matches_oracle(case):
+    """GRADIENT_MODE_ADJOINT_METHOD (renderer_volume_tensorcores.cuh:1198-1540): the renderer's normals and shading from the analytic
+    gradient of the network.  The HIP path differentiates in forward mode inside the MFMA pass (fv-srn_amd/csrc/srn_gradient.hpp),
+    the oracle restates the reference's backward pass (transposed weights, stored pre-activations, central differences of the
+    latent grid with step 1 / (4 * resolution)): same derivative, other rounding points."""
+    vn = util.random_network(seed=31, box_min=(-0.5, -0.5, -0.5), fourier_std=0.35, **case["net"])
+    kw = make_scene_kwargs(early_out=True, tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF, brdf=case["brdf"], gradient_mode=2, **case.get("tf", {}))
+    img, ref, stats, count = render_both(vn, kw, 40, 24)
+    assert img[3].max() > 0.05
+    assert np.abs(ref[4:7]).max() > 0.05, "no normals: the comparison would be vacuous"
+    assert_images_close(img, ref, 2 * TOL_IMG)
+    assert abs(int(stats[0]) - count) <= max(2, count // 1000)
+
+
+def test_adjoint_normals_agree_with_finite_differences():
+    """Two ways to the same normal: the analytic gradient and central differences of the network with a small step; unit box, so
+    that the adjoint's normalized coordinates are world coordinates.  Normals are normalised before blending: the images agree
+    up to the O(h^2) error of the differences."""
+    vn = util.random_network(seed=33, activation="SnakeAlt", output_mode="density", box_min=(-0.5, -0.5, -0.5), fourier_std=0.25)
+    base = dict(early_out=True, tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)
+    adj, _, _, _ = render_both(vn, make_scene_kwargs(gradient_mode=2, **base), 40, 24)
+    fd, _, _, _ = render_both(vn, make_scene_kwargs(gradient_mode=1, finite_differences_stepsize=1 / 256, **base), 40, 24)
+    assert np.abs(adj[4:7]).max() > 0.05
+    assert np.abs(adj[:4] - fd[:4]).max() < 1e-4          # colour does not depend on the normals without a shading BRDF
+    assert np.abs(adj[4:7] - fd[4:7]).max() < 0.05        # alpha-weighted unit normals
+
+
+def test_colour_networks_have_no_gradient_mode():
+    """SceneNetwork::getDefines (volume_interpolation_network.cpp:1148): colour networks render with GRADIENT_MODE off."""
+    vn = util.random_network(seed=3, activation="ReLU", output_mode="rgbo", box_min=(-0.5, -0.5, -0.5), fourier_std=0.35)
+    a, _, _, _ = render_both(vn, make_scene_kwargs(tf_kind=oracle.TF_NONE, gradient_mode=2), 24, 16)
+    b, _, _, _ = render_both(vn, make_scene_kwargs(tf_kind=oracle.TF_NONE), 24, 16)
+    # (the plain renderer takes the [0,1]-scaled ReLU image, the shaded one the plain image: equal up to fp16 subnormals)
+    assert np.abs(np.nan_to_num(a[:7], nan=-1.0) - np.nan_to_num(b[:7], nan=-1.0)).max() < 5e-4
 
 
 def test_render_ragged_image_and_row_stripes():
@@ -545,6 +587,37 @@ def test_relu_scaled_image_equals_plain_image(C, layers, grid):
     assert "RELU01" in net_scaled.kernel_name(True)
     # exact up to fp16 subnormal effects of the scaled activations: far below the parity tolerances
     assert np.abs(a - b).max() < 5e-4, np.abs(a - b).max()
+
+
+@pytest.mark.parametrize("C,layers,grid,param", [(32, 4, None, 1.0), (32, 3, None, 2.0), (64, 4, (16, 8), 0.5), (32, 4, (16, 8), 1.0), (32, 4, None, 1.5)])
+def test_snakealt_folded_image_matches_plain_image(C, layers, grid, param):
+    """SnakeAlt networks whose parameter is a power of two render from a second weight image: b = 1/(2p) is folded into the next
+    layer's weights (exact) and b * sum(W) into its fp32 bias, the activation computes x - cos(2 p x) (ACT_SNAKEALT0, pack.cpp).
+    Only the point where the activation is rounded to fp16 moves: both images agree to a few fp16 ulps of the activations and
+    both match the oracle.  p = 1.5 is not a power of two: no second image."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=C, layers=layers, activation="SnakeAlt", param=param, output_mode="density", grid=grid, seed=23,
+                             box_min=(-0.5, -0.5, -0.5), fourier_std=0.4)
+    kw = make_scene_kwargs(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF, early_out=False)
+    data = volnet_io.save_volnet(vn)
+    scene = capi.Scene(**kw)
+    net_plain = capi.Network.from_volnet(data)
+    net_plain.set_option("relu_clamp", 0)
+    plain = scene.render(net_plain, 64, 48)[0, :4].cpu().numpy()
+    net_folded = capi.Network.from_volnet(data)
+    folded = scene.render(net_folded, 64, 48)[0, :4].cpu().numpy()
+    name = net_folded.kernel_name(True)
+    if param == 1.5:
+        assert "SNAKEALT0" not in name and "act 6" not in name
+        assert np.array_equal(plain, folded)
+        return
+    assert "SNAKEALT0" in name or "act 6" in name, name
+    assert "SNAKEALT0" not in net_plain.kernel_name(True) and "act 6" not in net_plain.kernel_name(True)
+    assert plain[3].max() > 0.05
+    ref, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), 64, 48)
+    assert np.abs(plain - folded).max() < 1e-3, np.abs(plain - folded).max()
+    assert np.abs(folded - ref[:4]).max() < TOL_IMG and np.abs(plain - ref[:4]).max() < TOL_IMG
 
 
 @pytest.mark.parametrize("name", util.golden_names("g2_"))

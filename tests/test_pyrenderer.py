@@ -291,8 +291,14 @@ def test_shaded_configuration_through_the_module_api():
     ref, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), 40, 24)
     assert np.abs(ref[4:7]).max() > 0.05 and img[3].max() > 0.05
     assert np.abs(img[:7] - ref[:7]).max() < 1.2e-2
-    with pytest.raises(RuntimeError, match="ADJOINT"):
-        vol.gradient_mode = pr.VolumeInterpolationNetwork.GradientMode.ADJOINT_METHOD
+    # GradientMode.ADJOINT_METHOD through the same module tree: the analytic gradient, against the oracle's backward pass
+    vol.gradient_mode = pr.VolumeInterpolationNetwork.GradientMode.ADJOINT_METHOD
+    img2 = ev.render(40, 24).cpu().numpy()[0]
+    kw.update(gradient_mode=2)
+    ref2, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), 40, 24)
+    assert np.abs(ref2[4:7]).max() > 0.05
+    assert np.abs(img2[:7] - ref2[:7]).max() < 6e-3
+    assert vol.current_network().compute_max_warps(False, True) <= vol.current_network().compute_max_warps(False, False)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,7 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r02c5; mkdir -p $O
+timeout 600 tools/microbench/r02_issue > $O/r02_issue.txt 2>&1
+python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/pytest.txt
+for cfg in c32l4_fourier_1024x512 c32l4_grid16_1024x512 c64l6_grid16_1024x512; do tools/quick_bench.sh main --config $cfg >> $O/bench.txt; done
+sed -n '/part 5/,$p' $O/r02_issue.txt; cat $O/pytest.txt $O/bench.txt

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #define CLOB_V "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", \
                "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "vcc"
@@ -216,6 +217,107 @@ void run4(float* out, long long* clk, const char* note) {
            CVT ? "pkrtz " : "cvt_pk", simdCyclesPerStep, ghz, 64.0 * 1024.0 * ghz / simdCyclesPerStep, note);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// part 5: do transcendentals of one wave run beside plain VALU work of the other wave of the SIMD?  (waves w / w + 4)
+//   KA / KB: 0 = 32 v_cos, 1 = 32 v_fma, 2 = 32 v_cvt_pk, 3 = 16 v_pk_fma_f32; both waves loop a fixed number of iterations
+template <int KA, int KB>
+__global__ void __launch_bounds__(512) pair_kinds(float* out, int iters, long long* clk) {
+    const int wave = threadIdx.x >> 6;
+    const long long c0 = clock64();
+    auto body = [&](auto kind) {
+        constexpr int K = decltype(kind)::value;
+        for (int it = 0; it < iters; ++it) {
+            if constexpr (K == 0) asm volatile(X32(L_COS) ::: CLOB_V);
+            else if constexpr (K == 1) asm volatile(X32(L_FMA) ::: CLOB_V);
+            else if constexpr (K == 2) asm volatile(X32(L_CVTPK) ::: CLOB_V);
+            else asm volatile(X16E(L_PKFMA) ::: CLOB_V);
+        }
+    };
+    if (wave < 4) body(std::integral_constant<int, KA>{}); else body(std::integral_constant<int, KB>{});
+    const long long c1 = clock64();
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (wave == 0 || wave == 4)) clk[wave >> 2] = c1 - c0;
+    out[blockIdx.x * 512 + threadIdx.x] = 0;
+}
+template <int KA, int KB>
+void run5(float* out, long long* clk, const char* note) {
+    const int iters = 4000;
+    pair_kinds<KA, KB><<<256, 512>>>(out, 10, clk);
+    (void)hipDeviceSynchronize();
+    pair_kinds<KA, KB><<<256, 512>>>(out, iters, clk);
+    (void)hipDeviceSynchronize();
+    long long h[2];
+    (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+    printf("  %-34s wave A %6.1f cycles per iteration, wave B %6.1f\n", note, double(h[0]) / iters, double(h[1]) / iters);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// part 6: wave-step skeletons of the other two kernels, 2 waves per SIMD running the same program
+//   SnakeAlt 32x4 (register-resident kernel): the chain carries, per MFMA, 4 x { pk_mul, 2 cos, pk_add, [pk_fma], cvt }
+//   (FOLD: the 1/(2p) scale folded into the next layer's weights: no pk_fma)
+#define SA_PAIR(d) "v_pk_mul_f32 v[" #d ":" #d "+1], v[64:65], v[2:3]\nv_cos_f32 v[" #d "], v[" #d "]\nv_cos_f32 v[" #d "+1], v[" #d "+1]\nv_pk_add_f32 v[" #d ":" #d "+1], v[64:65], v[" #d ":" #d "+1]\n"
+#define SA_FMA(d) "v_pk_fma_f32 v[" #d ":" #d "+1], v[" #d ":" #d "+1], v[2:3], v[2:3]\n"
+#define SA_CVT(d) "v_cvt_pk_f16_f32 v[" #d "], v[" #d "], v[" #d "+1]\n"
+#define SA4(F) SA_PAIR(8) F(8) SA_CVT(8) SA_PAIR(10) F(10) SA_CVT(10) SA_PAIR(12) F(12) SA_CVT(12) SA_PAIR(14) F(14) SA_CVT(14)
+#define NOFMA(d) ""
+#define SA_SLOT(F) MA SA4(F) MA SA4(F) MB SA4(F) MB SA4(F)
+#define SA_CHAIN(F) MA MA SA_SLOT(F) SA_SLOT(F) MB SA4(F) MB SA4(F) M16A SA4(F) M16A SA4(F) M16B M16B
+template <int FOLD>
+__global__ void __launch_bounds__(512) snakealt_skeleton(float* out, int iters, long long* clk) {
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+        asm volatile(VPHASE(PK) ::: CLOB_V, CLOB_M);
+        if constexpr (FOLD) asm volatile(SA_CHAIN(NOFMA) ::: CLOB_V, CLOB_M); else asm volatile(SA_CHAIN(SA_FMA) ::: CLOB_V, CLOB_M);
+    }
+    const long long c1 = clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = wall_clock64() - w0; }
+    out[blockIdx.x * 512 + threadIdx.x] = 0;
+}
+//   32x4 + 16-channel latent grid (LDS kernel, no rotation): per wave step 2 phase MFMAs, 30 v_cos, ~16 + 3 converts, 3 + 8 lane
+//   swaps, ~40 scalar ops of tap arithmetic, 64 v_dot2 + 8 converts (the loads are left out), then the layer chain (18 MFMAs with
+//   48 converts) and the 16-instruction tail.  BLOCK = 1: the trilinear fetch as 6 more MFMAs on per-cell-block matrices: 3 swaps,
+//   ~2 x (15 scalar + 27 packed) for the vertex weights instead of taps / swaps / dot products.
+#define X30COS L_COS(8) L_COS(9) L_COS(10) L_COS(11) L_COS(12) L_COS(13) L_COS(14) L_COS(15) L_COS(16) L_COS(17) L_COS(18) L_COS(19) L_COS(20) L_COS(21) L_COS(22) \
+               L_COS(23) L_COS(24) L_COS(25) L_COS(26) L_COS(27) L_COS(28) L_COS(29) L_COS(30) L_COS(31) L_COS(32) L_COS(33) L_COS(34) L_COS(35) L_COS(36) L_COS(37)
+#define L_SWAP(d) "v_permlane32_swap_b32 v" #d ", v40\n"
+#define SWAP3 L_SWAP(8) L_SWAP(9) L_SWAP(10)
+#define SWAP8 SWAP3 L_SWAP(11) L_SWAP(12) L_SWAP(13) L_SWAP(14) L_SWAP(15)
+#define F16x F8 F8
+#define GRID_GATHER SWAP8 F16x F16x F8 X32(L_DOT2) X32(L_DOT2) CV8(PK, 64)
+#define GRID_BLOCK F16x F8 F4 F2 X16E(L_PKMUL) X16E(L_PKMUL) CV8(PK, 64) CV8(PK, 80) CV8(PK, 64) L_PKMUL(8) L_PKMUL(10) L_PKMUL(12) MA MB MA MB MA MB
+#define LAYERS MA MA SLOT(PK) SLOT(PK) MB CV4(PK, 64) MB CV4(PK, 64) M16A CV4(PK, 80) M16A CV4(PK, 80) M16B M16B
+template <int BLOCK>
+__global__ void __launch_bounds__(768) grid_skeleton(float* out, int iters, long long* clk) {
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+        asm volatile(SWAP3 CV2(PK, 64) L_CVTPK(10) MA MB X30COS CV8(PK, 64) CV8(PK, 80) ::: CLOB_V, CLOB_M);
+        if constexpr (BLOCK) asm volatile(GRID_BLOCK ::: CLOB_V, CLOB_M); else asm volatile(GRID_GATHER MA MB ::: CLOB_V, CLOB_M);
+        asm volatile(LAYERS F8 F8 ::: CLOB_V, CLOB_M);
+    }
+    const long long c1 = clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = wall_clock64() - w0; }
+    out[blockIdx.x * 768 + threadIdx.x] = 0;
+}
+template <class K>
+void run6(K kernel, int threads, float* out, long long* clk, const char* note) {
+    const int iters = 2000;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    kernel<<<256, threads>>>(out, 10, clk);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    kernel<<<256, threads>>>(out, iters, clk);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    long long h[2];
+    (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+    const double ghz = double(h[0]) / (double(h[1]) * 10.0);
+    const double cyc = double(ms) * 1e6 * ghz / iters / (threads / 256);
+    printf("  %-58s %7.1f SIMD cycles per wave step (%.2f GHz): %.1f Gsamples/s at this clock, %.1f at 2.04 GHz\n", note, cyc, ghz, 64.0 * 1024.0 * ghz / cyc,
+           64.0 * 1024.0 * 2.04 / cyc);
+}
+
 int main(int argc, char** argv) {
     float* out; long long* clk;
     (void)hipMalloc(&out, 1024 * 512 * 4);
@@ -249,5 +351,13 @@ int main(int argc, char** argv) {
     run4<0, 0, 8>(out, clk, ""); run4<1, 0, 8>(out, clk, "shipped policy"); run4<2, 0, 8>(out, clk, ""); run4<3, 0, 8>(out, clk, "staggered start");
     run4<0, 1, 8>(out, clk, ""); run4<1, 1, 8>(out, clk, ""); run4<2, 1, 8>(out, clk, ""); run4<3, 1, 8>(out, clk, "staggered start");
     run4<0, 0, 12>(out, clk, "3 waves"); run4<1, 0, 12>(out, clk, "3 waves"); run4<1, 1, 12>(out, clk, "3 waves");
+    printf("== part 5: two waves on one SIMD, each with one instruction kind (alone = the other wave idle)\n");
+    run5<0, 0>(out, clk, "A cos, B cos"); run5<1, 1>(out, clk, "A fma, B fma"); run5<0, 1>(out, clk, "A cos, B fma"); run5<0, 2>(out, clk, "A cos, B cvt_pk");
+    run5<0, 3>(out, clk, "A cos, B pk_fma_f32 (16 per iteration)"); run5<2, 1>(out, clk, "A cvt_pk, B fma"); run5<2, 2>(out, clk, "A cvt_pk, B cvt_pk");
+    printf("== part 6: wave-step skeletons, 2 (SnakeAlt) / 3 (latent grid) waves per SIMD\n");
+    run6(snakealt_skeleton<0>, 512, out, clk, "32x4 SnakeAlt, as shipped in r01");
+    run6(snakealt_skeleton<1>, 512, out, clk, "32x4 SnakeAlt, 1/(2p) folded into the next layer");
+    run6(grid_skeleton<0>, 768, out, clk, "32x4 + latent grid, gather + v_dot2 (loads left out)");
+    run6(grid_skeleton<1>, 768, out, clk, "32x4 + latent grid, trilinear fetch as 6 MFMAs on cell-block matrices");
     return 0;
 }
