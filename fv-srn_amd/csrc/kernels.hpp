@@ -16,7 +16,14 @@ namespace fvsrn {
 // slowest wave (= longest ray of 4 pixel tiles) is done, so small networks run one wave per workgroup.
 constexpr int kBlockThreads = 256;  // upper bound (launch bounds)
 // register budget: 512 / waves.  32-wide Fourier-only kernels (input features + their rotation in registers) fit 168.
-constexpr int min_waves_per_simd(int CD, int GRID) { return CD >= 8 ? 1 : (CD == 2 && GRID == 0 ? FVSRN_WAVES_PER_EU_CD2 : FVSRN_WAVES_PER_EU); }
+#ifndef FVSRN_WAVES_PER_EU_CD2_GRID
+#define FVSRN_WAVES_PER_EU_CD2_GRID 3
+#endif
+constexpr int min_waves_per_simd(int CD, int GRID) {
+    // 32 wide: Fourier-only and decoded-grid kernels fit the 168 registers of 3 waves per SIMD (r02, 32x4 + 16^3 grid: gathers hoisted
+    // in front of the Fourier work, GridPre: 2 waves 66.8, 3 waves 69.5 Gsamples/s; without the hoist 68.5); BYTE_GAUSSIAN would spill
+    return CD >= 8 ? 1 : (CD == 2 ? (GRID == 0 ? FVSRN_WAVES_PER_EU_CD2 : (GRID == 1 ? FVSRN_WAVES_PER_EU_CD2_GRID : FVSRN_WAVES_PER_EU)) : FVSRN_WAVES_PER_EU);
+}
 // __launch_bounds__(256, 2): at most 256 registers per lane, which also makes hipcc use the VGPR form of the MFMA
 // (accumulators in AGPRs cost one v_accvgpr_read per value before the VALU can touch them: +32 VALU per layer).
 // C = 128 needs more than 256 registers and takes the 512-register budget instead.

@@ -241,21 +241,30 @@ struct GridRaw {
 };
 
 __device__ __forceinline__ void grid_load(const void* grid, const GridTap& t, int g, int h, GridRaw& r) {
-    const char* base = reinterpret_cast<const char*>(grid) + (g * 64 + h * 32);
+    // wave-uniform base + 32-bit per-lane offset: the loads take the SGPR-base form (no 64-bit address arithmetic per record)
+    const char* base = reinterpret_cast<const char*>(grid) + g * 64;
+    const unsigned hoff = unsigned(h) * 32u;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
 #ifdef FVSRN_ABL_NOGRIDLOAD  // ablation build (tools/ablate.sh): no memory access
         r.v[k][0] = uint4_t{t.off[k], t.w[k], 0x3c003c00u, 0x38003800u};
         r.v[k][1] = uint4_t{t.w[k], t.off[k], 0x3c003c00u, 0x38003800u};
 #else
-        const uint4_t* p = reinterpret_cast<const uint4_t*>(base + t.off[k]);
+        const uint4_t* p = reinterpret_cast<const uint4_t*>(base + (t.off[k] + hoff));
         r.v[k][0] = p[0];
         r.v[k][1] = p[1];
 #endif
     }
 }
 
-template <bool WITH_LO>
+// FIRST: record 0 starts the sums (v_dot2_f32_f16 with the constant 0 as its addend: hipcc otherwise picks the accumulate-in-place
+// form v_dot2c and spends a v_mov per accumulator on the zeros -- 16 of the 57 v_mov of the r01 wave step)
+__device__ __forceinline__ float dot2_from_zero(unsigned a, unsigned w) {
+    float r;
+    asm("v_dot2_f32_f16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
+template <bool WITH_LO, bool FIRST = false>
 __device__ __forceinline__ void grid_reduce_record(const GridRaw& r, const GridTap& t, int k, float acc[8]) {
     const half2_t w = __builtin_bit_cast(half2_t, t.w[k]);
 #pragma unroll
@@ -263,8 +272,13 @@ __device__ __forceinline__ void grid_reduce_record(const GridRaw& r, const GridT
         // NB: __builtin_bit_cast applied directly to a vector ELEMENT (v[j]) is miscompiled by clang 22 /
         // ROCm 7.2 (only element 0 survives): go through a scalar temporary
         const unsigned u0 = r.v[k][0][j], u1 = r.v[k][1][j];
-        acc[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u0), w, acc[j], false);
-        acc[4 + j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u1), w, acc[4 + j], false);
+        if constexpr (FIRST) {
+            acc[j] = dot2_from_zero(u0, t.w[k]);
+            acc[4 + j] = dot2_from_zero(u1, t.w[k]);
+        } else {
+            acc[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u0), w, acc[j], false);
+            acc[4 + j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u1), w, acc[4 + j], false);
+        }
         if constexpr (WITH_LO) {
             const half2_t wl = __builtin_bit_cast(half2_t, t.wlo[k]);
             acc[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u0), wl, acc[j], false);
@@ -288,10 +302,9 @@ template <bool WITH_LO>
 __device__ __forceinline__ void grid_fetch8(const void* grid, const GridTap& t, int g, int h, float acc[8]) {
     GridRaw r;
     grid_load(grid, t, g, h, r);
+    grid_reduce_record<WITH_LO, true>(r, t, 0, acc);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) grid_reduce_record<WITH_LO>(r, t, k, acc);
+    for (int k = 1; k < 4; ++k) grid_reduce_record<WITH_LO>(r, t, k, acc);
 }
 
 // 8 channels [16*g + 8*h, +8) of the tile sample described by `t`, as the B fragment of latent K step g
@@ -907,10 +920,9 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
         __builtin_amdgcn_sched_barrier(0);
         {
             float acc[8];
+            grid_reduce_record<false, true>(raw, G.gt[0], 0, acc);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) grid_reduce_record<false>(raw, G.gt[0], k, acc);
+            for (int k = 1; k < 4; ++k) grid_reduce_record<false>(raw, G.gt[0], k, acc);
             G.gf[0] = grid_pack(acc);
         }
         grid_load(P.grid, G.gt[1], 0, h, raw);
@@ -919,10 +931,9 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
         __builtin_amdgcn_sched_barrier(0);
         {
             float acc[8];
+            grid_reduce_record<false, true>(raw, G.gt[1], 0, acc);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) grid_reduce_record<false>(raw, G.gt[1], k, acc);
+            for (int k = 1; k < 4; ++k) grid_reduce_record<false>(raw, G.gt[1], k, acc);
             G.gf[1] = grid_pack(acc);
         }
         return srn_layers<CD, ACT, GRID, HAS_DIR, 0, false>(P, lds, xb, px, py, pz, []() {}, [](int) {}, &G);
