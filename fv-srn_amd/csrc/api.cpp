@@ -810,8 +810,9 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
             const VariantKey& k = net->keyScaled;
             const bool scalarNet = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
             const bool colourNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
-            if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && k.grid == 0 && !P.noFourier && !P.fourierNeedsFract && (scalarNet || colourNet) &&
-                render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1))
+            const int smallGrid = k.grid == 1 && P.gridK == 1 ? 1 : k.grid;
+            if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !P.noFourier && !P.fourierNeedsFract && (scalarNet || colourNet) &&
+                render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1, smallGrid))
                 name = "render_small_kernel<act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "," + std::to_string(P.numLayers) +
                        "> (unshaded; else " + name + ")";
         }
@@ -1105,13 +1106,15 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             // Small networks in registers (render_small_kernel, kernels.hpp): 32-wide Fourier-only scalar network with at most
             // three C->C layers, phases inside the v_cos domain, a transfer function, no shading.  FVSRN_SMALL_KERNEL=0: off.
             const void* smallFn = nullptr;
+            int smallGrid = 0;
             const int smallTail = rgbo ? 3 : (d.tf_kind == FVSRN_TF_PIECEWISE || d.tf_kind == FVSRN_TF_GAUSSIAN ? 2 : 1);  // kernels.hpp TAIL_*
             {
                 const VariantKey& k = net->keyScaled;
                 const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
-                if (O[FVSRN_OPT_SMALL_KERNEL] != 0 && net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && !a.shaded && k.CD == 2 && k.grid == 0 && !a.P.noFourier && !a.P.fourierNeedsFract &&
+                smallGrid = k.grid == 1 && a.P.gridK == 1 ? 1 : k.grid;  // one decoded 16-channel chunk: resident kernel with direct features
+                if (O[FVSRN_OPT_SMALL_KERNEL] != 0 && net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && !a.shaded && k.CD == 2 && smallGrid <= 1 && !a.P.noFourier && !a.P.fourierNeedsFract &&
                     a.P.numLayers >= 1 && a.P.numLayers <= 3 && (rgbo || (scalarNet && d.tf_kind != FVSRN_TF_NONE)))
-                    smallFn = render_small_fn(k.act, k.dir, a.P.numLayers, smallTail);
+                    smallFn = render_small_fn(k.act, k.dir, a.P.numLayers, smallTail, smallGrid);
             }
             const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded, smallFn, O[FVSRN_OPT_MAX_BLOCKS_PER_CU]);
             const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));  // workgroups the chip holds at once
@@ -1172,7 +1175,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             // starts the long rays first, which pays whenever a workgroup holds several waves or waits on memory.
             const bool useOrder = O[FVSRN_OPT_TILE_ORDER] >= 0 ? O[FVSRN_OPT_TILE_ORDER] == 1 : (S.tileCounter == nullptr && (wpb > 1 || net->key.grid != 0));
             S.tileOrder = useOrder ? scene->tileOrder(S, P_boxCenter(a.P), tilesX, tilesY, s) : nullptr;
-            hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, a, grid, unsigned(64 * wpb), lds, s)
+            hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid, a, grid, unsigned(64 * wpb), lds, s)
                                    : launch_render(a.shaded ? net->key : net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
             if (e == hipSuccess && K > 1) e = launch_composite(S.partial, d_out8, K, plane, S, s);
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during rendering! ") + hipGetErrorString(e));

@@ -297,7 +297,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     const int K = S.segments;
 #endif
     const int numUnits = numTiles * K;
-    ResidentNet<(NLC > 0 ? NLC : 1)> resident;
+    ResidentNet<(NLC > 0 ? NLC : 1), (NLC > 0 && GRID == 1 ? 1 : 0)> resident;
     if constexpr (NLC > 0) load_resident(P, lds, resident);
     // TAIL_SCALAR_TABLE: loop-invariant scalars
     const float alphaLimit = S.earlyOut ? S.alphaEarlyOut : __builtin_inff();
@@ -369,7 +369,10 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
 #ifdef FVSRN_NO_ROTATE
     constexpr bool kRotate = false;
 #else
-    constexpr bool kRotate = CD == 2 && GRID == 0 && FMODE != FM_FIRST_LAYER && !SHADED;
+#ifndef FVSRN_ROTATE_GRID
+#define FVSRN_ROTATE_GRID 0
+#endif
+    constexpr bool kRotate = CD == 2 && (GRID == 0 || (GRID == 1 && FVSRN_ROTATE_GRID && NLC == 0)) && FMODE != FM_FIRST_LAYER && !SHADED;
 #endif
     floatx16 feat[2][mtiles(CD)], dfeat[2][mtiles(CD)];
     float stepIndex = float(i0);
@@ -421,6 +424,8 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             }
             if constexpr (NLC > 0) o = srn_forward_rotating_resident<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeat);
             else o = srn_forward_rotating<CD, ACT, GRID, HAS_DIR>(P, lds, feat, dfeat, px, py, pz);
+        } else if constexpr (NLC > 0 && GRID == 1) {
+            o = srn_forward_resident_grid<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, px, py, pz, dx, dy, dz);
         } else {
             o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz);
         }
@@ -659,12 +664,14 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void r
 // 32-wide Fourier-only scalar networks with NLC <= 3 C->C layers behind a transfer function, phases inside the v_cos domain
 // (the host checks all of that, api.cpp): weights and biases in registers, 2 waves per SIMD (256 registers)
 // TAILK: TAIL_SCALAR_TABLE (Identity / Texture TF), TAIL_SCALAR_LOOP (Piecewise / Gaussian TF) or TAIL_RGBO (colour network)
-template <int ACT, bool HAS_DIR, int NLC, int TAILK>
+// SGRID = 1: the same with ONE 16-channel latent grid chunk of decoded values (direct Fourier features instead of the rotation:
+// the registers of the rotation state hold the grid fetch)
+template <int ACT, bool HAS_DIR, int NLC, int TAILK, int SGRID = 0>
 __global__ __launch_bounds__(kBlockThreads, 2) void render_small_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                       unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* tfLds = render_prologue(P, S, lds);
-    render_body<2, ACT, 0, HAS_DIR, FM_COS, false, TAILK, NLC>(P, S, lds, tfLds, out, stats);
+    render_body<2, ACT, SGRID, HAS_DIR, FM_COS, false, TAILK, NLC>(P, S, lds, tfLds, out, stats);
 }
 
 // finite-difference normals / shading BRDF (SceneParams::gradientMode, brdf*): 7 network evaluations per sample

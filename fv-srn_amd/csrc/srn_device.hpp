@@ -952,14 +952,42 @@ __device__ __forceinline__ float4_t srn_forward_rotating(const NetParams& P, con
     constexpr int NP = 16 * mtiles(CD);
     constexpr int NFILL = 0;
     half8_t xb[2][2 * mtiles(CD)];
-    return srn_layers<CD, ACT, GRID, HAS_DIR, NFILL, false>(
-        P, lds, xb, px, py, pz,
-        [&]() {
-            feature_fragments<CD>(feat, xb);
+    if constexpr (GRID == 1) {
+        // latent grid + rotated features: the gathers of a tile are in flight behind that tile's converts and rotations (GridPre)
+        constexpr int MT = mtiles(CD);
+        const int h = lane_id() >> 5;
+        GridPre G;
+        grid_tap_bcast<false>(grid_tap(P, px, py, pz), G.gt[0], G.gt[1]);
+        G.valid = 1;
+        GridRaw raw;
 #pragma unroll
-            for (int c = 0; c < NP - NFILL; ++c) fourier_advance_piece<CD, HAS_DIR>(feat, dfeat, c);
-        },
-        [&](int j) { fourier_advance_piece<CD, HAS_DIR>(feat, dfeat, NP - NFILL + j); });
+        for (int t = 0; t < 2; ++t) {
+            grid_load(P.grid, G.gt[t], 0, h, raw);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(feat[t][m], q, 0.f, 0.f, xb[t][2 * m], xb[t][2 * m + 1]);
+#pragma unroll
+            for (int c = t * 8 * MT; c < (t + 1) * 8 * MT; ++c) fourier_advance_piece<CD, HAS_DIR>(feat, dfeat, c);
+            __builtin_amdgcn_sched_barrier(0);
+            float acc[8];
+            grid_reduce_record<false, true>(raw, G.gt[t], 0, acc);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) grid_reduce_record<false>(raw, G.gt[t], k, acc);
+            G.gf[t] = grid_pack(acc);
+        }
+        return srn_layers<CD, ACT, GRID, HAS_DIR, 0, false>(P, lds, xb, px, py, pz, []() {}, [](int) {}, &G);
+    } else {
+        return srn_layers<CD, ACT, GRID, HAS_DIR, NFILL, false>(
+            P, lds, xb, px, py, pz,
+            [&]() {
+                feature_fragments<CD>(feat, xb);
+#pragma unroll
+                for (int c = 0; c < NP - NFILL; ++c) fourier_advance_piece<CD, HAS_DIR>(feat, dfeat, c);
+            },
+            [&](int j) { fourier_advance_piece<CD, HAS_DIR>(feat, dfeat, NP - NFILL + j); });
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -973,15 +1001,19 @@ __device__ __forceinline__ float4_t srn_forward_rotating(const NetParams& P, con
 #ifndef FVSRN_SLOT_ORDER
 #define FVSRN_SLOT_ORDER 0
 #endif
-template <int NLC>
+// RGRID = 1: the network has one 16-channel latent grid chunk: the phase fragment and the latent K-step fragment of layer 0 stay
+// resident too (render_small_kernel with a latent grid: direct Fourier features, no LDS access in the sample loop either)
+template <int NLC, int RGRID = 0>
 struct ResidentNet {
     half8_t w[2 * (NLC + 1)];  // [layer 0 | hidden 1..NLC-1 | last][K step]
     floatx16 b[NLC];           // bias rows of this lane half, layers 0..NLC-1
     float4_t bLast;
+    half8_t wg[RGRID ? 1 : 0];  // latent K step of layer 0
+    half8_t wp[RGRID ? 1 : 0];  // phase fragment
 };
 
-template <int NLC>
-__device__ __forceinline__ void load_resident(const NetParams& P, const char* lds, ResidentNet<NLC>& R) {
+template <int NLC, int RGRID>
+__device__ __forceinline__ void load_resident(const NetParams& P, const char* lds, ResidentNet<NLC, RGRID>& R) {
     const int lane = lane_id();
     const char* ldsA = lds + 16 * lane;
     const char* ldsB = lds + 16 * (lane >> 5);
@@ -1001,12 +1033,17 @@ __device__ __forceinline__ void load_resident(const NetParams& P, const char* ld
         }
     }
     R.bLast = *reinterpret_cast<const float4_t*>(lds + P.offBias + NLC * 128);
+    if constexpr (RGRID != 0) {
+        R.wg[0] = *reinterpret_cast<const half8_t*>(ldsA + P.offLayer0 + 2 * kFragBytes);  // [g = 0][m = 0] behind the MT * KS Fourier fragments
+        R.wp[0] = *reinterpret_cast<const half8_t*>(ldsA + P.offPhase);
+    }
 }
 
 // srn_layers_pipelined for CD = 2, GRID = 0 on a ResidentNet; returns the raw outputs of this lane's sample (ALL4: all four,
 // colour networks; otherwise only output 0)
-template <int ACT, int NLC, int NFILL, bool ALL4, class Pre, class Fill>
-__device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, const ResidentNet<NLC>& R, half8_t (&xb)[2][2], Pre&& pre, Fill&& fill) {
+template <int ACT, int NLC, int NFILL, bool ALL4, int RGRID = 0, class Pre, class Fill>
+__device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, const ResidentNet<NLC, RGRID>& R, half8_t (&xb)[2][2], Pre&& pre, Fill&& fill,
+                                                        const half8_t* gf = nullptr) {
     const float actA = P.actA, actB = P.actB;
     constexpr int NF0 = NFILL / 2;
     floatx16 acc[2];
@@ -1020,6 +1057,10 @@ __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, cons
     // first layer, tile 0 (its MFMAs carry rotation pieces)
     interleave<2, NF0>([&](int i) { acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.w[i], xb[0][i], i == 0 ? R.b[0] : acc[0], 0, 0, 0); },
                        [&](int j) { fill(j); });
+    if constexpr (RGRID != 0) {  // latent K step of layer 0 (gf: B fragments of the two tiles' latent features)
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wg[0], gf[0], acc[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // half-layer slot: layer l for tile T || activation + convert of the other tile
     auto slot = [&](auto tileTag, auto layerTag) {
         constexpr int T = decltype(tileTag)::value, O = 1 - T, L = decltype(layerTag)::value;
@@ -1037,6 +1078,10 @@ __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, cons
         interleave<2, 4>([&](int i) { acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.w[2 * L + i], xb[T][i], i == 0 ? R.b[L] : acc[T], 0, 0, 0); },
                          [&](int q) { act_pack_quarter<ACT>(acc[O], q, actA, actB, xb[O][0], xb[O][1]); });
 #endif
+        if constexpr (RGRID != 0 && L == 0) {
+            acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wg[0], gf[T], acc[T], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     using T0 = std::integral_constant<int, 0>;
     using T1 = std::integral_constant<int, 1>;
@@ -1056,6 +1101,38 @@ __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, cons
     float4_t out = {h ? o1[0] : o0[0], 0.f, 0.f, 0.f};
     if constexpr (ALL4) { out[1] = h ? o1[1] : o0[1]; out[2] = h ? o1[2] : o0[2]; out[3] = h ? o1[3] : o0[3]; }
     return out;
+}
+
+// 32-wide network with one 16-channel latent grid chunk, resident in registers: direct Fourier features (one phase MFMA + v_cos per
+// tile), the tile's 8 gathers in flight behind them (GridPre order), then srn_layers_resident with the latent K step
+template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
+__device__ __forceinline__ float4_t srn_forward_resident_grid(const NetParams& P, const ResidentNet<NLC, 1>& R, float px, float py, float pz,
+                                                             float dx, float dy, float dz) {
+    constexpr int NPASS = HAS_DIR ? 4 : 2;
+    const int h = lane_id() >> 5;
+    half8_t xb[2][2], gf[2];
+    GridTap gt[2];
+    grid_tap_bcast<false>(grid_tap(P, px, py, pz), gt[0], gt[1]);
+    half8_t b0[2];
+    phase_operands<HAS_DIR, true>(px, py, pz, dx, dy, dz, h, b0);
+    GridRaw raw;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        grid_load(P.grid, gt[t], 0, h, raw);
+        __builtin_amdgcn_sched_barrier(0);
+        floatx16 d = {0};
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wp[0], b0[t], d, 0, 0, 0);
+        phase_cos<FM_COS>(d, NPASS);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d, q, 0.f, 0.f, xb[t][0], xb[t][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        float acc[8];
+        grid_reduce_record<false, true>(raw, gt[t], 0, acc);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) grid_reduce_record<false>(raw, gt[t], k, acc);
+        gf[t] = grid_pack(acc);
+    }
+    return srn_layers_resident<ACT, NLC, 0, ALL4, 1>(P, R, xb, []() {}, [](int) {}, gf);
 }
 
 // srn_forward_rotating on a ResidentNet

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-V=${1:-v13}
+V=${1:-r02}
 python -m pytest tests -m gpu -x -q 2>&1 | tail -1
 python bench.py > gpurun_out/bench_${V}.json 2> gpurun_out/bench_${V}.err
 for c in c32l4_fourier_512x256 c32l4_grid16_1024x512 c64l6_grid16_1024x512 c64l6_grid16_time16_1024x512; do python bench.py --config $c --no-cpu-baseline > gpurun_out/bench_${V}_$c.json 2>/dev/null; done
