@@ -65,6 +65,7 @@ struct NetParams {
     float gridFrac;
     int gridEncoding, gridTimeChannels;
     int gridX, gridY, gridZ, gridC;
+    float gridXf, gridYf, gridZf;  // the same as floats (grid_tap works in fp32: fewer than 2^24 records, pack.cpp)
 };
 
 struct SceneParams {

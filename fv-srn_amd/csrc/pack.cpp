@@ -256,6 +256,10 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
     // The latent grid is packed first: the ReLU scaling below needs the range of its channels.
     packLatentGrid(net, P);
     np.gridX = P.gridX; np.gridY = P.gridY; np.gridZ = P.gridZ; np.gridC = P.gridC;
+    np.gridXf = float(P.gridX); np.gridYf = float(P.gridY); np.gridZf = float(P.gridZ);
+    // grid_tap (srn_device.hpp) computes record indices in fp32 and byte offsets in 32 bits
+    if (double(P.gridZ) * P.gridY * (P.gridX + 1) >= 16777216.0 || double(P.gridZ) * P.gridY * (P.gridX + 1) * P.gridC * 4.0 >= 4294967296.0)
+        throw Unsupported("latent grids with 2^24 or more records are not in the compiled variant set");
 
     // ---- C->C layers + last layer, optionally with power-of-two activation scaling (see reluExponents) -----
     // exps == nullptr: plain image.  exps[l] = e_l: layer l produces h_l * 2^-e_l, i.e. W'_l = W_l * 2^(e_{l-1} - e_l),

@@ -174,20 +174,23 @@ struct GridTap {
 };
 
 __device__ __forceinline__ GridTap grid_tap(const NetParams& P, float px, float py, float pz) {
-    const float fx = px * float(P.gridX) - 0.5f, fy = py * float(P.gridY) - 0.5f, fz = pz * float(P.gridZ) - 0.5f;
+    // Record indices in fp32 (exact below 2^24 records, which pack.cpp guarantees): clamps are v_med3_f32, the row / record arithmetic
+    // is 8 v_fma_f32 -- the integer form needed 10 min / max, 3 v_mul_lo_u32 and 4 v_mad_u64_u32 (quarter rate) per sample.
+    const float fx = fmaf(px, P.gridXf, -0.5f), fy = fmaf(py, P.gridYf, -0.5f), fz = fmaf(pz, P.gridZf, -0.5f);
     const float x0f = floorf(fx), y0f = floorf(fy), z0f = floorf(fz);
     const float wx = fx - x0f, wy = fy - y0f, wz = fz - z0f;
-    const int xi = min(max(int(x0f) + 1, 0), P.gridX);  // record index: x-clamping is baked into the records
-    const int y0 = min(max(int(y0f), 0), P.gridY - 1), y1 = min(max(int(y0f) + 1, 0), P.gridY - 1);
-    const int z0 = min(max(int(z0f), 0), P.gridZ - 1), z1 = min(max(int(z0f) + 1, 0), P.gridZ - 1);
+    const float xi = __builtin_amdgcn_fmed3f(x0f + 1.f, 0.f, P.gridXf);  // record index: x-clamping is baked into the records
+    const float ym = P.gridYf - 1.f, zm = P.gridZf - 1.f;
+    const float y0 = __builtin_amdgcn_fmed3f(y0f, 0.f, ym), y1 = __builtin_amdgcn_fmed3f(y0f + 1.f, 0.f, ym);
+    const float z0 = __builtin_amdgcn_fmed3f(z0f, 0.f, zm), z1 = __builtin_amdgcn_fmed3f(z0f + 1.f, 0.f, zm);
+    const float rowLen = P.gridXf + 1.f;                     // records per (z, y) row
     const unsigned rec = unsigned(P.gridC) * 4u;             // bytes per record: G channels x 2 x fp16
-    const unsigned row = unsigned(P.gridX + 1) * rec;
-    const unsigned xo = unsigned(xi) * rec;
+    const float r00 = fmaf(z0, P.gridYf, y0), r01 = fmaf(z0, P.gridYf, y1), r10 = fmaf(z1, P.gridYf, y0), r11 = fmaf(z1, P.gridYf, y1);
     GridTap t;
-    t.off[0] = unsigned(z0 * P.gridY + y0) * row + xo;
-    t.off[1] = unsigned(z0 * P.gridY + y1) * row + xo;
-    t.off[2] = unsigned(z1 * P.gridY + y0) * row + xo;
-    t.off[3] = unsigned(z1 * P.gridY + y1) * row + xo;
+    t.off[0] = __umul24(unsigned(fmaf(r00, rowLen, xi)), rec);
+    t.off[1] = __umul24(unsigned(fmaf(r01, rowLen, xi)), rec);
+    t.off[2] = __umul24(unsigned(fmaf(r10, rowLen, xi)), rec);
+    t.off[3] = __umul24(unsigned(fmaf(r11, rowLen, xi)), rec);
     const float ux = 1.f - wx, uy = 1.f - wy, uz = 1.f - wz;
     const float w4[4] = {uz * uy, uz * wy, wz * uy, wz * wy};
 #pragma unroll
@@ -1116,15 +1119,22 @@ __device__ __forceinline__ float4_t srn_forward_resident_grid(const NetParams& P
     half8_t b0[2];
     phase_operands<HAS_DIR, true>(px, py, pz, dx, dy, dz, h, b0);
     GridRaw raw;
+    grid_load(P.grid, gt[0], 0, h, raw);
+    // both phase MFMAs first: the second runs while the first tile's cosines issue (one exposed MFMA latency instead of two)
+    floatx16 d[2];
+    {
+        const floatx16 z = {0};
+        d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wp[0], b0[0], z, 0, 0, 0);
+        d[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wp[0], b0[1], z, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        grid_load(P.grid, gt[t], 0, h, raw);
+        if (t == 1) grid_load(P.grid, gt[1], 0, h, raw);
         __builtin_amdgcn_sched_barrier(0);
-        floatx16 d = {0};
-        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wp[0], b0[t], d, 0, 0, 0);
-        phase_cos<FM_COS>(d, NPASS);
+        phase_cos<FM_COS>(d[t], NPASS);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d, q, 0.f, 0.f, xb[t][0], xb[t][1]);
+        for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d[t], q, 0.f, 0.f, xb[t][0], xb[t][1]);
         __builtin_amdgcn_sched_barrier(0);
         float acc[8];
         grid_reduce_record<false, true>(raw, gt[t], 0, acc);
