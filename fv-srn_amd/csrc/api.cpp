@@ -1046,6 +1046,7 @@ static void fillSceneParams(fvsrn_scene* scene, const fvsrn_scene_desc& d, int w
     S.tfRows = d.tf_rows; S.tfRowsF = float(d.tf_rows);
     S.tfScaleAbsorption = d.tf_scale_absorption;
     S.tfScaleEmission = d.tf_scale_emission;
+    S.tfAbsorptionStep = d.tf_scale_absorption * d.stepsize;
     S.tfTable = static_cast<const float*>(scene->dTf.ptr);
     S.tfPreintegration = d.tf_preintegration;
     S.tfPreintegrated = static_cast<const float*>(scene->dPreint.ptr);

@@ -265,6 +265,13 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // rgbo:direct, no transfer function) in the same frame.
 enum { TAIL_GENERIC = 0, TAIL_SCALAR_TABLE = 1, TAIL_SCALAR_LOOP = 2, TAIL_RGBO = 3 };
 
+// x in the lanes whose bit is set in the wave mask m (an SGPR pair), 0 elsewhere: one v_cndmask_b32 with the mask as its selector
+__device__ __forceinline__ float select_by_mask(unsigned long long m, float x) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
+    return r;
+}
+
 // NLC > 0 (render_small_kernel): the network stays in registers (ResidentNet, srn_device.hpp); CD = 2, GRID = 0, rotation path
 template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, bool SHADED, int TAIL = TAIL_GENERIC, int NLC = 0>
 __device__ __forceinline__ void render_body(const NetParams& P, const SceneParams& S, const char* lds, const float* tfLds,
@@ -387,13 +394,14 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
         bool inRange, valid;
         unsigned long long validMask;
         if constexpr (TAIL != TAIL_GENERIC) {  // straight-line: i0 = 0, i1 = INT_MAX without segments
-            // the global step index i0 + i as a float counter (exact below 2^24): one add per step instead of add + convert
+            // the global step index i0 + i as a float counter (exact below 2^24): one add per step instead of add + convert.
+            // The lane predicates live as wave masks in scalar registers only (three v_cmp, two s_and): kept as `bool`s hipcc
+            // materialises them in VGPRs across the network code (v_cndmask + v_cmp_ne per step).
             t = tmin + stepIndex * S.stepsize;
-            inRange = (t <= tmax) & (stepIndex < stepEnd);
+            validMask = __builtin_amdgcn_ballot_w64(t <= tmax) & __builtin_amdgcn_ballot_w64(stepIndex < stepEnd) &
+                        __builtin_amdgcn_ballot_w64(ca < alphaLimit);
             stepIndex += 1.f;
-            const bool notOpaque = ca < alphaLimit;
-            valid = inRange & notOpaque;
-            validMask = __builtin_amdgcn_ballot_w64(inRange) & __builtin_amdgcn_ballot_w64(notOpaque);  // scalar ops only
+            inRange = valid = false;  // (unused in the straight-line tails)
         } else {
             if (K > 1) {  // wave-uniform; kept as a branch so that the unsegmented loop does no per-lane index arithmetic
                 const int gi = i0 + i;
@@ -446,7 +454,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             c3 *= S.stepsize;
             const float aBeer = 1.f - __expf(-c3), aAlpha = fminf(1.f, c3);
             const float a = beerLambert ? aBeer : aAlpha;
-            const float w = (valid & (c3 > 0.f)) ? (1.f - ca) * a : 0.f;
+            const float w = select_by_mask(validMask & __builtin_amdgcn_ballot_w64(c3 > 0.f), (1.f - ca) * a);
             cr += w * c0; cg += w * c1; cb += w * c2;
             depth += w * t;
             ca += w;
@@ -477,13 +485,13 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
                 c3 = (a[3] + df * (b[3] - a[3])) * S.stepsize;
             } else {  // renderer_tf_identity.cuh:36-54
                 c0 = c1 = c2 = density * S.tfScaleEmission;
-                c3 = density * S.tfScaleAbsorption * S.stepsize;
+                c3 = density * S.tfAbsorptionStep;  // absorption * stepsize, multiplied on the host
             }
             // Blending::eval (renderer_blending.cuh:35-51) where the sample counts: valid, value >= densityMin, absorption > 0
             const float aBeer = 1.f - __expf(-c3), aAlpha = fminf(1.f, c3);
             const float a = beerLambert ? aBeer : aAlpha;
-            const bool counts = valid & (value >= S.densityMin) & (c3 > 0.f);
-            const float w = counts ? (1.f - ca) * a : 0.f;
+            const float w = select_by_mask(validMask & __builtin_amdgcn_ballot_w64(value >= S.densityMin) & __builtin_amdgcn_ballot_w64(c3 > 0.f),
+                                           (1.f - ca) * a);
             cr += w * c0; cg += w * c1; cb += w * c2;
             depth += w * t;
             ca += w;
