@@ -47,6 +47,7 @@ CONFIGS = {
     "c32l4_fourier_1024x512": (32, 4, None, 1024, 1024, 512),    # the size the metric is quoted on
     "c32l4_grid16_1024x512": (32, 4, (16, 16), 1024, 1024, 512),  # configs[2]
     "c64l6_grid16_1024x512": (64, 6, (16, 32), 1024, 1024, 512),  # configs[3]
+    "c32l4_grid16r32_1024x512": (32, 4, (16, 32), 1024, 1024, 512),  # the paper's fV-SRN size: 32x4 network, 32^3 x 16 grid
     # configs[4]: time-dependent latent grids, 16 key frames, the time advances 0.25 key frames per rendered frame
     "c64l6_grid16_time16_1024x512": (64, 6, (16, 32), 1024, 1024, 512),
 }

@@ -810,7 +810,7 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
             const VariantKey& k = net->keyScaled;
             const bool scalarNet = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
             const bool colourNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
-            const int smallGrid = k.grid == 1 && P.gridK == 1 ? 1 : k.grid;
+            const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && P.gridK == 1 ? 1 : 2);
             if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !P.noFourier && !P.fourierNeedsFract && (scalarNet || colourNet) &&
                 render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1, smallGrid))
                 name = "render_small_kernel<act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "," + std::to_string(P.numLayers) +
@@ -904,10 +904,11 @@ int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const fl
             hipError_t e = hipErrorInvalidDeviceFunction;
             {
                 const VariantKey& k = net->key;
-                if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && k.grid == 0 && !a.P.noFourier && !a.P.fourierNeedsFractEval && a.P.numLayers >= 1 &&
+                const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.gridK == 1 ? 1 : 2);  // one decoded 16-channel chunk, as in renderImpl
+                if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !a.P.noFourier && !a.P.fourierNeedsFractEval && a.P.numLayers >= 1 &&
                     a.P.numLayers <= 3) {
                     const unsigned gridSmall = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 8 / wpb));  // 2 waves per SIMD
-                    e = launch_eval_small(k.act, k.dir, a.P.numLayers, a, gridSmall, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
+                    e = launch_eval_small(k.act, k.dir, a.P.numLayers, smallGrid, a, gridSmall, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
                 }
             }
             if (e == hipErrorInvalidDeviceFunction)
@@ -1112,7 +1113,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             {
                 const VariantKey& k = net->keyScaled;
                 const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
-                smallGrid = k.grid == 1 && a.P.gridK == 1 ? 1 : k.grid;  // one decoded 16-channel chunk: resident kernel with direct features
+                smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.gridK == 1 ? 1 : 2);  // one decoded 16-channel chunk: resident kernel with direct features
                 if (O[FVSRN_OPT_SMALL_KERNEL] != 0 && net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && !a.shaded && k.CD == 2 && smallGrid <= 1 && !a.P.noFourier && !a.P.fourierNeedsFract &&
                     a.P.numLayers >= 1 && a.P.numLayers <= 3 && (rgbo || (scalarNet && d.tf_kind != FVSRN_TF_NONE)))
                     smallFn = render_small_fn(k.act, k.dir, a.P.numLayers, smallTail, smallGrid);

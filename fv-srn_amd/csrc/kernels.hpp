@@ -123,12 +123,13 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void e
 
 // evaluate_kernel for 32-wide Fourier-only networks with NLC <= 3 C->C layers: weights and biases in registers (ResidentNet,
 // srn_device.hpp), 2 waves per SIMD; the phase fragments of the Fourier stage are the only LDS reads of a batch
-template <int ACT, bool HAS_DIR, int NLC>
+// EGRID = 1: with one decoded 16-channel latent chunk (srn_forward_resident_grid)
+template <int ACT, bool HAS_DIR, int NLC, int EGRID = 0>
 __global__ __launch_bounds__(kBlockThreads, 2) void evaluate_small_kernel(NetParams P, const float* __restrict__ pos, const float* __restrict__ dir,
                                                                         size_t n, float* __restrict__ out, int outChannels) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     load_network_to_lds(P, lds);
-    ResidentNet<NLC> R;
+    ResidentNet<NLC, EGRID> R;
     load_resident(P, lds, R);
     const int lane = lane_id();
     const size_t wavesPerBlock = blockDim.x >> 6;
@@ -146,9 +147,14 @@ __global__ __launch_bounds__(kBlockThreads, 2) void evaluate_small_kernel(NetPar
         px = (px - P.boxMin[0]) * P.invBoxSize[0];
         py = (py - P.boxMin[1]) * P.invBoxSize[1];
         pz = (pz - P.boxMin[2]) * P.invBoxSize[2];
-        half8_t xb[2][2];
-        const float4_t o = srn_layers_resident<ACT, NLC, 0, true>(
-            P, R, xb, [&]() { fourier_fragments<2, ACT, HAS_DIR, FM_COS>(P, lds, px, py, pz, dx, dy, dz, xb); }, [](int) {});
+        float4_t o;
+        if constexpr (EGRID == 1) {
+            o = srn_forward_resident_grid<ACT, HAS_DIR, NLC, true>(P, R, px, py, pz, dx, dy, dz);
+        } else {
+            half8_t xb[2][2];
+            o = srn_layers_resident<ACT, NLC, 0, true>(
+                P, R, xb, [&]() { fourier_fragments<2, ACT, HAS_DIR, FM_COS>(P, lds, px, py, pz, dx, dy, dz, xb); }, [](int) {});
+        }
         if (valid) write_eval_outputs(P, o, out, i, outChannels);
     }
 }

@@ -58,7 +58,21 @@ hipError_t launch_render_small(int act, bool dir, int numLayers, int tail, int g
     X(ACT_SNAKEALT, false) X(ACT_SNAKEALT, true) X(ACT_SIGMOID, false) X(ACT_SIGMOID, true)
 #define FVSRN_SMALL_EVAL_LAYERS(A, D) Z(A, D, 1) Z(A, D, 2) Z(A, D, 3)
 
-hipError_t launch_eval_small(int act, bool dir, int numLayers, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s) {
+#define FVSRN_SMALL_EVAL_GRID_VARIANTS(X) X(ACT_RELU, false) X(ACT_SINE, false) X(ACT_SNAKE, false) X(ACT_SNAKEALT, false)
+
+hipError_t launch_eval_small(int act, bool dir, int numLayers, int grid, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s) {
+    if (grid == 1) {
+#define Z(A, D, N)                                                                                                  \
+        if (act == A && dir == D && numLayers == N) {                                                               \
+            hipLaunchKernelGGL((evaluate_small_kernel<A, D, N, 1>), dim3(gridDim), dim3(blockDim), ldsBytes, s, a.P, a.pos, a.dir, a.n, a.out, \
+                               a.outChannels);                                                                      \
+            return hipGetLastError();                                                                               \
+        }
+        FVSRN_SMALL_EVAL_GRID_VARIANTS(FVSRN_SMALL_EVAL_LAYERS)
+#undef Z
+        return hipErrorInvalidDeviceFunction;
+    }
+    if (grid != 0) return hipErrorInvalidDeviceFunction;
 #define Z(A, D, N)                                                                                                  \
     if (act == A && dir == D && numLayers == N) {                                                                   \
         hipLaunchKernelGGL((evaluate_small_kernel<A, D, N>), dim3(gridDim), dim3(blockDim), ldsBytes, s, a.P, a.pos, a.dir, a.n, a.out, \

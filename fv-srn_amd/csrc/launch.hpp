@@ -94,7 +94,7 @@ const void* render_small_fn(int act, bool dir, int numLayers, int tail, int grid
 hipError_t launch_render_small(int act, bool dir, int numLayers, int tail, int grid, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 
 // evaluate_small_kernel: hipErrorInvalidDeviceFunction if that variant is not compiled in
-hipError_t launch_eval_small(int act, bool dir, int numLayers, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
+hipError_t launch_eval_small(int act, bool dir, int numLayers, int grid, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 
 bool kernel_info(const VariantKey& k, KernelInfo* info);
 hipError_t launch_eval(const VariantKey& k, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);

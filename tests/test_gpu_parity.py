@@ -298,15 +298,19 @@ def test_feature_rotation_stays_close_to_per_step_features(activation):
     assert float((exact - rotated).abs().max()) < TOL_IMG
 
 
-@pytest.mark.parametrize("layers,activation,output_mode,tf", [
-    (4, "ReLU", "density:direct", "identity"), (3, "SnakeAlt", "density", "texture"), (2, "Sine", "density", "identity"),
+@pytest.mark.parametrize("layers,activation,output_mode,tf,grid", [
+    (4, "ReLU", "density:direct", "identity", None), (3, "SnakeAlt", "density", "texture", None), (2, "Sine", "density", "identity", None),
+    # one 16-channel latent chunk: resident too (direct Fourier features); two chunks: the LDS kernel either way
+    (4, "ReLU", "density:direct", "identity", (16, 8)), (3, "SnakeAlt", "density", "texture", (16, 12)), (4, "ReLU", "density", "identity", (32, 8)),
 ])
-def test_register_resident_kernel_matches_lds_kernel(layers, activation, output_mode, tf):
-    """render_small_kernel (32-wide Fourier-only scalar networks with <= 3 C->C layers: weights and biases resident in
-    registers, no LDS access in the sample loop) runs the same schedule as render_kernel (scene option small_kernel = 0): images
-    agree to rounding (measured <= 1e-4: hipcc contracts the fp32 tail differently in the two kernels), both match the oracle."""
+def test_register_resident_kernel_matches_lds_kernel(layers, activation, output_mode, tf, grid):
+    """render_small_kernel (32-wide scalar networks with <= 3 C->C layers, Fourier-only or with one 16-channel latent chunk:
+    weights and biases resident in registers, no LDS access in the sample loop) runs the same arithmetic as render_kernel
+    (scene option small_kernel = 0): images agree to rounding (measured <= 1e-4: hipcc contracts the fp32 tail differently
+    in the two kernels), both match the oracle.  evaluate_points takes the same two kernels."""
     from fvsrn_amd import capi, volnet_io
-    vn = util.random_network(C=32, layers=layers, activation=activation, output_mode=output_mode, seed=77, box_min=(-0.5, -0.5, -0.5))
+    vn = util.random_network(C=32, layers=layers, activation=activation, output_mode=output_mode, seed=77, box_min=(-0.5, -0.5, -0.5),
+                             grid=grid, grid_scale=0.3)
     kw = make_scene_kwargs(stepsize=1 / 128, early_out=True, tf_scale_absorption=10.0, density_min=-1.0, density_max=1.0)
     if tf == "texture":
         rng = np.random.RandomState(5)
@@ -325,6 +329,12 @@ def test_register_resident_kernel_matches_lds_kernel(layers, activation, output_
     assert diff < 5e-4, diff
     ref, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), W, H, 0, H)
     assert np.abs(small[:4].cpu().numpy() - ref[:4]).max() < TOL_IMG
+    pos = torch.rand(4096, 3, device="cuda", generator=torch.Generator("cuda").manual_seed(3)) - 0.5
+    ev_small = net.evaluate(pos, world=True).clone()
+    net.set_option("small_kernel", 0)
+    ev_plain = net.evaluate(pos, world=True)
+    assert float((ev_small - ev_plain).abs().max()) < 5e-4
+    assert float(ev_small.std()) > 1e-3
 
 
 PHONG = dict(enable_phong=True, ambient=0.2, specular=0.4, magnitude_center=0.6, magnitude_radius=0.5, specular_exponent=8,
@@ -624,15 +634,19 @@ def test_snakealt_folded_image_matches_plain_image(C, layers, grid, param):
     assert np.abs(folded - ref[:4]).max() < TOL_IMG and np.abs(plain - ref[:4]).max() < TOL_IMG
 
 
+@pytest.mark.parametrize("slots", [0, 2])
 @pytest.mark.parametrize("name", util.golden_names("g2_"))
-def test_time_change_on_a_live_network_reblends_on_the_device(name):
+def test_time_change_on_a_live_network_reblends_on_the_device(name, slots):
     """set_time_and_ensemble on a network whose key frames are already resident: only the device-side blend kernel
-    (and the 2-byte time patch) run; results equal the reference at every time, in any order."""
+    (and the 2-byte time patch) run; results equal the reference at every time, in any order. With a slot budget of 2
+    the key frames stream from pinned host memory instead (ensemble grids stay resident either way)."""
     import torch
     from fvsrn_amd import capi, volnet_io
     d, meta = util.load_golden(name)
     vn = util.golden_to_volnet(d, meta)
     net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    if slots:
+        net.set_option("keyframe_slots", slots)
     pos = torch.from_numpy(d["positions"]).cuda()
     tes = [(t, 0) for t in meta["times"]] if "times" in meta else meta["time_ensemble"]
     order = list(range(len(tes))) + list(reversed(range(len(tes))))
