@@ -91,6 +91,7 @@ SYMBOLS = [
     ("fvsrn_network_get_layer", _I, [_VP, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _FP, _U16P, _U16P]),
     ("fvsrn_network_get_fourier", _I, [_VP, _U16P, _I, C.POINTER(_I)]),
     ("fvsrn_evaluate_points", _I, [_VP, _VP, _VP, _SZ, _VP, _I, _VP]),
+    ("fvsrn_evaluate_points_adjoint", _I, [_VP, _VP, _VP, _SZ, _VP, _F, _I, _VP]),
     ("fvsrn_scene_desc_size", _SZ, []),
     ("fvsrn_network_info_size", _SZ, []),
     ("fvsrn_scene_create", _I, [C.POINTER(SceneDesc), C.POINTER(_VP)]),
@@ -310,6 +311,19 @@ class Network:
         _check(lib().fvsrn_evaluate_points(self._h, pp, dp, n, op, 1 if world else 0,
                                            _current_stream() if stream is None else stream))
         return out
+
+    def evaluate_with_adjoint_gradient(self, positions, directions=None, grid_step: float = 0.0, stream: Optional[int] = None,
+                                       world: bool = False):
+        """IVolumeInterpolation.evaluate_with_gradients in GRADIENT_MODE_ADJOINT_METHOD (volume_interpolation.cpp:128-243): (n,1) values
+        and (n,3) analytic gradients w.r.t. the normalized position; grid_step = 0: 1 / (4 * latent grid resolution)."""
+        import torch
+        n = positions.shape[0]
+        pp = _torch_ptr(positions, "torch.float32", "positions")
+        dp = _torch_ptr(directions, "torch.float32", "directions") if directions is not None else None
+        out = torch.empty((n, 4), dtype=torch.float32, device=positions.device)
+        _check(lib().fvsrn_evaluate_points_adjoint(self._h, pp, dp, n, _torch_ptr(out, "torch.float32", "out"), float(grid_step),
+                                                   1 if world else 0, _current_stream() if stream is None else stream))
+        return out[:, 0:1].contiguous(), out[:, 1:4].contiguous()
 
 
 class Scene:

@@ -875,8 +875,8 @@ int fvsrn_scene_get_option(fvsrn_scene* scene, int option, int* value) {
 }
 
 // ------------------------------------------------------------------------------------------- evaluation
-int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const float* d_directions, size_t n,
-                          float* d_out, int flags, void* stream) {
+static int evaluateImpl(fvsrn_network* net, const float* d_positions, const float* d_directions, size_t n, float* d_out, int flags,
+                        bool adjoint, float adjointGridStep, void* stream) {
     return guarded([&] {
         if (!net || (n > 0 && (!d_positions || !d_out))) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
         std::lock_guard<std::mutex> lock(net->mu);
@@ -899,6 +899,19 @@ int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const fl
             const size_t batches = (n + 63) / 64;
             const size_t wpb = size_t(wavesPerBlockFor(size_t(net->packed.params.ldsBytes), net->opts));
             const size_t blocks = (batches + wpb - 1) / wpb;
+            if (adjoint) {
+                // evalNormal in GRADIENT_MODE_ADJOINT_METHOD differentiates output 0 of a scalar network
+                if (flags & FVSRN_EVAL_WITH_PREDICTED_GRADIENT) return fail(FVSRN_ERR_INVALID_ARGUMENT, "predicted and adjoint gradients exclude each other");
+                if (a.P.outputMode == FVSRN_OUT_RGBO || a.P.outputMode == FVSRN_OUT_RGBO_DIRECT)
+                    return fail(FVSRN_ERR_INVALID_ARGUMENT, "gradients can only be evaluated for scalar networks");
+                if (!(adjointGridStep >= 0.f)) return fail(FVSRN_ERR_INVALID_ARGUMENT, "adjoint_grid_stepsize must not be negative");
+                const float gridStep = adjointGridStep > 0.f ? adjointGridStep : 1.0f / (float(std::max(1, a.P.gridX)) * 4.0f);
+                const unsigned gridG = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 8 / wpb));  // 2 waves per SIMD (1 at 128 wide)
+                const hipError_t e = launch_eval_gradient(net->key, a, gridStep, gridG, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
+                if (e == hipErrorInvalidDeviceFunction) return fail(FVSRN_ERR_UNSUPPORTED, "this network variant has no gradient kernel");
+                if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during evaluation! ") + hipGetErrorString(e));
+                return FVSRN_OK;
+            }
             const unsigned grid = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 32 / wpb));
             // small networks in registers (evaluate_small_kernel): see renderImpl; the plain weight image, any output mode
             hipError_t e = hipErrorInvalidDeviceFunction;
@@ -919,6 +932,16 @@ int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const fl
             return fail(fvsrn_device_count() == 0 ? FVSRN_ERR_NO_DEVICE : FVSRN_ERR_DEVICE, e.what());
         }
     });
+}
+
+int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const float* d_directions, size_t n, float* d_out, int flags,
+                          void* stream) {
+    return evaluateImpl(net, d_positions, d_directions, n, d_out, flags, false, 0.f, stream);
+}
+
+int fvsrn_evaluate_points_adjoint(fvsrn_network* net, const float* d_positions, const float* d_directions, size_t n, float* d_out4,
+                                  float adjoint_grid_stepsize, int flags, void* stream) {
+    return evaluateImpl(net, d_positions, d_directions, n, d_out4, flags, true, adjoint_grid_stepsize, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ scene

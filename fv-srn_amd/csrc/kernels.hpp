@@ -121,6 +121,50 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void e
     else evaluate_body<CD, ACT, GRID, HAS_DIR, FM_COS>(P, lds, pos, dir, n, out, outChannels);
 }
 
+// ------------------------------------------------------------------------------------------------
+// EvaluateNoBatchesWithGradient (reference volume_interpolation.cpp:128-243) for GRADIENT_MODE_ADJOINT_METHOD: value + the analytic
+// gradient w.r.t. the normalized position (evalNormal, renderer_volume_tensorcores.cuh:1198-1540; forward mode here, srn_gradient.hpp).
+// out: (n,4) = value (output parametrization of evaluate), gradient
+// ------------------------------------------------------------------------------------------------
+template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE>
+__device__ __forceinline__ void evaluate_gradient_body(const NetParams& P, const char* lds, const float* __restrict__ pos,
+                                                       const float* __restrict__ dir, size_t n, float* __restrict__ out, float gridStep) {
+    const int lane = lane_id();
+    const size_t wavesPerBlock = blockDim.x >> 6;
+    const size_t wave = size_t(blockIdx.x) * wavesPerBlock + (threadIdx.x >> 6);
+    const size_t numWaves = size_t(gridDim.x) * wavesPerBlock;
+    const size_t batches = (n + 63) / 64;
+    for (size_t b = wave; b < batches; b += numWaves) {
+        const size_t i = b * 64 + lane;
+        float np_[3], nd_[3];
+        load_eval_point<HAS_DIR>(pos, dir, n, b, lane, np_, nd_);
+        const float px = (np_[0] - P.boxMin[0]) * P.invBoxSize[0];
+        const float py = (np_[1] - P.boxMin[1]) * P.invBoxSize[1];
+        const float pz = (np_[2] - P.boxMin[2]) * P.invBoxSize[2];
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        float4_t o = srn_forward_gradient<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, nd_[0], nd_[1], nd_[2], gridStep, gx, gy, gz);
+        if (i < n) {
+            o[1] = o[2] = o[3] = 0.f;
+            float v[4];
+            // (value through the same switch as evaluate; a scalar network's parametrization only touches channel 0)
+            write_eval_outputs(P, o, v, 0, 1);
+            *reinterpret_cast<float4_t*>(out + 4 * i) = float4_t{v[0], gx, gy, gz};
+        }
+    }
+}
+
+template <int CD, int ACT, int GRID, bool HAS_DIR>
+__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : 2)) void evaluate_gradient_kernel(NetParams P, const float* __restrict__ pos,
+                                                                 const float* __restrict__ dir, size_t n, float* __restrict__ out, float gridStep) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    load_network_to_lds(P, lds);
+    if constexpr (GRID == 0) {
+        if (P.noFourier) return evaluate_gradient_body<CD, ACT, GRID, HAS_DIR, FM_FIRST_LAYER>(P, lds, pos, dir, n, out, gridStep);
+    }
+    if (P.fourierNeedsFractEval) evaluate_gradient_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS>(P, lds, pos, dir, n, out, gridStep);
+    else evaluate_gradient_body<CD, ACT, GRID, HAS_DIR, FM_COS>(P, lds, pos, dir, n, out, gridStep);
+}
+
 // evaluate_kernel for 32-wide Fourier-only networks with NLC <= 3 C->C layers: weights and biases in registers (ResidentNet,
 // srn_device.hpp), 2 waves per SIMD; the phase fragments of the Fourier stage are the only LDS reads of a batch
 // EGRID = 1: with one decoded 16-channel latent chunk (srn_forward_resident_grid)

@@ -310,6 +310,10 @@ hipError_t launch_eval(const VariantKey& k, const EvalArgs& a, unsigned gridDim,
     FVSRN_DISPATCH_CD(launch_eval_cd, k, a, gridDim, blockDim, ldsBytes, s)
     return hipErrorInvalidDeviceFunction;
 }
+hipError_t launch_eval_gradient(const VariantKey& k, const EvalArgs& a, float gridStep, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s) {
+    FVSRN_DISPATCH_CD(launch_eval_gradient_cd, k, a, gridStep, gridDim, blockDim, ldsBytes, s)
+    return hipErrorInvalidDeviceFunction;
+}
 hipError_t launch_render(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s) {
     FVSRN_DISPATCH_CD(launch_render_cd, k, a, gridDim, blockDim, ldsBytes, s)
     return hipErrorInvalidDeviceFunction;

@@ -69,6 +69,11 @@ __device__ __forceinline__ float act_f32(float x, float a, float b) {
 #ifndef FVSRN_PK_F32
 #define FVSRN_PK_F32 1
 #endif
+// Wave priorities in the LDS kernels like in srn_layers_resident (MFMA chain 0, vector phases 3).  Measured r02 (1024^2 x 512):
+// 32-wide + 16^3 grid 73.9 -> 76.0 Gsamples/s, 32x4 Fourier-only 139.1 -> 140.2, but 64x6 + grid 24.65 -> 24.3: 32-wide networks only
+#ifndef FVSRN_LDS_PRIO
+#define FVSRN_LDS_PRIO 1
+#endif
 template <int ACT>
 __device__ __forceinline__ float2_t act_f32x2(float2_t x, float a, float b) {
 #if !FVSRN_PK_F32
@@ -664,6 +669,7 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
     pre();
     __builtin_amdgcn_sched_barrier(0);
     FVSRN_MARK(P, 2);  // pre(): B fragments of the first layer (+ half of the rotation)
+    if constexpr (FVSRN_LDS_PRIO && CD == 2) __builtin_amdgcn_s_setprio(0);  // the MFMA chain yields to the vector phases of the SIMD's other waves
 
     const int NL = P.numLayers;
     constexpr int kBiasLayer = 32 * MT * 4;
@@ -794,6 +800,7 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
                        });
     interleave<KS, NFILL - NF0>([&](int s) { o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s], xb[1][s], o1, 0, 0, 0); },
                                 [&](int j) { fill(NF0 + j); });
+    if constexpr (FVSRN_LDS_PRIO && CD == 2) __builtin_amdgcn_s_setprio(3);
     float4_t out = {0, 0, 0, 0};
     out[0] = h ? o1[0] : o0[0];
     if (P.outputMode >= FVSRN_OUT_RGBO) {  // wave-uniform: only colour / gradient networks have outputs 1..3
@@ -823,6 +830,7 @@ __device__ __forceinline__ float4_t srn_layers_kmajor(const NetParams& P, const 
     pre();
 #pragma unroll
     for (int j = 0; j < NFILL; ++j) fill(j);
+    if constexpr (FVSRN_LDS_PRIO && CD == 2) __builtin_amdgcn_s_setprio(0);
 
     // ---- C -> C layers -----------------------------------------------------------------------------------
     const int NL = P.numLayers;
@@ -869,6 +877,7 @@ __device__ __forceinline__ float4_t srn_layers_kmajor(const NetParams& P, const 
         o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[0][s], o0, 0, 0, 0);
         o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[1][s], o1, 0, 0, 0);
     }
+    if constexpr (FVSRN_LDS_PRIO && CD == 2) __builtin_amdgcn_s_setprio(3);
     float4_t out = {0, 0, 0, 0};
     out[0] = h ? o1[0] : o0[0];
     if (P.outputMode >= FVSRN_OUT_RGBO) {  // wave-uniform: only colour / gradient networks have outputs 1..3

@@ -383,8 +383,7 @@ struct VolumeInterpolationNetwork : IVolumeInterpolation {
     void setBoxMax(double3 v) override { boxMax_ = v; pushBox(); }
     int outputChannels() const override { return currentNetwork()->info().output_channels; }
     double3 gradientStep() const override {  // unit-box coordinates (see evaluate)
-        // (tensor API evaluate_with_gradients: the adjoint mode is a renderer mode here, the tensor API differentiates by central
-        // differences for it like IVolumeInterpolation's base implementation does)
+        // (ADJOINT_METHOD does not come here: evaluateWithGradients below takes fvsrn_evaluate_points_adjoint for it)
         if (gradientMode == OFF_OR_DIRECT) return {0, 0, 0};
         return {finiteDifferencesStepsize, finiteDifferencesStepsize, finiteDifferencesStepsize};
     }
@@ -392,14 +391,23 @@ struct VolumeInterpolationNetwork : IVolumeInterpolation {
     // GRADIENT_MODE_OFF_OR_DIRECT on a gradient-predicting network: the network's own gradient outputs (evalNormal,
     // renderer_volume_tensorcores.cuh:1166-1183); otherwise central differences like the base class
     std::tuple<torch::Tensor, torch::Tensor> evaluateWithGradients(const torch::Tensor& positions, const std::optional<torch::Tensor>& direction) override {
-        const int om = currentNetwork()->info().output_mode;
+        const auto info = currentNetwork()->info();
+        const int om = info.output_mode;
         const bool predicts = om >= FVSRN_OUT_DENSITY_GRADIENT && om <= FVSRN_OUT_DENSITY_CURVATURE_DIRECT;
-        if (gradientMode != OFF_OR_DIRECT || !predicts) return IVolumeInterpolation::evaluateWithGradients(positions, direction);
+        const bool adjoint = gradientMode == ADJOINT_METHOD;
+        if (!adjoint && (gradientMode != OFF_OR_DIRECT || !predicts)) return IVolumeInterpolation::evaluateWithGradients(positions, direction);
         TORCH_CHECK(positions.is_cuda() && positions.dim() == 2 && positions.size(1) == 3, "positions must be a CUDA tensor of shape (N,3)");
         const torch::Tensor p = positions.to(c10::kFloat).contiguous();
         torch::Tensor d;
         if (direction.has_value() && direction->defined()) d = direction->to(c10::kFloat).contiguous();
         torch::Tensor out = torch::empty({p.size(0), 4}, p.options());
+        if (adjoint) {
+            // GRADIENT_MODE_ADJOINT_METHOD: analytic gradients (evalNormal :1198-1540); latent-grid step as in the renderer
+            if (info.output_channels != 1) raise("evaluateWithGradient can only be called for scalar volumes");
+            const float gridStep = 1.0f / (float(std::max(info.grid_res[0], 1)) * float(adjointScale));
+            check(fvsrn_evaluate_points_adjoint(currentNetwork()->h, p.data_ptr<float>(), d.defined() ? d.data_ptr<float>() : nullptr,
+                                                size_t(p.size(0)), out.data_ptr<float>(), gridStep, 0, currentStream()));
+        } else
         check(fvsrn_evaluate_points(currentNetwork()->h, p.data_ptr<float>(), d.defined() ? d.data_ptr<float>() : nullptr, size_t(p.size(0)),
                                     out.data_ptr<float>(), FVSRN_EVAL_WITH_PREDICTED_GRADIENT, currentStream()));
         return {out.slice(1, 0, 1).to(positions.scalar_type()).contiguous(), out.slice(1, 1, 4).to(positions.scalar_type()).contiguous()};

@@ -192,6 +192,14 @@ int fvsrn_network_keyframe_stats(const fvsrn_network* net, unsigned long long ou
 #define FVSRN_EVAL_WITH_PREDICTED_GRADIENT 2
 int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const float* d_directions,
                           size_t n, float* d_out, int flags, void* stream);
+/* IVolumeInterpolation::evaluateWithGradient (volume_interpolation.cpp:128-243) of a VolumeInterpolationNetwork in
+ * GRADIENT_MODE_ADJOINT_METHOD: d_out4 is (n,4) = value (as fvsrn_evaluate_points) + the analytic gradient of output 0 w.r.t. the
+ * normalized (unit-box) position (evalNormal, renderer_volume_tensorcores.cuh:1198-1540; computed in forward mode,
+ * fv-srn_amd/csrc/srn_gradient.hpp).  Latent grids are differentiated by central differences with step adjoint_grid_stepsize in
+ * unit-box coordinates (0: 1 / (4 * grid resolution), volume_interpolation_network.cpp:1808-1812).  Scalar networks only.
+ * flags: FVSRN_EVAL_WORLD_POSITIONS. */
+int fvsrn_evaluate_points_adjoint(fvsrn_network* net, const float* d_positions, const float* d_directions, size_t n, float* d_out4,
+                                  float adjoint_grid_stepsize, int flags, void* stream);
 
 /* ----------------------------------------------------------------------------------------
  * scene = ImageEvaluatorSimple + CameraOnASphere(->reference frame) + RayEvaluationSteppingDvr

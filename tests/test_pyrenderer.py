@@ -299,6 +299,16 @@ def test_shaded_configuration_through_the_module_api():
     assert np.abs(ref2[4:7]).max() > 0.05
     assert np.abs(img2[:7] - ref2[:7]).max() < 6e-3
     assert vol.current_network().compute_max_warps(False, True) <= vol.current_network().compute_max_warps(False, False)
+    # evaluate_with_gradients in the same mode: analytic gradients w.r.t. the unit-box position (volume_interpolation.cpp:128-243)
+    import torch
+    pos = torch.rand(500, 3, device="cuda", generator=torch.Generator("cuda").manual_seed(5))
+    dens, grad = vol.evaluate_with_gradients(pos)
+    assert tuple(dens.shape) == (500, 1) and tuple(grad.shape) == (500, 3)
+    world = pos.cpu().numpy() - 0.5   # the box of this network is [-0.5, 0.5]^3; the tensor API takes unit-box positions
+    gref = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).adjoint_gradient(world)
+    assert np.abs(gref).max() > 0.01
+    assert np.abs(grad.cpu().numpy() - gref).max() < 3e-3 * max(1.0, np.abs(gref).max())
+    assert float((dens - vol.evaluate(pos)).abs().max()) < 5e-4
 
 
 @pytest.mark.gpu
