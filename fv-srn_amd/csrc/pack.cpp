@@ -146,6 +146,7 @@ void packLatentGrid(const SceneNetwork& net, PackedNetwork& out) {
     if (K.ensNum) layout(lg.ensembleGrids, Ge, Gt, K.ensData, K.ensOffset, K.ensScale, false);
 }
 
+constexpr int kNoFold = -1000;  // packLayers: no SnakeAlt fold (namespace scope: g++ takes no local variable as a lambda default argument)
 PackedNetwork packNetwork(const SceneNetwork& net) {
     std::string why;
     if (!net.valid(&why)) throw InvalidNetwork(why);
@@ -269,7 +270,6 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
     };
     // foldExp != INT_MIN (SnakeAlt with b = 1/(2p) = 2^foldExp, see ACT_SNAKEALT0): every layer behind an activation takes
     // W' = b W and b' = bias + b * sum_j W_j (fp32), the activation itself leaves out its affine part
-    constexpr int kNoFold = -1000;
     auto packLayers = [&](std::vector<char>& img, const std::vector<int>* exps, int foldExp = kNoFold) {
         float* bias = reinterpret_cast<float*>(img.data() + np.offBias);
         for (int l = 0; l < NL; ++l) {
