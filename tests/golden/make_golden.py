@@ -409,6 +409,26 @@ def generate():
     trace_case(SRN, Raytracing, "g3b_trace_rgbo_64x64_s512_snakealt", activation="SnakeAlt:1", fourierstd=-1, W=64, H=64, stepsize=1.0 / 512)
     trace_case(SRN, Raytracing, "g3b_trace_rgbo_64x64_s512_relu", activation="ReLU", fourierstd=-1, W=64, H=64, stepsize=1.0 / 512)
 
+    # ---- G4 (round 2): position gradients of the reference's own PyTorch model by autograd, fp32 -- what the renderer's
+    # GRADIENT_MODE_ADJOINT_METHOD computes analytically (renderer_volume_tensorcores.cuh:1198-1540).  Fourier-only networks: with a
+    # latent grid the adjoint mode differentiates the grid by central differences (volume_interpolation_network.cpp:1808-1812),
+    # torch.grid_sample analytically.
+    for name, kw in [
+        ("g4_grad_c32l4_snakealt_density", dict(layers="32:32:32", activation="SnakeAlt:1", outputmode="density", F=14, std=0.35)),
+        ("g4_grad_c32l4_sine_density-direct", dict(layers="32:32:32", activation="Sine:1", outputmode="density:direct", F=14, std=0.6)),
+        ("g4_grad_c64l3_snake_density", dict(layers="64:64", activation="Snake:2", outputmode="density", F=30, std=0.35)),
+        ("g4_grad_c48l4_relu_density-direct", dict(layers="48:48:48", activation="ReLU", outputmode="density:direct", F=22, std=0.35)),
+    ]:
+        ns, ps, _ = seeds(name)
+        net, opt = make_network(SRN, layers=kw["layers"], activation=kw["activation"], fouriercount=kw["F"], fourierstd=kw["std"],
+                                outputmode=kw["outputmode"], seed=ns)
+        pos = positions(N, 0, ps)
+        x = torch.from_numpy(pos).clone().requires_grad_(True)
+        n = x.shape[0]
+        out = net(x, torch.zeros(n), torch.zeros(n), torch.zeros(n), "world")
+        out[:, 0].sum().backward()
+        save_case(name, net, opt, pos, out_fp32=out.detach().numpy(), grad_fp32=x.grad.detach().numpy().copy())
+
 
 def camera_frame(pitch, yaw, distance):
     """CameraOnASphere, orientation Ym, centre 0 (formulas of renderer/camera.cpp:458-490,553-569)."""

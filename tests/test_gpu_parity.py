@@ -463,6 +463,24 @@ def test_evaluate_points_adjoint_gradient_matches_oracle(case):
     assert err < 5e-3 * scale, (err, scale)   # relative to the largest gradient; measured r02: <= 1e-3 of it over these cases
 
 
+@pytest.mark.parametrize("name", util.golden_names("g4_"))
+def test_evaluate_points_adjoint_gradient_matches_reference_autograd(name):
+    """The analytic gradients of the HIP path against torch.autograd on the reference's own PyTorch model (G4 fixtures)."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    d, meta = util.load_golden(name)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(util.golden_to_volnet(d, meta)))
+    val, grad = net.evaluate_with_adjoint_gradient(torch.from_numpy(d["positions"]).cuda())
+    ref = d["grad_fp32"]
+    scale = float(np.abs(ref).max())
+    err = np.abs(grad.cpu().numpy() - ref)
+    if meta["activation"] == "ReLU":
+        assert np.median(err) < 4e-4 * scale and np.percentile(err, 95) < 4e-3 * scale, (np.median(err), np.percentile(err, 95))
+    else:
+        assert err.max() < 4e-3 * scale, (err.max(), scale)
+    assert np.abs(val.cpu().numpy() - d["out_fp32"]).max() < TOL_SAME_MODEL
+
+
 def test_evaluate_points_adjoint_argument_checks():
     import torch
     from fvsrn_amd import capi, volnet_io

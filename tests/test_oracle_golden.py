@@ -84,6 +84,26 @@ def test_ray_march_matches_reference_python_trace(name, tol_f, tol_h):
     assert d["image"][3].max() > 0.5  # the fixture is not an empty image
 
 
+@pytest.mark.parametrize("name", util.golden_names("g4_"))
+def test_adjoint_gradient_matches_reference_autograd(name):
+    """GRADIENT_MODE_ADJOINT_METHOD (renderer_volume_tensorcores.cuh:1198-1540) as restated in the oracle, against torch.autograd on the
+    reference's own PyTorch model in fp32 (tests/golden/make_golden.py, G4): pins the restatement of the backward pass.  Smooth
+    activations agree everywhere (measured <= 7e-4 of the largest gradient in the FLOAT model, 3e-3 in the HALF model); ReLU networks
+    have samples whose fp16-rounded pre-activation sits on the other side of the kink: by quantile there."""
+    d, meta = util.load_golden(name)
+    vn = util.golden_to_volnet(d, meta)
+    ref = d["grad_fp32"]
+    scale = float(np.abs(ref).max())
+    assert scale > 1e-2
+    for mode, tol in ((oracle.ACC_FLOAT, 2e-3), (oracle.ACC_HALF, 8e-3)):
+        err = np.abs(oracle.OracleNetwork(vn, mode).adjoint_gradient(d["positions"]) - ref)
+        if meta["activation"] == "ReLU":
+            assert np.median(err) < 0.1 * tol * scale and np.percentile(err, 95) < tol * scale, (mode, np.median(err), np.percentile(err, 95))
+        else:
+            assert err.max() < tol * scale, (mode, err.max(), scale)
+    assert np.abs(oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(d["positions"])[:, :1] - d["out_fp32"]).max() < 1e-3
+
+
 def test_camera_on_a_sphere_matches_generator_frame():
     d, meta = util.load_golden("g3_trace_rgbo_32x32")
     eye, right, up = oracle.camera_on_a_sphere(meta["orientation"], (0, 0, 0), meta["pitch"], meta["yaw"], meta["distance"])
