@@ -312,6 +312,18 @@ class Network:
                                            _current_stream() if stream is None else stream))
         return out
 
+    def evaluate_with_gradients_and_curvature(self, positions, directions=None, stream: Optional[int] = None, world: bool = False):
+        """IVolumeInterpolation.evaluate_with_gradients_and_curvature of a network that predicts all three (output mode
+        densitycurvature[:direct], volume_interpolation.cpp:245-360): (n,1) values, (n,3) gradients, (n,2) curvature values."""
+        import torch
+        n = positions.shape[0]
+        pp = _torch_ptr(positions, "torch.float32", "positions")
+        dp = _torch_ptr(directions, "torch.float32", "directions") if directions is not None else None
+        out = torch.empty((n, 6), dtype=torch.float32, device=positions.device)
+        _check(lib().fvsrn_evaluate_points(self._h, pp, dp, n, _torch_ptr(out, "torch.float32", "out"), (1 if world else 0) | 4,
+                                           _current_stream() if stream is None else stream))
+        return out[:, 0:1].contiguous(), out[:, 1:4].contiguous(), out[:, 4:6].contiguous()
+
     def evaluate_with_adjoint_gradient(self, positions, directions=None, grid_step: float = 0.0, stream: Optional[int] = None,
                                        world: bool = False):
         """IVolumeInterpolation.evaluate_with_gradients in GRADIENT_MODE_ADJOINT_METHOD (volume_interpolation.cpp:128-243): (n,1) values

@@ -274,9 +274,10 @@ struct fvsrn_network {
     // device image (lazy; invalidated by any mutation)
     bool deviceValid = false;
     PackedNetwork packed;
-    DeviceBuffer dLds, dLdsScaled, dGrid, dGridB, dKeysEns, dCoeffs;
+    DeviceBuffer dLds, dLdsScaled, dLdsCurvature, dEvalTmp, dGrid, dGridB, dKeysEns, dCoeffs;
     KeyframeStore keyStore;  // time key frames
     const void* scaledImage = nullptr;
+    const void* curvatureImage = nullptr;
     bool timeDirty = true;  // working grid / time slot do not match net->currentTime yet
     VariantKey key{};       // plain image
     VariantKey keyScaled{};  // ReLU networks: [0,1]-scaled image (render only)
@@ -350,6 +351,12 @@ struct fvsrn_network {
             dLdsScaled.ensure(packed.ldsImageScaled.size());
             HIP_CHECK(hipMemcpyAsync(dLdsScaled.ptr, packed.ldsImageScaled.data(), packed.ldsImageScaled.size(), hipMemcpyHostToDevice, stream));
             scaledImage = dLdsScaled.ptr;
+        }
+        curvatureImage = nullptr;
+        if (!packed.ldsImageCurvature.empty()) {  // densitycurvature networks: last layer = the two curvature outputs (pack.cpp)
+            dLdsCurvature.ensure(packed.ldsImageCurvature.size());
+            HIP_CHECK(hipMemcpyAsync(dLdsCurvature.ptr, packed.ldsImageCurvature.data(), packed.ldsImageCurvature.size(), hipMemcpyHostToDevice, stream));
+            curvatureImage = dLdsCurvature.ptr;
         }
         // latent key frames: uploaded once and kept resident; the working grid is blended from them on the device
         const GridKeyframes& K = packed.keys;
@@ -888,7 +895,18 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
             if (net->key.dir && !d_directions)
                 return fail(FVSRN_ERR_INVALID_ARGUMENT, "the network uses the view direction, but no directions were given");
             EvalArgs a{net->packed.params, d_positions, d_directions, n, d_out, net->net->outputChannels()};
-            if (flags & FVSRN_EVAL_WITH_PREDICTED_GRADIENT) {
+            const bool curvature = (flags & FVSRN_EVAL_WITH_PREDICTED_CURVATURE) != 0;
+            if (curvature) {
+                // evalCurvature (renderer_volume_tensorcores.cuh:1541-1556): only networks that estimate it, GRADIENT_MODE_OFF_OR_DIRECT
+                const int om = a.P.outputMode;
+                if (adjoint || (om != FVSRN_OUT_DENSITY_CURVATURE && om != FVSRN_OUT_DENSITY_CURVATURE_DIRECT) || !net->curvatureImage)
+                    return fail(FVSRN_ERR_INVALID_ARGUMENT, "curvature is only available from networks that predict it (output mode densitycurvature*)");
+                // two passes over the points -- value + predicted gradient, then the same layers with the last one computing the two
+                // curvature outputs -- into a temporary (n,4) + (n,4), combined into d_out (n,6) by two strided copies
+                net->dEvalTmp.ensure(n * 8 * sizeof(float));
+                a.out = static_cast<float*>(net->dEvalTmp.ptr);
+                a.outChannels = 4;
+            } else if (flags & FVSRN_EVAL_WITH_PREDICTED_GRADIENT) {
                 const int om = a.P.outputMode;
                 if (om < FVSRN_OUT_DENSITY_GRADIENT || om > FVSRN_OUT_DENSITY_CURVATURE_DIRECT)
                     return fail(FVSRN_ERR_INVALID_ARGUMENT, "the network does not predict gradients (output mode densitygrad* / densitycurvature*)");
@@ -926,6 +944,17 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
             }
             if (e == hipErrorInvalidDeviceFunction)
                 e = launch_eval(net->key, a, grid, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
+            if (e == hipSuccess && curvature) {
+                EvalArgs c = a;
+                c.P.ldsImage = net->curvatureImage;
+                c.P.outputMode = FVSRN_OUT_DENSITY_GRADIENT_DIRECT;  // rows 0, 1 of the last layer, raw
+                c.out = a.out + 4 * n;
+                e = launch_eval(net->key, c, grid, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
+                if (e == hipSuccess)
+                    e = hipMemcpy2DAsync(d_out, 6 * sizeof(float), a.out, 4 * sizeof(float), 4 * sizeof(float), n, hipMemcpyDeviceToDevice, s);
+                if (e == hipSuccess)
+                    e = hipMemcpy2DAsync(d_out + 4, 6 * sizeof(float), c.out, 4 * sizeof(float), 2 * sizeof(float), n, hipMemcpyDeviceToDevice, s);
+            }
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during evaluation! ") + hipGetErrorString(e));
             return FVSRN_OK;
         } catch (const DeviceError& e) {

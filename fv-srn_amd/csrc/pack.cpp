@@ -270,7 +270,8 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
     };
     // foldExp != INT_MIN (SnakeAlt with b = 1/(2p) = 2^foldExp, see ACT_SNAKEALT0): every layer behind an activation takes
     // W' = b W and b' = bias + b * sum_j W_j (fp32), the activation itself leaves out its affine part
-    auto packLayers = [&](std::vector<char>& img, const std::vector<int>* exps, int foldExp = kNoFold) {
+    // outShift: the last layer's C-operand rows 4g + o carry output o + outShift (4: the two curvature outputs, see ldsImageCurvature)
+    auto packLayers = [&](std::vector<char>& img, const std::vector<int>* exps, int foldExp = kNoFold, int outShift = 0) {
         float* bias = reinterpret_cast<float*>(img.data() + np.offBias);
         for (int l = 0; l < NL; ++l) {
             const Layer& L = net.hidden[size_t(L0 + l)];
@@ -326,8 +327,9 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
             Frag f{};
             for (int lane = 0; lane < 64; ++lane) {
                 const int m = lane & 15, kg = lane >> 4;  // row, K group
-                const int o = m & 3, g = m >> 2;          // output, consumer lane group
-                if (o >= Cout) continue;                  // outputs 0..3 (curvature outputs 4,5 have no consumer on this path)
+                const int g = m >> 2;                     // consumer lane group
+                const int o = (m & 3) + outShift;         // output (the renderer and evaluate() take 0..3; curvature: ldsImageCurvature)
+                if (o >= Cout) continue;
                 if ((kg & 1) != (g & 1)) continue;        // K groups 0,2 belong to sample n, 1,3 to sample n + 16
                 const int h = kg >> 1;                    // lane half of the data: channel slots 8h .. 8h+7
                 for (int j = 0; j < 8; ++j) {
@@ -338,17 +340,26 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
             putFrag(img, size_t(np.offLast) + size_t(s) * kFragBytes, f);
         }
         float* bl = bias + size_t(NL) * 32 * MT;
-        for (int o = 0; o < std::min(Cout, 4); ++o) {  // C operand rows 4g + o, any g
+        for (int r = 0; r < 4; ++r) bl[r] = 0.f;
+        for (int r = 0; r < 4 && r + outShift < Cout; ++r) {  // C operand rows 4g + r, any g
+            const int o = r + outShift;
             double b = double(half_bits_to_float(L.bias[size_t(o)]));
             if (foldLast) {
                 double sum = 0;
                 for (int col = 0; col < C; ++col) sum += double(half_bits_to_float(transposed ? L.weights[size_t(col) * Cout + o] : L.weights[size_t(o) * C + col]));
                 b += std::ldexp(sum, foldExp);
             }
-            bl[o] = float(b);
+            bl[r] = float(b);
         }
     };
     packLayers(P.ldsImage, nullptr);
+    // densitycurvature networks: a second image whose last layer computes outputs 4 and 5 (the two curvature values) in rows 0 and 1;
+    // only IVolumeInterpolation::evaluateWithGradientAndCurvature reads them (fvsrn_evaluate_points, FVSRN_EVAL_WITH_PREDICTED_CURVATURE)
+    P.ldsImageCurvature.clear();
+    if (Cout > 4) {
+        P.ldsImageCurvature = P.ldsImage;
+        packLayers(P.ldsImageCurvature, nullptr, kNoFold, 4);
+    }
 
     // ---- ReLU networks: second image with activations scaled into [0,1] ------------------------------------
     // relu(x) = max(x,0) costs the VALU one v_pk_max_f16 per two values on top of the fp32->fp16 convert.  With

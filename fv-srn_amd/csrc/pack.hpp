@@ -28,6 +28,7 @@ struct PackedNetwork {
     std::vector<char> ldsImageScaled;  // second image for the renderer (empty if not applicable): ReLU networks with activations scaled
                                        // into [0,1], SnakeAlt networks with the 1/(2p) factor folded into the next layer
     int scaledAct = -1;                // ACT_RELU01 / ACT_SNAKEALT0: the kernel variant that goes with ldsImageScaled
+    std::vector<char> ldsImageCurvature;  // densitycurvature networks: the plain image with the last layer computing outputs 4, 5 in rows 0, 1
     std::vector<int> reluExponents;    // e_l of the scaled image
     std::vector<float> gridMaxAbs;     // per latent channel
     NetParams params{};          // pointers left null (filled by the device layer)

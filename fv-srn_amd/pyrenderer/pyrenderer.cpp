@@ -340,6 +340,13 @@ struct IVolumeInterpolation {
         }
         return {densities, gradients};
     }
+    // IVolumeInterpolation::evaluateWithGradientAndCurvature (:245-360): only volumes that estimate the curvature themselves provide it
+    // (evalCurvature traps otherwise, renderer_volume_tensorcores.cuh:1541-1556; grids: renderer_volume_grid.cuh has no curvature at all)
+    virtual std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> evaluateWithGradientsAndCurvature(const torch::Tensor&,
+                                                                                                     const std::optional<torch::Tensor>&) {
+        raise("this volume provides no curvature (only networks with output mode densitycurvature / densitycurvature:direct do)");
+        return {};
+    }
 };
 
 enum GradientMode { OFF_OR_DIRECT = 0, FINITE_DIFFERENCES = 1, ADJOINT_METHOD = 2 };
@@ -411,6 +418,22 @@ struct VolumeInterpolationNetwork : IVolumeInterpolation {
         check(fvsrn_evaluate_points(currentNetwork()->h, p.data_ptr<float>(), d.defined() ? d.data_ptr<float>() : nullptr, size_t(p.size(0)),
                                     out.data_ptr<float>(), FVSRN_EVAL_WITH_PREDICTED_GRADIENT, currentStream()));
         return {out.slice(1, 0, 1).to(positions.scalar_type()).contiguous(), out.slice(1, 1, 4).to(positions.scalar_type()).contiguous()};
+    }
+
+    std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> evaluateWithGradientsAndCurvature(const torch::Tensor& positions,
+                                                                                             const std::optional<torch::Tensor>& direction) override {
+        const int om = currentNetwork()->info().output_mode;
+        if (gradientMode != OFF_OR_DIRECT || (om != FVSRN_OUT_DENSITY_CURVATURE && om != FVSRN_OUT_DENSITY_CURVATURE_DIRECT))
+            raise("curvature is only supported if the network directly estimates it (output mode densitycurvature*, gradient mode OFF_OR_DIRECT)");
+        TORCH_CHECK(positions.is_cuda() && positions.dim() == 2 && positions.size(1) == 3, "positions must be a CUDA tensor of shape (N,3)");
+        const torch::Tensor p = positions.to(c10::kFloat).contiguous();
+        torch::Tensor d;
+        if (direction.has_value() && direction->defined()) d = direction->to(c10::kFloat).contiguous();
+        torch::Tensor out = torch::empty({p.size(0), 6}, p.options());
+        check(fvsrn_evaluate_points(currentNetwork()->h, p.data_ptr<float>(), d.defined() ? d.data_ptr<float>() : nullptr, size_t(p.size(0)),
+                                    out.data_ptr<float>(), FVSRN_EVAL_WITH_PREDICTED_CURVATURE, currentStream()));
+        const auto st = positions.scalar_type();
+        return {out.slice(1, 0, 1).to(st).contiguous(), out.slice(1, 1, 4).to(st).contiguous(), out.slice(1, 4, 6).to(st).contiguous()};
     }
 
     torch::Tensor evaluate(const torch::Tensor& positions, const std::optional<torch::Tensor>& direction) override {
@@ -1414,9 +1437,8 @@ PYBIND11_MODULE(pyrenderer, m) {
              py::doc("Evaluates the volume on the given position array of shape (B,3) and returns the interpolated densities of shape (B,1)"))
         .def("evaluate_with_gradients", &IVolumeInterpolation::evaluateWithGradients, py::arg("positions"), py::arg("direction") = std::optional<torch::Tensor>{},
              py::doc("Densities of shape (B,1) and gradients of shape (B,3)"))
-        .def("evaluate_with_gradients_and_curvature", [](IVolumeInterpolation&, const torch::Tensor&, const std::optional<torch::Tensor>&) -> py::object {
-                 raise("curvature evaluation is not in the compiled variant set");
-             }, py::arg("positions"), py::arg("direction") = std::optional<torch::Tensor>{})
+        .def("evaluate_with_gradients_and_curvature", &IVolumeInterpolation::evaluateWithGradientsAndCurvature, py::arg("positions"),
+             py::arg("direction") = std::optional<torch::Tensor>{}, py::doc("Densities (B,1), gradients (B,3) and curvature values (B,2)"))
         // volume_interpolation.cpp:651-695: training-data samplers, not on the inference path (out of scope): present, and raise
         .def("importance_sampling", [](IVolumeInterpolation&, py::args, py::kwargs) -> py::object {
                  raise("importance_sampling is not part of this build (training-data sampler, outside the inference hot path)");

@@ -190,6 +190,11 @@ int fvsrn_network_keyframe_stats(const fvsrn_network* net, unsigned long long ou
  * value + the predicted gradient, i.e. eval() + evalNormal() in GRADIENT_MODE_OFF_OR_DIRECT
  * (renderer_volume_tensorcores.cuh:1166-1183; IVolumeInterpolation::evaluateWithGradient, volume_interpolation.cpp:128-243) */
 #define FVSRN_EVAL_WITH_PREDICTED_GRADIENT 2
+/* networks that also predict the curvature (densitycurvature, densitycurvature:direct): d_out is (n,6) = value, predicted gradient,
+ * the two predicted curvature values, i.e. eval() + evalNormal() + evalCurvature() (renderer_volume_tensorcores.cuh:1104-1133,1541-1556;
+ * IVolumeInterpolation::evaluateWithGradientAndCurvature, volume_interpolation.cpp:245-360).  Other networks: FVSRN_ERR_INVALID_ARGUMENT
+ * (the reference traps) */
+#define FVSRN_EVAL_WITH_PREDICTED_CURVATURE 4
 int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const float* d_directions,
                           size_t n, float* d_out, int flags, void* stream);
 /* IVolumeInterpolation::evaluateWithGradient (volume_interpolation.cpp:128-243) of a VolumeInterpolationNetwork in

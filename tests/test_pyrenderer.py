@@ -80,7 +80,7 @@ def test_value_types_and_enums():
 
 def test_entries_outside_the_hot_path_exist_and_raise():
     """world2screen (OpenGL matrices), importance_sampling* (training-data samplers) and the curvature
-    evaluation are present on the surface and raise a RuntimeError, rather than being absent attributes."""
+    evaluation of volumes that do not estimate it are present on the surface and raise a RuntimeError, rather than being absent attributes."""
     cam = pr.CameraOnASphere()
     with pytest.raises(RuntimeError, match="world2screen"):
         cam.world2screen(64, 64, [])
@@ -89,8 +89,8 @@ def test_entries_outside_the_hot_path_exist_and_raise():
         vol.importance_sampling(10, None, 0.1, 1, 0, 0.0, 1.0, "float")
     with pytest.raises(RuntimeError, match="importance_sampling_with_probability_grid"):
         vol.importance_sampling_with_probability_grid(10, None, None, 1.0, 0.1, 1, 0, 0.0, 1.0)
-    with pytest.raises(RuntimeError, match="curvature"):
-        vol.evaluate_with_gradients_and_curvature(torch.zeros(1, 3))
+    with pytest.raises(RuntimeError, match="curvature"):   # (networks that predict the curvature provide it: see below)
+        pr.VolumeInterpolationGrid().evaluate_with_gradients_and_curvature(torch.zeros(1, 3))
 
 
 def test_load_from_json_builds_the_module_tree(tmp_path):
@@ -599,6 +599,39 @@ def test_network_evaluate_with_gradients_and_ray_multisampling(tmp_path):
     assert float((direction[0] - direction[1]).abs().max()) > 0
     again, _ = cam.generate_rays_multisampling(24, 16, 5), None
     assert torch.equal(again[1], direction)  # seeded like the reference: (42, time)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,C,layers,grid", [("densitycurvature", 32, 4, None), ("densitycurvature:direct", 64, 3, (16, 8))])
+def test_evaluate_with_gradients_and_curvature_of_a_curvature_predicting_network(tmp_path, mode, C, layers, grid):
+    """IVolumeInterpolation.evaluate_with_gradients_and_curvature (volume_interpolation.cpp:245-360) on a densitycurvature network:
+    eval + evalNormal + evalCurvature, all three from the network's six outputs -- against oracle_eval_points_full; any other
+    network raises (the reference traps)."""
+    from oracle import oracle
+    vn = util.random_network(C=C, layers=layers, activation="SnakeAlt", output_mode=mode, seed=6, fourier_std=0.4, grid=grid)
+    path = str(tmp_path / "net.volnet")
+    open(path, "wb").write(volnet_io.save_volnet(vn))
+    vol = pr.VolumeInterpolationNetwork()
+    vol.set_network(pr.SceneNetwork.load(path))
+    pos = torch.rand(1000, 3, device="cuda")
+    dens, grad, curv = vol.evaluate_with_gradients_and_curvature(pos)
+    full = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate_full(pos.cpu().numpy())  # value[4], normal[3], curvature[2]
+    assert dens.shape == (1000, 1) and grad.shape == (1000, 3) and curv.shape == (1000, 2)
+    assert np.abs(dens.cpu().numpy()[:, 0] - full[:, 0]).max() < 2e-3
+    assert np.abs(grad.cpu().numpy() - full[:, 4:7]).max() < 2e-3 * max(1.0, np.abs(full[:, 4:7]).max())
+    assert np.abs(curv.cpu().numpy() - full[:, 7:9]).max() < 2e-3 * max(1.0, np.abs(full[:, 7:9]).max())
+    assert np.abs(full[:, 7:9]).max() > 1e-3 and np.abs(full[:, 7] - full[:, 8]).max() > 1e-3
+    # same through the ctypes binding, and the other entry points of this network are unchanged
+    from fvsrn_amd import capi
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    d2, g2, c2 = net.evaluate_with_gradients_and_curvature(pos)
+    assert torch.equal(c2, curv) and torch.equal(g2, grad)
+    assert float((net.evaluate(pos) - d2).abs().max()) < 5e-4
+    vn2 = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode="densitygrad", seed=6, fourier_std=0.4)
+    open(path, "wb").write(volnet_io.save_volnet(vn2))
+    vol.set_network(pr.SceneNetwork.load(path))
+    with pytest.raises(RuntimeError, match="curvature"):
+        vol.evaluate_with_gradients_and_curvature(pos)
 
 
 @pytest.mark.gpu
