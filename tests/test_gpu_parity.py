@@ -719,6 +719,73 @@ def test_time_change_on_a_live_network_reblends_on_the_device(name, slots):
         assert np.abs(out - d["out_fp32"][i]).max() < TOL_SAME_MODEL, (t, e)
 
 
+@pytest.mark.parametrize("slots", [2, 3, 5])
+@pytest.mark.parametrize("enc", [0, 2])
+def test_keyframe_streaming_is_bit_identical_to_resident_key_frames(slots, enc):
+    """Time key frames under a residency budget (network option keyframe_slots: pinned host copies, `slots` device slots, uploads on a
+    copy stream, the next key frame in the time direction prefetched) against all key frames resident: the same working grid, bit for
+    bit, at every time of a forward sweep, a jump back, a reverse sweep and a random walk -- through evaluate() and through the
+    renderer; the store's counters show that slots were re-used and that prefetches happened."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    KEYS = 7
+    vn = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode="density", grid=(16, 8), seed=41,
+                             box_min=(-0.5, -0.5, -0.5), fourier_std=0.4, encoding=enc, time_grids=KEYS)
+    blob = volnet_io.save_volnet(vn)
+    resident, streamed = capi.Network.from_volnet(blob), capi.Network.from_volnet(blob)
+    streamed.set_option("keyframe_slots", slots)
+    assert streamed.get_option("keyframe_slots") == slots and resident.get_option("keyframe_slots") == 0
+    pos = torch.rand(2048, 3, device="cuda", generator=torch.Generator("cuda").manual_seed(9)) - 0.5
+    rng = np.random.RandomState(4)
+    times = ([0.25 * i for i in range(0, 4 * (KEYS - 1) + 1, 3)] + [0.5] + [0.25 * i for i in range(4 * (KEYS - 1), -1, -5)] +
+             [float(t) for t in rng.uniform(0, KEYS - 1, 12)])
+    kw = make_scene_kwargs(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)
+    scene = capi.Scene(**kw)
+    for k, t in enumerate(times):
+        resident.set_time_and_ensemble(t, 0)
+        streamed.set_time_and_ensemble(t, 0)
+        a, b = resident.evaluate(pos, world=True), streamed.evaluate(pos, world=True)
+        assert torch.equal(a, b), (k, t)
+        if k % 4 == 0:
+            ia, ib = scene.render(resident, 40, 24).clone(), scene.render(streamed, 40, 24).clone()
+            assert torch.equal(torch.nan_to_num(ia, nan=-7.0), torch.nan_to_num(ib, nan=-7.0)), (k, t)
+    # the values themselves: the oracle at the last time
+    ref = oracle.OracleNetwork(vn, oracle.ACC_FLOAT, time=times[-1]).evaluate(pos.cpu().numpy())
+    assert np.abs(b.cpu().numpy() - ref).max() < TOL_SAME_MODEL
+    st, sr = streamed.keyframe_stats(), resident.keyframe_stats()
+    assert st["key_frames"] == KEYS and st["slots"] == slots and sr["slots"] == KEYS
+    assert sr["uploads"] == KEYS                      # resident: every key frame once
+    assert st["uploads"] > KEYS                       # streamed: slots were re-used
+    assert st["on_demand"] >= 2 and st["on_demand"] + st["prefetched"] == st["uploads"]
+    assert (st["prefetched"] > 0) == (slots >= 3)     # the prefetch needs a slot beside the two key frames of the current blend
+    assert st["bytes"] == st["uploads"] * (sr["bytes"] // KEYS)
+
+
+def test_keyframe_slot_budget_can_change_on_a_live_network():
+    """keyframe_slots set on a network that already holds device state: the device state is rebuilt under the new budget, results stay
+    the same; illegal budgets are rejected."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density:direct", grid=(16, 8), seed=42,
+                             box_min=(-0.5, -0.5, -0.5), time_grids=5)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    pos = torch.rand(1024, 3, device="cuda") - 0.5
+    outs = []
+    for slots in (0, 3, 2, 0, 4):
+        net.set_option("keyframe_slots", slots)
+        per_time = []
+        for t in (0.0, 1.5, 3.75, 2.25, 4.0):
+            net.set_time_and_ensemble(t, 0)
+            per_time.append(net.evaluate(pos, world=True).clone())
+        outs.append(torch.stack(per_time))
+        assert net.keyframe_stats()["slots"] == (slots if slots else 5)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    for bad in (1, -1, 70000):
+        with pytest.raises(capi.FvsrnError):
+            net.set_option("keyframe_slots", bad)
+
+
 @pytest.mark.parametrize("enc", [1, 2])
 def test_render_time_dependent_byte_grids(enc):
     """Time-interpolated BYTE_LINEAR / BYTE_GAUSSIAN grids through the renderer, including the reference's quirk of
