@@ -1136,6 +1136,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                        d.tf_preintegration != FVSRN_PREINTEGRATE_NONE;
             // finite differences also sample up to a step outside the box, where the [0,1] bound of the scaled image does
             // not hold: the shaded renderer takes the plain image
+            if (!a.shaded) a.P.fourierNeedsFract = a.P.fourierNeedsFractPlain;  // positions inside the box only (pack.cpp)
             if (net->scaledImage && !a.shaded) {  // ReLU network: image with activations scaled into [0,1] (pack.cpp)
                 a.P.ldsImage = net->scaledImage;
                 a.P.reluClamp = net->keyScaled.act == ACT_RELU01 ? 1 : 0;

@@ -48,6 +48,7 @@ struct NetParams {
     int offPhase, offLayer0, offHidden, offLast, offBias;  // byte offsets into the LDS image
     int fourierNeedsFract;      // |phase| may exceed the v_cos_f32 domain of 256 revolutions for positions inside the box
     int fourierNeedsFractEval;  // ... for positions up to 4 box sizes away (evaluate_points takes arbitrary positions)
+    int fourierNeedsFractPlain; // ... for positions inside the box only (unshaded renders: fvsrn_render copies it into fourierNeedsFract)
     int reluClamp;          // ldsImage is the [0,1]-scaled ReLU image: convert+ReLU is one clamped v_cvt_pk_f16_f32
     float actA, actB;       // activation constants, see act() in srn_device.hpp
     float boxMin[3];

@@ -195,11 +195,13 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
     const int fcols = c.directionMode == 2 ? 6 : 3;
 
     // ---- phase fragments: D = Fm * [x,x,y,y,z,z,1,1 | dx,dx,dy,dy,dz,dz,0,0] in revolutions --------
-    // Matrix entries are split hi + lo in fp16 (two K slots per input).  The two constant slots carry, also split,
-    // -1/4 for sine rows (sin 2 pi x = cos 2 pi (x - 1/4)) minus the integer nearest to the centre of the row's phase
-    // range over the unit box (directions in [-1,1]): a whole number of revolutions does not change cos, and centred
-    // phases stay inside the +-256 revolution domain of v_cos_f32 twice as long (NeRF ladders up to 2^9 need no v_fract).
-    double maxPhase = 0, maxPhaseUncentred = 0;
+    // Matrix entries are split hi + lo in fp16 (two K slots per input).  The two constant slots carry, also split, minus the
+    // integer nearest to the centre of the row's phase range over the unit box (directions in [-1,1]): a whole number of
+    // revolutions changes neither cos nor sin, and centred phases stay inside the +-256 revolution domain of v_cos_f32 / v_sin_f32
+    // twice as long.  Cosine rows sit on even, sine rows on odd accumulator registers (rowToChannel): the kernels take v_sin_f32 for
+    // the odd ones (phase_cos, srn_device.hpp), so both kinds of row have the same, symmetric range -- a NeRF ladder up to 2^9
+    // (256 revolutions to either side of the box centre) needs no v_fract in the unshaded renderer.
+    double maxPhase = 0, maxPhaseUncentred = 0, maxPhasePlain = 0;
     for (int m = 0; m < MT; ++m) {
         Frag f{};
         for (int lane = 0; lane < 64; ++lane) {
@@ -235,19 +237,26 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
                     else { lo -= std::fabs(v); hi += std::fabs(v); }
                 }
                 const double centre = std::nearbyint(0.5 * (lo + hi));
-                const double konst = (idx >= F ? -0.25 : 0.0) - centre;
+                const double konst = -centre;
                 const float kh = half_bits_to_float(float_to_half_bits(float(konst)));
                 slots[6] = kh;
                 slots[7] = half_bits_to_float(float_to_half_bits(float(konst - double(kh))));
                 maxPhase = std::max(maxPhase, 0.5 * (hi - lo) + 0.75);
+                maxPhasePlain = std::max(maxPhasePlain, 0.5 * (hi - lo) + std::fabs(0.5 * (lo + hi) - centre));
                 maxPhaseUncentred = std::max(maxPhaseUncentred, std::max(std::fabs(lo), std::fabs(hi)) + 0.25);
             }
             for (int j = 0; j < 8; ++j) f.v[lane][j] = float_to_half_bits(slots[8 * h + j]);
         }
         putFrag(P.ldsImage, size_t(np.offPhase) + size_t(m) * kFragBytes, f);
     }
-    if (!c.hasFourier) maxPhase = maxPhaseUncentred = 0;
+    if (!c.hasFourier) maxPhase = maxPhaseUncentred = maxPhasePlain = 0;
+    // (with a margin of 3/4 revolution: finite-difference gradients sample up to a step outside the box)
     np.fourierNeedsFract = maxPhase >= 255.0 ? 1 : 0;
+    // The unshaded renderer evaluates positions inside the box up to the rounding of o + t d (a few 1e-7, i.e. <= 2e-4 revolutions at
+    // 2^9): a range of exactly +-256 is taken without v_fract.  Just outside the domain v_cos_f32 returns 1 and v_sin_f32 0 (the ISA's
+    // out-of-range results), which at +-(256 + 2e-4) revolutions differ from the true values by 8e-7 and 1.3e-3 -- on the last sample
+    // of a ray, in the top octave only.
+    np.fourierNeedsFractPlain = maxPhasePlain > 256.0 ? 1 : 0;
     // evaluate_points takes arbitrary positions: stay exact up to 4 box sizes away without the v_fract
     np.fourierNeedsFractEval = (4.0 * maxPhaseUncentred + std::fabs(maxPhase)) >= 255.0 ? 1 : 0;
     // byte offset of the fp16 "time" entry inside the phase fragment (patched on the device when the time changes):

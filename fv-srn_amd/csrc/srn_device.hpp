@@ -426,9 +426,10 @@ __device__ __forceinline__ void phase_cos(floatx16& d, int npass) {
     static_assert(FMODE != FM_FIRST_LAYER, "no cos stage without Fourier features");
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-        if (r >= npass) {
-            if constexpr (FMODE == FM_FRACT_COS) d[r] = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(d[r]));
-            else d[r] = __builtin_amdgcn_cosf(d[r]);
+        if (r >= npass) {  // (cos_j, sin_j) on registers (2i, 2i + 1): pack.cpp, rowToChannel
+            float x = d[r];
+            if constexpr (FMODE == FM_FRACT_COS) x = __builtin_amdgcn_fractf(x);
+            d[r] = (r & 1) ? __builtin_amdgcn_sinf(x) : __builtin_amdgcn_cosf(x);
         }
 }
 
