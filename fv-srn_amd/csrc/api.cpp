@@ -72,6 +72,9 @@ static const Options& defaultOptions() {
 // Waves per workgroup: as few as the LDS budget allows.  16 waves per CU (4 per SIMD) must fit their network copies
 // into the 160 KiB of LDS; a workgroup's slot is only recycled when its slowest wave is done, so fewer waves per
 // workgroup = better balance between long and empty pixel tiles (measured r01: 1 wave 110.8, 4 waves 92.3 Gsamples/s).
+#ifndef FVSRN_IDENTITY_TAIL
+#define FVSRN_IDENTITY_TAIL 4  // TAIL_SCALAR_IDENTITY (1 = the Identity TF through TAIL_SCALAR_TABLE: A/B builds)
+#endif
 static int wavesPerBlockFor(size_t ldsBytesPerBlock, const Options& o) {
     if (o[FVSRN_OPT_WAVES_PER_BLOCK]) return o[FVSRN_OPT_WAVES_PER_BLOCK];
     const size_t budget = 160 * 1024;
@@ -1162,7 +1165,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             // three C->C layers, phases inside the v_cos domain, a transfer function, no shading.  FVSRN_SMALL_KERNEL=0: off.
             const void* smallFn = nullptr;
             int smallGrid = 0;
-            const int smallTail = rgbo ? 3 : (d.tf_kind == FVSRN_TF_PIECEWISE || d.tf_kind == FVSRN_TF_GAUSSIAN ? 2 : 1);  // kernels.hpp TAIL_*
+            const int smallTail = rgbo ? 3 : (d.tf_kind == FVSRN_TF_PIECEWISE || d.tf_kind == FVSRN_TF_GAUSSIAN ? 2 : (d.tf_kind == FVSRN_TF_IDENTITY ? FVSRN_IDENTITY_TAIL : 1));  // kernels.hpp TAIL_*
             {
                 const VariantKey& k = net->keyScaled;
                 const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;

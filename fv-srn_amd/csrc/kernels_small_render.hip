@@ -9,16 +9,17 @@ namespace fvsrn {
     X(ACT_SNAKE, false) X(ACT_SNAKE, true) X(ACT_SNAKEALT, false) X(ACT_SNAKEALT, true) X(ACT_SIGMOID, false) X(ACT_SIGMOID, true) \
     X(ACT_SNAKEALT0, false) X(ACT_SNAKEALT0, true)
 #define FVSRN_SMALL_LAYERS(A, D) \
-    Y(A, D, 1, 1) Y(A, D, 2, 1) Y(A, D, 3, 1) Y(A, D, 1, 2) Y(A, D, 2, 2) Y(A, D, 3, 2) Y(A, D, 1, 3) Y(A, D, 2, 3) Y(A, D, 3, 3)
+    Y(A, D, 1, 1) Y(A, D, 2, 1) Y(A, D, 3, 1) Y(A, D, 1, 2) Y(A, D, 2, 2) Y(A, D, 3, 2) Y(A, D, 1, 3) Y(A, D, 2, 3) Y(A, D, 3, 3) \
+    Y(A, D, 1, 4) Y(A, D, 2, 4) Y(A, D, 3, 4)
 
-// grid: 0 none, 1 one 16-channel chunk of decoded latent values (scalar networks behind an Identity / Texture TF only: tail 1)
+// grid: 0 none, 1 one 16-channel chunk of decoded latent values (scalar networks behind an Identity / Texture TF only: tails 4 / 1)
 #define FVSRN_SMALL_GRID_VARIANTS(X) X(ACT_RELU01, false) X(ACT_SNAKEALT, false) X(ACT_SNAKEALT0, false) X(ACT_SINE, false) X(ACT_SNAKE, false)
-#define FVSRN_SMALL_GRID_LAYERS(A, D) G(A, D, 1) G(A, D, 2) G(A, D, 3)
+#define FVSRN_SMALL_GRID_LAYERS(A, D) G(A, D, 1, 1) G(A, D, 2, 1) G(A, D, 3, 1) G(A, D, 1, 4) G(A, D, 2, 4) G(A, D, 3, 4)
 
 const void* render_small_fn(int act, bool dir, int numLayers, int tail, int grid) {
     if (grid == 1) {
-#define G(A, D, N) \
-        if (act == A && dir == D && numLayers == N && tail == 1) return reinterpret_cast<const void*>(&render_small_kernel<A, D, N, 1, 1>);
+#define G(A, D, N, L) \
+        if (act == A && dir == D && numLayers == N && tail == L) return reinterpret_cast<const void*>(&render_small_kernel<A, D, N, L, 1>);
         FVSRN_SMALL_GRID_VARIANTS(FVSRN_SMALL_GRID_LAYERS)
 #undef G
         return nullptr;
@@ -33,9 +34,9 @@ const void* render_small_fn(int act, bool dir, int numLayers, int tail, int grid
 
 hipError_t launch_render_small(int act, bool dir, int numLayers, int tail, int grid, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s) {
     if (grid == 1) {
-#define G(A, D, N)                                                                                                \
-        if (act == A && dir == D && numLayers == N && tail == 1) {                                                \
-            hipLaunchKernelGGL((render_small_kernel<A, D, N, 1, 1>), dim3(gridDim), dim3(blockDim), ldsBytes, s, a.P, a.S, a.out, a.stats); \
+#define G(A, D, N, L)                                                                                             \
+        if (act == A && dir == D && numLayers == N && tail == L) {                                                \
+            hipLaunchKernelGGL((render_small_kernel<A, D, N, L, 1>), dim3(gridDim), dim3(blockDim), ldsBytes, s, a.P, a.S, a.out, a.stats); \
             return hipGetLastError();                                                                             \
         }
         FVSRN_SMALL_GRID_VARIANTS(FVSRN_SMALL_GRID_LAYERS)
