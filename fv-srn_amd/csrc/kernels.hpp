@@ -313,9 +313,10 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // TAIL_SCALAR_LOOP: the same frame around Piecewise / Gaussian TFs, which loop over their control points (a separate
 // instantiation, so that the loops stay out of the Identity / Texture instruction stream).  TAIL_RGBO: colour networks (rgbo |
 // rgbo:direct, no transfer function) in the same frame.
-// TAIL_SCALAR_IDENTITY (render_small_kernel only): TAIL_SCALAR_TABLE for the Identity TF alone -- no texture branch in the step, and
-// r = g = b = density * emission scale kept as ONE accumulator of w * density that is scaled once per ray (3 vector instructions and a
-// scalar branch less per step; as a run-time branch inside TAIL_SCALAR_TABLE the same idea measured 2 % slower, r02).
+// TAIL_SCALAR_IDENTITY (render_small_kernel only): the Identity TF with Beer-Lambert blending alone -- no texture branch and no blend-mode
+// select in the step, every constant folded on the host, r = g = b = density * emission scale kept as ONE accumulator of w * density that is
+// scaled once per ray: 12 vector instructions per step instead of 20 (as a run-time branch inside TAIL_SCALAR_TABLE the single accumulator
+// alone measured 2 % slower, r02).
 enum { TAIL_GENERIC = 0, TAIL_SCALAR_TABLE = 1, TAIL_SCALAR_LOOP = 2, TAIL_RGBO = 3, TAIL_SCALAR_IDENTITY = 4 };
 
 // x in the lanes whose bit is set in the wave mask m (an SGPR pair), 0 elsewhere: one v_cndmask_b32 with the mask as its selector
@@ -508,8 +509,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             const float aBeer = 1.f - __expf(-c3), aAlpha = fminf(1.f, c3);
             const float a = beerLambert ? aBeer : aAlpha;
             const float w = select_by_mask(validMask & __builtin_amdgcn_ballot_w64(c3 > 0.f), (1.f - ca) * a);
-            cr += w * c0;
-            if constexpr (TAIL != TAIL_SCALAR_IDENTITY) { cg += w * c1; cb += w * c2; }
+            cr += w * c0; cg += w * c1; cb += w * c2;
             depth += w * t;
             ca += w;
             continue;
@@ -522,14 +522,23 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
                 asm volatile("");
                 value = sigmoid_f(value);
             }
+            if constexpr (TAIL == TAIL_SCALAR_IDENTITY) {
+                // Identity TF + Beer-Lambert blending (the host routes Alpha blending to TAIL_SCALAR_TABLE), with every constant folded on the
+                // host: density = clamp01(value * s + b), alpha = 1 - 2^(density * k), k = -absorption * stepsize * log2 e.  The sample
+                // counts where it is valid and value >= densityMin; "absorption > 0" of the reference is implied (density 0 gives alpha 0).
+                const float density = __builtin_amdgcn_fmed3f(fmaf(value, S.divDensityRange, S.densityBias), 0.f, 1.f);
+                const float a = 1.f - __builtin_amdgcn_exp2f(density * S.tfAbsorptionStepLog2e);
+                const float w = select_by_mask(validMask & __builtin_amdgcn_ballot_w64(value >= S.densityMin), (1.f - ca) * a);
+                cr += w * density;  // emission scale behind the loop
+                depth += w * t;
+                ca += w;
+                continue;
+            }
             const float density = fminf(fmaxf((value - S.densityMin) * S.divDensityRange, 0.f), 1.f);  // tf_eval clamps
             float c0, c1, c2, c3;
             if constexpr (TAIL == TAIL_SCALAR_LOOP) {  // Piecewise / Gaussian: per-lane loops over the control points
                 const float4_t c = tf_eval(S, tfLds, density);
                 c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3];
-            } else if constexpr (TAIL == TAIL_SCALAR_IDENTITY) {  // renderer_tf_identity.cuh:36-54, emission scale behind the loop
-                c0 = c1 = c2 = density;
-                c3 = density * S.tfAbsorptionStep;
             } else if (textureTf) {  // wave-uniform; renderer_tf_texture.cuh:46-55
                 const int R = S.tfRows;
                 const float d = density * S.tfRowsF - 0.5f;
