@@ -209,12 +209,16 @@ __device__ __forceinline__ GridTap grid_tap(const NetParams& P, float px, float 
     return t;
 }
 
-// own-sample tap -> taps of sample (lane&31) of tile 0 / tile 1
+// own-sample tap -> taps of sample (lane&31) of tile 0 / tile 1, their offsets INCLUDING this lane half's 32 bytes (kTapHalfInOffset for
+// grid_load / grid_features; taps straight from grid_tap() take the lane half there)
+constexpr int kTapHalfInOffset = 0;
 template <bool WITH_LO>
 __device__ __forceinline__ void grid_tap_bcast(const GridTap& own, GridTap& t0, GridTap& t1) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        auto a = __builtin_amdgcn_permlane32_swap(own.off[k], own.off[k], false, false);
+        // the consumer's lane-half offset (lane half h reads channels [16 g + 8 h, +8): 32 bytes of a record) rides along: the second
+        // operand of the swap is a copy of the first anyway, here it is an add (8 v_add_u32 per wave step less in grid_load)
+        auto a = __builtin_amdgcn_permlane32_swap(own.off[k], own.off[k] + 32u, false, false);
         t0.off[k] = a[0]; t1.off[k] = a[1];
         auto b = __builtin_amdgcn_permlane32_swap(own.w[k], own.w[k], false, false);
         t0.w[k] = b[0]; t1.w[k] = b[1];
@@ -317,13 +321,14 @@ __device__ __forceinline__ void grid_fetch8(const void* grid, const GridTap& t, 
 
 // 8 channels [16*g + 8*h, +8) of the tile sample described by `t`, as the B fragment of latent K step g
 // GRID: 1 = `grid` holds decoded, time-blended values (FLOAT, BYTE_LINEAR); 2 = BYTE_GAUSSIAN
+// hLoad: the lane half for the record offset (kTapHalfInOffset for taps from grid_tap_bcast)
 template <int GRID>
-__device__ __forceinline__ half8_t grid_features(const NetParams& P, const GridTap& t, int g, int h) {
+__device__ __forceinline__ half8_t grid_features(const NetParams& P, const GridTap& t, int g, int h, int hLoad) {
     float acc[8];
-    grid_fetch8<GRID == 2>(P.grid, t, g, h, acc);
+    grid_fetch8<GRID == 2>(P.grid, t, g, hLoad, acc);
     if constexpr (GRID == 2) {  // EncodeGridValue<BYTE_GAUSSIAN> :370-383
         float accB[8];
-        grid_fetch8<true>(P.gridB, t, g, h, accB);
+        grid_fetch8<true>(P.gridB, t, g, hLoad, accB);
         const int c0 = 16 * g + 8 * h;
         const bool isTime = c0 < P.gridTimeChannels;  // a 16-channel chunk never straddles time / ensemble channels
         const float* mean = isTime ? P.gridMeanTime + c0 : P.gridMeanEns + (c0 - P.gridTimeChannels);
@@ -662,7 +667,7 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
         }
         if (gpre) { gt[0] = gpre->gt[0]; gt[1] = gpre->gt[1]; }
         else grid_tap_bcast<GRID == 2>(grid_tap(P, px, py, pz), gt[0], gt[1]);
-        if constexpr (GRID_AHEAD) grid_load(P.grid, gt[0], 0, h, raw);
+        if constexpr (GRID_AHEAD) grid_load(P.grid, gt[0], 0, kTapHalfInOffset, raw);
     }
     const bool havePre = GRID == 1 && gpre && gpre->valid;
     __builtin_amdgcn_sched_barrier(0);
@@ -686,7 +691,7 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
                               if (j < 4) grid_reduce_record<false>(raw, gt[0], j, gacc);
                               else gf = grid_pack(gacc);
                           });
-        grid_load(P.grid, gt[1], 0, h, raw);  // tile 1's chunk: in flight behind tile 1's first-layer MFMAs
+        grid_load(P.grid, gt[1], 0, kTapHalfInOffset, raw);  // tile 1's chunk: in flight behind tile 1's first-layer MFMAs
 #pragma unroll
         for (int j = 0; j < NF0; ++j) fill(j);
     } else {
@@ -696,7 +701,7 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
     if constexpr (GRID != 0) {
         for (int g = 0; g < P.gridK; ++g) {
             if (havePre && g == 0) gf = gpre->gf[0];
-            else if (!GRID_AHEAD || g > 0) gf = grid_features<GRID>(P, gt[0], g, h);
+            else if (!GRID_AHEAD || g > 0) gf = grid_features<GRID>(P, gt[0], g, h, kTapHalfInOffset);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const half8_t w = (PREFETCH_AG && g == 0) ? ag[m] : frag(offGridW + (g * MT + m) * kFragBytes);
@@ -763,7 +768,7 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
             } else if (havePre && g == 0) {
                 gf = gpre->gf[1];
             } else {
-                gf = grid_features<GRID>(P, gt[1], g, h);
+                gf = grid_features<GRID>(P, gt[1], g, h, kTapHalfInOffset);
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -852,8 +857,8 @@ __device__ __forceinline__ float4_t srn_layers_kmajor(const NetParams& P, const 
         if constexpr (GRID != 0) {
             if (l == 0) {
                 for (int g = 0; g < P.gridK; ++g) {
-                    const half8_t g0 = (havePre && g == 0) ? gpre->gf[0] : grid_features<GRID>(P, gt[0], g, h);
-                    const half8_t g1 = (havePre && g == 0) ? gpre->gf[1] : grid_features<GRID>(P, gt[1], g, h);
+                    const half8_t g0 = (havePre && g == 0) ? gpre->gf[0] : grid_features<GRID>(P, gt[0], g, h, kTapHalfInOffset);
+                    const half8_t g1 = (havePre && g == 0) ? gpre->gf[1] : grid_features<GRID>(P, gt[1], g, h, kTapHalfInOffset);
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const half8_t a = lds_frag(lds, wOff + (MT * KS + g * MT + m) * kFragBytes, lane);
@@ -925,7 +930,7 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
         grid_tap_bcast<false>(grid_tap(P, px, py, pz), G.gt[0], G.gt[1]);
         G.valid = 1;
         GridRaw raw;
-        grid_load(P.grid, G.gt[0], 0, h, raw);
+        grid_load(P.grid, G.gt[0], 0, kTapHalfInOffset, raw);
         half8_t b0[2];
         phase_operands<HAS_DIR, true>(px, py, pz, dx, dy, dz, h, b0);
         __builtin_amdgcn_sched_barrier(0);
@@ -938,7 +943,7 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
             for (int k = 1; k < 4; ++k) grid_reduce_record<false>(raw, G.gt[0], k, acc);
             G.gf[0] = grid_pack(acc);
         }
-        grid_load(P.grid, G.gt[1], 0, h, raw);
+        grid_load(P.grid, G.gt[1], 0, kTapHalfInOffset, raw);
         __builtin_amdgcn_sched_barrier(0);
         fourier_fragments_tile<CD, ACT, HAS_DIR, FMODE>(P, lds, b0[1], xb[1]);
         __builtin_amdgcn_sched_barrier(0);
@@ -968,14 +973,13 @@ __device__ __forceinline__ float4_t srn_forward_rotating(const NetParams& P, con
     if constexpr (GRID == 1) {
         // latent grid + rotated features: the gathers of a tile are in flight behind that tile's converts and rotations (GridPre)
         constexpr int MT = mtiles(CD);
-        const int h = lane_id() >> 5;
         GridPre G;
         grid_tap_bcast<false>(grid_tap(P, px, py, pz), G.gt[0], G.gt[1]);
         G.valid = 1;
         GridRaw raw;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            grid_load(P.grid, G.gt[t], 0, h, raw);
+            grid_load(P.grid, G.gt[t], 0, kTapHalfInOffset, raw);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -1129,7 +1133,7 @@ __device__ __forceinline__ float4_t srn_forward_resident_grid(const NetParams& P
     half8_t b0[2];
     phase_operands<HAS_DIR, true>(px, py, pz, dx, dy, dz, h, b0);
     GridRaw raw;
-    grid_load(P.grid, gt[0], 0, h, raw);
+    grid_load(P.grid, gt[0], 0, kTapHalfInOffset, raw);
     // both phase MFMAs first: the second runs while the first tile's cosines issue (one exposed MFMA latency instead of two)
     floatx16 d[2];
     {
@@ -1140,7 +1144,7 @@ __device__ __forceinline__ float4_t srn_forward_resident_grid(const NetParams& P
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        if (t == 1) grid_load(P.grid, gt[1], 0, h, raw);
+        if (t == 1) grid_load(P.grid, gt[1], 0, kTapHalfInOffset, raw);
         __builtin_amdgcn_sched_barrier(0);
         phase_cos<FM_COS>(d[t], NPASS);
 #pragma unroll
