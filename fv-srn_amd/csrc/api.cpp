@@ -1105,6 +1105,7 @@ static void fillSceneParams(fvsrn_scene* scene, const fvsrn_scene_desc& d, int w
     S.tfAbsorptionStep = d.tf_scale_absorption * d.stepsize;
     S.tfAbsorptionStepLog2e = float(-double(d.tf_scale_absorption) * double(d.stepsize) * 1.4426950408889634);
     S.densityBias = -d.density_min * S.divDensityRange;
+    S.stepLog2e = float(-double(d.stepsize) * 1.4426950408889634);
     S.tfTable = static_cast<const float*>(scene->dTf.ptr);
     S.tfPreintegration = d.tf_preintegration;
     S.tfPreintegrated = static_cast<const float*>(scene->dPreint.ptr);
@@ -1167,7 +1168,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             // three C->C layers, phases inside the v_cos domain, a transfer function, no shading.  FVSRN_SMALL_KERNEL=0: off.
             const void* smallFn = nullptr;
             int smallGrid = 0;
-            const int smallTail = rgbo ? 3 : (d.tf_kind == FVSRN_TF_PIECEWISE || d.tf_kind == FVSRN_TF_GAUSSIAN ? 2 : (d.tf_kind == FVSRN_TF_IDENTITY && d.blend_mode == FVSRN_BLEND_BEER_LAMBERT && d.tf_scale_absorption >= 0.f ? FVSRN_IDENTITY_TAIL : 1));  // kernels.hpp TAIL_*
+            const int smallTail = rgbo ? 3 : (d.tf_kind == FVSRN_TF_PIECEWISE || d.tf_kind == FVSRN_TF_GAUSSIAN ? 2 : (d.blend_mode != FVSRN_BLEND_BEER_LAMBERT ? 1 : (d.tf_kind == FVSRN_TF_IDENTITY && d.tf_scale_absorption >= 0.f ? FVSRN_IDENTITY_TAIL : (d.tf_kind == FVSRN_TF_TEXTURE ? 5 : 1))));  // kernels.hpp TAIL_*
             {
                 const VariantKey& k = net->keyScaled;
                 const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;

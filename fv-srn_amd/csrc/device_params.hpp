@@ -90,6 +90,7 @@ struct SceneParams {
     float tfScaleAbsorption, tfScaleEmission;
     float tfAbsorptionStep;  // tfScaleAbsorption * stepsize (Identity TF, straight-line tail)
     float tfAbsorptionStepLog2e, densityBias;  // TAIL_SCALAR_IDENTITY: -tfAbsorptionStep * log2(e); -densityMin * divDensityRange
+    float stepLog2e;                           // TAIL_SCALAR_TEXTURE: -stepsize * log2(e)
     const float* tfTable;  // device pointer
     int tfPreintegration;          // 0 none, 1: tfPreintegrated = [R][4] running integral, 2: [R][R][4] (previous, current density)
     const float* tfPreintegrated;  // device pointer (global memory: 1 MiB in 2D mode), R = tfRows

@@ -317,7 +317,8 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // select in the step, every constant folded on the host, r = g = b = density * emission scale kept as ONE accumulator of w * density that is
 // scaled once per ray: 12 vector instructions per step instead of 20 (as a run-time branch inside TAIL_SCALAR_TABLE the single accumulator
 // alone measured 2 % slower, r02).
-enum { TAIL_GENERIC = 0, TAIL_SCALAR_TABLE = 1, TAIL_SCALAR_LOOP = 2, TAIL_RGBO = 3, TAIL_SCALAR_IDENTITY = 4 };
+// TAIL_SCALAR_TEXTURE (render_small_kernel only): the same for the Texture TF -- what convert_to_texture_tf() of the evaluation scripts produces.
+enum { TAIL_GENERIC = 0, TAIL_SCALAR_TABLE = 1, TAIL_SCALAR_LOOP = 2, TAIL_RGBO = 3, TAIL_SCALAR_IDENTITY = 4, TAIL_SCALAR_TEXTURE = 5 };
 
 // x in the lanes whose bit is set in the wave mask m (an SGPR pair), 0 elsewhere: one v_cndmask_b32 with the mask as its selector
 __device__ __forceinline__ float select_by_mask(unsigned long long m, float x) {
@@ -534,6 +535,26 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
                 ca += w;
                 continue;
             }
+            if constexpr (TAIL == TAIL_SCALAR_TEXTURE) {
+                // Texture TF (renderer_tf_texture.cuh:46-55) + Beer-Lambert blending, constants folded like in TAIL_SCALAR_IDENTITY:
+                // alpha = 1 - 2^(opacity * k), k = -stepsize * log2 e
+                const float density = __builtin_amdgcn_fmed3f(fmaf(value, S.divDensityRange, S.densityBias), 0.f, 1.f);
+                const int R = S.tfRows;
+                const float d = fmaf(density, S.tfRowsF, -0.5f);
+                const float fl = floorf(d);
+                const int di = int(fl);
+                const float df = d - fl;
+                const float4_t ta = *reinterpret_cast<const float4_t*>(tfLds + 4 * min(max(di, 0), R - 1));
+                const float4_t tb = *reinterpret_cast<const float4_t*>(tfLds + 4 * min(max(di + 1, 0), R - 1));
+                const float a = 1.f - __builtin_amdgcn_exp2f((ta[3] + df * (tb[3] - ta[3])) * S.stepLog2e);
+                const float w = select_by_mask(validMask & __builtin_amdgcn_ballot_w64(value >= S.densityMin), (1.f - ca) * a);
+                cr += w * (ta[0] + df * (tb[0] - ta[0]));
+                cg += w * (ta[1] + df * (tb[1] - ta[1]));
+                cb += w * (ta[2] + df * (tb[2] - ta[2]));
+                depth += w * t;
+                ca += w;
+                continue;
+            }
             const float density = fminf(fmaxf((value - S.densityMin) * S.divDensityRange, 0.f), 1.f);  // tf_eval clamps
             float c0, c1, c2, c3;
             if constexpr (TAIL == TAIL_SCALAR_LOOP) {  // Piecewise / Gaussian: per-lane loops over the control points
@@ -742,7 +763,8 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void r
 
 // 32-wide Fourier-only scalar networks with NLC <= 3 C->C layers behind a transfer function, phases inside the v_cos domain
 // (the host checks all of that, api.cpp): weights and biases in registers, 2 waves per SIMD (256 registers)
-// TAILK: TAIL_SCALAR_IDENTITY (Identity TF), TAIL_SCALAR_TABLE (Texture TF), TAIL_SCALAR_LOOP (Piecewise / Gaussian TF) or TAIL_RGBO (colour network)
+// TAILK: TAIL_SCALAR_IDENTITY / TAIL_SCALAR_TEXTURE (Identity / Texture TF with Beer-Lambert blending), TAIL_SCALAR_TABLE (the same two with Alpha
+// blending), TAIL_SCALAR_LOOP (Piecewise / Gaussian TF) or TAIL_RGBO (colour network)
 // SGRID = 1: the same with ONE 16-channel latent grid chunk of decoded values (direct Fourier features instead of the rotation:
 // the registers of the rotation state hold the grid fetch)
 template <int ACT, bool HAS_DIR, int NLC, int TAILK, int SGRID = 0>

@@ -10,11 +10,12 @@ namespace fvsrn {
     X(ACT_SNAKEALT0, false) X(ACT_SNAKEALT0, true)
 #define FVSRN_SMALL_LAYERS(A, D) \
     Y(A, D, 1, 1) Y(A, D, 2, 1) Y(A, D, 3, 1) Y(A, D, 1, 2) Y(A, D, 2, 2) Y(A, D, 3, 2) Y(A, D, 1, 3) Y(A, D, 2, 3) Y(A, D, 3, 3) \
-    Y(A, D, 1, 4) Y(A, D, 2, 4) Y(A, D, 3, 4)
+    Y(A, D, 1, 4) Y(A, D, 2, 4) Y(A, D, 3, 4) Y(A, D, 1, 5) Y(A, D, 2, 5) Y(A, D, 3, 5)
 
-// grid: 0 none, 1 one 16-channel chunk of decoded latent values (scalar networks behind an Identity / Texture TF only: tails 4 / 1)
+// grid: 0 none, 1 one 16-channel chunk of decoded latent values (scalar networks behind an Identity / Texture TF only: tails 4 / 5 / 1)
 #define FVSRN_SMALL_GRID_VARIANTS(X) X(ACT_RELU01, false) X(ACT_SNAKEALT, false) X(ACT_SNAKEALT0, false) X(ACT_SINE, false) X(ACT_SNAKE, false)
-#define FVSRN_SMALL_GRID_LAYERS(A, D) G(A, D, 1, 1) G(A, D, 2, 1) G(A, D, 3, 1) G(A, D, 1, 4) G(A, D, 2, 4) G(A, D, 3, 4)
+#define FVSRN_SMALL_GRID_LAYERS(A, D) \
+    G(A, D, 1, 1) G(A, D, 2, 1) G(A, D, 3, 1) G(A, D, 1, 4) G(A, D, 2, 4) G(A, D, 3, 4) G(A, D, 1, 5) G(A, D, 2, 5) G(A, D, 3, 5)
 
 const void* render_small_fn(int act, bool dir, int numLayers, int tail, int grid) {
     if (grid == 1) {

@@ -90,7 +90,7 @@ hipError_t launch_generate_rays(const SceneParams& S, float* rayStart, float* ra
 hipError_t launch_evaluate_tf(const SceneParams& S, const float* density, const float* previous, size_t n, float* colors, hipStream_t s);
 
 // render_small_kernel (kernels_small_render.hip): nullptr / hipErrorInvalidDeviceFunction if that variant is not compiled in
-// tail: 4 Identity TF, 1 Texture TF, 2 Piecewise/Gaussian TF, 3 colour network; grid: 0 Fourier-only, 1 one decoded 16-channel latent chunk
+// tail: 4 / 5 Identity / Texture TF with Beer-Lambert blending, 1 the same with Alpha blending, 2 Piecewise/Gaussian TF, 3 colour network; grid: 0 Fourier-only, 1 one decoded 16-channel latent chunk
 const void* render_small_fn(int act, bool dir, int numLayers, int tail, int grid = 0);
 hipError_t launch_render_small(int act, bool dir, int numLayers, int tail, int grid, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 
