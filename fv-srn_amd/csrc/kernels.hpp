@@ -308,16 +308,17 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
 // TAIL: what follows the network inside the step loop.  TAIL_GENERIC handles every output mode / transfer function /
 // blend mode / early-out setting through wave-uniform branches (~20 scalar branches, exec-mask regions and scalar spills
 // per step: ~1000 cycles of latency for a lone wave, r01 tools/section_profile.py, more than the network itself).
-// TAIL_SCALAR_TABLE is the common case -- a scalar density network (density | density:direct) with an Identity or
-// Texture transfer function -- as straight-line predicated code with two wave-uniform branches (sigmoid, texture).
+// TAIL_SCALAR_TABLE -- a scalar density network (density | density:direct) with an Identity or Texture transfer function, either
+// blend mode -- as straight-line predicated code with two wave-uniform branches (sigmoid, texture); since r02 only render_small_kernel
+// instantiates it, for Alpha blending (Beer-Lambert: TAIL_SCALAR_IDENTITY / TAIL_SCALAR_TEXTURE below).
 // TAIL_SCALAR_LOOP: the same frame around Piecewise / Gaussian TFs, which loop over their control points (a separate
 // instantiation, so that the loops stay out of the Identity / Texture instruction stream).  TAIL_RGBO: colour networks (rgbo |
 // rgbo:direct, no transfer function) in the same frame.
-// TAIL_SCALAR_IDENTITY (render_small_kernel only): the Identity TF with Beer-Lambert blending alone -- no texture branch and no blend-mode
+// TAIL_SCALAR_IDENTITY: the Identity TF with Beer-Lambert blending alone -- no texture branch and no blend-mode
 // select in the step, every constant folded on the host, r = g = b = density * emission scale kept as ONE accumulator of w * density that is
 // scaled once per ray: 12 vector instructions per step instead of 20 (as a run-time branch inside TAIL_SCALAR_TABLE the single accumulator
 // alone measured 2 % slower, r02).
-// TAIL_SCALAR_TEXTURE (render_small_kernel only): the same for the Texture TF -- what convert_to_texture_tf() of the evaluation scripts produces.
+// TAIL_SCALAR_TEXTURE: the same for the Texture TF -- what convert_to_texture_tf() of the evaluation scripts produces.
 enum { TAIL_GENERIC = 0, TAIL_SCALAR_TABLE = 1, TAIL_SCALAR_LOOP = 2, TAIL_RGBO = 3, TAIL_SCALAR_IDENTITY = 4, TAIL_SCALAR_TEXTURE = 5 };
 
 // x in the lanes whose bit is set in the wave mask m (an SGPR pair), 0 elsewhere: one v_cndmask_b32 with the mask as its selector
@@ -743,12 +744,15 @@ __device__ __forceinline__ void render_entry(const NetParams& P, const ScenePara
         if (P.noFourier) return render_body<CD, ACT, GRID, HAS_DIR, FM_FIRST_LAYER, SHADED>(P, S, lds, tfLds, out, stats);
     }
     if constexpr (!SHADED) {
+        // The straight-line tails: a scalar network behind an Identity or Texture TF with Beer-Lambert blending, phases inside the v_cos /
+        // v_sin domain (with the sine rows on v_sin_f32 that includes the 2^9 NeRF ladder of a 64-wide network, which took the generic tail
+        // until r02: 64x6 + 32^3 grid 24.3 -> 25.9 Gsamples/s).  Alpha blending and phases that need v_fract take the generic tail.
         const bool scalarNet = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
-        if (scalarNet && (S.tfKind == FVSRN_TF_IDENTITY || S.tfKind == FVSRN_TF_TEXTURE)) {
-            // (until r02 phases outside the v_cos domain -- e.g. the 10-octave NeRF ladder of a 64-wide network -- took the generic tail:
-            // 64x6 + 32^3 grid 24.3 -> 25.2 Gsamples/s)
-            if (P.fourierNeedsFract) return render_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS, SHADED, TAIL_SCALAR_TABLE>(P, S, lds, tfLds, out, stats);
-            return render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_SCALAR_TABLE>(P, S, lds, tfLds, out, stats);
+        if (scalarNet && !P.fourierNeedsFract && S.blendMode == FVSRN_BLEND_BEER_LAMBERT) {
+            if (S.tfKind == FVSRN_TF_IDENTITY && S.tfAbsorptionStepLog2e <= 0.f)
+                return render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_SCALAR_IDENTITY>(P, S, lds, tfLds, out, stats);
+            if (S.tfKind == FVSRN_TF_TEXTURE)
+                return render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_SCALAR_TEXTURE>(P, S, lds, tfLds, out, stats);
         }
     }
     if (P.fourierNeedsFract) return render_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS, SHADED>(P, S, lds, tfLds, out, stats);
