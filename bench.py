@@ -18,8 +18,9 @@ renderer_ray_evaluation_stepping_dvr.cuh:84-90 summed over all rays), read from 
 N > 1 (`python bench.py --gpus N` starts the N rank processes itself; under torch.distributed.run it takes the launcher's
 RANK / WORLD_SIZE instead): the SAME frame is split into round-robin 16-row stripes, one
 process per GPU, each rank renders its stripes and one RCCL all-gather assembles the frame ("strong" scaling;
-the gather of frame i overlaps the render of frame i+1 on a side stream, and consecutive frames alternate between two render
-streams so that the tail of one launch overlaps the start of the next).
+the frame pipeline is fv-srn_amd/tiles.py StripeRenderer: the gather of frame i overlaps the render of frame i+1 on a side stream,
+consecutive frames alternate between two render streams so that the tail of one launch overlaps the start of the next --
+time-dependent networks included, the library blends into the working grid the frame in flight does not read).
 
 Prints ONE JSON line (see the contract in the task description) with "roofline" and "cpu_baseline".
 """
@@ -27,8 +28,6 @@ import argparse
 import json
 import math
 import os
-import socket
-import subprocess
 import sys
 import time
 
@@ -74,92 +73,51 @@ def make_network(volnet_io, capi, cfg, activation, time_keys=1):
     return vn, capi.Network.from_volnet(volnet_io.save_volnet(vn))
 
 
-class Runner:
-    """Renders frames of one network on this rank (whole frame, or this rank's stripes + all-gather)."""
+def bench_arrays(C, layers, grid, time_keys=1):
+    """The fp32 arrays bench_network() is built from (the CPU baseline times exactly this network)."""
+    from fvsrn_amd import synthetic
+    return synthetic.random_arrays(C=C, layers=layers, output_mode="density:direct", grid=grid, seed=1234, grid_scale=0.01, time_grids=time_keys)
 
-    def __init__(self, capi, net, cfg, rank, world, early_out, time_keys=1):
+
+class Runner:
+    """The benchmark's frame sequence (rotating camera, advancing time) on fv-srn_amd/tiles.py StripeRenderer: whole frames on
+    one GPU, this rank's stripes + all-gather on several.  All multi-GPU logic lives in the package."""
+
+    def __init__(self, capi, net, cfg, rank, world, early_out, time_keys=1, scene_options=None):
+        from fvsrn_amd import tiles
         self.capi, self.net, self.rank, self.world = capi, net, rank, world
         self.time_keys = time_keys
         _, _, _, self.W, self.H, steps = cfg
         self.stepsize = 1.0 / steps
         self.early_out = early_out
-        self.scene = capi.Scene(**build_scene_kwargs(capi, 0.0, self.stepsize, early_out))
-        self.stats = torch.zeros(2, dtype=torch.int64, device="cuda")
-        # N > 1: frames alternate between two scenes on two streams, so that the launch tail of frame i (its last waves, the
-        # composite of its depth segments) overlaps the start of frame i + 1.  Not with time-dependent grids: a time change
-        # rewrites the working grid the previous frame may still read.  At N = 1 the same trick is worth +4 % (r01: 152.7 ->
-        # 159.0 Gsamples/s, FVSRN_BENCH_PIPELINE=1), but the default keeps one launch at a time there so that the HIP-event
-        # duration of the kernel, the rocprofv3 kernel trace and the frame period are the same number.
+        # N > 1: two frames in flight on two streams (time-dependent networks too: FVSRN_OPT_WORKING_GRIDS).  At N = 1 the same
+        # trick is worth +4 % (r01: 152.7 -> 159.0 Gsamples/s, FVSRN_BENCH_PIPELINE=1), but the default keeps one launch at a time
+        # there so that the HIP-event duration of the kernel, the rocprofv3 kernel trace and the frame period are the same number.
         pipe = os.environ.get("FVSRN_BENCH_PIPELINE")
-        self.pipelined = time_keys == 1 and (pipe == "1" if pipe is not None else world > 1)
-        if world == 1:
-            self.outs = [torch.zeros((1, 8, self.H, self.W), dtype=torch.float32, device="cuda") for _ in range(2)]
-            self.out = self.outs[0]
-        else:
-            assert self.H % (STRIPE * world) == 0, "image height must be a multiple of stripe*world"
-            rows = capi.stripe_rows(self.H, STRIPE, rank, world)
-            self.local = [torch.zeros((8, rows, self.W), dtype=torch.float32, device="cuda") for _ in range(2)]
-            self.gathered = [torch.zeros((world, 8, rows, self.W), dtype=torch.float32, device="cuda") for _ in range(2)]
-            self.comm_stream = torch.cuda.Stream()
-            self.render_done = [torch.cuda.Event() for _ in range(2)]
-            self.gather_done = [torch.cuda.Event() for _ in range(2)]
-        if self.pipelined:
-            self.scenes = [self.scene, capi.Scene(**build_scene_kwargs(capi, 0.0, self.stepsize, early_out))]
-            # First use of a network handle (upload of the LDS image and the key frames, include/fvsrn.h) is ordered on the
-            # stream of the call that triggers it only: do it once here, untimed, and let both render streams start behind it.
-            if world == 1:
-                self.scene.render(net, self.W, self.H, out=self.outs[0])
-            else:
-                capi.render_stripes(self.scene, net, self.W, self.H, STRIPE, rank, world, out=self.local[0])
-            torch.cuda.synchronize()
-            self.render_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-            for st in self.render_streams:
-                st.wait_stream(torch.cuda.current_stream())
-        self.kernel_events = []
+        pipelined = pipe == "1" if pipe is not None else world > 1
+        self.pipeline = tiles.StripeRenderer(net, self.W, self.H, build_scene_kwargs(capi, 0.0, self.stepsize, early_out), rank=rank,
+                                             world=world, stripe=STRIPE, pipelined=pipelined)
+        for sc in self.pipeline.scenes:
+            for k, v in (scene_options or {}).items():
+                sc.set_option(k, v)
+        self.pipelined = self.pipeline.pipelined
+        self.stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+
+    @property
+    def kernel_events(self):
+        return self.pipeline.kernel_events
 
     def frame(self, index, record=False, gather=True):
-        import torch.distributed as dist
         yaw = 2 * math.pi * (index % 64) / 64
-        b = index & 1
-        scene = self.scenes[b] if self.pipelined else self.scene
-        stream = self.render_streams[b] if self.pipelined else torch.cuda.current_stream()
-        scene.update(**build_scene_kwargs(self.capi, yaw, self.stepsize, self.early_out))
-        if self.time_keys > 1:  # key frames are resident in HBM; this only schedules the device-side blend
-            self.net.set_time_and_ensemble((0.25 * index) % (self.time_keys - 1), 0)
-        with torch.cuda.stream(stream):
-            if record:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            if self.world == 1:
-                scene.render(self.net, self.W, self.H, out=self.outs[b], stats=self.stats)
-            else:
-                stream.wait_event(self.gather_done[b])  # buffer b free again
-                self.capi.render_stripes(scene, self.net, self.W, self.H, STRIPE, self.rank, self.world,
-                                         out=self.local[b], stats=self.stats)
-                self.render_done[b].record()
-            if record:
-                e1.record()
-                self.kernel_events.append((e0, e1))
-        if self.world > 1 and gather:
-            with torch.cuda.stream(self.comm_stream):  # gather(frame i) overlaps render(frame i+1)
-                self.comm_stream.wait_event(self.render_done[b])
-                dist.all_gather_into_tensor(self.gathered[b].view(self.world * 8, -1, self.W), self.local[b])
-                self.gather_done[b].record()
+        t = (0.25 * index) % (self.time_keys - 1) if self.time_keys > 1 else None
+        return self.pipeline.submit(index, build_scene_kwargs(self.capi, yaw, self.stepsize, self.early_out), time=t, stats=self.stats,
+                                    gather=gather, record=record)
 
     def finish(self):
-        if self.pipelined:
-            for st in self.render_streams:
-                torch.cuda.current_stream().wait_stream(st)
-        if self.world > 1:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.pipeline.finish()
 
     def assemble(self, b=0):
-        """(world, 8, rows, W) -> (1, 8, H, W): undo the round-robin stripe order."""
-        if self.world == 1:
-            return self.out
-        g = self.gathered[b]
-        R, _, rows, W = g.shape
-        return g.view(R, 8, rows // STRIPE, STRIPE, W).permute(1, 2, 0, 3, 4).reshape(1, 8, self.H, W)
+        return self.pipeline.frame(b)
 
 
 def timed_run(runner, steps, warmup, distributed, spinup_ms=0.0):
@@ -204,20 +162,13 @@ def timed_run(runner, steps, warmup, distributed, spinup_ms=0.0):
 
 
 def cpu_baseline(cfg, activation):
-    """The reference's PyTorch path (port: oracle/torch_port.py) on the host cores, bounded sample."""
+    """The reference's PyTorch path (port: oracle/torch_port.py) on the host cores, bounded sample; the network is
+    bench_network()'s (same seed, same arrays, fp32 like the reference's PyTorch model)."""
     from oracle import torch_port
     from fvsrn_amd import capi
     C, layers, grid, *_ = cfg
-    rng = np.random.RandomState(1234)
-    F = (C - 4) // 2
-    blocks = [(2.0 ** i) * np.eye(3) for i in range((F + 2) // 3)]
-    B = (np.concatenate(blocks, axis=0)[:F] * 2 * np.pi).astype(np.float32)
-    G = grid[0] if grid else 0
-    dims = [3 + 2 * F + G] + [C] * (layers - 1) + [1]
-    ws = [rng.uniform(-1, 1, (dims[i + 1], dims[i])).astype(np.float32) / np.sqrt(dims[i]) for i in range(layers)]
-    bs = [rng.uniform(-1, 1, dims[i + 1]).astype(np.float32) / np.sqrt(dims[i]) for i in range(layers)]
-    g = (rng.randn(1, G, grid[1], grid[1], grid[1]) * 0.01).astype(np.float32) if grid else None
-    net = torch_port.TorchSRN(B, ws, bs, activation, 1.0, "density:direct", g)
+    a = bench_arrays(C, layers, grid)
+    net = torch_port.TorchSRN(a["B"], a["weights"], a["biases"], activation, 1.0, "density:direct", a["grids"][0][None] if a["grids"] else None)
     eye, right, up = capi.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, 0.0, 1.6)
     # torch's intra-op pool degrades badly beyond a few dozen threads on these small GEMMs (256 threads: 1.3e4
     # samples/s, measured r01) -- use at most 32 host threads and say so in "cores"
@@ -228,7 +179,7 @@ def cpu_baseline(cfg, activation):
                                      height=H, stepsize=1.0 / steps, tf_identity=(10.0, 1.0), threads=cores, budget_s=15.0)
     return {"value": r["value"], "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": "PyTorch-CPU fp32 port of SceneRepresentationNetwork.forward + Raytracing._full_trace_forward, "
-                      "same network/camera, %dx%d rays at step 1/%d, the first %d network samples (%.1f s of the step loop)"
+                      "the bench network (seed 1234) and camera, %dx%d rays at step 1/%d, the first %d network samples (%.1f s of the step loop)"
                       % (W, H, steps, r["samples"], r["seconds"])}
 
 
@@ -316,38 +267,9 @@ def dist_world_size(distributed):
 
 
 def launch_ranks(n, argv, child=None):
-    """`python bench.py --gpus N` without a launcher around it: start N rank processes (fresh interpreters, one per GPU, RCCL
-    rendezvous on 127.0.0.1), relay rank 0's JSON line and return the worst exit code.  This process never initialises a GPU
-    (torch.cuda.device_count() does not, on this image).  Fewer than N visible GPUs is an error, not a silent 1-GPU run --
-    unless FVSRN_BENCH_BACKEND=gloo, the test mode in which all ranks share the visible GPU(s).
-    child: command prefix of a rank process (tests substitute a stand-in); default = this script."""
-    backend = os.environ.get("FVSRN_BENCH_BACKEND", "nccl")
-    have = torch.cuda.device_count()
-    if backend == "nccl" and have < n:
-        print("bench.py --gpus %d: only %d GPU(s) visible, one per rank is required" % (n, have), file=sys.stderr)
-        return 2
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    cmd = list(child) if child else [sys.executable, os.path.abspath(__file__)]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:  # rank 0 is gone and this one hangs in a collective: end exactly this process
-            p.kill()
-            rcs.append(p.wait())
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
-    bad = [rc for rc in rcs if rc != 0]
-    return 0 if not bad else (bad[0] if bad[0] > 0 else 1)
+    """`python bench.py --gpus N` without a launcher around it: N rank processes of this script (fv-srn_amd/tiles.py)."""
+    from fvsrn_amd import tiles
+    return tiles.launch_ranks(n, argv, script=os.path.abspath(__file__), child=child)
 
 
 def main():
@@ -423,16 +345,12 @@ def main():
         gathered = runner.assemble(last & 1)
         yaw = 2 * math.pi * (last % 64) / 64
         scene = capi.Scene(**build_scene_kwargs(capi, yaw, runner.stepsize, args.early_out))
+        if time_keys > 1:
+            net.set_time_and_ensemble((0.25 * last) % (time_keys - 1), 0)
         full = scene.render(net, runner.W, runner.H)
         torch.cuda.synchronize()
-        # Same samples, but a rank's stripes are a small launch and may be rendered in depth segments (re-associated sums,
-        # other restart points of the feature rotation): compare within the image tolerance of the parity tests, depth
-        # (NaN where alpha == 0) only on pixels that are not within rounding of empty.
-        solid = (full[0, 3] > 1e-4) | (gathered[0, 3] > 1e-4)
-        frame_check = bool(
-            float((full[0, :7] - gathered[0, :7]).abs().max()) < 3e-3
-            and torch.equal(torch.isnan(full[0, 7])[solid], torch.isnan(gathered[0, 7])[solid])
-            and float((torch.nan_to_num(full[0, 7], nan=0.0) - torch.nan_to_num(gathered[0, 7], nan=0.0))[solid].abs().max()) < 3e-2)
+        from fvsrn_amd import tiles
+        frame_check = tiles.frames_match(full, gathered)
         ok = torch.tensor([1 if frame_check else 0], device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         frame_check = bool(ok.item())
@@ -446,6 +364,16 @@ def main():
         twin = {"activation": other, "value": ev2 / dt2, "unit": "samples/s", "ms_per_step": 1e3 * dt2 / args.steps, "steps": args.steps,
                 "kernel": net2.kernel_name(True),
                 "mfma_frac": (ev2 * info.flops_per_sample / (sum(k2) * 1e-3)) / (MFMA_F16_PEAK_TFLOPS * 1e12)}
+
+    exact = None
+    if not args.no_twin and not distributed:
+        # the same frames with exact Fourier features at every step (FVSRN_OPT_FOURIER_RESYNC = 1: the reference's per-sample
+        # arithmetic, positions rounded to fp16 at every sample, no feature rotation)
+        r3 = Runner(capi, net, cfg, rank, world, args.early_out, time_keys, scene_options={"fourier_resync": 1})
+        dt3, k3, ev3, ex3 = timed_run(r3, args.steps, args.warmup, False)
+        exact = {"option": "FVSRN_OPT_FOURIER_RESYNC=1", "activation": args.activation, "value": ev3 / dt3, "unit": "samples/s",
+                 "ms_per_step": 1e3 * dt3 / args.steps, "steps": args.steps,
+                 "mfma_frac": (ev3 * info.flops_per_sample / (sum(k3) * 1e-3)) / (MFMA_F16_PEAK_TFLOPS * 1e12)}
 
     if rank == 0:
         _, _, _, W, H, steps = cfg
@@ -478,6 +406,8 @@ def main():
             out["gathered_frame_matches_single_gpu_frame"] = frame_check
         if twin:
             out["twin"] = twin
+        if exact:
+            out["exact_features"] = exact
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args.activation)
         print(json.dumps(out))

@@ -54,17 +54,18 @@ class SceneDesc(C.Structure):
                 ("brdf_magnitude_scaling", C.c_float), ("brdf_ambient", C.c_float), ("brdf_specular", C.c_float),
                 ("brdf_magnitude_center", C.c_float), ("brdf_magnitude_radius", C.c_float),
                 ("brdf_specular_exponent", C.c_int), ("brdf_light_type", C.c_int), ("brdf_light", C.c_float * 3),
-                ("tf_preintegration", C.c_int), ("adjoint_grid_stepsize", C.c_float)]
+                ("tf_preintegration", C.c_int), ("adjoint_grid_stepsize", C.c_float), ("tf_gaussian_mode", C.c_int)]
 
 
 # fvsrn_option (include/fvsrn.h): tuning / developer switches of a handle
 OPTIONS = {"small_kernel": 0, "persistent": 1, "depth_segments": 2, "fourier_resync": 3, "unit_quota": 4, "tile_order": 5,
-           "waves_per_block": 6, "max_blocks_per_cu": 7, "relu_clamp": 8, "keyframe_slots": 9}
+           "waves_per_block": 6, "max_blocks_per_cu": 7, "relu_clamp": 8, "keyframe_slots": 9, "working_grids": 10}
 ERR_WRONG_DEVICE = -8
 
 GRADIENT_OFF_OR_DIRECT, GRADIENT_FINITE_DIFFERENCES, GRADIENT_ADJOINT_METHOD = 0, 1, 2
 LIGHT_POINT, LIGHT_DIRECTIONAL = 0, 1
 PREINTEGRATE_NONE, PREINTEGRATE_1D, PREINTEGRATE_2D = 0, 1, 2
+TF_GAUSSIAN_PLAIN, TF_GAUSSIAN_SCALE_WITH_GRADIENT, TF_GAUSSIAN_ANALYTIC = 0, 1, 2
 
 
 # every symbol include/fvsrn.h declares: (name, restype, argtypes)
@@ -352,7 +353,7 @@ class Scene:
     def _desc(self, *, eye, right, up, fov_y_radians, stepsize, density_min=0.0, density_max=1.0, early_out=True,
               blend_mode=BLEND_BEER_LAMBERT, tf_kind=TF_IDENTITY, tf_scale_absorption=1.0, tf_scale_emission=1.0,
               tf_table=None, gradient_mode=GRADIENT_OFF_OR_DIRECT, finite_differences_stepsize=0.0, brdf=None,
-              tf_preintegration=PREINTEGRATE_NONE, adjoint_grid_stepsize=0.0) -> SceneDesc:
+              tf_preintegration=PREINTEGRATE_NONE, adjoint_grid_stepsize=0.0, tf_gaussian_mode=TF_GAUSSIAN_PLAIN) -> SceneDesc:
         d = SceneDesc()
         d.cam_eye[:] = [float(v) for v in eye]
         d.cam_right[:] = [float(v) for v in right]
@@ -377,6 +378,7 @@ class Scene:
         d.finite_differences_stepsize = finite_differences_stepsize
         d.tf_preintegration = tf_preintegration
         d.adjoint_grid_stepsize = adjoint_grid_stepsize
+        d.tf_gaussian_mode = tf_gaussian_mode
         if brdf:  # BRDFLambert: dict(enable_phong=, enable_magnitude_scaling=, magnitude_scaling=, ambient=, specular=,
             #                     magnitude_center=, magnitude_radius=, specular_exponent=, light_type=, light=(x,y,z))
             d.brdf_enable_phong = int(brdf.get("enable_phong", False))

@@ -29,7 +29,7 @@ struct Options {
     Options() {
         v[FVSRN_OPT_SMALL_KERNEL] = -1; v[FVSRN_OPT_PERSISTENT] = -1; v[FVSRN_OPT_DEPTH_SEGMENTS] = 0; v[FVSRN_OPT_FOURIER_RESYNC] = 0;
         v[FVSRN_OPT_UNIT_QUOTA] = -1; v[FVSRN_OPT_TILE_ORDER] = -1; v[FVSRN_OPT_WAVES_PER_BLOCK] = 0; v[FVSRN_OPT_MAX_BLOCKS_PER_CU] = 0;
-        v[FVSRN_OPT_RELU_CLAMP] = 1; v[FVSRN_OPT_KEYFRAME_SLOTS] = 0;
+        v[FVSRN_OPT_RELU_CLAMP] = 1; v[FVSRN_OPT_KEYFRAME_SLOTS] = 0; v[FVSRN_OPT_WORKING_GRIDS] = 0;
     }
     int operator[](int i) const { return v[i]; }
     // empty string = valid
@@ -45,6 +45,7 @@ struct Options {
             case FVSRN_OPT_MAX_BLOCKS_PER_CU: return value >= 0 && value <= 32 ? "" : "workgroups per CU must be 0 (no limit) .. 32";
             case FVSRN_OPT_RELU_CLAMP: return value == 0 || value == 1 ? "" : "value must be 0 or 1";
             case FVSRN_OPT_KEYFRAME_SLOTS: return value == 0 || (value >= 2 && value <= 65536) ? "" : "key-frame slots must be 0 (all resident) or >= 2";
+            case FVSRN_OPT_WORKING_GRIDS: return value >= 0 && value <= 2 ? "" : "working grids must be 0 (automatic), 1 or 2";
             default: return "unknown option";
         }
     }
@@ -57,7 +58,7 @@ static const Options& defaultOptions() {
             {"FVSRN_SMALL_KERNEL", FVSRN_OPT_SMALL_KERNEL}, {"FVSRN_PERSISTENT", FVSRN_OPT_PERSISTENT}, {"FVSRN_SEGMENTS", FVSRN_OPT_DEPTH_SEGMENTS},
             {"FVSRN_FOURIER_RESYNC", FVSRN_OPT_FOURIER_RESYNC}, {"FVSRN_UNIT_QUOTA", FVSRN_OPT_UNIT_QUOTA}, {"FVSRN_TILE_ORDER", FVSRN_OPT_TILE_ORDER},
             {"FVSRN_WAVES_PER_BLOCK", FVSRN_OPT_WAVES_PER_BLOCK}, {"FVSRN_MAX_BLOCKS_PER_CU", FVSRN_OPT_MAX_BLOCKS_PER_CU},
-            {"FVSRN_KEYFRAME_SLOTS", FVSRN_OPT_KEYFRAME_SLOTS}};
+            {"FVSRN_KEYFRAME_SLOTS", FVSRN_OPT_KEYFRAME_SLOTS}, {"FVSRN_WORKING_GRIDS", FVSRN_OPT_WORKING_GRIDS}};
         for (const auto& e : kEnv)
             if (const char* t = std::getenv(e.name)) {
                 const int val = std::atoi(t);
@@ -139,6 +140,54 @@ struct DeviceBuffer {
     }
 };
 
+// Cross-stream ordering of one device resource that is written rarely and read by kernels on any stream (a working grid, a
+// key-frame slot, the weight images): the writer records an event, every reader on ANOTHER stream waits for it; every reader
+// records an event of its own stream, and the next writer waits for all of them.  One event per (resource, stream): a reader
+// on a second stream does not overwrite the first stream's mark.  Waiting on an event that has completed costs a
+// microsecond of host time and nothing on the device.
+struct StreamOrder {
+    struct Reader { hipStream_t stream; hipEvent_t done; bool pending; };
+    std::vector<Reader> readers;
+    hipEvent_t written = nullptr;
+    hipStream_t writer = nullptr;
+    bool haveWrite = false;
+    void beginWrite(hipStream_t s) {
+        for (Reader& r : readers)
+            if (r.pending && r.stream != s) HIP_CHECK(hipStreamWaitEvent(s, r.done, 0));
+        if (haveWrite && writer != s) HIP_CHECK(hipStreamWaitEvent(s, written, 0));
+    }
+    void endWrite(hipStream_t s) {
+        if (!written) HIP_CHECK(hipEventCreateWithFlags(&written, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(written, s));
+        writer = s;
+        haveWrite = true;
+        // readers of the old content on the writer's own stream are ordered by the stream; the others were waited for
+        for (Reader& r : readers) r.pending = false;
+    }
+    void beginRead(hipStream_t s) {
+        if (haveWrite && writer != s) HIP_CHECK(hipStreamWaitEvent(s, written, 0));
+    }
+    void endRead(hipStream_t s) {
+        for (Reader& r : readers)
+            if (r.stream == s) {
+                HIP_CHECK(hipEventRecord(r.done, s));
+                r.pending = true;
+                return;
+            }
+        Reader r{s, nullptr, true};
+        HIP_CHECK(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(r.done, s));
+        readers.push_back(r);
+    }
+    void release() {
+        for (Reader& r : readers) (void)hipEventDestroy(r.done);
+        readers.clear();
+        if (written) (void)hipEventDestroy(written);
+        written = nullptr;
+        haveWrite = false;
+    }
+};
+
 struct WrongDevice : WrongDeviceBase { using WrongDeviceBase::WrongDeviceBase; };
 // A handle's device state lives on the device that was current at its first use; every later call must run there.
 void bindOrCheckDevice(int& bound, const char* what) {
@@ -165,9 +214,9 @@ int actIndex(fvsrn_activation a) {
 // Time key frames of a latent grid on the device (BASELINE.json configs[4]; reference: LatentGrid textures uploaded lazily by a
 // synchronous cudaMemcpy3D at first use and kept forever, volume_interpolation_network.cpp:482-488,524-535,1308-1315).
 // Here every key frame sits in PINNED host memory in device layout and `slots` of them are resident in HBM (all of them by
-// default, FVSRN_OPT_KEYFRAME_SLOTS bounds it; >= 2).  Uploads run on a copy stream of the store: a slot is overwritten once the
-// last blend kernel that read it is done (event), the blend of a frame waits for the uploads it needs (event) -- and for nothing
-// else, so the copy of frame i+1's key frame overlaps the render of frame i (the render kernel reads the blended working grid,
+// default, FVSRN_OPT_KEYFRAME_SLOTS bounds it; >= 2).  Uploads run on a copy stream of the store: a slot is overwritten once every
+// blend kernel that read it is done (one event per slot and reading stream, StreamOrder), the blend of a frame waits for the
+// uploads it needs (event) -- and for nothing else, so the copy of frame i+1's key frame overlaps the render of frame i (the render kernel reads the blended working grid,
 // not the key frames).  With >= 3 slots the key frame the time is moving towards is prefetched one interval ahead.
 struct KeyframeStore {
     char* pinned = nullptr;      // [numKeys][bytesPerKey]
@@ -176,8 +225,7 @@ struct KeyframeStore {
     DeviceBuffer dSlots;         // [slots][bytesPerKey]
     std::vector<int> keyOfSlot, slotOfKey;
     std::vector<unsigned long long> lastUse;
-    std::vector<hipEvent_t> readDone, uploadDone;
-    std::vector<char> readRecorded;
+    std::vector<StreamOrder> order;  // per slot: upload (copy stream) <-> blend kernels (any stream)
     hipStream_t copyStream = nullptr;
     unsigned long long tick = 0;
     float lastTime = -1.f;
@@ -185,9 +233,8 @@ struct KeyframeStore {
 
     bool active() const { return numKeys > 0; }
     void release() {
-        for (hipEvent_t e : readDone) (void)hipEventDestroy(e);
-        for (hipEvent_t e : uploadDone) (void)hipEventDestroy(e);
-        readDone.clear(); uploadDone.clear();
+        for (StreamOrder& o : order) o.release();
+        order.clear();
         if (copyStream) { (void)hipStreamSynchronize(copyStream); (void)hipStreamDestroy(copyStream); copyStream = nullptr; }
         if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; }
         dSlots.release();
@@ -207,13 +254,7 @@ struct KeyframeStore {
         keyOfSlot.assign(size_t(slots), -1);
         slotOfKey.assign(size_t(keys), -1);
         lastUse.assign(size_t(slots), 0);
-        readRecorded.assign(size_t(slots), 0);
-        readDone.resize(size_t(slots));
-        uploadDone.resize(size_t(slots));
-        for (int i = 0; i < slots; ++i) {
-            HIP_CHECK(hipEventCreateWithFlags(&readDone[size_t(i)], hipEventDisableTiming));
-            HIP_CHECK(hipEventCreateWithFlags(&uploadDone[size_t(i)], hipEventDisableTiming));
-        }
+        order.assign(size_t(slots), StreamOrder{});
         tick = 0;
         lastTime = -1.f;
         if (slots == keys)  // everything resident: upload now, asynchronously, the first blend waits for what it needs
@@ -221,9 +262,9 @@ struct KeyframeStore {
     }
     const char* slotPtr(int slot) const { return static_cast<const char*>(dSlots.ptr) + size_t(slot) * bytesPerKey; }
     void upload(int key, int slot, bool prefetch) {
-        if (readRecorded[size_t(slot)]) HIP_CHECK(hipStreamWaitEvent(copyStream, readDone[size_t(slot)], 0));  // last reader of the old content
+        order[size_t(slot)].beginWrite(copyStream);  // every blend kernel that read the old content, on whatever stream
         HIP_CHECK(hipMemcpyAsync(const_cast<char*>(slotPtr(slot)), pinned + size_t(key) * bytesPerKey, bytesPerKey, hipMemcpyHostToDevice, copyStream));
-        HIP_CHECK(hipEventRecord(uploadDone[size_t(slot)], copyStream));
+        order[size_t(slot)].endWrite(copyStream);
         if (keyOfSlot[size_t(slot)] >= 0) slotOfKey[size_t(keyOfSlot[size_t(slot)])] = -1;
         keyOfSlot[size_t(slot)] = key;
         slotOfKey[size_t(key)] = slot;
@@ -248,7 +289,7 @@ struct KeyframeStore {
             if (slotOfKey[size_t(key)] < 0) upload(key, victim(lo, hi), false);
             const int s = slotOfKey[size_t(key)];
             lastUse[size_t(s)] = tick;
-            HIP_CHECK(hipStreamWaitEvent(stream, uploadDone[size_t(s)], 0));
+            order[size_t(s)].beginRead(stream);
         }
         *pLo = slotPtr(slotOfKey[size_t(lo)]);
         *pHi = slotPtr(slotOfKey[size_t(hi)]);
@@ -265,9 +306,8 @@ struct KeyframeStore {
     // call after the blend kernel has been enqueued on `stream`
     void released(int lo, int hi, hipStream_t stream) {
         for (int key : {lo, hi}) {
-            const int s = slotOfKey[size_t(key)];
-            HIP_CHECK(hipEventRecord(readDone[size_t(s)], stream));
-            readRecorded[size_t(s)] = 1;
+            order[size_t(slotOfKey[size_t(key)])].endRead(stream);
+            if (hi == lo) break;
         }
     }
 };
@@ -277,7 +317,15 @@ struct fvsrn_network {
     // device image (lazy; invalidated by any mutation)
     bool deviceValid = false;
     PackedNetwork packed;
-    DeviceBuffer dLds, dLdsScaled, dLdsCurvature, dEvalTmp, dGrid, dGridB, dKeysEns, dCoeffs;
+    DeviceBuffer dLds, dLdsScaled, dLdsCurvature, dKeysEns, dCoeffs;
+    // Working grids: the fp16 x-pair records the kernels read, blended from the key frames when the time / ensemble changes
+    // (grid_blend_kernel).  Two of them for networks with more than one key frame: the blend of frame i + 1 writes the grid that
+    // frame i does NOT read, so a caller may keep two frames in flight on two streams (tiles.StripeRenderer, BASELINE.json
+    // configs[4]); `order` makes a blend wait for every kernel that still reads the grid it overwrites, on whatever stream.
+    struct WorkingGrid { DeviceBuffer a, b; StreamOrder order; };
+    WorkingGrid workGrid[2];
+    int numWorkGrids = 1, curWorkGrid = 0;
+    StreamOrder imagesOrder;  // weight images, ensemble key frames, decode coefficients: written at first use
     KeyframeStore keyStore;  // time key frames
     const void* scaledImage = nullptr;
     const void* curvatureImage = nullptr;
@@ -345,6 +393,7 @@ struct fvsrn_network {
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         numCUs = prop.multiProcessorCount;
+        imagesOrder.beginWrite(stream);  // a changed network: kernels on other streams may still read the old images
         dLds.ensure(packed.ldsImage.size());
         HIP_CHECK(hipMemcpyAsync(dLds.ptr, packed.ldsImage.data(), packed.ldsImage.size(), hipMemcpyHostToDevice, stream));
         packed.params.ldsImage = dLds.ptr;
@@ -373,19 +422,23 @@ struct fvsrn_network {
             for (const auto* v : {&K.timeOffset, &K.timeScale, &K.ensOffset, &K.ensScale}) coeffs.insert(coeffs.end(), v->begin(), v->end());
             dCoeffs.ensure(std::max<size_t>(coeffs.size(), 1) * 4);
             if (!coeffs.empty()) HIP_CHECK(hipMemcpyAsync(dCoeffs.ptr, coeffs.data(), coeffs.size() * 4, hipMemcpyHostToDevice, stream));
-            dGrid.ensure(K.records * size_t(K.Gt + K.Ge) * 2 * 2);
-            packed.params.grid = dGrid.ptr;
-            packed.params.gridB = nullptr;
-            if (K.enc == FVSRN_GRID_BYTE_GAUSSIAN) {
-                dGridB.ensure(K.records * size_t(K.Gt + K.Ge) * 2 * 2);
-                packed.params.gridB = dGridB.ptr;
+            const int wantGrids = opts[FVSRN_OPT_WORKING_GRIDS] ? opts[FVSRN_OPT_WORKING_GRIDS] : (K.timeNum > 1 || K.ensNum > 1 ? 2 : 1);
+            numWorkGrids = wantGrids;
+            curWorkGrid = 0;
+            for (int i = 0; i < 2; ++i) {
+                if (i >= numWorkGrids) { workGrid[i].a.release(); workGrid[i].b.release(); continue; }
+                workGrid[i].a.ensure(K.records * size_t(K.Gt + K.Ge) * 2 * 2);
+                if (K.enc == FVSRN_GRID_BYTE_GAUSSIAN) workGrid[i].b.ensure(K.records * size_t(K.Gt + K.Ge) * 2 * 2);
             }
+            packed.params.grid = workGrid[0].a.ptr;
+            packed.params.gridB = K.enc == FVSRN_GRID_BYTE_GAUSSIAN ? workGrid[0].b.ptr : nullptr;
             packed.params.gridEncoding = int(K.enc);
             packed.params.gridTimeChannels = K.Gt;
         } else {
             packed.params.grid = nullptr;
         }
         timeDirty = true;
+        imagesOrder.endWrite(stream);  // launches on other streams wait for the uploads above (beginUse)
         // the staging vectors are pageable: the copies above complete before hipMemcpyAsync returns
         const size_t maxLds = packed.ldsImage.size() + 4096 + 256 * 6 * 4;
         HIP_CHECK(hipFuncSetAttribute(kinfo.evalFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
@@ -405,13 +458,21 @@ struct fvsrn_network {
             const GridSelection g = selectGrid(*net);
             BlendParams b{};
             b.ensData = dKeysEns.ptr;
+            imagesOrder.beginRead(stream);  // ensemble key frames + coefficients
+            const int next = numWorkGrids > 1 ? (curWorkGrid + 1) % numWorkGrids : 0;
+            WorkingGrid& W = workGrid[next];
+            W.order.beginWrite(stream);  // every kernel that still reads this grid, on whatever stream
             if (keyStore.active()) keyStore.acquire(g.lo, g.hi, g.timeIndex, stream, &b.timeLo, &b.timeHi);
             const float* c = static_cast<const float*>(dCoeffs.ptr);
             b.timeOffset = c; b.timeScale = c + K.timeOffset.size();
             b.ensOffset = c + 2 * K.timeOffset.size(); b.ensScale = b.ensOffset + K.ensOffset.size();
-            b.out = dGrid.ptr; b.outB = dGridB.ptr; b.records = K.records; b.enc = int(K.enc); b.Gt = K.Gt; b.Ge = K.Ge;
+            b.out = W.a.ptr; b.outB = W.b.ptr; b.records = K.records; b.enc = int(K.enc); b.Gt = K.Gt; b.Ge = K.Ge;
             b.lo = g.lo; b.hi = g.hi; b.ens = g.ens; b.frac = g.frac;
             HIP_CHECK(launch_grid_blend(b, stream));
+            W.order.endWrite(stream);
+            curWorkGrid = next;
+            packed.params.grid = W.a.ptr;
+            packed.params.gridB = K.enc == FVSRN_GRID_BYTE_GAUSSIAN ? W.b.ptr : nullptr;
             if (keyStore.active()) keyStore.released(g.lo, g.hi, stream);
             // decode coefficients of the selected key frames (BYTE_GAUSSIAN decodes inside the render kernel)
             packed.params.gridFrac = g.frac;
@@ -419,26 +480,37 @@ struct fvsrn_network {
             packed.params.gridStdTime = b.timeScale + size_t(g.lo) * K.Gt;
             packed.params.gridMeanEns = b.ensOffset + size_t(g.ens) * K.Ge;
             packed.params.gridStdEns = b.ensScale + size_t(g.ens) * K.Ge;
-            if (packed.timeSlotOffset >= 0) {
-                timeSlotStaging = float_to_half_bits(g.timeIndex);
-                HIP_CHECK(hipMemcpyAsync(static_cast<char*>(dLds.ptr) + packed.timeSlotOffset, &timeSlotStaging, 2, hipMemcpyHostToDevice, stream));
-                if (scaledImage)
-                    HIP_CHECK(hipMemcpyAsync(static_cast<char*>(dLdsScaled.ptr) + packed.timeSlotOffset, &timeSlotStaging, 2, hipMemcpyHostToDevice, stream));
-            }
+            // Networks that take the time as an input: the fp16 time entry of the phase fragment is a KERNEL ARGUMENT (every
+            // kernel patches its LDS copy of the image, load_network_to_lds) -- no write to the shared device images, so frames
+            // at different times can be in flight at once and every image (plain, scaled, curvature) sees the same time.
+            packed.params.timeSlotOffset = packed.timeSlotOffset;
+            packed.params.timeSlotBits = packed.timeSlotOffset >= 0 ? float_to_half_bits(g.timeIndex) : 0;
         }
         timeDirty = false;
     }
-    uint16_t timeSlotStaging = 0;
 
-    ~fvsrn_network() {
+    // Brackets of every kernel launch that reads the network's device state on `stream`
+    void beginUse(hipStream_t stream) {
+        imagesOrder.beginRead(stream);
+        if (packed.keys.records) workGrid[curWorkGrid].order.beginRead(stream);
+    }
+    void endUse(hipStream_t stream) {
+        imagesOrder.endRead(stream);
+        if (packed.keys.records) workGrid[curWorkGrid].order.endRead(stream);
+    }
+
+    void releaseDevice() {
         dLds.release();
         dLdsScaled.release();
-        dGrid.release();
-        dGridB.release();
+        dLdsCurvature.release();
+        for (WorkingGrid& w : workGrid) { w.a.release(); w.b.release(); w.order.release(); }
+        imagesOrder.release();
         keyStore.release();
         dKeysEns.release();
         dCoeffs.release();
+        scaledImage = curvatureImage = nullptr;
     }
+    ~fvsrn_network() { releaseDevice(); }
 };
 
 struct BoxCenter { float c[3]; };
@@ -450,6 +522,7 @@ struct fvsrn_scene {
     fvsrn_scene_desc desc{};
     std::vector<float> tfTable;
     DeviceBuffer dTf, dOrder, dCounters, dPartial, dPreint;
+    bool tfOpacityNonNegative = true;  // Texture TF: no negative opacity in the table (fvsrn_scene_update)
     int preintMode = 0;          // what dPreint holds
     float preintStepsize = -1.f;
     unsigned launches = 0;  // parity selects which of the two tile counters a launch uses (the kernel zeroes the other)
@@ -715,13 +788,7 @@ int fvsrn_network_clear_gpu_resources(fvsrn_network* net) {
         if (!net) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null network");
         std::lock_guard<std::mutex> lock(net->mu);
         net->invalidate();
-        net->dLds.release();
-        net->dLdsScaled.release();
-        net->dGrid.release();
-        net->dGridB.release();
-        net->keyStore.release();
-        net->dKeysEns.release();
-        net->dCoeffs.release();
+        net->releaseDevice();
         return FVSRN_OK;
     });
 }
@@ -821,10 +888,10 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
             const bool scalarNet = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
             const bool colourNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
             const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && P.gridK == 1 ? 1 : 2);
-            if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !P.noFourier && !P.fourierNeedsFract && (scalarNet || colourNet) &&
+            if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !P.noFourier && !P.fourierNeedsFractPlain && (scalarNet || colourNet) &&
                 render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1, smallGrid))
                 name = "render_small_kernel<act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "," + std::to_string(P.numLayers) +
-                       "> (unshaded; else " + name + ")";
+                       ",SGRID=" + std::to_string(smallGrid) + "> (unshaded; else " + name + ")";
         }
         std::strncpy(buf, name.c_str(), cap - 1);
         buf[cap - 1] = 0;
@@ -848,7 +915,7 @@ int fvsrn_network_set_option(fvsrn_network* net, int option, int value) {
         const int old = option >= 0 && option < FVSRN_OPT_COUNT_ ? net->opts[option] : 0;
         const int rc = setOption(net->opts, option, value);
         // the weight image / the key-frame residency are part of the device state
-        if (rc == FVSRN_OK && (option == FVSRN_OPT_RELU_CLAMP || option == FVSRN_OPT_KEYFRAME_SLOTS) && old != value) net->invalidate();
+        if (rc == FVSRN_OK && (option == FVSRN_OPT_RELU_CLAMP || option == FVSRN_OPT_KEYFRAME_SLOTS || option == FVSRN_OPT_WORKING_GRIDS) && old != value) net->invalidate();
         return rc;
     });
 }
@@ -895,9 +962,13 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
             net->ensureDevice(s);
             net->syncTime(s);
             if (n == 0) return FVSRN_OK;
+            net->beginUse(s);
+            struct Done { fvsrn_network* n; hipStream_t s; ~Done() { try { n->endUse(s); } catch (...) {} } } done{net, s};
             if (net->key.dir && !d_directions)
                 return fail(FVSRN_ERR_INVALID_ARGUMENT, "the network uses the view direction, but no directions were given");
             EvalArgs a{net->packed.params, d_positions, d_directions, n, d_out, net->net->outputChannels()};
+            void* evalTmp = nullptr;
+            struct FreeTmp { void*& p; hipStream_t s; ~FreeTmp() { if (p) (void)hipFreeAsync(p, s); } } freeTmp{evalTmp, s};
             const bool curvature = (flags & FVSRN_EVAL_WITH_PREDICTED_CURVATURE) != 0;
             if (curvature) {
                 // evalCurvature (renderer_volume_tensorcores.cuh:1541-1556): only networks that estimate it, GRADIENT_MODE_OFF_OR_DIRECT
@@ -906,8 +977,9 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
                     return fail(FVSRN_ERR_INVALID_ARGUMENT, "curvature is only available from networks that predict it (output mode densitycurvature*)");
                 // two passes over the points -- value + predicted gradient, then the same layers with the last one computing the two
                 // curvature outputs -- into a temporary (n,4) + (n,4), combined into d_out (n,6) by two strided copies
-                net->dEvalTmp.ensure(n * 8 * sizeof(float));
-                a.out = static_cast<float*>(net->dEvalTmp.ptr);
+                // (allocated and freed in stream order, per call: two calls on different streams share nothing)
+                HIP_CHECK(hipMallocAsync(&evalTmp, n * 8 * sizeof(float), s));
+                a.out = static_cast<float*>(evalTmp);
                 a.outChannels = 4;
             } else if (flags & FVSRN_EVAL_WITH_PREDICTED_GRADIENT) {
                 const int om = a.P.outputMode;
@@ -1000,6 +1072,10 @@ static int sceneValidate(const fvsrn_scene_desc* d) {
         return fail(FVSRN_ERR_INVALID_ARGUMENT, "pre-integration is a mode of the Texture transfer function");
     if (d->blend_mode != FVSRN_BLEND_ALPHA && d->blend_mode != FVSRN_BLEND_BEER_LAMBERT)
         return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad blend mode");
+    if (d->tf_gaussian_mode < FVSRN_TF_GAUSSIAN_PLAIN || d->tf_gaussian_mode > FVSRN_TF_GAUSSIAN_ANALYTIC)
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad tf_gaussian_mode");
+    if (d->tf_gaussian_mode != FVSRN_TF_GAUSSIAN_PLAIN && d->tf_kind != FVSRN_TF_GAUSSIAN)
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "tf_gaussian_mode is a mode of the Gaussian transfer function");
     return FVSRN_OK;
 }
 
@@ -1012,6 +1088,10 @@ int fvsrn_scene_update(fvsrn_scene* scene, const fvsrn_scene_desc* desc) {
         std::vector<float> table(desc->tf_table ? desc->tf_table : nullptr, desc->tf_table ? desc->tf_table + n : nullptr);
         if (table != scene->tfTable) scene->tfDirty = true;
         scene->tfTable = std::move(table);
+        scene->tfOpacityNonNegative = true;
+        if (desc->tf_kind == FVSRN_TF_TEXTURE)
+            for (size_t i = 3; i < scene->tfTable.size(); i += 4)
+                if (!(scene->tfTable[i] >= 0.f)) scene->tfOpacityNonNegative = false;
         scene->desc = *desc;
         scene->desc.tf_table = nullptr;
         return FVSRN_OK;
@@ -1107,6 +1187,8 @@ static void fillSceneParams(fvsrn_scene* scene, const fvsrn_scene_desc& d, int w
     S.densityBias = -d.density_min * S.divDensityRange;
     S.stepLog2e = float(-double(d.stepsize) * 1.4426950408889634);
     S.tfTable = static_cast<const float*>(scene->dTf.ptr);
+    S.tfOpacityNonNegative = scene->tfOpacityNonNegative ? 1 : 0;
+    S.tfGaussianMode = d.tf_gaussian_mode;
     S.tfPreintegration = d.tf_preintegration;
     S.tfPreintegrated = static_cast<const float*>(scene->dPreint.ptr);
 }
@@ -1133,13 +1215,16 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             if (!rgbo && d.tf_kind == FVSRN_TF_NONE)
                 return fail(FVSRN_ERR_INVALID_ARGUMENT, "the network outputs densities; the scene needs a transfer function");
             if (numLocalRows == 0) return FVSRN_OK;
+            net->beginUse(s);
+            struct Done { fvsrn_network* n; hipStream_t s; ~Done() { try { n->endUse(s); } catch (...) {} } } done{net, s};
 
             const size_t tfFloats = scene->tfTable.size();
             if (const int rc = scene->uploadTf(d.stepsize, s)) return rc;
             RenderArgs a{};
             a.P = net->packed.params;
             a.shaded = d.gradient_mode != FVSRN_GRADIENT_OFF_OR_DIRECT || d.brdf_enable_phong || d.brdf_enable_magnitude_scaling ||
-                       d.tf_preintegration != FVSRN_PREINTEGRATE_NONE;
+                       d.tf_preintegration != FVSRN_PREINTEGRATE_NONE || d.tf_gaussian_mode != FVSRN_TF_GAUSSIAN_PLAIN;  // (the Gaussian variants
+                       // read the gradient / the previous sample's density: the shaded kernel tracks both)
             // finite differences also sample up to a step outside the box, where the [0,1] bound of the scaled image does
             // not hold: the shaded renderer takes the plain image
             if (!a.shaded) a.P.fourierNeedsFract = a.P.fourierNeedsFractPlain;  // positions inside the box only (pack.cpp)
@@ -1168,7 +1253,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             // three C->C layers, phases inside the v_cos domain, a transfer function, no shading.  FVSRN_SMALL_KERNEL=0: off.
             const void* smallFn = nullptr;
             int smallGrid = 0;
-            const int smallTail = rgbo ? 3 : (d.tf_kind == FVSRN_TF_PIECEWISE || d.tf_kind == FVSRN_TF_GAUSSIAN ? 2 : (d.blend_mode != FVSRN_BLEND_BEER_LAMBERT ? 1 : (d.tf_kind == FVSRN_TF_IDENTITY && d.tf_scale_absorption >= 0.f ? FVSRN_IDENTITY_TAIL : (d.tf_kind == FVSRN_TF_TEXTURE ? 5 : 1))));  // kernels.hpp TAIL_*
+            const int smallTail = rgbo ? 3 : (d.tf_kind == FVSRN_TF_PIECEWISE || d.tf_kind == FVSRN_TF_GAUSSIAN ? 2 : (d.blend_mode != FVSRN_BLEND_BEER_LAMBERT ? 1 : (d.tf_kind == FVSRN_TF_IDENTITY && d.tf_scale_absorption >= 0.f ? FVSRN_IDENTITY_TAIL : (d.tf_kind == FVSRN_TF_TEXTURE && scene->tfOpacityNonNegative ? 5 : 1))));  // kernels.hpp TAIL_*
             {
                 const VariantKey& k = net->keyScaled;
                 const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
@@ -1189,8 +1274,9 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 const float* bs = a.P.boxSize;
                 const double maxSteps = std::sqrt(double(bs[0]) * bs[0] + double(bs[1]) * bs[1] + double(bs[2]) * bs[2]) / d.stepsize;
                 // (a pre-integrated TF looks at the previous sample of the ray: no cuts)
-                while (d.tf_preintegration == FVSRN_PREINTEGRATE_NONE && K < 8 && double(tiles) * K < 4.0 * waves && maxSteps / (2 * K) >= 48.0) K *= 2;
-                if (O[FVSRN_OPT_DEPTH_SEGMENTS] >= 1 && d.tf_preintegration == FVSRN_PREINTEGRATE_NONE) K = O[FVSRN_OPT_DEPTH_SEGMENTS];
+                const bool looksBack = d.tf_preintegration != FVSRN_PREINTEGRATE_NONE || d.tf_gaussian_mode == FVSRN_TF_GAUSSIAN_ANALYTIC;
+                while (!looksBack && K < 8 && double(tiles) * K < 4.0 * waves && maxSteps / (2 * K) >= 48.0) K *= 2;
+                if (O[FVSRN_OPT_DEPTH_SEGMENTS] >= 1 && !looksBack) K = O[FVSRN_OPT_DEPTH_SEGMENTS];
             }
             // FVSRN_OPT_FOURIER_RESYNC: 1 = exact Fourier features at every step (the reference's arithmetic), default every 64 steps
             S.resyncMask = (O[FVSRN_OPT_FOURIER_RESYNC] ? O[FVSRN_OPT_FOURIER_RESYNC] : kFourierResync) - 1;
@@ -1336,6 +1422,7 @@ int fvsrn_scene_evaluate_tf(fvsrn_scene* scene, const float* d_density, const fl
         S.tfTable = static_cast<const float*>(scene->dTf.ptr);
         S.tfPreintegration = d.tf_preintegration;
         S.tfPreintegrated = static_cast<const float*>(scene->dPreint.ptr);
+        S.tfGaussianMode = d.tf_gaussian_mode;
         const hipError_t e = launch_evaluate_tf(S, d_density, d_previous_density, n, d_colors, s);
         if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("evaluate_tf failed: ") + hipGetErrorString(e));
         return FVSRN_OK;
@@ -1567,7 +1654,8 @@ int fvsrn_render_volume(fvsrn_scene* scene, fvsrn_volume* volume, int source, in
             const fvsrn_scene_desc& d = scene->desc;
             if (d.tf_kind == FVSRN_TF_NONE) return fail(FVSRN_ERR_INVALID_ARGUMENT, "a grid volume holds densities; the scene needs a transfer function");
             // (fvsrn_scene_desc::gradient_mode configures network volumes; a grid always differentiates by central differences)
-            const int normals = provide_normals || d.brdf_enable_phong || d.brdf_enable_magnitude_scaling;  // brdf.cpp:40,279
+            const int normals = provide_normals || d.brdf_enable_phong || d.brdf_enable_magnitude_scaling ||  // brdf.cpp:40,279
+                                d.tf_gaussian_mode == FVSRN_TF_GAUSSIAN_SCALE_WITH_GRADIENT;                 // transfer_function_gaussian.cpp:271-272
             volume->ensureDevice(s);
             const size_t tfFloats = scene->tfTable.size();
             if (const int rc = scene->uploadTf(d.stepsize, s)) return rc;
@@ -1587,8 +1675,9 @@ int fvsrn_render_volume(fvsrn_scene* scene, fvsrn_volume* volume, int source, in
                 const double waves = double(((width + 15) / 16) * ((height + 15) / 16)) * 4.0, slots = double(numCUs) * 32.0;
                 const float* bs = volume->boxSize;
                 const double maxSteps = std::sqrt(double(bs[0]) * bs[0] + double(bs[1]) * bs[1] + double(bs[2]) * bs[2]) / d.stepsize;
-                while (d.tf_preintegration == FVSRN_PREINTEGRATE_NONE && K < 8 && waves * K < slots / 2 && maxSteps / (2 * K) >= 48.0) K *= 2;  // r01, 256^2: K = 1 / 2 / 4 / 8 -> 0.34 / 0.19 / 0.17 / 0.24 ms
-                if (scene->opts[FVSRN_OPT_DEPTH_SEGMENTS] >= 1 && d.tf_preintegration == FVSRN_PREINTEGRATE_NONE) K = scene->opts[FVSRN_OPT_DEPTH_SEGMENTS];
+                const bool looksBack = d.tf_preintegration != FVSRN_PREINTEGRATE_NONE || d.tf_gaussian_mode == FVSRN_TF_GAUSSIAN_ANALYTIC;
+                while (!looksBack && K < 8 && waves * K < slots / 2 && maxSteps / (2 * K) >= 48.0) K *= 2;  // r01, 256^2: K = 1 / 2 / 4 / 8 -> 0.34 / 0.19 / 0.17 / 0.24 ms
+                if (scene->opts[FVSRN_OPT_DEPTH_SEGMENTS] >= 1 && !looksBack) K = scene->opts[FVSRN_OPT_DEPTH_SEGMENTS];
             }
             S.segments = K;
             const size_t plane = size_t(width) * size_t(height);

@@ -49,6 +49,10 @@ struct NetParams {
     int fourierNeedsFract;      // |phase| may exceed the v_cos_f32 domain of 256 revolutions for positions inside the box
     int fourierNeedsFractEval;  // ... for positions up to 4 box sizes away (evaluate_points takes arbitrary positions)
     int fourierNeedsFractPlain; // ... for positions inside the box only (unshaded renders: fvsrn_render copies it into fourierNeedsFract)
+    int fourierClampPos;    // unshaded renders: the phase range is the whole +-256 revolution domain (a 2^9 ladder); sample positions are
+                            // clamped to the unit box (they leave it by the rounding of o + t d only) instead of a v_fract per phase
+    int timeSlotOffset;     // networks that take the time as an input: byte offset of the fp16 time entry inside the LDS image (-1: none) ...
+    unsigned timeSlotBits;  // ... and its value for this launch: the kernel patches its LDS copy, the device images are never written
     int reluClamp;          // ldsImage is the [0,1]-scaled ReLU image: convert+ReLU is one clamped v_cvt_pk_f16_f32
     float actA, actB;       // activation constants, see act() in srn_device.hpp
     float boxMin[3];
@@ -92,6 +96,8 @@ struct SceneParams {
     float tfAbsorptionStepLog2e, densityBias;  // TAIL_SCALAR_IDENTITY: -tfAbsorptionStep * log2(e); -densityMin * divDensityRange
     float stepLog2e;                           // TAIL_SCALAR_TEXTURE: -stepsize * log2(e)
     const float* tfTable;  // device pointer
+    int tfGaussianMode;        // fvsrn_tf_gaussian_mode (scale sigma with |gradient| / piecewise analytic integration)
+    int tfOpacityNonNegative;  // Texture TF: no table entry has a negative opacity (the straight-line tail leaves out the reference's `opacity > 0` test)
     int tfPreintegration;          // 0 none, 1: tfPreintegrated = [R][4] running integral, 2: [R][R][4] (previous, current density)
     const float* tfPreintegrated;  // device pointer (global memory: 1 MiB in 2D mode), R = tfRows
     // image: the launch covers `numLocalRows` rows; local row l is image row

@@ -75,10 +75,10 @@ __global__ __launch_bounds__(256) void volume_render_kernel(VolumeParams V, Scen
         const float prev = previousDensity;
         previousDensity = density2;  // stepping_dvr.cuh:135
         if (value >= S.densityMin) {  // :110-135
-            float4_t color = SHADE && S.tfPreintegration != FVSRN_PREINTEGRATE_NONE ? tf_eval_preintegrated(S, tfLds, fminf(fmaxf(density2, 0.f), 1.f), prev)
-                                                                                  : tf_eval(S, tfLds, density2);
             float g[3] = {0.f, 0.f, 0.f};
             if (SHADE && V.provideNormals) vol_normal(V, wx, wy, wz, g);  // :122-128 (requireNormal)
+            float4_t color = SHADE && S.tfPreintegration != FVSRN_PREINTEGRATE_NONE ? tf_eval_preintegrated(S, tfLds, fminf(fmaxf(density2, 0.f), 1.f), prev)
+                                                                                  : tf_eval(S, tfLds, density2, sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), prev);
             if (SHADE && color[3] > 0.f && (S.brdfMagnitudeScaling | S.brdfPhong)) {  // BRDFLambert::eval, renderer_brdf_lambert.cuh:56-103
                 const float g2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
                 if (S.brdfMagnitudeScaling) color[3] *= 1.f - __expf(-S.brdfMagScale * g2);
@@ -152,7 +152,8 @@ hipError_t launch_volume_evaluate(const VolumeParams& V, const float* pos, size_
 hipError_t launch_volume_render(const VolumeParams& V, const SceneParams& S, float* out, unsigned long long* stats, size_t tfFloats,
                                 hipStream_t s) {
     const dim3 grid(unsigned(((S.width + 15) / 16) * ((S.height + 15) / 16)), unsigned(std::max(S.segments, 1)));
-    const bool shade = V.provideNormals || S.brdfMagnitudeScaling || S.brdfPhong || S.tfPreintegration != FVSRN_PREINTEGRATE_NONE;
+    const bool shade = V.provideNormals || S.brdfMagnitudeScaling || S.brdfPhong || S.tfPreintegration != FVSRN_PREINTEGRATE_NONE ||
+                       S.tfGaussianMode != FVSRN_TF_GAUSSIAN_PLAIN;
     if (shade) hipLaunchKernelGGL(volume_render_kernel<true>, grid, dim3(256), tfFloats * 4, s, V, S, out, stats);
     else hipLaunchKernelGGL(volume_render_kernel<false>, grid, dim3(256), tfFloats * 4, s, V, S, out, stats);
     return hipGetLastError();

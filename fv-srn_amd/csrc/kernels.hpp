@@ -33,6 +33,10 @@ __device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* ld
     uint4_t* dst = reinterpret_cast<uint4_t*>(lds);
     const int n = P.ldsBytes >> 4;
     for (int i = threadIdx.x; i < n; i += int(blockDim.x)) dst[i] = src[i];
+    if (P.timeSlotOffset >= 0) {  // the time input of this launch (api.cpp, syncTime): the 16-byte chunk that holds it is copied by thread (offset / 16) % blockDim
+        __syncthreads();
+        if (threadIdx.x == 0) *reinterpret_cast<unsigned short*>(lds + P.timeSlotOffset) = static_cast<unsigned short>(P.timeSlotBits);
+    }
     __syncthreads();
 }
 
@@ -251,7 +255,11 @@ __device__ __forceinline__ float4_t tf_eval_preintegrated(const SceneParams& S, 
     return rgba;
 }
 
-__device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* __restrict__ tfLds, float density) {
+// gradLen / previousDensity: only the Gaussian TF variants read them (SceneParams::tfGaussianMode): |gradient| of the sample for
+// TRANSFER_FUNCTION_GAUSSIAN__SCALE_WITH_GRADIENT, the un-clamped mapped density of the previous sample of the ray (-1: none) for
+// TRANSFER_FUNCTION_GAUSSIAN__ANALYTIC (renderer_tf_gaussian.cuh:55-73)
+__device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* __restrict__ tfLds, float density, float gradLen = 0.f,
+                                            float previousDensity = -1.f) {
     density = fminf(fmaxf(density, 0.f), 1.f);
     float4_t c = {0, 0, 0, 0};
     switch (S.tfKind) {
@@ -259,11 +267,21 @@ __device__ __forceinline__ float4_t tf_eval(const SceneParams& S, const float* _
             const float e = density * S.tfScaleEmission;
             c = float4_t{e, e, e, density * S.tfScaleAbsorption * S.stepsize};
         } break;
-        case FVSRN_TF_GAUSSIAN: {  // renderer_tf_gaussian.cuh:43-86 (non-analytic, no gradient scaling)
+        case FVSRN_TF_GAUSSIAN: {  // renderer_tf_gaussian.cuh:43-86
+            // (wave-uniform mode; the plain form keeps the fast exponential it had, the two variants are restated with erff / expf)
+            const float sigmaScale = S.tfGaussianMode == FVSRN_TF_GAUSSIAN_SCALE_WITH_GRADIENT ? fmaxf(1e-5f, gradLen * 0.1f) : 1.f;
+            const bool segment = S.tfGaussianMode == FVSRN_TF_GAUSSIAN_ANALYTIC && !(previousDensity < 0.f || previousDensity == density);
             for (int i = 0; i < S.tfRows; ++i) {
                 const float* r = tfLds + 6 * i;
-                const float t = density - r[4];
-                const float ni = __expf(-t * t / (r[5] * r[5]));
+                const float mu = r[4], sigma = r[5] * sigmaScale;
+                float ni;
+                if (segment) {  // piecewise analytic integration over [previousDensity, density], constant colour per segment
+                    constexpr float kSqrtPi2 = 0.8862269254527580136f;  // sqrt(pi) / 2
+                    ni = kSqrtPi2 / (previousDensity - density) * sigma * (erff((previousDensity - mu) / sigma) + erff((mu - density) / sigma));
+                } else {
+                    const float t = density - mu;
+                    ni = __expf(-t * t / (sigma * sigma));
+                }
                 c[0] += r[0] * ni; c[1] += r[1] * ni; c[2] += r[2] * ni; c[3] += r[3] * ni;
             }
             c[3] *= S.stepsize;
@@ -476,7 +494,12 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
         ++nSteps;
         nValid += unsigned(__builtin_popcountll(validMask));
 
-        const float px = fmaf(dnx, t, pn0x), py = fmaf(dny, t, pn0y), pz = fmaf(dnz, t, pn0z);
+        float px = fmaf(dnx, t, pn0x), py = fmaf(dny, t, pn0y), pz = fmaf(dnz, t, pn0z);
+        if constexpr (!SHADED) {
+            if (P.fourierClampPos) {  // wave-uniform; see device_params.hpp
+                px = __builtin_amdgcn_fmed3f(px, 0.f, 1.f); py = __builtin_amdgcn_fmed3f(py, 0.f, 1.f); pz = __builtin_amdgcn_fmed3f(pz, 0.f, 1.f);
+            }
+        }
         float4_t o;
         if constexpr (kRotate) {
             // Fourier features by rotation (fourier_advance): exact features every kFourierResync steps, the per-step
@@ -633,7 +656,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
                 if (SHADED && S.tfPreintegration != FVSRN_PREINTEGRATE_NONE)
                     color = tf_eval_preintegrated(S, tfLds, fminf(fmaxf(density2, 0.f), 1.f), previousDensity);
                 else
-                    color = tf_eval(S, tfLds, density2);
+                    color = tf_eval(S, tfLds, density2, sqrtf(gx * gx + gy * gy + gz * gz), previousDensity);
             }
             if (SHADED) previousDensity = density2;  // stepping_dvr.cuh:135
         }
@@ -751,7 +774,7 @@ __device__ __forceinline__ void render_entry(const NetParams& P, const ScenePara
         if (scalarNet && !P.fourierNeedsFract && S.blendMode == FVSRN_BLEND_BEER_LAMBERT) {
             if (S.tfKind == FVSRN_TF_IDENTITY && S.tfAbsorptionStepLog2e <= 0.f)
                 return render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_SCALAR_IDENTITY>(P, S, lds, tfLds, out, stats);
-            if (S.tfKind == FVSRN_TF_TEXTURE)
+            if (S.tfKind == FVSRN_TF_TEXTURE && S.tfOpacityNonNegative)  // (a negative opacity: the generic tail skips the sample, stepping_dvr.cuh:137)
                 return render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_SCALAR_TEXTURE>(P, S, lds, tfLds, out, stats);
         }
     }

@@ -273,7 +273,9 @@ __global__ void evaluate_tf_kernel(SceneParams S, const float* __restrict__ dens
                 const float p2 = p >= 0.f ? (p - S.densityMin) * S.divDensityRange : -1.f;
                 c = tf_eval_preintegrated(S, S.tfTable, fminf(fmaxf(d2, 0.f), 1.f), p2);
             } else {
-                c = tf_eval(S, S.tfTable, d2);
+                // (no gradient on this entry: the reference passes a zero normal, renderer_tf_kernels.cuh:30,61)
+                const float p = previous ? previous[i] : -1.f;
+                c = tf_eval(S, S.tfTable, d2, 0.f, p >= 0.f ? (p - S.densityMin) * S.divDensityRange : -1.f);
             }
         }
         colors[4 * i + 0] = c[0]; colors[4 * i + 1] = c[1]; colors[4 * i + 2] = c[2]; colors[4 * i + 3] = c[3];

@@ -257,6 +257,11 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
     // out-of-range results), which at +-(256 + 2e-4) revolutions differ from the true values by 8e-7 and 1.3e-3 -- on the last sample
     // of a ray, in the top octave only.
     np.fourierNeedsFractPlain = maxPhasePlain > 256.0 ? 1 : 0;
+    // ... and so that no phase ever lands in that sliver, a network whose range fills the domain has its sample positions clamped to
+    // the unit box (three v_med3_f32 per step; the positions leave the box by rounding only, so the clamp moves a sample by <= 1e-6)
+    np.fourierClampPos = (!np.fourierNeedsFractPlain && maxPhasePlain > 256.0 - 0.01) ? 1 : 0;
+    np.timeSlotOffset = -1;  // set per launch by the device layer (api.cpp, syncTime)
+    np.timeSlotBits = 0;
     // evaluate_points takes arbitrary positions: stay exact up to 4 box sizes away without the v_fract
     np.fourierNeedsFractEval = (4.0 * maxPhaseUncentred + std::fabs(maxPhase)) >= 255.0 ? 1 : 0;
     // byte offset of the fp16 "time" entry inside the phase fragment (patched on the device when the time changes):

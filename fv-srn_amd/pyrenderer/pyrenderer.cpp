@@ -718,11 +718,15 @@ struct TableTF : ITransferFunction {
 };
 struct TransferFunctionGaussian : TableTF {
     double absorptionScaling = 1.0;            // transfer_function_gaussian.cpp:264 (the tensor rows already carry opacity * scaling)
-    bool piecewiseAnalyticIntegration = false;  // :265; only the non-analytic evaluation is compiled in
+    bool piecewiseAnalyticIntegration = false;  // :265  usePiecewiseAnalyticIntegration_  (TRANSFER_FUNCTION_GAUSSIAN__ANALYTIC)
+    bool scaleWithGradient = false;             // :238  scaleWithGradient_ (JSON only in the reference; a property here as well)
     TransferFunctionGaussian() : TableTF(FVSRN_TF_GAUSSIAN, 6) {}
     void fill(fvsrn_scene_desc& d, std::vector<float>& table) const override {
-        if (piecewiseAnalyticIntegration) raise("piecewise analytic integration of Gaussian transfer functions is not in the compiled variant set");
+        if (scaleWithGradient && piecewiseAnalyticIntegration)  // getDefines, :296-297
+            raise("Gaussian TF: gradient scaling and piecewise analytic integration are incompatible");
         TableTF::fill(d, table);
+        d.tf_gaussian_mode = scaleWithGradient ? FVSRN_TF_GAUSSIAN_SCALE_WITH_GRADIENT
+                                               : (piecewiseAnalyticIntegration ? FVSRN_TF_GAUSSIAN_ANALYTIC : FVSRN_TF_GAUSSIAN_PLAIN);
     }
 };
 struct TransferFunctionPiecewise : TableTF { TransferFunctionPiecewise() : TableTF(FVSRN_TF_PIECEWISE, 5) {} };
@@ -1202,9 +1206,9 @@ std::shared_ptr<ImageEvaluatorSimple> loadFromJson(const std::string& filename) 
             tf->absorptionEmission->value = {jget<double>(jt, "absorptionScaling", 1.0), jget<double>(jt, "emissionScaling", 1.0)};
             dvr->tf = tf;
         } else if (tfSel == "Gaussian") {  // transfer_function_gaussian.cpp:234-242,340-360
-            if (jget<bool>(jt, "scaleWithGradient", false) || jget<bool>(jt, "usePiecewiseAnalyticIntegration", false))
-                raise("Gaussian transfer functions with scaleWithGradient / usePiecewiseAnalyticIntegration are not in the compiled variant set");
             auto tf = std::make_shared<TransferFunctionGaussian>();
+            tf->scaleWithGradient = jget<bool>(jt, "scaleWithGradient", false);  // :238-239
+            tf->piecewiseAnalyticIntegration = jget<bool>(jt, "usePiecewiseAnalyticIntegration", false);
             const double scale = jget<double>(jt, "absorptionScaling", 1.0);
             auto pts = jt["points"].cast<std::vector<std::vector<double>>>();
             torch::Tensor t = torch::empty({1, int64_t(pts.size()), 6}, torch::kFloat);
@@ -1513,7 +1517,10 @@ PYBIND11_MODULE(pyrenderer, m) {
                  return t.evaluate(densities, mn, mx, previous, stepsize);
              }, py::arg("densities"), py::arg("min_density"), py::arg("max_density"), py::arg("previous_density"), py::arg("stepsize"),
              py::arg("gradients") = std::optional<torch::Tensor>())
-        .def("requires_gradients", [](ITransferFunction&) { return false; })
+        .def("requires_gradients", [](ITransferFunction& t) {  // ITransferFunction::requiresGradients (transfer_function.cpp:216-223):
+                 auto g = dynamic_cast<TransferFunctionGaussian*>(&t);  // only the Gaussian TF with scaleWithGradient asks for normals
+                 return g != nullptr && g->scaleWithGradient;
+             })
         .def("get_max_absorption", [](ITransferFunction& t) {  // ITransferFunction::getMaxAbsorption: per unit step size
                  fvsrn_scene_desc d{};
                  std::vector<float> table;
@@ -1531,7 +1538,8 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def(py::init<>())
         .def_property("tensor", [](TransferFunctionGaussian& t) { return t.tensor; }, &TransferFunctionGaussian::setTensor)
         .def_readwrite("absorption_scaling", &TransferFunctionGaussian::absorptionScaling)
-        .def_readwrite("piecewise_analytic_integraton", &TransferFunctionGaussian::piecewiseAnalyticIntegration);
+        .def_readwrite("piecewise_analytic_integraton", &TransferFunctionGaussian::piecewiseAnalyticIntegration)  // (sic: the reference's spelling)
+        .def_readwrite("scale_with_gradient", &TransferFunctionGaussian::scaleWithGradient);
     py::class_<TransferFunctionPiecewise, ITransferFunction, std::shared_ptr<TransferFunctionPiecewise>>(m, "TransferFunctionPiecewiseLinear")
         .def(py::init<>())
         .def_property("tensor", [](TransferFunctionPiecewise& t) { return t.tensor; }, &TransferFunctionPiecewise::setTensor);

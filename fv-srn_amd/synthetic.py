@@ -5,13 +5,13 @@ import numpy as np
 from . import volnet_io
 
 
-def random_network(*, C=32, layers=4, activation="SnakeAlt", param=1.0, output_mode="density:direct", grid=None,
-                   fourier_std=None, seed=0, box_min=(0.0, 0.0, 0.0), box_size=(1.0, 1.0, 1.0), encoding=volnet_io.ENC_FLOAT,
-                   grid_scale=0.3, time_grids=1, no_fourier=False):
-    """Seeded random SRN in the reference's shape conventions: nn.Linear default init U(+-1/sqrt(in)),
-    NeRF block-identity Fourier matrix (network.py:55-63) unless fourier_std is given; grid = (channels, res)."""
+def random_arrays(*, C=32, layers=4, output_mode="density:direct", grid=None, fourier_std=None, seed=0, grid_scale=0.3, time_grids=1,
+                  no_fourier=False, has_time=False):
+    """The fp32 arrays of a seeded random SRN in the reference's shape conventions: nn.Linear default init U(+-1/sqrt(in)),
+    NeRF block-identity Fourier matrix (network.py:55-63) unless fourier_std is given; grid = (channels, res).
+    Returns dict(B, weights, biases, grids): what export_to_pyrenderer hands over, and what the CPU baseline of bench.py times."""
     rng = np.random.RandomState(seed)
-    F = 0 if no_fourier else (C - 4) // 2
+    F = 0 if no_fourier else (C - 4) // 2  # (has_time: the time takes the padding channel 3, network.py:123-169 "extra" input)
     if no_fourier:
         B = np.zeros((0, 3), np.float32)
     elif fourier_std is None:
@@ -22,7 +22,7 @@ def random_network(*, C=32, layers=4, activation="SnakeAlt", param=1.0, output_m
     G = grid[0] if grid else 0
     cout = 6 if output_mode.startswith("densitycurvature") else (
         4 if output_mode.startswith("rgbo") or output_mode.startswith("densitygrad") else 1)
-    dims = [3 + 2 * F + G] + [C] * (layers - 1) + [cout]
+    dims = [3 + int(has_time) + 2 * F + G] + [C] * (layers - 1) + [cout]
     weights, biases = [], []
     for i in range(layers):
         k = 1.0 / np.sqrt(dims[i])
@@ -33,7 +33,15 @@ def random_network(*, C=32, layers=4, activation="SnakeAlt", param=1.0, output_m
     tg = None
     if grid:
         tg = [(rng.randn(G, grid[1], grid[1], grid[1]) * grid_scale).astype(np.float32) for _ in range(time_grids)]
-    vn = volnet_io.build_volnet(fourier_B=B, weights=weights, biases=biases, activation=activation, activation_param=param,
-                                output_mode=output_mode, box_min=box_min, box_size=box_size, time_grids=tg,
-                                grid_encoding=encoding)
-    return vn
+    return dict(B=B, weights=weights, biases=biases, grids=tg)
+
+
+def random_network(*, C=32, layers=4, activation="SnakeAlt", param=1.0, output_mode="density:direct", grid=None,
+                   fourier_std=None, seed=0, box_min=(0.0, 0.0, 0.0), box_size=(1.0, 1.0, 1.0), encoding=volnet_io.ENC_FLOAT,
+                   grid_scale=0.3, time_grids=1, no_fourier=False, has_time=False):
+    """random_arrays() as a VolnetData (fp16 weights in the stored layouts of the .volnet format)."""
+    a = random_arrays(C=C, layers=layers, output_mode=output_mode, grid=grid, fourier_std=fourier_std, seed=seed, grid_scale=grid_scale,
+                      time_grids=time_grids, no_fourier=no_fourier, has_time=has_time)
+    return volnet_io.build_volnet(fourier_B=a["B"], weights=a["weights"], biases=a["biases"], activation=activation, activation_param=param,
+                                  output_mode=output_mode, box_min=box_min, box_size=box_size, time_grids=a["grids"],
+                                  grid_encoding=encoding, has_time=has_time)

@@ -1,8 +1,9 @@
 """
-Multi-GPU image-tile partition: one process per GPU, round-robin row stripes, one RCCL all-gather.
+Multi-GPU image-tile partition: one process per GPU, round-robin row stripes, one RCCL all-gather per frame.
 
-The reference has no distributed code at all; this is the new part the north star
-asks for.  Pixels are independent, so the only exchange step of a frame is assembling it:
+The reference has no distributed code at all; its entry this sits behind is
+ImageEvaluatorSimple::render(W, H) (renderer/image_evaluator_simple.cpp:198-361), which renders a whole frame on one
+device.  Pixels are independent, so the only exchange step of a frame is assembling it:
 
   rank r renders the rows {y : (y // stripe) % world == r}  (fvsrn_render_stripes, include/fvsrn.h) into a
   compact (8, rows_r, W) image; all compact images have the same size when H % (stripe*world) == 0, so ONE
@@ -10,12 +11,26 @@ asks for.  Pixels are independent, so the only exchange step of a frame is assem
   rank and a view/permute puts the stripes back in image order.
 
 Round-robin stripes (instead of H/world contiguous blocks) balance empty-space rows against dense rows.
+
+``StripeRenderer`` is the frame pipeline of one rank: double-buffered local / gathered images, the gather
+of frame i on a communication stream while frame i + 1 renders, consecutive frames on two render streams so that the
+tail of one launch overlaps the head of the next, time-dependent networks included (the C library keeps two working
+grids, FVSRN_OPT_WORKING_GRIDS).  bench.py, __graft_entry__.smoke() and the tests drive this class; ``launch_ranks``
+starts one process per rank when no launcher (torch.distributed.run) did.
 """
 from __future__ import annotations
 
-from typing import List
+import contextlib
+import os
+import socket
+import subprocess
+import sys
+import time
+from typing import Callable, List, Optional, Sequence
 
 import torch
+
+STRIPE = 16  # default stripe height: two 8-row pixel tiles of a wave
 
 
 def owned_rows(height: int, stripe: int, rank: int, world: int) -> List[int]:
@@ -51,3 +66,210 @@ def assemble(gathered: torch.Tensor, height: int, stripe: int) -> torch.Tensor:
     check_even_partition(height, stripe, world)
     assert rows * world == height
     return gathered.view(world, ch, rows // stripe, stripe, width).permute(1, 2, 0, 3, 4).reshape(1, ch, height, width)
+
+
+class _HostEvent:
+    """Stand-in for torch.cuda.Event on the CPU (gloo tests): host code is already ordered."""
+
+    def record(self, stream=None):
+        pass
+
+    def elapsed_time(self, other):
+        return 0.0
+
+
+class _HostStream:
+    def wait_event(self, e):
+        pass
+
+    def wait_stream(self, s):
+        pass
+
+
+class StripeRenderer:
+    """Frame pipeline of one rank.
+
+    net        capi.Network (device renders), or anything ``render`` understands
+    scene_kw   keyword arguments of capi.Scene for the first frame (camera, step size, TF ...)
+    render     None: the HIP path (capi.Scene.render for world == 1, capi.render_stripes otherwise).  A callable
+               ``render(scene_kwargs, out, rank, world, stripe)`` that fills ``out`` ((1,8,H,W) for world == 1, compact
+               (8, rows, W) otherwise) replaces it -- the CPU tests hand in the oracle so that the partition, the buffers and
+               the collective are exercised with gloo.
+    pipelined  consecutive frames alternate between two scenes on two render streams (default: world > 1).  At world == 1
+               the same trick is worth +4 % (r01), but one launch at a time keeps the HIP-event duration of the kernel, the
+               rocprofv3 trace and the frame period the same number, which is what bench.py reports there.
+    """
+
+    def __init__(self, net, width: int, height: int, scene_kw: dict, *, rank: int = 0, world: int = 1, stripe: int = STRIPE,
+                 group=None, pipelined: Optional[bool] = None, device: str = "cuda", render: Optional[Callable] = None):
+        self.net, self.W, self.H = net, int(width), int(height)
+        self.rank, self.world, self.stripe, self.group = int(rank), int(world), int(stripe), group
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        if not self.on_gpu and render is None:
+            raise RuntimeError("StripeRenderer: the HIP path needs a GPU (there is no CPU fallback); pass render= for host-side tests")
+        self._render_fn = render
+        self.pipelined = (world > 1) if pipelined is None else bool(pipelined)
+        self.kernel_events = []
+        self.frames_submitted = 0
+        if world > 1:
+            check_even_partition(self.H, self.stripe, self.world)
+        self.rows = self.H // self.world if world > 1 else self.H
+        nbuf = 2
+        if world == 1:
+            self.outs = [torch.zeros((1, 8, self.H, self.W), dtype=torch.float32, device=self.device) for _ in range(nbuf)]
+        else:
+            self.local = [torch.zeros((8, self.rows, self.W), dtype=torch.float32, device=self.device) for _ in range(nbuf)]
+            self.gathered = [torch.zeros((self.world, 8, self.rows, self.W), dtype=torch.float32, device=self.device) for _ in range(nbuf)]
+        if self.on_gpu:
+            from . import capi
+            self._capi = capi
+            self.scenes = [capi.Scene(**scene_kw) for _ in range(2 if self.pipelined else 1)]
+            self.comm_stream = torch.cuda.Stream() if world > 1 else None
+            self.render_done = [torch.cuda.Event() for _ in range(nbuf)]
+            self.gather_done = [torch.cuda.Event() for _ in range(nbuf)]
+            if self.pipelined:
+                # The first use of a network handle uploads its weight images and key frames on the stream of that call; the
+                # library orders other streams behind it by events (include/fvsrn.h), this untimed frame only keeps the
+                # uploads out of the first timed one.
+                self._render(self.scenes[0], 0, None)
+                torch.cuda.synchronize()
+                self.render_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+                for st in self.render_streams:
+                    st.wait_stream(torch.cuda.current_stream())
+        else:
+            self.scenes = [dict(scene_kw) for _ in range(2 if self.pipelined else 1)]
+            self.comm_stream = _HostStream() if world > 1 else None
+            self.render_done = [_HostEvent() for _ in range(nbuf)]
+            self.gather_done = [_HostEvent() for _ in range(nbuf)]
+            self.render_streams = [_HostStream(), _HostStream()]
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def _render(self, scene, b: int, stats):
+        out = self.outs[b] if self.world == 1 else self.local[b]
+        if self._render_fn is not None:
+            self._render_fn(scene, out, self.rank, self.world, self.stripe)
+        elif self.world == 1:
+            scene.render(self.net, self.W, self.H, out=out, stats=stats)
+        else:
+            self._capi.render_stripes(scene, self.net, self.W, self.H, self.stripe, self.rank, self.world, out=out, stats=stats)
+
+    def _stream_ctx(self, stream):
+        return torch.cuda.stream(stream) if self.on_gpu else contextlib.nullcontext()
+
+    def submit(self, index: int, scene_kw: dict, *, time: Optional[float] = None, ensemble: int = 0, stats=None,
+               gather: bool = True, record: bool = False) -> int:
+        """Enqueues frame `index`: scene update, optional time change, render of this rank's share, gather.  Returns the
+        buffer index b (= index & 1): ``frame(b)`` is this frame once ``finish()`` (or a later wait) has passed."""
+        import torch.distributed as dist
+        b = index & 1
+        s = b if self.pipelined else 0
+        if self.on_gpu:
+            scene = self.scenes[s]
+            scene.update(**scene_kw)
+            stream = self.render_streams[b] if self.pipelined else torch.cuda.current_stream()
+        else:
+            scene = self.scenes[s]
+            scene.clear()
+            scene.update(scene_kw)
+            stream = self.render_streams[b]
+        if time is not None:
+            # key frames are resident (or streamed by the library's copy stream); this only marks the working grid dirty, the
+            # blend into the grid the other frame in flight does NOT read is enqueued by the render call below
+            self.net.set_time_and_ensemble(time, ensemble)
+        with self._stream_ctx(stream):
+            if record and self.on_gpu:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            if self.world > 1:
+                stream.wait_event(self.gather_done[b])  # buffer b is free again
+            self._render(scene, b, stats)
+            self.render_done[b].record()
+            if record and self.on_gpu:
+                e1.record()
+                self.kernel_events.append((e0, e1))
+        if self.world > 1 and gather:
+            with self._stream_ctx(self.comm_stream):  # gather(frame i) overlaps render(frame i + 1)
+                self.comm_stream.wait_event(self.render_done[b])
+                dist.all_gather_into_tensor(self.gathered[b].view(self.world * 8, -1, self.W), self.local[b], group=self.group)
+                self.gather_done[b].record()
+        self.frames_submitted += 1
+        return b
+
+    def finish(self) -> None:
+        """The current stream waits for everything submitted (renders on both streams, gathers)."""
+        if not self.on_gpu:
+            return
+        cur = torch.cuda.current_stream()
+        if self.pipelined:
+            for st in self.render_streams:
+                cur.wait_stream(st)
+        if self.world > 1:
+            cur.wait_stream(self.comm_stream)
+
+    def frame(self, b: int = 0) -> torch.Tensor:
+        """(1, 8, H, W) image of buffer b: the render target itself on one GPU, the gathered stripes put back in image order
+        (a view + one permuting copy) otherwise."""
+        if self.world == 1:
+            return self.outs[b]
+        return assemble(self.gathered[b], self.H, self.stripe)
+
+
+def frames_match(full: torch.Tensor, gathered: torch.Tensor, tol_image: float = 3e-3, tol_depth: float = 3e-2) -> bool:
+    """A frame assembled from stripes against the single-GPU render of the same scene.  Same samples, but a rank's stripes
+    are a small launch and may be rendered in depth segments (re-associated sums, other restart points of the feature
+    rotation): compare within the image tolerance of the parity tests; depth (NaN where alpha == 0) only on pixels that
+    are not within rounding of empty."""
+    solid = (full[0, 3] > 1e-4) | (gathered[0, 3] > 1e-4)
+    if float((full[0, :7] - gathered[0, :7]).abs().max()) >= tol_image:
+        return False
+    if not torch.equal(torch.isnan(full[0, 7])[solid], torch.isnan(gathered[0, 7])[solid]):
+        return False
+    if not bool(solid.any()):
+        return True
+    d = (torch.nan_to_num(full[0, 7], nan=0.0) - torch.nan_to_num(gathered[0, 7], nan=0.0))[solid]
+    return float(d.abs().max()) < tol_depth
+
+
+def launch_ranks(n: int, argv: Sequence[str], script: Optional[str] = None, child: Optional[Sequence[str]] = None,
+                 capture: bool = False, timeout: float = 1800.0):
+    """Starts `n` rank processes of `script` (fresh interpreters, one per GPU, rendezvous on 127.0.0.1), relays rank 0's
+    stdout and returns the worst exit code (with capture=True: (code, rank 0's stdout) and nothing is printed).  This process
+    never initialises a GPU (torch.cuda.device_count() does not, on this image).  Fewer than `n` visible GPUs is an error, not
+    a silent 1-GPU run -- unless FVSRN_BENCH_BACKEND=gloo, the test mode in which all ranks share the visible GPU(s).
+    child: command prefix of a rank process (tests substitute a stand-in); default = `script` under this interpreter."""
+    backend = os.environ.get("FVSRN_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        print("--gpus %d: only %d GPU(s) visible, one per rank is required" % (n, have), file=sys.stderr)
+        return (2, "") if capture else 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = list(child) if child else [sys.executable, os.path.abspath(script)]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        for p in procs:  # exactly the processes started here
+            p.kill()
+        out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:  # rank 0 is gone and this one hangs in a collective: end exactly this process
+            p.kill()
+            rcs.append(p.wait())
+    bad = [rc for rc in rcs if rc != 0]
+    code = 0 if not bad else (bad[0] if bad[0] > 0 else 1)
+    if capture:
+        return code, out0.decode()
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return code

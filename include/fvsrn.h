@@ -17,9 +17,10 @@
  *   - handles are re-entrant per object; distinct objects may be used from distinct threads
  *   - a handle's device state (weight image, latent key frames, TF tables) is created at its first use on the HIP device
  *     that is current then; every later call must run with that device current (FVSRN_ERR_WRONG_DEVICE otherwise) --
- *     one handle per device, the reference's "one renderer per CUDA context".  First use and time changes of a network
- *     are ordered on the stream of the call that triggers them: callers that render one network from several streams
- *     synchronise those streams behind the first call / a time change themselves
+ *     one handle per device, the reference's "one renderer per CUDA context".  A network may be used from several
+ *     streams: its first use (upload of the weight images and key frames) and every time change (blend into a working grid)
+ *     are enqueued on the stream of the call that triggers them, and calls on other streams wait for them by events; a blend
+ *     waits for every kernel that still reads the working grid it overwrites (r03; before, callers had to synchronise)
  *   - nothing on a per-frame path reads the process environment; the FVSRN_* variables only seed the option defaults once
  */
 #ifndef FVSRN_H_
@@ -167,7 +168,10 @@ typedef enum {
     FVSRN_OPT_KEYFRAME_SLOTS = 9,    /* network: time key frames of the latent grid resident in HBM; 0 = all, k >= 2 = at most k, the
                                         others are streamed from pinned host memory on a copy stream, overlapped with rendering
                                         (k >= 3: prefetched one key-frame interval ahead)                      [FVSRN_KEYFRAME_SLOTS] */
-    FVSRN_OPT_COUNT_ = 10
+    FVSRN_OPT_WORKING_GRIDS = 10,    /* network: blended fp16 working grids (what the kernels read); 0 = auto: 2 for a network with several
+                                        key frames -- a time change then blends into the grid the frame in flight does not read, so
+                                        two frames at different times may be in flight on two streams --, 1 otherwise  [FVSRN_WORKING_GRIDS] */
+    FVSRN_OPT_COUNT_ = 11
 } fvsrn_option;
 int fvsrn_network_set_option(fvsrn_network* net, int option, int value);
 int fvsrn_network_get_option(const fvsrn_network* net, int option, int* value);
@@ -248,7 +252,14 @@ typedef struct {
      * 256 entries / 256 x 256 entries with 256 quadrature steps) whenever the table or the step size changes */
     int tf_preintegration;      /* fvsrn_tf_preintegration */
     float adjoint_grid_stepsize; /* FVSRN_GRADIENT_ADJOINT_METHOD: see gradient_mode */
+    /* TransferFunctionGaussian's two variants (renderer_tf_gaussian.cuh:55-73; host flags scaleWithGradient_ /
+     * usePiecewiseAnalyticIntegration_, transfer_function_gaussian.cpp:238-239,293-303 -- mutually exclusive there too):
+     * SCALE_WITH_GRADIENT multiplies every sigma by max(1e-5, 0.1 |gradient|) with the gradient the volume provides (gradient_mode,
+     * or a gradient-predicting network; none: |gradient| = 0); ANALYTIC integrates every Gaussian between the previous and the
+     * current sample's density in closed form (erf), falling back to the point value for the first sample of a ray and equal densities */
+    int tf_gaussian_mode;       /* fvsrn_tf_gaussian_mode, FVSRN_TF_GAUSSIAN only */
 } fvsrn_scene_desc;
+typedef enum { FVSRN_TF_GAUSSIAN_PLAIN = 0, FVSRN_TF_GAUSSIAN_SCALE_WITH_GRADIENT = 1, FVSRN_TF_GAUSSIAN_ANALYTIC = 2 } fvsrn_tf_gaussian_mode;
 typedef enum { FVSRN_PREINTEGRATE_NONE = 0, FVSRN_PREINTEGRATE_1D = 1, FVSRN_PREINTEGRATE_2D = 2 } fvsrn_tf_preintegration;
 typedef enum { FVSRN_GRADIENT_OFF_OR_DIRECT = 0, FVSRN_GRADIENT_FINITE_DIFFERENCES = 1, FVSRN_GRADIENT_ADJOINT_METHOD = 2 } fvsrn_gradient_mode;
 typedef enum { FVSRN_LIGHT_POINT = 0, FVSRN_LIGHT_DIRECTIONAL = 1 } fvsrn_light_type;

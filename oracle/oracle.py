@@ -49,7 +49,7 @@ class _OracleScene(C.Structure):
                 ("brdfMagnitudeScaling", C.c_int), ("brdfPhong", C.c_int), ("brdfLightType", C.c_int),
                 ("brdfSpecularExponent", C.c_int), ("brdfMagScale", C.c_float), ("brdfAmbient", C.c_float),
                 ("brdfSpecular", C.c_float), ("brdfMagCenter", C.c_float), ("brdfMagRadius", C.c_float),
-                ("brdfLight", C.c_float * 3), ("tfPreintegration", C.c_int), ("tfPreintegrated", _FP)]
+                ("brdfLight", C.c_float * 3), ("tfPreintegration", C.c_int), ("tfPreintegrated", _FP), ("tfGaussianMode", C.c_int)]
 
 
 _lib = None
@@ -291,8 +291,9 @@ class OracleScene:
     def __init__(self, *, eye, right, up, fov_y_radians, stepsize, density_min=0.0, density_max=1.0, early_out=True,
                  blend_mode=BLEND_BEER_LAMBERT, tf_kind=TF_IDENTITY, tf_scale_absorption=1.0, tf_scale_emission=1.0,
                  tf_table=None, gradient_mode=0, finite_differences_stepsize=0.0, brdf=None, tf_preintegration=0,
-                 adjoint_grid_stepsize=0.0):
+                 adjoint_grid_stepsize=0.0, tf_gaussian_mode=0):
         s = _OracleScene()
+        s.tfGaussianMode = tf_gaussian_mode
         s.eye[:] = [float(v) for v in eye]
         s.right[:] = [float(v) for v in right]
         s.up[:] = [float(v) for v in up]

@@ -665,7 +665,9 @@ static void tf_eval_preintegrated(const OracleScene* s, float density, float pre
     }
 }
 
-static void tf_eval(const OracleScene* s, float density, float c[4]) {
+/* normalLength: |gradient| the volume handed to the TF (0 where it provides none); previousDensity: the un-clamped mapped density of
+ * the previous sample of the ray, -1 for the first one (stepping_dvr.cuh:81,135) -- only the Gaussian variants read them */
+static void tf_eval(const OracleScene* s, float density, float normalLength, float previousDensity, float c[4]) {
     density = clamp01(density);
     c[0] = c[1] = c[2] = c[3] = 0.f;
     const float* T = s->tfTable;
@@ -677,7 +679,16 @@ static void tf_eval(const OracleScene* s, float density, float c[4]) {
         case ORACLE_TF_GAUSSIAN: /* renderer_tf_gaussian.cuh:43-86 */
             for (int i = 0; i < s->tfRows; ++i) {
                 const float* r = T + 6 * i;
-                const float ni = expf(-(density - r[4]) * (density - r[4]) / (r[5] * r[5]));
+                const float mu = r[4];
+                float sigma = r[5], ni;
+                if (s->tfGaussianMode == 1) sigma *= fmaxf(1e-5f, normalLength * 0.1f); /* :55-57 "some arbitrary scaling factor" */
+                if (s->tfGaussianMode == 2 && !(previousDensity < 0 || previousDensity == density)) {
+                    /* :61-72 piecewise analytic integration, constant colour per segment */
+                    const float SQRT_PI_2 = 0.8862269254527580136f;
+                    ni = SQRT_PI_2 / (previousDensity - density) * sigma * (erff((previousDensity - mu) / sigma) + erff((mu - density) / sigma));
+                } else {
+                    ni = expf(-(density - mu) * (density - mu) / (sigma * sigma));
+                }
                 for (int k = 0; k < 4; ++k) c[k] += r[k] * ni;
             }
             c[3] *= s->stepsize;
@@ -717,8 +728,9 @@ void oracle_tf_evaluate(const OracleScene* s, const float* density, const float*
             if (s->tfPreintegration) {
                 const float p = previous ? previous[i] : -1.f;
                 tf_eval_preintegrated(s, d2, p >= 0 ? (p - s->densityMin) * divRange : -1.f, c);
-            } else {
-                tf_eval(s, d2, c);
+            } else { /* renderer_tf_kernels.cuh:30,61: zero normal; previous density mapped when it is >= 0 */
+                const float p = previous ? previous[i] : -1.f;
+                tf_eval(s, d2, 0.f, p >= 0 ? (p - s->densityMin) * divRange : -1.f, c);
             }
         }
         for (int k = 0; k < 4; ++k) out4[4 * i + k] = c[k];
@@ -783,7 +795,7 @@ static void render_pixel(const OracleNet* n, const OracleScene* s, int W, int H,
                     srn_adjoint(n, pos, dir, s->gridDiffStep, g);
                 }
                 if (s->tfPreintegration) tf_eval_preintegrated(s, density2, previousDensity, c);
-                else tf_eval(s, density2, c); /* :113-133 */
+                else tf_eval(s, density2, sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), previousDensity, c); /* :113-133 */
             }
             previousDensity = density2; /* :135 */
         }
@@ -998,7 +1010,7 @@ static void render_pixel_volume(const OracleVolume* v, const OracleScene* s, int
     const float divRange = 1.0f / (s->densityMax - s->densityMin);
     float col[4] = {0, 0, 0, 0}, nacc[3] = {0, 0, 0}, depth = 0;
     float previousDensity = -1.f;
-    const int normals = v->provideNormals || s->brdfPhong || s->brdfMagnitudeScaling;
+    const int normals = v->provideNormals || s->brdfPhong || s->brdfMagnitudeScaling || s->tfGaussianMode == 1; /* transfer_function_gaussian.cpp:271-272 */
     unsigned long long cnt = 0;
     for (int i = 0;; ++i) {
         const float t = tmin + (float)i * s->stepsize;
@@ -1012,7 +1024,7 @@ static void render_pixel_volume(const OracleVolume* v, const OracleScene* s, int
         if (value >= s->densityMin) {
             if (normals) vol_normal(v, pos, g);
             if (s->tfPreintegration) tf_eval_preintegrated(s, density2, previousDensity, c);
-            else tf_eval(s, density2, c);
+            else tf_eval(s, density2, sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), previousDensity, c);
         }
         previousDensity = density2;
         if (c[3] > 0 && (s->brdfMagnitudeScaling || s->brdfPhong)) { /* BRDFLambert::eval, as in render_pixel */

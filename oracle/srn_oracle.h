@@ -64,6 +64,8 @@ typedef struct {
      * built by oracle_tf_preintegrate (transfer_function_texture_cuda.cu:9-90) */
     int tfPreintegration;
     const float* tfPreintegrated;
+    /* TRANSFER_FUNCTION_GAUSSIAN__SCALE_WITH_GRADIENT (1) / __ANALYTIC (2), renderer_tf_gaussian.cuh:55-73; 0: neither */
+    int tfGaussianMode;
 } OracleScene;
 /* tex [R][4] -> out [R][4] (mode 1) or [R][R][4] (mode 2, N quadrature steps, world step size) */
 /* EvaluateTF / EvaluateTFWithPrevious (renderer_tf_kernels.cuh:11-70) with the scene's TF, density range and step size;

@@ -370,6 +370,47 @@ def test_shaded_render_matches_oracle(case):
     assert abs(int(stats[0]) - count) <= max(2, count // 1000)
 
 
+@pytest.mark.parametrize("case", [
+    # TRANSFER_FUNCTION_GAUSSIAN__ANALYTIC: closed-form integral between the previous and the current sample's density
+    dict(net=dict(activation="SnakeAlt", output_mode="density"), mode=2),
+    dict(net=dict(activation="ReLU", output_mode="density:direct", C=64, layers=3, grid=(16, 8)), mode=2, tf=dict(density_min=-0.5, density_max=1.0)),
+    # TRANSFER_FUNCTION_GAUSSIAN__SCALE_WITH_GRADIENT: sigma * max(1e-5, 0.1 |gradient|), gradient by finite differences, by the
+    # adjoint method, predicted by the network -- and none at all (sigma * 1e-5: an empty image, like the reference would give)
+    dict(net=dict(activation="SnakeAlt", output_mode="density"), mode=1, grad=dict(gradient_mode=1, finite_differences_stepsize=1 / 16)),
+    dict(net=dict(activation="Sine", output_mode="density", C=48), mode=1, grad=dict(gradient_mode=2)),
+    dict(net=dict(activation="Sine", output_mode="densitygrad"), mode=1),
+    dict(net=dict(activation="SnakeAlt", output_mode="density"), mode=1, empty=True),
+])
+def test_gaussian_tf_variants_match_oracle(case):
+    """Row a11 of SURVEY 8: the two compile-time variants of the Gaussian TF (renderer_tf_gaussian.cuh:55-73, host flags
+    transfer_function_gaussian.cpp:238-239,293-303) through the renderer, against the oracle's restatement."""
+    vn = util.random_network(seed=33, box_min=(-0.5, -0.5, -0.5), fourier_std=0.35, **case["net"])
+    # wide Gaussians for the gradient-scaled variant: |gradient| of these networks is O(1), so sigma shrinks by ~10
+    table = GAUSS_TF.copy()
+    if case["mode"] == 1:
+        table[:, 5] *= 8.0
+    kw = make_scene_kwargs(early_out=True, tf_kind=oracle.TF_GAUSSIAN, tf_table=table, tf_gaussian_mode=case["mode"], **case.get("tf", {}),
+                           **case.get("grad", {}))
+    img, ref, stats, count = render_both(vn, kw, 40, 24)
+    if case.get("empty"):
+        assert ref[3].max() < 1e-3 and img[3].max() < 1e-3
+        return
+    assert ref[3].max() > 0.05, "empty image: the comparison would be vacuous"
+    plain, _ = oracle.OracleScene(**dict(kw, tf_gaussian_mode=0)).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), 40, 24)
+    assert np.abs(plain[:4] - ref[:4]).max() > 2e-2, "the variant does not differ from the plain Gaussian TF here"
+    fd = case.get("grad", {}).get("gradient_mode") == 1
+    assert_images_close(img, ref, 4 * TOL_IMG if (fd or case["mode"] == 2) else 2 * TOL_IMG)
+    assert abs(int(stats[0]) - count) <= max(2, count // 1000)
+
+
+def test_gaussian_tf_mode_is_validated():
+    from fvsrn_amd import capi
+    with pytest.raises(capi.FvsrnError, match="Gaussian"):
+        capi.Scene(**make_scene_kwargs(tf_kind=oracle.TF_IDENTITY, tf_gaussian_mode=2))
+    with pytest.raises(capi.FvsrnError, match="tf_gaussian_mode"):
+        capi.Scene(**make_scene_kwargs(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF, tf_gaussian_mode=3))
+
+
 TEX256 = np.stack([0.5 + 0.5 * np.sin(np.arange(256) / 20.0), np.linspace(0, 1, 256), np.linspace(1, 0, 256) ** 2,
                    60.0 * (0.5 + 0.5 * np.cos(np.arange(256) / 33.0))], axis=1).astype(np.float32)
 
@@ -883,13 +924,17 @@ def test_generate_rays_matches_camera_restatement():
     assert np.abs(direction - d).max() < 2e-6
 
 
-@pytest.mark.parametrize("tf", ["identity", "gaussian", "piecewise", "texture", "texture_pre1d", "texture_pre2d"])
+@pytest.mark.parametrize("tf", ["identity", "gaussian", "gaussian_analytic", "gaussian_scale_with_gradient", "piecewise", "texture", "texture_pre1d",
+                                "texture_pre2d"])
 def test_evaluate_tf_matches_restatement(tf):
     """ITransferFunction::evaluate / evaluate_with_previous (EvaluateTF kernels, renderer_tf_kernels.cuh:11-70)."""
     import torch
     from fvsrn_amd import capi
     kw = dict(identity=dict(tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=12.0, tf_scale_emission=0.7),
-              gaussian=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF), piecewise=dict(tf_kind=oracle.TF_PIECEWISE, tf_table=PIECE_TF),
+              gaussian=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF),
+              # the two variants of renderer_tf_gaussian.cuh:55-73; this entry has no gradient (zero normal: sigma * 1e-5)
+              gaussian_analytic=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF, tf_gaussian_mode=2),
+              gaussian_scale_with_gradient=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF, tf_gaussian_mode=1), piecewise=dict(tf_kind=oracle.TF_PIECEWISE, tf_table=PIECE_TF),
               texture=dict(tf_kind=oracle.TF_TEXTURE, tf_table=TEX256),
               texture_pre1d=dict(tf_kind=oracle.TF_TEXTURE, tf_table=TEX256, tf_preintegration=1),
               texture_pre2d=dict(tf_kind=oracle.TF_TEXTURE, tf_table=TEX256, tf_preintegration=2))[tf]
@@ -898,7 +943,9 @@ def test_evaluate_tf_matches_restatement(tf):
     prev = np.where(rng.rand(5000) < 0.2, -1.0, dens + rng.uniform(-0.05, 0.05, 5000)).astype(np.float32)
     dmin, dmax, step = 0.1, 0.9, 1 / 40
     # pre-integrated tables: 256-step sums with the device's exp / division, then a division by a small alpha
-    tol = 5e-4 if "pre" in tf else 2e-5
+    # (analytic Gaussian: a difference of two erf over a density difference as small as 1e-5 -- cancellation amplifies the few ulp
+    # between the device's and glibc's erff)
+    tol = 5e-4 if "pre" in tf else (5e-3 if tf == "gaussian_analytic" else 2e-5)
     scene = capi.Scene(**make_scene_kwargs(stepsize=step, density_min=dmin, density_max=dmax, **kw))
     d_t = torch.from_numpy(dens).cuda().reshape(-1, 1)
     # evaluate(): step size 1, no previous density

@@ -197,6 +197,10 @@ PHONG = dict(enable_phong=True, ambient=0.2, specular=0.4, magnitude_center=0.6,
     # pre-integrated Texture TF, 2D table (looks at the previous sample of the ray; the 1D mode switches formulas at
     # |d - d_prev| = 1e-3, where one ulp of density flips isolated pixels by a few percent)
     dict(brdf=None, normals=False, preint=2),
+    # Gaussian TF variants (renderer_tf_gaussian.cuh:55-73): sigma scaled by the grid's gradient length (the TF requests normals,
+    # transfer_function_gaussian.cpp:271-272) / closed-form integration between consecutive samples
+    dict(brdf=None, normals=False, preint=0, gauss=1),
+    dict(brdf=None, normals=False, preint=0, gauss=2),
 ])
 def test_render_volume_normals_shading_preintegration(case):
     """evalNormalImpl (renderer_volume_grid.cuh:234-283) feeding BRDFLambert and the normal channels; pre-integrated TFs."""
@@ -209,15 +213,24 @@ def test_render_volume_normals_shading_preintegration(case):
         tab = rng.uniform(0.0, 1.0, (64, 4)).astype(np.float32)
         tab[:, 3] *= 40.0
         kw.update(tf_kind=oracle.TF_TEXTURE, tf_table=tab, tf_preintegration=case["preint"])
+    if case.get("gauss"):
+        tab = np.array([[0.9, 0.1, 0.1, 30.0, 0.25, 0.08], [0.1, 0.9, 0.2, 60.0, 0.5, 0.05], [0.2, 0.3, 0.95, 90.0, 0.8, 0.1]], np.float32)
+        if case["gauss"] == 1:
+            tab[:, 5] *= 4.0  # gradients of this volume are a few per unit length: sigma * 0.1 |g|
+        kw.update(tf_kind=oracle.TF_GAUSSIAN, tf_table=tab, tf_gaussian_mode=case["gauss"])
     W, H = 64, 48
     ov = oracle.OracleVolume(data, BOX_MIN, BOX_SIZE, oracle.VOLUME_TRILINEAR, oracle.VOLUME_SOURCE_TENSOR, provide_normals=case["normals"])
     ref, _ = ov.render(oracle.OracleScene(**kw), W, H)
     vol = capi.Volume.from_array(data, BOX_MIN, BOX_SIZE)
     img = vol.render(capi.Scene(**kw), W, H, oracle.VOLUME_TRILINEAR, oracle.VOLUME_SOURCE_TENSOR, provide_normals=case["normals"])[0].cpu().numpy()
-    assert ref[3].max() > 0.5
+    assert ref[3].max() > (0.05 if case.get("gauss") else 0.5)
     # Phong: rsqrt / powf / exp of the device vs libm on gradients of ~10/unit: looser, like the shaded network renders
-    assert np.abs(img[:4] - ref[:4]).max() < (5e-3 if case["brdf"] else 5e-4)
-    if case["normals"] or case["brdf"]:
+    assert np.abs(img[:4] - ref[:4]).max() < (5e-3 if case["brdf"] or case.get("gauss") else 5e-4)
+    if case.get("gauss"):  # (the gradient-scaled variant makes the volume provide normals: they show up in the normal channels)
+        plain, _ = ov.render(oracle.OracleScene(**dict(kw, tf_gaussian_mode=0)), W, H)
+        assert np.abs(plain[:4] - ref[:4]).max() > 2e-2
+        assert np.abs(img[4:7] - ref[4:7]).max() < 2e-3 and (np.abs(ref[4:7]).max() > 0.1) == (case["gauss"] == 1)
+    elif case["normals"] or case["brdf"]:
         assert np.abs(ref[4:7]).max() > 0.1 and np.abs(img[4:7] - ref[4:7]).max() < (5e-3 if case["brdf"] else 2e-3)
     else:
         assert np.abs(img[4:7]).max() == 0.0

@@ -119,6 +119,21 @@ def test_load_from_json_builds_the_module_tree(tmp_path):
         ev.volume.current_network()
 
 
+def test_gaussian_tf_flags_of_scene_files(tmp_path):
+    """scaleWithGradient / usePiecewiseAnalyticIntegration (transfer_function_gaussian.cpp:238-239) load into the TF object; both at
+    once are refused when the kernel variant is selected, like the reference's getDefines (:296-297)."""
+    body = {"absorptionScaling": 2.0, "points": [[1, 0, 0, 10, 0.3, 0.1], [0, 1, 0, 20, 0.7, 0.05]]}
+    for flags, want in (({}, (False, False)), ({"scaleWithGradient": True}, (True, False)), ({"usePiecewiseAnalyticIntegration": True}, (False, True))):
+        p = tmp_path / "g.json"
+        p.write_text(json.dumps(_scene_json("Gaussian", dict(body, **flags), volume="SRN")))
+        tf = pr.load_from_json(str(p)).ray_evaluator.tf
+        assert (tf.scale_with_gradient, tf.piecewise_analytic_integraton) == want
+        assert tf.requires_gradients() == want[0]
+    tf.scale_with_gradient = True
+    with pytest.raises(RuntimeError, match="incompatible"):
+        tf.get_max_absorption()  # (any call that builds the TF's device description)
+
+
 def _scene_json(tf_name, tf_body, brdf=None, volume="Grid"):
     return {"version": 1, "root": "Simple",
             "ImageEvaluator": {"Simple": {"selectedCamera": "Sphere", "selectedVolume": volume, "selectedRayEvaluator": "DVR",
@@ -127,7 +142,7 @@ def _scene_json(tf_name, tf_body, brdf=None, volume="Grid"):
             "RayEvaluation": {"DVR": {"stepsize": 1 / 48, "stepsizeIsObjectSpace": False, "minDensity": 0.0, "maxDensity": 1.0,
                                       "earlyOut": True, "selectedTF": tf_name, "selectedBRDF": "Lambert"}},
             "tf": {tf_name: tf_body}, "brdf": {"Lambert": brdf or {"enablePhong": False}},
-            "blending": {"blending": {"blending": "BeerLambert"}}, "volume": {"Grid": {}}}
+            "blending": {"blending": {"blending": "BeerLambert"}}, "volume": {volume: {}}}
 
 
 PIECEWISE_JSON = {"absorptionScaling": 25.0, "colorPoints": [[0.0033, 1e-6, 1e-6, 1e-6], [0.44, 1.0, 0.04, 0.04], [0.7558, 0.9167, 0.9167, 0.1168]],

@@ -1,7 +1,8 @@
 """
 The N > 1 path on CPU: two processes (gloo), round-robin row stripes, all-gather, assembly.
 The stripe images come from the CPU oracle (this is a test of the partition / exchange logic in
-fv-srn_amd/tiles.py, the same code bench.py drives with RCCL).
+fv-srn_amd/tiles.py, the same code bench.py drives with RCCL): the free functions, and the frame pipeline
+``StripeRenderer`` (double-buffered local / gathered images) with the oracle handed in as its render function.
 """
 import os
 import socket
@@ -49,6 +50,67 @@ def _worker(rank, world, port, H, W, stripe, tmp):
     if rank == 0:
         open(tmp, "w").write(str(int(flag.item())))
     dist.destroy_process_group()
+
+
+def _pipeline_worker(rank, world, port, H, W, stripe, tmp):
+    """StripeRenderer on the CPU: three frames (two buffers, so frame 2 reuses frame 0's), every gathered frame against a
+    whole-frame oracle render of the same camera."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density", seed=5, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4)
+    net = oracle.OracleNetwork(vn, oracle.ACC_FLOAT)
+
+    def scene_kw(yaw):
+        eye, right, up = oracle.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, yaw, 1.6)
+        return dict(eye=eye, right=right, up=up, fov_y_radians=float(np.deg2rad(45)), stepsize=1 / 16, tf_kind=oracle.TF_IDENTITY,
+                    tf_scale_absorption=20.0)
+
+    calls = []
+
+    def render(kw, out, r, w, st):  # the rows this rank owns, in compact order
+        assert (r, w, st) == (rank, world, stripe)
+        scene = oracle.OracleScene(**kw)
+        rows = tiles.owned_rows(H, st, r, w)
+        assert tuple(out.shape) == (8, len(rows), W)
+        for i, y in enumerate(rows):
+            img, _ = scene.render(net, W, H, y, y + 1)
+            out[:, i] = torch.from_numpy(img[:, y])
+        calls.append(len(rows))
+
+    pipe = tiles.StripeRenderer(net, W, H, scene_kw(0.0), rank=rank, world=world, stripe=stripe, device="cpu", render=render)
+    assert pipe.pipelined and pipe.rows * world == H
+    ok = True
+    yaws = [0.3, 1.1, 2.0]
+    for i, yaw in enumerate(yaws):
+        b = pipe.submit(i, scene_kw(yaw))
+        assert b == (i & 1)
+        pipe.finish()
+        full, _ = oracle.OracleScene(**scene_kw(yaw)).render(net, W, H)
+        frame = pipe.frame(b)
+        assert tuple(frame.shape) == (1, 8, H, W)
+        ok = ok and np.array_equal(np.nan_to_num(frame[0].numpy(), nan=-1), np.nan_to_num(full, nan=-1))
+        ok = ok and tiles.frames_match(torch.from_numpy(full)[None], frame)
+    ok = ok and len(calls) == len(yaws) and pipe.frames_submitted == len(yaws)
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        open(tmp, "w").write(str(int(flag.item())))
+    dist.destroy_process_group()
+
+
+def test_stripe_renderer_pipeline_two_ranks(tmp_path):
+    out = str(tmp_path / "ok.txt")
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), 32, 24, 8, out), nprocs=2, join=True)
+    assert open(out).read() == "1"
+
+
+def test_stripe_renderer_refuses_the_cpu_without_a_render_function():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tiles.StripeRenderer(None, 16, 16, {}, device="cpu")
+    with pytest.raises(ValueError):  # ranks would own different row counts
+        tiles.StripeRenderer(None, 16, 40, {}, world=3, stripe=8, device="cpu", render=lambda *a: None)
 
 
 @pytest.mark.parametrize("world,stripe,H", [(2, 8, 32), (2, 16, 64)])
