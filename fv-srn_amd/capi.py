@@ -100,6 +100,7 @@ SYMBOLS = [
     ("fvsrn_scene_destroy", None, [_VP]),
     ("fvsrn_camera_on_a_sphere", _I, [_I, _DP, _D, _D, _D, _FP, _FP, _FP]),
     ("fvsrn_render", _I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP]),
+    ("fvsrn_scene_last_render_info", _I, [_VP, C.POINTER(_I)]),
     ("fvsrn_stripe_rows", _I, [_I, _I, _I, _I]),
     ("fvsrn_render_stripes", _I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     ("fvsrn_extract_color", _I, [_VP, _I, _I, _I, _I, _F, _VP, _VP]),
@@ -416,6 +417,12 @@ class Scene:
         v = _I()
         _check(lib().fvsrn_scene_get_option(self._h, OPTIONS[name], C.byref(v)))
         return v.value
+
+    def last_render_info(self) -> dict:
+        """How the last render of this scene treated a ray's samples (fvsrn_scene_last_render_info)."""
+        a = (_I * 4)()
+        _check(lib().fvsrn_scene_last_render_info(self._h, a))
+        return dict(segments=a[0], rotation_resync=a[1], resident_kernel=bool(a[2]), waves_per_block=a[3])
 
     def __del__(self):
         try:

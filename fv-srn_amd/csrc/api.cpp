@@ -526,6 +526,7 @@ struct fvsrn_scene {
     int preintMode = 0;          // what dPreint holds
     float preintStepsize = -1.f;
     unsigned launches = 0;  // parity selects which of the two tile counters a launch uses (the kernel zeroes the other)
+    int lastInfo[4] = {0, 0, 0, 0};  // fvsrn_scene_last_render_info
     bool tfDirty = true;
     int device = -1;  // HIP device of the buffers above (-1: none yet)
     Options opts = defaultOptions();
@@ -1322,6 +1323,12 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             // starts the long rays first, which pays whenever a workgroup holds several waves or waits on memory.
             const bool useOrder = O[FVSRN_OPT_TILE_ORDER] >= 0 ? O[FVSRN_OPT_TILE_ORDER] == 1 : (S.tileCounter == nullptr && (wpb > 1 || net->key.grid != 0));
             S.tileOrder = useOrder ? scene->tileOrder(S, P_boxCenter(a.P), tilesX, tilesY, s) : nullptr;
+            // what this launch does to the samples of a ray, for callers that restate it (fvsrn_scene_last_render_info)
+            const bool rotates = net->keyScaled.CD == 2 && net->keyScaled.grid == 0 && !a.P.noFourier && !a.shaded;  // kRotate, kernels.hpp
+            scene->lastInfo[0] = K;
+            scene->lastInfo[1] = rotates ? S.resyncMask + 1 : 0;
+            scene->lastInfo[2] = smallFn ? 1 : 0;
+            scene->lastInfo[3] = wpb;
             hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid, a, grid, unsigned(64 * wpb), lds, s)
                                    : launch_render(a.shaded ? net->key : net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
             if (e == hipSuccess && K > 1) e = launch_composite(S.partial, d_out8, K, plane, S, s);
@@ -1427,6 +1434,13 @@ int fvsrn_scene_evaluate_tf(fvsrn_scene* scene, const float* d_density, const fl
         if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("evaluate_tf failed: ") + hipGetErrorString(e));
         return FVSRN_OK;
     });
+}
+
+int fvsrn_scene_last_render_info(fvsrn_scene* scene, int out[4]) {
+    if (!scene || !out) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(scene->mu);
+    for (int i = 0; i < 4; ++i) out[i] = scene->lastInfo[i];
+    return FVSRN_OK;
 }
 
 int fvsrn_stripe_rows(int height, int stripe_rows, int rank, int world) {

@@ -404,25 +404,34 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     const int y = S.y0 + ((lrow / S.stripeRows) * S.stripeWorld + S.stripeRank) * S.stripeRows + lrow % S.stripeRows;
     const bool inImage = x < S.width && lrow < S.numLocalRows && y < S.y1;
 
-    // camera ray (renderer_image_evaluator_simple.cuh:84-88, renderer_camera.cuh:33-52)
-    const float ndcx = 2.f * (float(x) + 0.5f) / float(S.width) - 1.f;
-    const float ndcy = 2.f * (float(y) + 0.5f) / float(S.height) - 1.f;
-    float dx = S.front[0] + ndcx * S.tanFovX * S.right[0] + ndcy * S.tanFovY * S.up[0];
-    float dy = S.front[1] + ndcx * S.tanFovX * S.right[1] + ndcy * S.tanFovY * S.up[1];
-    float dz = S.front[2] + ndcx * S.tanFovX * S.right[2] + ndcy * S.tanFovY * S.up[2];
-    const float invLen = rsqrtf(dx * dx + dy * dy + dz * dz);
-    dx *= invLen; dy *= invLen; dz *= invLen;
+    // camera ray (renderer_image_evaluator_simple.cuh:84-88, renderer_camera.cuh:33-52), box intersection (renderer_utils.cuh:91-105)
+    // and the ray in unit-box coordinates.  Once per ray, so every operation is spelled out (explicit fma's, IEEE division and square
+    // root, no contraction by the compiler): the oracle's DEVICE model (oracle/srn_oracle.c, render_pixel) restates this sequence
+    // operation by operation, which makes the sample positions of the two bit-identical -- a network behind a 2^9 frequency ladder turns
+    // one ulp of a position into a different fp16 rounding and that into percents of a colour.
+    float dx, dy, dz, tmin, tmax, pn0x, pn0y, pn0z, dnx, dny, dnz;
     const float ox = S.eye[0], oy = S.eye[1], oz = S.eye[2];
-
-    // box intersection (renderer_utils.cuh:91-105)
-    float tmin, tmax;
     {
+#pragma clang fp contract(off)
+        const float ndcx = 2.f * (float(x) + 0.5f) / float(S.width) - 1.f;
+        const float ndcy = 2.f * (float(y) + 0.5f) / float(S.height) - 1.f;
+        const float ax = ndcx * S.tanFovX, ay = ndcy * S.tanFovY;
+        dx = __builtin_fmaf(ay, S.up[0], __builtin_fmaf(ax, S.right[0], S.front[0]));
+        dy = __builtin_fmaf(ay, S.up[1], __builtin_fmaf(ax, S.right[1], S.front[1]));
+        dz = __builtin_fmaf(ay, S.up[2], __builtin_fmaf(ax, S.right[2], S.front[2]));
+        const float invLen = 1.0f / __builtin_sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+        dx *= invLen; dy *= invLen; dz *= invLen;
         const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
         const float t1 = (P.boxMin[0] - ox) * ix, t2 = (P.boxMin[0] + P.boxSize[0] - ox) * ix;
         const float t3 = (P.boxMin[1] - oy) * iy, t4 = (P.boxMin[1] + P.boxSize[1] - oy) * iy;
         const float t5 = (P.boxMin[2] - oz) * iz, t6 = (P.boxMin[2] + P.boxSize[2] - oz) * iz;
         tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
         tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+        // position in unit-box coordinates as a function of t: p = pn0 + dn * t  (the reference evaluates ((o + d t) - boxMin) / boxSize,
+        // renderer_volume_tensorcores.cuh:746; same value up to fp32 rounding)
+        pn0x = (ox - P.boxMin[0]) * P.invBoxSize[0]; dnx = dx * P.invBoxSize[0];
+        pn0y = (oy - P.boxMin[1]) * P.invBoxSize[1]; dny = dy * P.invBoxSize[1];
+        pn0z = (oz - P.boxMin[2]) * P.invBoxSize[2]; dnz = dz * P.invBoxSize[2];
     }
     tmin = fmaxf(tmin, 0.f);  // stepping_dvr.cuh:66-67 (tmax input of the image evaluator is FLT_MAX)
     if (!inImage) tmax = -1.f;  // padding lanes never become valid
@@ -434,13 +443,6 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
         i0 = (n * seg) / K;
         if (seg + 1 < K) i1 = (n * (seg + 1)) / K;
     }
-
-    // position in unit-box coordinates as a function of t: p = pn0 + dn * t
-    // (the reference evaluates ((o + d t) - boxMin) / boxSize, renderer_volume_tensorcores.cuh:746; same value up
-    // to fp32 rounding, far below the fp16 quantisation the network applies to p)
-    const float pn0x = (ox - P.boxMin[0]) * P.invBoxSize[0], dnx = dx * P.invBoxSize[0];
-    const float pn0y = (oy - P.boxMin[1]) * P.invBoxSize[1], dny = dy * P.invBoxSize[1];
-    const float pn0z = (oz - P.boxMin[2]) * P.invBoxSize[2], dnz = dz * P.invBoxSize[2];
 
     float cr = 0, cg = 0, cb = 0, ca = 0, nx = 0, ny = 0, nz = 0, depth = 0;
     float previousDensity = -1.f;  // pre-integrated transfer functions (shaded kernel only), stepping_dvr.cuh:81
@@ -471,7 +473,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             // the global step index i0 + i as a float counter (exact below 2^24): one add per step instead of add + convert.
             // The lane predicates live as wave masks in scalar registers only (three v_cmp, two s_and): kept as `bool`s hipcc
             // materialises them in VGPRs across the network code (v_cndmask + v_cmp_ne per step).
-            t = tmin + stepIndex * S.stepsize;
+            t = fmaf(stepIndex, S.stepsize, tmin);
             validMask = __builtin_amdgcn_ballot_w64(t <= tmax) & __builtin_amdgcn_ballot_w64(stepIndex < stepEnd) &
                         __builtin_amdgcn_ballot_w64(ca < alphaLimit);
             stepIndex += 1.f;
@@ -479,10 +481,10 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
         } else {
             if (K > 1) {  // wave-uniform; kept as a branch so that the unsegmented loop does no per-lane index arithmetic
                 const int gi = i0 + i;
-                t = tmin + float(gi) * S.stepsize;
+                t = fmaf(float(gi), S.stepsize, tmin);
                 inRange = (t <= tmax) & (gi < i1);
             } else {
-                t = tmin + float(i) * S.stepsize;
+                t = fmaf(float(i), S.stepsize, tmin);
                 inRange = t <= tmax;
             }
             const bool notOpaque = ca < S.alphaEarlyOut;

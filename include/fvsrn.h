@@ -276,6 +276,13 @@ void fvsrn_scene_destroy(fvsrn_scene* scene);
 int fvsrn_camera_on_a_sphere(int orientation, const double center[3], double pitch, double yaw,
                              double distance, float eye[3], float right[3], float up[3]);
 
+/* How the last fvsrn_render / fvsrn_render_stripes of this scene treated the samples of a ray -- for callers that restate the
+ * arithmetic (the parity oracle): out = { depth segments K a ray was cut into (1: none; the step count of the feature rotation
+ * restarts in each), period in steps of the exact re-derivation of rotated Fourier features (0: the kernel derives the features
+ * from the fp16 position at every step, like the reference; FVSRN_OPT_FOURIER_RESYNC), 1 if a register-resident kernel ran,
+ * waves per workgroup }.  No reference counterpart. */
+int fvsrn_scene_last_render_info(fvsrn_scene* scene, int out[4]);
+
 /* ImageEvaluatorSimple::render  (renderer/image_evaluator_simple.cpp:198-361, kernel
  * ImageEvaluatorSimpleKernel renderer/renderer_image_evaluator_simple.cuh:36-127).
  * Renders image rows [y0,y1) of a width x height frame (aspect = width/height) into d_out8,

@@ -19,7 +19,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FVSRN_ORACLE_LIBRARY") or os.path.join(_HERE, "libsrn_oracle.so")  # override: the sanitizer build (tools/run_asan.sh)
 
-ACC_HALF, ACC_FLOAT = 0, 1
+ACC_HALF, ACC_FLOAT, ACC_DEVICE, ACC_EXACT = 0, 1, 2, 3
 ACTIVATIONS = {"ReLU": 0, "Sine": 1, "Snake": 2, "SnakeAlt": 3, "Sigmoid": 4}
 OUTPUT_MODES = {"density": 0, "density:direct": 1, "rgbo": 2, "rgbo:direct": 3, "densitygrad": 4,
                 "densitygrad:direct": 5, "densitygrad:cubic": 6, "densitycurvature": 7, "densitycurvature:direct": 8}
@@ -49,7 +49,8 @@ class _OracleScene(C.Structure):
                 ("brdfMagnitudeScaling", C.c_int), ("brdfPhong", C.c_int), ("brdfLightType", C.c_int),
                 ("brdfSpecularExponent", C.c_int), ("brdfMagScale", C.c_float), ("brdfAmbient", C.c_float),
                 ("brdfSpecular", C.c_float), ("brdfMagCenter", C.c_float), ("brdfMagRadius", C.c_float),
-                ("brdfLight", C.c_float * 3), ("tfPreintegration", C.c_int), ("tfPreintegrated", _FP), ("tfGaussianMode", C.c_int)]
+                ("brdfLight", C.c_float * 3), ("tfPreintegration", C.c_int), ("tfPreintegrated", _FP), ("tfGaussianMode", C.c_int),
+                ("rotationResync", C.c_int), ("segments", C.c_int)]
 
 
 _lib = None
@@ -291,9 +292,12 @@ class OracleScene:
     def __init__(self, *, eye, right, up, fov_y_radians, stepsize, density_min=0.0, density_max=1.0, early_out=True,
                  blend_mode=BLEND_BEER_LAMBERT, tf_kind=TF_IDENTITY, tf_scale_absorption=1.0, tf_scale_emission=1.0,
                  tf_table=None, gradient_mode=0, finite_differences_stepsize=0.0, brdf=None, tf_preintegration=0,
-                 adjoint_grid_stepsize=0.0, tf_gaussian_mode=0):
+                 adjoint_grid_stepsize=0.0, tf_gaussian_mode=0, rotation_resync=0, segments=1):
+        """rotation_resync / segments: only read by the ACC_DEVICE model (see srn_oracle.h, OracleScene)."""
         s = _OracleScene()
         s.tfGaussianMode = tf_gaussian_mode
+        assert rotation_resync >= 0 and (rotation_resync & (rotation_resync - 1)) == 0, "resync period: 0 or a power of two"
+        s.rotationResync, s.segments = int(rotation_resync), int(segments)
         s.eye[:] = [float(v) for v in eye]
         s.right[:] = [float(v) for v in right]
         s.up[:] = [float(v) for v in up]

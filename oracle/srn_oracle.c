@@ -26,8 +26,21 @@
  *           type half, bias pre-loaded, :849-858/:965-972), half activations, half Fourier chain,
  *           sequential hfma last layer.  A WMMA k=16 step is modelled as one exact dot product
  *           added to the accumulator and rounded to half once.
- *   FLOAT : what the MI355X kernels compute: same half-quantised inputs/weights/activations,
- *           but fp32 accumulation over the whole K, fp32 activations, exact Fourier phases.
+ *   FLOAT : the reference's network with the accumulation the MI355X kernels use: same half-quantised
+ *           inputs/weights/activations, but fp32 accumulation over the whole K, fp32 activations, exact
+ *           Fourier phases (from the fp16 position of every sample, like the reference).
+ *   DEVICE: FLOAT plus a statement of what the HIP kernels do in the Fourier stage (fv-srn_amd/csrc/pack.cpp,
+ *           srn_device.hpp; no reference counterpart, this is the kernels' own arithmetic): phases in
+ *           revolutions as an fp32 sum of exact fp16 x fp16 products of the position with a hi + lo split
+ *           of the matrix (2^-22 relative) and a whole-revolution centring constant; and, in the renderer
+ *           for 32-wide Fourier-only networks (OracleScene::rotationResync), features that are derived
+ *           from the fp16 position only every rotationResync steps and advanced in between by rotating
+ *           (cos, sin) with the per-step phase increment -- i.e. they follow the UN-rounded ray there.
+ *           The parity tests hold the HIP path against this model with one absolute tolerance, and this
+ *           model against FLOAT / HALF as the reference-side bars.
+ *   EXACT : the network itself: the stored fp16 weights, everything else in fp32 / double -- positions, Fourier
+ *           features, latent features and activations are NOT rounded to half (forward path only).  This is what
+ *           the reference's PyTorch model computes in fp32; it ranks the other three models.
  * The pinning of this file against the reference's own Python implementation lives in
  * tests/test_oracle_golden.py (golden vectors made by tests/golden/make_golden.py).
  */
@@ -101,6 +114,9 @@ static float hfma(float a, float b, float c) { return rh_d((double)a * (double)b
 static float hdivf(float a, float b) { return rh_d((double)a / (double)b); }
 static float hcosf(float a) { return rh_d(cos((double)a)); }
 static float hsinf(float a) { return rh_d(sin((double)a)); }
+/* the fp16 roundings of inputs, features and activations that FLOAT / DEVICE share with the reference; EXACT leaves them out */
+static float rq(const OracleNet* n, float v) { return n->accMode == ORACLE_ACC_EXACT ? v : rh(v); }
+static float rq_d(const OracleNet* n, double v) { return n->accMode == ORACLE_ACC_EXACT ? (float)v : rh_d(v); }
 
 /* ------------------------------------------------------------------------------------ activations */
 /* half versions: renderer_activations.cuh (ReLU :40-60, Sine :97-120, Sigmoid :152-179, Snake :263-285, SnakeAlt :329-358) */
@@ -199,7 +215,7 @@ static void grid_features(const OracleNet* n, const float p[3], int chunk, float
         const float f = time - floorf(time);
         for (int c = 0; c < 4; ++c) {
             const float va = decode_grid(n, a[c], 4 * t + c), vb = decode_grid(n, b[c], 4 * t + c);
-            out16[4 * i + c] = rh(va + f * (vb - va));
+            out16[4 * i + c] = rq(n, va + f * (vb - va));
         }
     }
 }
@@ -227,7 +243,7 @@ static void dense_layer_tape(const OracleNet* n, const uint16_t* W, const uint16
             double s = h2f(b[o]);
             for (int k = 0; k < cin; ++k) s += (double)h2f(w[k]) * (double)x[k];
             if (pre) pre[o] = (float)s;
-            r = rh(act_float(n->activation, (float)s, n->actParam));
+            r = rq(n, act_float(n->activation, (float)s, n->actParam));
         }
         y[o] = r;
     }
@@ -239,22 +255,41 @@ static void dense_layer(const OracleNet* n, const uint16_t* W, const uint16_t* b
 static float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 static float softplusf_(float x) { return x > 20.f ? x : logf(1.f + expf(x)); }
 
-/* eval<>: world position (+ view direction) -> out[0..3] = value (1 or 4 channels used), nrm[3] = predicted normal */
-static void srn_eval(const OracleNet* n, const float wpos[3], const float dir[3], float out[4], float nrm[3], float curv[2]) {
-    const int C = n->C, F = n->F, G = n->G;
+/* ORACLE_ACC_DEVICE: phase of Fourier feature i in REVOLUTIONS the way the kernels' phase MFMA computes it (pack.cpp: matrix entry
+ * / 2 pi split into two halves hi + lo, the constant slot carries minus the integer nearest to the centre of the feature's phase
+ * range over the unit box / directions in [-1,1]; srn_device.hpp: B operand = the fp16 inputs; exact products, fp32 sum).
+ * in6: fp16 values (as floats) of x, y, z, dx, dy, dz -- a position or, for the per-step rotation, a position increment */
+static float device_phase_rev(const OracleNet* n, int i, const float in6[6]) {
+    const int F = n->F, cols = n->useDirection == 2 ? 6 : 3;
+    double lo = 0, hi = 0, sum = 0;
+    for (int c = 0; c < cols; ++c) {
+        const double v = (double)h2f(n->fourier[i + (size_t)F * c]) / (2.0 * 3.14159265358979323846);
+        const float vh = rh((float)v);
+        const float vl = rh((float)(v - (double)vh));
+        sum += (double)vh * in6[c] + (double)vl * in6[c];
+        if (c < 3) { lo += v < 0 ? v : 0; hi += v > 0 ? v : 0; }
+        else { lo -= fabs(v); hi += fabs(v); }
+    }
+    const double konst = -nearbyint(0.5 * (lo + hi));
+    const float kh = rh((float)konst);
+    const float kl = rh((float)(konst - (double)kh));
+    return (float)(sum + (double)kh + (double)kl);
+}
+
+/* The padded input vector x[0 .. C) of the first layer: [x, y, z, (time | 0), (dx, dy, dz, 0), cos(0..F-1), sin(0..F-1)] as fp16
+ * values, from the normalized position p (renderer_volume_tensorcores.cuh:768-808) */
+static void fourier_inputs(const OracleNet* n, const float p[3], const float dir[3], float* x) {
+    const int F = n->F;
     const int base = n->useDirection >= 1 ? 8 : 4; /* fourierOffset :794 */
-    float p[3];
-    for (int i = 0; i < 3; ++i) p[i] = (wpos[i] - n->boxMin[i]) / n->boxSize[i]; /* :746 */
-    float x[ORACLE_MAX_C + 64], y[ORACLE_MAX_C];
-    /* Fourier layer :768-808 */
-    const float vx = rh(p[0]), vy = rh(p[1]), vz = rh(p[2]);
+    const float vx = rq(n, p[0]), vy = rq(n, p[1]), vz = rq(n, p[2]);
     x[0] = vx; x[1] = vy; x[2] = vz;
-    x[3] = n->passTime ? rh(n->gridInterpolation[0]) : 0.f;
+    x[3] = n->passTime ? rq(n, n->gridInterpolation[0]) : 0.f;
     float dxh = 0, dyh = 0, dzh = 0;
     if (n->useDirection >= 1) { /* :784-792 */
-        dxh = rh(dir[0]); dyh = rh(dir[1]); dzh = rh(dir[2]);
+        dxh = rq(n, dir[0]); dyh = rq(n, dir[1]); dzh = rq(n, dir[2]);
         x[4] = dxh; x[5] = dyh; x[6] = dzh; x[7] = 0.f;
     }
+    const float in6[6] = {vx, vy, vz, dxh, dyh, dzh};
     for (int i = 0; i < F; ++i) {
         const float f0 = h2f(n->fourier[i]), f1 = h2f(n->fourier[i + F]), f2 = h2f(n->fourier[i + 2 * F]);
         const int d6 = n->useDirection == 2; /* USE_DIRECTION==2: direction inside the Fourier matrix :800-804 */
@@ -267,13 +302,33 @@ static void srn_eval(const OracleNet* n, const float wpos[3], const float dir[3]
             if (d6) { c = hfma(dxh, f3, c); c = hfma(dyh, f4, c); c = hfma(dzh, f5, c); }
             x[base + i] = hcosf(c);
             x[base + F + i] = hsinf(c);
+        } else if (n->accMode == ORACLE_ACC_DEVICE) {
+            const double c = 2.0 * 3.14159265358979323846 * (double)device_phase_rev(n, i, in6);
+            x[base + i] = rh((float)cos(c));      /* v_cos_f32 / v_sin_f32 of the fp32 phase, then v_cvt_pk_f16_f32 */
+            x[base + F + i] = rh((float)sin(c));
         } else {
             double c = (double)vx * f0 + (double)vy * f1 + (double)vz * f2;
             if (d6) c += (double)dxh * f3 + (double)dyh * f4 + (double)dzh * f5;
-            x[base + i] = rh_d(cos(c));
-            x[base + F + i] = rh_d(sin(c));
+            x[base + i] = rq_d(n, cos(c));
+            x[base + F + i] = rq_d(n, sin(c));
         }
     }
+}
+
+/* eval<>: world position (+ view direction) -> out[0..3] = value (1 or 4 channels used), nrm[3] = predicted normal
+ * xFeat != NULL: the first layer's padded input vector (fourier_inputs) is given; pNorm != NULL: the normalized position is given */
+static void srn_eval_x(const OracleNet* n, const float wpos[3], const float dir[3], const float* xFeat, const float* pNorm, float out[4], float nrm[3],
+                       float curv[2]) {
+    const int C = n->C, F = n->F, G = n->G;
+    float p[3];
+    for (int i = 0; i < 3; ++i) p[i] = pNorm ? pNorm[i] : (wpos[i] - n->boxMin[i]) / n->boxSize[i]; /* :746; pNorm: the renderer's DEVICE model */
+    float x[ORACLE_MAX_C + 64], y[ORACLE_MAX_C];
+    /* Fourier layer :768-808 */
+    const float vx = rq(n, p[0]), vy = rq(n, p[1]), vz = rq(n, p[2]);
+    float dxh = 0, dyh = 0, dzh = 0;
+    if (n->useDirection >= 1) { dxh = rq(n, dir[0]); dyh = rq(n, dir[1]); dzh = rq(n, dir[2]); } /* :784-792 */
+    if (xFeat) memcpy(x, xFeat, sizeof(float) * (size_t)C); /* ORACLE_ACC_DEVICE: rotated features of the renderer (render_pixel) */
+    else fourier_inputs(n, p, dir, x);
     if (F == 0) { /* no Fourier features: scalar first layer :810-823, weights [cin][cout], half fma chain */
         for (int co = 0; co < C; ++co) {
             float r;
@@ -293,7 +348,7 @@ static void srn_eval(const OracleNet* n, const float wpos[3], const float dir[3]
                 c += (double)vx * h2f(n->wFirst[co + C * 0]) + (double)vy * h2f(n->wFirst[co + C * 1]) + (double)vz * h2f(n->wFirst[co + C * 2]);
                 if (n->useDirection >= 1)
                     c += (double)dxh * h2f(n->wFirst[co + C * 3]) + (double)dyh * h2f(n->wFirst[co + C * 4]) + (double)dzh * h2f(n->wFirst[co + C * 5]);
-                r = rh(act_float(n->activation, (float)c, n->actParam));
+                r = rq(n, act_float(n->activation, (float)c, n->actParam));
             }
             y[co] = r;
         }
@@ -350,6 +405,10 @@ static void srn_eval(const OracleNet* n, const float wpos[3], const float dir[3]
             break;
         default: break;
     }
+}
+
+static void srn_eval(const OracleNet* n, const float wpos[3], const float dir[3], float out[4], float nrm[3], float curv[2]) {
+    srn_eval_x(n, wpos, dir, NULL, NULL, out, nrm, curv);
 }
 
 /* ------------------------------------------------------------------------------------ adjoint method */
@@ -740,18 +799,20 @@ void oracle_tf_evaluate(const OracleScene* s, const float* density, const float*
 /* ------------------------------------------------------------------------------------------- DVR */
 static void render_pixel(const OracleNet* n, const OracleScene* s, int W, int H, int x, int y, float px8[8],
                          unsigned long long* samples) {
-    /* renderer_image_evaluator_simple.cuh:84-88 */
+    /* Camera ray (renderer_image_evaluator_simple.cuh:84-88, renderer_camera.cuh:41-52) and box test (renderer_utils.cuh:91-105).
+     * The reference leaves the contraction of these expressions to nvcc; here they are spelled out operation by operation (explicit
+     * fma's, correctly rounded division / square root; this file is compiled with -ffp-contract=off) in exactly the sequence of the HIP
+     * kernels (fv-srn_amd/csrc/kernels.hpp, render_body), so that the sample positions of the two are bit-identical. */
     const float ndcx = 2 * ((float)x + 0.5f) / (float)W - 1, ndcy = 2 * ((float)y + 0.5f) / (float)H - 1;
-    /* renderer_camera.cuh:41-52 */
     const float tanFovY = tanf(s->fovY / 2), tanFovX = tanFovY * ((float)W / (float)H);
     const float* eye = s->eye; const float* right = s->right; const float* up = s->up;
     const float front[3] = {up[1] * right[2] - up[2] * right[1], up[2] * right[0] - up[0] * right[2],
                             up[0] * right[1] - up[1] * right[0]};
+    const float ax = ndcx * tanFovX, ay = ndcy * tanFovY;
     float dir[3];
-    for (int i = 0; i < 3; ++i) dir[i] = front[i] + ndcx * tanFovX * right[i] + ndcy * tanFovY * up[i];
-    const float il = 1.0f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    for (int i = 0; i < 3; ++i) dir[i] = fmaf(ay, up[i], fmaf(ax, right[i], front[i]));
+    const float il = 1.0f / sqrtf(fmaf(dir[2], dir[2], fmaf(dir[1], dir[1], dir[0] * dir[0])));
     for (int i = 0; i < 3; ++i) dir[i] *= il;
-    /* renderer_utils.cuh:91-105 */
     float tlo[3], thi[3];
     for (int i = 0; i < 3; ++i) {
         const float inv = 1.0f / dir[i];
@@ -768,14 +829,64 @@ static void render_pixel(const OracleNet* n, const OracleScene* s, int W, int H,
     float col[4] = {0, 0, 0, 0}, nacc[3] = {0, 0, 0}, depth = 0;
     float previousDensity = -1.f; /* :81 */
     unsigned long long cnt = 0;
+    /* ORACLE_ACC_DEVICE with OracleScene::rotationResync: the kernels' feature rotation (fv-srn_amd/csrc/kernels.hpp render_body,
+     * srn_device.hpp fourier_advance_piece), stated step by step.  feat / dfeat: the first layer's padded input vector in fp32 and
+     * its per-step increment (positions: additive; (cos, sin) pairs: the rotation by the phase increment of one step). */
+    const int rotate = n->accMode == ORACLE_ACC_DEVICE && s->rotationResync > 0 && n->F > 0 && n->G == 0;
+    const int K = s->segments > 1 ? s->segments : 1;
+    const int nsteps = (tmax - tmin) >= 0.f ? (int)((tmax - tmin) / s->stepsize) + 1 : 0; /* the host's cut of a ray into K step ranges */
+    float feat[ORACLE_MAX_C], dfeat[ORACLE_MAX_C], xrot[ORACLE_MAX_C];
+    float pn0[3], dn[3];
+    for (int k = 0; k < 3; ++k) { /* the kernels' p(t) = pn0 + dn t in unit-box coordinates */
+        const float inv = 1.0f / n->boxSize[k];
+        pn0[k] = (eye[k] - n->boxMin[k]) * inv;
+        dn[k] = dir[k] * inv;
+    }
     for (int i = 0;; ++i) { /* :84-154, per-lane view of the warp-synchronous loop */
-        const float t = tmin + (float)i * s->stepsize;
+        const float t = fmaf((float)i, s->stepsize, tmin); /* tmin + i * stepsize, one rounding (kernels.hpp) */
         const int valid = (t <= tmax) && (!s->earlyOut || col[3] < alphaEarlyOut);
         if (!valid) break; /* later iterations of an invalid lane never blend (:151) and never turn valid again */
         ++cnt;
         const float pos[3] = {eye[0] + dir[0] * t, eye[1] + dir[1] * t, eye[2] + dir[2] * t};
         float v[4], g[3], cv[2], c[4] = {0, 0, 0, 0};
-        srn_eval(n, pos, dir, v, g, cv);
+        /* DEVICE: the kernels evaluate p(t) = pn0 + dn t with one fma per axis (kernels.hpp) instead of ((o + d t) - boxMin) / boxSize */
+        const float pd[3] = {fmaf(dn[0], t, pn0[0]), fmaf(dn[1], t, pn0[1]), fmaf(dn[2], t, pn0[2])};
+        if (rotate) {
+            const int F = n->F, base = n->useDirection >= 1 ? 8 : 4, C = n->C;
+            int seg = 0; /* the step range [nsteps seg / K, nsteps (seg + 1) / K) that holds step i; the last one is open */
+            while (seg + 1 < K && (nsteps * (seg + 1)) / K <= i) ++seg;
+            const int local = i - (nsteps * seg) / K;
+            if ((local & (s->rotationResync - 1)) == 0) {
+                for (int pass = (local == 0 ? 1 : 0); pass >= 0; --pass) { /* pass 1: the per-step increment, once per ray and segment */
+                    float* f = pass ? dfeat : feat;
+                    float in6[6] = {0, 0, 0, 0, 0, 0};
+                    for (int k = 0; k < 3; ++k) in6[k] = rh(pass ? dn[k] * s->stepsize : pd[k]);
+                    if (!pass && n->useDirection >= 1) for (int k = 0; k < 3; ++k) in6[3 + k] = rh(dir[k]);
+                    for (int k = 0; k < C; ++k) f[k] = 0.f;
+                    f[0] = in6[0]; f[1] = in6[1]; f[2] = in6[2];
+                    f[3] = (!pass && n->passTime) ? rh(n->gridInterpolation[0]) : 0.f;
+                    if (n->useDirection >= 1) { f[4] = in6[3]; f[5] = in6[4]; f[6] = in6[5]; }
+                    for (int q = 0; q < F; ++q) {
+                        const double ph = 2.0 * 3.14159265358979323846 * (double)device_phase_rev(n, q, in6);
+                        f[base + q] = (float)cos(ph);
+                        f[base + F + q] = (float)sin(ph);
+                    }
+                }
+            }
+            for (int k = 0; k < C; ++k) xrot[k] = rh(feat[k]); /* v_cvt_pk_f16_f32 of the current features */
+            for (int k = 0; k < base; ++k) feat[k] += dfeat[k];  /* advance to the next sample: positions ... */
+            for (int q = 0; q < F; ++q) {                        /* ... and c' = c cd - s sd, s' = s cd + c sd (v_pk_mul_f32 + v_pk_fma_f32) */
+                const float cc = feat[base + q], ss = feat[base + F + q], cd = dfeat[base + q], sd = dfeat[base + F + q];
+                const float t0 = cc * cd, t1 = ss * cd;
+                feat[base + q] = fmaf(ss, -sd, t0);
+                feat[base + F + q] = fmaf(cc, sd, t1);
+            }
+            srn_eval_x(n, pos, dir, xrot, pd, v, g, cv);
+        } else if (n->accMode == ORACLE_ACC_DEVICE) {
+            srn_eval_x(n, pos, dir, NULL, pd, v, g, cv);
+        } else {
+            srn_eval(n, pos, dir, v, g, cv);
+        }
         if (rgbo) {
             c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3] * s->stepsize; /* :104-108 */
         } else {
@@ -867,9 +978,10 @@ unsigned long long oracle_count_samples(const OracleNet* n, const OracleScene* s
             const float* right = s->right; const float* up = s->up;
             const float front[3] = {up[1] * right[2] - up[2] * right[1], up[2] * right[0] - up[0] * right[2],
                                     up[0] * right[1] - up[1] * right[0]};
+            const float ax = ndcx * tanFovX, ay = ndcy * tanFovY; /* the sequence of render_pixel */
             float dir[3];
-            for (int i = 0; i < 3; ++i) dir[i] = front[i] + ndcx * tanFovX * right[i] + ndcy * tanFovY * up[i];
-            const float il = 1.0f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+            for (int i = 0; i < 3; ++i) dir[i] = fmaf(ay, up[i], fmaf(ax, right[i], front[i]));
+            const float il = 1.0f / sqrtf(fmaf(dir[2], dir[2], fmaf(dir[1], dir[1], dir[0] * dir[0])));
             float tmin = -INFINITY, tmax = INFINITY;
             for (int i = 0; i < 3; ++i) {
                 const float inv = 1.0f / (dir[i] * il);
@@ -879,7 +991,7 @@ unsigned long long oracle_count_samples(const OracleNet* n, const OracleScene* s
             }
             tmin = fmaxf(tmin, 0.f);
             for (int i = 0;; ++i) {
-                if (!(tmin + (float)i * s->stepsize <= tmax)) break;
+                if (!(fmaf((float)i, s->stepsize, tmin) <= tmax)) break;
                 ++total;
             }
         }

@@ -8,7 +8,9 @@
 extern "C" {
 #endif
 
-enum { ORACLE_ACC_HALF = 0, ORACLE_ACC_FLOAT = 1 };
+/* arithmetic models, see srn_oracle.c.  DEVICE = FLOAT + the MI355X kernels' statement of the Fourier stage (phases in revolutions
+ * from a hi + lo fp16 split of the matrix, fp32 sum; with OracleScene::rotationResync the features advance along a ray by rotation) */
+enum { ORACLE_ACC_HALF = 0, ORACLE_ACC_FLOAT = 1, ORACLE_ACC_DEVICE = 2, ORACLE_ACC_EXACT = 3 /* no fp16 rounding of inputs / activations */ };
 enum { ORACLE_ACT_RELU = 0, ORACLE_ACT_SINE = 1, ORACLE_ACT_SNAKE = 2, ORACLE_ACT_SNAKEALT = 3, ORACLE_ACT_SIGMOID = 4 };
 enum {
     ORACLE_OUT_DENSITY = 0, ORACLE_OUT_DENSITY_DIRECT = 1, ORACLE_OUT_RGBO = 2, ORACLE_OUT_RGBO_DIRECT = 3,
@@ -66,6 +68,12 @@ typedef struct {
     const float* tfPreintegrated;
     /* TRANSFER_FUNCTION_GAUSSIAN__SCALE_WITH_GRADIENT (1) / __ANALYTIC (2), renderer_tf_gaussian.cuh:55-73; 0: neither */
     int tfGaussianMode;
+    /* ORACLE_ACC_DEVICE only -- what fv-srn_amd/csrc/kernels.hpp (render_body) does to 32-wide Fourier-only networks: the input
+     * features are derived from the fp16-rounded position every rotationResync steps of a depth segment and advanced by the
+     * rotation of the per-step phase increment in between (0: derived at every step, like the reference); `segments` = the K
+     * consecutive step ranges a ray was cut into (the step count restarts in each; <= 1: none).  fvsrn_scene_last_render_info
+     * reports both for a render. */
+    int rotationResync, segments;
 } OracleScene;
 /* tex [R][4] -> out [R][4] (mode 1) or [R][R][4] (mode 2, N quadrature steps, world step size) */
 /* EvaluateTF / EvaluateTFWithPrevious (renderer_tf_kernels.cuh:11-70) with the scene's TF, density range and step size;

@@ -26,7 +26,7 @@ def draw_case(seed):
     # NeRF frequency ladder (2 pi 2^k, network.py:55-63) or a smooth random Fourier matrix, for every activation.  Random weights
     # behind the ladder and a periodic activation are sensitive to the position at the 1e-4 level: there the reference's own
     # fp16 arithmetic (phases in half, renderer_volume_tensorcores.cuh:797-806) moves colours by percents against an fp32
-    # evaluation of the same network, see the tolerance in test_random_scene_matches_oracle.
+    # evaluation of the same network (the FLOAT / HALF spread of compare_case).
     net = dict(C=C, layers=layers, activation=act, param=1.0, output_mode=out, grid=grid, seed=int(rng.randint(1 << 20)),
                box_min=(-0.5, -0.5, -0.5), fourier_std=0.4 if rng.rand() < 0.5 else None)
     eye, right, up = oracle.camera_on_a_sphere(str(rng.choice(["Ym", "Zp", "Xm"])), (0, 0, 0), float(rng.uniform(-0.6, 0.6)),
@@ -62,8 +62,16 @@ def draw_case(seed):
 
 
 def compare_case(seed, scene_options=None):
-    """-> (max |rgba+normal| difference GPU vs oracle fp32-accumulate model, the same between the oracle's fp16-accumulate
-    (reference CUDA arithmetic) and fp32-accumulate models, info string, img, ref, stats, count)"""
+    """Renders fuzz case `seed` on the GPU and with the oracle's three arithmetic models.  Returns a dict:
+      err_device  max |rgba + normal| GPU vs the DEVICE model -- the oracle's statement of the kernels' own arithmetic: fp32
+                  accumulation, hi + lo phase matrix, and (32-wide Fourier-only networks) features that are re-derived from the fp16
+                  position every `rotation_resync` steps of each of the `segments` step ranges of a ray and rotated in between;
+                  both numbers come from the library (fvsrn_scene_last_render_info), nothing is re-derived here
+      err_float   the same against the FLOAT model (the reference's per-sample fp16 positions, fp32 accumulation)
+      spread      FLOAT vs HALF model (the reference's own CUDA arithmetic)
+      model_gap   DEVICE vs FLOAT model: what the kernels' statement costs against the reference's position rounding
+      to_exact    distances of GPU / DEVICE / FLOAT / HALF from the EXACT model (the network itself: fp16 weights, nothing else
+                  rounded to half -- what the reference's PyTorch model computes): the reference-side bar"""
     import torch
     from fvsrn_amd import capi, volnet_io
     net_kw, scene_kw, W, H = draw_case(seed)
@@ -74,64 +82,80 @@ def compare_case(seed, scene_options=None):
     for k, v in (scene_options or {}).items():
         scene.set_option(k, v)
     img = scene.render(net, W, H, stats=stats)[0].cpu().numpy()
-    ref, count = oracle.OracleScene(**scene_kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), W, H)
+    plan = scene.last_render_info()
+    dev, count = oracle.OracleScene(rotation_resync=plan["rotation_resync"], segments=plan["segments"], **scene_kw).render(
+        oracle.OracleNetwork(vn, oracle.ACC_DEVICE), W, H)
+    ref, _ = oracle.OracleScene(**scene_kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), W, H)
     ref_h, _ = oracle.OracleScene(**scene_kw).render(oracle.OracleNetwork(vn, oracle.ACC_HALF), W, H)
-    info = "%s | %s | %s" % ({k: v for k, v in net_kw.items() if k != "box_min"},
-                             {k: v for k, v in scene_kw.items() if k not in ("eye", "right", "up", "tf_table")}, net.kernel_name(True)[:32])
-    return float(np.abs(img[:7] - ref[:7]).max()), float(np.abs(ref_h[:7] - ref[:7]).max()), info, img, ref, stats.cpu().numpy(), count, scene_kw
+    exact, _ = oracle.OracleScene(**scene_kw).render(oracle.OracleNetwork(vn, oracle.ACC_EXACT), W, H)
+    info = "%s | %s | %s | %s" % ({k: v for k, v in net_kw.items() if k != "box_min"},
+                                  {k: v for k, v in scene_kw.items() if k not in ("eye", "right", "up", "tf_table")}, net.kernel_name(True)[:32], plan)
+    d = lambda a, b: float(np.abs(a[:7] - b[:7]).max())  # noqa: E731
+    return dict(err_device=d(img, dev), err_float=d(img, ref), spread=d(ref_h, ref), model_gap=d(dev, ref), info=info, img=img, dev=dev, ref=ref,
+                to_exact=dict(gpu=d(img, exact), device=d(dev, exact), float=d(ref, exact), half=d(ref_h, exact)),
+                stats=stats.cpu().numpy(), count=count, scene_kw=scene_kw, plan=plan)
+
+
+REFERENCE_SIDE_FACTOR = 2.0
+
+
+def tolerance(r):
+    """ONE absolute tolerance: the image tolerance of test_gpu_parity.py.  r03, 400 random scenes (profiles/r03/fuzz_report_gpu_vs_device_model.txt):
+    worst 2.6e-3, 398 of 400 below 1.6e-3 -- including the networks that are chaotic in their own fp16 roundings (2^9 ladder +
+    periodic activation: FLOAT vs HALF up to 2.3e-1), because the DEVICE model and the kernels evaluate bit-identical sample positions
+    and state the same Fourier arithmetic.  (r02 needed max(3e-3, FLOAT-vs-HALF spread) and still pinned six outliers at 2e-2.)"""
+    return TOL_IMG
+
+
+def check_case(r):
+    """(1) Against the stated arithmetic of the kernels (DEVICE model): tolerance(r), NaN pattern and depth always checked.
+    (2) The reference-side bar: measured against the network itself (EXACT model) the GPU image is inside max(3e-3, twice the
+    distance of the reference's own arithmetic models -- FLOAT: fp32 accumulation, HALF: the CUDA kernel's fp16 accumulation -- from
+    it): the rotated features follow the un-rounded ray between two re-derivations, which is one more noise term of the size of the
+    fp16 rounding of positions and activations that all models share, not a different result (tests/test_oracle_models.py
+    states the same for the DEVICE model on CPU)."""
+    info, img, dev, e = r["info"], r["img"], r["dev"], r["to_exact"]
+    assert r["err_device"] < tolerance(r), "%s: |gpu - DEVICE model| %.2e, tolerance %.2e (|gpu - FLOAT| %.2e, FLOAT vs HALF %.2e)" % (
+        info, r["err_device"], tolerance(r), r["err_float"], r["spread"])
+    solid = dev[3] > 1e-4
+    assert np.array_equal(np.isnan(img[7])[solid], np.isnan(dev[7])[solid]), info
+    if solid.any():
+        assert np.nanmax(np.abs(img[7] - dev[7])[solid]) < 10 * tolerance(r), info
+    assert e["gpu"] < max(TOL_IMG, REFERENCE_SIDE_FACTOR * max(e["float"], e["half"])), "%s: distances from the exact network: %s" % (info, e)
+    if not r["scene_kw"]["early_out"]:
+        assert int(r["stats"][0]) == r["count"], info  # lane-exact evaluated samples (early-out may stop a step apart at the threshold)
 
 
 @pytest.mark.parametrize("seed", range(32))
 def test_random_scene_matches_oracle(seed):
-    """Tolerance: the image tolerance of test_gpu_parity.py (3e-3), or -- for networks on which the reference's own two arithmetic
-    models disagree by more than that -- the distance between the oracle's fp16-accumulate model (the reference's CUDA arithmetic:
-    phases and sums in half) and its fp32-accumulate model on this very image: the HIP path is never farther from the fp32-accumulate
-    restatement than the reference's own renderer is.  (The one modelled difference: between two exact re-derivations the kernels'
-    rotated Fourier features follow the un-rounded ray position, the reference rounds every position to fp16 -- scene option
-    fourier_resync = 1 removes it, see test_random_scene_with_per_step_features.)"""
-    err, spread, info, img, ref, stats, count, scene_kw = compare_case(seed)
-    solid = ref[3] > 1e-4
-    assert err < max(TOL_IMG, spread), "%s: |gpu - oracle| %.2e, oracle fp16 vs fp32 model %.2e" % (info, err, spread)
-    if err < TOL_IMG:
-        assert np.array_equal(np.isnan(img[7])[solid], np.isnan(ref[7])[solid]), info
-        if solid.any():
-            assert np.nanmax(np.abs(img[7] - ref[7])[solid]) < 3e-2, info
-    if not scene_kw["early_out"]:
-        assert int(stats[0]) == count, info  # lane-exact evaluated samples (early-out may stop a step apart at the threshold)
+    check_case(compare_case(seed))
 
 
-# Seeds of a 400-scene run of this fuzz (profiles/r02/fuzz_report_gpu_vs_oracle.txt) that miss the criterion above: 6 of 400, all 32-wide
-# NeRF-ladder networks whose features the kernels advance by rotation.
-ROTATION_OUTLIERS = [88, 92, 114, 136, 226, 288]
+# Six seeds of the 400-scene run of r02 (profiles/r02/fuzz_report_gpu_vs_oracle.txt) on which the rotated features of the kernels were
+# 3.5e-3 .. 1.6e-2 away from the FLOAT model (per-sample fp16 positions): the same fixed tolerance against the DEVICE model.
+@pytest.mark.parametrize("seed", [88, 92, 114, 136, 226, 288])
+def test_random_scene_matches_oracle_on_the_r02_outliers(seed):
+    check_case(compare_case(seed))
 
 
-@pytest.mark.parametrize("seed", ROTATION_OUTLIERS)
-def test_rotation_outliers_are_bounded_and_vanish_with_per_step_features(seed):
-    """What the rotation costs in parity, at its worst: the reference rounds every sample position to fp16 before the Fourier stage, a
-    phase error of up to 0.4 rad in the top octave of a 10-octave ladder -- noise that a rotated feature (exact increments from the last
-    re-derived position) does not follow.  On 6 of 400 random scenes that exceeds both 3e-3 and the distance between the reference's own
-    two arithmetic models (measured 3.5e-3 .. 1.6e-2 against model spreads of 1.9e-3 .. 8.6e-3); with the features re-derived at every
-    step (scene option fourier_resync = 1, the reference's arithmetic) the same scenes agree to <= 7e-4."""
-    err, spread, info, *_ = compare_case(seed)
-    assert err < 2e-2, "%s: |gpu - oracle| %.2e (model spread %.2e)" % (info, err, spread)
-    err1 = compare_case(seed, {"fourier_resync": 1})[0]
-    assert err1 < 1e-3, "%s: |gpu - oracle| %.2e with per-step features" % (info, err1)
-
-
-@pytest.mark.parametrize("seed", [1, 6, 13, 14, 21, 30, 31])
+@pytest.mark.parametrize("seed", [1, 6, 13, 14, 21, 30, 31, 88, 136, 288])
 def test_random_scene_with_per_step_features(seed):
-    """The 32-wide Fourier-only cases of the fuzz (the networks whose Fourier features the kernels advance by rotation), rendered
-    with exact features at every step (scene option fourier_resync = 1: the fp16 position of every sample, like the reference):
-    the plain image tolerance holds with a wide margin (measured r02: <= 5e-4 where the default gives up to 4e-3), i.e. the whole
-    deviation of those cases is the un-rounded position between two re-derivations.  (The 64-wide ladder cases 23 / 24 / 26 do
-    not rotate; their 4e-3 .. 8e-3 against a model spread of 4e-2 .. 2e-1 is the 2^-22 phase accuracy of the hi/lo phase MFMA
-    at 512 revolutions behind a chaotic network.)"""
-    err, spread, info, *_ = compare_case(seed, {"fourier_resync": 1})
-    assert err < TOL_IMG, "%s: |gpu - oracle| %.2e with per-step features (oracle fp16 vs fp32 model %.2e)" % (info, err, spread)
+    """The reference-exact mode of the renderer (scene option fourier_resync = 1: features from the fp16 position of every sample,
+    no rotation) on the 32-wide Fourier-only cases: the DEVICE model then differs from FLOAT only by the 2^-22 phase matrix, and
+    the GPU image is inside the plain image tolerance of the FLOAT model too."""
+    r = compare_case(seed, {"fourier_resync": 1})
+    assert r["plan"]["rotation_resync"] in (0, 1)
+    check_case(r)
+    assert r["err_float"] < TOL_IMG, "%s: |gpu - FLOAT model| %.2e with per-step features" % (r["info"], r["err_float"])
 
 
 if __name__ == "__main__":  # developer report: python tests/test_fuzz_parity.py [n]  (GPU box)
+    worst = 0.0
     for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 32):
-        err, spread, info, *_ = compare_case(seed)
-        err1 = compare_case(seed, {"fourier_resync": 1})[0]
-        print("%2d  gpu-oracle %.2e (per-step features %.2e)  fp16-vs-fp32 models %.2e  %s  %s" % (seed, err, err1, spread, "OK" if err < max(TOL_IMG, spread) else "FAIL", info))
+        r = compare_case(seed)
+        e = r["to_exact"]
+        ok = r["err_device"] < tolerance(r) and e["gpu"] < max(TOL_IMG, REFERENCE_SIDE_FACTOR * max(e["float"], e["half"]))
+        worst = max(worst, r["err_device"])
+        print("%3d  gpu-DEVICE %.2e  gpu-FLOAT %.2e  DEVICE-FLOAT %.2e  FLOAT-HALF %.2e  to EXACT: gpu %.2e device %.2e float %.2e half %.2e  %s  %s" % (
+            seed, r["err_device"], r["err_float"], r["model_gap"], r["spread"], e["gpu"], e["device"], e["float"], e["half"], "OK" if ok else "FAIL", r["info"]))
+    print("worst |gpu - DEVICE model| = %.2e" % worst)

@@ -147,7 +147,9 @@ def test_texture_tf_with_negative_opacity_texels(grid):
     vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density", seed=56, box_min=(-0.5, -0.5, -0.5), grid=grid,
                              grid_scale=0.3)
     tab = np.random.RandomState(8).uniform(0.0, 1.0, (48, 4)).astype(np.float32)
-    tab[:, 3] = 30.0 * np.cos(np.linspace(0, 6 * np.pi, 48))  # opacity changes sign every 8 texels
+    # opacity +, -, -, +, ...: both signs inside any density interval of 0.06 (a moderate amplitude: the slope of this table turns an
+    # fp16-level difference of the density into 500 times as much opacity)
+    tab[:, 3] = 10.0 * np.cos(np.arange(48) * np.pi / 2 + np.pi / 4)
     kw = make_scene_kwargs(stepsize=1 / 96, early_out=True, tf_kind=oracle.TF_TEXTURE, tf_table=tab)
     net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
     ref, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), 96, 64)
@@ -155,7 +157,7 @@ def test_texture_tf_with_negative_opacity_texels(grid):
         img = capi.Scene(**kw).set_option("small_kernel", small).render(net, 96, 64)
         torch.cuda.synchronize()
         assert_images_close(img.cpu().numpy()[0], ref, TOL_IMG)
-    assert ref[3].min() >= 0.0 and ref[3].max() > 0.2
+    assert ref[3].min() >= 0.0 and ref[3].max() > 0.04
 
 
 def test_two_rank_processes_share_the_gpu_and_assemble_the_frame():
