@@ -87,6 +87,7 @@ SYMBOLS = [
     ("fvsrn_network_valid", _I, [_VP]),
     ("fvsrn_network_save_volnet", _I, [_VP, _VP, _SZ, C.POINTER(_SZ)]),
     ("fvsrn_network_set_time_and_ensemble", _I, [_VP, _F, _I]),
+    ("fvsrn_network_prepare", _I, [_VP, _VP]),
     ("fvsrn_network_clear_gpu_resources", _I, [_VP]),
     ("fvsrn_network_get_info", _I, [_VP, C.POINTER(NetworkInfo)]),
     ("fvsrn_network_get_layer", _I, [_VP, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _FP, _U16P, _U16P]),
@@ -281,6 +282,10 @@ class Network:
 
     def set_time_and_ensemble(self, time: float, ensemble: int = 0):
         _check(lib().fvsrn_network_set_time_and_ensemble(self._h, float(time), int(ensemble)))
+
+    def prepare(self, stream: Optional[int] = None):
+        """Uploads (first use) and the key-frame blend of the current time on `stream`, ahead of the next launch (fvsrn_network_prepare)."""
+        _check(lib().fvsrn_network_prepare(self._h, _current_stream() if stream is None else stream))
 
     def set_option(self, name: str, value: int):
         _check(lib().fvsrn_network_set_option(self._h, OPTIONS[name], int(value)))

@@ -784,6 +784,21 @@ int fvsrn_network_set_time_and_ensemble(fvsrn_network* net, float time, int ense
     });
 }
 
+int fvsrn_network_prepare(fvsrn_network* net, void* stream) {
+    return guarded([&] {
+        if (!net) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null network");
+        std::lock_guard<std::mutex> lock(net->mu);
+        try {
+            hipStream_t s = static_cast<hipStream_t>(stream);
+            net->ensureDevice(s);
+            net->syncTime(s);
+            return FVSRN_OK;
+        } catch (const DeviceError& e) {
+            return fail(fvsrn_device_count() == 0 ? FVSRN_ERR_NO_DEVICE : FVSRN_ERR_DEVICE, e.what());
+        }
+    });
+}
+
 int fvsrn_network_clear_gpu_resources(fvsrn_network* net) {
     return guarded([&] {
         if (!net) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null network");
@@ -888,7 +903,7 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
             const VariantKey& k = net->keyScaled;
             const bool scalarNet = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
             const bool colourNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
-            const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && P.gridK == 1 ? 1 : 2);
+            const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && P.gridK == 1 && P.bias0Folded ? 1 : 2);
             if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !P.noFourier && !P.fourierNeedsFractPlain && (scalarNet || colourNet) &&
                 render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1, smallGrid))
                 name = "render_small_kernel<act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "," + std::to_string(P.numLayers) +
@@ -1011,7 +1026,7 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
             hipError_t e = hipErrorInvalidDeviceFunction;
             {
                 const VariantKey& k = net->key;
-                const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.gridK == 1 ? 1 : 2);  // one decoded 16-channel chunk, as in renderImpl
+                const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.gridK == 1 && a.P.bias0Folded ? 1 : 2);  // one decoded 16-channel chunk, as in renderImpl
                 if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !a.P.noFourier && !a.P.fourierNeedsFractEval && a.P.numLayers >= 1 &&
                     a.P.numLayers <= 3) {
                     const unsigned gridSmall = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 8 / wpb));  // 2 waves per SIMD
@@ -1246,10 +1261,11 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             a.stats = d_stats;
             const int tilesX = (width + 7) / 8, tilesY = (numLocalRows + 7) / 8;
             const int tiles = tilesX * tilesY;
-            const size_t lds = size_t(a.P.ldsBytes) + tfFloats * 4;
+            size_t lds = size_t(a.P.ldsBytes) + ((tfFloats + 3) & ~size_t(3)) * 4;
+            S.tfLdsFloats = int((tfFloats + 3) & ~size_t(3));
             const Options& O = scene->opts;
             const bool persistent = O[FVSRN_OPT_PERSISTENT] >= 0 ? O[FVSRN_OPT_PERSISTENT] != 0 : stripeWorld == 1;
-            const int wpb = wavesPerBlockFor(lds, O);
+            int wpb = wavesPerBlockFor(lds, O);
             // Small networks in registers (render_small_kernel, kernels.hpp): 32-wide Fourier-only scalar network with at most
             // three C->C layers, phases inside the v_cos domain, a transfer function, no shading.  FVSRN_SMALL_KERNEL=0: off.
             const void* smallFn = nullptr;
@@ -1258,10 +1274,24 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             {
                 const VariantKey& k = net->keyScaled;
                 const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
-                smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.gridK == 1 ? 1 : 2);  // one decoded 16-channel chunk: resident kernel with direct features
+                smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.gridK == 1 && a.P.bias0Folded ? 1 : 2);  // one decoded 16-channel chunk (no time input: bias0Folded): resident kernel
                 if (O[FVSRN_OPT_SMALL_KERNEL] != 0 && net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && !a.shaded && k.CD == 2 && smallGrid <= 1 && !a.P.noFourier && !a.P.fourierNeedsFract &&
                     a.P.numLayers >= 1 && a.P.numLayers <= 3 && (rgbo || (scalarNet && d.tf_kind != FVSRN_TF_NONE)))
                     smallFn = render_small_fn(k.act, k.dir, a.P.numLayers, smallTail, smallGrid);
+            }
+#ifndef FVSRN_ROTATE_SGRID
+#define FVSRN_ROTATE_SGRID 0  // kernels.hpp: the rotating variant of the resident latent-grid kernel is an A/B build, not the shipped one
+#endif
+            if (FVSRN_ROTATE_SGRID && smallFn && smallGrid == 1) {
+                // the resident kernel with a latent chunk parks the per-ray feature rotation of every wave in LDS (8 KiB per wave behind the
+                // TF table, srn_forward_rotating_resident_grid); it runs 2 waves per SIMD = 8 per CU
+                constexpr size_t kRotationBytes = 64 * 32 * 4;
+                if (!O[FVSRN_OPT_WAVES_PER_BLOCK]) {
+                    wpb = 4;
+                    for (int w : {1, 2})
+                        if (size_t(8 / w) * (lds + size_t(w) * kRotationBytes) <= 160 * 1024) { wpb = w; break; }
+                }
+                lds += size_t(wpb) * kRotationBytes;
             }
             const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded, smallFn, O[FVSRN_OPT_MAX_BLOCKS_PER_CU]);
             const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));  // workgroups the chip holds at once
@@ -1324,7 +1354,8 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const bool useOrder = O[FVSRN_OPT_TILE_ORDER] >= 0 ? O[FVSRN_OPT_TILE_ORDER] == 1 : (S.tileCounter == nullptr && (wpb > 1 || net->key.grid != 0));
             S.tileOrder = useOrder ? scene->tileOrder(S, P_boxCenter(a.P), tilesX, tilesY, s) : nullptr;
             // what this launch does to the samples of a ray, for callers that restate it (fvsrn_scene_last_render_info)
-            const bool rotates = net->keyScaled.CD == 2 && net->keyScaled.grid == 0 && !a.P.noFourier && !a.shaded;  // kRotate, kernels.hpp
+            const bool rotates = net->keyScaled.CD == 2 && (net->keyScaled.grid == 0 || (FVSRN_ROTATE_SGRID && smallFn && smallGrid == 1)) && !a.P.noFourier &&
+                                 !a.shaded;  // kRotate / kRotateLds, kernels.hpp
             scene->lastInfo[0] = K;
             scene->lastInfo[1] = rotates ? S.resyncMask + 1 : 0;
             scene->lastInfo[2] = smallFn ? 1 : 0;

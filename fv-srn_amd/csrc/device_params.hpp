@@ -53,6 +53,7 @@ struct NetParams {
                             // clamped to the unit box (they leave it by the rounding of o + t d only) instead of a v_fract per phase
     int timeSlotOffset;     // networks that take the time as an input: byte offset of the fp16 time entry inside the LDS image (-1: none) ...
     unsigned timeSlotBits;  // ... and its value for this launch: the kernel patches its LDS copy, the device images are never written
+    int bias0Folded;        // the first layer's bias sits in its weight column of input channel 3, which carries the constant 1 (pack.cpp)
     int reluClamp;          // ldsImage is the [0,1]-scaled ReLU image: convert+ReLU is one clamped v_cvt_pk_f16_f32
     float actA, actB;       // activation constants, see act() in srn_device.hpp
     float boxMin[3];
@@ -96,6 +97,7 @@ struct SceneParams {
     float tfAbsorptionStepLog2e, densityBias;  // TAIL_SCALAR_IDENTITY: -tfAbsorptionStep * log2(e); -densityMin * divDensityRange
     float stepLog2e;                           // TAIL_SCALAR_TEXTURE: -stepsize * log2(e)
     const float* tfTable;  // device pointer
+    int tfLdsFloats;       // floats of the TF table in LDS (behind the network image); render_small_kernel<.., SGRID = 1> keeps its waves' rotation state behind it
     int tfGaussianMode;        // fvsrn_tf_gaussian_mode (scale sigma with |gradient| / piecewise analytic integration)
     int tfOpacityNonNegative;  // Texture TF: no table entry has a negative opacity (the straight-line tail leaves out the reference's `opacity > 0` test)
     int tfPreintegration;          // 0 none, 1: tfPreintegrated = [R][4] running integral, 2: [R][R][4] (previous, current density)

@@ -406,7 +406,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
 
     // camera ray (renderer_image_evaluator_simple.cuh:84-88, renderer_camera.cuh:33-52), box intersection (renderer_utils.cuh:91-105)
     // and the ray in unit-box coordinates.  Once per ray, so every operation is spelled out (explicit fma's, IEEE division and square
-    // root, no contraction by the compiler): the oracle's DEVICE model (oracle/srn_oracle.c, render_pixel) restates this sequence
+    // root, no contraction by the compiler): the DEVICE arithmetic model of the parity tests (tests/test_fuzz_parity.py) restates this sequence
     // operation by operation, which makes the sample positions of the two bit-identical -- a network behind a 2^9 frequency ladder turns
     // one ulp of a position into a different fp16 rounding and that into percents of a colour.
     float dx, dy, dz, tmin, tmax, pn0x, pn0y, pn0z, dnx, dny, dnz;
@@ -457,6 +457,16 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
 #endif
     constexpr bool kRotate = CD == 2 && (GRID == 0 || (GRID == 1 && FVSRN_ROTATE_GRID && NLC == 0)) && FMODE != FM_FIRST_LAYER && !SHADED;
 #endif
+    // r03 experiment, measured and NOT shipped (profiles/r03/sgrid_rotation_experiment.md): the register-resident kernel with one latent
+    // chunk with rotated features, the per-ray rotation parked in LDS (8 KiB per wave behind the TF table; srn_forward_rotating_resident_grid):
+    // 56 v_cos / v_sin and 2 phase MFMAs per wave step less, 32 packed-fp32 instructions and 8 LDS reads more -- 82.7 against 85.7
+    // Gsamples/s for the direct features (32x4 + 16^3 grid).  -DFVSRN_ROTATE_SGRID=1 builds it (tools/variant.sh).
+#ifndef FVSRN_ROTATE_SGRID
+#define FVSRN_ROTATE_SGRID 0
+#endif
+    constexpr bool kRotateLds = FVSRN_ROTATE_SGRID && NLC > 0 && GRID == 1 && CD == 2 && !SHADED && FMODE == FM_COS;
+    float* dfeatLds = nullptr;
+    if constexpr (kRotateLds) dfeatLds = const_cast<float*>(tfLds) + S.tfLdsFloats + int(threadIdx.x >> 6) * (64 * 32);
     floatx16 feat[2][mtiles(CD)], dfeat[2][mtiles(CD)];
     float stepIndex = float(i0);
     const float stepEnd = float(i1);  // INT_MAX -> 2^31: never reached
@@ -513,6 +523,15 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             }
             if constexpr (NLC > 0) o = srn_forward_rotating_resident<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeat);
             else o = srn_forward_rotating<CD, ACT, GRID, HAS_DIR>(P, lds, feat, dfeat, px, py, pz);
+        } else if constexpr (kRotateLds) {
+            if ((i & S.resyncMask) == 0) {  // wave-uniform: exact features; the per-step rotation once per ray (and depth segment) -> LDS
+                fourier_features<CD, HAS_DIR, FM_COS>(P, lds, px, py, pz, dx, dy, dz, feat);  // (phase fragment: from the LDS image)
+                if (i == 0) {
+                    fourier_features<CD, HAS_DIR, FM_COS, true>(P, lds, dnx * S.stepsize, dny * S.stepsize, dnz * S.stepsize, 0.f, 0.f, 0.f, dfeat);
+                    park_dfeat(dfeatLds, dfeat);
+                }
+            }
+            o = srn_forward_rotating_resident_grid<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeatLds, px, py, pz);
         } else if constexpr (NLC > 0 && GRID == 1) {
             o = srn_forward_resident_grid<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, px, py, pz, dx, dy, dz);
         } else {

@@ -187,6 +187,12 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
 
     const bool hasDir = c.directionMode > 0;
     const int F = c.numFourier;
+    // Networks without a time input have a zero in input channel 3 (the padding of the reference's first layer,
+    // renderer_volume_tensorcores.cuh:770-782).  Here that channel carries the constant 1 and the first layer's weight column 3 its
+    // bias (stored as fp16 like every bias of the reference; 1 x bias is exact in the MFMA), the fp32 bias block of layer 0 is zero:
+    // the register-resident kernel with a latent chunk drops those 16 registers (ResidentNet), every other kernel adds a zero.
+    const bool foldBias0 = c.hasFourier && !c.passTime && NL > 0;
+    np.bias0Folded = foldBias0 ? 1 : 0;
     np.noFourier = c.hasFourier ? 0 : 1;
     std::vector<int> chanOfRow(size_t(C), 0);
     if (c.hasFourier) chanOfRow = rowToChannel(C, hasDir, F);
@@ -219,7 +225,7 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
             } else if (ch < base) {
                 if (ch < 3) slots[2 * ch] = 1.f;  // position pass-through
                 else if (ch == 3) slots[6] = c.passTime ? half_bits_to_float(float_to_half_bits(
-                                       net.latentGrid ? net.latentGrid->interpolateTime(net.currentTime) : 0.f)) : 0.f;
+                                       net.latentGrid ? net.latentGrid->interpolateTime(net.currentTime) : 0.f)) : (foldBias0 ? 1.f : 0.f);
                 else if (ch < 7) slots[8 + 2 * (ch - 4)] = 1.f;  // direction pass-through
             } else {
                 const int idx = ch - base;
@@ -310,6 +316,7 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
                                 col = C + 16 * (s - KS) + 8 * h + j;  // latent grid channel
                             }
                             f.v[lane][j] = scaleHalf(L.weights[size_t(row) * L.channelsIn + col], kW);
+                            if (l == 0 && foldBias0 && s < KS && col == 3) f.v[lane][j] = scaleHalf(L.bias[size_t(row)], kW);  // (kW == kB for l = 0)
                         }
                     }
                     const size_t fragIndex = s < KS ? size_t(m) * KS + s : size_t(MT) * KS + size_t(s - KS) * MT + m;
@@ -322,7 +329,7 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
                     for (int j = 0; j < L.channelsIn; ++j) sum += double(half_bits_to_float(L.weights[size_t(r) * L.channelsIn + j]));
                     b += std::ldexp(sum, foldExp);
                 }
-                bias[size_t(l) * 32 * MT + r] = float(b);
+                bias[size_t(l) * 32 * MT + r] = (l == 0 && foldBias0) ? 0.f : float(b);
             }
         }
         // Last layer (C -> 1|4): one v_mfma_f32_16x16x32_f16 per K step and tile -- 16 output rows instead of 32 halve

@@ -463,16 +463,17 @@ __device__ __forceinline__ void phase_operands(float px, float py, float pz, flo
     b0[1] = phase_operand<HAS_DIR>(tph[1], td[1], h);
 }
 
+// wp != nullptr: the phase fragments are given (resident in registers) instead of read from the LDS image
 template <int CD, bool HAS_DIR, int FMODE, bool DELTA = false>
 __device__ __forceinline__ void fourier_features(const NetParams& P, const char* lds, float px, float py, float pz, float dx,
-                                                 float dy, float dz, floatx16 (&f)[2][mtiles(CD)]) {
+                                                 float dy, float dz, floatx16 (&f)[2][mtiles(CD)], const half8_t* wp = nullptr) {
     constexpr int MT = mtiles(CD);
     constexpr int NPASS = HAS_DIR ? 4 : 2;
     const int lane = lane_id();
     const int h = lane >> 5;
     half8_t aph[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) aph[m] = lds_frag(lds, P.offPhase + m * kFragBytes, lane);
+    for (int m = 0; m < MT; ++m) aph[m] = wp ? wp[m] : lds_frag(lds, P.offPhase + m * kFragBytes, lane);
     half8_t b0[2];
     phase_operands<HAS_DIR, !DELTA>(px, py, pz, dx, dy, dz, h, b0);
 #pragma unroll
@@ -1023,7 +1024,8 @@ __device__ __forceinline__ float4_t srn_forward_rotating(const NetParams& P, con
 template <int NLC, int RGRID = 0>
 struct ResidentNet {
     half8_t w[2 * (NLC + 1)];  // [layer 0 | hidden 1..NLC-1 | last][K step]
-    floatx16 b[NLC];           // bias rows of this lane half, layers 0..NLC-1
+    floatx16 b[NLC];           // bias rows of this lane half, layers 0..NLC-1 (RGRID: b[0] is never read -- the first layer's bias is folded
+                               // into its weights, NetParams::bias0Folded, and the compiler drops the 16 registers)
     float4_t bLast;
     half8_t wg[RGRID ? 1 : 0];  // latent K step of layer 0
     half8_t wp[RGRID ? 1 : 0];  // phase fragment
@@ -1072,7 +1074,8 @@ __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, cons
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     // first layer, tile 0 (its MFMAs carry rotation pieces)
-    interleave<2, NF0>([&](int i) { acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.w[i], xb[0][i], i == 0 ? R.b[0] : acc[0], 0, 0, 0); },
+    const floatx16 zero16 = {0};
+    interleave<2, NF0>([&](int i) { acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.w[i], xb[0][i], i == 0 ? (RGRID ? zero16 : R.b[0]) : acc[0], 0, 0, 0); },
                        [&](int j) { fill(j); });
     if constexpr (RGRID != 0) {  // latent K step of layer 0 (gf: B fragments of the two tiles' latent features)
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wg[0], gf[0], acc[0], 0, 0, 0);
@@ -1092,7 +1095,7 @@ __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, cons
         for (int q = 0; q < 4; ++q) act_pack_quarter<ACT>(acc[O], q, actA, actB, xb[O][0], xb[O][1]);
         __builtin_amdgcn_sched_barrier(0);
 #else
-        interleave<2, 4>([&](int i) { acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.w[2 * L + i], xb[T][i], i == 0 ? R.b[L] : acc[T], 0, 0, 0); },
+        interleave<2, 4>([&](int i) { acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.w[2 * L + i], xb[T][i], i == 0 ? ((RGRID && L == 0) ? zero16 : R.b[L]) : acc[T], 0, 0, 0); },
                          [&](int q) { act_pack_quarter<ACT>(acc[O], q, actA, actB, xb[O][0], xb[O][1]); });
 #endif
         if constexpr (RGRID != 0 && L == 0) {
@@ -1149,6 +1152,69 @@ __device__ __forceinline__ float4_t srn_forward_resident_grid(const NetParams& P
         phase_cos<FM_COS>(d[t], NPASS);
 #pragma unroll
         for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d[t], q, 0.f, 0.f, xb[t][0], xb[t][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        float acc[8];
+        grid_reduce_record<false, true>(raw, gt[t], 0, acc);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) grid_reduce_record<false>(raw, gt[t], k, acc);
+        gf[t] = grid_pack(acc);
+    }
+    return srn_layers_resident<ACT, NLC, 0, ALL4, 1>(P, R, xb, []() {}, [](int) {}, gf);
+}
+
+// The same with rotated Fourier features (r03): the current features stay in 32 registers (fp32, both tiles), their per-step rotation
+// -- 32 more values per lane that are constant along a ray -- is parked in LDS (`dfeatLds`: this wave's 8 KiB, [tile][quad][lane] float4,
+// conflict-free ds_read_b128 / ds_write_b128) and read back 16 registers at a time while the tile's gathers are in flight.  Per wave step
+// this replaces 2 phase MFMAs, 56 v_cos_f32 / v_sin_f32 (quarter rate), the position converts and their lane swaps by 32 packed-fp32
+// instructions and 8 LDS reads; the LDS is idle in this kernel otherwise (SQ_INSTS_LDS = 0).
+__device__ __forceinline__ void park_dfeat(float* dfeatLds, const floatx16 (&dfeat)[2][1]) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4_t*>(dfeatLds + ((t * 4 + q) * 64 + lane) * 4) =
+                float4_t{dfeat[t][0][4 * q], dfeat[t][0][4 * q + 1], dfeat[t][0][4 * q + 2], dfeat[t][0][4 * q + 3]};
+}
+
+template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
+__device__ __forceinline__ float4_t srn_forward_rotating_resident_grid(const NetParams& P, const ResidentNet<NLC, 1>& R, floatx16 (&feat)[2][1],
+                                                                      const float* dfeatLds, float px, float py, float pz) {
+    const int lane = lane_id();
+    half8_t xb[2][2], gf[2];
+    GridTap gt[2];
+    grid_tap_bcast<false>(grid_tap(P, px, py, pz), gt[0], gt[1]);
+    GridRaw raw;
+    grid_load(P.grid, gt[0], 0, kTapHalfInOffset, raw);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t == 1) grid_load(P.grid, gt[1], 0, kTapHalfInOffset, raw);
+        float4_t rot[4];  // this tile's rotation: four LDS reads in flight behind the converts
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rot[q] = *reinterpret_cast<const float4_t*>(dfeatLds + ((t * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(feat[t][0], q, 0.f, 0.f, xb[t][0], xb[t][1]);
+        __builtin_amdgcn_sched_barrier(0);  // (converts first: the rotation then updates the feature registers in place, no copies)
+        // -> the next sample of the rays (fourier_advance_piece, in place)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {  // piece k = 2q + j of this tile: registers (2k, 2k + 1)
+                constexpr int NPASS = HAS_DIR ? 4 : 2;
+                const int k = 2 * q + j;
+                float2_t cs = {feat[t][0][2 * k], feat[t][0][2 * k + 1]};
+                const float2_t dd = {rot[q][2 * j], rot[q][2 * j + 1]};
+                if (2 * k < NPASS) {
+                    cs += dd;
+                } else {
+                    float2_t tmp;
+                    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(tmp) : "v"(cs), "v"(dd));
+                    asm("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(cs) : "v"(dd), "v"(tmp));
+                }
+                feat[t][0][2 * k] = cs[0];
+                feat[t][0][2 * k + 1] = cs[1];
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         float acc[8];
         grid_reduce_record<false, true>(raw, gt[t], 0, acc);

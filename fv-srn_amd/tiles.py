@@ -126,6 +126,7 @@ class StripeRenderer:
             self._capi = capi
             self.scenes = [capi.Scene(**scene_kw) for _ in range(2 if self.pipelined else 1)]
             self.comm_stream = torch.cuda.Stream() if world > 1 else None
+            self.blend_stream = None  # created with the first next_time: key-frame blends of the NEXT frame, beside the current render
             self.render_done = [torch.cuda.Event() for _ in range(nbuf)]
             self.gather_done = [torch.cuda.Event() for _ in range(nbuf)]
             if self.pipelined:
@@ -157,10 +158,13 @@ class StripeRenderer:
     def _stream_ctx(self, stream):
         return torch.cuda.stream(stream) if self.on_gpu else contextlib.nullcontext()
 
-    def submit(self, index: int, scene_kw: dict, *, time: Optional[float] = None, ensemble: int = 0, stats=None,
-               gather: bool = True, record: bool = False) -> int:
+    def submit(self, index: int, scene_kw: dict, *, time: Optional[float] = None, ensemble: int = 0, next_time: Optional[float] = None,
+               stats=None, gather: bool = True, record: bool = False) -> int:
         """Enqueues frame `index`: scene update, optional time change, render of this rank's share, gather.  Returns the
-        buffer index b (= index & 1): ``frame(b)`` is this frame once ``finish()`` (or a later wait) has passed."""
+        buffer index b (= index & 1): ``frame(b)`` is this frame once ``finish()`` (or a later wait) has passed.
+        next_time: the time of the frame that will be submitted next -- its key-frame blend is enqueued right behind this frame's
+        render call on a high-priority side stream (fvsrn_network_prepare), so that it runs beside this render (into the working
+        grid this render does not read) instead of between the two renders."""
         import torch.distributed as dist
         b = index & 1
         s = b if self.pipelined else 0
@@ -173,10 +177,11 @@ class StripeRenderer:
             scene.clear()
             scene.update(scene_kw)
             stream = self.render_streams[b]
-        if time is not None:
+        if time is not None and (time, ensemble) != getattr(self, "_prepared", None):
             # key frames are resident (or streamed by the library's copy stream); this only marks the working grid dirty, the
             # blend into the grid the other frame in flight does NOT read is enqueued by the render call below
             self.net.set_time_and_ensemble(time, ensemble)
+        self._prepared = None
         with self._stream_ctx(stream):
             if record and self.on_gpu:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -188,6 +193,13 @@ class StripeRenderer:
             if record and self.on_gpu:
                 e1.record()
                 self.kernel_events.append((e0, e1))
+        if next_time is not None and self.on_gpu and self._render_fn is None:
+            if self.blend_stream is None:
+                self.blend_stream = torch.cuda.Stream(priority=-1)
+                self.blend_stream.wait_stream(torch.cuda.current_stream())
+            self.net.set_time_and_ensemble(next_time, ensemble)
+            self.net.prepare(stream=self.blend_stream.cuda_stream)
+            self._prepared = (next_time, ensemble)
         if self.world > 1 and gather:
             with self._stream_ctx(self.comm_stream):  # gather(frame i) overlaps render(frame i + 1)
                 self.comm_stream.wait_event(self.render_done[b])
@@ -206,6 +218,8 @@ class StripeRenderer:
                 cur.wait_stream(st)
         if self.world > 1:
             cur.wait_stream(self.comm_stream)
+        if self.blend_stream is not None:
+            cur.wait_stream(self.blend_stream)
 
     def frame(self, b: int = 0) -> torch.Tensor:
         """(1, 8, H, W) image of buffer b: the render target itself on one GPU, the gathered stripes put back in image order

@@ -119,6 +119,14 @@ int fvsrn_network_valid(const fvsrn_network* net);
 int fvsrn_network_save_volnet(const fvsrn_network* net, void* buf, size_t cap, size_t* len);
 /* SceneNetwork::setTimeAndEnsemble    :923-938 (clamps silently) */
 int fvsrn_network_set_time_and_ensemble(fvsrn_network* net, float time, int ensemble);
+/* Brings the device state of a network up to date on `stream` without launching anything else: uploads at first use, and -- after
+ * fvsrn_network_set_time_and_ensemble -- the blend of the selected key frames into a working grid (what the next evaluate / render
+ * call would do first).  A frame pipeline calls it on a side stream as soon as the NEXT frame's time is known, so that the blend
+ * runs beside the current frame's render instead of between two renders (with two working grids, FVSRN_OPT_WORKING_GRIDS; the
+ * render on another stream waits for it by an event).  The reference uploads / re-fills at the start of render()
+ * (volume_interpolation_network.cpp:923-938,1308-1328). */
+int fvsrn_network_prepare(fvsrn_network* net, void* stream);
+
 /* SceneNetwork::clearGPUResources     :1106-1112 */
 int fvsrn_network_clear_gpu_resources(fvsrn_network* net);
 

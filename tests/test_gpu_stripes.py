@@ -18,12 +18,15 @@ def _scene_kw(yaw, **kw):
     return d
 
 
+@pytest.mark.parametrize("ahead", [False, True])
 @pytest.mark.parametrize("enc,has_time,slots", [(0, False, 0), (0, True, 0), (2, False, 0), (0, False, 2), (1, True, 3)])
-def test_two_frames_in_flight_at_different_times(enc, has_time, slots):
+def test_two_frames_in_flight_at_different_times(enc, has_time, slots, ahead):
     """BASELINE.json configs[4] in small: a time-dependent network rendered by StripeRenderer with consecutive frames on two
     streams, every frame at another time (and another camera).  The library blends frame i + 1's working grid while frame i
     still renders from the other one, and hands the time input over as a kernel argument; every frame must equal, bit for bit,
-    the same frame rendered alone on a second network handle with a device synchronisation around it."""
+    the same frame rendered alone on a second network handle with a device synchronisation around it.
+    ahead: the pipeline is told the next frame's time (submit(next_time=)) and enqueues its blend on a side stream beside the current
+    render (fvsrn_network_prepare)."""
     import torch
     from fvsrn_amd import capi, tiles, volnet_io
     KEYS = 5
@@ -42,11 +45,12 @@ def test_two_frames_in_flight_at_different_times(enc, has_time, slots):
     got = {}
     for i in range(0, len(times), 2):  # two frames in flight, then read both buffers back
         for j in (i, i + 1):
-            pipe.submit(j, _scene_kw(yaws[j]), time=times[j])
+            pipe.submit(j, _scene_kw(yaws[j]), time=times[j], next_time=times[j + 1] if ahead and j + 1 < len(times) else None)
         pipe.finish()
         torch.cuda.synchronize()
         for j in (i, i + 1):
             got[j] = pipe.frame(j & 1).clone()
+    assert (pipe.blend_stream is not None) == ahead
     ref_scene = capi.Scene(**_scene_kw(0.0))
     for j, (t, yaw) in enumerate(zip(times, yaws)):
         serial.set_time_and_ensemble(t, 0)
@@ -152,12 +156,15 @@ def test_texture_tf_with_negative_opacity_texels(grid):
     tab[:, 3] = 10.0 * np.cos(np.arange(48) * np.pi / 2 + np.pi / 4)
     kw = make_scene_kwargs(stepsize=1 / 96, early_out=True, tf_kind=oracle.TF_TEXTURE, tf_table=tab)
     net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
-    ref, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), 96, 64)
     for small in (-1, 0):
-        img = capi.Scene(**kw).set_option("small_kernel", small).render(net, 96, 64)
+        scene = capi.Scene(**kw).set_option("small_kernel", small)
+        img = scene.render(net, 96, 64)
         torch.cuda.synchronize()
+        plan = scene.last_render_info()  # (the steep table amplifies: compare with the kernels' stated arithmetic, test_fuzz_parity.py)
+        ref, _ = oracle.OracleScene(rotation_resync=plan["rotation_resync"], segments=plan["segments"], **kw).render(
+            oracle.OracleNetwork(vn, oracle.ACC_DEVICE), 96, 64)
         assert_images_close(img.cpu().numpy()[0], ref, TOL_IMG)
-    assert ref[3].min() >= 0.0 and ref[3].max() > 0.04
+    assert ref[3].min() >= 0.0 and ref[3].max() > 0.03
 
 
 def test_two_rank_processes_share_the_gpu_and_assemble_the_frame():

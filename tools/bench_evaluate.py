@@ -15,29 +15,46 @@ from fvsrn_amd import synthetic as util  # noqa: E402
 from fvsrn_amd import capi, volnet_io  # noqa: E402
 
 
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0
+
+
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 24
-    pos = torch.rand(n, 3, device="cuda")
-    for name, kw in [("c32l4_fourier_relu", dict(C=32, layers=4, activation="ReLU")),
-                     ("c32l4_fourier_snakealt", dict(C=32, layers=4, activation="SnakeAlt")),
-                     ("c32l4_grid16_relu", dict(C=32, layers=4, activation="ReLU", grid=(16, 16))),
-                     ("c64l6_grid16_relu", dict(C=64, layers=6, activation="ReLU", grid=(16, 32)))]:
-        vn = util.random_network(output_mode="density:direct", seed=1234, **kw)
-        net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
-        out = net.evaluate(pos)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 10
-        e0.record()
-        for _ in range(reps):
+    """One JSON line per network and batch size.  evaluate_points sits between two rooflines: 12 B in + 4 B out per point against
+    HBM, the network's algorithmic FLOP per point against the matrix cores -- both are reported, the larger fraction names the bound."""
+    sizes = [int(a) for a in sys.argv[1:]] or [1 << 24, 1 << 26]
+    for n in sizes:
+        pos = torch.rand(n, 3, device="cuda")
+        for name, kw in [("c32l4_fourier_relu", dict(C=32, layers=4, activation="ReLU")),
+                         ("c32l4_fourier_snakealt", dict(C=32, layers=4, activation="SnakeAlt")),
+                         ("c32l4_grid16_relu", dict(C=32, layers=4, activation="ReLU", grid=(16, 16))),
+                         ("c64l6_grid16_relu", dict(C=64, layers=6, activation="ReLU", grid=(16, 32)))]:
+            vn = util.random_network(output_mode="density:direct", seed=1234, **kw)
+            net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
             out = net.evaluate(pos)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        info = net.info()
-        print(json.dumps({"workload": "evaluate_points:" + name, "points": n, "ms": ms, "points_per_s": n / ms * 1e3,
-                          "kernel": net.kernel_name(False), "algorithmic_tflops": info.flops_per_sample * n / ms / 1e9,
-                          "hbm_GBps_algorithmic": 16.0 * n / ms / 1e6}))
+            torch.cuda.synchronize()
+            reps = 10 if n <= (1 << 24) else 4
+            for _ in range(3):  # clock spin-up
+                out = net.evaluate(pos, out=out)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                out = net.evaluate(pos, out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            info = net.info()
+            tflops = info.flops_per_sample * n / ms / 1e9
+            gbps = 16.0 * n / ms / 1e6
+            print(json.dumps({"workload": "evaluate_points:" + name, "points": n, "ms": ms, "points_per_s": n / ms * 1e3,
+                              "kernel": net.kernel_name(False),
+                              "roofline": {"bound": "mfma" if tflops / MFMA_F16_PEAK_TFLOPS > gbps / HBM_PEAK_GBPS else "hbm",
+                                           "mfma": {"achieved": tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F16_PEAK_TFLOPS,
+                                                    "flops_per_point": info.flops_per_sample},
+                                           "hbm": {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                                                   "bytes_per_point": 16}}}), flush=True)
+        del pos
 
 
 if __name__ == "__main__":

@@ -1,47 +1,60 @@
 #!/usr/bin/env python3
-"""How long does ONE rank's share of a multi-GPU frame take on its GPU, against frame_time / world?  (The communication is
-not part of this: one GPU, no collective.)  usage: tools/stripe_efficiency.py [config]"""
+"""How long does ONE rank's share of a multi-GPU frame take on its GPU, against frame_time / world?  One GPU, no collective: the
+rank's frame pipeline (fv-srn_amd/tiles.py StripeRenderer: two frames in flight on two streams, for time-dependent networks the
+blend of frame i + 1 into the second working grid) is run with gather=False, for every rank of world = 2 / 4 / 8 in turn.
+Prints one JSON line per configuration: the frame period of the slowest rank and the efficiency against full_frame / world.
+usage: tools/stripe_efficiency.py [config ...]      default: BASELINE.json configs[3] and configs[4]"""
 import importlib.util
+import json
+import math
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
 b = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(b)
 import torch  # noqa: E402
-from fvsrn_amd import synthetic as util  # noqa: E402
-from fvsrn_amd import capi, volnet_io  # noqa: E402
-
-name = sys.argv[1] if len(sys.argv) > 1 else "c32l4_fourier_1024x512"
-cfg = b.CONFIGS[name]
-vn, net = b.make_network(volnet_io, capi, cfg, "ReLU")
-_, _, _, W, H, steps = cfg
-scene = capi.Scene(**b.build_scene_kwargs(capi, 0.3, 1.0 / steps, False))
+from fvsrn_amd import capi, tiles, volnet_io  # noqa: E402
 
 
-def timed(fn, reps=20):
-    for _ in range(4):
-        fn()
+def frame_period(net, cfg, time_keys, rank, world, frames=24, warm=8, pipelined=None, ahead=True):
+    _, _, _, W, H, steps = cfg
+    kw = lambda i: b.build_scene_kwargs(capi, 2 * math.pi * (i % 64) / 64, 1.0 / steps, False)  # noqa: E731
+    pipe = tiles.StripeRenderer(net, W, H, kw(0), rank=rank, world=world, stripe=b.STRIPE, pipelined=pipelined)
+    t = lambda i: (0.25 * i) % (time_keys - 1) if time_keys > 1 else None  # noqa: E731
+    tn = (lambda i: t(i + 1)) if (ahead and pipe.pipelined) else (lambda i: None)
+    for i in range(warm):
+        pipe.submit(i, kw(i), time=t(i), next_time=tn(i), gather=False)
+    pipe.finish()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    for i in range(warm, warm + frames):
+        pipe.submit(i, kw(i), time=t(i), next_time=tn(i), gather=False)
+    pipe.finish()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    return e0.elapsed_time(e1) / frames
 
 
-full = torch.zeros((1, 8, H, W), dtype=torch.float32, device="cuda")
-t_full = timed(lambda: scene.render(net, W, H, out=full))
-print("%s: full frame %.3f ms" % (name, t_full))
-for world in (2, 4, 8):
-    worst = 0.0
-    for rank in range(world):
-        rows = capi.stripe_rows(H, b.STRIPE, rank, world)
-        out = torch.zeros((8, rows, W), dtype=torch.float32, device="cuda")
-        worst = max(worst, timed(lambda: capi.render_stripes(scene, net, W, H, b.STRIPE, rank, world, out=out)))
-    print("  world %d: slowest rank %.3f ms, ideal %.3f ms -> render-only efficiency %.0f%%" % (world, worst, t_full / world, 100 * t_full / world / worst))
+def main():
+    names = sys.argv[1:] or ["c64l6_grid16_1024x512", "c64l6_grid16_time16_1024x512"]
+    for name in names:
+        cfg = b.CONFIGS[name]
+        keys = b.TIME_KEYS.get(name, 1)
+        _, net = b.make_network(volnet_io, capi, cfg, "ReLU", keys)
+        full = frame_period(net, cfg, keys, 0, 1, pipelined=False)
+        row = {"workload": name, "full_frame_ms": full, "time_keys": keys, "world": {}}
+        ahead = os.environ.get("FVSRN_BENCH_BLEND_AHEAD", "1") == "1"
+        row["blend_ahead"] = bool(ahead and keys > 1)
+        row["working_grids"] = net.get_option("working_grids")
+        for world in (2, 4, 8):
+            worst = max(frame_period(net, cfg, keys, r, world, ahead=ahead) for r in range(world))
+            row["world"][str(world)] = {"slowest_rank_frame_period_ms": worst, "ideal_ms": full / world, "render_only_efficiency": full / world / worst}
+        print(json.dumps(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()
