@@ -111,7 +111,7 @@ class Runner:
         yaw = 2 * math.pi * (index % 64) / 64
         t = (0.25 * index) % (self.time_keys - 1) if self.time_keys > 1 else None
         # (the next frame's time is known: its key-frame blend is enqueued beside this frame's render, tiles.StripeRenderer.submit)
-        tn = (0.25 * (index + 1)) % (self.time_keys - 1) if self.time_keys > 1 and self.pipelined and os.environ.get("FVSRN_BENCH_BLEND_AHEAD", "1") == "1" else None
+        tn = (0.25 * (index + 1)) % (self.time_keys - 1) if self.time_keys > 1 and self.pipelined and os.environ.get("FVSRN_BENCH_BLEND_AHEAD", "0") == "1" else None
         return self.pipeline.submit(index, build_scene_kwargs(self.capi, yaw, self.stepsize, self.early_out), time=t, next_time=tn, stats=self.stats,
                                     gather=gather, record=record)
 

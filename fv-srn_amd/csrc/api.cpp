@@ -188,6 +188,42 @@ struct StreamOrder {
     }
 };
 
+// Kernels that use scratch memory (register spills) are never put on the chip from two streams at once.  Measured on MI355X / ROCm 7.2
+// (r03, tools/dev/stress_concurrent.py, profiles/r03/scratch_concurrency.md): two launches of such a kernel running concurrently on two
+// streams return, in a few per cent of the frames, 16 lanes of one wave with slightly wrong values (the 64-byte chunk of a spilled
+// register that belongs to lanes 48-63) -- alone, or with the kernel compiled without spills, every frame is bit-identical, and no
+// runtime switch changes it.  So a launch of a scratch-using kernel waits for the last such launch on any other stream of the device
+// (one event, process-wide per device); scratch-free kernels -- the register-resident renderers, every evaluate kernel of the
+// benchmark configurations -- keep their full concurrency.
+struct ScratchFence {
+    std::mutex mu;
+    hipEvent_t last[16] = {};
+    hipStream_t stream[16] = {};
+    bool have[16] = {};
+    // brackets the launch: call before (orders `s` behind the previous scratch launch on another stream) ...
+    void before(int device, hipStream_t s) {
+        if (device < 0 || device >= 16) return;
+        std::lock_guard<std::mutex> lock(mu);
+        if (have[device] && stream[device] != s) HIP_CHECK(hipStreamWaitEvent(s, last[device], 0));
+    }
+    // ... and after it has been enqueued
+    void after(int device, hipStream_t s) {
+        if (device < 0 || device >= 16) return;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!last[device]) HIP_CHECK(hipEventCreateWithFlags(&last[device], hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(last[device], s));
+        stream[device] = s;
+        have[device] = true;
+    }
+};
+ScratchFence g_scratchFence;
+// bytes of scratch per lane of a kernel function (0: none); cached by the callers
+int kernelScratchBytes(const void* fn) {
+    hipFuncAttributes a{};
+    if (!fn || hipFuncGetAttributes(&a, fn) != hipSuccess) return 0;
+    return int(a.localSizeBytes);
+}
+
 struct WrongDevice : WrongDeviceBase { using WrongDeviceBase::WrongDeviceBase; };
 // A handle's device state lives on the device that was current at its first use; every later call must run there.
 void bindOrCheckDevice(int& bound, const char* what) {
@@ -334,6 +370,14 @@ struct fvsrn_network {
     VariantKey keyScaled{};  // ReLU networks: [0,1]-scaled image (render only)
     KernelInfo kinfo{}, kinfoScaled{};
     int numCUs = 0;
+    int scratchRender = 0, scratchShaded = 0, scratchEval = 0, scratchEvalPlain = 0;  // kernelScratchBytes of the selected variants
+    std::vector<std::pair<const void*, int>> scratchSmall;                         // ... and of the register-resident kernels used so far
+    int scratchOf(const void* fn) {
+        for (const auto& e : scratchSmall)
+            if (e.first == fn) return e.second;
+        scratchSmall.emplace_back(fn, kernelScratchBytes(fn));
+        return scratchSmall.back().second;
+    }
     int device = -1;  // HIP device of the buffers above (-1: none yet)
     Options opts = defaultOptions();
     mutable std::mutex mu;
@@ -442,6 +486,12 @@ struct fvsrn_network {
         // the staging vectors are pageable: the copies above complete before hipMemcpyAsync returns
         const size_t maxLds = packed.ldsImage.size() + 4096 + 256 * 6 * 4;
         HIP_CHECK(hipFuncSetAttribute(kinfo.evalFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
+        if (kinfoScaled.evalFn != kinfo.evalFn) HIP_CHECK(hipFuncSetAttribute(kinfoScaled.evalFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
+        scratchRender = kernelScratchBytes(kinfoScaled.renderFn);
+        scratchShaded = kernelScratchBytes(kinfo.renderShadedFn);
+        scratchEval = kernelScratchBytes(kinfoScaled.evalFn);
+        scratchEvalPlain = kernelScratchBytes(kinfo.evalFn);
+        scratchSmall.clear();
         HIP_CHECK(hipFuncSetAttribute(kinfoScaled.renderFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         HIP_CHECK(hipFuncSetAttribute(kinfo.renderShadedFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         deviceValid = true;
@@ -897,7 +947,7 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
         if (!net || !buf || cap == 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
         std::lock_guard<std::mutex> lock(net->mu);
         if (!net->deviceValid) net->pack();  // (a live network keeps its packed state: it carries the device pointers)
-        std::string name = render ? net->kinfoScaled.renderName : net->kinfo.evalName;
+        std::string name = render ? net->kinfoScaled.renderName : net->kinfoScaled.evalName;  // (evaluate_points runs the re-scaled image too, r03)
         if (render) {  // the register-resident kernel takes over for scenes with an Identity / Texture TF and no shading (renderImpl)
             const NetParams& P = net->packed.params;
             const VariantKey& k = net->keyScaled;
@@ -983,6 +1033,23 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
             if (net->key.dir && !d_directions)
                 return fail(FVSRN_ERR_INVALID_ARGUMENT, "the network uses the view direction, but no directions were given");
             EvalArgs a{net->packed.params, d_positions, d_directions, n, d_out, net->net->outputChannels()};
+            // The re-scaled weight images (pack.cpp) serve evaluate_points too: SnakeAlt with its affine part in the next layer is exact
+            // algebra for any input; the [0,1]-scaled ReLU image is bounded for points inside the unit box, so the kernel checks every
+            // batch of 64 points and evaluates a batch with a point outside from the plain image in global memory (kernels.hpp).
+            VariantKey evalKey = net->key;
+            a.P.evalTodo = nullptr;
+            void* evalTodo = nullptr;
+            struct FreeTodo { void*& p; hipStream_t s; ~FreeTodo() { if (p) (void)hipFreeAsync(p, s); } } freeTodo{evalTodo, s};
+            if (net->scaledImage && !adjoint) {
+                evalKey = net->keyScaled;
+                a.P.ldsImage = net->scaledImage;
+                a.P.reluClamp = net->keyScaled.act == ACT_RELU01 ? 1 : 0;
+                if (net->keyScaled.act == ACT_RELU01) {  // two launches, see kernels.hpp (eval_batch_deferred); stream-ordered scratch per call
+                    HIP_CHECK(hipMallocAsync(&evalTodo, (1 + (n + 63) / 64) * sizeof(unsigned), s));
+                    HIP_CHECK(hipMemsetAsync(evalTodo, 0, sizeof(unsigned), s));
+                    a.P.evalTodo = static_cast<unsigned*>(evalTodo);
+                }
+            }
             void* evalTmp = nullptr;
             struct FreeTmp { void*& p; hipStream_t s; ~FreeTmp() { if (p) (void)hipFreeAsync(p, s); } } freeTmp{evalTmp, s};
             const bool curvature = (flags & FVSRN_EVAL_WITH_PREDICTED_CURVATURE) != 0;
@@ -1005,6 +1072,10 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
             }
             if (!(flags & FVSRN_EVAL_WORLD_POSITIONS))  // volume_interpolation.cpp:46-49: box := [0,1]^3
                 for (int i = 0; i < 3; ++i) { a.P.boxMin[i] = 0.f; a.P.boxSize[i] = 1.f; a.P.invBoxSize[i] = 1.f; }
+            // (ScratchFence: the gradient kernels are not queried individually and count as scratch users)
+            const bool usesScratch = adjoint || net->scratchEval > 0 || net->scratchEvalPlain > 0;
+            if (usesScratch) g_scratchFence.before(net->device, s);
+            struct FenceAfter { bool on; int dev; hipStream_t s; ~FenceAfter() { if (on) { try { g_scratchFence.after(dev, s); } catch (...) {} } } } fenceAfter{usesScratch, net->device, s};
             const size_t batches = (n + 63) / 64;
             const size_t wpb = size_t(wavesPerBlockFor(size_t(net->packed.params.ldsBytes), net->opts));
             const size_t blocks = (batches + wpb - 1) / wpb;
@@ -1025,18 +1096,36 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
             // small networks in registers (evaluate_small_kernel): see renderImpl; the plain weight image, any output mode
             hipError_t e = hipErrorInvalidDeviceFunction;
             {
-                const VariantKey& k = net->key;
+                const VariantKey& k = evalKey;
                 const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.gridK == 1 && a.P.bias0Folded ? 1 : 2);  // one decoded 16-channel chunk, as in renderImpl
                 if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !a.P.noFourier && !a.P.fourierNeedsFractEval && a.P.numLayers >= 1 &&
                     a.P.numLayers <= 3) {
-                    const unsigned gridSmall = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 8 / wpb));  // 2 waves per SIMD
+                    // (the Fourier-only kernels need 156 registers: three waves per SIMD fit, and the grid-stride loop profits from them)
+                    const unsigned gridSmall = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * (smallGrid == 0 ? 12 : 8) / wpb));
                     e = launch_eval_small(k.act, k.dir, a.P.numLayers, smallGrid, a, gridSmall, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
                 }
             }
             if (e == hipErrorInvalidDeviceFunction)
-                e = launch_eval(net->key, a, grid, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
+                e = launch_eval(evalKey, a, grid, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
+            if (e == hipSuccess && a.P.evalTodo) {  // the batches the scaled-image launch deferred (as a rule: none), from the plain image
+                EvalArgs b2 = a;
+                b2.P.ldsImage = net->packed.params.ldsImage;
+                b2.P.reluClamp = 0;
+                hipError_t e2 = hipErrorInvalidDeviceFunction;
+                const VariantKey& k = net->key;
+                const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && b2.P.gridK == 1 && b2.P.bias0Folded ? 1 : 2);
+                if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !b2.P.noFourier && !b2.P.fourierNeedsFractEval && b2.P.numLayers >= 1 &&
+                    b2.P.numLayers <= 3)
+                    e2 = launch_eval_small(k.act, k.dir, b2.P.numLayers, smallGrid, b2, unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 8 / wpb)),
+                                           unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
+                if (e2 == hipErrorInvalidDeviceFunction) e2 = launch_eval(k, b2, grid, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
+                e = e2;
+            }
             if (e == hipSuccess && curvature) {
                 EvalArgs c = a;
+                c.P = net->packed.params;  // (the curvature image is a variant of the plain image)
+                if (!(flags & FVSRN_EVAL_WORLD_POSITIONS))
+                    for (int i = 0; i < 3; ++i) { c.P.boxMin[i] = 0.f; c.P.boxSize[i] = 1.f; c.P.invBoxSize[i] = 1.f; }
                 c.P.ldsImage = net->curvatureImage;
                 c.P.outputMode = FVSRN_OUT_DENSITY_GRADIENT_DIRECT;  // rows 0, 1 of the last layer, raw
                 c.out = a.out + 4 * n;
@@ -1360,6 +1449,9 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             scene->lastInfo[1] = rotates ? S.resyncMask + 1 : 0;
             scene->lastInfo[2] = smallFn ? 1 : 0;
             scene->lastInfo[3] = wpb;
+            const bool usesScratch = (smallFn ? net->scratchOf(smallFn) : (a.shaded ? net->scratchShaded : net->scratchRender)) > 0;
+            if (usesScratch) g_scratchFence.before(net->device, s);
+            struct FenceAfter { bool on; int dev; hipStream_t s; ~FenceAfter() { if (on) { try { g_scratchFence.after(dev, s); } catch (...) {} } } } fenceAfter{usesScratch, net->device, s};
             hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid, a, grid, unsigned(64 * wpb), lds, s)
                                    : launch_render(a.shaded ? net->key : net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
             if (e == hipSuccess && K > 1) e = launch_composite(S.partial, d_out8, K, plane, S, s);

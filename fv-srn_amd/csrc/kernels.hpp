@@ -40,20 +40,63 @@ __device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* ld
     __syncthreads();
 }
 
-// positions (and directions) of batch b for this lane; lanes beyond n read point 0.  The next batch is fetched before the
-// current one is evaluated: with 2-3 waves per SIMD the ~1 us of a dependent global load is otherwise exposed once per batch.
+// positions (and directions) of batch b for this lane; lanes beyond n read point 0.  The batch base is wave-uniform (scalar address
+// arithmetic), the lane adds a 32-bit offset: no 64-bit vector arithmetic per point (r02: 18 v_lshl_add_u64 + 6 v_mad_u64_u32 per batch).
 template <bool HAS_DIR>
 __device__ __forceinline__ void load_eval_point(const float* __restrict__ pos, const float* __restrict__ dir, size_t n, size_t b, int lane,
                                                 float (&p)[3], float (&d)[3]) {
-    const size_t i = b * 64 + lane;
-    const size_t j = i < n ? i : 0;
-    p[0] = pos[3 * j + 0]; p[1] = pos[3 * j + 1]; p[2] = pos[3 * j + 2];
-    if constexpr (HAS_DIR) { d[0] = dir[3 * j + 0]; d[1] = dir[3 * j + 1]; d[2] = dir[3 * j + 2]; }
+    const size_t first = b * 64;                        // wave-uniform
+    const unsigned cnt = unsigned(n - first < 64 ? n - first : 64);
+    const unsigned j = unsigned(lane) < cnt ? unsigned(lane) : 0u;
+    const float* pb = pos + 3 * first;                  // scalar
+    p[0] = pb[3 * j + 0]; p[1] = pb[3 * j + 1]; p[2] = pb[3 * j + 2];
+    if constexpr (HAS_DIR) { const float* db = dir + 3 * first; d[0] = db[3 * j + 0]; d[1] = db[3 * j + 1]; d[2] = db[3 * j + 2]; }
     else { d[0] = d[1] = d[2] = 0.f; }
 }
 
+// evaluate_points of a ReLU network runs the weight image whose activations are scaled into [0,1] (pack.cpp: convert + ReLU is one clamped
+// v_cvt_pk_f16_f32; the plain ReLU costs 48 v_pk_max_f16 per batch of a 32x4 network on top of the converts).  Its bound holds for positions
+// inside the unit box and directions inside [-1,1]^3 -- what a caller evaluates as a rule, but not a promise of this entry point.  So the
+// ACT_RELU01 launch checks the 64 points of every batch and hands a batch with a point outside to a second launch with the plain image
+// (NetParams::evalTodo), which as a rule finds an empty list.
+template <int ACT, bool HAS_DIR>
+__device__ __forceinline__ bool eval_batch_deferred(const NetParams& P, size_t b, int lane, float px, float py, float pz, float dx, float dy, float dz) {
+    if constexpr (ACT == ACT_RELU01) {
+        bool outside = !(px >= 0.f && px <= 1.f && py >= 0.f && py <= 1.f && pz >= 0.f && pz <= 1.f);
+        if constexpr (HAS_DIR) outside = outside || !(fabsf(dx) <= 1.f && fabsf(dy) <= 1.f && fabsf(dz) <= 1.f);
+        if (__builtin_amdgcn_ballot_w64(outside) != 0) {  // wave-uniform
+            if (lane == 0) P.evalTodo[1 + atomicAdd(P.evalTodo, 1u)] = unsigned(b);
+            return true;
+        }
+    }
+    return false;
+}
+// batch index of loop iteration k: the k-th entry of the list (plain-image launch behind an ACT_RELU01 launch) or k itself
+template <int ACT>
+__device__ __forceinline__ size_t eval_batch_index(const NetParams& P, size_t k) {
+    if constexpr (ACT != ACT_RELU01) {
+        if (P.evalTodo) return P.evalTodo[1 + k];
+    }
+    return k;
+}
+// the plain-image launch behind an ACT_RELU01 launch: a workgroup whose first wave is beyond the list leaves before it copies the network
+template <int ACT>
+__device__ __forceinline__ bool eval_block_has_nothing_to_do(const NetParams& P) {
+    if constexpr (ACT != ACT_RELU01) {
+        if (P.evalTodo) return size_t(blockIdx.x) * (blockDim.x >> 6) >= size_t(P.evalTodo[0]);  // workgroup-uniform
+    }
+    return false;
+}
+template <int ACT>
+__device__ __forceinline__ size_t eval_batch_count(const NetParams& P, size_t n) {
+    if constexpr (ACT != ACT_RELU01) {
+        if (P.evalTodo) return P.evalTodo[0];
+    }
+    return (n + 63) / 64;
+}
+
 // output parametrization of IVolumeInterpolation::evaluate for point i (renderer_volume_tensorcores.cuh:1054-1158)
-__device__ __forceinline__ void write_eval_outputs(const NetParams& P, const float4_t& o, float* __restrict__ out, size_t i, int outChannels) {
+__device__ __forceinline__ void write_eval_outputs(const NetParams& P, const float4_t& o, float* __restrict__ out, unsigned i, int outChannels) {
     switch (P.outputMode) {
         case FVSRN_OUT_DENSITY:
         case FVSRN_OUT_DENSITY_GRADIENT:
@@ -92,8 +135,9 @@ __device__ __forceinline__ void evaluate_body(const NetParams& P, const char* ld
     const size_t wavesPerBlock = blockDim.x >> 6;
     const size_t wave = size_t(blockIdx.x) * wavesPerBlock + (threadIdx.x >> 6);
     const size_t numWaves = size_t(gridDim.x) * wavesPerBlock;
-    const size_t batches = (n + 63) / 64;
-    for (size_t b = wave; b < batches; b += numWaves) {  // wave-uniform trip count: EXEC stays full
+    const size_t batches = eval_batch_count<ACT>(P, n);
+    for (size_t k = wave; k < batches; k += numWaves) {  // wave-uniform trip count: EXEC stays full
+        const size_t b = eval_batch_index<ACT>(P, k);
         const size_t i = b * 64 + lane;
         const bool valid = i < n;
         float np_[3], nd_[3];  // (the next batch is not fetched ahead here: six more live registers for the wide kernels, +3 % at 32 wide)
@@ -104,8 +148,9 @@ __device__ __forceinline__ void evaluate_body(const NetParams& P, const char* ld
         px = (px - P.boxMin[0]) * P.invBoxSize[0];
         py = (py - P.boxMin[1]) * P.invBoxSize[1];
         pz = (pz - P.boxMin[2]) * P.invBoxSize[2];
+        if (eval_batch_deferred<ACT, HAS_DIR>(P, b, lane, px, py, pz, dx, dy, dz)) continue;
         const float4_t o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz);
-        if (valid) write_eval_outputs(P, o, out, i, outChannels);
+        if (valid) write_eval_outputs(P, o, out + b * 64 * size_t(outChannels), unsigned(lane), outChannels);  // (wave-uniform base, 32-bit lane offset)
     }
 }
 
@@ -117,6 +162,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void e
                                                                  const float* __restrict__ dir, size_t n,
                                                                  float* __restrict__ out, int outChannels) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (eval_block_has_nothing_to_do<ACT>(P)) return;
     load_network_to_lds(P, lds);
     if constexpr (GRID == 0) {  // a latent grid needs Fourier features (SceneNetwork::valid)
         if (P.noFourier) return evaluate_body<CD, ACT, GRID, HAS_DIR, FM_FIRST_LAYER>(P, lds, pos, dir, n, out, outChannels);
@@ -176,6 +222,7 @@ template <int ACT, bool HAS_DIR, int NLC, int EGRID = 0>
 __global__ __launch_bounds__(kBlockThreads, 2) void evaluate_small_kernel(NetParams P, const float* __restrict__ pos, const float* __restrict__ dir,
                                                                         size_t n, float* __restrict__ out, int outChannels) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (eval_block_has_nothing_to_do<ACT>(P)) return;
     load_network_to_lds(P, lds);
     ResidentNet<NLC, EGRID> R;
     load_resident(P, lds, R);
@@ -183,18 +230,20 @@ __global__ __launch_bounds__(kBlockThreads, 2) void evaluate_small_kernel(NetPar
     const size_t wavesPerBlock = blockDim.x >> 6;
     const size_t wave = size_t(blockIdx.x) * wavesPerBlock + (threadIdx.x >> 6);
     const size_t numWaves = size_t(gridDim.x) * wavesPerBlock;
-    const size_t batches = (n + 63) / 64;
+    const size_t batches = eval_batch_count<ACT>(P, n);
     float np_[3], nd_[3];
-    if (wave < batches) load_eval_point<HAS_DIR>(pos, dir, n, wave, lane, np_, nd_);
-    for (size_t b = wave; b < batches; b += numWaves) {
+    if (wave < batches) load_eval_point<HAS_DIR>(pos, dir, n, eval_batch_index<ACT>(P, wave), lane, np_, nd_);
+    for (size_t k = wave; k < batches; k += numWaves) {
+        const size_t b = eval_batch_index<ACT>(P, k);
         const size_t i = b * 64 + lane;
         const bool valid = i < n;
         float px = np_[0], py = np_[1], pz = np_[2];
         const float dx = nd_[0], dy = nd_[1], dz = nd_[2];
-        if (b + numWaves < batches) load_eval_point<HAS_DIR>(pos, dir, n, b + numWaves, lane, np_, nd_);
+        if (k + numWaves < batches) load_eval_point<HAS_DIR>(pos, dir, n, eval_batch_index<ACT>(P, k + numWaves), lane, np_, nd_);
         px = (px - P.boxMin[0]) * P.invBoxSize[0];
         py = (py - P.boxMin[1]) * P.invBoxSize[1];
         pz = (pz - P.boxMin[2]) * P.invBoxSize[2];
+        if (eval_batch_deferred<ACT, HAS_DIR>(P, b, lane, px, py, pz, dx, dy, dz)) continue;
         float4_t o;
         if constexpr (EGRID == 1) {
             o = srn_forward_resident_grid<ACT, HAS_DIR, NLC, true>(P, R, px, py, pz, dx, dy, dz);
@@ -203,7 +252,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void evaluate_small_kernel(NetPar
             o = srn_layers_resident<ACT, NLC, 0, true>(
                 P, R, xb, [&]() { fourier_fragments<2, ACT, HAS_DIR, FM_COS>(P, lds, px, py, pz, dx, dy, dz, xb); }, [](int) {});
         }
-        if (valid) write_eval_outputs(P, o, out, i, outChannels);
+        if (valid) write_eval_outputs(P, o, out + b * 64 * size_t(outChannels), unsigned(lane), outChannels);
     }
 }
 

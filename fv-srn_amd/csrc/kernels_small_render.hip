@@ -57,10 +57,11 @@ hipError_t launch_render_small(int act, bool dir, int numLayers, int tail, int g
 // ---- evaluate_small_kernel (plain weight image: evaluate takes positions outside the box) ---------------------------------------
 #define FVSRN_SMALL_EVAL_VARIANTS(X) \
     X(ACT_RELU, false) X(ACT_RELU, true) X(ACT_SINE, false) X(ACT_SINE, true) X(ACT_SNAKE, false) X(ACT_SNAKE, true) \
-    X(ACT_SNAKEALT, false) X(ACT_SNAKEALT, true) X(ACT_SIGMOID, false) X(ACT_SIGMOID, true)
+    X(ACT_SNAKEALT, false) X(ACT_SNAKEALT, true) X(ACT_SIGMOID, false) X(ACT_SIGMOID, true) \
+    X(ACT_RELU01, false) X(ACT_RELU01, true) X(ACT_SNAKEALT0, false) X(ACT_SNAKEALT0, true)
 #define FVSRN_SMALL_EVAL_LAYERS(A, D) Z(A, D, 1) Z(A, D, 2) Z(A, D, 3)
 
-#define FVSRN_SMALL_EVAL_GRID_VARIANTS(X) X(ACT_RELU, false) X(ACT_SINE, false) X(ACT_SNAKE, false) X(ACT_SNAKEALT, false)
+#define FVSRN_SMALL_EVAL_GRID_VARIANTS(X) X(ACT_RELU, false) X(ACT_SINE, false) X(ACT_SNAKE, false) X(ACT_SNAKEALT, false) X(ACT_RELU01, false) X(ACT_SNAKEALT0, false)
 
 hipError_t launch_eval_small(int act, bool dir, int numLayers, int grid, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s) {
     if (grid == 1) {

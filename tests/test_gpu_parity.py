@@ -79,6 +79,40 @@ def test_evaluate_ragged_sizes(n):
         assert np.abs(out - ref).max() < TOL_SAME_MODEL
 
 
+@pytest.mark.parametrize("net_kw", [dict(C=32, layers=4), dict(C=32, layers=4, grid=(16, 8)), dict(C=64, layers=3, grid=(16, 8)), dict(C=48, layers=5),
+                                    dict(C=32, layers=2)])
+@pytest.mark.parametrize("where", ["inside", "mixed", "outside", "one_point_outside"])
+def test_evaluate_points_relu_scaled_image_and_points_outside_the_box(net_kw, where):
+    """evaluate_points of a ReLU network runs the [0,1]-scaled weight image (one clamped convert per activation pair); its bound only
+    holds inside the unit box, so batches of 64 points with a point outside are deferred to a second launch with the plain image
+    (kernels.hpp, eval_batch_deferred).  Every mixture must equal the oracle and the network with the scaled image switched off."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(activation="ReLU", output_mode="density:direct", seed=91, grid_scale=0.3, **net_kw)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    plain = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    plain.set_option("relu_clamp", 0)
+    rng = np.random.RandomState(17)
+    n = 64 * 37 + 19
+    pos = rng.uniform(0.0, 1.0, (n, 3)).astype(np.float32)
+    if where == "mixed":
+        far = rng.rand(n) < 0.3
+        pos[far] = rng.uniform(-0.7, 1.8, (int(far.sum()), 3)).astype(np.float32)
+    elif where == "outside":
+        pos = rng.uniform(1.01, 1.6, (n, 3)).astype(np.float32)
+    elif where == "one_point_outside":
+        pos[64 * 20 + 5, 1] = -0.01
+    pos[0] = (0.0, 1.0, 0.0)  # the faces themselves are inside
+    p = torch.from_numpy(pos).cuda()
+    out, ref_plain = net.evaluate(p), plain.evaluate(p)
+    torch.cuda.synchronize()
+    ref = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(out.cpu().numpy() - ref).max() < TOL_SAME_MODEL * scale
+    assert float((out - ref_plain).abs().max()) < TOL_SAME_MODEL * scale
+    assert "ACT_RELU01" in net.kernel_name(False) and "ACT_RELU," in plain.kernel_name(False)
+
+
 @pytest.mark.parametrize("enc", [0, 1, 2])
 def test_evaluate_grid_encodings_and_box(enc):
     vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density", grid=(16, 8), seed=5,

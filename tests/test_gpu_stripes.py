@@ -57,7 +57,9 @@ def test_two_frames_in_flight_at_different_times(enc, has_time, slots, ahead):
         ref_scene.update(**_scene_kw(yaw))
         ref = ref_scene.render(serial, W, H)
         torch.cuda.synchronize()
-        assert torch.equal(torch.nan_to_num(got[j], nan=-7.0), torch.nan_to_num(ref, nan=-7.0)), (j, t)
+        d = (torch.nan_to_num(got[j], nan=-7.0) - torch.nan_to_num(ref, nan=-7.0)).abs()
+        assert float(d.max()) == 0.0, "frame %d (time %g): %d values differ, max %.3g, per channel %s" % (
+            j, t, int((d > 0).sum()), float(d.max()), [int((d[0, c] > 0).sum()) for c in range(8)])
         assert float(ref[0, 3].max()) > 0.2
     # ... and the values themselves against the oracle at one of the times
     want, _ = oracle.OracleScene(**_scene_kw(yaws[3])).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT, time=times[3]), W, H)

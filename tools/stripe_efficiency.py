@@ -47,7 +47,7 @@ def main():
         _, net = b.make_network(volnet_io, capi, cfg, "ReLU", keys)
         full = frame_period(net, cfg, keys, 0, 1, pipelined=False)
         row = {"workload": name, "full_frame_ms": full, "time_keys": keys, "world": {}}
-        ahead = os.environ.get("FVSRN_BENCH_BLEND_AHEAD", "1") == "1"
+        ahead = os.environ.get("FVSRN_BENCH_BLEND_AHEAD", "0") == "1"
         row["blend_ahead"] = bool(ahead and keys > 1)
         row["working_grids"] = net.get_option("working_grids")
         for world in (2, 4, 8):
