@@ -1109,6 +1109,8 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
                 e = launch_eval(evalKey, a, grid, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
             if (e == hipSuccess && a.P.evalTodo) {  // the batches the scaled-image launch deferred (as a rule: none), from the plain image
                 EvalArgs b2 = a;
+                // (one workgroup per CU walks the list: as a rule it is empty and the launch costs a few microseconds)
+                const unsigned gridTodo = unsigned(std::min<size_t>(blocks, size_t(net->numCUs)));
                 b2.P.ldsImage = net->packed.params.ldsImage;
                 b2.P.reluClamp = 0;
                 hipError_t e2 = hipErrorInvalidDeviceFunction;
@@ -1116,9 +1118,8 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
                 const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && b2.P.gridK == 1 && b2.P.bias0Folded ? 1 : 2);
                 if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !b2.P.noFourier && !b2.P.fourierNeedsFractEval && b2.P.numLayers >= 1 &&
                     b2.P.numLayers <= 3)
-                    e2 = launch_eval_small(k.act, k.dir, b2.P.numLayers, smallGrid, b2, unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 8 / wpb)),
-                                           unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
-                if (e2 == hipErrorInvalidDeviceFunction) e2 = launch_eval(k, b2, grid, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
+                    e2 = launch_eval_small(k.act, k.dir, b2.P.numLayers, smallGrid, b2, gridTodo, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
+                if (e2 == hipErrorInvalidDeviceFunction) e2 = launch_eval(k, b2, gridTodo, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
                 e = e2;
             }
             if (e == hipSuccess && curvature) {
