@@ -437,7 +437,9 @@ struct fvsrn_network {
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         numCUs = prop.multiProcessorCount;
-        imagesOrder.beginWrite(stream);  // a changed network: kernels on other streams may still read the old images
+        // a changed network (rare): kernels on any stream may still read the old images -- wait for the device instead of recording an
+        // event behind every launch (r03: that record cost 3 % of a 0.3 ms frame)
+        if (dLds.ptr) HIP_CHECK(hipDeviceSynchronize());
         dLds.ensure(packed.ldsImage.size());
         HIP_CHECK(hipMemcpyAsync(dLds.ptr, packed.ldsImage.data(), packed.ldsImage.size(), hipMemcpyHostToDevice, stream));
         packed.params.ldsImage = dLds.ptr;
@@ -545,7 +547,6 @@ struct fvsrn_network {
         if (packed.keys.records) workGrid[curWorkGrid].order.beginRead(stream);
     }
     void endUse(hipStream_t stream) {
-        imagesOrder.endRead(stream);
         if (packed.keys.records) workGrid[curWorkGrid].order.endRead(stream);
     }
 
@@ -954,7 +955,7 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
             const bool scalarNet = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
             const bool colourNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
             const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && P.gridK == 1 && P.bias0Folded ? 1 : 2);
-            if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !P.noFourier && !P.fourierNeedsFractPlain && (scalarNet || colourNet) &&
+            if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !P.noFourier && !P.fourierNeedsFractPlain && !P.fourierClampPos && (scalarNet || colourNet) &&
                 render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1, smallGrid))
                 name = "render_small_kernel<act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "," + std::to_string(P.numLayers) +
                        ",SGRID=" + std::to_string(smallGrid) + "> (unshaded; else " + name + ")";
@@ -1366,6 +1367,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
                 smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.gridK == 1 && a.P.bias0Folded ? 1 : 2);  // one decoded 16-channel chunk (no time input: bias0Folded): resident kernel
                 if (O[FVSRN_OPT_SMALL_KERNEL] != 0 && net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && !a.shaded && k.CD == 2 && smallGrid <= 1 && !a.P.noFourier && !a.P.fourierNeedsFract &&
+                    !a.P.fourierClampPos &&  // (the resident kernels compile the position clamp out)
                     a.P.numLayers >= 1 && a.P.numLayers <= 3 && (rgbo || (scalarNet && d.tf_kind != FVSRN_TF_NONE)))
                     smallFn = render_small_fn(k.act, k.dir, a.P.numLayers, smallTail, smallGrid);
             }

@@ -561,7 +561,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
         nValid += unsigned(__builtin_popcountll(validMask));
 
         float px = fmaf(dnx, t, pn0x), py = fmaf(dny, t, pn0y), pz = fmaf(dnz, t, pn0z);
-        if constexpr (!SHADED) {
+        if constexpr (!SHADED && NLC == 0) {  // (the register-resident kernels never see such a network: api.cpp)
             if (P.fourierClampPos) {  // wave-uniform; see device_params.hpp
                 px = __builtin_amdgcn_fmed3f(px, 0.f, 1.f); py = __builtin_amdgcn_fmed3f(py, 0.f, 1.f); pz = __builtin_amdgcn_fmed3f(pz, 0.f, 1.f);
             }

@@ -189,7 +189,8 @@ class StripeRenderer:
             if self.world > 1:
                 stream.wait_event(self.gather_done[b])  # buffer b is free again
             self._render(scene, b, stats)
-            self.render_done[b].record()
+            if self.world > 1:
+                self.render_done[b].record()
             if record and self.on_gpu:
                 e1.record()
                 self.kernel_events.append((e0, e1))

@@ -1,6 +1,10 @@
+#!/bin/bash
+# usage (GPU box): tools/run_round_profile.sh <round tag>      everything the round's profiles/ directory is built from -> gpurun_out/
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-V=${1:-r02}
+V=${1:-r03}
 python -m pytest tests -m gpu -x -q 2>&1 | tail -1
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep "smoke" > gpurun_out/smoke_${V}.txt
+grep "2-rank line" gpurun_out/smoke_${V}.txt | sed 's/^smoke 2-rank line: //' > gpurun_out/two_rank_gloo_${V}.json
 python bench.py > gpurun_out/bench_${V}.json 2> gpurun_out/bench_${V}.err
 for c in c32l4_fourier_512x256 c32l4_grid16_1024x512 c64l6_grid16_1024x512 c64l6_grid16_time16_1024x512; do python bench.py --config $c --no-cpu-baseline > gpurun_out/bench_${V}_$c.json 2>/dev/null; done
 for c in c32l4_fourier_1024x512 c32l4_grid16_1024x512 c64l6_grid16_1024x512; do tools/pmc_profile.sh ${c}_${V} --config $c > /dev/null 2>&1; done
@@ -15,10 +19,20 @@ for act in ("ReLU", "SnakeAlt"):
     open("/tmp/protocol_%s.volnet" % act, "wb").write(volnet_io.save_volnet(vn))
 PY
 for a in ReLU SnakeAlt; do python tools/render_protocol.py /tmp/protocol_$a.volnet 2>/dev/null | tail -1 >> gpurun_out/protocol_c32l4_512x512_${V}.jsonl; done
+# evaluate_points: throughput with both rooflines, and the rocprofv3 kernel summary of the same command
 python tools/bench_evaluate.py > /dev/null 2>&1; python tools/bench_evaluate.py > gpurun_out/bench_evaluate_${V}.jsonl 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_evaluate_${V} -- python3 tools/bench_evaluate.py 16777216 > gpurun_out/bench_evaluate_under_rocprof_${V}.jsonl 2>/dev/null
+cp $(ls gpurun_out/prof_evaluate_${V}/*/*kernel_stats.csv | head -1) gpurun_out/evaluate_points_${V}_kernel_stats.csv 2>/dev/null
+python tools/bench_evaluate_gradients.py > gpurun_out/bench_evaluate_gradients_${V}.jsonl 2>/dev/null
+python tools/bench_shaded.py > gpurun_out/bench_shaded_${V}.jsonl 2>/dev/null
+python tools/stripe_efficiency.py > gpurun_out/stripe_efficiency_${V}.jsonl 2>/dev/null
+FVSRN_WORKING_GRIDS=1 python tools/stripe_efficiency.py c64l6_grid16_time16_1024x512 > gpurun_out/stripe_efficiency_one_working_grid_${V}.jsonl 2>/dev/null
 python tools/bench_grid_volume.py > gpurun_out/grid_volume_bench_${V}.json 2>/dev/null
 python tools/bench_tail_variants.py 2>/dev/null | grep -v amdgpu > gpurun_out/tail_variants_${V}.txt
+[ -x tools/microbench/bin/r03_snakealt ] && tools/microbench/bin/r03_snakealt 2>&1 | grep -v amdgpu.ids > gpurun_out/snakealt_microbench_${V}.txt
+python tools/dev/stress_concurrent.py 100 2>&1 | grep -v amdgpu.ids > gpurun_out/stress_concurrent_${V}.txt
+python tests/test_fuzz_parity.py 400 > gpurun_out/fuzz_report_gpu_vs_device_model_${V}.txt 2>/dev/null
 for f in gpurun_out/bench_${V}*.json; do python -c "
 import json,sys
 d=json.load(open('$f'))
-print(d['config']['workload'].split(':')[0], '%.2f G %.3f ms frac %.3f' % (d['value']/1e9, d['ms_per_step'], d['roofline']['frac']), 'twin %.2f' % (d['twin']['value']/1e9) if d.get('twin') else '', d.get('cpu_baseline',{}).get('value'))"; done
+print(d['config']['workload'].split(':')[0], '%.2f G %.3f ms frac %.3f' % (d['value']/1e9, d['ms_per_step'], d['roofline']['frac']), 'twin %.2f' % (d['twin']['value']/1e9) if d.get('twin') else '', 'exact %.2f' % (d['exact_features']['value']/1e9) if d.get('exact_features') else '', d.get('cpu_baseline',{}).get('value'))"; done
