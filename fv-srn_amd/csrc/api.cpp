@@ -29,13 +29,13 @@ struct Options {
     Options() {
         v[FVSRN_OPT_SMALL_KERNEL] = -1; v[FVSRN_OPT_PERSISTENT] = -1; v[FVSRN_OPT_DEPTH_SEGMENTS] = 0; v[FVSRN_OPT_FOURIER_RESYNC] = 0;
         v[FVSRN_OPT_UNIT_QUOTA] = -1; v[FVSRN_OPT_TILE_ORDER] = -1; v[FVSRN_OPT_WAVES_PER_BLOCK] = 0; v[FVSRN_OPT_MAX_BLOCKS_PER_CU] = 0;
-        v[FVSRN_OPT_RELU_CLAMP] = 1; v[FVSRN_OPT_KEYFRAME_SLOTS] = 0; v[FVSRN_OPT_WORKING_GRIDS] = 0;
+        v[FVSRN_OPT_RELU_CLAMP] = 1; v[FVSRN_OPT_KEYFRAME_SLOTS] = 0; v[FVSRN_OPT_WORKING_GRIDS] = 0; v[FVSRN_OPT_OVERLAP_KERNEL] = -1;
     }
     int operator[](int i) const { return v[i]; }
     // empty string = valid
     static std::string check(int opt, int value) {
         switch (opt) {
-            case FVSRN_OPT_SMALL_KERNEL: case FVSRN_OPT_PERSISTENT: case FVSRN_OPT_TILE_ORDER:
+            case FVSRN_OPT_SMALL_KERNEL: case FVSRN_OPT_PERSISTENT: case FVSRN_OPT_TILE_ORDER: case FVSRN_OPT_OVERLAP_KERNEL:
                 return value >= -1 && value <= 1 ? "" : "value must be -1 (automatic), 0 or 1";
             case FVSRN_OPT_DEPTH_SEGMENTS: return value >= 0 && value <= 64 ? "" : "segments must be 0 (automatic) .. 64";
             case FVSRN_OPT_FOURIER_RESYNC:
@@ -58,7 +58,7 @@ static const Options& defaultOptions() {
             {"FVSRN_SMALL_KERNEL", FVSRN_OPT_SMALL_KERNEL}, {"FVSRN_PERSISTENT", FVSRN_OPT_PERSISTENT}, {"FVSRN_SEGMENTS", FVSRN_OPT_DEPTH_SEGMENTS},
             {"FVSRN_FOURIER_RESYNC", FVSRN_OPT_FOURIER_RESYNC}, {"FVSRN_UNIT_QUOTA", FVSRN_OPT_UNIT_QUOTA}, {"FVSRN_TILE_ORDER", FVSRN_OPT_TILE_ORDER},
             {"FVSRN_WAVES_PER_BLOCK", FVSRN_OPT_WAVES_PER_BLOCK}, {"FVSRN_MAX_BLOCKS_PER_CU", FVSRN_OPT_MAX_BLOCKS_PER_CU},
-            {"FVSRN_KEYFRAME_SLOTS", FVSRN_OPT_KEYFRAME_SLOTS}, {"FVSRN_WORKING_GRIDS", FVSRN_OPT_WORKING_GRIDS}};
+            {"FVSRN_KEYFRAME_SLOTS", FVSRN_OPT_KEYFRAME_SLOTS}, {"FVSRN_WORKING_GRIDS", FVSRN_OPT_WORKING_GRIDS}, {"FVSRN_OVERLAP_KERNEL", FVSRN_OPT_OVERLAP_KERNEL}};
         for (const auto& e : kEnv)
             if (const char* t = std::getenv(e.name)) {
                 const int val = std::atoi(t);
@@ -496,6 +496,7 @@ struct fvsrn_network {
         scratchSmall.clear();
         HIP_CHECK(hipFuncSetAttribute(kinfoScaled.renderFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         HIP_CHECK(hipFuncSetAttribute(kinfo.renderShadedFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
+        if (const void* fn = render_stripe_fn(keyScaled)) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         deviceValid = true;
     }
 
@@ -1385,7 +1386,13 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 }
                 lds += size_t(wpb) * kRotationBytes;
             }
-            const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded, smallFn, O[FVSRN_OPT_MAX_BLOCKS_PER_CU]);
+            // the spill-free variant of the wide latent-grid renderers (render_stripe_kernel, kernels.hpp): for launches that are meant to
+            // overlap with other launches -- the stripes of a multi-GPU frame alternate between two streams
+            const void* stripeFn = nullptr;
+            if (!smallFn && !a.shaded && (O[FVSRN_OPT_OVERLAP_KERNEL] >= 0 ? O[FVSRN_OPT_OVERLAP_KERNEL] == 1 : stripeWorld > 1))
+                stripeFn = render_stripe_fn(net->keyScaled);
+            const void* altFn = smallFn ? smallFn : stripeFn;
+            const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded, altFn, O[FVSRN_OPT_MAX_BLOCKS_PER_CU]);
             const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));  // workgroups the chip holds at once
             // Depth segments (kernels.hpp): with fewer tiles than ~4x the resident waves (small images, the stripes of one
             // rank of a multi-GPU frame) the longest tile dictates the launch time; cut the rays into K step ranges so that
@@ -1450,13 +1457,14 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                                  !a.shaded;  // kRotate / kRotateLds, kernels.hpp
             scene->lastInfo[0] = K;
             scene->lastInfo[1] = rotates ? S.resyncMask + 1 : 0;
-            scene->lastInfo[2] = smallFn ? 1 : 0;
+            scene->lastInfo[2] = smallFn ? 1 : (stripeFn ? 2 : 0);
             scene->lastInfo[3] = wpb;
-            const bool usesScratch = (smallFn ? net->scratchOf(smallFn) : (a.shaded ? net->scratchShaded : net->scratchRender)) > 0;
+            const bool usesScratch = (altFn ? net->scratchOf(altFn) : (a.shaded ? net->scratchShaded : net->scratchRender)) > 0;
             if (usesScratch) g_scratchFence.before(net->device, s);
             struct FenceAfter { bool on; int dev; hipStream_t s; ~FenceAfter() { if (on) { try { g_scratchFence.after(dev, s); } catch (...) {} } } } fenceAfter{usesScratch, net->device, s};
             hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid, a, grid, unsigned(64 * wpb), lds, s)
-                                   : launch_render(a.shaded ? net->key : net->keyScaled, a, grid, unsigned(64 * wpb), lds, s);
+                                   : (stripeFn ? launch_render_stripe(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s)
+                                               : launch_render(a.shaded ? net->key : net->keyScaled, a, grid, unsigned(64 * wpb), lds, s));
             if (e == hipSuccess && K > 1) e = launch_composite(S.partial, d_out8, K, plane, S, s);
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during rendering! ") + hipGetErrorString(e));
             return FVSRN_OK;

@@ -401,7 +401,8 @@ __device__ __forceinline__ float select_by_mask(unsigned long long m, float x) {
 }
 
 // NLC > 0 (render_small_kernel): the network stays in registers (ResidentNet, srn_device.hpp); CD = 2, GRID = 0, rotation path
-template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, bool SHADED, int TAIL = TAIL_GENERIC, int NLC = 0>
+// SCHED: srn_layers' schedule (1: fragment-major for every width, render_stripe_kernel)
+template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, bool SHADED, int TAIL = TAIL_GENERIC, int NLC = 0, int SCHED = 0>
 __device__ __forceinline__ void render_body(const NetParams& P, const SceneParams& S, const char* lds, const float* tfLds,
                                             float* __restrict__ out, unsigned long long* __restrict__ stats) {
     const int lane = lane_id();
@@ -589,7 +590,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
         } else if constexpr (NLC > 0 && GRID == 1) {
             o = srn_forward_resident_grid<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, px, py, pz, dx, dy, dz);
         } else {
-            o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz);
+            o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE, SCHED>(P, lds, px, py, pz, dx, dy, dz);
         }
 
         FVSRN_MARK(P, 5);  // last layer (+ the other half of the rotation)
@@ -833,13 +834,13 @@ __device__ __forceinline__ float* render_prologue(const NetParams& P, const Scen
     return tfLds;
 }
 
-template <int CD, int ACT, int GRID, bool HAS_DIR, bool SHADED>
+template <int CD, int ACT, int GRID, bool HAS_DIR, bool SHADED, int SCHED = 0>
 __device__ __forceinline__ void render_entry(const NetParams& P, const SceneParams& S, float* __restrict__ out,
                                              unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* tfLds = render_prologue(P, S, lds);
     if constexpr (GRID == 0) {
-        if (P.noFourier) return render_body<CD, ACT, GRID, HAS_DIR, FM_FIRST_LAYER, SHADED>(P, S, lds, tfLds, out, stats);
+        if (P.noFourier) return render_body<CD, ACT, GRID, HAS_DIR, FM_FIRST_LAYER, SHADED, TAIL_GENERIC, 0, SCHED>(P, S, lds, tfLds, out, stats);
     }
     if constexpr (!SHADED) {
         // The straight-line tails: a scalar network behind an Identity or Texture TF with Beer-Lambert blending, phases inside the v_cos /
@@ -848,19 +849,30 @@ __device__ __forceinline__ void render_entry(const NetParams& P, const ScenePara
         const bool scalarNet = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
         if (scalarNet && !P.fourierNeedsFract && S.blendMode == FVSRN_BLEND_BEER_LAMBERT) {
             if (S.tfKind == FVSRN_TF_IDENTITY && S.tfAbsorptionStepLog2e <= 0.f)
-                return render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_SCALAR_IDENTITY>(P, S, lds, tfLds, out, stats);
+                return render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_SCALAR_IDENTITY, 0, SCHED>(P, S, lds, tfLds, out, stats);
             if (S.tfKind == FVSRN_TF_TEXTURE && S.tfOpacityNonNegative)  // (a negative opacity: the generic tail skips the sample, stepping_dvr.cuh:137)
-                return render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_SCALAR_TEXTURE>(P, S, lds, tfLds, out, stats);
+                return render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_SCALAR_TEXTURE, 0, SCHED>(P, S, lds, tfLds, out, stats);
         }
     }
-    if (P.fourierNeedsFract) return render_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS, SHADED>(P, S, lds, tfLds, out, stats);
-    render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED>(P, S, lds, tfLds, out, stats);
+    if (P.fourierNeedsFract) return render_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS, SHADED, TAIL_GENERIC, 0, SCHED>(P, S, lds, tfLds, out, stats);
+    render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_GENERIC, 0, SCHED>(P, S, lds, tfLds, out, stats);
 }
 
 template <int CD, int ACT, int GRID, bool HAS_DIR>
 __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                unsigned long long* __restrict__ stats) {
     render_entry<CD, ACT, GRID, HAS_DIR, false>(P, S, out, stats);
+}
+
+// render_kernel for the stripes of a multi-GPU frame (and any caller that keeps two frames in flight on two streams): 48- and 64-wide
+// latent-grid networks in the fragment-major layer order.  On one stream the pipelined order of render_kernel is 1.2 % faster (64x6 + 32^3
+// grid: 24.75 vs 24.45 Gsamples/s), but it spills 76 registers to scratch, and kernels with scratch are serialised across streams
+// (ScratchFence, api.cpp); this variant needs 218 registers and no scratch, its launches overlap on two streams: per-rank frame period of
+// configs[3] 7.2 - 7.7 / 3.86 / 2.02 ms at world 2 / 4 / 8 against 8.21 / 4.09 / 2.05 ms (profiles/r03/experiments_r03.md).
+template <int CD, int ACT, int GRID, bool HAS_DIR>
+__global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void render_stripe_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+                                                                      unsigned long long* __restrict__ stats) {
+    render_entry<CD, ACT, GRID, HAS_DIR, false, 1>(P, S, out, stats);
 }
 
 // 32-wide Fourier-only scalar networks with NLC <= 3 C->C layers behind a transfer function, phases inside the v_cos domain

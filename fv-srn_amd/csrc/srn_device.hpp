@@ -896,14 +896,15 @@ __device__ __forceinline__ float4_t srn_layers_kmajor(const NetParams& P, const 
 }
 
 // MAYBE_NO_LAYERS: the network may consist of first + last layer only (possible without Fourier features)
-template <int CD, int ACT, int GRID, bool HAS_DIR, int NFILL, bool MAYBE_NO_LAYERS, class Pre, class Fill>
+// SCHED = 1: the fragment-major order for every width (render_stripe_kernel: no register spills, see kernels.hpp)
+template <int CD, int ACT, int GRID, bool HAS_DIR, int NFILL, bool MAYBE_NO_LAYERS, int SCHED = 0, class Pre, class Fill>
 __device__ __forceinline__ float4_t srn_layers(const NetParams& P, const char* lds, half8_t (&xb)[2][2 * mtiles(CD)], float px,
                                                float py, float pz, Pre&& pre, Fill&& fill, const GridPre* gpre = nullptr) {
 #ifndef FVSRN_NO_PIPELINE
     // measured (r01, 1024^2 x 512): the pipelined order wins for Fourier-only networks (32x4: 106.7 -> 110.3 Gsamples/s) and
     // for 64-wide latent-grid networks (23.1 -> 23.9); for 32-wide ones with a grid its extra registers cost more
     // occupancy than the schedule gains (64.2 -> 62.2)
-    if constexpr (CD <= 4 && (GRID == 0 || CD >= 3)) {
+    if constexpr (SCHED == 0 && CD <= 4 && (GRID == 0 || CD >= 3)) {
         if constexpr (MAYBE_NO_LAYERS) {
             if (P.numLayers == 0)  // wave-uniform
                 return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill, gpre);
@@ -918,7 +919,7 @@ __device__ __forceinline__ float4_t srn_layers(const NetParams& P, const char* l
 #ifndef FVSRN_GRID_PRE
 #define FVSRN_GRID_PRE 1
 #endif
-template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE>
+template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, int SCHED = 0>
 __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* lds, float px, float py, float pz,
                                                 float dx, float dy, float dz) {
     half8_t xb[2][2 * mtiles(CD)];
@@ -955,9 +956,9 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
             for (int k = 1; k < 4; ++k) grid_reduce_record<false>(raw, G.gt[1], k, acc);
             G.gf[1] = grid_pack(acc);
         }
-        return srn_layers<CD, ACT, GRID, HAS_DIR, 0, false>(P, lds, xb, px, py, pz, []() {}, [](int) {}, &G);
+        return srn_layers<CD, ACT, GRID, HAS_DIR, 0, false, SCHED>(P, lds, xb, px, py, pz, []() {}, [](int) {}, &G);
     } else {
-        return srn_layers<CD, ACT, GRID, HAS_DIR, 0, FMODE == FM_FIRST_LAYER>(
+        return srn_layers<CD, ACT, GRID, HAS_DIR, 0, FMODE == FM_FIRST_LAYER, SCHED>(
             P, lds, xb, px, py, pz, [&]() { fourier_fragments<CD, ACT, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, xb); }, [](int) {});
     }
 }

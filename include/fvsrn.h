@@ -179,7 +179,10 @@ typedef enum {
     FVSRN_OPT_WORKING_GRIDS = 10,    /* network: blended fp16 working grids (what the kernels read); 0 = auto: 2 for a network with several
                                         key frames -- a time change then blends into the grid the frame in flight does not read, so
                                         two frames at different times may be in flight on two streams --, 1 otherwise  [FVSRN_WORKING_GRIDS] */
-    FVSRN_OPT_COUNT_ = 11
+    FVSRN_OPT_OVERLAP_KERNEL = 11,   /* scene: 48 / 64-wide latent-grid networks: 1 = render with the spill-free kernel variant (1 % slower alone,
+                                        but its launches may overlap on two streams: kernels with scratch memory are serialised across
+                                        streams), 0 = the default variant, -1 auto = 1 for the stripes of a multi-GPU frame  [FVSRN_OVERLAP_KERNEL] */
+    FVSRN_OPT_COUNT_ = 12
 } fvsrn_option;
 int fvsrn_network_set_option(fvsrn_network* net, int option, int value);
 int fvsrn_network_get_option(const fvsrn_network* net, int option, int* value);
@@ -287,7 +290,8 @@ int fvsrn_camera_on_a_sphere(int orientation, const double center[3], double pit
 /* How the last fvsrn_render / fvsrn_render_stripes of this scene treated the samples of a ray -- for callers that restate the
  * arithmetic (the parity oracle): out = { depth segments K a ray was cut into (1: none; the step count of the feature rotation
  * restarts in each), period in steps of the exact re-derivation of rotated Fourier features (0: the kernel derives the features
- * from the fp16 position at every step, like the reference; FVSRN_OPT_FOURIER_RESYNC), 1 if a register-resident kernel ran,
+ * from the fp16 position at every step, like the reference; FVSRN_OPT_FOURIER_RESYNC), kernel family (0 render_kernel, 1 register-resident, 2 spill-free
+ * stripe variant),
  * waves per workgroup }.  No reference counterpart. */
 int fvsrn_scene_last_render_info(fvsrn_scene* scene, int out[4]);
 

@@ -169,6 +169,37 @@ def test_texture_tf_with_negative_opacity_texels(grid):
     assert ref[3].min() >= 0.0 and ref[3].max() > 0.03
 
 
+@pytest.mark.parametrize("C,act,enc", [(64, "ReLU", 0), (48, "SnakeAlt", 0), (64, "Sine", 2)])
+def test_overlap_kernel_variant_renders_the_same_image(C, act, enc):
+    """render_stripe_kernel (48 / 64-wide latent-grid networks in the fragment-major layer order: no register spills, so its launches
+    may overlap on two streams; the stripes of a multi-GPU frame take it, scene option overlap_kernel forces it) against render_kernel:
+    the same arithmetic in another order of the MFMAs -- same image up to rounding, both inside the tolerance of the oracle."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=C, layers=4, activation=act, output_mode="density", grid=(16, 8), seed=61, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4,
+                             encoding=enc, grid_scale=0.3)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    kw = make_scene_kwargs(stepsize=1 / 64, early_out=True, tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)
+    W, H = 96, 64
+    a = capi.Scene(**kw).set_option("overlap_kernel", 0)
+    b = capi.Scene(**kw).set_option("overlap_kernel", 1)
+    ia, ib = a.render(net, W, H)[0].cpu().numpy(), b.render(net, W, H)[0].cpu().numpy()
+    assert a.last_render_info()["resident_kernel"] is False and b.last_render_info()["segments"] == a.last_render_info()["segments"]
+    ref, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), W, H)
+    assert_images_close(ia, ref, TOL_IMG)
+    assert_images_close(ib, ref, TOL_IMG)
+    assert np.abs(ia[:4] - ib[:4]).max() < 1e-3 and ref[3].max() > 0.2
+    # the stripes of a multi-GPU frame take the variant by themselves: rank 1 of 2, compact image against the rows of the whole frame
+    stripe = capi.render_stripes(capi.Scene(**kw), net, W, H, 16, 1, 2)
+    rows = tiles_rows(H, 16, 1, 2)
+    assert np.abs(np.nan_to_num(stripe.cpu().numpy()[:4]) - np.nan_to_num(ib[:4][:, rows])).max() < 1e-3
+
+
+def tiles_rows(H, stripe, rank, world):
+    from fvsrn_amd import tiles
+    return tiles.owned_rows(H, stripe, rank, world)
+
+
 def test_two_rank_processes_share_the_gpu_and_assemble_the_frame():
     """The N > 1 path end to end on one GPU: bench.py --gpus 2 as two rank processes (gloo; RCCL needs one GPU per rank), each
     rendering its round-robin stripes with the HIP kernels, all-gather, frame check against a whole-frame render."""
