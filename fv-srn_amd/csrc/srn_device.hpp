@@ -271,12 +271,18 @@ __device__ __forceinline__ void grid_load(const void* grid, const GridTap& t, in
 
 // FIRST: record 0 starts the sums (v_dot2_f32_f16 with the constant 0 as its addend: hipcc otherwise picks the accumulate-in-place
 // form v_dot2c and spends a v_mov per accumulator on the zeros -- 16 of the 57 v_mov of the r01 wave step)
+// HAZARD: hipcc's hazard recognizer does not look into inline assembly.  On gfx950 an instruction of another opcode (VALU, store, export)
+// that reads the result of a DOT instruction needs three wait states (LLVM GCNHazardRecognizer::checkMAIVALUHazards,
+// DotWriteDifferentVALURead); the compiler inserts `s_nop 2` for DOT instructions it emitted itself, not for this one (found r03: fp32
+// arithmetic right behind these came out wrong in three of eight channels).  Callers keep three instructions between this and the first
+// reader -- the sums below continue with seven more records' v_dot2c first -- and tools/check_dot_hazard.py (a CPU test runs it over
+// the built objects) disassembles the build and fails on any reader that is closer.  Code outside the hot path takes SAFE = true.
 __device__ __forceinline__ float dot2_from_zero(unsigned a, unsigned w) {
     float r;
     asm("v_dot2_f32_f16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(w));
     return r;
 }
-template <bool WITH_LO, bool FIRST = false>
+template <bool WITH_LO, bool FIRST = false, bool SAFE = false>
 __device__ __forceinline__ void grid_reduce_record(const GridRaw& r, const GridTap& t, int k, float acc[8]) {
     const half2_t w = __builtin_bit_cast(half2_t, t.w[k]);
 #pragma unroll
@@ -284,7 +290,10 @@ __device__ __forceinline__ void grid_reduce_record(const GridRaw& r, const GridT
         // NB: __builtin_bit_cast applied directly to a vector ELEMENT (v[j]) is miscompiled by clang 22 /
         // ROCm 7.2 (only element 0 survives): go through a scalar temporary
         const unsigned u0 = r.v[k][0][j], u1 = r.v[k][1][j];
-        if constexpr (FIRST) {
+        if constexpr (FIRST && SAFE) {  // (the compiler's own form: a v_mov for the zero, and its hazard handling)
+            acc[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u0), w, 0.f, false);
+            acc[4 + j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, u1), w, 0.f, false);
+        } else if constexpr (FIRST) {
             acc[j] = dot2_from_zero(u0, t.w[k]);
             acc[4 + j] = dot2_from_zero(u1, t.w[k]);
         } else {
@@ -310,11 +319,11 @@ __device__ __forceinline__ half8_t grid_pack(const float acc[8]) {
     return out;
 }
 
-template <bool WITH_LO>
+template <bool WITH_LO, bool SAFE = false>
 __device__ __forceinline__ void grid_fetch8(const void* grid, const GridTap& t, int g, int h, float acc[8]) {
     GridRaw r;
     grid_load(grid, t, g, h, r);
-    grid_reduce_record<WITH_LO, true>(r, t, 0, acc);
+    grid_reduce_record<WITH_LO, true, SAFE>(r, t, 0, acc);
 #pragma unroll
     for (int k = 1; k < 4; ++k) grid_reduce_record<WITH_LO>(r, t, k, acc);
 }
@@ -325,10 +334,10 @@ __device__ __forceinline__ void grid_fetch8(const void* grid, const GridTap& t, 
 template <int GRID>
 __device__ __forceinline__ half8_t grid_features(const NetParams& P, const GridTap& t, int g, int h, int hLoad) {
     float acc[8];
-    grid_fetch8<GRID == 2>(P.grid, t, g, hLoad, acc);
+    grid_fetch8<GRID == 2, GRID == 2>(P.grid, t, g, hLoad, acc);  // (BYTE_GAUSSIAN: SAFE, its decode spills around the sums)
     if constexpr (GRID == 2) {  // EncodeGridValue<BYTE_GAUSSIAN> :370-383
         float accB[8];
-        grid_fetch8<true>(P.gridB, t, g, hLoad, accB);
+        grid_fetch8<true, true>(P.gridB, t, g, hLoad, accB);
         const int c0 = 16 * g + 8 * h;
         const bool isTime = c0 < P.gridTimeChannels;  // a 16-channel chunk never straddles time / ensemble channels
         const float* mean = isTime ? P.gridMeanTime + c0 : P.gridMeanEns + (c0 - P.gridTimeChannels);

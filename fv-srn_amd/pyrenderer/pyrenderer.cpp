@@ -776,7 +776,8 @@ struct RayEvaluationSteppingDvr : IRayEvaluationStepping {
 struct ICamera {
     virtual ~ICamera() = default;
     double aspectRatio = 1.0;
-    virtual void frame(float eye[3], float right[3], float up[3]) = 0;
+    virtual void frame(float eye[3], float right[3], float up[3], int batch = 0) = 0;
+    virtual int batches() const { return 1; }  // ICamera::getBatches (imodule.h): B of externally set (B,3,3) camera matrices
     double fovYRadians = 45.0 * 3.14159265358979323846 / 180.0;
 };
 struct CameraOnASphere : ICamera {
@@ -785,11 +786,14 @@ struct CameraOnASphere : ICamera {
     std::shared_ptr<Parameter<double3>> pitchYawDistance = std::make_shared<Parameter<double3>>();
     torch::Tensor external;  // (B,3,3) from set_parameters
     CameraOnASphere() { pitchYawDistance->value = {0, 0, 1}; }
-    void frame(float eye[3], float right[3], float up[3]) override {
+    int batches() const override { return external.defined() && external.numel() > 0 ? int(external.size(0)) : 1; }
+    void frame(float eye[3], float right[3], float up[3], int batch = 0) override {
         if (external.defined() && external.numel() > 0) {
-            TORCH_CHECK(external.size(0) == 1, "batched cameras are not supported (the reference throws here as well, camera.cpp:519)");
+            // (B,3,3) reference frames set from outside (camera.cpp:242-258): batch entry b renders with matrix b -- the batch dimension
+            // virtual_size.z of ImageEvaluatorSimpleKernel (renderer_image_evaluator_simple.cuh:36-127) is a host loop over launches here
+            TORCH_CHECK(batch >= 0 && batch < external.size(0), "camera batch index out of range");
             torch::Tensor m = external.to(c10::kCPU, c10::kFloat).contiguous();
-            const float* p = m.data_ptr<float>();
+            const float* p = m.data_ptr<float>() + 9 * batch;
             for (int i = 0; i < 3; ++i) { eye[i] = p[i]; right[i] = p[3 + i]; up[i] = p[6 + i]; }
             return;
         }
@@ -798,11 +802,14 @@ struct CameraOnASphere : ICamera {
                                        pitchYawDistance->value.z, eye, right, up));
     }
     torch::Tensor getParameters() {
-        float e[3], r[3], u[3];
-        frame(e, r, u);
-        torch::Tensor m = torch::empty({1, 3, 3}, torch::kFloat);
-        float* p = m.data_ptr<float>();
-        for (int i = 0; i < 3; ++i) { p[i] = e[i]; p[3 + i] = r[i]; p[6 + i] = u[i]; }
+        const int B = batches();
+        torch::Tensor m = torch::empty({B, 3, 3}, torch::kFloat);
+        for (int b = 0; b < B; ++b) {
+            float e[3], r[3], u[3];
+            frame(e, r, u, b);
+            float* p = m.data_ptr<float>() + 9 * b;
+            for (int i = 0; i < 3; ++i) { p[i] = e[i]; p[3 + i] = r[i]; p[6 + i] = u[i]; }
+        }
         return m.to(torch::kCUDA);
     }
     void setParameters(const torch::Tensor& t) {
@@ -853,9 +860,13 @@ struct ImageEvaluatorSimple {
         if (!camera) raise("no camera selected");
         if (doublePrecision) raise("double precision rendering is not supported by the SRN path");
         camera->aspectRatio = double(width) / height;
+        // computeBatchCount (iimage_evaluator.cpp:138-165): only the camera can carry a batch dimension here (TF / step-size tensors: B = 1)
+        const int B = camera->batches();
+        torch::Tensor out = torch::empty({B, 8, height, width}, torch::TensorOptions().dtype(torch::kFloat).device(torch::kCUDA));
+        for (int batch = 0; batch < B; ++batch) {
         fvsrn_scene_desc d{};
         std::vector<float> table;
-        camera->frame(d.cam_eye, d.cam_right, d.cam_up);
+        camera->frame(d.cam_eye, d.cam_right, d.cam_up, batch);
         d.fov_y_radians = float(camera->fovYRadians);
         d.stepsize = float(dvr->stepsize);
         d.density_min = float(dvr->minDensity);
@@ -904,13 +915,14 @@ struct ImageEvaluatorSimple {
         }
         if (!scene) check(fvsrn_scene_create(&d, &scene));
         else check(fvsrn_scene_update(scene, &d));
-        torch::Tensor out = torch::empty({1, 8, height, width}, torch::TensorOptions().dtype(torch::kFloat).device(torch::kCUDA));
+        float* dst = out.data_ptr<float>() + size_t(batch) * 8 * size_t(height) * size_t(width);
         if (vol)
-            check(fvsrn_render(scene, vol->currentNetwork()->h, width, height, 0, height, out.data_ptr<float>(), nullptr, currentStream()));
+            check(fvsrn_render(scene, vol->currentNetwork()->h, width, height, 0, height, dst, nullptr, currentStream()));
         else
             check(fvsrn_render_volume(scene, grid->handle(), grid->sourceMode(), grid->interpolation_, grid->newBehavior ? 1 : 0,
                                       selectedChannel == ChannelNormal ? 1 : 0 /* image_evaluator_simple.cpp:249-252 */, width, height,
-                                      out.data_ptr<float>(), nullptr, currentStream()));
+                                      dst, nullptr, currentStream()));
+        }  // batch
         lastRender = out;
         exposureStale = true;
         refiningCounter = 0;
@@ -920,8 +932,8 @@ struct ImageEvaluatorSimple {
     // the previous one with weight 1 / refiningCounter (the DVR ray evaluator is deterministic: the average converges at once)
     int refiningCounter = 0;
     torch::Tensor refine(int width, int height, const torch::Tensor& previous) {
-        TORCH_CHECK(previous.dim() == 4 && previous.size(0) == 1 && previous.size(1) == 8 && previous.size(2) == height && previous.size(3) == width,
-                    "previous must be a (1,8,H,W) render of the same size");
+        TORCH_CHECK(previous.dim() == 4 && previous.size(0) == (camera ? camera->batches() : 1) && previous.size(1) == 8 && previous.size(2) == height &&
+                        previous.size(3) == width, "previous must be a (B,8,H,W) render of the same size");
         const int counter = refiningCounter;
         const torch::Tensor t = render(width, height);
         refiningCounter = counter + 1;
@@ -1649,7 +1661,7 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def("render", &ImageEvaluatorSimple::render, py::arg("width"), py::arg("height"))
         .def("refine", &ImageEvaluatorSimple::refine, py::arg("width"), py::arg("height"), py::arg("previous"))
         .def("get_module_for_tag", &ImageEvaluatorSimple::moduleForTag, py::arg("tag"))
-        .def("compute_batch_count", [](ImageEvaluatorSimple&) { return 1; })
+        .def("compute_batch_count", [](ImageEvaluatorSimple& e) { return e.camera ? e.camera->batches() : 1; })
         .def("is_iterative_refining", [](ImageEvaluatorSimple&) { return false; })
         .def("get_supported_tags", [](ImageEvaluatorSimple&) { return std::vector<std::string>{"camera", "volume", "RayEvaluation"}; })
         .def_readwrite("camera", &ImageEvaluatorSimple::camera)

@@ -48,3 +48,17 @@ def test_product_package_does_not_reference_the_oracle():
                 if re.search(r"srn_oracle|from oracle|import oracle|oracle/", text):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_built_kernels_keep_the_dot_hazard_distance():
+    """The latent-grid sums start with an inline-assembly v_dot2_f32_f16 (srn_device.hpp dot2_from_zero); hipcc's hazard recognizer
+    does not see it, so the three wait states gfx950 wants between a DOT instruction and a reader of another opcode are the source's
+    job.  tools/check_dot_hazard.py disassembles the objects of the build and reports every reader that comes too early."""
+    import glob
+    import subprocess
+    import sys
+    objs = sorted(glob.glob(os.path.join(util.ROOT, "fv-srn_amd", "csrc", "build", "kernels_*.o")))
+    if not objs:
+        pytest.skip("no object files (the library was built elsewhere)")
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tools", "check_dot_hazard.py")] + objs, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-4000:]

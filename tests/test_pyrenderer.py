@@ -269,6 +269,39 @@ def test_render_network_sequence_matches_oracle():
 
 
 @pytest.mark.gpu
+def test_batched_camera_matrices_render_one_image_per_batch_entry():
+    """The batch dimension B of ImageEvaluatorSimple::render (renderer_image_evaluator_simple.cuh:36-127 `virtual_size.z`,
+    iimage_evaluator.cpp:138-165 computeBatchCount) through externally set (B,3,3) camera matrices (camera.cpp:242-258): batch entry b is
+    the image of camera b; the module loops over launches."""
+    d, meta = util.load_golden("g3_trace_rgbo_32x32")
+    n = export_like_the_reference(d, meta)
+    n.box_min = pr.float3(*meta["box_min"])
+    n.box_size = pr.float3(*meta["box_size"])
+    vol = pr.VolumeInterpolationNetwork()
+    vol.set_network(n)
+    ev = pr.ImageEvaluatorSimple()
+    ev.volume = vol
+    ev.camera.orientation = pr.CameraOnASphere.Ym
+    ev.camera.fov_y_radians = meta["fov_y"]
+    ev.ray_evaluator.stepsize = meta["stepsize"]
+    singles, mats = [], []
+    for yaw in (0.2, 1.4, 2.9):
+        ev.camera.pitchYawDistance.value = pr.double3(meta["pitch"], yaw, meta["distance"])
+        mats.append(ev.camera.get_parameters())
+        singles.append(ev.render(40, 24).clone())
+    assert ev.compute_batch_count() == 1
+    ev.camera.set_parameters(torch.cat(mats, dim=0))
+    assert ev.compute_batch_count() == 3 and tuple(ev.camera.get_parameters().shape) == (3, 3, 3)
+    img = ev.render(40, 24)
+    assert tuple(img.shape) == (3, 8, 24, 40) and tuple(ev.extract_color(img).shape) == (3, 4, 24, 40)
+    for b in range(3):
+        assert torch.equal(torch.nan_to_num(img[b], nan=-7.0), torch.nan_to_num(singles[b][0], nan=-7.0))
+    assert float((img[0, :4] - img[1, :4]).abs().max()) > 1e-2
+    ev.camera.set_parameters(torch.empty(0))  # back to pitch / yaw / distance
+    assert ev.compute_batch_count() == 1 and tuple(ev.render(40, 24).shape) == (1, 8, 24, 40)
+
+
+@pytest.mark.gpu
 def test_shaded_configuration_through_the_module_api():
     """The shaded scene files of the reference (e.g. config-files/ejecta1024-v7-shaded.json) select finite-difference
     gradients on the volume and Phong shading on the BRDF: same image as the C ABI driven directly, and as the oracle."""

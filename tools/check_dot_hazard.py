@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Developer check (runs HERE): hipcc's hazard recognizer does not look into inline assembly, and on gfx950 a VALU instruction of another opcode
+that reads the result of a DOT instruction needs three wait states (LLVM GCNHazardRecognizer, checkMAIVALUHazards: DotWriteDifferentVALURead).
+The kernels start their latent-grid sums with an inline-assembly `v_dot2_f32_f16 vD, vA, vB, 0` (srn_device.hpp dot2_from_zero); this
+script disassembles every object of the build and reports any such instruction whose result is read within the next three wait states.
+usage: tools/check_dot_hazard.py [object files ...]     exit code 1 if a violation is found"""
+import glob
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+L = "/opt/rocm/lib/llvm/bin"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def regs(tok):
+    m = re.fullmatch(r"-?\|?v(\d+)\|?", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"-?v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def check(obj):
+    bad = 0
+    with tempfile.TemporaryDirectory() as t:
+        subprocess.check_call([L + "/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, t + "/fat.bin"])
+        subprocess.check_call([L + "/clang-offload-bundler", "--type=o", "--input=" + t + "/fat.bin", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                               "--output=" + t + "/dev.co", "--unbundle"])
+        dis = subprocess.run([L + "/llvm-objdump", "-d", "--no-show-raw-insn", t + "/dev.co"], capture_output=True, text=True).stdout.splitlines()
+    kernel = "?"
+    pending = []  # (register, wait states left, line)
+    n_dots = 0
+    for line in dis:
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            kernel = m.group(1)
+            pending = []
+            continue
+        body = line.split("//")[0].strip()
+        if not body:
+            continue
+        parts = body.replace(",", " ").split()
+        op, args = parts[0], parts[1:]
+        if op.startswith("s_nop"):
+            states = int(args[0], 0) + 1
+        else:
+            states = 1
+            if op.startswith("v_") or op.startswith("global_") or op.startswith("ds_") or op.startswith("buffer_") or op.startswith("scratch_"):
+                # sources: every operand but the first (stores have no destination: all of them)
+                srcs = args if ("store" in op or op.startswith("ds_write")) else args[1:]
+                used = set()
+                for a in srcs:
+                    used |= regs(a)
+                # (a write of the same register by another VALU opcode needs four wait states: one more than a read)
+                wrote = regs(args[0]) if (args and not ("store" in op or op.startswith("ds_write"))) else set()
+                for (r, left, src_line) in pending:
+                    if r in wrote and not op.startswith("v_dot2") and left + 1 > 0 and r not in used:
+                        print("%s: %s\n    overwrites v%d, written by `%s` with %d wait state(s) still due" % (kernel[:90], body, r, src_line, left + 1))
+                        bad += 1
+                for (r, left, src_line) in pending:
+                    if r in used and not op.startswith("v_dot2_f32_f16"):
+                        print("%s: %s\n    reads v%d, written by `%s` with %d wait state(s) still due" % (kernel[:90], body, r, src_line, left))
+                        bad += 1
+        pending = [(r, left - states, s) for (r, left, s) in pending if left - states > 0]
+        if op == "v_dot2_f32_f16" and args and args[-1] == "0":
+            n_dots += 1
+            for r in regs(args[0]):
+                pending.append((r, 3, body))
+        if op.startswith("s_cbranch") or op.startswith("s_branch"):
+            pass  # (conservative: the window continues on the fall-through path)
+    return bad, n_dots
+
+
+def main():
+    objs = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "fv-srn_amd", "csrc", "build", "*.o")))
+    total = 0
+    for o in objs:
+        if os.path.basename(o) in ("api.o", "pack.o", "scene_network.o"):
+            continue
+        bad, n = check(o)
+        print("%-28s %6d inline dot2-from-zero instructions, %d read too early" % (os.path.basename(o), n, bad))
+        total += bad
+    sys.exit(1 if total else 0)
+
+
+if __name__ == "__main__":
+    main()
