@@ -427,7 +427,8 @@ class Scene:
         """How the last render of this scene treated a ray's samples (fvsrn_scene_last_render_info)."""
         a = (_I * 4)()
         _check(lib().fvsrn_scene_last_render_info(self._h, a))
-        return dict(segments=a[0], rotation_resync=a[1], resident_kernel=a[2] == 1, overlap_kernel=a[2] == 2, waves_per_block=a[3])
+        return dict(segments=a[0], rotation_resync=a[1], resident_kernel=a[2] == 1, overlap_kernel=a[2] == 2, adjoint_kernel=a[2] == 3,
+                    waves_per_block=a[3])
 
     def __del__(self):
         try:

@@ -528,6 +528,7 @@ struct fvsrn_network {
         HIP_CHECK(hipFuncSetAttribute(kinfoScaled.renderFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         HIP_CHECK(hipFuncSetAttribute(kinfo.renderShadedFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         if (const void* fn = render_stripe_fn(keyScaled)) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
+        if (const void* fn = render_adjoint_fn(key)) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         deviceValid = true;
     }
 
@@ -1119,7 +1120,7 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
                     return fail(FVSRN_ERR_INVALID_ARGUMENT, "gradients can only be evaluated for scalar networks");
                 if (!(adjointGridStep >= 0.f)) return fail(FVSRN_ERR_INVALID_ARGUMENT, "adjoint_grid_stepsize must not be negative");
                 const float gridStep = adjointGridStep > 0.f ? adjointGridStep : 1.0f / (float(std::max(1, a.P.gridX)) * 4.0f);
-                const unsigned gridG = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 8 / wpb));  // 2 waves per SIMD (1 at 128 wide)
+                const unsigned gridG = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * 8 / wpb));  // (two waves per SIMD where the variant fits 256 registers)
                 const hipError_t e = launch_eval_gradient(net->key, a, gridStep, gridG, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
                 if (e == hipErrorInvalidDeviceFunction) return fail(FVSRN_ERR_UNSUPPORTED, "this network variant has no gradient kernel");
                 if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during evaluation! ") + hipGetErrorString(e));
@@ -1422,7 +1423,9 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const void* stripeFn = nullptr;
             if (!smallFn && !a.shaded && (O[FVSRN_OPT_OVERLAP_KERNEL] >= 0 ? O[FVSRN_OPT_OVERLAP_KERNEL] == 1 : stripeWorld > 1))
                 stripeFn = render_stripe_fn(net->keyScaled);
-            const void* altFn = smallFn ? smallFn : stripeFn;
+            // the adjoint gradient mode up to 64 channels: its own kernel (render_adjoint_kernel, kernels.hpp)
+            const void* adjointFn = (a.shaded && d.gradient_mode == FVSRN_GRADIENT_ADJOINT_METHOD) ? render_adjoint_fn(net->key) : nullptr;
+            const void* altFn = smallFn ? smallFn : (stripeFn ? stripeFn : adjointFn);
             const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded, altFn, O[FVSRN_OPT_MAX_BLOCKS_PER_CU]);
             const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));  // workgroups the chip holds at once
             // Depth segments (kernels.hpp): with fewer tiles than ~4x the resident waves (small images, the stripes of one
@@ -1488,14 +1491,15 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                                  !a.shaded;  // kRotate / kRotateLds, kernels.hpp
             scene->lastInfo[0] = K;
             scene->lastInfo[1] = rotates ? S.resyncMask + 1 : 0;
-            scene->lastInfo[2] = smallFn ? 1 : (stripeFn ? 2 : 0);
+            scene->lastInfo[2] = smallFn ? 1 : (stripeFn ? 2 : (adjointFn ? 3 : 0));
             scene->lastInfo[3] = wpb;
             const bool usesScratch = (altFn ? net->scratchOf(altFn) : (a.shaded ? net->scratchShaded : net->scratchRender)) > 0;
             if (usesScratch) g_scratchFence.before(net->device, s);
             struct FenceAfter { bool on; int dev; hipStream_t s; ~FenceAfter() { if (on) { try { g_scratchFence.after(dev, s); } catch (...) {} } } } fenceAfter{usesScratch, net->device, s};
             hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid, a, grid, unsigned(64 * wpb), lds, s)
                                    : (stripeFn ? launch_render_stripe(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s)
-                                               : launch_render(a.shaded ? net->key : net->keyScaled, a, grid, unsigned(64 * wpb), lds, s));
+                                      : (adjointFn ? launch_render_adjoint(net->key, a, grid, unsigned(64 * wpb), lds, s)
+                                                   : launch_render(a.shaded ? net->key : net->keyScaled, a, grid, unsigned(64 * wpb), lds, s)));
             if (e == hipSuccess && K > 1) e = launch_composite(S.partial, d_out8, K, plane, S, s);
             if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("Error during rendering! ") + hipGetErrorString(e));
             return FVSRN_OK;

@@ -203,8 +203,10 @@ __device__ __forceinline__ void evaluate_gradient_body(const NetParams& P, const
     }
 }
 
+// (one wave per SIMD = the 512-register budget: the four column sets spill nothing; measured r03, 2^22 points: 32x4 + grid 0.61 -> 0.56 ms,
+// 64x6 + grid 1.80 -> 1.25 ms against the 256-register build)
 template <int CD, int ACT, int GRID, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : 2)) void evaluate_gradient_kernel(NetParams P, const float* __restrict__ pos,
+__global__ __launch_bounds__(kBlockThreads, 1) void evaluate_gradient_kernel(NetParams P, const float* __restrict__ pos,
                                                                  const float* __restrict__ dir, size_t n, float* __restrict__ out, float gridStep) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     load_network_to_lds(P, lds);
@@ -402,7 +404,10 @@ __device__ __forceinline__ float select_by_mask(unsigned long long m, float x) {
 
 // NLC > 0 (render_small_kernel): the network stays in registers (ResidentNet, srn_device.hpp); CD = 2, GRID = 0, rotation path
 // SCHED: srn_layers' schedule (1: fragment-major for every width, render_stripe_kernel)
-template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, bool SHADED, int TAIL = TAIL_GENERIC, int NLC = 0, int SCHED = 0>
+// SHADED: 0 = plain renderer; 1 = render_shaded_kernel (finite differences / predicted gradients / BRDF, and the adjoint mode at 96 and
+// 128 channels); 2 = render_adjoint_kernel (up to 64 channels, adjoint mode only, see there)
+constexpr bool adjoint_in_its_own_kernel(int CD) { return CD <= 4; }
+template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, int SHADED, int TAIL = TAIL_GENERIC, int NLC = 0, int SCHED = 0>
 __device__ __forceinline__ void render_body(const NetParams& P, const SceneParams& S, const char* lds, const float* tfLds,
                                             float* __restrict__ out, unsigned long long* __restrict__ stats) {
     const int lane = lane_id();
@@ -523,6 +528,9 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     float* dfeatLds = nullptr;
     if constexpr (kRotateLds) dfeatLds = const_cast<float*>(tfLds) + S.tfLdsFloats + int(threadIdx.x >> 6) * (64 * 32);
     floatx16 feat[2][mtiles(CD)], dfeat[2][mtiles(CD)];
+    // the adjoint gradient mode lives in this instantiation (render_shaded_kernel except at 48 / 64 channels, render_adjoint_kernel there)
+    constexpr bool kAdjointHere = SHADED == 2 || (SHADED == 1 && !adjoint_in_its_own_kernel(CD));
+    [[maybe_unused]] bool normalsAtPreviousStep = false;  // (wave-uniform) per ray tile
     float stepIndex = float(i0);
     const float stepEnd = float(i1);  // INT_MAX -> 2^31: never reached
 
@@ -568,6 +576,8 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             }
         }
         float4_t o;
+        [[maybe_unused]] bool fusedGradient = false;
+        [[maybe_unused]] float fgx = 0.f, fgy = 0.f, fgz = 0.f;
         if constexpr (kRotate) {
             // Fourier features by rotation (fourier_advance): exact features every kFourierResync steps, the per-step
             // rotation once per ray
@@ -589,6 +599,14 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             o = srn_forward_rotating_resident_grid<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeatLds, px, py, pz);
         } else if constexpr (NLC > 0 && GRID == 1) {
             o = srn_forward_resident_grid<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, px, py, pz, dx, dy, dz);
+        } else if constexpr (kAdjointHere) {
+            // Adjoint mode: the gradient pass computes the value as well (its first column), so where the wave needed normals at the
+            // previous step -- inside the volume that is every step -- the value comes out of that pass and the plain evaluation is
+            // skipped: 4 tile evaluations per step instead of 5.  (The reference evaluates, then runs evalNormal where any lane needs it:
+            // same numbers up to the rounding of the two evaluations, <= 5e-4 of the value, tests/test_gpu_parity.py.)
+            fusedGradient = S.gradientMode == FVSRN_GRADIENT_ADJOINT_METHOD && !rgboNet && normalsAtPreviousStep;
+            if (fusedGradient) o = srn_forward_gradient<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, S.gridDiffStep, fgx, fgy, fgz);
+            else o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE, SCHED>(P, lds, px, py, pz, dx, dy, dz);
         } else {
             o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE, SCHED>(P, lds, px, py, pz, dx, dy, dz);
         }
@@ -698,7 +716,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             const float value = sigmoidDensity ? sigmoid_f(o[0]) : o[0];
             const float density2 = (value - S.densityMin) * S.divDensityRange;
             const bool requireNormal = valid && (value >= S.densityMin);
-            if (SHADED && S.gradientMode == FVSRN_GRADIENT_FINITE_DIFFERENCES) {
+            if (SHADED == 1 && S.gradientMode == FVSRN_GRADIENT_FINITE_DIFFERENCES) {
                 // evalNormal, GRADIENT_MODE_FINITE_DIFFERENCES (renderer_volume_tensorcores.cuh:1185-1196): central
                 // differences of valueNoClamping with a world-space step, evaluated by the whole wave if ANY lane needs a
                 // normal (stepping_dvr.cuh:122-128); takes precedence over gradients the network predicts
@@ -720,9 +738,11 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             } else if (SHADED && S.gradientMode == FVSRN_GRADIENT_ADJOINT_METHOD) {
                 // evalNormal, GRADIENT_MODE_ADJOINT_METHOD (renderer_volume_tensorcores.cuh:1198-1540): the analytic gradient w.r.t.
                 // the normalized position, by the whole wave if ANY lane needs a normal; forward mode, see srn_gradient.hpp
-                if constexpr (SHADED) {
-                    if (__builtin_amdgcn_ballot_w64(requireNormal) != 0)
-                        (void)srn_forward_gradient<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, S.gridDiffStep, gx, gy, gz);
+                if constexpr (kAdjointHere) {
+                    const bool any = __builtin_amdgcn_ballot_w64(requireNormal) != 0;
+                    if (fusedGradient) { gx = fgx; gy = fgy; gz = fgz; }
+                    else if (any) (void)srn_forward_gradient<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, S.gridDiffStep, gx, gy, gz);
+                    normalsAtPreviousStep = any;
                 }
             } else if (gradNet) {
                 gx = o[1]; gy = o[2]; gz = o[3];
@@ -834,7 +854,7 @@ __device__ __forceinline__ float* render_prologue(const NetParams& P, const Scen
     return tfLds;
 }
 
-template <int CD, int ACT, int GRID, bool HAS_DIR, bool SHADED, int SCHED = 0>
+template <int CD, int ACT, int GRID, bool HAS_DIR, int SHADED, int SCHED = 0>
 __device__ __forceinline__ void render_entry(const NetParams& P, const SceneParams& S, float* __restrict__ out,
                                              unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -861,7 +881,7 @@ __device__ __forceinline__ void render_entry(const NetParams& P, const ScenePara
 template <int CD, int ACT, int GRID, bool HAS_DIR>
 __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                unsigned long long* __restrict__ stats) {
-    render_entry<CD, ACT, GRID, HAS_DIR, false>(P, S, out, stats);
+    render_entry<CD, ACT, GRID, HAS_DIR, 0>(P, S, out, stats);
 }
 
 // render_kernel for the stripes of a multi-GPU frame (and any caller that keeps two frames in flight on two streams): 48- and 64-wide
@@ -872,7 +892,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void r
 template <int CD, int ACT, int GRID, bool HAS_DIR>
 __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void render_stripe_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                       unsigned long long* __restrict__ stats) {
-    render_entry<CD, ACT, GRID, HAS_DIR, false, 1>(P, S, out, stats);
+    render_entry<CD, ACT, GRID, HAS_DIR, 0, 1>(P, S, out, stats);
 }
 
 // 32-wide Fourier-only scalar networks with NLC <= 3 C->C layers behind a transfer function, phases inside the v_cos domain
@@ -886,14 +906,26 @@ __global__ __launch_bounds__(kBlockThreads, 2) void render_small_kernel(NetParam
                                                                       unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* tfLds = render_prologue(P, S, lds);
-    render_body<2, ACT, SGRID, HAS_DIR, FM_COS, false, TAILK, NLC>(P, S, lds, tfLds, out, stats);
+    render_body<2, ACT, SGRID, HAS_DIR, FM_COS, 0, TAILK, NLC>(P, S, lds, tfLds, out, stats);
 }
 
 // finite-difference normals / shading BRDF (SceneParams::gradientMode, brdf*): 7 network evaluations per sample
 template <int CD, int ACT, int GRID, bool HAS_DIR>
 __global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : 2)) void render_shaded_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                unsigned long long* __restrict__ stats) {
-    render_entry<CD, ACT, GRID, HAS_DIR, true>(P, S, out, stats);
+    render_entry<CD, ACT, GRID, HAS_DIR, 1>(P, S, out, stats);
+}
+
+// GRADIENT_MODE_ADJOINT_METHOD up to 64 channels: the shaded renderer without the finite-difference code (and render_shaded_kernel without
+// the gradient pass: with both in one kernel the finite differences of the 32-wide latent-grid network lost 14 %, 38.9 -> 44.4 ms, to the
+// spills of the other mode).  At 48 / 64 channels with the 512-register budget of one wave per SIMD: what the four column sets of the
+// gradient pass do not fit into 256 registers goes to AGPRs instead of scratch memory (measured r03, 64x6 + 32^3 grid: 130 -> 106 ms per
+// frame; finite differences keep two waves per SIMD, which are worth 35 % to them: 113 vs 153 ms).  32 channels fit 256 registers.
+template <int CD, int ACT, int GRID, bool HAS_DIR>
+__global__ __launch_bounds__(kBlockThreads, (CD >= 3 ? 1 : 2)) void render_adjoint_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+                                                               unsigned long long* __restrict__ stats) {
+    static_assert(adjoint_in_its_own_kernel(CD), "only instantiated where render_shaded_kernel leaves the adjoint mode out");
+    render_entry<CD, ACT, GRID, HAS_DIR, 2>(P, S, out, stats);
 }
 
 }  // namespace fvsrn

@@ -326,6 +326,18 @@ hipError_t launch_render_stripe(const VariantKey& k, const RenderArgs& a, unsign
     if (k.CD == 4) return launch_render_stripe_cd<4>(k, a, gridDim, blockDim, ldsBytes, s);
     return hipErrorInvalidDeviceFunction;
 }
+const void* render_adjoint_fn(const VariantKey& k) {
+    if (k.CD == 2) return render_adjoint_fn_cd<2>(k);
+    if (k.CD == 3) return render_adjoint_fn_cd<3>(k);
+    if (k.CD == 4) return render_adjoint_fn_cd<4>(k);
+    return nullptr;
+}
+hipError_t launch_render_adjoint(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s) {
+    if (k.CD == 2) return launch_render_adjoint_cd<2>(k, a, gridDim, blockDim, ldsBytes, s);
+    if (k.CD == 3) return launch_render_adjoint_cd<3>(k, a, gridDim, blockDim, ldsBytes, s);
+    if (k.CD == 4) return launch_render_adjoint_cd<4>(k, a, gridDim, blockDim, ldsBytes, s);
+    return hipErrorInvalidDeviceFunction;
+}
 hipError_t launch_render(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s) {
     FVSRN_DISPATCH_CD(launch_render_cd, k, a, gridDim, blockDim, ldsBytes, s)
     return hipErrorInvalidDeviceFunction;

@@ -290,8 +290,8 @@ int fvsrn_camera_on_a_sphere(int orientation, const double center[3], double pit
 /* How the last fvsrn_render / fvsrn_render_stripes of this scene treated the samples of a ray -- for callers that restate the
  * arithmetic (the parity oracle): out = { depth segments K a ray was cut into (1: none; the step count of the feature rotation
  * restarts in each), period in steps of the exact re-derivation of rotated Fourier features (0: the kernel derives the features
- * from the fp16 position at every step, like the reference; FVSRN_OPT_FOURIER_RESYNC), kernel family (0 render_kernel, 1 register-resident, 2 spill-free
- * stripe variant),
+ * from the fp16 position at every step, like the reference; FVSRN_OPT_FOURIER_RESYNC), kernel family (0 render_kernel / render_shaded_kernel, 1 register-resident, 2 spill-free
+ * stripe variant, 3 render_adjoint_kernel: the adjoint gradient mode up to 64 channels),
  * waves per workgroup }.  No reference counterpart. */
 int fvsrn_scene_last_render_info(fvsrn_scene* scene, int out[4]);
 
