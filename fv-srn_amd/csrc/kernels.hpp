@@ -920,9 +920,11 @@ __global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : 2)) void render_shade
 // the gradient pass: with both in one kernel the finite differences of the 32-wide latent-grid network lost 14 %, 38.9 -> 44.4 ms, to the
 // spills of the other mode).  At 48 / 64 channels with the 512-register budget of one wave per SIMD: what the four column sets of the
 // gradient pass do not fit into 256 registers goes to AGPRs instead of scratch memory (measured r03, 64x6 + 32^3 grid: 130 -> 106 ms per
-// frame; finite differences keep two waves per SIMD, which are worth 35 % to them: 113 vs 153 ms).  32 channels fit 256 registers.
+// frame; finite differences keep two waves per SIMD, which are worth 35 % to them: 113 vs 153 ms).  At 32 channels the same holds with a
+// latent grid (12 records in flight: 37.6 -> 36.2 ms, 28 scratch stores per wave step -> none); without one 256 registers are enough and the
+// second wave is worth more (20.5 vs 24.0 ms).
 template <int CD, int ACT, int GRID, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads, (CD >= 3 ? 1 : 2)) void render_adjoint_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+__global__ __launch_bounds__(kBlockThreads, ((CD >= 3 || GRID != 0) ? 1 : 2)) void render_adjoint_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                unsigned long long* __restrict__ stats) {
     static_assert(adjoint_in_its_own_kernel(CD), "only instantiated where render_shaded_kernel leaves the adjoint mode out");
     render_entry<CD, ACT, GRID, HAS_DIR, 2>(P, S, out, stats);

@@ -416,35 +416,53 @@ __device__ __forceinline__ float4_t srn_forward_gradient(const NetParams& P, con
                             }
                         }
                     }
-                    // y = act(x), dy = act'(x) dx
+                    // y = act(x), dy = act'(x) dx.  The tangents are converted to fp16 first and scaled there (v_pk_mul_f16 with act'(x) as
+                    // packed fp16: one instruction per two values instead of two multiplies and a convert back): the product is rounded to
+                    // fp16 either way, and act'(x) of a ReLU is exactly 0 or 1.
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         if (p == 0) {
+                            act_pack<ACT>(acc[0][m], actA, actB, xb[0][2 * m], xb[0][2 * m + 1]);
+                            if constexpr (ACT == ACT_RELU) {
+                                // act'(x) = [x > 0] = [y != 0] from the packed outputs: 1.0h where the half is non-zero (two packed integer
+                                // instructions per pair instead of two compares, two selects and a convert)
+                                // (inline assembly: hipcc turns the vector form into 16 compares, 16 selects and 8 packs.  Plain VALU
+                                // instructions on plain VALU results: none of the hazard classes of dot2_from_zero)
 #pragma unroll
-                            for (int r = 0; r < 16; r += 2) {
-                                const float d0 = act_derivative<ACT>(acc[0][m][r], actA, actB), d1 = act_derivative<ACT>(acc[0][m][r + 1], actA, actB);
-                                acc[1][m][r] *= d0;
-                                acc[1][m][r + 1] *= d1;
-                                if constexpr (NP > 1) {
-                                    const float2_t dv = {d0, d1};
+                                for (int e = 0; e < 2; ++e) {
+                                    const uint4_t y = __builtin_bit_cast(uint4_t, xb[0][2 * m + e]);
+                                    uint4_t d;
+#pragma unroll
+                                    for (int w = 0; w < 4; ++w) {
+                                        const unsigned yw = y[w];
+                                        unsigned t, dw;
+                                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(yw), "s"(0x00010001u));
+                                        asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(dw) : "v"(t), "s"(0x3c003c00u));
+                                        d[w] = dw;
+                                    }
+                                    dh[m][e] = __builtin_bit_cast(half8_t, d);
+                                }
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 16; r += 2) {
+                                    const float2_t dv = {act_derivative<ACT>(acc[0][m][r], actA, actB), act_derivative<ACT>(acc[0][m][r + 1], actA, actB)};
                                     const half2_t dp = __builtin_convertvector(dv, half2_t);
                                     dh[m][r >> 3][r & 7] = dp[0];
                                     dh[m][r >> 3][(r & 7) + 1] = dp[1];
                                 }
                             }
-                            act_pack<ACT>(acc[0][m], actA, actB, xb[0][2 * m], xb[0][2 * m + 1]);
                         } else {
+                            half8_t t0, t1;
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const float d = float(dh[m][r >> 3][r & 7]);
-                                acc[0][m][r] *= d;
-                                acc[1][m][r] *= d;
-                            }
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(acc[0][m], q, 0.f, 0.f, xb[2 * p][2 * m], xb[2 * p][2 * m + 1]);
+                            for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(acc[0][m], q, 0.f, 0.f, t0, t1);
+                            xb[2 * p][2 * m] = t0 * dh[m][0];
+                            xb[2 * p][2 * m + 1] = t1 * dh[m][1];
                         }
+                        half8_t t0, t1;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(acc[1][m], q, 0.f, 0.f, xb[2 * p + 1][2 * m], xb[2 * p + 1][2 * m + 1]);
+                        for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(acc[1][m], q, 0.f, 0.f, t0, t1);
+                        xb[2 * p + 1][2 * m] = t0 * dh[m][0];
+                        xb[2 * p + 1][2 * m + 1] = t1 * dh[m][1];
                     }
                 }
             };

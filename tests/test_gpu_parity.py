@@ -545,6 +545,54 @@ def test_evaluate_points_adjoint_gradient_matches_oracle(case):
     assert err < 5e-3 * scale, (err, scale)   # relative to the largest gradient; measured r02: <= 1e-3 of it over these cases
 
 
+@pytest.mark.parametrize("scale", [10.0, 4.0, 2.0, 1.6, 0.8])
+@pytest.mark.parametrize("net_kw", [dict(activation="ReLU", output_mode="density:direct", grid=(16, 8)),
+                                    dict(activation="SnakeAlt", output_mode="density", C=64, layers=3, grid=(32, 6))])
+def test_adjoint_latent_grid_differences_at_other_steps(net_kw, scale):
+    """latentGridDifferencesStepSize = 1 / (resolution * scale) (volume_interpolation_network.cpp:1808-1812,
+    adjoint_latent_grid_central_differences_stepsize_scale, default 4).  Up to half a texel (scale >= 2) the HIP path takes the
+    central difference of the trilinear fetch from the sample's own cell and one neighbour cell (srn_gradient.hpp,
+    grid_value_and_differences8: 12 records); above that, six more fetches.  Both against the oracle's six fetches, with points
+    beyond the faces of the box (clamp addressing: the slope of a cell outside the grid is 0)."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(seed=37, box_min=(-0.5, -0.5, -0.5), fourier_std=0.35, **net_kw)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    res = net_kw["grid"][1]
+    step = 1.0 / (res * scale)
+    rng = np.random.RandomState(12)
+    pos = rng.uniform(-0.56, 0.56, (1500, 3)).astype(np.float32)
+    # some points exactly on texel centres and cell faces
+    pos[:64] = (np.round((pos[:64] + 0.5) * res * 2) / (res * 2) - 0.5).astype(np.float32)
+    tp = torch.from_numpy(pos).cuda()
+    _, grad = net.evaluate_with_adjoint_gradient(tp, None, grid_step=step, world=True)
+    ref = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).adjoint_gradient(pos, None, grid_step=step)
+    scale_g = float(np.abs(ref).max())
+    assert scale_g > 1e-3
+    err = np.abs(grad.cpu().numpy() - ref)
+    # a sample within rounding of a cell face may take the neighbour cell's slope on one side and the own cell's on the other: the
+    # central difference is continuous there, so that costs nothing; what is left is the fp16 rounding of tangents and filter weights
+    if net_kw["activation"] == "ReLU":  # a pre-activation within rounding of 0 switches a whole unit on one side: single points, like in
+        assert np.median(err) < 4e-4 * scale_g and np.percentile(err, 99) < 6e-3 * scale_g, (np.median(err), np.percentile(err, 99), scale_g)  # g4_grad_*
+    else:
+        assert err.max() < 6e-3 * scale_g, (err.max(), scale_g, int(np.argmax(err.max(axis=1))))
+
+
+def test_adjoint_mode_runs_in_its_own_kernel_up_to_64_channels():
+    """render_adjoint_kernel (kernels.hpp): the adjoint gradient mode without the finite-difference code, one wave per SIMD at 48 / 64
+    channels; 96 / 128 channels stay in render_shaded_kernel.  fvsrn_scene_last_render_info reports the family."""
+    from fvsrn_amd import capi, volnet_io
+    for C_, expect in ((32, True), (64, True), (96, False)):
+        vn = util.random_network(seed=5, C=C_, layers=3, activation="SnakeAlt", output_mode="density", box_min=(-0.5, -0.5, -0.5), fourier_std=0.3)
+        net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+        for mode in (1, 2):
+            kw = make_scene_kwargs(early_out=True, tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF, brdf=PHONG, gradient_mode=mode,
+                                   finite_differences_stepsize=1 / 64)
+            scene = capi.Scene(**kw)
+            scene.render(net, 24, 16)
+            assert scene.last_render_info()["adjoint_kernel"] == (expect and mode == 2), (C_, mode, scene.last_render_info())
+
+
 @pytest.mark.parametrize("name", util.golden_names("g4_"))
 def test_evaluate_points_adjoint_gradient_matches_reference_autograd(name):
     """The analytic gradients of the HIP path against torch.autograd on the reference's own PyTorch model (G4 fixtures)."""
