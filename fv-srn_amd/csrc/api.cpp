@@ -1132,7 +1132,9 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
             {
                 const VariantKey& k = evalKey;
                 const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.gridK == 1 && a.P.bias0Folded ? 1 : 2);  // one decoded 16-channel chunk, as in renderImpl
-                if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !a.P.noFourier && !a.P.fourierNeedsFractEval && a.P.numLayers >= 1 &&
+                // (no v_fract in the register-resident kernels: the bound on the phases that applies -- the in-box one for the scaled ReLU image)
+                const int needsFract = k.act == ACT_RELU01 ? a.P.fourierNeedsFractPlain : a.P.fourierNeedsFractEval;
+                if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !a.P.noFourier && !needsFract && a.P.numLayers >= 1 &&
                     a.P.numLayers <= 3) {
                     // (the Fourier-only kernels need 156 registers: three waves per SIMD fit, and the grid-stride loop profits from them)
                     const unsigned gridSmall = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * (smallGrid == 0 ? 12 : 8) / wpb));

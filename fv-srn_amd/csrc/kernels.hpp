@@ -167,7 +167,11 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void e
     if constexpr (GRID == 0) {  // a latent grid needs Fourier features (SceneNetwork::valid)
         if (P.noFourier) return evaluate_body<CD, ACT, GRID, HAS_DIR, FM_FIRST_LAYER>(P, lds, pos, dir, n, out, outChannels);
     }
-    if (P.fourierNeedsFractEval) evaluate_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS>(P, lds, pos, dir, n, out, outChannels);
+    // the [0,1]-scaled ReLU image only ever sees positions inside the unit box (eval_batch_deferred hands the others to the plain image):
+    // the renderer's bound on the phases holds for it, not the one for arbitrary positions (r03: no v_fract for the 2^9 ladder of the 64-wide
+    // bench network, like in the renderer since r02)
+    const int needsFract = ACT == ACT_RELU01 ? P.fourierNeedsFractPlain : P.fourierNeedsFractEval;
+    if (needsFract) evaluate_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS>(P, lds, pos, dir, n, out, outChannels);
     else evaluate_body<CD, ACT, GRID, HAS_DIR, FM_COS>(P, lds, pos, dir, n, out, outChannels);
 }
 
