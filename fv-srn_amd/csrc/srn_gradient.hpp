@@ -250,6 +250,55 @@ __device__ __forceinline__ float4_t srn_forward_gradient(const NetParams& P, con
         tile_bcast(dz, td[0][2], td[1][2]);
     }
 
+    // ---- latent-grid chunk g: value and central differences of 16 channels as B fragments of the layer-0 grid steps --------
+    auto gridChunkAt = [&](const float (&tq)[3], int pass, int g, half8_t (&gb)[1 + NT]) {
+        float val[8], dd[3][8];
+        if (GRID == 1 && localDiff) {
+            const GridDiffTap dtap = grid_diff_tap(P, tq[0], tq[1], tq[2], gridStep);
+            grid_value_and_differences8(P, dtap, g, h, val, dd[0], dd[1], dd[2]);
+        } else {
+            // six more fetches; a rolled loop (one copy of the fetch, few registers): this path is the rare one and must not
+            // set the register budget of the kernel
+            grid_values8<GRID>(P, grid_tap(P, tq[0], tq[1], tq[2]), g, h, val);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dd[0][j] = dd[1][j] = dd[2][j] = 0.f;
+            const float s2 = 0.5f / gridStep;
+#pragma unroll 1
+            for (int k = 0; k < 2 * NT; ++k) {
+                const int axis = pass * NT + (k >> 1);
+                const float sg = (k & 1) ? -gridStep : gridStep, w = (k & 1) ? -s2 : s2;
+                float v[8];
+                grid_values8<GRID>(P, grid_tap(P, tq[0] + (axis == 0 ? sg : 0.f), tq[1] + (axis == 1 ? sg : 0.f), tq[2] + (axis == 2 ? sg : 0.f)), g, h, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {  // (no run-time array index: scratch)
+                    dd[0][j] = fmaf(axis == 0 ? w : 0.f, v[j], dd[0][j]);
+                    dd[1][j] = fmaf(axis == 1 ? w : 0.f, v[j], dd[1][j]);
+                    dd[2][j] = fmaf(axis == 2 ? w : 0.f, v[j], dd[2][j]);
+                }
+            }
+        }
+        gb[0] = grid_pack(val);
+        if constexpr (NT == 3) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) gb[1 + i] = grid_pack(dd[i]);
+        } else {  // one tangent per pass
+            float d1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d1[j] = pass == 0 ? dd[0][j] : (pass == 1 ? dd[1][j] : dd[2][j]);
+            gb[1] = grid_pack(d1);
+        }
+    };
+    // With one pass of three tangents the latent-grid fragments of BOTH tiles (chunk 0) are fetched before the tile loop: the gradient pass runs
+    // with one wave per SIMD where a latent grid is present (render_adjoint_kernel), nothing else hides the 24 gathers of a tile, and two
+    // tiles' gathers in flight at once cost one latency instead of two (2 x 16 registers across the first tile).
+    constexpr bool kChunksAhead = GRID != 0 && NT == 3;
+    half8_t gbTile0[1 + NT], gbTile1[1 + NT];
+    if constexpr (kChunksAhead) {
+        const float q0[3] = {tp[0][0], tp[0][1], tp[0][2]}, q1[3] = {tp[1][0], tp[1][1], tp[1][2]};
+        gridChunkAt(q0, 0, 0, gbTile0);
+        gridChunkAt(q1, 0, 0, gbTile1);
+    }
+
 #pragma unroll 1
     for (int t = 0; t < 2; ++t) {
         // (selects instead of tp[t][i]: a run-time index would put the arrays into scratch memory)
@@ -267,48 +316,19 @@ __device__ __forceinline__ float4_t srn_forward_gradient(const NetParams& P, con
         for (int pass = 0; pass < 3 / NT; ++pass) {
             // column sets: 0 = value, 1 + i = tangent of axis (pass * NT + i)
             half8_t xb[1 + NT][2 * MT];
-            // ---- latent-grid chunk g: value and central differences of 16 channels as B fragments of the layer-0 grid steps --------
-            auto gridChunk = [&](int g, half8_t (&gb)[1 + NT]) {
-                float val[8], dd[3][8];
-                if (GRID == 1 && localDiff) {
-                    const GridDiffTap dtap = grid_diff_tap(P, tq[0], tq[1], tq[2], gridStep);
-                    grid_value_and_differences8(P, dtap, g, h, val, dd[0], dd[1], dd[2]);
-                } else {
-                    // six more fetches; a rolled loop (one copy of the fetch, few registers): this path is the rare one and must not
-                    // set the register budget of the kernel
-                    grid_values8<GRID>(P, grid_tap(P, tq[0], tq[1], tq[2]), g, h, val);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) dd[0][j] = dd[1][j] = dd[2][j] = 0.f;
-                    const float s2 = 0.5f / gridStep;
-#pragma unroll 1
-                    for (int k = 0; k < 2 * NT; ++k) {
-                        const int axis = pass * NT + (k >> 1);
-                        const float sg = (k & 1) ? -gridStep : gridStep, w = (k & 1) ? -s2 : s2;
-                        float v[8];
-                        grid_values8<GRID>(P, grid_tap(P, tq[0] + (axis == 0 ? sg : 0.f), tq[1] + (axis == 1 ? sg : 0.f), tq[2] + (axis == 2 ? sg : 0.f)), g, h, v);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {  // (no run-time array index: scratch)
-                            dd[0][j] = fmaf(axis == 0 ? w : 0.f, v[j], dd[0][j]);
-                            dd[1][j] = fmaf(axis == 1 ? w : 0.f, v[j], dd[1][j]);
-                            dd[2][j] = fmaf(axis == 2 ? w : 0.f, v[j], dd[2][j]);
-                        }
-                    }
-                }
-                gb[0] = grid_pack(val);
-                if constexpr (NT == 3) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) gb[1 + i] = grid_pack(dd[i]);
-                } else {  // one tangent per pass
-                    float d1[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) d1[j] = pass == 0 ? dd[0][j] : (pass == 1 ? dd[1][j] : dd[2][j]);
-                    gb[1] = grid_pack(d1);
-                }
-            };
             // chunk 0 is fetched before anything else of the pass is live (12 records = 96 registers in the piecewise-exact form); its four
             // fragments (16 registers) wait for layer 0
             half8_t gb0[1 + NT];
-            if constexpr (GRID != 0) gridChunk(0, gb0);
+            if constexpr (kChunksAhead) {
+#pragma unroll
+                for (int v = 0; v <= NT; ++v) {  // (selects, no run-time array index)
+                    const uint4_t a = __builtin_bit_cast(uint4_t, gbTile0[v]), b = __builtin_bit_cast(uint4_t, gbTile1[v]);
+                    const uint4_t c = {t ? b[0] : a[0], t ? b[1] : a[1], t ? b[2] : a[2], t ? b[3] : a[3]};
+                    gb0[v] = __builtin_bit_cast(half8_t, c);
+                }
+            } else if constexpr (GRID != 0) {
+                gridChunkAt(tq, pass, 0, gb0);
+            }
             // ---- input features and their tangents -----------------------------------------------------------------------
             {
                 floatx16 f[MT], c[NT][MT];
@@ -393,7 +413,7 @@ __device__ __forceinline__ float4_t srn_forward_gradient(const NetParams& P, con
                         }
                         for (int g = 1; g < P.gridK; ++g) {  // (more than 16 latent channels: fetched again for the second pair)
                             half8_t gb[1 + NT];
-                            gridChunk(g, gb);
+                            gridChunkAt(tq, pass, g, gb);
 #pragma unroll
                             for (int m = 0; m < MT; ++m) {
                                 const half8_t a = lds_frag(lds, wOff + (MT * KS + g * MT + m) * kFragBytes, lane);
