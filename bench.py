@@ -33,6 +33,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# before the HIP runtime starts (fv-srn_amd/__init__.py): the frame pipeline's streams need more than ROCm's default four hardware queues
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

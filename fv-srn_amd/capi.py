@@ -59,7 +59,8 @@ class SceneDesc(C.Structure):
 
 # fvsrn_option (include/fvsrn.h): tuning / developer switches of a handle
 OPTIONS = {"small_kernel": 0, "persistent": 1, "depth_segments": 2, "fourier_resync": 3, "unit_quota": 4, "tile_order": 5,
-           "waves_per_block": 6, "max_blocks_per_cu": 7, "relu_clamp": 8, "keyframe_slots": 9, "working_grids": 10, "overlap_kernel": 11}
+           "waves_per_block": 6, "max_blocks_per_cu": 7, "relu_clamp": 8, "keyframe_slots": 9, "working_grids": 10, "overlap_kernel": 11,
+           "persistent_reserve": 12}
 ERR_WRONG_DEVICE = -8
 
 GRADIENT_OFF_OR_DIRECT, GRADIENT_FINITE_DIFFERENCES, GRADIENT_ADJOINT_METHOD = 0, 1, 2

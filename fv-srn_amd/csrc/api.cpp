@@ -30,6 +30,7 @@ struct Options {
         v[FVSRN_OPT_SMALL_KERNEL] = -1; v[FVSRN_OPT_PERSISTENT] = -1; v[FVSRN_OPT_DEPTH_SEGMENTS] = 0; v[FVSRN_OPT_FOURIER_RESYNC] = 0;
         v[FVSRN_OPT_UNIT_QUOTA] = -1; v[FVSRN_OPT_TILE_ORDER] = -1; v[FVSRN_OPT_WAVES_PER_BLOCK] = 0; v[FVSRN_OPT_MAX_BLOCKS_PER_CU] = 0;
         v[FVSRN_OPT_RELU_CLAMP] = 1; v[FVSRN_OPT_KEYFRAME_SLOTS] = 0; v[FVSRN_OPT_WORKING_GRIDS] = 0; v[FVSRN_OPT_OVERLAP_KERNEL] = -1;
+        v[FVSRN_OPT_PERSISTENT_RESERVE] = -1;
     }
     int operator[](int i) const { return v[i]; }
     // empty string = valid
@@ -46,6 +47,7 @@ struct Options {
             case FVSRN_OPT_RELU_CLAMP: return value == 0 || value == 1 ? "" : "value must be 0 or 1";
             case FVSRN_OPT_KEYFRAME_SLOTS: return value == 0 || (value >= 2 && value <= 65536) ? "" : "key-frame slots must be 0 (all resident) or >= 2";
             case FVSRN_OPT_WORKING_GRIDS: return value >= 0 && value <= 2 ? "" : "working grids must be 0 (automatic), 1 or 2";
+            case FVSRN_OPT_PERSISTENT_RESERVE: return value >= -1 && value <= 4096 ? "" : "reserved workgroup slots must be -1 (automatic) .. 4096";
             default: return "unknown option";
         }
     }
@@ -58,7 +60,8 @@ static const Options& defaultOptions() {
             {"FVSRN_SMALL_KERNEL", FVSRN_OPT_SMALL_KERNEL}, {"FVSRN_PERSISTENT", FVSRN_OPT_PERSISTENT}, {"FVSRN_SEGMENTS", FVSRN_OPT_DEPTH_SEGMENTS},
             {"FVSRN_FOURIER_RESYNC", FVSRN_OPT_FOURIER_RESYNC}, {"FVSRN_UNIT_QUOTA", FVSRN_OPT_UNIT_QUOTA}, {"FVSRN_TILE_ORDER", FVSRN_OPT_TILE_ORDER},
             {"FVSRN_WAVES_PER_BLOCK", FVSRN_OPT_WAVES_PER_BLOCK}, {"FVSRN_MAX_BLOCKS_PER_CU", FVSRN_OPT_MAX_BLOCKS_PER_CU},
-            {"FVSRN_KEYFRAME_SLOTS", FVSRN_OPT_KEYFRAME_SLOTS}, {"FVSRN_WORKING_GRIDS", FVSRN_OPT_WORKING_GRIDS}, {"FVSRN_OVERLAP_KERNEL", FVSRN_OPT_OVERLAP_KERNEL}};
+            {"FVSRN_KEYFRAME_SLOTS", FVSRN_OPT_KEYFRAME_SLOTS}, {"FVSRN_WORKING_GRIDS", FVSRN_OPT_WORKING_GRIDS}, {"FVSRN_OVERLAP_KERNEL", FVSRN_OPT_OVERLAP_KERNEL},
+            {"FVSRN_PERSISTENT_RESERVE", FVSRN_OPT_PERSISTENT_RESERVE}};
         for (const auto& e : kEnv)
             if (const char* t = std::getenv(e.name)) {
                 const int val = std::atoi(t);
@@ -1390,7 +1393,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             size_t lds = size_t(a.P.ldsBytes) + ((tfFloats + 3) & ~size_t(3)) * 4;
             S.tfLdsFloats = int((tfFloats + 3) & ~size_t(3));
             const Options& O = scene->opts;
-            const bool persistent = O[FVSRN_OPT_PERSISTENT] >= 0 ? O[FVSRN_OPT_PERSISTENT] != 0 : stripeWorld == 1;
+            const bool persistent = O[FVSRN_OPT_PERSISTENT] >= 0 ? O[FVSRN_OPT_PERSISTENT] != 0 : true;
             int wpb = wavesPerBlockFor(lds, O);
             // Small networks in registers (render_small_kernel, kernels.hpp): 32-wide Fourier-only scalar network with at most
             // three C->C layers, phases inside the v_cos domain, a transfer function, no shading.  FVSRN_SMALL_KERNEL=0: off.
@@ -1457,14 +1460,21 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             unsigned grid = unsigned((units + wpb - 1) / wpb);
             // persistent waves: no more workgroups than the chip holds at once; the rest of the units is handed out by
             // a device counter (kernels.hpp).  FVSRN_PERSISTENT=0: one unit per wave, hardware dispatch order.
-            // A rank of a multi-GPU frame (stripeWorld > 1) launches one workgroup per work unit instead: its frame is
-            // gathered by an RCCL kernel on another stream while the next frame renders, and that kernel only gets onto the
-            // chip when render workgroups retire -- persistent waves would hold every wave slot until their launch ends and
-            // serialise gather and render (the hardware dispatcher hands out the units dynamically either way).
+            // A rank of a multi-GPU frame (stripeWorld > 1) has its previous frame gathered by a collective's kernel on another stream
+            // while this one renders.  Until r03 its launches were therefore not persistent (bounded waves, below), on the assumption that
+            // persistent waves hold every wave slot until their launch ends.  Measured r03 (tools/dev/coschedule.py, a 24-workgroup
+            // stand-in kernel submitted into a persistent launch): it starts at once and ends on time -- the wide kernels leave ~60
+            // registers per lane and SIMD unallocated, enough for a small kernel's waves.  What did serialise the two was ROCm's default of
+            // FOUR hardware queues for all streams of a process (GPU_MAX_HW_QUEUES: the comm stream shared a queue with a render stream);
+            // with eight, a rank's share at world 8 runs at 97 - 98 % of frame / world persistent against 86 % with bounded waves
+            // (profiles/r03/stripe_pipeline_r03.md).  Since a real collective may need more registers than a launch leaves, stripe
+            // launches keep 1/16 of the workgroup slots free (FVSRN_OPT_PERSISTENT_RESERVE).
             S.unitQuota = 0;
             if (persistent) {
                 if (perCU > 0 && grid > resident) {
-                    grid = resident;
+                    // FVSRN_OPT_PERSISTENT_RESERVE: slots left to kernels of other streams while this launch holds the chip
+                    const unsigned reserve = O[FVSRN_OPT_PERSISTENT_RESERVE] >= 0 ? unsigned(O[FVSRN_OPT_PERSISTENT_RESERVE]) : (stripeWorld > 1 ? resident / 16 : 0u);
+                    grid = resident > reserve + unsigned(net->numCUs) / 2 ? resident - reserve : resident;
                     if (!scene->tileCounters(s, &S.tileCounter, &S.tileCounterNext))
                         return fail(FVSRN_ERR_DEVICE, "could not set up the tile counters");
                 }

@@ -95,13 +95,14 @@ class StripeRenderer:
                ``render(scene_kwargs, out, rank, world, stripe)`` that fills ``out`` ((1,8,H,W) for world == 1, compact
                (8, rows, W) otherwise) replaces it -- the CPU tests hand in the oracle so that the partition, the buffers and
                the collective are exercised with gloo.
+    streams    optional (render stream 0, render stream 1, collective's stream) to use instead of new ones
     pipelined  consecutive frames alternate between two scenes on two render streams (default: world > 1).  At world == 1
                the same trick is worth +4 % (r01), but one launch at a time keeps the HIP-event duration of the kernel, the
                rocprofv3 trace and the frame period the same number, which is what bench.py reports there.
     """
 
     def __init__(self, net, width: int, height: int, scene_kw: dict, *, rank: int = 0, world: int = 1, stripe: int = STRIPE,
-                 group=None, pipelined: Optional[bool] = None, device: str = "cuda", render: Optional[Callable] = None):
+                 group=None, pipelined: Optional[bool] = None, device: str = "cuda", render: Optional[Callable] = None, streams=None):
         self.net, self.W, self.H = net, int(width), int(height)
         self.rank, self.world, self.stripe, self.group = int(rank), int(world), int(stripe), group
         self.device = torch.device(device)
@@ -125,7 +126,9 @@ class StripeRenderer:
             from . import capi
             self._capi = capi
             self.scenes = [capi.Scene(**scene_kw) for _ in range(2 if self.pipelined else 1)]
-            self.comm_stream = torch.cuda.Stream() if world > 1 else None
+            # streams = (render stream 0, render stream 1, collective's stream): a caller that builds several pipelines in one process hands
+            # the same three to all of them (torch hands out streams from a pool, ROCm maps them onto its hardware queues by creation order)
+            self.comm_stream = (streams[2] if streams else torch.cuda.Stream()) if world > 1 else None
             self.blend_stream = None  # created with the first next_time: key-frame blends of the NEXT frame, beside the current render
             self.render_done = [torch.cuda.Event() for _ in range(nbuf)]
             self.gather_done = [torch.cuda.Event() for _ in range(nbuf)]
@@ -135,7 +138,7 @@ class StripeRenderer:
                 # uploads out of the first timed one.
                 self._render(self.scenes[0], 0, None)
                 torch.cuda.synchronize()
-                self.render_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+                self.render_streams = [streams[0], streams[1]] if streams else [torch.cuda.Stream(), torch.cuda.Stream()]
                 for st in self.render_streams:
                     st.wait_stream(torch.cuda.current_stream())
         else:
@@ -265,7 +268,8 @@ def launch_ranks(n: int, argv: Sequence[str], script: Optional[str] = None, chil
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "8"))  # (see __init__.py)
         procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
     try:
         out0, _ = procs[0].communicate(timeout=timeout)

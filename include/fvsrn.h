@@ -164,7 +164,8 @@ int fvsrn_network_get_fourier(const fvsrn_network* net, uint16_t* matrix, int ca
  * -------------------------------------------------------------------------------------- */
 typedef enum {
     FVSRN_OPT_SMALL_KERNEL = 0,      /* network + scene: 0 = never take the register-resident kernels, -1 auto  [FVSRN_SMALL_KERNEL]  */
-    FVSRN_OPT_PERSISTENT = 1,        /* scene: persistent render waves 0 / 1, -1 auto                          [FVSRN_PERSISTENT]    */
+    FVSRN_OPT_PERSISTENT = 1,        /* scene: persistent render waves 0 / 1, -1 auto = 1 (stripes of a multi-GPU frame too since r03,
+                                        with FVSRN_OPT_PERSISTENT_RESERVE slots left free)                      [FVSRN_PERSISTENT]    */
     FVSRN_OPT_DEPTH_SEGMENTS = 2,    /* scene: cut rays into k step ranges composited afterwards, 0 auto       [FVSRN_SEGMENTS]      */
     FVSRN_OPT_FOURIER_RESYNC = 3,    /* scene: exact Fourier features every k steps (power of two), 0 = 64; 1 = the reference's
                                         per-step arithmetic (fp16 position at every sample), no feature rotation [FVSRN_FOURIER_RESYNC] */
@@ -182,7 +183,10 @@ typedef enum {
     FVSRN_OPT_OVERLAP_KERNEL = 11,   /* scene: 48 / 64-wide latent-grid networks: 1 = render with the spill-free kernel variant (1 % slower alone,
                                         but its launches may overlap on two streams: kernels with scratch memory are serialised across
                                         streams), 0 = the default variant, -1 auto = 1 for the stripes of a multi-GPU frame  [FVSRN_OVERLAP_KERNEL] */
-    FVSRN_OPT_COUNT_ = 12
+    FVSRN_OPT_PERSISTENT_RESERVE = 12, /* scene: persistent launches leave this many workgroup slots of the chip unused, so that a kernel on
+                                        another stream (the all-gather of the previous frame) finds room while the frame renders; -1 auto
+                                        (0 for whole frames, 1/16 of the slots for the stripes of a multi-GPU frame)  [FVSRN_PERSISTENT_RESERVE] */
+    FVSRN_OPT_COUNT_ = 13
 } fvsrn_option;
 int fvsrn_network_set_option(fvsrn_network* net, int option, int value);
 int fvsrn_network_get_option(const fvsrn_network* net, int option, int* value);

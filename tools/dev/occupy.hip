@@ -1,0 +1,18 @@
+// Developer tool: a kernel that holds `blocks` workgroups of `threads` threads for `microseconds` on a stream -- a stand-in for the
+// collective of another rank's frame when a rank's frame pipeline is timed on one GPU (tools/stripe_efficiency.py,
+// FVSRN_STRIPE_EMULATE_GATHER=blocks,threads,microseconds).  build: hipcc --offload-arch=gfx950 -O2 -shared -fPIC -o tools/dev/bin/liboccupy.so tools/dev/occupy.hip
+#include <hip/hip_runtime.h>
+
+__global__ void occupy_kernel(long long ticks, unsigned* sink) {
+    const long long t0 = wall_clock64();  // 100 MHz
+    unsigned x = threadIdx.x;
+    while (wall_clock64() - t0 < ticks) x = x * 1664525u + 1013904223u;
+    if (x == 0xdeadbeefu) *sink = x;
+}
+
+extern "C" int occupy(int blocks, int threads, int microseconds, void* stream) {
+    static unsigned* sink = nullptr;
+    if (!sink && hipMalloc(&sink, 4) != hipSuccess) return -1;
+    hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(threads), 0, static_cast<hipStream_t>(stream), (long long)microseconds * 100, sink);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

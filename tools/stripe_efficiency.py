@@ -19,20 +19,50 @@ import torch  # noqa: E402
 from fvsrn_amd import capi, tiles, volnet_io  # noqa: E402
 
 
+_OCCUPY = None
+_STREAMS = None
+
+
+def _streams():
+    """one set of streams for every pipeline this process builds (a rank has one pipeline; this tool builds 14 per configuration)"""
+    global _STREAMS
+    if _STREAMS is None:
+        _STREAMS = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream())
+    return _STREAMS
+
+
+def emulate_gather(pipe, b):
+    """FVSRN_STRIPE_EMULATE_GATHER=blocks,threads,microseconds: a kernel of that shape on the comm stream behind this frame's render,
+    in the place of the all-gather (tools/dev/occupy.hip); the next use of buffer b waits for it like for the collective."""
+    global _OCCUPY
+    spec = os.environ.get("FVSRN_STRIPE_EMULATE_GATHER")
+    if not spec or pipe.world == 1:
+        return
+    import ctypes
+    if _OCCUPY is None:
+        _OCCUPY = ctypes.CDLL(os.path.join(ROOT, "tools", "dev", "bin", "liboccupy.so"))
+        _OCCUPY.occupy.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    blocks, threads, us = [int(v) for v in spec.split(",")]
+    with torch.cuda.stream(pipe.comm_stream):
+        pipe.comm_stream.wait_event(pipe.render_done[b])
+        assert _OCCUPY.occupy(blocks, threads, us, ctypes.c_void_p(pipe.comm_stream.cuda_stream)) == 0
+        pipe.gather_done[b].record()
+
+
 def frame_period(net, cfg, time_keys, rank, world, frames=24, warm=8, pipelined=None, ahead=True):
     _, _, _, W, H, steps = cfg
     kw = lambda i: b.build_scene_kwargs(capi, 2 * math.pi * (i % 64) / 64, 1.0 / steps, False)  # noqa: E731
-    pipe = tiles.StripeRenderer(net, W, H, kw(0), rank=rank, world=world, stripe=b.STRIPE, pipelined=pipelined)
+    pipe = tiles.StripeRenderer(net, W, H, kw(0), rank=rank, world=world, stripe=b.STRIPE, pipelined=pipelined, streams=_streams())
     t = lambda i: (0.25 * i) % (time_keys - 1) if time_keys > 1 else None  # noqa: E731
     tn = (lambda i: t(i + 1)) if (ahead and pipe.pipelined) else (lambda i: None)
     for i in range(warm):
-        pipe.submit(i, kw(i), time=t(i), next_time=tn(i), gather=False)
+        emulate_gather(pipe, pipe.submit(i, kw(i), time=t(i), next_time=tn(i), gather=False))
     pipe.finish()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(warm, warm + frames):
-        pipe.submit(i, kw(i), time=t(i), next_time=tn(i), gather=False)
+        emulate_gather(pipe, pipe.submit(i, kw(i), time=t(i), next_time=tn(i), gather=False))
     pipe.finish()
     e1.record()
     torch.cuda.synchronize()
@@ -50,7 +80,8 @@ def main():
         ahead = os.environ.get("FVSRN_BENCH_BLEND_AHEAD", "0") == "1"
         row["blend_ahead"] = bool(ahead and keys > 1)
         row["working_grids"] = net.get_option("working_grids")
-        for world in (2, 4, 8):
+        row["emulated_gather"] = os.environ.get("FVSRN_STRIPE_EMULATE_GATHER")
+        for world in [int(w) for w in os.environ.get("FVSRN_STRIPE_WORLDS", "2,4,8").split(",")]:
             worst = max(frame_period(net, cfg, keys, r, world, ahead=ahead) for r in range(world))
             row["world"][str(world)] = {"slowest_rank_frame_period_ms": worst, "ideal_ms": full / world, "render_only_efficiency": full / world / worst}
         print(json.dumps(row), flush=True)
