@@ -27,6 +27,13 @@ python tools/bench_evaluate_gradients.py > gpurun_out/bench_evaluate_gradients_$
 python tools/bench_shaded.py > gpurun_out/bench_shaded_${V}.jsonl 2>/dev/null
 python tools/stripe_efficiency.py > gpurun_out/stripe_efficiency_${V}.jsonl 2>/dev/null
 FVSRN_WORKING_GRIDS=1 python tools/stripe_efficiency.py c64l6_grid16_time16_1024x512 > gpurun_out/stripe_efficiency_one_working_grid_${V}.jsonl 2>/dev/null
+# the same with a stand-in for the collective on the comm stream (tools/dev/occupy.hip), with ROCm's default of four hardware queues, and with the r02 launch shape
+if [ -f tools/dev/bin/liboccupy.so ]; then
+  FVSRN_STRIPE_EMULATE_GATHER=24,512,150 python tools/stripe_efficiency.py > gpurun_out/stripe_efficiency_with_stand_in_${V}.jsonl 2>/dev/null
+  FVSRN_STRIPE_EMULATE_GATHER=24,512,150 GPU_MAX_HW_QUEUES=4 python tools/stripe_efficiency.py c64l6_grid16_1024x512 > gpurun_out/stripe_efficiency_four_queues_with_stand_in_${V}.jsonl 2>/dev/null
+  FVSRN_STRIPE_EMULATE_GATHER=24,512,150 FVSRN_PERSISTENT=0 python tools/stripe_efficiency.py c64l6_grid16_1024x512 > gpurun_out/stripe_efficiency_bounded_waves_with_stand_in_${V}.jsonl 2>/dev/null
+  python tools/dev/coschedule.py 2>/dev/null > gpurun_out/coschedule_${V}.txt
+fi
 python tools/bench_grid_volume.py > gpurun_out/grid_volume_bench_${V}.json 2>/dev/null
 python tools/bench_tail_variants.py 2>/dev/null | grep -v amdgpu > gpurun_out/tail_variants_${V}.txt
 [ -x tools/microbench/bin/r03_snakealt ] && tools/microbench/bin/r03_snakealt 2>&1 | grep -v amdgpu.ids > gpurun_out/snakealt_microbench_${V}.txt
