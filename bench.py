@@ -346,7 +346,7 @@ def main():
     frame_check = None
     if distributed:  # untimed: the gathered stripes of the last frame equal a whole-frame render on this rank
         last = args.warmup + args.steps - 1
-        gathered = runner.assemble(last & 1)
+        gathered = runner.assemble(last % runner.pipeline.buffers)
         yaw = 2 * math.pi * (last % 64) / 64
         scene = capi.Scene(**build_scene_kwargs(capi, yaw, runner.stepsize, args.early_out))
         if time_keys > 1:

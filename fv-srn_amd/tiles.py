@@ -116,7 +116,11 @@ class StripeRenderer:
         if world > 1:
             check_even_partition(self.H, self.stripe, self.world)
         self.rows = self.H // self.world if world > 1 else self.H
-        nbuf = 2
+        # Buffers: two render targets at world 1.  A rank of a multi-GPU frame rotates THREE local / gathered pairs: frame i + 2 then does not wait
+        # for the collective of frame i, which may only get onto the chip once the render of frame i + 1 has ended (a collective whose
+        # workgroups need more registers than a persistent render launch leaves free) -- with two pairs that wait is a bubble of one
+        # collective per frame, with three the collective runs beside the start of the next render.
+        nbuf = self.buffers = 3 if world > 1 else 2
         if world == 1:
             self.outs = [torch.zeros((1, 8, self.H, self.W), dtype=torch.float32, device=self.device) for _ in range(nbuf)]
         else:
@@ -164,22 +168,23 @@ class StripeRenderer:
     def submit(self, index: int, scene_kw: dict, *, time: Optional[float] = None, ensemble: int = 0, next_time: Optional[float] = None,
                stats=None, gather: bool = True, record: bool = False) -> int:
         """Enqueues frame `index`: scene update, optional time change, render of this rank's share, gather.  Returns the
-        buffer index b (= index & 1): ``frame(b)`` is this frame once ``finish()`` (or a later wait) has passed.
+        buffer index b (= index % self.buffers): ``frame(b)`` is this frame once ``finish()`` (or a later wait) has passed.
         next_time: the time of the frame that will be submitted next -- its key-frame blend is enqueued right behind this frame's
         render call on a high-priority side stream (fvsrn_network_prepare), so that it runs beside this render (into the working
         grid this render does not read) instead of between the two renders."""
         import torch.distributed as dist
-        b = index & 1
-        s = b if self.pipelined else 0
+        b = index % self.buffers
+        r = index & 1  # scene / render stream: consecutive frames alternate
+        s = r if self.pipelined else 0
         if self.on_gpu:
             scene = self.scenes[s]
             scene.update(**scene_kw)
-            stream = self.render_streams[b] if self.pipelined else torch.cuda.current_stream()
+            stream = self.render_streams[r] if self.pipelined else torch.cuda.current_stream()
         else:
             scene = self.scenes[s]
             scene.clear()
             scene.update(scene_kw)
-            stream = self.render_streams[b]
+            stream = self.render_streams[r]
         if time is not None and (time, ensemble) != getattr(self, "_prepared", None):
             # key frames are resident (or streamed by the library's copy stream); this only marks the working grid dirty, the
             # blend into the grid the other frame in flight does NOT read is enqueued by the render call below

@@ -85,7 +85,7 @@ def _pipeline_worker(rank, world, port, H, W, stripe, tmp):
     yaws = [0.3, 1.1, 2.0]
     for i, yaw in enumerate(yaws):
         b = pipe.submit(i, scene_kw(yaw))
-        assert b == (i & 1)
+        assert b == i % pipe.buffers and pipe.buffers == 3
         pipe.finish()
         full, _ = oracle.OracleScene(**scene_kw(yaw)).render(net, W, H)
         frame = pipe.frame(b)
