@@ -15,6 +15,9 @@ L = "/opt/rocm/lib/llvm/bin"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+TRANS = re.compile(r"v_(exp|log|rcp|rcp_iflag|rsq|sqrt|sin|cos)_(f32|f16|legacy_f32)")
+
+
 def regs(tok):
     m = re.fullmatch(r"-?\|?v(\d+)\|?", tok)
     if m:
@@ -59,14 +62,22 @@ def check(obj):
                 # (a write of the same register by another VALU opcode needs four wait states: one more than a read)
                 wrote = regs(args[0]) if (args and not ("store" in op or op.startswith("ds_write"))) else set()
                 for (r, left, src_line) in pending:
-                    if r in wrote and not op.startswith("v_dot2") and left + 1 > 0 and r not in used:
+                    if r in wrote and not op.startswith("v_dot2") and left + 1 > 0 and r not in used and not TRANS.match(src_line.split()[0]):
                         print("%s: %s\n    overwrites v%d, written by `%s` with %d wait state(s) still due" % (kernel[:90], body, r, src_line, left + 1))
                         bad += 1
                 for (r, left, src_line) in pending:
+                    if TRANS.match(src_line.split()[0]) and (TRANS.match(op) or not op.startswith("v_")):
+                        continue  # (trans -> trans and trans -> memory are not in that hazard class)
                     if r in used and not op.startswith("v_dot2_f32_f16"):
                         print("%s: %s\n    reads v%d, written by `%s` with %d wait state(s) still due" % (kernel[:90], body, r, src_line, left))
                         bad += 1
         pending = [(r, left - states, s) for (r, left, s) in pending if left - states > 0]
+        # VALU trans-use hazard (gfx940 / gfx950): a non-transcendental VALU instruction that reads the result of a transcendental one
+        # needs one wait state.  The compiler handles its own instructions; the inline-assembly rotations (srn_device.hpp) read feature
+        # registers that v_cos / v_sin wrote, so the same scan covers them.
+        if TRANS.match(op) and args:
+            for r in regs(args[0]):
+                pending.append((r, 1, body))
         if op == "v_dot2_f32_f16" and args and args[-1] == "0":
             n_dots += 1
             for r in regs(args[0]):
