@@ -428,6 +428,26 @@ def generate():
         out = net(x, torch.zeros(n), torch.zeros(n), torch.zeros(n), "world")
         out[:, 0].sum().backward()
         save_case(name, net, opt, pos, out_fp32=out.detach().numpy(), grad_fp32=x.grad.detach().numpy().copy())
+    # ... with a latent grid, at positions in the middle half of a cell on every axis (texel fraction in [0.27, 0.73], no clamped cell):
+    # there both points of the reference's central difference (step 1 / (4 resolution) = a quarter texel) stay inside the sample's own
+    # cell, where the trilinear interpolant is linear along the axis -- central difference = torch.grid_sample's analytic derivative.
+    for name, kw in [
+        ("g4_grad_grid16r8_c32l4_snakealt_density", dict(layers="32:32:32", activation="SnakeAlt:1", outputmode="density", F=14, std=0.35, gc=16, gr=8)),
+        ("g4_grad_grid16r16_c64l3_sine_density-direct", dict(layers="64:64", activation="Sine:1", outputmode="density:direct", F=30, std=0.35, gc=16, gr=16)),
+    ]:
+        ns, ps, _ = seeds(name)
+        net, opt = make_network(SRN, layers=kw["layers"], activation=kw["activation"], fouriercount=kw["F"], fourierstd=kw["std"],
+                                outputmode=kw["outputmode"], grid_channels=kw["gc"], grid_res=kw["gr"], seed=ns)
+        rng = np.random.RandomState(ps)
+        r = kw["gr"]
+        cell = rng.randint(0, r - 1, size=(N, 3))
+        frac = rng.uniform(0.27, 0.73, size=(N, 3))
+        pos = ((cell + frac + 0.5) / r).astype(np.float32)  # texel coordinate = p * r - 0.5 = cell + frac
+        x = torch.from_numpy(pos).clone().requires_grad_(True)
+        n = x.shape[0]
+        out = net(x, torch.zeros(n), torch.zeros(n), torch.zeros(n), "world")
+        out[:, 0].sum().backward()
+        save_case(name, net, opt, pos, out_fp32=out.detach().numpy(), grad_fp32=x.grad.detach().numpy().copy())
 
 
 def camera_frame(pitch, yaw, distance):
