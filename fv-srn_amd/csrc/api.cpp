@@ -191,35 +191,6 @@ struct StreamOrder {
     }
 };
 
-// Kernels that use scratch memory (register spills) are never put on the chip from two streams at once.  Measured on MI355X / ROCm 7.2
-// (r03, tools/dev/stress_concurrent.py, profiles/r03/scratch_concurrency.md): two launches of such a kernel running concurrently on two
-// streams return, in a few per cent of the frames, 16 lanes of one wave with slightly wrong values (the 64-byte chunk of a spilled
-// register that belongs to lanes 48-63) -- alone, or with the kernel compiled without spills, every frame is bit-identical, and no
-// runtime switch changes it.  So a launch of a scratch-using kernel waits for the last such launch on any other stream of the device
-// (one event, process-wide per device); scratch-free kernels -- the register-resident renderers, every evaluate kernel of the
-// benchmark configurations -- keep their full concurrency.
-struct ScratchFence {
-    std::mutex mu;
-    hipEvent_t last[16] = {};
-    hipStream_t stream[16] = {};
-    bool have[16] = {};
-    // brackets the launch: call before (orders `s` behind the previous scratch launch on another stream) ...
-    void before(int device, hipStream_t s) {
-        if (device < 0 || device >= 16) return;
-        std::lock_guard<std::mutex> lock(mu);
-        if (have[device] && stream[device] != s) HIP_CHECK(hipStreamWaitEvent(s, last[device], 0));
-    }
-    // ... and after it has been enqueued
-    void after(int device, hipStream_t s) {
-        if (device < 0 || device >= 16) return;
-        std::lock_guard<std::mutex> lock(mu);
-        if (!last[device]) HIP_CHECK(hipEventCreateWithFlags(&last[device], hipEventDisableTiming));
-        HIP_CHECK(hipEventRecord(last[device], s));
-        stream[device] = s;
-        have[device] = true;
-    }
-};
-ScratchFence g_scratchFence;
 // Per-call temporaries of evaluate_points (the list of deferred batches, the two passes of the curvature evaluation) are allocated
 // and freed in stream order from a pool of the library's own (one per device, created on first use): the device's default pool
 // hands memory back to the driver at every synchronisation, which turned a 134 MB temporary into 1.5 ms of host time per call;
@@ -251,12 +222,6 @@ struct TemporaryPools {
     }
 };
 TemporaryPools g_temporaries;
-// bytes of scratch per lane of a kernel function (0: none); cached by the callers
-int kernelScratchBytes(const void* fn) {
-    hipFuncAttributes a{};
-    if (!fn || hipFuncGetAttributes(&a, fn) != hipSuccess) return 0;
-    return int(a.localSizeBytes);
-}
 
 struct WrongDevice : WrongDeviceBase { using WrongDeviceBase::WrongDeviceBase; };
 // A handle's device state lives on the device that was current at its first use; every later call must run there.
@@ -404,14 +369,6 @@ struct fvsrn_network {
     VariantKey keyScaled{};  // ReLU networks: [0,1]-scaled image (render only)
     KernelInfo kinfo{}, kinfoScaled{};
     int numCUs = 0;
-    int scratchRender = 0, scratchShaded = 0, scratchEval = 0, scratchEvalPlain = 0;  // kernelScratchBytes of the selected variants
-    std::vector<std::pair<const void*, int>> scratchSmall;                         // ... and of the register-resident kernels used so far
-    int scratchOf(const void* fn) {
-        for (const auto& e : scratchSmall)
-            if (e.first == fn) return e.second;
-        scratchSmall.emplace_back(fn, kernelScratchBytes(fn));
-        return scratchSmall.back().second;
-    }
     int device = -1;  // HIP device of the buffers above (-1: none yet)
     Options opts = defaultOptions();
     mutable std::mutex mu;
@@ -523,11 +480,6 @@ struct fvsrn_network {
         const size_t maxLds = packed.ldsImage.size() + 4096 + 256 * 6 * 4;
         HIP_CHECK(hipFuncSetAttribute(kinfo.evalFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         if (kinfoScaled.evalFn != kinfo.evalFn) HIP_CHECK(hipFuncSetAttribute(kinfoScaled.evalFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
-        scratchRender = kernelScratchBytes(kinfoScaled.renderFn);
-        scratchShaded = kernelScratchBytes(kinfo.renderShadedFn);
-        scratchEval = kernelScratchBytes(kinfoScaled.evalFn);
-        scratchEvalPlain = kernelScratchBytes(kinfo.evalFn);
-        scratchSmall.clear();
         HIP_CHECK(hipFuncSetAttribute(kinfoScaled.renderFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         HIP_CHECK(hipFuncSetAttribute(kinfo.renderShadedFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         if (const void* fn = render_stripe_fn(keyScaled)) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
@@ -1109,10 +1061,6 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
             }
             if (!(flags & FVSRN_EVAL_WORLD_POSITIONS))  // volume_interpolation.cpp:46-49: box := [0,1]^3
                 for (int i = 0; i < 3; ++i) { a.P.boxMin[i] = 0.f; a.P.boxSize[i] = 1.f; a.P.invBoxSize[i] = 1.f; }
-            // (ScratchFence: the gradient kernels are not queried individually and count as scratch users)
-            const bool usesScratch = adjoint || net->scratchEval > 0 || net->scratchEvalPlain > 0;
-            if (usesScratch) g_scratchFence.before(net->device, s);
-            struct FenceAfter { bool on; int dev; hipStream_t s; ~FenceAfter() { if (on) { try { g_scratchFence.after(dev, s); } catch (...) {} } } } fenceAfter{usesScratch, net->device, s};
             const size_t batches = (n + 63) / 64;
             const size_t wpb = size_t(wavesPerBlockFor(size_t(net->packed.params.ldsBytes), net->opts));
             const size_t blocks = (batches + wpb - 1) / wpb;
@@ -1423,10 +1371,11 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 }
                 lds += size_t(wpb) * kRotationBytes;
             }
-            // the spill-free variant of the wide latent-grid renderers (render_stripe_kernel, kernels.hpp): for launches that are meant to
-            // overlap with other launches -- the stripes of a multi-GPU frame alternate between two streams
+            // the fragment-major variant of the wide latent-grid renderers (render_stripe_kernel, kernels.hpp: no register spills, 1 % slower):
+            // on request only (FVSRN_OPT_OVERLAP_KERNEL = 1) since the launch-to-launch differences it was built around turned out to be a
+            // hazard in the tap arithmetic (srn_device.hpp, grid_tap) and not concurrent scratch use
             const void* stripeFn = nullptr;
-            if (!smallFn && !a.shaded && (O[FVSRN_OPT_OVERLAP_KERNEL] >= 0 ? O[FVSRN_OPT_OVERLAP_KERNEL] == 1 : stripeWorld > 1))
+            if (!smallFn && !a.shaded && O[FVSRN_OPT_OVERLAP_KERNEL] == 1)
                 stripeFn = render_stripe_fn(net->keyScaled);
             // the adjoint gradient mode up to 64 channels: its own kernel (render_adjoint_kernel, kernels.hpp)
             const void* adjointFn = (a.shaded && d.gradient_mode == FVSRN_GRADIENT_ADJOINT_METHOD) ? render_adjoint_fn(net->key) : nullptr;
@@ -1505,9 +1454,6 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             scene->lastInfo[1] = rotates ? S.resyncMask + 1 : 0;
             scene->lastInfo[2] = smallFn ? 1 : (stripeFn ? 2 : (adjointFn ? 3 : 0));
             scene->lastInfo[3] = wpb;
-            const bool usesScratch = (altFn ? net->scratchOf(altFn) : (a.shaded ? net->scratchShaded : net->scratchRender)) > 0;
-            if (usesScratch) g_scratchFence.before(net->device, s);
-            struct FenceAfter { bool on; int dev; hipStream_t s; ~FenceAfter() { if (on) { try { g_scratchFence.after(dev, s); } catch (...) {} } } } fenceAfter{usesScratch, net->device, s};
             hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid, a, grid, unsigned(64 * wpb), lds, s)
                                    : (stripeFn ? launch_render_stripe(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s)
                                       : (adjointFn ? launch_render_adjoint(net->key, a, grid, unsigned(64 * wpb), lds, s)

@@ -888,11 +888,10 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void r
     render_entry<CD, ACT, GRID, HAS_DIR, 0>(P, S, out, stats);
 }
 
-// render_kernel for the stripes of a multi-GPU frame (and any caller that keeps two frames in flight on two streams): 48- and 64-wide
-// latent-grid networks in the fragment-major layer order.  On one stream the pipelined order of render_kernel is 1.2 % faster (64x6 + 32^3
-// grid: 24.75 vs 24.45 Gsamples/s), but it spills 76 registers to scratch, and kernels with scratch are serialised across streams
-// (ScratchFence, api.cpp); this variant needs 218 registers and no scratch, its launches overlap on two streams: per-rank frame period of
-// configs[3] 7.2 - 7.7 / 3.86 / 2.02 ms at world 2 / 4 / 8 against 8.21 / 4.09 / 2.05 ms (profiles/r03/experiments_r03.md).
+// render_kernel for 48- and 64-wide latent-grid networks in the fragment-major layer order: 218 registers and no scratch against the 76
+// spilled registers of the pipelined order, 1.2 % slower on one stream (64x6 + 32^3 grid: 24.45 vs 24.75 Gsamples/s).  Built in r03 for
+// overlapping launches when kernels with scratch were serialised across streams; that rule is gone, the variant is
+// taken on request only (FVSRN_OPT_OVERLAP_KERNEL = 1).
 template <int CD, int ACT, int GRID, bool HAS_DIR>
 __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void render_stripe_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                       unsigned long long* __restrict__ stats) {

@@ -207,3 +207,30 @@ def test_two_rank_processes_share_the_gpu_and_assemble_the_frame():
     line = entry.two_rank_smoke(steps=3)
     assert line["gathered_frame_matches_single_gpu_frame"] is True and line["backend"] == "gloo"
     assert line["value"] > 1e7  # samples/s of the whole job (two ranks on one GPU, frames gathered through host memory by gloo)
+
+
+@pytest.mark.gpu
+def test_stripe_launch_shapes_render_the_same_rows():
+    """A rank's launch is persistent with a reserve of workgroup slots for the collective of the previous frame (r03; until then: bounded
+    waves).  The launch shape only changes which wave renders which tile: persistent with any reserve, bounded waves and one unit per
+    wave give the same image (bit for bit: one tile is one wave's work in every shape); the option validates its range."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=64, layers=3, activation="ReLU", output_mode="density", grid=(16, 8), seed=62, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4,
+                             grid_scale=0.3)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    kw = make_scene_kwargs(stepsize=1 / 128, early_out=False, tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=20.0, tf_scale_emission=1.0)
+    W, H = 1024, 512  # a rank's share large enough that the launch exceeds what the chip holds at once
+    images = []
+    for opts in (dict(), dict(persistent_reserve=0), dict(persistent_reserve=100), dict(persistent=0), dict(persistent=0, unit_quota=0)):
+        scene = capi.Scene(**kw).set_option("depth_segments", 1)
+        for k, v in opts.items():
+            scene.set_option(k, v)
+        images.append(torch.nan_to_num(capi.render_stripes(scene, net, W, H, 16, 1, 2), nan=-7.0).clone())
+    assert float(images[0][3].max()) > 0.2
+    for i, img in enumerate(images[1:]):
+        assert torch.equal(images[0], img), (i + 1, float((images[0] - img).abs().max()), int((images[0] != img).sum()))
+    scene = capi.Scene(**kw)
+    assert scene.get_option("persistent_reserve") == -1
+    with pytest.raises(capi.FvsrnError):
+        scene.set_option("persistent_reserve", 5000)

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Developer tool: is a render bit-identical from launch to launch?  Renders one scene N times per configuration and reports every
+launch whose image differs from the first one: how many values, which planes, which pixels (tile and lane inside the 8x8 tile).
+usage: tools/dev/determinism.py [repeats]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from fvsrn_amd import capi, synthetic, volnet_io  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+POISON = None
+if len(sys.argv) > 2:  # a bit pattern (hex) written into every vector register of the chip before each launch
+    import ctypes
+    _occ = ctypes.CDLL(os.path.join(ROOT, "tools", "dev", "bin", "liboccupy.so"))
+    _occ.poison.argtypes = [ctypes.c_uint, ctypes.c_void_p]
+    POISON = int(sys.argv[2], 16)
+eye, right, up = capi.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, 0.7, 1.6)
+kw = dict(eye=eye, right=right, up=up, fov_y_radians=float(np.deg2rad(45.0)), stepsize=1 / 128, early_out=False,
+          tf_kind=capi.TF_IDENTITY, tf_scale_absorption=20.0, tf_scale_emission=1.0)
+W, H = 1024, 512
+G = dict(grid=(16, 8))
+CASES = [("64x3 ReLU + grid, stripes (render_stripe_kernel)", dict(C=64, layers=3, activation="ReLU", **G), "stripes", {}),
+         ("64x3 ReLU + grid, stripes, render_kernel", dict(C=64, layers=3, activation="ReLU", **G), "stripes", dict(overlap_kernel=0)),
+         ("64x3 ReLU + grid, frame, render_kernel", dict(C=64, layers=3, activation="ReLU", **G), "frame", {}),
+         ("64x3 ReLU + grid, frame, render_stripe_kernel", dict(C=64, layers=3, activation="ReLU", **G), "frame", dict(overlap_kernel=1)),
+         ("64x3 ReLU + grid, frame, render_stripe_kernel, not persistent", dict(C=64, layers=3, activation="ReLU", **G), "frame", dict(overlap_kernel=1, persistent=0)),
+         ("64x3 SnakeAlt + grid, stripes (render_stripe_kernel)", dict(C=64, layers=3, activation="SnakeAlt", **G), "stripes", {}),
+         ("64x3 SnakeAlt + grid, stripes, render_kernel", dict(C=64, layers=3, activation="SnakeAlt", **G), "stripes", dict(overlap_kernel=0)),
+         ("64x3 SnakeAlt + grid, stripes, not persistent", dict(C=64, layers=3, activation="SnakeAlt", **G), "stripes", dict(persistent=0, unit_quota=0)),
+         ("64x3 SnakeAlt, no grid, stripes", dict(C=64, layers=3, activation="SnakeAlt"), "stripes", {}),
+         ("64x3 ReLU, no grid, frame", dict(C=64, layers=3, activation="ReLU"), "frame", {}),
+         ("48x3 SnakeAlt + grid, stripes", dict(C=48, layers=3, activation="SnakeAlt", **G), "stripes", {}),
+         ("32x4 ReLU + grid, frame (resident kernel)", dict(C=32, layers=4, activation="ReLU", **G), "frame", {}),
+         ("32x4 SnakeAlt + grid, frame (resident kernel)", dict(C=32, layers=4, activation="SnakeAlt", **G), "frame", {}),
+         ("32x4 SnakeAlt + grid, frame, LDS kernel", dict(C=32, layers=4, activation="SnakeAlt", **G), "frame", dict(small_kernel=0)),
+         ("32x4 SnakeAlt + grid, stripes, LDS kernel, not persistent", dict(C=32, layers=4, activation="SnakeAlt", **G), "stripes", dict(small_kernel=0, persistent=0, unit_quota=0))]
+for name, net_kw, what, opts in CASES:
+    vn = synthetic.random_network(output_mode="density", seed=62, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4, grid_scale=0.3, **net_kw)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    scene = capi.Scene(**kw).set_option("depth_segments", 1)
+    for k, v in opts.items():
+        scene.set_option(k, v)
+    first, bad = None, []
+    for i in range(N):
+        if POISON is not None and i > 0:
+            _occ.poison(POISON, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        img = capi.render_stripes(scene, net, W, H, 16, 1, 2) if what == "stripes" else scene.render(net, W, H)[0]
+        img = torch.nan_to_num(img, nan=-7.0).clone()
+        if first is None:
+            first = img
+        elif not torch.equal(first, img):
+            d = (first != img).nonzero().cpu().numpy()
+            planes = sorted(set(d[:, 0].tolist()))
+            px = sorted(set((int(y), int(x)) for _, y, x in d))
+            lanes = sorted(set((y % 8) * 8 + (x % 8) for y, x in px))
+            tiles = sorted(set((y // 8, x // 8) for y, x in px))
+            bad.append((i, len(d), float((first - img).abs().max()), planes, tiles[:4], lanes))
+    print("%-56s %d of %d launches differ from the first" % (name, len(bad), N - 1))
+    for b in bad[:2]:
+        print("     launch %d: %d values, max |diff| %.2e, planes %s, tiles %s, lanes %s" % b)
