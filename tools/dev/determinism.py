@@ -38,18 +38,34 @@ CASES = [("64x3 ReLU + grid, stripes (render_stripe_kernel)", dict(C=64, layers=
          ("32x4 ReLU + grid, frame (resident kernel)", dict(C=32, layers=4, activation="ReLU", **G), "frame", {}),
          ("32x4 SnakeAlt + grid, frame (resident kernel)", dict(C=32, layers=4, activation="SnakeAlt", **G), "frame", {}),
          ("32x4 SnakeAlt + grid, frame, LDS kernel", dict(C=32, layers=4, activation="SnakeAlt", **G), "frame", dict(small_kernel=0)),
-         ("32x4 SnakeAlt + grid, stripes, LDS kernel, not persistent", dict(C=32, layers=4, activation="SnakeAlt", **G), "stripes", dict(small_kernel=0, persistent=0, unit_quota=0))]
+         ("32x4 SnakeAlt + grid, stripes, LDS kernel, not persistent", dict(C=32, layers=4, activation="SnakeAlt", **G), "stripes", dict(small_kernel=0, persistent=0, unit_quota=0)),
+         ("32x4 ReLU + grid, shaded, adjoint gradients", dict(C=32, layers=4, activation="ReLU", **G), "adjoint", {}),
+         ("64x3 SnakeAlt + grid, shaded, adjoint gradients", dict(C=64, layers=3, activation="SnakeAlt", **G), "adjoint", {}),
+         ("64x3 ReLU + grid, shaded, finite differences", dict(C=64, layers=3, activation="ReLU", **G), "fd", {}),
+         ("32x4 SnakeAlt + grid, evaluate_points_adjoint", dict(C=32, layers=4, activation="SnakeAlt", **G), "eval_adjoint", {}),
+         ("64x3 ReLU + grid, evaluate_points", dict(C=64, layers=3, activation="ReLU", **G), "eval", {})]
+PHONG = dict(enable_phong=True, ambient=0.2, specular=0.4, magnitude_center=0.6, magnitude_radius=0.5, specular_exponent=8, light_type=0, light=tuple(float(v) for v in eye))
+POINTS = torch.from_numpy(np.random.RandomState(3).uniform(-0.5, 0.5, (1 << 18, 3)).astype(np.float32)).cuda()
 for name, net_kw, what, opts in CASES:
     vn = synthetic.random_network(output_mode="density", seed=62, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4, grid_scale=0.3, **net_kw)
     net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
-    scene = capi.Scene(**kw).set_option("depth_segments", 1)
+    skw = dict(kw)
+    if what in ("adjoint", "fd"):
+        skw.update(gradient_mode=2 if what == "adjoint" else 1, finite_differences_stepsize=1 / 256, brdf=PHONG, stepsize=1 / 64)
+    scene = capi.Scene(**skw).set_option("depth_segments", 1)
     for k, v in opts.items():
         scene.set_option(k, v)
     first, bad = None, []
     for i in range(N):
         if POISON is not None and i > 0:
             _occ.poison(POISON, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-        img = capi.render_stripes(scene, net, W, H, 16, 1, 2) if what == "stripes" else scene.render(net, W, H)[0]
+        if what == "eval_adjoint":
+            v, g = net.evaluate_with_adjoint_gradient(POINTS, None, world=True)
+            img = torch.cat([v, g], dim=1).t().reshape(4, 512, 512)
+        elif what == "eval":
+            img = net.evaluate(POINTS, None, world=True).t().reshape(1, 512, 512)
+        else:
+            img = capi.render_stripes(scene, net, W, H, 16, 1, 2) if what == "stripes" else scene.render(net, W, H)[0]
         img = torch.nan_to_num(img, nan=-7.0).clone()
         if first is None:
             first = img
