@@ -234,3 +234,29 @@ def test_stripe_launch_shapes_render_the_same_rows():
     assert scene.get_option("persistent_reserve") == -1
     with pytest.raises(capi.FvsrnError):
         scene.set_option("persistent_reserve", 5000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,layers,act,opts", [(64, 3, "ReLU", dict(overlap_kernel=1)), (64, 3, "SnakeAlt", dict(overlap_kernel=1)),
+                                               (64, 3, "ReLU", dict(overlap_kernel=1, persistent=0)), (32, 4, "ReLU", dict())])
+def test_latent_grid_kernels_are_bit_identical_from_launch_to_launch(C, layers, act, opts):
+    """The same frame, twelve launches: identical bits.  Before the spacing in grid_tap (srn_device.hpp, FVSRN_TAP_NOPS) these were the
+    configurations of tools/dev/determinism.py that differed most often -- lanes 48-63 of one tile by 1e-7 ... 2e-4, from one launch in twenty
+    to every launch (profiles/r03/nondeterminism_r03.md)."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=C, layers=layers, activation=act, output_mode="density", grid=(16, 8), seed=62, box_min=(-0.5, -0.5, -0.5),
+                             fourier_std=0.4, grid_scale=0.3)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    kw = make_scene_kwargs(stepsize=1 / 128, early_out=False, tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=20.0, tf_scale_emission=1.0)
+    scene = capi.Scene(**kw).set_option("depth_segments", 1)
+    for k, v in opts.items():
+        scene.set_option(k, v)
+    first = None
+    for i in range(12):
+        img = torch.nan_to_num(scene.render(net, 1024, 512)[0], nan=-7.0).clone()
+        if first is None:
+            first = img
+            assert float(img[3].max()) > 0.2
+        else:
+            assert torch.equal(first, img), (i, int((first != img).sum()), float((first - img).abs().max()))

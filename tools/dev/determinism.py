@@ -46,6 +46,20 @@ CASES = [("64x3 ReLU + grid, stripes (render_stripe_kernel)", dict(C=64, layers=
          ("64x3 ReLU + grid, evaluate_points", dict(C=64, layers=3, activation="ReLU", **G), "eval", {})]
 PHONG = dict(enable_phong=True, ambient=0.2, specular=0.4, magnitude_center=0.6, magnitude_radius=0.5, specular_exponent=8, light_type=0, light=tuple(float(v) for v in eye))
 POINTS = torch.from_numpy(np.random.RandomState(3).uniform(-0.5, 0.5, (1 << 18, 3)).astype(np.float32)).cuda()
+# the dense grid-volume renderer (BASELINE configs[0] on the GPU): trilinear fetches of its own
+_ax = np.linspace(-1, 1, 96, dtype=np.float32)
+_x, _y, _z = np.meshgrid(_ax, _ax, _ax, indexing="ij")
+_vol = capi.Volume.from_array(np.clip(np.exp(-3 * (_x * _x + _y * _y + _z * _z)) + 0.1 * np.sin(9 * _x) * np.cos(7 * _y) * np.sin(5 * _z), 0, 1).astype(np.float32),
+                              (-0.5, -0.5, -0.5), (1, 1, 1))
+_vscene = capi.Scene(**dict(kw, stepsize=1 / 96, tf_scale_absorption=10.0))
+_first, _bad = None, 0
+for _i in range(N):
+    _img = torch.nan_to_num(_vol.render(_vscene, 512, 512, 1), nan=-7.0).clone()
+    if _first is None:
+        _first = _img
+    elif not torch.equal(_first, _img):
+        _bad += 1
+print("%-56s %d of %d launches differ from the first" % ("dense 96^3 grid volume, trilinear, frame", _bad, N - 1))
 for name, net_kw, what, opts in CASES:
     vn = synthetic.random_network(output_mode="density", seed=62, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4, grid_scale=0.3, **net_kw)
     net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
