@@ -43,7 +43,15 @@ CASES = [("64x3 ReLU + grid, stripes (render_stripe_kernel)", dict(C=64, layers=
          ("64x3 SnakeAlt + grid, shaded, adjoint gradients", dict(C=64, layers=3, activation="SnakeAlt", **G), "adjoint", {}),
          ("64x3 ReLU + grid, shaded, finite differences", dict(C=64, layers=3, activation="ReLU", **G), "fd", {}),
          ("32x4 SnakeAlt + grid, evaluate_points_adjoint", dict(C=32, layers=4, activation="SnakeAlt", **G), "eval_adjoint", {}),
-         ("64x3 ReLU + grid, evaluate_points", dict(C=64, layers=3, activation="ReLU", **G), "eval", {})]
+         ("64x3 ReLU + grid, evaluate_points", dict(C=64, layers=3, activation="ReLU", **G), "eval", {}),
+         ("32x4 ReLU Fourier-only, Gaussian TF, early-out", dict(C=32, layers=4, activation="ReLU"), "gauss", {}),
+         ("32x4 SnakeAlt + grid, Gaussian TF, early-out", dict(C=32, layers=4, activation="SnakeAlt", **G), "gauss", {}),
+         ("64x3 ReLU + grid, piecewise TF", dict(C=64, layers=3, activation="ReLU", **G), "piecewise", {}),
+         ("32x4 SnakeAlt rgbo Fourier-only", dict(C=32, layers=4, activation="SnakeAlt", output_mode="rgbo"), "frame", {}),
+         ("128x3 ReLU + grid", dict(C=128, layers=3, activation="ReLU", **G), "frame", {}),
+         ("96x3 SnakeAlt + grid", dict(C=96, layers=3, activation="SnakeAlt", **G), "frame", {})]
+GAUSS = np.array([[0.9, 0.2, 0.1, 30.0, 0.25, 0.08], [0.1, 0.7, 0.9, 20.0, 0.6, 0.1], [0.9, 0.9, 0.2, 40.0, 0.85, 0.05]], np.float32)
+PIECE = np.array([[0.0, 0, 0, 0, 0], [0.2, 1, 0, 0, 10], [0.5, 0, 1, 0, 30], [0.8, 0, 0, 1, 5], [1.0, 1, 1, 1, 40]], np.float32)
 PHONG = dict(enable_phong=True, ambient=0.2, specular=0.4, magnitude_center=0.6, magnitude_radius=0.5, specular_exponent=8, light_type=0, light=tuple(float(v) for v in eye))
 POINTS = torch.from_numpy(np.random.RandomState(3).uniform(-0.5, 0.5, (1 << 18, 3)).astype(np.float32)).cuda()
 # the dense grid-volume renderer (BASELINE configs[0] on the GPU): trilinear fetches of its own
@@ -61,11 +69,18 @@ for _i in range(N):
         _bad += 1
 print("%-56s %d of %d launches differ from the first" % ("dense 96^3 grid volume, trilinear, frame", _bad, N - 1))
 for name, net_kw, what, opts in CASES:
-    vn = synthetic.random_network(output_mode="density", seed=62, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4, grid_scale=0.3, **net_kw)
+    net_kw = dict(net_kw)
+    vn = synthetic.random_network(output_mode=net_kw.pop("output_mode", "density"), seed=62, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4, grid_scale=0.3, **net_kw)
     net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
     skw = dict(kw)
     if what in ("adjoint", "fd"):
         skw.update(gradient_mode=2 if what == "adjoint" else 1, finite_differences_stepsize=1 / 256, brdf=PHONG, stepsize=1 / 64)
+    if what == "gauss":
+        skw.update(tf_kind=capi.TF_GAUSSIAN, tf_table=GAUSS, early_out=True)
+    if what == "piecewise":
+        skw.update(tf_kind=capi.TF_PIECEWISE, tf_table=PIECE)
+    if name.find("rgbo") >= 0:
+        skw.update(tf_kind=capi.TF_NONE)
     scene = capi.Scene(**skw).set_option("depth_segments", 1)
     for k, v in opts.items():
         scene.set_option(k, v)
