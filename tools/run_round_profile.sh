@@ -38,6 +38,7 @@ python tools/bench_grid_volume.py > gpurun_out/grid_volume_bench_${V}.json 2>/de
 python tools/bench_tail_variants.py 2>/dev/null | grep -v amdgpu > gpurun_out/tail_variants_${V}.txt
 [ -x tools/microbench/bin/r03_snakealt ] && tools/microbench/bin/r03_snakealt 2>&1 | grep -v amdgpu.ids > gpurun_out/snakealt_microbench_${V}.txt
 python tools/dev/stress_concurrent.py 100 2>&1 | grep -v amdgpu.ids > gpurun_out/stress_concurrent_${V}.txt
+python tools/dev/determinism.py 30 2>&1 | grep -v amdgpu.ids > gpurun_out/determinism_${V}.txt
 python tests/test_fuzz_parity.py 400 > gpurun_out/fuzz_report_gpu_vs_device_model_${V}.txt 2>/dev/null
 for f in gpurun_out/bench_${V}*.json; do python -c "
 import json,sys
