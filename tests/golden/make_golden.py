@@ -344,6 +344,25 @@ def generate():
     ]:
         simple(name, layers=kw["layers"], activation=kw["activation"], outputmode=kw["outputmode"], F=kw["F"], std=0.5)
 
+    # ---- G1g (round 4): 96- and 128-wide networks -- the (96, 3) / (128, 2) rows of the reference's study grid
+    # (applications/volnet/eval_NetworkConfigsGrid.py:36), without and with a latent grid; gaussian Fourier matrices (a NeRF ladder of
+    # (C - 4) / 2 = 46 features reaches 2^14, outside the half range of the reference's own fp16 path)
+    for name, kw in [
+        ("g1_c96l3_relu_density", dict(layers="96:96", activation="ReLU", outputmode="density")),
+        ("g1_c96l3_snakealt_density-direct", dict(layers="96:96", activation="SnakeAlt:1", outputmode="density:direct")),
+        ("g1_c128l2_relu_rgbo", dict(layers="128", activation="ReLU", outputmode="rgbo")),
+        ("g1_c128l3_snakealt_rgbo-direct", dict(layers="128:128", activation="SnakeAlt:1", outputmode="rgbo:direct")),
+        ("g1_c96l3_grid16r8_relu_density-direct", dict(layers="96:96", activation="ReLU", outputmode="density:direct", gc=16, gr=8)),
+        ("g1_c96l3_grid16r8_snakealt_rgbo", dict(layers="96:96", activation="SnakeAlt:1", outputmode="rgbo", gc=16, gr=8)),
+        ("g1_c128l3_grid16r8_relu_density", dict(layers="128:128", activation="ReLU", outputmode="density", gc=16, gr=8)),
+        ("g1_c128l2_grid32r8_sine_rgbo-direct", dict(layers="128", activation="Sine:1", outputmode="rgbo:direct", gc=32, gr=8)),
+        ("g1_dir2_c96l3_snake_density", dict(layers="96:96", activation="Snake:2", outputmode="density", use_direction=True, direction_in_fourier=True)),
+    ]:
+        C = int(kw["layers"].split(":")[0])
+        extra = {k: kw[k] for k in ("use_direction", "direction_in_fourier") if k in kw}
+        simple(name, layers=kw["layers"], activation=kw["activation"], outputmode=kw["outputmode"], F=(C - (8 if extra else 4)) // 2, std=0.5,
+               gc=kw.get("gc", 0), gr=kw.get("gr", 0), **extra)
+
     # ---- G1d: view direction as network input (USE_DIRECTION 1 and 2) ---------------------------------------
     for name, kw in [
         ("g1_dir1_c32l4_snakealt_rgbo", dict(layers="32:32:32", activation="SnakeAlt:1", outputmode="rgbo", F=12, dif=False)),

@@ -54,8 +54,10 @@ def test_evaluate_points_golden(name):
     spread = np.abs(ref32 - ref16).max()
     assert np.abs(out - out_f).max() < TOL_SAME_MODEL
     assert np.abs(out - ref32).max() < TOL_SAME_MODEL
-    assert np.abs(out - ref16).max() < max(TOL_REF_BAR, 1.5 * spread)
-    assert np.abs(out - out_h).max() < max(TOL_REF_BAR, 1.5 * spread)
+    # (fp16-accumulate models at 96 / 128 channels: 1.5e-2, see tests/test_oracle_golden.py)
+    bar = 1.5e-2 if int(meta["layers"].split(":")[0]) > 64 else TOL_REF_BAR
+    assert np.abs(out - ref16).max() < max(bar, 1.5 * spread)
+    assert np.abs(out - out_h).max() < max(bar, 1.5 * spread)
 
 
 @pytest.mark.parametrize("name", util.golden_names("g2_"))
@@ -68,9 +70,11 @@ def test_time_and_ensemble_golden(name):
         assert np.abs(out - d["out_fp32"][i]).max() < TOL_SAME_MODEL, (t, e)
 
 
+@pytest.mark.parametrize("net_kw", [dict(C=32, layers=4), dict(C=96, layers=3), dict(C=128, layers=2, grid=(16, 8)), dict(C=96, layers=3, grid=(16, 8), activation="ReLU")],
+                         ids=lambda k: "c%d%s%s" % (k["C"], "grid" if "grid" in k else "", k.get("activation", "")))
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000, 4097])
-def test_evaluate_ragged_sizes(n):
-    vn = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode="rgbo", seed=3)
+def test_evaluate_ragged_sizes(n, net_kw):
+    vn = util.random_network(**dict(dict(activation="SnakeAlt", output_mode="rgbo", seed=3), **net_kw))
     pos = np.random.RandomState(n).rand(n, 3).astype(np.float32)
     out = gpu_eval(vn, pos)
     assert out.shape == (n, 4)
@@ -250,6 +254,12 @@ TEX_TF = np.stack([np.linspace(0, 1, 32), np.linspace(1, 0, 32) ** 2, np.full(32
     dict(act="SnakeAlt", out="density", grid=(16, 8), tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)),
     dict(act="ReLU", out="density", C=64, layers=6, grid=(16, 8), tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)),
     dict(act="SnakeAlt", out="density", C=48, layers=3, tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)),
+    # r04: the 96- and 128-wide kernels (render_kernel<6|8,...>: eval_NetworkConfigsGrid.py:36), without and with a latent grid
+    dict(act="ReLU", out="density", C=96, layers=3, tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)),
+    dict(act="SnakeAlt", out="density", C=96, layers=3, grid=(16, 8), tf=dict(tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=20.0, tf_scale_emission=1.0)),
+    dict(act="SnakeAlt", out="rgbo", C=128, layers=2, tf=dict(tf_kind=oracle.TF_NONE)),
+    dict(act="ReLU", out="density", C=128, layers=3, grid=(16, 8), tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)),
+    dict(act="ReLU", out="density:direct", C=96, layers=3, grid=(32, 8), tf=dict(tf_kind=oracle.TF_TEXTURE, tf_table=TEX_TF)),
     # predicted gradients (normal channels 4..6 of the image) and the 6-output curvature modes
     dict(act="SnakeAlt", out="densitygrad", tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)),
     dict(act="ReLU", out="densitygrad:direct", tf=dict(tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=30.0, density_min=-1.0, density_max=1.0)),
