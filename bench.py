@@ -40,6 +40,12 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+NOMINAL_CLOCK_HZ = 2.4e9
+NUM_SIMDS = 256 * 4
+# transcendental instructions (v_cos_f32 / v_sin_f32 / v_exp_f32 ...): 8 issue cycles per wave64 instruction = 8 lanes per clock and SIMD
+# (MI355X_MICROARCH.md, constants table "vector-instruction ISSUE cost"; measured here: 8.3 - 8.4, profiles/r01/microbench_issue_model.md).
+# SURVEY 8(d) prices them at a quarter of the plain VALU rate (4 lanes per clock); "frac_at_quarter_rate" restates the line for that figure.
+TRANS_LANES_PER_CLOCK = 8.0
 STRIPE = 16
 
 CONFIGS = {
@@ -85,7 +91,7 @@ class Runner:
     """The benchmark's frame sequence (rotating camera, advancing time) on fv-srn_amd/tiles.py StripeRenderer: whole frames on
     one GPU, this rank's stripes + all-gather on several.  All multi-GPU logic lives in the package."""
 
-    def __init__(self, capi, net, cfg, rank, world, early_out, time_keys=1, scene_options=None):
+    def __init__(self, capi, net, cfg, rank, world, early_out, time_keys=1, scene_options=None, force_collective=False):
         from fvsrn_amd import tiles
         self.capi, self.net, self.rank, self.world = capi, net, rank, world
         self.time_keys = time_keys
@@ -98,7 +104,7 @@ class Runner:
         pipe = os.environ.get("FVSRN_BENCH_PIPELINE")
         pipelined = pipe == "1" if pipe is not None else world > 1
         self.pipeline = tiles.StripeRenderer(net, self.W, self.H, build_scene_kwargs(capi, 0.0, self.stepsize, early_out), rank=rank,
-                                             world=world, stripe=STRIPE, pipelined=pipelined)
+                                             world=world, stripe=STRIPE, pipelined=pipelined, force_collective=force_collective)
         for sc in self.pipeline.scenes:
             for k, v in (scene_options or {}).items():
                 sc.set_option(k, v)
@@ -149,6 +155,7 @@ def timed_run(runner, steps, warmup, distributed, spinup_ms=0.0):
     torch.cuda.synchronize()
     runner.stats.zero_()
     runner.kernel_events.clear()
+    runner.pipeline.gather_events.clear()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -243,24 +250,56 @@ def grid_volume_bench(res, size, interpolation, frames, with_cpu):
     print(json.dumps(res_))
 
 
-def pmc_traffic(workload):
-    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC summary of this workload
-    (profiles/r*/<workload>_*_pmc.csv, written by tools/pmc_profile.sh: separate --pmc passes; WRITE_SIZE is exact,
-    FETCH_SIZE counts 128-B requests as 64 B on gfx950 and is doubled, MI355X_MICROARCH.md).  None if there is no
-    profile of this workload: the counters cannot be read inside the timed run.  Unit: bytes per launch."""
+def pmc_counters(workload):
+    """Per-launch averages of the committed rocprofv3 PMC summary of this workload (profiles/r*/<workload>_*_pmc.csv, the newest round), {} if
+    there is none.  The counters cannot be read inside the timed run; tools/pmc_profile.sh collects them in separate --pmc passes."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", workload + "_*pmc.csv")))
     if not files:
-        return None
-    vals = {}
+        return {}
+    vals = {"file": os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))}
     with open(files[-1]) as f:
         for row in csv.reader(l for l in f if not l.startswith("#")):
-            if len(row) == 5 and row[2] in ("FETCH_SIZE", "WRITE_SIZE"):
+            if len(row) == 5 and row[0].startswith("pmc"):
                 vals[row[2]] = float(row[4])
-    if len(vals) != 2:
-        return None
-    return 1024.0 * (vals["WRITE_SIZE"] + 2.0 * vals["FETCH_SIZE"])  # bytes per launch
+    return vals
+
+
+def transcendentals_per_sample(info, activation, rotation_resync):
+    """SURVEY 8(d) "secondary bounds": 2F for the Fourier features + (L - 1) C for a periodic activation (Sine / Snake / SnakeAlt: one v_sin / v_cos
+    per channel and hidden layer; Sigmoid: exp + rcp), minus what the feature rotation of the 32-wide Fourier-only kernels removes (exact features
+    only every `rotation_resync` steps, fvsrn_scene_last_render_info)."""
+    per_act = {"ReLU": 0, "Sine": 1, "Snake": 1, "SnakeAlt": 1, "Sigmoid": 2}[activation]
+    fourier = 2.0 * info.num_fourier / (rotation_resync if rotation_resync > 0 else 1)
+    return fourier + per_act * (info.num_layers - 1) * info.hidden_channels
+
+
+def roofline(info, activation, evaluated_per_launch, kernel_s, workload_tag, rotation_resync, world=1):
+    """The roofline object of one bench line.  ReLU: the MFMA roofline (algorithmic FLOP).  Periodic activations: the
+    transcendental unit -- achieved = evaluated samples x transcendentals per sample / kernel time, peak = SIMDs x lanes per clock x
+    the shader clock, which is taken from GRBM_GUI_ACTIVE of the committed PMC profile of this workload (summed over the 8 XCDs) where
+    there is one, else the nominal 2.4 GHz; the MFMA fraction rides along as "mfma_frac"."""
+    pmc = pmc_counters(workload_tag) if world == 1 else {}
+    flops = info.flops_per_sample * evaluated_per_launch
+    mfma_achieved = flops / kernel_s / 1e12
+    traffic = 1024.0 * (pmc["WRITE_SIZE"] + 2.0 * pmc["FETCH_SIZE"]) if "WRITE_SIZE" in pmc and "FETCH_SIZE" in pmc else None
+    common = {"traffic": traffic, "flops_per_sample": info.flops_per_sample, "mfma_flops_per_sample": info.mfma_flops_per_sample,
+              "kernel_ms_avg": 1e3 * kernel_s, "mfma_frac": mfma_achieved / MFMA_F16_PEAK_TFLOPS}
+    if activation == "ReLU":
+        return dict({"bound": "mfma", "achieved": mfma_achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mfma_achieved / MFMA_F16_PEAK_TFLOPS}, **common)
+    tps = transcendentals_per_sample(info, activation, rotation_resync)
+    clock, clock_from = NOMINAL_CLOCK_HZ, "nominal"
+    if "GRBM_GUI_ACTIVE" in pmc and "kernel_ms_avg_under_pmc" in pmc:
+        clock, clock_from = pmc["GRBM_GUI_ACTIVE"] / 8.0 / (1e-3 * pmc["kernel_ms_avg_under_pmc"]), pmc["file"]
+    achieved = tps * evaluated_per_launch / kernel_s / 1e12               # T lane-operations / s
+    peak = NUM_SIMDS * TRANS_LANES_PER_CLOCK * clock / 1e12
+    r = dict({"bound": "valu_trans", "achieved": achieved, "peak": peak, "unit": "Ttrans/s", "frac": achieved / peak,
+              "frac_at_quarter_rate": achieved / (peak * 4.0 / TRANS_LANES_PER_CLOCK), "transcendentals_per_sample": tps,
+              "lanes_per_clock_and_simd": TRANS_LANES_PER_CLOCK, "clock_ghz": clock / 1e9, "clock_from": clock_from}, **common)
+    if "SQ_INSTS_VALU_TRANS_F32" in pmc:
+        r["pmc_trans_insts_per_launch"] = pmc["SQ_INSTS_VALU_TRANS_F32"]   # wave instructions; x 64 lanes / evaluated samples ~ tps
+    return r
 
 
 def dist_world_size(distributed):
@@ -287,6 +326,9 @@ def main():
     ap.add_argument("--early-out", action="store_true", help="as-shipped DVR with alpha early-out")
     ap.add_argument("--no-twin", action="store_true", help="skip the second-activation twin run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1 only: take the multi-GPU route (compact stripes, all_gather_into_tensor on the collective's stream, assemble) "
+                         "with a one-rank process group, so that the RCCL path runs on a one-GPU box")
     ap.add_argument("--grid-volume", action="store_true",
                     help="side benchmark (not the headline metric): DVR of a dense grid volume, BASELINE.json configs[0]; one JSON line")
     ap.add_argument("--grid-res", type=int, default=256)
@@ -305,6 +347,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    collective = distributed or args.force_collective
+    if args.force_collective and world != 1:
+        raise SystemExit("bench.py: --force-collective is the one-GPU mode of the multi-GPU route")
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -316,9 +361,13 @@ def main():
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible, one per rank is required" % (world, torch.cuda.device_count()))
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
-    if distributed:
+    if collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not distributed:  # a one-rank group of our own
+            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:
@@ -332,8 +381,17 @@ def main():
     time_keys = TIME_KEYS.get(args.config, 1)
     vn, net = make_network(volnet_io, capi, cfg, args.activation, time_keys)
     info = net.info()
-    runner = Runner(capi, net, cfg, rank, world, args.early_out, time_keys)
-    dt, kernel_ms, evaluated, executed = timed_run(runner, args.steps, args.warmup, distributed, args.spinup_ms)
+    runner = Runner(capi, net, cfg, rank, world, args.early_out, time_keys, force_collective=args.force_collective)
+    dt, kernel_ms, evaluated, executed = timed_run(runner, args.steps, args.warmup, collective, args.spinup_ms)
+    plan = runner.pipeline.scenes[0].last_render_info()
+    gather_ms = [a.elapsed_time(b) for a, b in runner.pipeline.gather_events]
+    # per-rank decomposition of a frame (HIP events on the render / collective streams of every rank): rank 0 prints all of them
+    per_rank = None
+    if collective:
+        mine = torch.tensor([sum(kernel_ms) / max(1, len(kernel_ms)), sum(gather_ms) / max(1, len(gather_ms)), 1e3 * dt / args.steps], dtype=torch.float64, device="cuda")
+        allr = torch.zeros((world, 3), dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(allr.view(-1), mine)
+        per_rank = [{"rank": r, "render_ms": float(allr[r, 0]), "gather_ms": float(allr[r, 1]), "frame_period_ms": float(allr[r, 2])} for r in range(world)]
     if distributed:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -344,7 +402,7 @@ def main():
         evaluated, executed = int(c[0]), int(c[1])
 
     frame_check = None
-    if distributed:  # untimed: the gathered stripes of the last frame equal a whole-frame render on this rank
+    if collective:  # untimed: the gathered stripes of the last frame equal a whole-frame render on this rank
         last = args.warmup + args.steps - 1
         gathered = runner.assemble(last % runner.pipeline.buffers)
         yaw = 2 * math.pi * (last % 64) / 64
@@ -355,40 +413,48 @@ def main():
         torch.cuda.synchronize()
         from fvsrn_amd import tiles
         frame_check = tiles.frames_match(full, gathered)
+        if args.force_collective:  # one rank, one launch shape: the assembled frame is the same render -- bitwise
+            frame_check = frame_check and bool(torch.equal(torch.nan_to_num(full, nan=-7.0), torch.nan_to_num(gathered, nan=-7.0)))
         ok = torch.tensor([1 if frame_check else 0], device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         frame_check = bool(ok.item())
 
+    def tag_of(activation):  # the name tools/pmc_profile.sh files the PMC summary of (config, activation) under
+        return args.config if activation == "ReLU" else args.config.replace("_1024x512", "_%s_1024x512" % activation.lower())
+
     twin = None
-    if not args.no_twin and not distributed:
+    if not args.no_twin and not collective:
         other = "SnakeAlt" if args.activation == "ReLU" else "ReLU"
         _, net2 = make_network(volnet_io, capi, cfg, other, time_keys)
         r2 = Runner(capi, net2, cfg, rank, world, args.early_out, time_keys)
         dt2, k2, ev2, ex2 = timed_run(r2, args.steps, args.warmup, False)  # the same step counts as the primary
+        plan2 = r2.pipeline.scenes[0].last_render_info()
         twin = {"activation": other, "value": ev2 / dt2, "unit": "samples/s", "ms_per_step": 1e3 * dt2 / args.steps, "steps": args.steps,
                 "kernel": net2.kernel_name(True),
-                "mfma_frac": (ev2 * info.flops_per_sample / (sum(k2) * 1e-3)) / (MFMA_F16_PEAK_TFLOPS * 1e12)}
+                "roofline": roofline(net2.info(), other, ev2 / args.steps, sum(k2) * 1e-3 / len(k2), tag_of(other), plan2["rotation_resync"])}
+        twin["mfma_frac"] = twin["roofline"]["mfma_frac"]
 
     exact = None
-    if not args.no_twin and not distributed:
+    if not args.no_twin and not collective:
         # the same frames with exact Fourier features at every step (FVSRN_OPT_FOURIER_RESYNC = 1: the reference's per-sample
         # arithmetic, positions rounded to fp16 at every sample, no feature rotation)
         r3 = Runner(capi, net, cfg, rank, world, args.early_out, time_keys, scene_options={"fourier_resync": 1})
         dt3, k3, ev3, ex3 = timed_run(r3, args.steps, args.warmup, False)
+        plan3 = r3.pipeline.scenes[0].last_render_info()
         exact = {"option": "FVSRN_OPT_FOURIER_RESYNC=1", "activation": args.activation, "value": ev3 / dt3, "unit": "samples/s",
                  "ms_per_step": 1e3 * dt3 / args.steps, "steps": args.steps,
-                 "mfma_frac": (ev3 * info.flops_per_sample / (sum(k3) * 1e-3)) / (MFMA_F16_PEAK_TFLOPS * 1e12)}
+                 "roofline": roofline(info, args.activation, ev3 / args.steps, sum(k3) * 1e-3 / len(k3), "no_profile_of_this_option", plan3["rotation_resync"])}
+        exact["mfma_frac"] = exact["roofline"]["mfma_frac"]
 
     if rank == 0:
         _, _, _, W, H, steps = cfg
         kernel_s = sum(kernel_ms) * 1e-3 / len(kernel_ms)             # average launch duration on this rank
         if runner.pipelined:  # consecutive frames overlap on two streams: the event pairs overlap too, use the frame period
             kernel_s = dt / args.steps
-        flops_per_launch = info.flops_per_sample * (evaluated / world) / args.steps  # algorithmic, SURVEY 8(d)
-        achieved = flops_per_launch / kernel_s / 1e12
+        rl = roofline(info, args.activation, (evaluated / world) / args.steps, kernel_s, tag_of(args.activation), plan["rotation_resync"], world)
         out = {
             "metric": "srn_samples_per_s", "value": evaluated / dt, "unit": "samples/s", "n_gpus": world,
-            "world_size": dist_world_size(distributed), "backend": backend if distributed else None,
+            "world_size": dist_world_size(collective), "backend": backend if collective else None,
             "steps": args.steps, "warmup": args.warmup, "spinup_ms": args.spinup_ms, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "%s: %dx%d, %d steps/ray, %d-wide x %d-layer fp16 SRN%s, %s, density:direct + Identity TF, "
@@ -401,11 +467,15 @@ def main():
             "nominal_samples_per_frame": W * H * steps,
             "wave_executed_samples_per_frame": executed / args.steps,
             "kernel": net.kernel_name(True),
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": pmc_traffic(args.config) if world == 1 else None,
-                         "flops_per_sample": info.flops_per_sample, "mfma_flops_per_sample": info.mfma_flops_per_sample,
-                         "kernel_ms_avg": 1e3 * kernel_s},
+            "roofline": rl,
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+            out["stripe_launches"] = {"persistent": bool(runner.pipeline.persistent_stripes), "hw_streams_concurrent": runner.pipeline.hw_streams_concurrent,
+                                      "needs": "GPU_MAX_HW_QUEUES >= 8 in the environment before the process starts (set by bench.py / launch_ranks)",
+                                      "persistent_reserve": "1/16 of the workgroup slots (FVSRN_OPT_PERSISTENT_RESERVE, automatic)"}
+        if args.force_collective:
+            out["force_collective"] = True
         if frame_check is not None:
             out["gathered_frame_matches_single_gpu_frame"] = frame_check
         if twin:
@@ -415,7 +485,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args.activation)
         print(json.dumps(out))
-    if distributed:
+    if collective:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

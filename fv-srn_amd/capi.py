@@ -76,6 +76,7 @@ SYMBOLS = [
     ("fvsrn_last_error", C.c_char_p, []),
     ("fvsrn_version", C.c_char_p, []),
     ("fvsrn_device_count", _I, []),
+    ("fvsrn_probe_stream_concurrency", _I, [_I, _I, _FP]),
     ("fvsrn_network_create_from_volnet", _I, [_VP, _SZ, C.POINTER(_VP)]),
     ("fvsrn_network_create", _I, [C.POINTER(_VP)]),
     ("fvsrn_network_destroy", None, [_VP]),
@@ -163,6 +164,13 @@ def _fptr(a: np.ndarray):
 
 def device_count() -> int:
     return lib().fvsrn_device_count()
+
+
+def probe_stream_concurrency(streams: int = 6, microseconds: int = 300) -> float:
+    """How many of `streams` streams of this process run side by side (fvsrn_probe_stream_concurrency): ~min(streams, GPU_MAX_HW_QUEUES)."""
+    out = C.c_float(0.0)
+    _check(lib().fvsrn_probe_stream_concurrency(int(streams), int(microseconds), C.byref(out)))
+    return float(out.value)
 
 
 def _torch_ptr(t, dtype_name: str, what: str) -> int:

@@ -177,6 +177,16 @@ struct StreamOrder {
                 r.pending = true;
                 return;
             }
+        // a stream handle seen for the first time: drop the entries of streams whose last read has completed (a caller that creates a
+        // stream per frame would otherwise grow this list by one event per stream)
+        if (readers.size() >= 8) {
+            size_t keep = 0;
+            for (Reader& r : readers) {
+                if (r.pending && hipEventQuery(r.done) == hipErrorNotReady) readers[keep++] = r;
+                else (void)hipEventDestroy(r.done);
+            }
+            readers.resize(keep);
+        }
         Reader r{s, nullptr, true};
         HIP_CHECK(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
         HIP_CHECK(hipEventRecord(r.done, s));
@@ -361,6 +371,10 @@ struct fvsrn_network {
     WorkingGrid workGrid[2];
     int numWorkGrids = 1, curWorkGrid = 0;
     StreamOrder imagesOrder;  // weight images, ensemble key frames, decode coefficients: written at first use
+    // streams that have launched kernels reading the images (handles only: recording an event behind every launch cost 3 % of a 0.3 ms
+    // frame, r03): a re-pack of a live network waits for THESE streams, not for the device (hipDeviceSynchronize stalled the
+    // collective's and every other pipeline's streams, and is illegal during stream capture)
+    std::vector<hipStream_t> imageReaders;
     KeyframeStore keyStore;  // time key frames
     const void* scaledImage = nullptr;
     const void* curvatureImage = nullptr;
@@ -428,9 +442,15 @@ struct fvsrn_network {
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         numCUs = prop.multiProcessorCount;
-        // a changed network (rare): kernels on any stream may still read the old images -- wait for the device instead of recording an
-        // event behind every launch (r03: that record cost 3 % of a 0.3 ms frame)
-        if (dLds.ptr) HIP_CHECK(hipDeviceSynchronize());
+        // a changed network (rare): kernels on the streams that used it may still read the old images -- wait for exactly those streams
+        // (no event is recorded behind the launches: that record cost 3 % of a 0.3 ms frame, r03)
+        if (dLds.ptr) {
+            bool unknown = imageReaders.size() >= 64;  // (the list is bounded: beyond it, or for a stream that no longer exists, the device)
+            for (hipStream_t rs : imageReaders)
+                if (rs != stream && hipStreamSynchronize(rs) != hipSuccess) { (void)hipGetLastError(); unknown = true; }
+            if (unknown) HIP_CHECK(hipDeviceSynchronize());
+        }
+        imageReaders.clear();
         dLds.ensure(packed.ldsImage.size());
         HIP_CHECK(hipMemcpyAsync(dLds.ptr, packed.ldsImage.data(), packed.ldsImage.size(), hipMemcpyHostToDevice, stream));
         packed.params.ldsImage = dLds.ptr;
@@ -532,6 +552,9 @@ struct fvsrn_network {
     // Brackets of every kernel launch that reads the network's device state on `stream`
     void beginUse(hipStream_t stream) {
         imagesOrder.beginRead(stream);
+        if (std::find(imageReaders.begin(), imageReaders.end(), stream) == imageReaders.end()) {
+            if (imageReaders.size() < 64) imageReaders.push_back(stream);  // (bounded: a full list makes the next re-pack wait for the device)
+        }
         if (packed.keys.records) workGrid[curWorkGrid].order.beginRead(stream);
     }
     void endUse(hipStream_t stream) {
@@ -544,6 +567,7 @@ struct fvsrn_network {
         dLdsCurvature.release();
         for (WorkingGrid& w : workGrid) { w.a.release(); w.b.release(); w.order.release(); }
         imagesOrder.release();
+        imageReaders.clear();
         keyStore.release();
         dKeysEns.release();
         dCoeffs.release();
@@ -682,6 +706,39 @@ int fvsrn_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int fvsrn_probe_stream_concurrency(int streams, int microseconds, float* concurrent) {
+    if (!concurrent || streams < 2 || streams > 16 || microseconds < 10 || microseconds > 100000)
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "2 .. 16 streams, 10 .. 100000 microseconds, a result pointer");
+    if (fvsrn_device_count() == 0) return fail(FVSRN_ERR_NO_DEVICE, "no HIP device");
+    std::vector<hipStream_t> st(size_t(streams), nullptr);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    for (auto& s : st) ok = ok && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
+    float ms = 0.f;
+    if (ok) {
+        // warm-up (module load, queue creation), then the timed round: the events sit on the first stream, which every other stream
+        // is ordered against through events of its own
+        for (int round = 0; round < 2 && ok; ++round) {
+            ok = hipDeviceSynchronize() == hipSuccess && hipEventRecord(e0, st[0]) == hipSuccess;
+            std::vector<hipEvent_t> done(size_t(streams), nullptr);
+            for (int i = 0; i < streams && ok; ++i) {
+                if (i > 0) ok = hipStreamWaitEvent(st[size_t(i)], e0, 0) == hipSuccess;
+                ok = ok && launch_spin((long long)microseconds * 100, st[size_t(i)]) == hipSuccess;
+                if (i > 0) ok = ok && hipEventCreateWithFlags(&done[size_t(i)], hipEventDisableTiming) == hipSuccess && hipEventRecord(done[size_t(i)], st[size_t(i)]) == hipSuccess &&
+                                hipStreamWaitEvent(st[0], done[size_t(i)], 0) == hipSuccess;
+            }
+            ok = ok && hipEventRecord(e1, st[0]) == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+            for (auto e : done) if (e) (void)hipEventDestroy(e);
+        }
+    }
+    for (auto s : st) if (s) (void)hipStreamDestroy(s);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (!ok || ms <= 0.f) return fail(FVSRN_ERR_DEVICE, "stream concurrency probe failed");
+    *concurrent = float(streams) * float(microseconds) * 1e-3f / ms;
+    return FVSRN_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- network
@@ -942,7 +999,8 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
             const VariantKey& k = net->keyScaled;
             const bool scalarNet = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
             const bool colourNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
-            const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && P.gridK == 1 && P.bias0Folded ? 1 : 2);
+            const bool folded = P.bias0Folded && (!net->scaledImage || net->packed.scaledBias0Exact);
+            const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && P.gridK == 1 && folded ? 1 : 2);
             if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !P.noFourier && !P.fourierNeedsFractPlain && !P.fourierClampPos && (scalarNet || colourNet) &&
                 render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1, smallGrid))
                 name = "render_small_kernel<act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "," + std::to_string(P.numLayers) +
@@ -1032,6 +1090,7 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
             if (net->scaledImage && !adjoint) {
                 evalKey = net->keyScaled;
                 a.P.ldsImage = net->scaledImage;
+                if (!net->packed.scaledBias0Exact) a.P.bias0Folded = 0;  // (a residue of the folded bias sits in the fp32 block: pack.cpp)
                 a.P.reluClamp = net->keyScaled.act == ACT_RELU01 ? 1 : 0;
                 if (net->keyScaled.act == ACT_RELU01) {  // two launches, see kernels.hpp (eval_batch_deferred); stream-ordered scratch per call
                     evalTodo = g_temporaries.alloc(net->device, (1 + (n + 63) / 64) * sizeof(unsigned), s);
@@ -1324,6 +1383,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             if (net->scaledImage && !a.shaded) {  // ReLU network: image with activations scaled into [0,1] (pack.cpp)
                 a.P.ldsImage = net->scaledImage;
                 a.P.reluClamp = net->keyScaled.act == ACT_RELU01 ? 1 : 0;
+                if (!net->packed.scaledBias0Exact) a.P.bias0Folded = 0;  // (a residue of the folded bias sits in the fp32 block: pack.cpp)
             }
             SceneParams& S = a.S;
             fillSceneParams(scene, d, width, height, S);
@@ -1341,7 +1401,9 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             size_t lds = size_t(a.P.ldsBytes) + ((tfFloats + 3) & ~size_t(3)) * 4;
             S.tfLdsFloats = int((tfFloats + 3) & ~size_t(3));
             const Options& O = scene->opts;
-            const bool persistent = O[FVSRN_OPT_PERSISTENT] >= 0 ? O[FVSRN_OPT_PERSISTENT] != 0 : true;
+            // automatic: whole frames persistent; the stripes of a multi-GPU frame in bounded waves (below) unless the caller opts in --
+            // tiles.StripeRenderer does after it has MEASURED that the process's streams really run side by side (fvsrn_probe_stream_concurrency)
+            const bool persistent = O[FVSRN_OPT_PERSISTENT] >= 0 ? O[FVSRN_OPT_PERSISTENT] != 0 : stripeWorld <= 1;
             int wpb = wavesPerBlockFor(lds, O);
             // Small networks in registers (render_small_kernel, kernels.hpp): 32-wide Fourier-only scalar network with at most
             // three C->C layers, phases inside the v_cos domain, a transfer function, no shading.  FVSRN_SMALL_KERNEL=0: off.
@@ -1417,7 +1479,10 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             // FOUR hardware queues for all streams of a process (GPU_MAX_HW_QUEUES: the comm stream shared a queue with a render stream);
             // with eight, a rank's share at world 8 runs at 97 - 98 % of frame / world persistent against 86 % with bounded waves
             // (profiles/r03/stripe_pipeline_r03.md).  Since a real collective may need more registers than a launch leaves, stripe
-            // launches keep 1/16 of the workgroup slots free (FVSRN_OPT_PERSISTENT_RESERVE).
+            // launches keep 1/16 of the workgroup slots free (FVSRN_OPT_PERSISTENT_RESERVE).  r04: that gain is a one-GPU
+            // emulation and depends on a process setting the library cannot make (GPU_MAX_HW_QUEUES is read when HIP starts; with four
+            // queues persistent stripes measured 75 - 87 % against 82 - 90 % bounded), so the AUTOMATIC choice for stripes is bounded waves
+            // again and persistent stripes are an opt-in (FVSRN_OPT_PERSISTENT = 1).
             S.unitQuota = 0;
             if (persistent) {
                 if (perCU > 0 && grid > resident) {

@@ -343,4 +343,16 @@ hipError_t launch_render(const VariantKey& k, const RenderArgs& a, unsigned grid
     return hipErrorInvalidDeviceFunction;
 }
 
+// fvsrn_probe_stream_concurrency: one wave that spins for `ticks` of the 100 MHz wall clock
+__global__ void spin_kernel(long long ticks, unsigned* sink) {
+    const long long t0 = wall_clock64();
+    unsigned x = threadIdx.x;
+    while (wall_clock64() - t0 < ticks) x = x * 1664525u + 1013904223u;
+    if (x == 0xdeadbeefu && sink) *sink = x;
+}
+hipError_t launch_spin(long long ticks, hipStream_t s) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, ticks, static_cast<unsigned*>(nullptr));
+    return hipGetLastError();
+}
+
 }  // namespace fvsrn

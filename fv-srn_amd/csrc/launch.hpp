@@ -84,6 +84,7 @@ hipError_t launch_extract_color(const ExtractParams& p, hipStream_t s);
 
 // front-to-back composite of the depth segments of a render (kernels.hpp): partial [K][8][plane] raw accumulators ->
 // out [8][plane] in the layout of ImageEvaluatorSimpleKernel (normal and depth finished like :100-124)
+hipError_t launch_spin(long long ticks, hipStream_t s);  // one wave spinning for `ticks` x 10 ns (fvsrn_probe_stream_concurrency)
 hipError_t launch_composite(const float* partial, float* out, int segments, unsigned long long plane, const SceneParams& S,
                             hipStream_t s);
 

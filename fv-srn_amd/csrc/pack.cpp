@@ -291,7 +291,11 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
     // foldExp != INT_MIN (SnakeAlt with b = 1/(2p) = 2^foldExp, see ACT_SNAKEALT0): every layer behind an activation takes
     // W' = b W and b' = bias + b * sum_j W_j (fp32), the activation itself leaves out its affine part
     // outShift: the last layer's C-operand rows 4g + o carry output o + outShift (4: the two curvature outputs, see ldsImageCurvature)
-    auto packLayers = [&](std::vector<char>& img, const std::vector<int>* exps, int foldExp = kNoFold, int outShift = 0) {
+    // returns whether the folded first-layer bias (foldBias0) is EXACT in this image: the bias is an fp16 value, but 2^kW x bias may leave the
+    // normal range of fp16 in the [0,1]-scaled ReLU image; what the fp16 weight column cannot hold stays in the fp32 bias block of
+    // layer 0 (zero as a rule), and an image with such a residue is not run by the register-resident latent-chunk kernel, which drops that block
+    auto packLayers = [&](std::vector<char>& img, const std::vector<int>* exps, int foldExp = kNoFold, int outShift = 0) -> bool {
+        bool bias0Exact = true;
         float* bias = reinterpret_cast<float*>(img.data() + np.offBias);
         for (int l = 0; l < NL; ++l) {
             const Layer& L = net.hidden[size_t(L0 + l)];
@@ -329,7 +333,11 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
                     for (int j = 0; j < L.channelsIn; ++j) sum += double(half_bits_to_float(L.weights[size_t(r) * L.channelsIn + j]));
                     b += std::ldexp(sum, foldExp);
                 }
-                bias[size_t(l) * 32 * MT + r] = (l == 0 && foldBias0) ? 0.f : float(b);
+                if (l == 0 && foldBias0) {  // b = 2^kB x bias exactly; the weight column holds its fp16 rounding (kW == kB for l = 0)
+                    b -= double(half_bits_to_float(scaleHalf(L.bias[size_t(r)], kW)));
+                    if (b != 0.0) bias0Exact = false;
+                }
+                bias[size_t(l) * 32 * MT + r] = float(b);
             }
         }
         // Last layer (C -> 1|4): one v_mfma_f32_16x16x32_f16 per K step and tile -- 16 output rows instead of 32 halve
@@ -372,8 +380,9 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
             }
             bl[r] = float(b);
         }
+        return bias0Exact;
     };
-    packLayers(P.ldsImage, nullptr);
+    packLayers(P.ldsImage, nullptr);  // (plain image: kW = 0, the folded bias is exact)
     // densitycurvature networks: a second image whose last layer computes outputs 4 and 5 (the two curvature values) in rows 0 and 1;
     // only IVolumeInterpolation::evaluateWithGradientAndCurvature reads them (fvsrn_evaluate_points, FVSRN_EVAL_WITH_PREDICTED_CURVATURE)
     P.ldsImageCurvature.clear();
@@ -408,7 +417,7 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
             }
         if (ok) {
             P.ldsImageScaled = P.ldsImage;  // phase fragments, first layer: shared
-            packLayers(P.ldsImageScaled, nullptr, foldExp);
+            P.scaledBias0Exact = packLayers(P.ldsImageScaled, nullptr, foldExp);
             P.scaledAct = ACT_SNAKEALT0;
         }
     }
@@ -446,7 +455,7 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
         }
         if (ok) {
             P.ldsImageScaled = P.ldsImage;  // phase fragments are shared
-            packLayers(P.ldsImageScaled, &exps);
+            P.scaledBias0Exact = packLayers(P.ldsImageScaled, &exps);
             P.reluExponents = exps;
             P.scaledAct = ACT_RELU01;
         }

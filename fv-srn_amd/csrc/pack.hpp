@@ -27,6 +27,7 @@ struct PackedNetwork {
     std::vector<char> ldsImage;  // see device_params.hpp
     std::vector<char> ldsImageScaled;  // second image for the renderer (empty if not applicable): ReLU networks with activations scaled
                                        // into [0,1], SnakeAlt networks with the 1/(2p) factor folded into the next layer
+    bool scaledBias0Exact = true;      // ldsImageScaled: the folded first-layer bias is exact in fp16 (else: residue in the fp32 bias block, no resident SGRID kernel)
     int scaledAct = -1;                // ACT_RELU01 / ACT_SNAKEALT0: the kernel variant that goes with ldsImageScaled
     std::vector<char> ldsImageCurvature;  // densitycurvature networks: the plain image with the last layer computing outputs 4, 5 in rows 0, 1
     std::vector<int> reluExponents;    // e_l of the scaled image

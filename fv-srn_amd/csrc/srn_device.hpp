@@ -34,14 +34,12 @@ typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int lane_id() { return int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); }
 
-// OPEN (r03, tools/dev/determinism.py, profiles/r03/nondeterminism_r03.md): kernels with a latent grid are not bit-identical from launch
-// to launch -- in one launch out of twenty (register-resident 32-wide kernel) to every launch (render_stripe_kernel at 64 channels) the 16
-// rays of lanes 48-63 of ONE tile come out 1e-7 ... 2e-4 off, i.e. samples 16-31 of the wave's second sample tile.  No memory is involved
-// (it happens with the gathers compiled out), no DOT instruction, no inline assembly, and not this exchange (ds_bpermute instead of
-// v_permlane32_swap: the same); r03 first blamed concurrent scratch use for it.  What moved the rate most is the instruction order around
-// the exchange: with the operands of a group of swaps put through an `s_nop 4` (below) the worst kernel went from every launch to one in
-// thirty.  Not understood; within the parity tolerance (3e-3) by a factor of ten.
-#define FVSRN_SWAP_GUARD_2(a, b) asm volatile("s_nop 4" : "+v"(a), "+v"(b))
+// Hardware erratum found in r04 (profiles/r04/nondeterminism_r04.md, tools/microbench/r04_pk_opsel_sweep.hip): a packed-fp32 instruction
+// (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) whose LOW pass selects src0's low and src1's HIGH register -- op_sel:[0,1] -- reads one operand
+// as 0 in lanes 48-63 while another wave of the SIMD has MFMAs in flight.  hipcc emits that selection when it vectorises scalar fp32 code
+// (the latent-grid tap arithmetic below): the launch-to-launch differences of the latent-grid kernels that r03 spaced out with s_nops.  The
+// build rewrites every such instruction with its two (commuting) sources exchanged (tools/fix_pk_opsel.py via hipcc_fixed.sh); hand-written
+// packed-fp32 assembly in this file uses the selections measured clean ([0,0], [1,0], [1,1]); a CPU test scans the built objects.
 typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint2_t lane_half_swap(unsigned a, unsigned b) {
     auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
@@ -50,9 +48,8 @@ __device__ __forceinline__ uint2_t lane_half_swap(unsigned a, unsigned b) {
 
 // own value v (one per lane = per sample) -> value of sample (lane&31) of tile 0 / tile 1
 __device__ __forceinline__ void tile_bcast(float v, float& t0, float& t1) {
-    unsigned u = __float_as_uint(v), u2 = u;
-    FVSRN_SWAP_GUARD_2(u, u2);
-    auto r = lane_half_swap(u, u2);
+    const unsigned u = __float_as_uint(v);
+    auto r = lane_half_swap(u, u);
     t0 = __uint_as_float(r[0]);
     t1 = __uint_as_float(r[1]);
 }
@@ -193,54 +190,26 @@ struct GridTap {
     unsigned wlo[4];  // their fp16 rounding residuals (only the BYTE_GAUSSIAN path, whose erfinv amplifies errors, uses them)
 };
 
-// FVSRN_TAP_NOPS (bit mask of the seven stages below, default 7 = the first three): `s_nop 4` between stages of the tap arithmetic.
-// Empirical fix for the launch-to-launch differences described at lane_half_swap() -- with the first three (or the last four, or all)
-// stages separated, 0 of 29 launches differ in every kernel of tools/dev/determinism.py, twice in a row; without, up to every launch.
-// Which instruction pair it is that needs the distance is not known (profiles/r03/nondeterminism_r03.md); 15 cycles per wave step.
-#ifndef FVSRN_TAP_NOPS
-#define FVSRN_TAP_NOPS 7
-#endif
 __device__ __forceinline__ GridTap grid_tap(const NetParams& P, float px, float py, float pz) {
     // Record indices in fp32 (exact below 2^24 records, which pack.cpp guarantees): clamps are v_med3_f32, the row / record arithmetic
     // is 8 v_fma_f32 -- the integer form needed 10 min / max, 3 v_mul_lo_u32 and 4 v_mad_u64_u32 (quarter rate) per sample.
     float fx = fmaf(px, P.gridXf, -0.5f), fy = fmaf(py, P.gridYf, -0.5f), fz = fmaf(pz, P.gridZf, -0.5f);
-#if 1
-    if constexpr ((FVSRN_TAP_NOPS & 1) != 0) asm volatile("s_nop 4" : "+v"(fx), "+v"(fy), "+v"(fz));
-#endif
     float x0f = floorf(fx), y0f = floorf(fy), z0f = floorf(fz);
-#if 1
-    if constexpr ((FVSRN_TAP_NOPS & 2) != 0) asm volatile("s_nop 4" : "+v"(x0f), "+v"(y0f), "+v"(z0f));
-#endif
     float wx = fx - x0f, wy = fy - y0f, wz = fz - z0f;
-#if 1
-    if constexpr ((FVSRN_TAP_NOPS & 4) != 0) asm volatile("s_nop 4" : "+v"(wx), "+v"(wy), "+v"(wz));
-#endif
     float xi = __builtin_amdgcn_fmed3f(x0f + 1.f, 0.f, P.gridXf);  // record index: x-clamping is baked into the records
     const float ym = P.gridYf - 1.f, zm = P.gridZf - 1.f;
     float y0 = __builtin_amdgcn_fmed3f(y0f, 0.f, ym), y1 = __builtin_amdgcn_fmed3f(y0f + 1.f, 0.f, ym);
     float z0 = __builtin_amdgcn_fmed3f(z0f, 0.f, zm), z1 = __builtin_amdgcn_fmed3f(z0f + 1.f, 0.f, zm);
-#if 1
-    if constexpr ((FVSRN_TAP_NOPS & 8) != 0) asm volatile("s_nop 4" : "+v"(xi), "+v"(y0), "+v"(y1), "+v"(z0), "+v"(z1));
-#endif
     const float rowLen = P.gridXf + 1.f;                     // records per (z, y) row
     const unsigned rec = unsigned(P.gridC) * 4u;             // bytes per record: G channels x 2 x fp16
     float r00 = fmaf(z0, P.gridYf, y0), r01 = fmaf(z0, P.gridYf, y1), r10 = fmaf(z1, P.gridYf, y0), r11 = fmaf(z1, P.gridYf, y1);
-#if 1
-    if constexpr ((FVSRN_TAP_NOPS & 16) != 0) asm volatile("s_nop 4" : "+v"(r00), "+v"(r01), "+v"(r10), "+v"(r11));
-#endif
     GridTap t;
     t.off[0] = __umul24(unsigned(fmaf(r00, rowLen, xi)), rec);
     t.off[1] = __umul24(unsigned(fmaf(r01, rowLen, xi)), rec);
     t.off[2] = __umul24(unsigned(fmaf(r10, rowLen, xi)), rec);
     t.off[3] = __umul24(unsigned(fmaf(r11, rowLen, xi)), rec);
-#if 1
-    if constexpr ((FVSRN_TAP_NOPS & 32) != 0) asm volatile("s_nop 4" : "+v"(t.off[0]), "+v"(t.off[1]), "+v"(t.off[2]), "+v"(t.off[3]));
-#endif
     float ux = 1.f - wx, uy = 1.f - wy, uz = 1.f - wz;
     float w4[4] = {uz * uy, uz * wy, wz * uy, wz * wy};
-#if 1
-    if constexpr ((FVSRN_TAP_NOPS & 64) != 0) asm volatile("s_nop 4" : "+v"(ux), "+v"(w4[0]), "+v"(w4[1]), "+v"(w4[2]), "+v"(w4[3]));
-#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float2_t v = {w4[k] * ux, w4[k] * wx};
@@ -266,11 +235,6 @@ __device__ __forceinline__ void grid_tap_bcast(const GridTap& own, GridTap& t0, 
         w0[k] = own.w[k]; w1[k] = own.w[k];
         l0[k] = own.wlo[k]; l1[k] = own.wlo[k];
     }
-    // one guard for the whole group (see lane_half_swap): every operand of the swaps below passes through it
-    asm volatile("s_nop 4" : "+v"(o0[0]), "+v"(o0[1]), "+v"(o0[2]), "+v"(o0[3]), "+v"(o1[0]), "+v"(o1[1]), "+v"(o1[2]), "+v"(o1[3]),
-                             "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]), "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]));
-    if constexpr (WITH_LO)
-        asm volatile("s_nop 4" : "+v"(l0[0]), "+v"(l0[1]), "+v"(l0[2]), "+v"(l0[3]), "+v"(l1[0]), "+v"(l1[1]), "+v"(l1[2]), "+v"(l1[3]));
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         auto a = lane_half_swap(o0[k], o1[k]);
@@ -519,7 +483,6 @@ __device__ __forceinline__ void phase_operands(float px, float py, float pz, flo
         const float2_t v = {pp[i], pp[i]};
         pu[i] = pv[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
     }
-    asm volatile("s_nop 4" : "+v"(pu[0]), "+v"(pu[1]), "+v"(pu[2]), "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]));  // (see lane_half_swap)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         auto r = lane_half_swap(pu[i], pv[i]);

@@ -12,6 +12,14 @@ device.  Pixels are independent, so the only exchange step of a frame is assembl
 
 Round-robin stripes (instead of H/world contiguous blocks) balance empty-space rows against dense rows.
 
+Hardware queues.  The pipeline of a rank runs on five streams (two render streams, the collective's, the library's copy stream for key
+frames, the caller's) and ROCm maps all streams of a process onto GPU_MAX_HW_QUEUES hardware queues, FOUR by default: two streams that
+share a queue run in submission order, and the collective of frame i ends up behind the render of frame i + 1 (r03: a rank's share at
+world 8 at 80 % of frame / world instead of 98 %).  The variable is read when the HIP runtime starts, so a library cannot set it: export
+GPU_MAX_HW_QUEUES=8 before the process starts (bench.py and launch_ranks() do that for the processes THEY start).  StripeRenderer measures
+what it got (``hw_streams_concurrent``, fvsrn_probe_stream_concurrency), warns when its streams do not all run side by side, and takes the
+persistent stripe launches that need them only then.
+
 ``StripeRenderer`` is the frame pipeline of one rank: double-buffered local / gathered images, the gather
 of frame i on a communication stream while frame i + 1 renders, consecutive frames on two render streams so that the
 tail of one launch overlaps the head of the next, time-dependent networks included (the C library keeps two working
@@ -26,11 +34,23 @@ import socket
 import subprocess
 import sys
 import time
+import warnings
 from typing import Callable, List, Optional, Sequence
 
 import torch
 
 STRIPE = 16  # default stripe height: two 8-row pixel tiles of a wave
+PIPELINE_STREAMS = 5  # render 0, render 1, collective, key-frame copies, the caller's
+_concurrency = None  # measured once per process
+
+
+def stream_concurrency() -> float:
+    """Streams of this process that run side by side on the current device, measured once (fvsrn_probe_stream_concurrency, 6 streams)."""
+    global _concurrency
+    if _concurrency is None:
+        from . import capi
+        _concurrency = capi.probe_stream_concurrency(PIPELINE_STREAMS + 1, 300)
+    return _concurrency
 
 
 def owned_rows(height: int, stripe: int, rank: int, world: int) -> List[int]:
@@ -99,12 +119,21 @@ class StripeRenderer:
     pipelined  consecutive frames alternate between two scenes on two render streams (default: world > 1).  At world == 1
                the same trick is worth +4 % (r01), but one launch at a time keeps the HIP-event duration of the kernel, the
                rocprofv3 trace and the frame period the same number, which is what bench.py reports there.
-    """
+    force_collective   world == 1 only: take the multi-GPU route anyway -- compact stripe image, ``all_gather_into_tensor`` on the
+               collective's stream, ``assemble`` -- so that the RCCL path executes on a one-GPU box (tests, bench.py --force-collective)
+
+    Attributes after construction: ``hw_streams_concurrent`` (measured, None on the CPU), ``persistent_stripes`` (whether the stripe
+    launches are persistent: only when the process's streams run side by side), ``timings`` (per submitted frame with record=True:
+    (render events, gather events))."""
 
     def __init__(self, net, width: int, height: int, scene_kw: dict, *, rank: int = 0, world: int = 1, stripe: int = STRIPE,
-                 group=None, pipelined: Optional[bool] = None, device: str = "cuda", render: Optional[Callable] = None, streams=None):
+                 group=None, pipelined: Optional[bool] = None, device: str = "cuda", render: Optional[Callable] = None, streams=None,
+                 force_collective: bool = False):
         self.net, self.W, self.H = net, int(width), int(height)
         self.rank, self.world, self.stripe, self.group = int(rank), int(world), int(stripe), group
+        if force_collective and world != 1:
+            raise ValueError("force_collective is the one-GPU test mode of the multi-GPU route (world == 1)")
+        self.collective = world > 1 or bool(force_collective)  # compact stripes + all-gather + assemble
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
         if not self.on_gpu and render is None:
@@ -112,16 +141,19 @@ class StripeRenderer:
         self._render_fn = render
         self.pipelined = (world > 1) if pipelined is None else bool(pipelined)
         self.kernel_events = []
+        self.gather_events = []
         self.frames_submitted = 0
-        if world > 1:
+        self.hw_streams_concurrent = None
+        self.persistent_stripes = False
+        if self.collective:
             check_even_partition(self.H, self.stripe, self.world)
-        self.rows = self.H // self.world if world > 1 else self.H
+        self.rows = self.H // self.world
         # Buffers: two render targets at world 1.  A rank of a multi-GPU frame rotates THREE local / gathered pairs: frame i + 2 then does not wait
         # for the collective of frame i, which may only get onto the chip once the render of frame i + 1 has ended (a collective whose
         # workgroups need more registers than a persistent render launch leaves free) -- with two pairs that wait is a bubble of one
         # collective per frame, with three the collective runs beside the start of the next render.
-        nbuf = self.buffers = 3 if world > 1 else 2
-        if world == 1:
+        nbuf = self.buffers = 3 if self.collective else 2
+        if not self.collective:
             self.outs = [torch.zeros((1, 8, self.H, self.W), dtype=torch.float32, device=self.device) for _ in range(nbuf)]
         else:
             self.local = [torch.zeros((8, self.rows, self.W), dtype=torch.float32, device=self.device) for _ in range(nbuf)]
@@ -132,10 +164,23 @@ class StripeRenderer:
             self.scenes = [capi.Scene(**scene_kw) for _ in range(2 if self.pipelined else 1)]
             # streams = (render stream 0, render stream 1, collective's stream): a caller that builds several pipelines in one process hands
             # the same three to all of them (torch hands out streams from a pool, ROCm maps them onto its hardware queues by creation order)
-            self.comm_stream = (streams[2] if streams else torch.cuda.Stream()) if world > 1 else None
+            self.comm_stream = (streams[2] if streams else torch.cuda.Stream()) if self.collective else None
+            if self.collective and render is None:
+                # persistent stripe launches (97 - 100 % of frame / world at world 8 in the one-GPU emulation of r03 against 82 - 90 % for
+                # bounded waves) need the collective's stream on a hardware queue of its own: measured, not assumed
+                self.hw_streams_concurrent = stream_concurrency()
+                self.persistent_stripes = self.hw_streams_concurrent >= PIPELINE_STREAMS - 0.5
+                if not self.persistent_stripes:
+                    warnings.warn("fvsrn StripeRenderer: only %.1f of the process's streams run side by side (ROCm's default of four hardware "
+                                  "queues?): export GPU_MAX_HW_QUEUES=8 before the process starts; stripe launches stay in bounded waves"
+                                  % self.hw_streams_concurrent, RuntimeWarning, stacklevel=2)
             self.blend_stream = None  # created with the first next_time: key-frame blends of the NEXT frame, beside the current render
             self.render_done = [torch.cuda.Event() for _ in range(nbuf)]
             self.gather_done = [torch.cuda.Event() for _ in range(nbuf)]
+            if self.persistent_stripes:
+                for sc in self.scenes:
+                    if sc.get_option("persistent") < 0:  # (an explicit setting of the caller / the environment stays)
+                        sc.set_option("persistent", 1)
             if self.pipelined:
                 # The first use of a network handle uploads its weight images and key frames on the stream of that call; the
                 # library orders other streams behind it by events (include/fvsrn.h), this untimed frame only keeps the
@@ -147,17 +192,17 @@ class StripeRenderer:
                     st.wait_stream(torch.cuda.current_stream())
         else:
             self.scenes = [dict(scene_kw) for _ in range(2 if self.pipelined else 1)]
-            self.comm_stream = _HostStream() if world > 1 else None
+            self.comm_stream = _HostStream() if self.collective else None
             self.render_done = [_HostEvent() for _ in range(nbuf)]
             self.gather_done = [_HostEvent() for _ in range(nbuf)]
             self.render_streams = [_HostStream(), _HostStream()]
 
     # ---------------------------------------------------------------------------------------------------------------
     def _render(self, scene, b: int, stats):
-        out = self.outs[b] if self.world == 1 else self.local[b]
+        out = self.local[b] if self.collective else self.outs[b]
         if self._render_fn is not None:
             self._render_fn(scene, out, self.rank, self.world, self.stripe)
-        elif self.world == 1:
+        elif not self.collective:
             scene.render(self.net, self.W, self.H, out=out, stats=stats)
         else:
             self._capi.render_stripes(scene, self.net, self.W, self.H, self.stripe, self.rank, self.world, out=out, stats=stats)
@@ -185,7 +230,8 @@ class StripeRenderer:
             scene.clear()
             scene.update(scene_kw)
             stream = self.render_streams[r]
-        if time is not None and (time, ensemble) != getattr(self, "_prepared", None):
+        prepared = getattr(self, "_prepared", None)
+        if time is not None and not (prepared is not None and abs(prepared[0] - time) <= 1e-6 * max(1.0, abs(time)) and prepared[1] == ensemble):
             # key frames are resident (or streamed by the library's copy stream); this only marks the working grid dirty, the
             # blend into the grid the other frame in flight does NOT read is enqueued by the render call below
             self.net.set_time_and_ensemble(time, ensemble)
@@ -194,10 +240,10 @@ class StripeRenderer:
             if record and self.on_gpu:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            if self.world > 1:
+            if self.collective:
                 stream.wait_event(self.gather_done[b])  # buffer b is free again
             self._render(scene, b, stats)
-            if self.world > 1:
+            if self.collective:
                 self.render_done[b].record()
             if record and self.on_gpu:
                 e1.record()
@@ -209,10 +255,16 @@ class StripeRenderer:
             self.net.set_time_and_ensemble(next_time, ensemble)
             self.net.prepare(stream=self.blend_stream.cuda_stream)
             self._prepared = (next_time, ensemble)
-        if self.world > 1 and gather:
+        if self.collective and gather:
             with self._stream_ctx(self.comm_stream):  # gather(frame i) overlaps render(frame i + 1)
                 self.comm_stream.wait_event(self.render_done[b])
+                if record and self.on_gpu:
+                    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    g0.record()
                 dist.all_gather_into_tensor(self.gathered[b].view(self.world * 8, -1, self.W), self.local[b], group=self.group)
+                if record and self.on_gpu:
+                    g1.record()
+                    self.gather_events.append((g0, g1))
                 self.gather_done[b].record()
         self.frames_submitted += 1
         return b
@@ -225,7 +277,7 @@ class StripeRenderer:
         if self.pipelined:
             for st in self.render_streams:
                 cur.wait_stream(st)
-        if self.world > 1:
+        if self.collective:
             cur.wait_stream(self.comm_stream)
         if self.blend_stream is not None:
             cur.wait_stream(self.blend_stream)
@@ -233,7 +285,7 @@ class StripeRenderer:
     def frame(self, b: int = 0) -> torch.Tensor:
         """(1, 8, H, W) image of buffer b: the render target itself on one GPU, the gathered stripes put back in image order
         (a view + one permuting copy) otherwise."""
-        if self.world == 1:
+        if not self.collective:
             return self.outs[b]
         return assemble(self.gathered[b], self.H, self.stripe)
 
@@ -274,7 +326,7 @@ def launch_ranks(n: int, argv: Sequence[str], script: Optional[str] = None, chil
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
-                   GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "8"))  # (see __init__.py)
+                   GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "8"))  # (module docstring: read when HIP starts in the child)
         procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
     try:
         out0, _ = procs[0].communicate(timeout=timeout)

@@ -83,6 +83,12 @@ const char* fvsrn_last_error(void);
 const char* fvsrn_version(void);
 /* number of visible HIP devices (0 without a GPU; never fails) */
 int fvsrn_device_count(void);
+/* How many streams of THIS process run side by side on the current device?  Creates `streams` (2 .. 16) streams, puts one wave that
+ * spins for `microseconds` on each and returns streams x microseconds / elapsed time in *concurrent (1.0: the streams run one after the
+ * other; = streams: all at once).  ROCm maps all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4), a setting that is
+ * read when the HIP runtime starts: the frame pipeline of a rank (five streams) checks here whether it got the eight queues it wants
+ * instead of trusting the environment.  Synchronises the device.  No reference counterpart. */
+int fvsrn_probe_stream_concurrency(int streams, int microseconds, float* concurrent);
 
 /* ----------------------------------------------------------------------------------------
  * SceneNetwork  (replaces renderer::SceneNetwork, renderer/volume_interpolation_network.{h,cpp})
@@ -164,8 +170,10 @@ int fvsrn_network_get_fourier(const fvsrn_network* net, uint16_t* matrix, int ca
  * -------------------------------------------------------------------------------------- */
 typedef enum {
     FVSRN_OPT_SMALL_KERNEL = 0,      /* network + scene: 0 = never take the register-resident kernels, -1 auto  [FVSRN_SMALL_KERNEL]  */
-    FVSRN_OPT_PERSISTENT = 1,        /* scene: persistent render waves 0 / 1, -1 auto = 1 (stripes of a multi-GPU frame too since r03,
-                                        with FVSRN_OPT_PERSISTENT_RESERVE slots left free)                      [FVSRN_PERSISTENT]    */
+    FVSRN_OPT_PERSISTENT = 1,        /* scene: persistent render waves 0 / 1; -1 auto = 1 for whole frames, 0 (bounded waves) for the stripes of
+                                        a multi-GPU frame: persistent stripes (with FVSRN_OPT_PERSISTENT_RESERVE slots left free) pay only when
+                                        the streams of the process run side by side -- fvsrn_probe_stream_concurrency measures that, the
+                                        frame pipeline (tiles.StripeRenderer) opts in on its result              [FVSRN_PERSISTENT]    */
     FVSRN_OPT_DEPTH_SEGMENTS = 2,    /* scene: cut rays into k step ranges composited afterwards, 0 auto       [FVSRN_SEGMENTS]      */
     FVSRN_OPT_FOURIER_RESYNC = 3,    /* scene: exact Fourier features every k steps (power of two), 0 = 64; 1 = the reference's
                                         per-step arithmetic (fp16 position at every sample), no feature rotation [FVSRN_FOURIER_RESYNC] */

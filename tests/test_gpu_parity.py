@@ -70,7 +70,9 @@ def test_time_and_ensemble_golden(name):
         assert np.abs(out - d["out_fp32"][i]).max() < TOL_SAME_MODEL, (t, e)
 
 
-@pytest.mark.parametrize("net_kw", [dict(C=32, layers=4), dict(C=96, layers=3), dict(C=128, layers=2, grid=(16, 8)), dict(C=96, layers=3, grid=(16, 8), activation="ReLU")],
+# (96 / 128 channels: a gaussian Fourier matrix -- the NeRF ladder of 46 features reaches 2^14, outside the half range)
+@pytest.mark.parametrize("net_kw", [dict(C=32, layers=4), dict(C=96, layers=3, fourier_std=0.5), dict(C=128, layers=2, grid=(16, 8), fourier_std=0.5),
+                                    dict(C=96, layers=3, grid=(16, 8), activation="ReLU", fourier_std=0.5)],
                          ids=lambda k: "c%d%s%s" % (k["C"], "grid" if "grid" in k else "", k.get("activation", "")))
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000, 4097])
 def test_evaluate_ragged_sizes(n, net_kw):
@@ -803,6 +805,39 @@ def test_relu_scaled_image_equals_plain_image(C, layers, grid):
     assert "RELU01" in net_scaled.kernel_name(True)
     # exact up to fp16 subnormal effects of the scaled activations: far below the parity tolerances
     assert np.abs(a - b).max() < 5e-4, np.abs(a - b).max()
+
+
+@pytest.mark.parametrize("grid", [None, (16, 8)])
+def test_relu_scaled_image_with_tiny_first_layer_biases(grid):
+    """The first layer's bias rides in an fp16 weight column of the [0,1]-scaled image (pack.cpp, foldBias0): first-layer weights of ~30 give a
+    scale of 2^-9 or so, biases of ~1e-5 then leave the normal range of fp16 -- the part the column cannot hold stays in the fp32 bias block,
+    and the register-resident latent-chunk kernel (which has no such block) must stand back.  Both images and the oracle agree."""
+    import torch
+    from fvsrn_amd import capi, synthetic, volnet_io
+    a = synthetic.random_arrays(C=32, layers=4, output_mode="density", grid=grid, fourier_std=0.4, seed=5, grid_scale=0.3)
+    a["weights"][0] = a["weights"][0] * 48.0
+    a["weights"][1] = a["weights"][1] / 48.0
+    a["biases"][0] = (np.random.RandomState(1).randn(32) * 3e-5).astype(np.float32)
+    vn = volnet_io.build_volnet(fourier_B=a["B"], weights=a["weights"], biases=a["biases"], activation="ReLU", activation_param=1.0, output_mode="density",
+                                box_min=(-0.5, -0.5, -0.5), box_size=(1, 1, 1), time_grids=a["grids"], grid_encoding=volnet_io.ENC_FLOAT)
+    kw = make_scene_kwargs(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF, early_out=False)
+    data = volnet_io.save_volnet(vn)
+    scene = capi.Scene(**kw)
+    net_plain = capi.Network.from_volnet(data)
+    net_plain.set_option("relu_clamp", 0)
+    plain = scene.render(net_plain, 64, 48)[0, :4].cpu().numpy()
+    net_scaled = capi.Network.from_volnet(data)
+    scaled = scene.render(net_scaled, 64, 48)[0, :4].cpu().numpy()
+    assert "RELU01" in net_scaled.kernel_name(False)
+    if grid:  # not the resident latent-chunk kernel: that one drops the fp32 bias block of layer 0
+        assert "SGRID=1" not in net_scaled.kernel_name(True), net_scaled.kernel_name(True)
+    ref, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), 64, 48)
+    assert plain[3].max() > 0.05
+    assert np.abs(plain - scaled).max() < 5e-4, np.abs(plain - scaled).max()
+    assert np.abs(scaled - ref[:4]).max() < TOL_IMG
+    pos = np.random.RandomState(2).rand(4096, 3).astype(np.float32)
+    out = gpu_eval(vn, pos)
+    assert np.abs(out - oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos)).max() < TOL_SAME_MODEL
 
 
 @pytest.mark.parametrize("C,layers,grid,param", [(32, 4, None, 1.0), (32, 3, None, 2.0), (64, 4, (16, 8), 0.5), (32, 4, (16, 8), 1.0), (32, 4, None, 1.5)])

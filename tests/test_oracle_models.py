@@ -31,7 +31,7 @@ def _models(seed):
     return out, rotates
 
 
-@pytest.mark.parametrize("seed", WORST_OF_400 + list(range(60)))
+@pytest.mark.parametrize("seed", WORST_OF_400 + list(range(60)) + [1000, 1001, 1002, 1003])  # (1000 ...: 96 / 128 wide, r04)
 def test_device_model_is_bounded_by_the_reference_models(seed):
     m, rotates = _models(seed)
     d = lambda a, b: float(np.abs(m[a][:7] - m[b][:7]).max())  # noqa: E731

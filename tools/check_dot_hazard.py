@@ -28,13 +28,19 @@ def regs(tok):
     return set()
 
 
-def check(obj):
-    bad = 0
+def disassemble(obj):
     with tempfile.TemporaryDirectory() as t:
         subprocess.check_call([L + "/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, t + "/fat.bin"])
-        subprocess.check_call([L + "/clang-offload-bundler", "--type=o", "--input=" + t + "/fat.bin", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                               "--output=" + t + "/dev.co", "--unbundle"])
-        dis = subprocess.run([L + "/llvm-objdump", "-d", "--no-show-raw-insn", t + "/dev.co"], capture_output=True, text=True).stdout.splitlines()
+        if subprocess.run([L + "/clang-offload-bundler", "--type=o", "--input=" + t + "/fat.bin", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                           "--output=" + t + "/dev.co", "--unbundle"], capture_output=True).returncode != 0:
+            return []  # (a host-only translation unit)
+        return subprocess.run([L + "/llvm-objdump", "-d", "--no-show-raw-insn", t + "/dev.co"], capture_output=True, text=True).stdout.splitlines()
+
+
+def check(obj, dis=None):
+    bad = 0
+    if dis is None:
+        dis = disassemble(obj)
     kernel = "?"
     pending = []  # (register, wait states left, line)
     n_dots = 0

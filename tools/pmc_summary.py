@@ -10,6 +10,7 @@ for d in sorted(glob.glob(root + "/pmc*")):
         continue
     for f in glob.glob(d + "/*/*counter_collection.csv"):
         acc = collections.defaultdict(lambda: collections.defaultdict(float))
+        dur = collections.defaultdict(dict)  # kernel -> dispatch -> ns (the launch durations of THIS pass: GRBM_GUI_ACTIVE / 8 XCDs / duration = shader clock)
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
             name = next((n for n in ("render_small_kernel", "render_shaded_kernel", "render_adjoint_kernel", "render_stripe_kernel", "render_kernel") if n in k), None)
@@ -17,5 +18,9 @@ for d in sorted(glob.glob(root + "/pmc*")):
                 continue
             k = k[k.index(name):].split("(")[0]
             acc[(k, row["Counter_Name"])][row["Dispatch_Id"]] += float(row["Counter_Value"])
+            if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and row.get("End_Timestamp"):
+                dur[k][row["Dispatch_Id"]] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
         for (k, c), per in sorted(acc.items()):
             print("%s,\"%s\",%s,%d,%.1f" % (d.split("/")[-1], k, c, len(per), sum(per.values()) / len(per)))
+        for k, per in sorted(dur.items()):
+            print("%s,\"%s\",kernel_ms_avg_under_pmc,%d,%.6f" % (d.split("/")[-1], k, len(per), 1e-6 * sum(per.values()) / len(per)))

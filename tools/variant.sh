@@ -14,9 +14,9 @@ for o in build/*.o; do
 done
 pids=""
 for tu in "$@"; do
-  src=$tu.hip; xflag=""
-  [ -f $src ] || { src=$tu.cpp; xflag="-x hip"; }
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags $xflag -c $src -o build_var_$name/$tu.o &
+  src=$tu.hip
+  [ -f $src ] || src=$tu.cpp
+  ./hipcc_fixed.sh $src build_var_$name/$tu.o -O3 -std=c++17 -fPIC $flags &   # (the same erratum pass as the main build)
   pids="$pids $!"
   objs="$objs build_var_$name/$tu.o"
 done
