@@ -76,7 +76,7 @@ SYMBOLS = [
     ("fvsrn_last_error", C.c_char_p, []),
     ("fvsrn_version", C.c_char_p, []),
     ("fvsrn_device_count", _I, []),
-    ("fvsrn_probe_stream_concurrency", _I, [_I, _I, _FP]),
+    ("fvsrn_probe_stream_concurrency", _I, [C.POINTER(_VP), _I, _I, _FP]),
     ("fvsrn_network_create_from_volnet", _I, [_VP, _SZ, C.POINTER(_VP)]),
     ("fvsrn_network_create", _I, [C.POINTER(_VP)]),
     ("fvsrn_network_destroy", None, [_VP]),
@@ -121,6 +121,8 @@ SYMBOLS = [
     ("fvsrn_volume_load_cvol", _I, [C.c_char_p, _I, C.POINTER(_VP)]),
     ("fvsrn_volume_save_cvol", _I, [C.c_char_p, C.c_char_p, _VP, _I, _I, _I, _I, _F, _F, _F]),
     ("fvsrn_volume_info", _I, [_VP, C.POINTER(_I), _FP, _FP]),
+    ("fvsrn_volume_get_data", _I, [_VP, _FP, _SZ]),
+    ("fvsrn_cvol_read", _I, [C.c_char_p, _FP, _VP, _VP]),
     ("fvsrn_volume_evaluate_points", _I, [_VP, _I, _I, _I, _VP, _SZ, _VP, _VP]),
     ("fvsrn_render_volume", _I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
 ]
@@ -166,10 +168,15 @@ def device_count() -> int:
     return lib().fvsrn_device_count()
 
 
-def probe_stream_concurrency(streams: int = 6, microseconds: int = 300) -> float:
-    """How many of `streams` streams of this process run side by side (fvsrn_probe_stream_concurrency): ~min(streams, GPU_MAX_HW_QUEUES)."""
+def probe_stream_concurrency(streams=6, microseconds: int = 2000) -> float:
+    """How many streams run side by side (fvsrn_probe_stream_concurrency).  streams: a count (fresh streams: ~min(count, hardware queues of the
+    process)) or a list of HIP stream handles (ints, e.g. torch.cuda.Stream.cuda_stream): the caller's own streams."""
     out = C.c_float(0.0)
-    _check(lib().fvsrn_probe_stream_concurrency(int(streams), int(microseconds), C.byref(out)))
+    if isinstance(streams, int):
+        _check(lib().fvsrn_probe_stream_concurrency(None, int(streams), int(microseconds), C.byref(out)))
+    else:
+        handles = (_VP * len(streams))(*[_VP(int(h)) for h in streams])
+        _check(lib().fvsrn_probe_stream_concurrency(handles, len(streams), int(microseconds), C.byref(out)))
     return float(out.value)
 
 
@@ -497,7 +504,7 @@ class Volume:
 
     @classmethod
     def load(cls, path: str, feature_index: int = 0) -> "Volume":
-        """Uncompressed .cvol (Volume::Volume(filename), volume.cpp:685-740); box = [-world/2, world/2]."""
+        """.cvol, version 1 or the old density-only format, uncompressed or LZ4 (Volume::Volume(filename), volume.cpp:685-793); box = [-world/2, world/2]."""
         h = _VP()
         _check(lib().fvsrn_volume_load_cvol(os.fsencode(path), feature_index, C.byref(h)))
         return cls(h)
@@ -515,6 +522,13 @@ class Volume:
         res, bmin, bsize = (_I * 3)(), (C.c_float * 3)(), (C.c_float * 3)()
         _check(lib().fvsrn_volume_info(self._h, res, bmin, bsize))
         return tuple(res), np.array(bmin, np.float32), np.array(bsize, np.float32)
+
+    def data(self) -> np.ndarray:
+        """(X,Y,Z) float32 copy of the voxels (u8 / u16 volumes: normalised to [0,1])."""
+        res = self.info()[0]
+        a = np.empty(res[0] * res[1] * res[2], np.float32)
+        _check(lib().fvsrn_volume_get_data(self._h, _fptr(a), a.size))
+        return a.reshape(res[2], res[1], res[0]).transpose(2, 1, 0)
 
     def evaluate(self, positions, interpolation=VOLUME_TRILINEAR, source=VOLUME_SOURCE_TEXTURE, new_behavior=False, stream=None):
         """IVolumeInterpolation::evaluate: (N,3) fp32 CUDA world positions -> (N,1)."""

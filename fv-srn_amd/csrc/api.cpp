@@ -708,14 +708,17 @@ int fvsrn_device_count(void) {
     return n;
 }
 
-int fvsrn_probe_stream_concurrency(int streams, int microseconds, float* concurrent) {
+int fvsrn_probe_stream_concurrency(void* const* stream_handles, int streams, int microseconds, float* concurrent) {
     if (!concurrent || streams < 2 || streams > 16 || microseconds < 10 || microseconds > 100000)
         return fail(FVSRN_ERR_INVALID_ARGUMENT, "2 .. 16 streams, 10 .. 100000 microseconds, a result pointer");
     if (fvsrn_device_count() == 0) return fail(FVSRN_ERR_NO_DEVICE, "no HIP device");
     std::vector<hipStream_t> st(size_t(streams), nullptr);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-    for (auto& s : st) ok = ok && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < streams; ++i) {
+        if (stream_handles) st[size_t(i)] = static_cast<hipStream_t>(stream_handles[i]);  // the caller's own streams (nullptr = the null stream)
+        else ok = ok && hipStreamCreateWithFlags(&st[size_t(i)], hipStreamNonBlocking) == hipSuccess;
+    }
     float ms = 0.f;
     if (ok) {
         // warm-up (module load, queue creation), then the timed round: the events sit on the first stream, which every other stream
@@ -733,7 +736,8 @@ int fvsrn_probe_stream_concurrency(int streams, int microseconds, float* concurr
             for (auto e : done) if (e) (void)hipEventDestroy(e);
         }
     }
-    for (auto s : st) if (s) (void)hipStreamDestroy(s);
+    if (!stream_handles)
+        for (auto s : st) if (s) (void)hipStreamDestroy(s);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (!ok || ms <= 0.f) return fail(FVSRN_ERR_DEVICE, "stream concurrency probe failed");
@@ -1737,6 +1741,13 @@ int fvsrn_volume_destroy(fvsrn_volume* volume) {
     return FVSRN_OK;
 }
 
+int fvsrn_volume_get_data(fvsrn_volume* volume, float* out, size_t count) {
+    if (!volume || !out) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+    if (count != volume->host.size()) return fail(FVSRN_ERR_INVALID_ARGUMENT, "count must be the number of voxels (fvsrn_volume_info)");
+    std::memcpy(out, volume->host.data(), count * sizeof(float));
+    return FVSRN_OK;
+}
+
 int fvsrn_volume_info(fvsrn_volume* volume, int resolution[3], float box_min[3], float box_size[3]) {
     if (!volume) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
     for (int i = 0; i < 3; ++i) {
@@ -1781,28 +1792,121 @@ int fvsrn_volume_save_cvol(const char* path, const char* feature_name, const voi
     });
 }
 
-int fvsrn_volume_load_cvol(const char* path, int feature_index, fvsrn_volume** out) {
+// ---- LZ4 framing of compressed .cvol bodies -------------------------------------------------------------------------------------
+// The reference compresses through its `lz4cpp` wrapper (LZ4Compressor / LZ4Decompressor, third-party/lz4cpp: an EMPTY submodule in the
+// reference snapshot), in streaming mode: messages of at most 64 KiB (LZ4Compressor::MAX_CHUNK_SIZE), each stored as
+//     int32 compressed size | one LZ4 block (the published block format: token, literals, 16-bit offset, match length)
+// whose matches may reach back up to 64 KiB into the messages before it (dependent blocks, one stream for the whole file).  The framing
+// is recovered from the one volume the snapshot holds, applications/volumes/RichtmyerMeshkov/ppm-t0020.cvol: 256 messages of exactly
+// 65 536 bytes decode to 256^3 bytes and consume the file to its last byte (tests/test_volnet_format.py keeps its histogram).
+// Decodes messages until `want` bytes are appended to `out` (`out` may already hold earlier features of the same stream: the history).
+static const char* lz4ReadMessages(std::istream& f, std::vector<unsigned char>& out, size_t want) {
+    const size_t end = out.size() + want;
+    std::vector<unsigned char> src;
+    while (out.size() < end) {
+        int csize = 0;
+        f.read(reinterpret_cast<char*>(&csize), 4);
+        if (!f || csize <= 0 || csize > (1 << 24)) return "corrupt LZ4 message header";
+        src.resize(size_t(csize));
+        f.read(reinterpret_cast<char*>(src.data()), csize);
+        if (!f) return "unexpected end of file inside an LZ4 message";
+        size_t i = 0;
+        const size_t n = src.size();
+        while (i < n) {
+            const unsigned tok = src[i++];
+            size_t lit = tok >> 4;
+            if (lit == 15) {
+                unsigned b;
+                do {
+                    if (i >= n) return "corrupt LZ4 block (literal length)";
+                    b = src[i++];
+                    lit += b;
+                } while (b == 255);
+            }
+            if (lit > n - i || lit > end - out.size()) return "corrupt LZ4 block (literals overrun)";
+            out.insert(out.end(), src.begin() + long(i), src.begin() + long(i + lit));
+            i += lit;
+            if (i >= n) break;  // the last sequence of a block has no match
+            if (n - i < 2) return "corrupt LZ4 block (offset)";
+            const size_t off = size_t(src[i]) | (size_t(src[i + 1]) << 8);
+            i += 2;
+            size_t len = tok & 15;
+            if (len == 15) {
+                unsigned b;
+                do {
+                    if (i >= n) return "corrupt LZ4 block (match length)";
+                    b = src[i++];
+                    len += b;
+                } while (b == 255);
+            }
+            len += 4;
+            if (off == 0 || off > out.size() || len > end - out.size()) return "corrupt LZ4 block (match outside the stream)";
+            const size_t start = out.size() - off;
+            out.resize(out.size() + len);
+            unsigned char* d = out.data() + start + off;
+            const unsigned char* sp = out.data() + start;
+            for (size_t k = 0; k < len; ++k) d[k] = sp[k];  // (overlapping matches repeat their pattern: byte by byte)
+        }
+    }
+    return nullptr;
+}
+
+int fvsrn_cvol_read(const char* path, float world_size[3], fvsrn_cvol_feature_callback on_feature, void* user) {
     return guarded([&] {
-        if (!path || !out) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        if (!path || !on_feature) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
         std::ifstream f(path, std::ios::binary);
         if (!f) return fail(FVSRN_ERR_IO, std::string("Unable to open file ") + path);
-        char magic[4];
+        char magic[4] = {0, 0, 0, 0};
+        f.read(magic, 4);
+        static const size_t bytesPerType[3] = {1, 2, 4};
+        constexpr size_t kMaxBytes = size_t(1) << 34;  // 16 GiB of decoded host data per feature
+        fvsrn_cvol_feature info;
+        std::memset(&info, 0, sizeof info);
+        if (f && std::memcmp(magic, "cvol", 4) == 0) {
+            // the old format: one density feature (Volume::Volume(filename), volume.cpp:741-793)
+            unsigned long long X = 0, Y = 0, Z = 0;
+            double voxel[3] = {0, 0, 0};
+            unsigned type = 0;
+            char useCompression = 0;
+            f.read(reinterpret_cast<char*>(&X), 8); f.read(reinterpret_cast<char*>(&Y), 8); f.read(reinterpret_cast<char*>(&Z), 8);
+            f.read(reinterpret_cast<char*>(voxel), 24);
+            f.read(reinterpret_cast<char*>(&type), 4);
+            f.read(&useCompression, 1);
+            f.ignore(7);
+            if (!f || type > 2 || X == 0 || Y == 0 || Z == 0 || X > 65536 || Y > 65536 || Z > 65536 || !(voxel[0] > 0) || !(voxel[1] > 0) || !(voxel[2] > 0))
+                return fail(FVSRN_ERR_FORMAT, "corrupt header of a legacy 'cvol' file");
+            const size_t bytes = bytesPerType[type] * X * Y * Z;
+            if (bytes > kMaxBytes) return fail(FVSRN_ERR_UNSUPPORTED, "volume too large");
+            std::vector<unsigned char> raw;
+            if (useCompression) {
+                raw.reserve(bytes);
+                if (const char* why = lz4ReadMessages(f, raw, bytes)) return fail(FVSRN_ERR_FORMAT, why);
+            } else {
+                raw.resize(bytes);
+                f.read(reinterpret_cast<char*>(raw.data()), std::streamsize(bytes));
+                if (!f) return fail(FVSRN_ERR_FORMAT, "unexpected end of file");
+            }
+            if (world_size) { world_size[0] = float(voxel[0] * double(X)); world_size[1] = float(voxel[1] * double(Y)); world_size[2] = float(voxel[2] * double(Z)); }
+            std::snprintf(info.name, sizeof info.name, "density");
+            info.index = 0; info.num_features = 1; info.dtype = int(type); info.channels = 1;
+            info.resolution[0] = int(X); info.resolution[1] = int(Y); info.resolution[2] = int(Z);
+            on_feature(user, &info, raw.data(), raw.size());
+            return FVSRN_OK;
+        }
         int version = 0, numFeatures = 0, flags = 0;
         float world[3];
-        f.read(magic, 4);
-        if (!f || std::memcmp(magic, "CVOL", 4) != 0)
-            return fail(FVSRN_ERR_FORMAT, std::memcmp(magic, "cvol", 4) == 0 ? "legacy 'cvol' files (density only, volume.cpp:741-793) are not supported"
-                                                                               : "Illegal magic number");
+        if (!f || std::memcmp(magic, "CVOL", 4) != 0) return fail(FVSRN_ERR_FORMAT, "Illegal magic number");
         f.read(reinterpret_cast<char*>(&version), 4);
         if (version != 1) return fail(FVSRN_ERR_FORMAT, "Unknown file version!");
         f.read(reinterpret_cast<char*>(world), 12);
         f.read(reinterpret_cast<char*>(&numFeatures), 4);
         f.read(reinterpret_cast<char*>(&flags), 4);
         f.ignore(4);
-        if (flags & 1) return fail(FVSRN_ERR_UNSUPPORTED, "LZ4-compressed .cvol files are not supported (save the volume with compression 0)");
-        if (feature_index < 0 || feature_index >= numFeatures) return fail(FVSRN_ERR_INVALID_ARGUMENT, "no such feature in the volume");
-        static const size_t bytesPerType[3] = {1, 2, 4};
-        for (int i = 0; i <= feature_index; ++i) {
+        if (!f || numFeatures < 0 || numFeatures > 1024) return fail(FVSRN_ERR_FORMAT, "corrupt .cvol header");
+        if (world_size) for (int i = 0; i < 3; ++i) world_size[i] = world[i];
+        const bool compressed = (flags & 1) != 0;  // Flag_Compressed: every feature body is a run of LZ4 messages of ONE stream (Volume::save :647-664)
+        std::vector<unsigned char> stream;  // compressed files: <= 64 KiB of history + the current feature (a match may reach into the previous feature)
+        for (int i = 0; i < numFeatures; ++i) {
             int lenName = 0, channels = 0, type = 0;
             unsigned long long X = 0, Y = 0, Z = 0;
             f.read(reinterpret_cast<char*>(&lenName), 4);
@@ -1814,19 +1918,44 @@ int fvsrn_volume_load_cvol(const char* path, int feature_index, fvsrn_volume** o
             f.read(reinterpret_cast<char*>(&Z), 8);
             f.read(reinterpret_cast<char*>(&channels), 4);
             f.read(reinterpret_cast<char*>(&type), 4);
-            if (!f || type < 0 || type > 2 || channels <= 0 || X == 0 || Y == 0 || Z == 0 || X > 65536 || Y > 65536 || Z > 65536)
+            if (!f || type < 0 || type > 2 || channels <= 0 || channels > 64 || X == 0 || Y == 0 || Z == 0 || X > 65536 || Y > 65536 || Z > 65536)
                 return fail(FVSRN_ERR_FORMAT, "corrupt feature header");
             const size_t bytes = bytesPerType[type] * X * Y * Z * size_t(channels);
-            if (i < feature_index) { f.ignore(std::streamsize(bytes)); continue; }
-            if (channels != 1) return fail(FVSRN_ERR_UNSUPPORTED, "only scalar (1-channel) features can be rendered as densities");
-            std::vector<char> raw(bytes);
-            f.read(raw.data(), std::streamsize(bytes));
-            if (!f) return fail(FVSRN_ERR_FORMAT, "unexpected end of file");
-            const float boxMin[3] = {-world[0] / 2, -world[1] / 2, -world[2] / 2};  // VolumeInterpolationGrid::setSource, :193-198
-            return fvsrn_volume_create(raw.data(), type, int(X), int(Y), int(Z), 1, boxMin, world, out);
+            if (bytes > kMaxBytes) return fail(FVSRN_ERR_UNSUPPORTED, "volume too large");
+            if (compressed) {
+                if (stream.size() > (size_t(1) << 16)) stream.erase(stream.begin(), stream.end() - (1 << 16));  // only the last 64 KiB can be referenced
+                if (const char* why = lz4ReadMessages(f, stream, bytes)) return fail(FVSRN_ERR_FORMAT, why);
+            } else {
+                stream.resize(bytes);
+                f.read(reinterpret_cast<char*>(stream.data()), std::streamsize(bytes));
+                if (!f) return fail(FVSRN_ERR_FORMAT, "unexpected end of file");
+            }
+            std::snprintf(info.name, sizeof info.name, "%s", name.c_str());
+            info.index = i; info.num_features = numFeatures; info.dtype = type; info.channels = channels;
+            info.resolution[0] = int(X); info.resolution[1] = int(Y); info.resolution[2] = int(Z);
+            if (on_feature(user, &info, stream.data() + (stream.size() - bytes), bytes) != 0) break;  // (non-zero: the caller has what it wants)
         }
-        return fail(FVSRN_ERR_FORMAT, "feature not found");
+        return FVSRN_OK;
     });
+}
+
+int fvsrn_volume_load_cvol(const char* path, int feature_index, fvsrn_volume** out) {
+    if (!path || !out) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+    struct Pick { int want; int rc; bool seen; int numFeatures; float world[3]; fvsrn_volume** out; } pick{feature_index, FVSRN_OK, false, 0, {1, 1, 1}, out};
+    // (the world size is known before the first callback: fvsrn_cvol_read fills it from the header)
+    const int rc = fvsrn_cvol_read(path, pick.world, [](void* user, const fvsrn_cvol_feature* info, const void* data, size_t) -> int {
+        Pick& p = *static_cast<Pick*>(user);
+        p.numFeatures = info->num_features;
+        if (info->index != p.want) return 0;
+        p.seen = true;
+        if (info->channels != 1) { p.rc = fail(FVSRN_ERR_UNSUPPORTED, "only scalar (1-channel) features can be rendered as densities"); return 1; }
+        const float boxMin[3] = {-p.world[0] / 2, -p.world[1] / 2, -p.world[2] / 2};  // VolumeInterpolationGrid::setSource, :193-198
+        p.rc = fvsrn_volume_create(data, info->dtype, info->resolution[0], info->resolution[1], info->resolution[2], 1, boxMin, p.world, p.out);
+        return 1;
+    }, &pick);
+    if (rc != FVSRN_OK) return rc;
+    if (!pick.seen) return fail(FVSRN_ERR_INVALID_ARGUMENT, "no such feature in the volume");
+    return pick.rc;
 }
 
 int fvsrn_volume_evaluate_points(fvsrn_volume* volume, int source, int interpolation, int grid_resolution_new_behavior,

@@ -455,7 +455,7 @@ struct VolumeInterpolationNetwork : IVolumeInterpolation {
 };
 
 // --------------------------------------------------------------------------------------------------- grid volumes
-// Volume (renderer/volume.h, volume.cpp:1244-1400): host container of named features; .cvol version 1, uncompressed.
+// Volume (renderer/volume.h, volume.cpp:1244-1400): host container of named features; .cvol version 1 and the old format, LZ4 or not (save: uncompressed).
 struct Volume {
     enum DataType { TypeUChar = 0, TypeUShort = 1, TypeFloat = 2 };
     struct Feature {
@@ -474,45 +474,20 @@ struct Volume {
     static size_t bytesPerType(DataType t) { return t == TypeUChar ? 1 : (t == TypeUShort ? 2 : 4); }
 
     Volume() = default;
-    explicit Volume(const std::string& filename) {  // Volume::Volume(filename), volume.cpp:685-740 + Feature::load :278-332
-        std::ifstream f(filename, std::ios::binary);
-        if (!f) raise("Unable to open file " + filename);
-        char magic[4];
-        int version = 0, numFeatures = 0, flags = 0;
-        f.read(magic, 4);
-        if (!f || std::memcmp(magic, "CVOL", 4) != 0) raise("Illegal magic number");
-        f.read(reinterpret_cast<char*>(&version), 4);
-        if (version != 1) raise("Unknown file version!");
-        f.read(reinterpret_cast<char*>(&worldX), 4);
-        f.read(reinterpret_cast<char*>(&worldY), 4);
-        f.read(reinterpret_cast<char*>(&worldZ), 4);
-        f.read(reinterpret_cast<char*>(&numFeatures), 4);
-        f.read(reinterpret_cast<char*>(&flags), 4);
-        f.ignore(4);
-        if (flags & 1) raise("LZ4-compressed .cvol files are not supported by this build (save the volume with compression 0)");
-        if (!f || numFeatures < 0 || numFeatures > 1024) raise("corrupt .cvol header");
-        for (int i = 0; i < numFeatures; ++i) {
+    explicit Volume(const std::string& filename) {  // Volume::Volume(filename), volume.cpp:685-793 + Feature::load :278-332
+        // version 1 and the old density-only format, uncompressed or LZ4: the container is read by the C library (fvsrn_cvol_read)
+        float world[3] = {1, 1, 1};
+        check(fvsrn_cvol_read(filename.c_str(), world, [](void* user, const fvsrn_cvol_feature* info, const void* data, size_t bytes) -> int {
             auto ft = std::make_shared<Feature>();
-            int lenName = 0, type = 0;
-            unsigned long long X = 0, Y = 0, Z = 0;
-            f.read(reinterpret_cast<char*>(&lenName), 4);
-            if (!f || lenName < 0 || lenName > 4096) raise("corrupt feature header");
-            ft->name_.resize(size_t(lenName));
-            f.read(ft->name_.data(), lenName);
-            f.read(reinterpret_cast<char*>(&X), 8);
-            f.read(reinterpret_cast<char*>(&Y), 8);
-            f.read(reinterpret_cast<char*>(&Z), 8);
-            f.read(reinterpret_cast<char*>(&ft->channels_), 4);
-            f.read(reinterpret_cast<char*>(&type), 4);
-            if (!f || type < 0 || type > 2 || ft->channels_ <= 0 || X == 0 || Y == 0 || Z == 0 || X > 65536 || Y > 65536 || Z > 65536)
-                raise("corrupt feature header");
-            ft->type_ = DataType(type);
-            ft->sx = int(X); ft->sy = int(Y); ft->sz = int(Z);
-            ft->data.resize(bytesPerType(ft->type_) * X * Y * Z * size_t(ft->channels_));
-            f.read(ft->data.data(), std::streamsize(ft->data.size()));
-            if (!f) raise("unexpected end of file in " + filename);
-            features.push_back(ft);
-        }
+            ft->name_ = info->name;
+            ft->type_ = DataType(info->dtype);
+            ft->channels_ = info->channels;
+            ft->sx = info->resolution[0]; ft->sy = info->resolution[1]; ft->sz = info->resolution[2];
+            ft->data.assign(static_cast<const char*>(data), static_cast<const char*>(data) + bytes);
+            static_cast<Volume*>(user)->features.push_back(ft);
+            return 0;
+        }, this));
+        worldX = world[0]; worldY = world[1]; worldZ = world[2];
     }
     void save(const std::string& filename, int compression) const {  // Volume::save, volume.cpp:623-668
         if (compression != 0) raise("this build writes uncompressed .cvol files only (compression=0)");

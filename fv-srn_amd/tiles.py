@@ -17,8 +17,8 @@ frames, the caller's) and ROCm maps all streams of a process onto GPU_MAX_HW_QUE
 share a queue run in submission order, and the collective of frame i ends up behind the render of frame i + 1 (r03: a rank's share at
 world 8 at 80 % of frame / world instead of 98 %).  The variable is read when the HIP runtime starts, so a library cannot set it: export
 GPU_MAX_HW_QUEUES=8 before the process starts (bench.py and launch_ranks() do that for the processes THEY start).  StripeRenderer measures
-what it got (``hw_streams_concurrent``, fvsrn_probe_stream_concurrency), warns when its streams do not all run side by side, and takes the
-persistent stripe launches that need them only then.
+what it got -- one spinning wave on each of ITS render / collective streams (``hw_streams_concurrent``, fvsrn_probe_stream_concurrency) --,
+warns when they do not all run side by side, and takes the persistent stripe launches that need them only then.
 
 ``StripeRenderer`` is the frame pipeline of one rank: double-buffered local / gathered images, the gather
 of frame i on a communication stream while frame i + 1 renders, consecutive frames on two render streams so that the
@@ -40,17 +40,6 @@ from typing import Callable, List, Optional, Sequence
 import torch
 
 STRIPE = 16  # default stripe height: two 8-row pixel tiles of a wave
-PIPELINE_STREAMS = 5  # render 0, render 1, collective, key-frame copies, the caller's
-_concurrency = None  # measured once per process
-
-
-def stream_concurrency() -> float:
-    """Streams of this process that run side by side on the current device, measured once (fvsrn_probe_stream_concurrency, 6 streams)."""
-    global _concurrency
-    if _concurrency is None:
-        from . import capi
-        _concurrency = capi.probe_stream_concurrency(PIPELINE_STREAMS + 1, 300)
-    return _concurrency
 
 
 def owned_rows(height: int, stripe: int, rank: int, world: int) -> List[int]:
@@ -165,22 +154,10 @@ class StripeRenderer:
             # streams = (render stream 0, render stream 1, collective's stream): a caller that builds several pipelines in one process hands
             # the same three to all of them (torch hands out streams from a pool, ROCm maps them onto its hardware queues by creation order)
             self.comm_stream = (streams[2] if streams else torch.cuda.Stream()) if self.collective else None
-            if self.collective and render is None:
-                # persistent stripe launches (97 - 100 % of frame / world at world 8 in the one-GPU emulation of r03 against 82 - 90 % for
-                # bounded waves) need the collective's stream on a hardware queue of its own: measured, not assumed
-                self.hw_streams_concurrent = stream_concurrency()
-                self.persistent_stripes = self.hw_streams_concurrent >= PIPELINE_STREAMS - 0.5
-                if not self.persistent_stripes:
-                    warnings.warn("fvsrn StripeRenderer: only %.1f of the process's streams run side by side (ROCm's default of four hardware "
-                                  "queues?): export GPU_MAX_HW_QUEUES=8 before the process starts; stripe launches stay in bounded waves"
-                                  % self.hw_streams_concurrent, RuntimeWarning, stacklevel=2)
+
             self.blend_stream = None  # created with the first next_time: key-frame blends of the NEXT frame, beside the current render
             self.render_done = [torch.cuda.Event() for _ in range(nbuf)]
             self.gather_done = [torch.cuda.Event() for _ in range(nbuf)]
-            if self.persistent_stripes:
-                for sc in self.scenes:
-                    if sc.get_option("persistent") < 0:  # (an explicit setting of the caller / the environment stays)
-                        sc.set_option("persistent", 1)
             if self.pipelined:
                 # The first use of a network handle uploads its weight images and key frames on the stream of that call; the
                 # library orders other streams behind it by events (include/fvsrn.h), this untimed frame only keeps the
@@ -190,6 +167,21 @@ class StripeRenderer:
                 self.render_streams = [streams[0], streams[1]] if streams else [torch.cuda.Stream(), torch.cuda.Stream()]
                 for st in self.render_streams:
                     st.wait_stream(torch.cuda.current_stream())
+            if self.collective and render is None:
+                # Persistent stripe launches (97 - 100 % of frame / world at world 8 in the one-GPU emulation of r03, against 82 - 90 % for
+                # bounded waves) need the collective's stream and the render streams on hardware queues of their own: measured on THESE
+                # streams (fvsrn_probe_stream_concurrency), not assumed from the environment.
+                mine = ([st.cuda_stream for st in self.render_streams] if self.pipelined else [torch.cuda.current_stream().cuda_stream]) + [self.comm_stream.cuda_stream]
+                self.hw_streams_concurrent = capi.probe_stream_concurrency(mine, 2000)
+                self.persistent_stripes = self.hw_streams_concurrent >= len(mine) - 0.4
+                if not self.persistent_stripes:
+                    warnings.warn("fvsrn StripeRenderer: its %d streams run only %.1f-wide (ROCm maps the streams of a process onto GPU_MAX_HW_QUEUES "
+                                  "hardware queues, default 4): export GPU_MAX_HW_QUEUES=8 before the process starts; stripe launches stay in "
+                                  "bounded waves" % (len(mine), self.hw_streams_concurrent), RuntimeWarning, stacklevel=2)
+                else:
+                    for sc in self.scenes:
+                        if sc.get_option("persistent") < 0:  # (an explicit setting of the caller / the environment stays)
+                            sc.set_option("persistent", 1)
         else:
             self.scenes = [dict(scene_kw) for _ in range(2 if self.pipelined else 1)]
             self.comm_stream = _HostStream() if self.collective else None

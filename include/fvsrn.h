@@ -83,12 +83,15 @@ const char* fvsrn_last_error(void);
 const char* fvsrn_version(void);
 /* number of visible HIP devices (0 without a GPU; never fails) */
 int fvsrn_device_count(void);
-/* How many streams of THIS process run side by side on the current device?  Creates `streams` (2 .. 16) streams, puts one wave that
- * spins for `microseconds` on each and returns streams x microseconds / elapsed time in *concurrent (1.0: the streams run one after the
- * other; = streams: all at once).  ROCm maps all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4), a setting that is
- * read when the HIP runtime starts: the frame pipeline of a rank (five streams) checks here whether it got the eight queues it wants
- * instead of trusting the environment.  Synchronises the device.  No reference counterpart. */
-int fvsrn_probe_stream_concurrency(int streams, int microseconds, float* concurrent);
+/* How many of these streams run side by side on the current device?  Puts one wave that spins for `microseconds` on each of the
+ * `streams` (2 .. 16) streams -- the caller's own (stream_handles, HIP stream handles) or, with stream_handles == NULL, freshly created ones --
+ * and returns streams x microseconds / elapsed time in *concurrent (1.0: one after the other; = streams: all at once).  ROCm maps all
+ * streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4; read when the HIP runtime starts) and two streams that share a
+ * queue run in submission order: the frame pipeline of a rank checks here whether ITS render and collective streams got queues of their
+ * own instead of trusting the environment (measured r04: n fresh streams on q queues give n / ceil(n / q); inside a process that has
+ * initialised RCCL six fresh streams ran 2.8-wide even with GPU_MAX_HW_QUEUES=8).  Use >= 2000 microseconds (300: launch overhead shows).
+ * Synchronises the device.  No reference counterpart. */
+int fvsrn_probe_stream_concurrency(void* const* stream_handles, int streams, int microseconds, float* concurrent);
 
 /* ----------------------------------------------------------------------------------------
  * SceneNetwork  (replaces renderer::SceneNetwork, renderer/volume_interpolation_network.{h,cpp})
@@ -372,13 +375,31 @@ typedef enum { FVSRN_VOLUME_SOURCE_TEXTURE = 0, FVSRN_VOLUME_SOURCE_TENSOR = 1 }
 int fvsrn_volume_create(const void* host_data, int dtype, int sx, int sy, int sz, int x_fastest, const float box_min[3],
                         const float box_size[3], fvsrn_volume** out);
 int fvsrn_volume_destroy(fvsrn_volume* volume);
-/* .cvol files, version 1, uncompressed (volume.cpp:278-332,685-740); LZ4-compressed files are rejected (the reference's LZ4
- * wrapper is an empty submodule).  load: feature `feature_index` at mipmap level 0, box = [-world/2, world/2] like
- * VolumeInterpolationGrid::setSource. */
+/* .cvol files: version 1 ("CVOL", volume.cpp:278-332,685-740) and the old density-only format ("cvol", volume.cpp:741-793), uncompressed
+ * or LZ4-compressed (Flag_Compressed / useCompression: int32 size + LZ4 block per message of <= 64 KiB, one dependent-block stream per
+ * file -- the framing of the reference's lz4cpp wrapper, an empty submodule in the snapshot, recovered from the volume the snapshot does
+ * hold, applications/volumes/RichtmyerMeshkov/ppm-t0020.cvol).  load: feature `feature_index` at mipmap level 0, box = [-world/2,
+ * world/2] like VolumeInterpolationGrid::setSource.  save writes version 1, uncompressed. */
 int fvsrn_volume_load_cvol(const char* path, int feature_index, fvsrn_volume** out);
+/* The container itself (Volume::Volume(filename) + Feature::load, volume.cpp:278-332,685-793): every feature of the file at level 0 as raw
+ * typed voxels -- channel fastest, then x, y, z (MipmapLevel::idx, volume.h:126-132) -- handed to `on_feature` in file order (return
+ * non-zero to stop early; `data` is only valid during the call).  world_size (may be NULL) is filled before the first callback.  The
+ * pyrenderer `Volume` class is built on this. */
+typedef struct {
+    char name[256];
+    int index, num_features;
+    int dtype;    /* fvsrn_volume_dtype */
+    int channels;
+    int resolution[3];
+} fvsrn_cvol_feature;
+typedef int (*fvsrn_cvol_feature_callback)(void* user, const fvsrn_cvol_feature* info, const void* data, size_t bytes);
+int fvsrn_cvol_read(const char* path, float world_size[3], fvsrn_cvol_feature_callback on_feature, void* user);
 int fvsrn_volume_save_cvol(const char* path, const char* feature_name, const void* host_data, int dtype, int sx, int sy, int sz,
                            float world_x, float world_y, float world_z);
 int fvsrn_volume_info(fvsrn_volume* volume, int resolution[3], float box_min[3], float box_size[3]);
+/* the voxels as the kernels see them (u8 / u16 normalised to [0,1]), x fastest: index x + sx*(y + sy*z); count = sx*sy*sz host floats
+ * (Volume::MipmapLevel::toTensor / dataCpu of level 0, volume.cpp:169-214) */
+int fvsrn_volume_get_data(fvsrn_volume* volume, float* out, size_t count);
 /* IVolumeInterpolation::evaluate for a grid volume: world positions [n][3] -> values [n] (device pointers) */
 int fvsrn_volume_evaluate_points(fvsrn_volume* volume, int source, int interpolation, int grid_resolution_new_behavior,
                                  const float* d_positions, size_t n, float* d_out, void* stream);

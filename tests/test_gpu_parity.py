@@ -835,8 +835,8 @@ def test_relu_scaled_image_with_tiny_first_layer_biases(grid):
     assert plain[3].max() > 0.05
     assert np.abs(plain - scaled).max() < 5e-4, np.abs(plain - scaled).max()
     assert np.abs(scaled - ref[:4]).max() < TOL_IMG
-    pos = np.random.RandomState(2).rand(4096, 3).astype(np.float32)
-    out = gpu_eval(vn, pos)
+    pos = (np.random.RandomState(2).rand(4096, 3) - 0.5).astype(np.float32)  # world positions inside the box [-0.5, 0.5]^3
+    out = gpu_eval(vn, pos, world=True)
     assert np.abs(out - oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos)).max() < TOL_SAME_MODEL
 
 

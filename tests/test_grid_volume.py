@@ -13,6 +13,7 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import util  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 BOX_MIN, BOX_SIZE = (-0.5, -0.4, -0.3), (1.0, 0.8, 0.6)
@@ -103,15 +104,75 @@ def test_cvol_round_trip(tmp_path):
         assert np.allclose(bmin, (-0.5, -0.4, -0.3)) and np.allclose(bsize, (1.0, 0.8, 0.6))
 
 
+def test_cvol_lz4_and_legacy_files(tmp_path):
+    """LZ4-compressed bodies (Flag_Compressed, volume.cpp:647-664,721-735) in the lz4cpp framing -- int32 size + LZ4 block per 64 KiB message, ONE
+    dependent-block stream per file, so a match in the second feature may reach into the first -- and the old density-only "cvol" format
+    (volume.cpp:741-793), compressed and not.  The files are written by the test-side encoder (util.lz4_messages)."""
+    from fvsrn_amd import capi
+    rng = np.random.RandomState(3)
+    x, y, z = np.meshgrid(*[np.linspace(-1, 1, n) for n in (48, 40, 36)], indexing="ij")
+    a = (np.round(np.exp(-3 * (x * x + y * y + z * z)) * 6) * 40).astype(np.uint8)                           # plateaus: long matches
+    b = rng.randint(0, 4, (40, 33, 50)).astype(np.uint16) * 1000                                             # noisy u16: short matches, > 64 KiB
+    xfast = lambda v: np.ascontiguousarray(v.transpose(2, 1, 0)).tobytes()  # noqa: E731
+    feat = lambda name, v, ty: struct.pack("<i", len(name)) + name + struct.pack("<3Q2i", *v.shape, 1, ty)  # noqa: E731
+    # one stream per file: feature b's messages are encoded with feature a's bytes as their history (front padding puts b's first byte on a
+    # message boundary of the encoder; distances between b and a are unchanged)
+    path = tmp_path / "two.cvol"
+    body_a = util.lz4_messages(xfast(a))
+    hist = xfast(a)
+    pad = (-len(hist)) % 65536
+    cont = util.lz4_messages(bytes(pad) + hist + xfast(b))
+    pos = 0
+    for _ in range((pad + len(hist)) // 65536):
+        pos += 4 + struct.unpack("<i", cont[pos:pos + 4])[0]
+    body_b = cont[pos:]
+    path.write_bytes(b"CVOL" + struct.pack("<i3f3i", 1, 1.0, 0.8, 0.6, 2, 1, 0) + feat(b"density", a, 0) + body_a + feat(b"other", b, 1) + body_b)
+    va, vb = capi.Volume.load(str(path), 0), capi.Volume.load(str(path), 1)
+    assert va.info()[0] == a.shape and vb.info()[0] == b.shape
+    assert np.array_equal(va.data(), a.astype(np.float32) / 255.0)
+    assert np.array_equal(vb.data(), b.astype(np.float32) / 65535.0)
+    assert len(body_a) < a.size // 2, "the smooth volume should compress (matches are exercised)"
+    for compressed in (0, 1):
+        old = tmp_path / ("old%d.cvol" % compressed)
+        old.write_bytes(b"cvol" + struct.pack("<3Q3dIB7x", *a.shape, 1 / 48, 1 / 48, 1 / 48, 0, compressed) + (util.lz4_messages(xfast(a)) if compressed else xfast(a)))
+        v = capi.Volume.load(str(old))
+        res, bmin, bsize = v.info()
+        assert res == a.shape and np.allclose(bsize, (1.0, 40 / 48, 36 / 48)) and np.allclose(bmin, -bsize / 2)
+        assert np.array_equal(v.data(), a.astype(np.float32) / 255.0)
+
+
+REFERENCE_CVOL = "/root/reference/applications/volumes/RichtmyerMeshkov/ppm-t0020.cvol"
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE_CVOL), reason="needs the reference checkout (build container only)")
+def test_reference_volume_file_loads():
+    """The one volume the reference snapshot holds (old format, 256^3 bytes, LZ4): what config-files/RichtmyerMeshkov-t20-v1-dvr.json points
+    at.  Pinned by tests/golden/cvol_ppm_t0020.npz, which tests/golden/make_cvol_fixture.py wrote with an independent pure-Python decoder."""
+    import zlib
+    from fvsrn_amd import capi
+    ref = np.load(os.path.join(util.GOLDEN_DIR, "cvol_ppm_t0020.npz"))
+    v = capi.Volume.load(REFERENCE_CVOL)
+    res, bmin, bsize = v.info()
+    assert res == tuple(ref["resolution"]) == (256, 256, 256) and np.allclose(bsize, 1.0) and np.allclose(bmin, -0.5)
+    d = np.rint(v.data() * 255.0).astype(np.uint8)
+    assert (int(d.min()), int(d.max())) == (int(ref["minimum"]), int(ref["maximum"])) and abs(float(d.mean()) - float(ref["mean"])) < 1e-9
+    assert np.array_equal(np.bincount(d.reshape(-1) >> 2, minlength=64), ref["histogram"])
+    assert zlib.crc32(np.ascontiguousarray(d.transpose(2, 1, 0)).tobytes()) == int(ref["crc32"])
+    assert np.abs(d.reshape(32, 8, 32, 8, 32, 8).astype(np.float64).mean(axis=(1, 3, 5)) / 255.0 - ref["block_mean_32"]).max() < 1e-6
+
+
 def test_cvol_errors(tmp_path):
     from fvsrn_amd import capi
     bad = tmp_path / "bad.cvol"
     bad.write_bytes(b"XXXX" + b"\0" * 64)
     with pytest.raises(capi.FvsrnError, match="magic"):
         capi.Volume.load(str(bad))
-    lz4 = tmp_path / "lz4.cvol"
-    lz4.write_bytes(b"CVOL" + struct.pack("<i3f3i", 1, 1, 1, 1, 1, 1, 0))
+    lz4 = tmp_path / "lz4.cvol"  # compressed flag, feature header, then a message that claims more bytes than the file has
+    lz4.write_bytes(b"CVOL" + struct.pack("<i3f3i", 1, 1, 1, 1, 1, 1, 0) + struct.pack("<i", 1) + b"d" + struct.pack("<3Q2i", 4, 4, 4, 1, 0) + struct.pack("<i", 1000) + b"\x10a")
     with pytest.raises(capi.FvsrnError, match="LZ4"):
+        capi.Volume.load(str(lz4))
+    lz4.write_bytes(b"CVOL" + struct.pack("<i3f3i", 1, 1, 1, 1, 1, 1, 0) + struct.pack("<i", 1) + b"d" + struct.pack("<3Q2i", 4, 4, 4, 1, 0) + struct.pack("<i", 4) + b"\x0f\x01\x00\x05")
+    with pytest.raises(capi.FvsrnError, match="LZ4"):  # a match that reaches in front of the stream
         capi.Volume.load(str(lz4))
     with pytest.raises(capi.FvsrnError, match="open"):
         capi.Volume.load(str(tmp_path / "missing.cvol"))

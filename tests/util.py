@@ -48,3 +48,49 @@ def golden_to_volnet(d, meta, *, encoding=volnet_io.ENC_FLOAT, box_min=(0.0, 0.0
 
 
 from fvsrn_amd.synthetic import random_network  # noqa: E402,F401  (lives in the package: bench.py uses it too)
+
+
+def lz4_messages(data: bytes, message: int = 65536) -> bytes:
+    """Test-side LZ4 encoder in the framing of compressed .cvol bodies (int32 size + one LZ4 block per message of `message` bytes, matches
+    may reach back into earlier messages: a dependent-block stream like the reference's lz4cpp wrapper writes).  Greedy 4-byte hash matcher;
+    the last 5 bytes of a block are literals and no match starts in its last 12 bytes, as the block format requires."""
+    import struct
+    out, table = bytearray(), {}
+    for base in range(0, len(data), message):
+        end = min(base + message, len(data))
+        blk, i, anchor = bytearray(), base, base
+
+        def emit(lit_from, lit_to, match_len, offset):
+            lit = lit_to - lit_from
+            tok_l, tok_m = min(lit, 15), (min(match_len - 4, 15) if match_len else 0)
+            blk.append((tok_l << 4) | tok_m)
+            if lit >= 15:
+                r = lit - 15
+                while r >= 255:
+                    blk.append(255); r -= 255
+                blk.append(r)
+            blk.extend(data[lit_from:lit_to])
+            if match_len:
+                blk.extend(struct.pack("<H", offset))
+                if match_len - 4 >= 15:
+                    r = match_len - 4 - 15
+                    while r >= 255:
+                        blk.append(255); r -= 255
+                    blk.append(r)
+
+        while i + 12 < end:
+            key = data[i:i + 4]
+            j = table.get(key)
+            table[key] = i
+            if j is not None and 0 < i - j <= 65535:
+                n = 4
+                while i + n < end - 5 and data[j + n] == data[i + n]:
+                    n += 1
+                emit(anchor, i, n, i - j)
+                i += n
+                anchor = i
+            else:
+                i += 1
+        emit(anchor, end, 0, 0)
+        out += struct.pack("<i", len(blk)) + blk
+    return bytes(out)
