@@ -781,7 +781,11 @@ def test_reference_scene_files_render_like_the_oracle(scene):
     ref, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), 48, 48)
     assert ref[3].max() > 0.05, "the scene is empty with this network: the comparison would be vacuous"
     tol = 1.2e-2 if shaded else 3e-3  # (the tolerances of the shaded / unshaded module tests above)
-    assert np.abs(img[:7] - ref[:7]).max() < tol, (scene, float(np.abs(img[:7] - ref[:7]).max()))
+    # a Gaussian TF with sigma 0.016 (ejecta70) turns 1e-4 of density into 1e-2 of opacity: there the bar is the distance between the reference's
+    # own two arithmetic models (fp32 / fp16 accumulation) on this image, like the randomised parity suite of r02
+    ref_h, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_HALF), 48, 48)
+    tol = max(tol, float(np.abs(ref_h[:7] - ref[:7]).max()))
+    assert np.abs(img[:7] - ref[:7]).max() < tol, (scene, float(np.abs(img[:7] - ref[:7]).max()), tol)
     solid = ref[3] > 1e-3
     assert np.array_equal(np.isnan(img[7])[solid], np.isnan(ref[7])[solid])
 
