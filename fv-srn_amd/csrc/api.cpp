@@ -1091,7 +1091,11 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
             a.P.evalTodo = nullptr;
             void* evalTodo = nullptr;
             struct FreeTodo { void*& p; hipStream_t s; ~FreeTodo() { if (p) (void)hipFreeAsync(p, s); } } freeTodo{evalTodo, s};
-            if (net->scaledImage && !adjoint) {
+            // The [0,1]-scaled ReLU image costs a second launch and a per-call list (below): ~9 us.  Measured r04 (32x4, best of interleaved
+            // repetitions, tools/dev/eval_knobs.py): 2^20 points 48 G points/s with it against 83 G on the plain image, 2^22: 93 against 107,
+            // 2^24: 119 against 116, 2^26: 117 against 110 -- the plain image below 2^23 points.
+            const bool scaledPays = net->keyScaled.act != ACT_RELU01 || n >= (size_t(1) << 23);
+            if (net->scaledImage && !adjoint && scaledPays) {
                 evalKey = net->keyScaled;
                 a.P.ldsImage = net->scaledImage;
                 if (!net->packed.scaledBias0Exact) a.P.bias0Folded = 0;  // (a residue of the folded bias sits in the fp32 block: pack.cpp)
@@ -1151,8 +1155,13 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
                 if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !a.P.noFourier && !needsFract && a.P.numLayers >= 1 &&
                     a.P.numLayers <= 3) {
                     // (the Fourier-only kernels need 156 registers: three waves per SIMD fit, and the grid-stride loop profits from them)
-                    const unsigned gridSmall = unsigned(std::min<size_t>(blocks, size_t(net->numCUs) * (smallGrid == 0 ? 12 : 8) / wpb));
-                    e = launch_eval_small(k.act, k.dir, a.P.numLayers, smallGrid, a, gridSmall, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
+                    // (FVSRN_OPT_MAX_BLOCKS_PER_CU on the network: waves per CU of this launch, for occupancy experiments)
+                    const int wavesPerCU = net->opts[FVSRN_OPT_MAX_BLOCKS_PER_CU] > 0 ? net->opts[FVSRN_OPT_MAX_BLOCKS_PER_CU] : (smallGrid == 0 ? 12 : 8);
+                    // four waves per workgroup: the network lives in registers, a workgroup only shares the copy of the image it is loaded from
+                    // (a quarter of the workgroups and LDS copies of a launch: 2^20 points 78 -> 83, 2^22 102 -> 107 G points/s, r04)
+                    const size_t wpbS = net->opts[FVSRN_OPT_WAVES_PER_BLOCK] ? wpb : 4;
+                    const unsigned gridSmall = unsigned(std::min<size_t>((batches + wpbS - 1) / wpbS, size_t(net->numCUs) * size_t(wavesPerCU) / wpbS));
+                    e = launch_eval_small(k.act, k.dir, a.P.numLayers, smallGrid, a, gridSmall, unsigned(64 * wpbS), size_t(net->packed.params.ldsBytes), s);
                 }
             }
             if (e == hipErrorInvalidDeviceFunction)

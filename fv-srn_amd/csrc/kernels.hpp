@@ -42,16 +42,24 @@ __device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* ld
 
 // positions (and directions) of batch b for this lane; lanes beyond n read point 0.  The batch base is wave-uniform (scalar address
 // arithmetic), the lane adds a 32-bit offset: no 64-bit vector arithmetic per point (r02: 18 v_lshl_add_u64 + 6 v_mad_u64_u32 per batch).
+// wave index inside the workgroup in a SCALAR register: threadIdx.x >> 6 is wave-uniform, which the compiler cannot see -- without this the
+// whole batch bookkeeping of evaluate_points (batch index, base addresses, loop bound) is 64-bit vector arithmetic under exec masks
+// (r04: 5 v_lshl_add_u64, 3 v_cmp_*_u64 and 4 exec-mask regions per batch of evaluate_small_kernel)
+__device__ __forceinline__ unsigned wave_in_block() { return unsigned(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))); }
+
 template <bool HAS_DIR>
 __device__ __forceinline__ void load_eval_point(const float* __restrict__ pos, const float* __restrict__ dir, size_t n, size_t b, int lane,
                                                 float (&p)[3], float (&d)[3]) {
-    const size_t first = b * 64;                        // wave-uniform
+    const size_t first = b * 64;                        // wave-uniform (scalar registers: b comes from wave_in_block())
     const unsigned cnt = unsigned(n - first < 64 ? n - first : 64);
     const unsigned j = unsigned(lane) < cnt ? unsigned(lane) : 0u;
-    const float* pb = pos + 3 * first;                  // scalar
-    p[0] = pb[3 * j + 0]; p[1] = pb[3 * j + 1]; p[2] = pb[3 * j + 2];
-    if constexpr (HAS_DIR) { const float* db = dir + 3 * first; d[0] = db[3 * j + 0]; d[1] = db[3 * j + 1]; d[2] = db[3 * j + 2]; }
-    else { d[0] = d[1] = d[2] = 0.f; }
+    const unsigned off = 12u * j;                        // 32-bit byte offset of the lane: SGPR base + VGPR offset loads
+    const char* pb = reinterpret_cast<const char*>(pos + 3 * first);
+    p[0] = *reinterpret_cast<const float*>(pb + off); p[1] = *reinterpret_cast<const float*>(pb + (off + 4u)); p[2] = *reinterpret_cast<const float*>(pb + (off + 8u));
+    if constexpr (HAS_DIR) {
+        const char* db = reinterpret_cast<const char*>(dir + 3 * first);
+        d[0] = *reinterpret_cast<const float*>(db + off); d[1] = *reinterpret_cast<const float*>(db + (off + 4u)); d[2] = *reinterpret_cast<const float*>(db + (off + 8u));
+    } else { d[0] = d[1] = d[2] = 0.f; }
 }
 
 // evaluate_points of a ReLU network runs the weight image whose activations are scaled into [0,1] (pack.cpp: convert + ReLU is one clamped
@@ -62,8 +70,11 @@ __device__ __forceinline__ void load_eval_point(const float* __restrict__ pos, c
 template <int ACT, bool HAS_DIR>
 __device__ __forceinline__ bool eval_batch_deferred(const NetParams& P, size_t b, int lane, float px, float py, float pz, float dx, float dy, float dz) {
     if constexpr (ACT == ACT_RELU01) {
-        bool outside = !(px >= 0.f && px <= 1.f && py >= 0.f && py <= 1.f && pz >= 0.f && pz <= 1.f);
-        if constexpr (HAS_DIR) outside = outside || !(fabsf(dx) <= 1.f && fabsf(dy) <= 1.f && fabsf(dz) <= 1.f);
+        // inside the unit box <=> max |p - 1/2| <= 1/2 (a NaN fails the comparison: outside): three subtractions, one v_max3_f32 with |.|, one compare
+        // (v_max3_f32 drops NaN operands: a NaN coordinate is caught by the unordered compare of the sums; `|` instead of `||`: no exec-mask regions)
+        bool outside = bool(int(!(__builtin_fmaxf(__builtin_fmaxf(fabsf(px - 0.5f), fabsf(py - 0.5f)), fabsf(pz - 0.5f)) <= 0.5f)) | int(__builtin_isunordered(px + py, pz)));
+        if constexpr (HAS_DIR)
+            outside = bool(int(outside) | int(!(__builtin_fmaxf(__builtin_fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) <= 1.f)) | int(__builtin_isunordered(dx + dy, dz)));
         if (__builtin_amdgcn_ballot_w64(outside) != 0) {  // wave-uniform
             if (lane == 0) P.evalTodo[1 + atomicAdd(P.evalTodo, 1u)] = unsigned(b);
             return true;
@@ -75,7 +86,7 @@ __device__ __forceinline__ bool eval_batch_deferred(const NetParams& P, size_t b
 template <int ACT>
 __device__ __forceinline__ size_t eval_batch_index(const NetParams& P, size_t k) {
     if constexpr (ACT != ACT_RELU01) {
-        if (P.evalTodo) return P.evalTodo[1 + k];
+        if (P.evalTodo) return size_t(unsigned(__builtin_amdgcn_readfirstlane(int(P.evalTodo[1 + k]))));
     }
     return k;
 }
@@ -133,13 +144,12 @@ __device__ __forceinline__ void evaluate_body(const NetParams& P, const char* ld
                                               const float* __restrict__ dir, size_t n, float* __restrict__ out, int outChannels) {
     const int lane = lane_id();
     const size_t wavesPerBlock = blockDim.x >> 6;
-    const size_t wave = size_t(blockIdx.x) * wavesPerBlock + (threadIdx.x >> 6);
+    const size_t wave = size_t(blockIdx.x) * wavesPerBlock + wave_in_block();
     const size_t numWaves = size_t(gridDim.x) * wavesPerBlock;
     const size_t batches = eval_batch_count<ACT>(P, n);
-    for (size_t k = wave; k < batches; k += numWaves) {  // wave-uniform trip count: EXEC stays full
+    for (size_t k = wave; k < batches; k += numWaves) {  // wave-uniform trip count (scalar loop control): EXEC stays full
         const size_t b = eval_batch_index<ACT>(P, k);
-        const size_t i = b * 64 + lane;
-        const bool valid = i < n;
+        const bool valid = unsigned(lane) < unsigned(n - b * 64 < 64 ? n - b * 64 : 64);
         float np_[3], nd_[3];  // (the next batch is not fetched ahead here: six more live registers for the wide kernels, +3 % at 32 wide)
         load_eval_point<HAS_DIR>(pos, dir, n, b, lane, np_, nd_);
         float px = np_[0], py = np_[1], pz = np_[2];
@@ -185,7 +195,7 @@ __device__ __forceinline__ void evaluate_gradient_body(const NetParams& P, const
                                                        const float* __restrict__ dir, size_t n, float* __restrict__ out, float gridStep) {
     const int lane = lane_id();
     const size_t wavesPerBlock = blockDim.x >> 6;
-    const size_t wave = size_t(blockIdx.x) * wavesPerBlock + (threadIdx.x >> 6);
+    const size_t wave = size_t(blockIdx.x) * wavesPerBlock + wave_in_block();
     const size_t numWaves = size_t(gridDim.x) * wavesPerBlock;
     const size_t batches = (n + 63) / 64;
     for (size_t b = wave; b < batches; b += numWaves) {
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void evaluate_small_kernel(NetPar
     load_resident(P, lds, R);
     const int lane = lane_id();
     const size_t wavesPerBlock = blockDim.x >> 6;
-    const size_t wave = size_t(blockIdx.x) * wavesPerBlock + (threadIdx.x >> 6);
+    const size_t wave = size_t(blockIdx.x) * wavesPerBlock + wave_in_block();
     const size_t numWaves = size_t(gridDim.x) * wavesPerBlock;
     const size_t batches = eval_batch_count<ACT>(P, n);
     // Two batches of positions in flight per wave (r03): at 90 G points/s the kernel streams 1.4 TB/s of positions and values; with one
@@ -244,8 +254,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void evaluate_small_kernel(NetPar
     if (wave + numWaves < batches) load_eval_point<HAS_DIR>(pos, dir, n, eval_batch_index<ACT>(P, wave + numWaves), lane, nq_, ne_);
     for (size_t k = wave; k < batches; k += numWaves) {
         const size_t b = eval_batch_index<ACT>(P, k);
-        const size_t i = b * 64 + lane;
-        const bool valid = i < n;
+        const bool valid = unsigned(lane) < unsigned(n - b * 64 < 64 ? n - b * 64 : 64);
         float px = np_[0], py = np_[1], pz = np_[2];
         const float dx = nd_[0], dy = nd_[1], dz = nd_[2];
 #pragma unroll
