@@ -422,7 +422,7 @@ struct fvsrn_network {
         if (!kernel_info(key, &kinfo))
             throw Unsupported("no ahead-of-time kernel for hidden width " + std::to_string(packed.cfg.hiddenChannels) +
                               ", activation " + activationName(packed.cfg.activation) +
-                              (key.dir ? ", with view direction" : "") + " (compiled: widths 32/48/64/96/128)");
+                              (key.dir ? ", with view direction" : "") + " (compiled: widths 16 .. 128 in steps of 16)");
         keyScaled = key;
         kinfoScaled = kinfo;
         if (!packed.ldsImageScaled.empty() && opts[FVSRN_OPT_RELU_CLAMP]) {  // ACT_RELU01 / ACT_SNAKEALT0 image (pack.cpp)

@@ -22,7 +22,8 @@ constexpr int kBlockThreads = 256;  // upper bound (launch bounds)
 constexpr int min_waves_per_simd(int CD, int GRID) {
     // 32 wide: Fourier-only and decoded-grid kernels fit the 168 registers of 3 waves per SIMD (r02, 32x4 + 16^3 grid: gathers hoisted
     // in front of the Fourier work, GridPre: 2 waves 66.8, 3 waves 69.5 Gsamples/s; without the hoist 68.5); BYTE_GAUSSIAN would spill
-    return CD >= 8 ? 1 : (CD == 2 ? (GRID == 0 ? FVSRN_WAVES_PER_EU_CD2 : (GRID == 1 ? FVSRN_WAVES_PER_EU_CD2_GRID : FVSRN_WAVES_PER_EU)) : FVSRN_WAVES_PER_EU);
+    // (112 channels with a latent grid spill at 256 registers like 128: one wave per SIMD from 112 on)
+    return CD >= 7 ? 1 : (CD == 2 ? (GRID == 0 ? FVSRN_WAVES_PER_EU_CD2 : (GRID == 1 ? FVSRN_WAVES_PER_EU_CD2_GRID : FVSRN_WAVES_PER_EU)) : FVSRN_WAVES_PER_EU);
 }
 // __launch_bounds__(256, 2): at most 256 registers per lane, which also makes hipcc use the VGPR form of the MFMA
 // (accumulators in AGPRs cost one v_accvgpr_read per value before the VALU can touch them: +32 VALU per layer).
@@ -419,7 +420,7 @@ __device__ __forceinline__ float select_by_mask(unsigned long long m, float x) {
 // SCHED: srn_layers' schedule (1: fragment-major for every width, render_stripe_kernel)
 // SHADED: 0 = plain renderer; 1 = render_shaded_kernel (finite differences / predicted gradients / BRDF, and the adjoint mode at 96 and
 // 128 channels); 2 = render_adjoint_kernel (up to 64 channels, adjoint mode only, see there)
-constexpr bool adjoint_in_its_own_kernel(int CD) { return CD <= 4; }
+constexpr bool adjoint_in_its_own_kernel(int CD) { return CD >= 2 && CD <= 4; }  // (render_adjoint_kernel is built for 32 / 48 / 64 channels)
 template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, int SHADED, int TAIL = TAIL_GENERIC, int NLC = 0, int SCHED = 0>
 __device__ __forceinline__ void render_body(const NetParams& P, const SceneParams& S, const char* lds, const float* tfLds,
                                             float* __restrict__ out, unsigned long long* __restrict__ stats) {
@@ -923,7 +924,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void render_small_kernel(NetParam
 
 // finite-difference normals / shading BRDF (SceneParams::gradientMode, brdf*): 7 network evaluations per sample
 template <int CD, int ACT, int GRID, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads, (CD >= 8 ? 1 : 2)) void render_shaded_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+// (r04: 80 and 112 channels spill > 1000 registers at the 256 of two waves per SIMD: one wave; 96 keeps the two it was measured with)
+__global__ __launch_bounds__(kBlockThreads, ((CD >= 7 || CD == 5) ? 1 : 2)) void render_shaded_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                unsigned long long* __restrict__ stats) {
     render_entry<CD, ACT, GRID, HAS_DIR, 1>(P, S, out, stats);
 }

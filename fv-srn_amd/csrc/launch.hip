@@ -296,10 +296,13 @@ hipError_t launch_grid_blend(const BlendParams& p, hipStream_t s) {
 
 #define FVSRN_DISPATCH_CD(expr_prefix, ...)          \
     switch (k.CD) {                                  \
+        case 1: return expr_prefix<1>(__VA_ARGS__);  \
         case 2: return expr_prefix<2>(__VA_ARGS__);  \
         case 3: return expr_prefix<3>(__VA_ARGS__);  \
         case 4: return expr_prefix<4>(__VA_ARGS__);  \
+        case 5: return expr_prefix<5>(__VA_ARGS__);  \
         case 6: return expr_prefix<6>(__VA_ARGS__);  \
+        case 7: return expr_prefix<7>(__VA_ARGS__);  \
         case 8: return expr_prefix<8>(__VA_ARGS__);  \
         default: break;                              \
     }

@@ -154,8 +154,10 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
     P.cfg = net.config();
     const NetworkConfig& c = P.cfg;
     const int C = c.hiddenChannels;
-    if (C != 32 && C != 48 && C != 64 && C != 96 && C != 128)
-        throw Unsupported("hidden width " + std::to_string(C) + " is not in the compiled variant set (32,48,64,96,128)");
+    // every multiple of 16 up to 128 (volume_interpolation_network.cpp:1177-1181 accepts any multiple of 16; wider networks do not fit the
+    // reference's 48 KiB of shared memory with more than one hidden layer either, computeMaxWarps :987-1057)
+    if (C < 16 || C > 128 || C % 16 != 0)
+        throw Unsupported("hidden width " + std::to_string(C) + " is not in the compiled variant set (16, 32, ..., 128)");
     if (c.gridChannels % 16 != 0) throw InvalidNetwork("latent grid channels must be a multiple of 16");
     const int MT = (C + 31) / 32, KS = C / 16, KG = c.gridChannels / 16, KS0 = KS + KG;
     // C->C layers: hidden[L0] (behind Fourier features, or the latent-grid layer) .. hidden[L0+NL-1]; hidden.back() is the
@@ -486,8 +488,10 @@ PackedNetwork packNetwork(const SceneNetwork& net) {
 // padded FLOPs per sample that the kernels issue to the matrix cores, from the tiling alone (no packing)
 double mfmaFlopsPerSample(const NetworkConfig& c, int numLinearLayers) {
     const int C = c.hiddenChannels;
-    if (C != 32 && C != 48 && C != 64 && C != 96 && C != 128)
-        throw Unsupported("hidden width " + std::to_string(C) + " is not in the compiled variant set (32,48,64,96,128)");
+    // every multiple of 16 up to 128 (volume_interpolation_network.cpp:1177-1181 accepts any multiple of 16; wider networks do not fit the
+    // reference's 48 KiB of shared memory with more than one hidden layer either, computeMaxWarps :987-1057)
+    if (C < 16 || C > 128 || C % 16 != 0)
+        throw Unsupported("hidden width " + std::to_string(C) + " is not in the compiled variant set (16, 32, ..., 128)");
     const int MT = (C + 31) / 32, KS = C / 16, KG = c.gridChannels / 16, KS0 = KS + KG;
     const int NL = numLinearLayers - 1 - (c.hasFourier ? 0 : 1);
     // 32x32x16: 32768 FLOP per 32 samples; the last layer runs 16x16x32 MFMAs (16384 FLOP per 32 samples)

@@ -941,7 +941,7 @@ __device__ __forceinline__ float4_t srn_layers(const NetParams& P, const char* l
     // measured (r01, 1024^2 x 512): the pipelined order wins for Fourier-only networks (32x4: 106.7 -> 110.3 Gsamples/s) and
     // for 64-wide latent-grid networks (23.1 -> 23.9); for 32-wide ones with a grid its extra registers cost more
     // occupancy than the schedule gains (64.2 -> 62.2)
-    if constexpr (SCHED == 0 && CD <= 4 && (GRID == 0 || CD >= 3)) {
+    if constexpr (SCHED == 0 && CD >= 2 && CD <= 4 && (GRID == 0 || CD >= 3)) {  // (16 channels: one K step, the fragment-major order)
         if constexpr (MAYBE_NO_LAYERS) {
             if (P.numLayers == 0)  // wave-uniform
                 return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill, gpre);

@@ -357,6 +357,13 @@ def generate():
         ("g1_c128l3_grid16r8_relu_density", dict(layers="128:128", activation="ReLU", outputmode="density", gc=16, gr=8)),
         ("g1_c128l2_grid32r8_sine_rgbo-direct", dict(layers="128", activation="Sine:1", outputmode="rgbo:direct", gc=32, gr=8)),
         ("g1_dir2_c96l3_snake_density", dict(layers="96:96", activation="Snake:2", outputmode="density", use_direction=True, direction_in_fourier=True)),
+        # the remaining multiples of 16 the reference accepts (volume_interpolation_network.cpp:1177-1181): 16, 80, 112 channels
+        ("g1_c16l3_snakealt_density", dict(layers="16:16", activation="SnakeAlt:1", outputmode="density")),
+        ("g1_c16l4_grid16r8_relu_rgbo", dict(layers="16:16:16", activation="ReLU", outputmode="rgbo", gc=16, gr=8)),
+        ("g1_c80l3_relu_density-direct", dict(layers="80:80", activation="ReLU", outputmode="density:direct")),
+        ("g1_c80l3_grid16r8_sine_rgbo", dict(layers="80:80", activation="Sine:1", outputmode="rgbo", gc=16, gr=8)),
+        ("g1_c112l2_snake_density", dict(layers="112", activation="Snake:2", outputmode="density")),
+        ("g1_c112l3_grid16r8_relu_density-direct", dict(layers="112:112", activation="ReLU", outputmode="density:direct", gc=16, gr=8)),
     ]:
         C = int(kw["layers"].split(":")[0])
         extra = {k: kw[k] for k in ("use_direction", "direction_in_fourier") if k in kw}

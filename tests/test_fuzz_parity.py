@@ -19,9 +19,9 @@ TOL_IMG = 3e-3  # the image tolerance of test_gpu_parity.py
 def draw_case(seed):
     rng = np.random.RandomState(1000 + seed)
     C = int(rng.choice([32, 32, 48, 64]))
-    wide = int(seed) >= 1000  # r04: seeds from 1000 on are 96 / 128 wide (the seeds below keep their r02 / r03 draws)
+    wide = int(seed) >= 1000  # r04: seeds from 1000 on are 96 / 128 wide, from 1100 on 16 / 80 / 112 (the seeds below keep their r02 / r03 draws)
     if wide:
-        C = 96 if int(seed) % 2 == 0 else 128
+        C = (96 if int(seed) % 2 == 0 else 128) if int(seed) < 1100 else (16, 80, 112)[int(seed) % 3]
     layers = int(rng.randint(2, 6))
     act = str(rng.choice(["ReLU", "SnakeAlt", "Sine", "Snake", "Sigmoid"]))
     out = str(rng.choice(["density", "density:direct", "rgbo", "rgbo:direct", "densitygrad"]))
@@ -137,7 +137,7 @@ def test_random_scene_matches_oracle(seed):
 
 
 # r04: the 96- and 128-wide kernels (render_kernel<6|8,...>; the reference's (96, 3) / (128, 2) study networks, eval_NetworkConfigsGrid.py:36)
-@pytest.mark.parametrize("seed", range(1000, 1012))
+@pytest.mark.parametrize("seed", list(range(1000, 1012)) + list(range(1100, 1112)))
 def test_random_wide_scene_matches_oracle(seed):
     check_case(compare_case(seed))
 

@@ -72,7 +72,8 @@ def test_time_and_ensemble_golden(name):
 
 # (96 / 128 channels: a gaussian Fourier matrix -- the NeRF ladder of 46 features reaches 2^14, outside the half range)
 @pytest.mark.parametrize("net_kw", [dict(C=32, layers=4), dict(C=96, layers=3, fourier_std=0.5), dict(C=128, layers=2, grid=(16, 8), fourier_std=0.5),
-                                    dict(C=96, layers=3, grid=(16, 8), activation="ReLU", fourier_std=0.5)],
+                                    dict(C=96, layers=3, grid=(16, 8), activation="ReLU", fourier_std=0.5), dict(C=16, layers=4, fourier_std=0.5),
+                                    dict(C=80, layers=3, grid=(16, 8), fourier_std=0.5), dict(C=112, layers=3, activation="ReLU", fourier_std=0.5)],
                          ids=lambda k: "c%d%s%s" % (k["C"], "grid" if "grid" in k else "", k.get("activation", "")))
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000, 4097])
 def test_evaluate_ragged_sizes(n, net_kw):
@@ -262,6 +263,13 @@ TEX_TF = np.stack([np.linspace(0, 1, 32), np.linspace(1, 0, 32) ** 2, np.full(32
     dict(act="SnakeAlt", out="rgbo", C=128, layers=2, tf=dict(tf_kind=oracle.TF_NONE)),
     dict(act="ReLU", out="density", C=128, layers=3, grid=(16, 8), tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)),
     dict(act="ReLU", out="density:direct", C=96, layers=3, grid=(32, 8), tf=dict(tf_kind=oracle.TF_TEXTURE, tf_table=TEX_TF)),
+    # ... and 16 / 80 / 112 channels (the other multiples of 16 the reference accepts)
+    dict(act="SnakeAlt", out="density", C=16, layers=4, tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)),
+    dict(act="ReLU", out="rgbo", C=16, layers=3, grid=(16, 8), tf=dict(tf_kind=oracle.TF_NONE)),
+    dict(act="ReLU", out="density", C=80, layers=3, grid=(16, 8), tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)),
+    dict(act="Sine", out="density", C=80, layers=3, tf=dict(tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=20.0, tf_scale_emission=1.0)),
+    dict(act="SnakeAlt", out="density", C=112, layers=3, grid=(16, 8), tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)),
+    dict(act="ReLU", out="rgbo:direct", C=112, layers=2, tf=dict(tf_kind=oracle.TF_NONE)),
     # predicted gradients (normal channels 4..6 of the image) and the 6-output curvature modes
     dict(act="SnakeAlt", out="densitygrad", tf=dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)),
     dict(act="ReLU", out="densitygrad:direct", tf=dict(tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=30.0, density_min=-1.0, density_max=1.0)),

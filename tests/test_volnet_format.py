@@ -152,11 +152,11 @@ def test_invalid_inputs_are_rejected_with_messages():
 
 def test_unsupported_variants_fail_loudly():
     rng = np.random.RandomState(0)
-    # a hidden width outside the ahead-of-time matrix (32/48/64/96/128)
+    # a hidden width outside the ahead-of-time matrix (16 .. 128 in steps of 16: what the reference's 48 KiB of shared memory can hold)
     net = capi.Network.create()
-    net.set_input(rng.randn(38, 3).astype(np.float32))
-    net.add_layer(rng.randn(80, 79), rng.randn(80), "ReLU")
-    net.add_layer(rng.randn(1, 80), rng.randn(1), "None")
+    net.set_input(rng.randn(70, 3).astype(np.float32))
+    net.add_layer(rng.randn(144, 143), rng.randn(144), "ReLU")
+    net.add_layer(rng.randn(1, 144), rng.randn(1), "None")
     assert net.valid()
     with pytest.raises(capi.FvsrnError) as e:
         net.kernel_name()
@@ -168,6 +168,13 @@ def test_unsupported_variants_fail_loudly():
     net.add_layer(rng.randn(32, 31), rng.randn(32), "Sigmoid")
     net.add_layer(rng.randn(1, 32), rng.randn(1), "None")
     assert net.valid() and "evaluate_kernel<2,ACT_SIGMOID" in net.kernel_name(False)
+    # r04: 16, 80 and 112 channels are compiled in as well
+    for C in (16, 80, 112):
+        net = capi.Network.create()
+        net.set_input(rng.randn((C - 4) // 2, 3).astype(np.float32))
+        net.add_layer(rng.randn(C, C - 1), rng.randn(C), "ReLU")
+        net.add_layer(rng.randn(1, C), rng.randn(1), "None")
+        assert net.valid() and ("evaluate_kernel<%d," % (C // 16)) in net.kernel_name(False)
 
 
 def test_curvature_and_no_fourier_networks_select_a_kernel():
