@@ -262,7 +262,8 @@ def check(only):
         OUT = committed
         bad = []
         made = sorted(os.path.basename(f) for f in glob.glob(os.path.join(tmp, "*.npz")))
-        have = sorted(os.path.basename(f) for f in glob.glob(os.path.join(committed, "*.npz")) if not only or any(
+        # (g<k>_*.npz: the fixtures of THIS generator; cvol_*.npz belongs to make_cvol_fixture.py)
+        have = sorted(os.path.basename(f) for f in glob.glob(os.path.join(committed, "g[0-9]*_*.npz")) if not only or any(
             os.path.basename(f).startswith(o) for o in only))
         if made != have:
             bad.append("fixture sets differ: generated %s, committed %s" % (sorted(set(made) - set(have)), sorted(set(have) - set(made))))

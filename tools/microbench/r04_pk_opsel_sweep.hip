@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(256) victim(const float* in, unsigned* bad, in
             if constexpr (OP == 1) asm volatile("v_pk_add_f32 v[10:11], %[p], %[q] op_sel:[" #A "," #B "] op_sel_hi:[" #C "," #D "]\n s_nop 7" : "=&{v[10:11]}"(r) : [p] "v"(p), [q] "v"(q)); \
             if constexpr (OP == 2) asm volatile("v_pk_fma_f32 v[10:11], %[p], %[q], %[t] op_sel:[" #A "," #B ",0] op_sel_hi:[" #C "," #D ",1]\n s_nop 7" : "=&{v[10:11]}"(r) : [p] "v"(p), [q] "v"(q), [t] "v"(t2)); \
             if constexpr (OP == 3) asm volatile("v_pk_fma_f32 v[10:11], %[p], %[q], %[t] op_sel:[" #A "," #B ",1] op_sel_hi:[" #C "," #D ",0]\n s_nop 7" : "=&{v[10:11]}"(r) : [p] "v"(p), [q] "v"(q), [t] "v"(t2)); \
+            if constexpr (OP == 4) asm volatile("v_pk_mov_b32 v[10:11], %[p], %[q] op_sel:[" #A "," #B "]\n s_nop 7" : "=&{v[10:11]}"(r) : [p] "v"(p), [q] "v"(q)); \
         }
         COMBOS(X)
 #undef X
@@ -67,11 +68,12 @@ __global__ void __launch_bounds__(256) victim(const float* in, unsigned* bad, in
         if constexpr (OP == 0) { el = safe_mul(pl, ql); eh = safe_mul(ph, qh); }
         else if constexpr (OP == 1) { el = safe_add(pl, ql); eh = safe_add(ph, qh); }
         else if constexpr (OP == 2) { el = safe_fma(pl, ql, t2[0]); eh = safe_fma(ph, qh, t2[1]); }
-        else { el = safe_fma(pl, ql, t2[1]); eh = safe_fma(ph, qh, t2[0]); }
+        else if constexpr (OP == 3) { el = safe_fma(pl, ql, t2[1]); eh = safe_fma(ph, qh, t2[0]); }
+        else { el = p[a]; eh = q[b]; }  // v_pk_mov_b32: D.lo = src0[op_sel[0]], D.hi = src1[op_sel[1]]
         if (__float_as_uint(r[0]) != __float_as_uint(el)) {  // what IS the wrong low result?
             ++wl;
             float dflt;  // the default selection {p0, q0}
-            if constexpr (OP == 0) dflt = safe_mul(p[0], q[0]); else if constexpr (OP == 1) dflt = safe_add(p[0], q[0]); else dflt = safe_fma(p[0], q[0], t2[OP == 3]);
+            if constexpr (OP == 0) dflt = safe_mul(p[0], q[0]); else if constexpr (OP == 1) dflt = safe_add(p[0], q[0]); else if constexpr (OP == 4) dflt = p[0]; else dflt = safe_fma(p[0], q[0], t2[OP == 3]);
             cz += r[0] == 0.f;
             cprev += __float_as_uint(r[0]) == __float_as_uint(prevl);
             cdef += __float_as_uint(r[0]) == __float_as_uint(dflt);
@@ -106,11 +108,11 @@ int main(int argc, char** argv) {
     hipMemcpy(d, h.data(), 4096 * 4, hipMemcpyHostToDevice);
     hipStream_t sa, sb;
     hipStreamCreateWithFlags(&sa, hipStreamNonBlocking); hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
-    static const char* ops[] = {"v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32", "v_pk_fma_f32 (src2 crossed: op_sel[2] = 1, op_sel_hi[2] = 0)"};
+    static const char* ops[] = {"v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32", "v_pk_fma_f32 (src2 crossed: op_sel[2] = 1, op_sel_hi[2] = 0)", "v_pk_mov_b32 (op_sel only; op_sel_hi ignored)"};
     printf("%llu checks per cell and quarter of the wave; wrong low / high results in lanes 0-47 and in lanes 48-63\n", 1024ull * 64 * iters);
     for (int kind = 0; kind < 3; ++kind) {
         printf("---- neighbour waves: %s\n", kNeighbour[kind]);
-        for (int op = 0; op < 4; ++op)
+        for (int op = 0; op < 5; ++op)
             for (int combo = 0; combo < 16; ++combo) {
                 hipMemset(bad, 0, 64);
                 hipDeviceSynchronize();
@@ -119,7 +121,7 @@ int main(int argc, char** argv) {
                     case 1: hipLaunchKernelGGL(neighbour<1>, dim3(512), dim3(256), 0, sb, 100ll * 1000 * 30, sink); break;
                     default: hipLaunchKernelGGL(neighbour<2>, dim3(512), dim3(256), 0, sb, 100ll * 1000 * 30, sink); break;
                 }
-                if (op == 0) run_victim<0>(combo, d, bad, iters, sa); else if (op == 1) run_victim<1>(combo, d, bad, iters, sa); else if (op == 2) run_victim<2>(combo, d, bad, iters, sa); else run_victim<3>(combo, d, bad, iters, sa);
+                if (op == 0) run_victim<0>(combo, d, bad, iters, sa); else if (op == 1) run_victim<1>(combo, d, bad, iters, sa); else if (op == 2) run_victim<2>(combo, d, bad, iters, sa); else if (op == 3) run_victim<3>(combo, d, bad, iters, sa); else run_victim<4>(combo, d, bad, iters, sa);
                 hipDeviceSynchronize();
                 unsigned b[16]; hipMemcpy(b, bad, 64, hipMemcpyDeviceToHost);
                 const unsigned lo47 = b[0] + b[2] + b[4], hi47 = b[1] + b[3] + b[5];

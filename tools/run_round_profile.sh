@@ -1,11 +1,15 @@
 #!/bin/bash
 # usage (GPU box): tools/run_round_profile.sh <round tag>      everything the round's profiles/ directory is built from -> gpurun_out/
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-V=${1:-r03}
+V=${1:-r04}
 python -m pytest tests -m gpu -x -q 2>&1 | tail -1
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep "smoke" > gpurun_out/smoke_${V}.txt
 grep "2-rank line" gpurun_out/smoke_${V}.txt | sed 's/^smoke 2-rank line: //' > gpurun_out/two_rank_gloo_${V}.json
 python bench.py > gpurun_out/bench_${V}.json 2> gpurun_out/bench_${V}.err
+python bench.py --activation SnakeAlt --no-cpu-baseline > gpurun_out/bench_${V}_snakealt.json 2>/dev/null
+# the RCCL route on one GPU (one-rank process group, compact stripes + all_gather_into_tensor + assemble; per-rank render / gather times)
+python bench.py --force-collective --no-twin --no-cpu-baseline > gpurun_out/bench_${V}_force_collective_nccl.json 2>/dev/null
+python bench.py --force-collective --no-twin --no-cpu-baseline --config c64l6_grid16_time16_1024x512 > gpurun_out/bench_${V}_force_collective_nccl_c64l6_time16.json 2>/dev/null
 for c in c32l4_fourier_512x256 c32l4_grid16_1024x512 c64l6_grid16_1024x512 c64l6_grid16_time16_1024x512; do python bench.py --config $c --no-cpu-baseline > gpurun_out/bench_${V}_$c.json 2>/dev/null; done
 for c in c32l4_fourier_1024x512 c32l4_grid16_1024x512 c64l6_grid16_1024x512; do tools/pmc_profile.sh ${c}_${V} --config $c > /dev/null 2>&1; done
 tools/pmc_profile.sh c32l4_fourier_snakealt_1024x512_${V} --config c32l4_fourier_1024x512 --activation SnakeAlt > /dev/null 2>&1
@@ -36,11 +40,12 @@ if [ -f tools/dev/bin/liboccupy.so ]; then
 fi
 python tools/bench_grid_volume.py > gpurun_out/grid_volume_bench_${V}.json 2>/dev/null
 python tools/bench_tail_variants.py 2>/dev/null | grep -v amdgpu > gpurun_out/tail_variants_${V}.txt
-[ -x tools/microbench/bin/r03_snakealt ] && tools/microbench/bin/r03_snakealt 2>&1 | grep -v amdgpu.ids > gpurun_out/snakealt_microbench_${V}.txt
 python tools/dev/stress_concurrent.py 100 2>&1 | grep -v amdgpu.ids > gpurun_out/stress_concurrent_${V}.txt
+python tools/dev/eval_knobs.py 2>&1 | grep -v amdgpu.ids > gpurun_out/evaluate_knobs_${V}.txt
 python tools/dev/determinism.py 30 2>&1 | grep -v amdgpu.ids > gpurun_out/determinism_${V}.txt
 python tests/test_fuzz_parity.py 400 > gpurun_out/fuzz_report_gpu_vs_device_model_${V}.txt 2>/dev/null
 for f in gpurun_out/bench_${V}*.json; do python -c "
 import json,sys
 d=json.load(open('$f'))
 print(d['config']['workload'].split(':')[0], '%.2f G %.3f ms frac %.3f' % (d['value']/1e9, d['ms_per_step'], d['roofline']['frac']), 'twin %.2f' % (d['twin']['value']/1e9) if d.get('twin') else '', 'exact %.2f' % (d['exact_features']['value']/1e9) if d.get('exact_features') else '', d.get('cpu_baseline',{}).get('value'))"; done
+rm -rf gpurun_out/prof_*   # (the summaries above are what is kept; the raw traces would overflow the 64 MiB that travel back)
