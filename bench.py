@@ -315,6 +315,16 @@ def launch_ranks(n, argv, child=None):
     return tiles.launch_ranks(n, argv, script=os.path.abspath(__file__), child=child)
 
 
+def only_the_json_line_on_stdout():
+    """Everything this process and its libraries write to file descriptor 1 goes to stderr from here on -- RCCL prints a version banner with
+    C stdio when a communicator comes up (measured r04: five lines behind the JSON line) -- and the returned stream is the real stdout, for the
+    ONE JSON line of the contract."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -343,6 +353,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # started plainly with --gpus N: this process becomes the launcher of N rank processes and never touches a GPU itself
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    json_out = only_the_json_line_on_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -484,7 +495,8 @@ def main():
             out["exact_features"] = exact
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args.activation)
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if collective:
         import torch.distributed as dist
         dist.barrier()
