@@ -60,7 +60,7 @@ class SceneDesc(C.Structure):
 # fvsrn_option (include/fvsrn.h): tuning / developer switches of a handle
 OPTIONS = {"small_kernel": 0, "persistent": 1, "depth_segments": 2, "fourier_resync": 3, "unit_quota": 4, "tile_order": 5,
            "waves_per_block": 6, "max_blocks_per_cu": 7, "relu_clamp": 8, "keyframe_slots": 9, "working_grids": 10, "overlap_kernel": 11,
-           "persistent_reserve": 12}
+           "persistent_reserve": 12, "cell_table": 13}
 ERR_WRONG_DEVICE = -8
 
 GRADIENT_OFF_OR_DIRECT, GRADIENT_FINITE_DIFFERENCES, GRADIENT_ADJOINT_METHOD = 0, 1, 2
@@ -443,7 +443,7 @@ class Scene:
         """How the last render of this scene treated a ray's samples (fvsrn_scene_last_render_info)."""
         a = (_I * 4)()
         _check(lib().fvsrn_scene_last_render_info(self._h, a))
-        return dict(segments=a[0], rotation_resync=a[1], resident_kernel=a[2] == 1, overlap_kernel=a[2] == 2, adjoint_kernel=a[2] == 3,
+        return dict(segments=a[0], rotation_resync=a[1], resident_kernel=a[2] in (1, 4), overlap_kernel=a[2] == 2, adjoint_kernel=a[2] == 3, cell_table=a[2] == 4,
                     waves_per_block=a[3])
 
     def __del__(self):

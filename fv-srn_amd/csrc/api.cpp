@@ -30,13 +30,13 @@ struct Options {
         v[FVSRN_OPT_SMALL_KERNEL] = -1; v[FVSRN_OPT_PERSISTENT] = -1; v[FVSRN_OPT_DEPTH_SEGMENTS] = 0; v[FVSRN_OPT_FOURIER_RESYNC] = 0;
         v[FVSRN_OPT_UNIT_QUOTA] = -1; v[FVSRN_OPT_TILE_ORDER] = -1; v[FVSRN_OPT_WAVES_PER_BLOCK] = 0; v[FVSRN_OPT_MAX_BLOCKS_PER_CU] = 0;
         v[FVSRN_OPT_RELU_CLAMP] = 1; v[FVSRN_OPT_KEYFRAME_SLOTS] = 0; v[FVSRN_OPT_WORKING_GRIDS] = 0; v[FVSRN_OPT_OVERLAP_KERNEL] = -1;
-        v[FVSRN_OPT_PERSISTENT_RESERVE] = -1;
+        v[FVSRN_OPT_PERSISTENT_RESERVE] = -1; v[FVSRN_OPT_CELL_TABLE] = -1;
     }
     int operator[](int i) const { return v[i]; }
     // empty string = valid
     static std::string check(int opt, int value) {
         switch (opt) {
-            case FVSRN_OPT_SMALL_KERNEL: case FVSRN_OPT_PERSISTENT: case FVSRN_OPT_TILE_ORDER: case FVSRN_OPT_OVERLAP_KERNEL:
+            case FVSRN_OPT_SMALL_KERNEL: case FVSRN_OPT_PERSISTENT: case FVSRN_OPT_TILE_ORDER: case FVSRN_OPT_OVERLAP_KERNEL: case FVSRN_OPT_CELL_TABLE:
                 return value >= -1 && value <= 1 ? "" : "value must be -1 (automatic), 0 or 1";
             case FVSRN_OPT_DEPTH_SEGMENTS: return value >= 0 && value <= 64 ? "" : "segments must be 0 (automatic) .. 64";
             case FVSRN_OPT_FOURIER_RESYNC:
@@ -61,7 +61,7 @@ static const Options& defaultOptions() {
             {"FVSRN_FOURIER_RESYNC", FVSRN_OPT_FOURIER_RESYNC}, {"FVSRN_UNIT_QUOTA", FVSRN_OPT_UNIT_QUOTA}, {"FVSRN_TILE_ORDER", FVSRN_OPT_TILE_ORDER},
             {"FVSRN_WAVES_PER_BLOCK", FVSRN_OPT_WAVES_PER_BLOCK}, {"FVSRN_MAX_BLOCKS_PER_CU", FVSRN_OPT_MAX_BLOCKS_PER_CU},
             {"FVSRN_KEYFRAME_SLOTS", FVSRN_OPT_KEYFRAME_SLOTS}, {"FVSRN_WORKING_GRIDS", FVSRN_OPT_WORKING_GRIDS}, {"FVSRN_OVERLAP_KERNEL", FVSRN_OPT_OVERLAP_KERNEL},
-            {"FVSRN_PERSISTENT_RESERVE", FVSRN_OPT_PERSISTENT_RESERVE}};
+            {"FVSRN_PERSISTENT_RESERVE", FVSRN_OPT_PERSISTENT_RESERVE}, {"FVSRN_CELL_TABLE", FVSRN_OPT_CELL_TABLE}};
         for (const auto& e : kEnv)
             if (const char* t = std::getenv(e.name)) {
                 const int val = std::atoi(t);
@@ -367,9 +367,10 @@ struct fvsrn_network {
     // (grid_blend_kernel).  Two of them for networks with more than one key frame: the blend of frame i + 1 writes the grid that
     // frame i does NOT read, so a caller may keep two frames in flight on two streams (tiles.StripeRenderer, BASELINE.json
     // configs[4]); `order` makes a blend wait for every kernel that still reads the grid it overwrites, on whatever stream.
-    struct WorkingGrid { DeviceBuffer a, b; StreamOrder order; };
+    struct WorkingGrid { DeviceBuffer a, b, cells; StreamOrder order; };  // cells: the grid's cell table (NetParams::cellTable), rebuilt with every blend
     WorkingGrid workGrid[2];
     int numWorkGrids = 1, curWorkGrid = 0;
+    size_t cellTableBytes = 0;  // 0: no cell table (no grid, BYTE_GAUSSIAN, a resolution below 2, above the size cap, FVSRN_OPT_CELL_TABLE = 0)
     StreamOrder imagesOrder;  // weight images, ensemble key frames, decode coefficients: written at first use
     // streams that have launched kernels reading the images (handles only: recording an event behind every launch cost 3 % of a 0.3 ms
     // frame, r03): a re-pack of a live network waits for THESE streams, not for the device (hipDeviceSynchronize stalled the
@@ -482,10 +483,21 @@ struct fvsrn_network {
             const int wantGrids = opts[FVSRN_OPT_WORKING_GRIDS] ? opts[FVSRN_OPT_WORKING_GRIDS] : (K.timeNum > 1 || K.ensNum > 1 ? 2 : 1);
             numWorkGrids = wantGrids;
             curWorkGrid = 0;
+            // Cell table (device_params.hpp): 512 bytes per cell and M tile; grids whose table would pass 1 GiB keep the gather path
+            cellTableBytes = 0;
+            {
+                const NetParams& np = packed.params;
+                const double cells = double(np.gridX - 1) * double(np.gridY - 1) * double(np.gridZ - 1);
+                const int MT = (packed.cfg.hiddenChannels + 31) / 32;
+                if (opts[FVSRN_OPT_CELL_TABLE] != 0 && K.enc != FVSRN_GRID_BYTE_GAUSSIAN && np.gridX >= 2 && np.gridY >= 2 && np.gridZ >= 2 &&
+                    np.numLayers >= 1 && cells * 512.0 * MT <= 1073741824.0)
+                    cellTableBytes = size_t(cells) * 512 * size_t(MT);
+            }
             for (int i = 0; i < 2; ++i) {
-                if (i >= numWorkGrids) { workGrid[i].a.release(); workGrid[i].b.release(); continue; }
+                if (i >= numWorkGrids) { workGrid[i].a.release(); workGrid[i].b.release(); workGrid[i].cells.release(); continue; }
                 workGrid[i].a.ensure(K.records * size_t(K.Gt + K.Ge) * 2 * 2);
                 if (K.enc == FVSRN_GRID_BYTE_GAUSSIAN) workGrid[i].b.ensure(K.records * size_t(K.Gt + K.Ge) * 2 * 2);
+                if (cellTableBytes) workGrid[i].cells.ensure(cellTableBytes); else workGrid[i].cells.release();
             }
             packed.params.grid = workGrid[0].a.ptr;
             packed.params.gridB = K.enc == FVSRN_GRID_BYTE_GAUSSIAN ? workGrid[0].b.ptr : nullptr;
@@ -493,7 +505,10 @@ struct fvsrn_network {
             packed.params.gridTimeChannels = K.Gt;
         } else {
             packed.params.grid = nullptr;
+            cellTableBytes = 0;
         }
+        packed.params.cellTable = nullptr;
+        packed.params.cellStride = packed.params.cellCount = 0;
         timeDirty = true;
         imagesOrder.endWrite(stream);  // launches on other streams wait for the uploads above (beginUse)
         // the staging vectors are pageable: the copies above complete before hipMemcpyAsync returns
@@ -529,6 +544,20 @@ struct fvsrn_network {
             b.out = W.a.ptr; b.outB = W.b.ptr; b.records = K.records; b.enc = int(K.enc); b.Gt = K.Gt; b.Ge = K.Ge;
             b.lo = g.lo; b.hi = g.hi; b.ens = g.ens; b.frac = g.frac;
             HIP_CHECK(launch_grid_blend(b, stream));
+            if (cellTableBytes) {
+                // the table of the image the unshaded renderer runs: the [0,1]-scaled one where the network has it
+                const NetParams& np = packed.params;
+                const int MT = (packed.cfg.hiddenChannels + 31) / 32, KS = packed.cfg.hiddenChannels / 16;
+                CellTableParams ct{};
+                ct.grid = W.a.ptr;
+                ct.latentFrags = static_cast<const char*>(scaledImage ? scaledImage : dLds.ptr) + np.offLayer0 + size_t(MT) * KS * kFragBytes;
+                ct.out = W.cells.ptr;
+                ct.X = np.gridX; ct.Y = np.gridY; ct.Z = np.gridZ; ct.G = np.gridC; ct.MT = MT;
+                HIP_CHECK(launch_grid_cell_table(ct, stream));
+                packed.params.cellTable = W.cells.ptr;
+                packed.params.cellStride = unsigned(512 * MT);
+                packed.params.cellCount = unsigned(cellTableBytes / (512 * size_t(MT)));
+            }
             W.order.endWrite(stream);
             curWorkGrid = next;
             packed.params.grid = W.a.ptr;
@@ -565,7 +594,7 @@ struct fvsrn_network {
         dLds.release();
         dLdsScaled.release();
         dLdsCurvature.release();
-        for (WorkingGrid& w : workGrid) { w.a.release(); w.b.release(); w.order.release(); }
+        for (WorkingGrid& w : workGrid) { w.a.release(); w.b.release(); w.cells.release(); w.order.release(); }
         imagesOrder.release();
         imageReaders.clear();
         keyStore.release();
@@ -1004,9 +1033,12 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
             const bool scalarNet = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
             const bool colourNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
             const bool folded = P.bias0Folded && (!net->scaledImage || net->packed.scaledBias0Exact);
-            const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && P.gridK == 1 && folded ? 1 : 2);
-            if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !P.noFourier && !P.fourierNeedsFractPlain && !P.fourierClampPos && (scalarNet || colourNet) &&
-                render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1, smallGrid))
+            const bool cells = k.grid == 1 && net->opts[FVSRN_OPT_CELL_TABLE] != 0 && P.gridX >= 2 && P.gridY >= 2 && P.gridZ >= 2 &&
+                               double(P.gridX - 1) * (P.gridY - 1) * (P.gridZ - 1) * 512.0 <= 1073741824.0;  // (ensureDevice: cellTableBytes)
+            const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && folded ? (cells ? 2 : (P.gridK == 1 ? 1 : 3)) : 3);
+            if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 2 && !P.noFourier && !P.fourierNeedsFractPlain && !P.fourierClampPos && (scalarNet || colourNet) &&
+                (render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1, smallGrid) ||
+                 (smallGrid == 2 && P.gridK == 1 && render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1, 1))))
                 name = "render_small_kernel<act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "," + std::to_string(P.numLayers) +
                        ",SGRID=" + std::to_string(smallGrid) + "> (unshaded; else " + name + ")";
         }
@@ -1426,11 +1458,16 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             {
                 const VariantKey& k = net->keyScaled;
                 const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
-                smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.gridK == 1 && a.P.bias0Folded ? 1 : 2);  // one decoded 16-channel chunk (no time input: bias0Folded): resident kernel
-                if (O[FVSRN_OPT_SMALL_KERNEL] != 0 && net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && !a.shaded && k.CD == 2 && smallGrid <= 1 && !a.P.noFourier && !a.P.fourierNeedsFract &&
+                // latent grid: 2 = through the cell table (any number of latent channels), 1 = one decoded 16-channel chunk by gathers;
+                // both need the first layer's bias in its weights (bias0Folded: no time input), the resident kernels drop that bias block
+                smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.bias0Folded ? (a.P.cellTable && O[FVSRN_OPT_CELL_TABLE] != 0 ? 2 : (a.P.gridK == 1 ? 1 : 3)) : 3);
+                if (O[FVSRN_OPT_SMALL_KERNEL] != 0 && net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && !a.shaded && k.CD == 2 && smallGrid <= 2 && !a.P.noFourier && !a.P.fourierNeedsFract &&
                     !a.P.fourierClampPos &&  // (the resident kernels compile the position clamp out)
                     a.P.numLayers >= 1 && a.P.numLayers <= 3 && (rgbo || (scalarNet && d.tf_kind != FVSRN_TF_NONE)))
+                {
                     smallFn = render_small_fn(k.act, k.dir, a.P.numLayers, smallTail, smallGrid);
+                    if (!smallFn && smallGrid == 2 && a.P.gridK == 1) smallFn = render_small_fn(k.act, k.dir, a.P.numLayers, smallTail, smallGrid = 1);
+                }
             }
 #ifndef FVSRN_ROTATE_SGRID
 #define FVSRN_ROTATE_SGRID 0  // kernels.hpp: the rotating variant of the resident latent-grid kernel is an A/B build, not the shipped one
@@ -1526,11 +1563,11 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const bool useOrder = O[FVSRN_OPT_TILE_ORDER] >= 0 ? O[FVSRN_OPT_TILE_ORDER] == 1 : (S.tileCounter == nullptr && (wpb > 1 || net->key.grid != 0));
             S.tileOrder = useOrder ? scene->tileOrder(S, P_boxCenter(a.P), tilesX, tilesY, s) : nullptr;
             // what this launch does to the samples of a ray, for callers that restate it (fvsrn_scene_last_render_info)
-            const bool rotates = net->keyScaled.CD == 2 && (net->keyScaled.grid == 0 || (FVSRN_ROTATE_SGRID && smallFn && smallGrid == 1)) && !a.P.noFourier &&
+            const bool rotates = net->keyScaled.CD == 2 && (net->keyScaled.grid == 0 || (FVSRN_ROTATE_SGRID && smallFn && smallGrid == 1) || (smallFn && smallGrid == 2)) && !a.P.noFourier &&
                                  !a.shaded;  // kRotate / kRotateLds, kernels.hpp
             scene->lastInfo[0] = K;
             scene->lastInfo[1] = rotates ? S.resyncMask + 1 : 0;
-            scene->lastInfo[2] = smallFn ? 1 : (stripeFn ? 2 : (adjointFn ? 3 : 0));
+            scene->lastInfo[2] = smallFn ? (smallGrid == 2 ? 4 : 1) : (stripeFn ? 2 : (adjointFn ? 3 : 0));
             scene->lastInfo[3] = wpb;
             hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid, a, grid, unsigned(64 * wpb), lds, s)
                                    : (stripeFn ? launch_render_stripe(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s)

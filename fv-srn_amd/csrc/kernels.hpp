@@ -421,7 +421,8 @@ __device__ __forceinline__ float select_by_mask(unsigned long long m, float x) {
 // SHADED: 0 = plain renderer; 1 = render_shaded_kernel (finite differences / predicted gradients / BRDF, and the adjoint mode at 96 and
 // 128 channels); 2 = render_adjoint_kernel (up to 64 channels, adjoint mode only, see there)
 constexpr bool adjoint_in_its_own_kernel(int CD) { return CD >= 2 && CD <= 4; }  // (render_adjoint_kernel is built for 32 / 48 / 64 channels)
-template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, int SHADED, int TAIL = TAIL_GENERIC, int NLC = 0, int SCHED = 0>
+// CELLS (render_small_kernel<.., SGRID = 2>): the latent grid enters through the cell table (srn_forward_resident_cells)
+template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, int SHADED, int TAIL = TAIL_GENERIC, int NLC = 0, int SCHED = 0, bool CELLS = false>
 __device__ __forceinline__ void render_body(const NetParams& P, const SceneParams& S, const char* lds, const float* tfLds,
                                             float* __restrict__ out, unsigned long long* __restrict__ stats) {
     const int lane = lane_id();
@@ -452,7 +453,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     const int K = S.segments;
 #endif
     const int numUnits = numTiles * K;
-    ResidentNet<(NLC > 0 ? NLC : 1), (NLC > 0 && GRID == 1 ? 1 : 0)> resident;
+    ResidentNet<(NLC > 0 ? NLC : 1), (NLC > 0 && GRID == 1 ? (CELLS ? 2 : 1) : 0)> resident;
     if constexpr (NLC > 0) load_resident(P, lds, resident);
     // TAIL_SCALAR_TABLE: loop-invariant scalars
     const float alphaLimit = S.earlyOut ? S.alphaEarlyOut : __builtin_inff();
@@ -529,7 +530,11 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
 #ifndef FVSRN_ROTATE_GRID
 #define FVSRN_ROTATE_GRID 0
 #endif
-    constexpr bool kRotate = CD == 2 && (GRID == 0 || (GRID == 1 && FVSRN_ROTATE_GRID && NLC == 0)) && FMODE != FM_FIRST_LAYER && !SHADED;
+#ifndef FVSRN_CELLS_ROTATE
+#define FVSRN_CELLS_ROTATE 1  // (0: the cell-table kernels with direct features, A/B builds)
+#endif
+    constexpr bool kRotate = CD == 2 && (GRID == 0 || (GRID == 1 && FVSRN_ROTATE_GRID && NLC == 0) || (GRID == 1 && NLC > 0 && CELLS && FVSRN_CELLS_ROTATE)) &&
+                             FMODE != FM_FIRST_LAYER && !SHADED;
 #endif
     // r03 experiment, measured and NOT shipped (profiles/r03/sgrid_rotation_experiment.md): the register-resident kernel with one latent
     // chunk with rotated features, the per-ray rotation parked in LDS (8 KiB per wave behind the TF table; srn_forward_rotating_resident_grid):
@@ -596,11 +601,13 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             // Fourier features by rotation (fourier_advance): exact features every kFourierResync steps, the per-step
             // rotation once per ray
             if ((i & S.resyncMask) == 0) {  // wave-uniform
-                fourier_features<CD, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, feat);
+                const bool hilo = S.resyncMask != 0;  // features that get advanced: from the fp32 position (srn_device.hpp, fourier_features)
+                fourier_features<CD, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, feat, nullptr, hilo);
                 if (i == 0)
-                    fourier_features<CD, HAS_DIR, FM_COS, true>(P, lds, dnx * S.stepsize, dny * S.stepsize, dnz * S.stepsize, 0.f, 0.f, 0.f, dfeat);
+                    fourier_features<CD, HAS_DIR, FM_COS, true>(P, lds, dnx * S.stepsize, dny * S.stepsize, dnz * S.stepsize, 0.f, 0.f, 0.f, dfeat, nullptr, hilo);
             }
-            if constexpr (NLC > 0) o = srn_forward_rotating_resident<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeat);
+            if constexpr (NLC > 0 && CELLS) o = srn_forward_rotating_resident_cells<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeat, px, py, pz, validMask);
+            else if constexpr (NLC > 0) o = srn_forward_rotating_resident<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeat);
             else o = srn_forward_rotating<CD, ACT, GRID, HAS_DIR>(P, lds, feat, dfeat, px, py, pz);
         } else if constexpr (kRotateLds) {
             if ((i & S.resyncMask) == 0) {  // wave-uniform: exact features; the per-step rotation once per ray (and depth segment) -> LDS
@@ -611,6 +618,8 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
                 }
             }
             o = srn_forward_rotating_resident_grid<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeatLds, px, py, pz);
+        } else if constexpr (NLC > 0 && GRID == 1 && CELLS) {
+            o = srn_forward_resident_cells<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, px, py, pz, dx, dy, dz, validMask);
         } else if constexpr (NLC > 0 && GRID == 1) {
             o = srn_forward_resident_grid<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, px, py, pz, dx, dy, dz);
         } else if constexpr (kAdjointHere) {
@@ -914,12 +923,14 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void r
 // blending), TAIL_SCALAR_LOOP (Piecewise / Gaussian TF) or TAIL_RGBO (colour network)
 // SGRID = 1: the same with ONE 16-channel latent grid chunk of decoded values (direct Fourier features instead of the rotation:
 // the registers of the rotation state hold the grid fetch)
+// SGRID = 2 (r04): a latent grid of any channel count through the cell table -- one MFMA K step on the trilinear weights, no gathers,
+// rotated features (srn_forward_rotating_resident_cells, srn_device.hpp); the default where a table exists (FVSRN_OPT_CELL_TABLE)
 template <int ACT, bool HAS_DIR, int NLC, int TAILK, int SGRID = 0>
 __global__ __launch_bounds__(kBlockThreads, 2) void render_small_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                       unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* tfLds = render_prologue(P, S, lds);
-    render_body<2, ACT, SGRID, HAS_DIR, FM_COS, 0, TAILK, NLC>(P, S, lds, tfLds, out, stats);
+    render_body<2, ACT, (SGRID ? 1 : 0), HAS_DIR, FM_COS, 0, TAILK, NLC, 0, SGRID == 2>(P, S, lds, tfLds, out, stats);
 }
 
 // finite-difference normals / shading BRDF (SceneParams::gradientMode, brdf*): 7 network evaluations per sample

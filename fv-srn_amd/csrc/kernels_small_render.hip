@@ -18,6 +18,7 @@ namespace fvsrn {
     G(A, D, 1, 1) G(A, D, 2, 1) G(A, D, 3, 1) G(A, D, 1, 4) G(A, D, 2, 4) G(A, D, 3, 4) G(A, D, 1, 5) G(A, D, 2, 5) G(A, D, 3, 5)
 
 const void* render_small_fn(int act, bool dir, int numLayers, int tail, int grid) {
+    if (grid == 2) return render_small_cells_fn(act, dir, numLayers, tail);
     if (grid == 1) {
 #define G(A, D, N, L) \
         if (act == A && dir == D && numLayers == N && tail == L) return reinterpret_cast<const void*>(&render_small_kernel<A, D, N, L, 1>);
@@ -34,6 +35,7 @@ const void* render_small_fn(int act, bool dir, int numLayers, int tail, int grid
 }
 
 hipError_t launch_render_small(int act, bool dir, int numLayers, int tail, int grid, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s) {
+    if (grid == 2) return launch_render_small_cells(act, dir, numLayers, tail, a, gridDim, blockDim, ldsBytes, s);
     if (grid == 1) {
 #define G(A, D, N, L)                                                                                             \
         if (act == A && dir == D && numLayers == N && tail == L) {                                                \

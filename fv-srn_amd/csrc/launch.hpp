@@ -70,6 +70,17 @@ struct BlendParams {
 };
 hipError_t launch_grid_blend(const BlendParams& p, hipStream_t s);
 
+// Cell table of a working grid (NetParams::cellTable, device_params.hpp): out[cell][m][row][corner] = sum over the latent channels of
+// (first-layer latent column of row 32 m + row) x (grid value at the cell's corner), fp32 sums rounded to fp16
+struct CellTableParams {
+    const void* grid;        // working grid, fp16 x-pair records [Z][Y][X+1][G][2]
+    const void* latentFrags; // the weight image's latent K-step fragments of layer 0, [g][m] x 1 KiB (pack.cpp)
+    void* out;               // fp16 [cells][MT][32][8]
+    int X, Y, Z, G;          // grid resolution, latent channels (a multiple of 16)
+    int MT;                  // M tiles of the network
+};
+hipError_t launch_grid_cell_table(const CellTableParams& p, hipStream_t s);
+
 // IImageEvaluator::ExtractColor: raw (8,H,W) -> planar fp32 (4,H,W) or packed RGBA8; d_minmax: 2 floats of scratch
 struct ExtractParams {
     const float* raw;
@@ -98,7 +109,10 @@ hipError_t launch_evaluate_tf(const SceneParams& S, const float* density, const 
 
 // render_small_kernel (kernels_small_render.hip): nullptr / hipErrorInvalidDeviceFunction if that variant is not compiled in
 // tail: 4 / 5 Identity / Texture TF with Beer-Lambert blending, 1 the same with Alpha blending, 2 Piecewise/Gaussian TF, 3 colour network; grid: 0 Fourier-only, 1 one decoded 16-channel latent chunk
+// (grid 2: the latent grid through the cell table, kernels_small_cells.hip)
 const void* render_small_fn(int act, bool dir, int numLayers, int tail, int grid = 0);
+const void* render_small_cells_fn(int act, bool dir, int numLayers, int tail);
+hipError_t launch_render_small_cells(int act, bool dir, int numLayers, int tail, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 hipError_t launch_render_small(int act, bool dir, int numLayers, int tail, int grid, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 
 // evaluate_small_kernel: hipErrorInvalidDeviceFunction if that variant is not compiled in

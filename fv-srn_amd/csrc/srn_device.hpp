@@ -46,6 +46,13 @@ __device__ __forceinline__ uint2_t lane_half_swap(unsigned a, unsigned b) {
     return uint2_t{r[0], r[1]};
 }
 
+// x in the lanes whose bit is set in the wave mask m (an SGPR pair), y elsewhere
+__device__ __forceinline__ float select_by_mask_or(unsigned long long m, float x, float y) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(y), "v"(x), "s"(m));
+    return r;
+}
+
 // own value v (one per lane = per sample) -> value of sample (lane&31) of tile 0 / tile 1
 __device__ __forceinline__ void tile_bcast(float v, float& t0, float& t1) {
     const unsigned u = __float_as_uint(v);
@@ -500,10 +507,42 @@ __device__ __forceinline__ void phase_operands(float px, float py, float pz, flo
     b0[1] = phase_operand<HAS_DIR>(tph[1], td[1], h);
 }
 
+// The same operands for the fp16 rounding residuals of the position (x - half(x): a second fp16 value, so that x = hi + lo carries
+// ~22 bits): constant and direction slots zero.  A second phase MFMA on these, accumulating into the first one's result, gives the
+// phases of the fp32 position (fourier_features, hilo).
+template <bool HAS_DIR>
+__device__ __forceinline__ void phase_operands_residual(float px, float py, float pz, int h, half8_t (&b1)[2]) {
+    const float pp[3] = {px, py, pz};
+    unsigned pu[3], pv[3], tph[2][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float r = pp[i] - float(_Float16(pp[i]));
+        const float2_t v = {r, r};
+        pu[i] = pv[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        auto r = lane_half_swap(pu[i], pv[i]);
+        tph[0][i] = r[0];
+        tph[1][i] = r[1];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const bool zero = HAS_DIR && h != 0;  // (without a direction the matrix entries of K slots 8..15 are zero: any finite value)
+        const uint4_t u = {zero ? 0u : tph[t][0], zero ? 0u : tph[t][1], zero ? 0u : tph[t][2], 0u};
+        b1[t] = __builtin_bit_cast(half8_t, u);
+    }
+}
+
 // wp != nullptr: the phase fragments are given (resident in registers) instead of read from the LDS image
+// hilo (wave-uniform; r04): the phases of the fp32 position instead of its fp16 rounding (a second MFMA on the rounding residuals).  The
+// rotating renderers re-derive with it: a feature set that is then ADVANCED for 64 steps should not carry the rounding of one position
+// (up to 0.025 rad on a 2^4 octave) and of the step vector coherently along the ray -- the reference rounds every sample's position anew,
+// which averages out in the integral (the CPU model of the parity tests restates both forms; image error of the rotation 3.1e-3 -> 1.7e-3
+// on the scene that exposed it).  With FVSRN_OPT_FOURIER_RESYNC = 1 (the reference's per-sample arithmetic) it stays off.
 template <int CD, bool HAS_DIR, int FMODE, bool DELTA = false>
 __device__ __forceinline__ void fourier_features(const NetParams& P, const char* lds, float px, float py, float pz, float dx,
-                                                 float dy, float dz, floatx16 (&f)[2][mtiles(CD)], const half8_t* wp = nullptr) {
+                                                 float dy, float dz, floatx16 (&f)[2][mtiles(CD)], const half8_t* wp = nullptr, bool hilo = false) {
     constexpr int MT = mtiles(CD);
     constexpr int NPASS = HAS_DIR ? 4 : 2;
     const int lane = lane_id();
@@ -520,6 +559,14 @@ __device__ __forceinline__ void fourier_features(const NetParams& P, const char*
             const floatx16 z = {0};
             f[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aph[m], b0[t], z, 0, 0, 0);
         }
+    if (hilo) {
+        half8_t b1[2];
+        phase_operands_residual<HAS_DIR>(px, py, pz, h, b1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) f[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aph[m], b1[t], f[t][m], 0, 0, 0);
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1065,8 +1112,8 @@ struct ResidentNet {
     floatx16 b[NLC];           // bias rows of this lane half, layers 0..NLC-1 (RGRID: b[0] is never read -- the first layer's bias is folded
                                // into its weights, NetParams::bias0Folded, and the compiler drops the 16 registers)
     float4_t bLast;
-    half8_t wg[RGRID ? 1 : 0];  // latent K step of layer 0
-    half8_t wp[RGRID ? 1 : 0];  // phase fragment
+    half8_t wg[RGRID == 1 ? 1 : 0];  // latent K step of layer 0 (RGRID = 2: the cell table takes its place, srn_forward_resident_cells)
+    half8_t wp[RGRID ? 1 : 0];       // phase fragment
 };
 
 template <int NLC, int RGRID>
@@ -1090,17 +1137,18 @@ __device__ __forceinline__ void load_resident(const NetParams& P, const char* ld
         }
     }
     R.bLast = *reinterpret_cast<const float4_t*>(lds + P.offBias + NLC * 128);
-    if constexpr (RGRID != 0) {
-        R.wg[0] = *reinterpret_cast<const half8_t*>(ldsA + P.offLayer0 + 2 * kFragBytes);  // [g = 0][m = 0] behind the MT * KS Fourier fragments
-        R.wp[0] = *reinterpret_cast<const half8_t*>(ldsA + P.offPhase);
-    }
+    if constexpr (RGRID == 1) R.wg[0] = *reinterpret_cast<const half8_t*>(ldsA + P.offLayer0 + 2 * kFragBytes);  // [g = 0][m = 0] behind the MT * KS Fourier fragments
+    if constexpr (RGRID != 0) R.wp[0] = *reinterpret_cast<const half8_t*>(ldsA + P.offPhase);
 }
 
 // srn_layers_pipelined for CD = 2, GRID = 0 on a ResidentNet; returns the raw outputs of this lane's sample (ALL4: all four,
 // colour networks; otherwise only output 0)
 template <int ACT, int NLC, int NFILL, bool ALL4, int RGRID = 0, class Pre, class Fill>
 __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, const ResidentNet<NLC, RGRID>& R, half8_t (&xb)[2][2], Pre&& pre, Fill&& fill,
-                                                        const half8_t* gf = nullptr) {
+                                                        const half8_t* gf = nullptr, const half8_t* ga = nullptr) {
+    // gf: B fragments of the two tiles' latent K step; its A fragment is R.wg[0] (RGRID = 1: the first layer's latent columns) or ga[tile]
+    // (RGRID = 2: the cell-table fragments of the tile's cells, gf = the trilinear weights)
+    auto latentA = [&](int T) -> half8_t { if constexpr (RGRID == 2) return ga[T]; else return R.wg[0]; };
     const float actA = P.actA, actB = P.actB;
     constexpr int NF0 = NFILL / 2;
     floatx16 acc[2];
@@ -1116,7 +1164,7 @@ __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, cons
     interleave<2, NF0>([&](int i) { acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.w[i], xb[0][i], i == 0 ? (RGRID ? zero16 : R.b[0]) : acc[0], 0, 0, 0); },
                        [&](int j) { fill(j); });
     if constexpr (RGRID != 0) {  // latent K step of layer 0 (gf: B fragments of the two tiles' latent features)
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wg[0], gf[0], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(latentA(0), gf[0], acc[0], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
     // half-layer slot: layer l for tile T || activation + convert of the other tile
@@ -1137,7 +1185,7 @@ __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, cons
                          [&](int q) { act_pack_quarter<ACT>(acc[O], q, actA, actB, xb[O][0], xb[O][1]); });
 #endif
         if constexpr (RGRID != 0 && L == 0) {
-            acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wg[0], gf[T], acc[T], 0, 0, 0);
+            acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(latentA(T), gf[T], acc[T], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -1198,6 +1246,123 @@ __device__ __forceinline__ float4_t srn_forward_resident_grid(const NetParams& P
         gf[t] = grid_pack(acc);
     }
     return srn_layers_resident<ACT, NLC, 0, ALL4, 1>(P, R, xb, []() {}, [](int) {}, gf);
+}
+
+// ---- latent grid through the cell table (r04) --------------------------------------------------------------------------------------
+// The samples a wave evaluates in one step belong to the rays of an 8 x 8 pixel tile at (almost) the same depth: a patch of a hundredth of
+// the box, against grid cells of 1/15 .. 1/31.  Nearly always the 32 samples of an MFMA column tile lie in ONE cell, sometimes in two.  Inside
+// a cell the trilinear fetch is linear in its eight weights, and so is the first layer behind it:
+//     W_latent . (sum_c w_c G_c) = sum_c w_c (W_latent . G_c) = T_cell . w,        T_cell = [W_latent G_c]_c   (C x 8, fp16, NetParams::cellTable)
+// i.e. ONE MFMA K step whose A operand is the cell's table entry and whose B operand holds the sample's eight weights -- K = 16 takes two
+// cells (lane half 0: slots of cell A, lane half 1: cell B; a sample's weights are zero in the slots of the cell it is not in).  That
+// replaces, per wave step, 16 x 16-byte gathers per lane, 64 v_dot2_f32_f16, the record address arithmetic and 8 converts by 2 coalesced
+// 512-byte loads, 8 v_cndmask and a handful of scalar instructions, with the same number of MFMAs as the latent K step it stands in for
+// (and any number of latent channels costs the same).  Tiles whose samples touch more than two cells (corners of the cell lattice) run the
+// network again for the samples not covered yet -- wave-uniform, a few percent of the steps.
+// Same texture semantics as grid_tap: texel coordinate p N - 0.5 clamped to [0, N - 1], cell x0 = min(floor, N - 2), weight wx = coordinate - x0
+// (1 exactly on the last texel); fp16 weights like there; the table entries carry one fp16 rounding of W.G where the gather path rounds
+// the interpolated feature.
+struct CellTap {
+    unsigned w[4];  // packed fp16 weight pairs {w_zy (1 - wx), w_zy wx}, zy = 2 dz + dy: the eight K slots of the sample's cell
+    unsigned cell;
+};
+
+__device__ __forceinline__ CellTap cell_tap(const NetParams& P, float px, float py, float pz) {
+    const float xm = P.gridXf - 1.f, ym = P.gridYf - 1.f, zm = P.gridZf - 1.f;
+    const float fx = __builtin_amdgcn_fmed3f(fmaf(px, P.gridXf, -0.5f), 0.f, xm);
+    const float fy = __builtin_amdgcn_fmed3f(fmaf(py, P.gridYf, -0.5f), 0.f, ym);
+    const float fz = __builtin_amdgcn_fmed3f(fmaf(pz, P.gridZf, -0.5f), 0.f, zm);
+    const float x0 = fminf(floorf(fx), xm - 1.f), y0 = fminf(floorf(fy), ym - 1.f), z0 = fminf(floorf(fz), zm - 1.f);
+    const float wx = fx - x0, wy = fy - y0, wz = fz - z0;
+    CellTap t;
+    // (exact in fp32: fewer than 2^24 cells; positions of rays that miss the box may be anything, also NaN: any valid cell will do)
+    t.cell = min(unsigned(fmaf(fmaf(z0, ym, y0), xm, x0)), P.cellCount - 1u);
+    const float ux = 1.f - wx, uy = 1.f - wy, uz = 1.f - wz;
+    const float w4[4] = {uz * uy, uz * wy, wz * uy, wz * wy};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float2_t v = {w4[k] * ux, w4[k] * wx};
+        t.w[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
+    }
+    return t;
+}
+
+__device__ __forceinline__ unsigned select_bits_by_mask(unsigned long long m, unsigned x) {
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
+    return r;
+}
+
+// One step of a tile's cell bookkeeping: the next (up to) two cells among the tile samples whose bit is set in `rem` (the wave mask of the
+// samples still to evaluate, 32 bits: both lane halves hold the same sample), the weights of the samples in them as the B fragment, the
+// cells' table entries as the A fragment.  Returns the samples covered.
+__device__ __forceinline__ unsigned cell_pair(const NetParams& P, const unsigned (&w)[4], unsigned cell, unsigned rem, int h, unsigned laneOff,
+                                              half8_t& bfrag, half8_t& afrag) {
+    const unsigned cA = __builtin_amdgcn_readlane(cell, rem ? __builtin_ctz(rem) : 0);
+    const unsigned long long mA = __builtin_amdgcn_ballot_w64(cell == cA);
+    const unsigned rem1 = rem & ~unsigned(mA);
+    const unsigned cB = __builtin_amdgcn_readlane(cell, rem1 ? __builtin_ctz(rem1) : 0);
+    const unsigned long long mB = rem1 ? __builtin_amdgcn_ballot_w64(cell == cB) : 0ull;
+    const unsigned long long sel = (mA & 0xffffffffull) | (mB & 0xffffffff00000000ull);
+    uint4_t b;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = select_bits_by_mask(sel, w[k]);
+    bfrag = __builtin_bit_cast(half8_t, b);
+    const unsigned off = __umul24(h ? cB : cA, P.cellStride) + laneOff;  // (both below 2^24, the table below 2^31 bytes: api.cpp)
+    afrag = *reinterpret_cast<const half8_t*>(static_cast<const char*>(P.cellTable) + off);
+    return unsigned(mA) | unsigned(mB);
+}
+
+template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
+__device__ __forceinline__ float4_t srn_forward_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, float px, float py, float pz,
+                                                              float dx, float dy, float dz, unsigned long long validMask) {
+    constexpr int NPASS = HAS_DIR ? 4 : 2;
+    const int lane = lane_id();
+    const int h = lane >> 5;
+    const unsigned laneOff = unsigned(lane & 31) * 16u;
+    const CellTap own = cell_tap(P, px, py, pz);
+    unsigned wT[2][4], cT[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        auto a = lane_half_swap(own.w[k], own.w[k]);
+        wT[0][k] = a[0]; wT[1][k] = a[1];
+    }
+    {
+        auto c = lane_half_swap(own.cell, own.cell);
+        cT[0] = c[0]; cT[1] = c[1];
+    }
+    half8_t b0[2];
+    phase_operands<HAS_DIR, true>(px, py, pz, dx, dy, dz, h, b0);
+    unsigned rem0 = unsigned(validMask), rem1 = unsigned(validMask >> 32);
+    float4_t out = {0.f, 0.f, 0.f, 0.f};
+    for (;;) {
+        half8_t xb[2][2], gf[2], ga[2];
+        const unsigned cov0 = cell_pair(P, wT[0], cT[0], rem0, h, laneOff, gf[0], ga[0]);
+        const unsigned cov1 = cell_pair(P, wT[1], cT[1], rem1, h, laneOff, gf[1], ga[1]);
+        floatx16 d[2];
+        {
+            const floatx16 z = {0};
+            d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wp[0], b0[0], z, 0, 0, 0);
+            d[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wp[0], b0[1], z, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            phase_cos<FM_COS>(d[t], NPASS);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d[t], q, 0.f, 0.f, xb[t][0], xb[t][1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float4_t o = srn_layers_resident<ACT, NLC, 0, ALL4, 2>(P, R, xb, []() {}, [](int) {}, gf, ga);
+        const unsigned long long covered = (unsigned long long)cov0 | ((unsigned long long)cov1 << 32);
+        out[0] = select_by_mask_or(covered, o[0], out[0]);
+        if constexpr (ALL4) {
+            out[1] = select_by_mask_or(covered, o[1], out[1]); out[2] = select_by_mask_or(covered, o[2], out[2]); out[3] = select_by_mask_or(covered, o[3], out[3]);
+        }
+        rem0 &= ~cov0; rem1 &= ~cov1;
+        if ((rem0 | rem1) == 0) break;  // wave-uniform; as a rule the first pass covers every sample
+    }
+    return out;
 }
 
 // The same with rotated Fourier features (r03): the current features stay in 32 registers (fp32, both tiles), their per-step rotation
@@ -1282,6 +1447,47 @@ __device__ __forceinline__ float4_t srn_forward_rotating_resident(const NetParam
             for (int c = 0; c < NP - NFILL; ++c) fourier_advance_piece<2, HAS_DIR>(feat, dfeat, c);
         },
         [&](int j) { fourier_advance_piece<2, HAS_DIR>(feat, dfeat, NP - NFILL + j); });
+}
+
+// srn_forward_resident_cells with rotated Fourier features (the registers the gathers held take the rotation state): the features
+// of the current sample are converted inside the pass loop, the rotation to the next sample runs once, behind it
+template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
+__device__ __forceinline__ float4_t srn_forward_rotating_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, floatx16 (&feat)[2][1],
+                                                                       const floatx16 (&dfeat)[2][1], float px, float py, float pz,
+                                                                       unsigned long long validMask) {
+    const int lane = lane_id();
+    const int h = lane >> 5;
+    const unsigned laneOff = unsigned(lane & 31) * 16u;
+    const CellTap own = cell_tap(P, px, py, pz);
+    unsigned wT[2][4], cT[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        auto a = lane_half_swap(own.w[k], own.w[k]);
+        wT[0][k] = a[0]; wT[1][k] = a[1];
+    }
+    {
+        auto c = lane_half_swap(own.cell, own.cell);
+        cT[0] = c[0]; cT[1] = c[1];
+    }
+    unsigned rem0 = unsigned(validMask), rem1 = unsigned(validMask >> 32);
+    float4_t out = {0.f, 0.f, 0.f, 0.f};
+    for (;;) {
+        half8_t xb[2][2], gf[2], ga[2];
+        const unsigned cov0 = cell_pair(P, wT[0], cT[0], rem0, h, laneOff, gf[0], ga[0]);
+        const unsigned cov1 = cell_pair(P, wT[1], cT[1], rem1, h, laneOff, gf[1], ga[1]);
+        feature_fragments<2>(feat, xb);
+        const float4_t o = srn_layers_resident<ACT, NLC, 0, ALL4, 2>(P, R, xb, []() {}, [](int) {}, gf, ga);
+        const unsigned long long covered = (unsigned long long)cov0 | ((unsigned long long)cov1 << 32);
+        out[0] = select_by_mask_or(covered, o[0], out[0]);
+        if constexpr (ALL4) {
+            out[1] = select_by_mask_or(covered, o[1], out[1]); out[2] = select_by_mask_or(covered, o[2], out[2]); out[3] = select_by_mask_or(covered, o[3], out[3]);
+        }
+        rem0 &= ~cov0; rem1 &= ~cov1;
+        if ((rem0 | rem1) == 0) break;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) fourier_advance_piece<2, HAS_DIR>(feat, dfeat, c);
+    return out;
 }
 
 // output parametrization, renderer_volume_tensorcores.cuh:1054-1158. The reference rounds the

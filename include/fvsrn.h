@@ -196,7 +196,10 @@ typedef enum {
     FVSRN_OPT_PERSISTENT_RESERVE = 12, /* scene: persistent launches leave this many workgroup slots of the chip unused, so that a kernel on
                                         another stream (the all-gather of the previous frame) finds room while the frame renders; -1 auto
                                         (0 for whole frames, 1/16 of the slots for the stripes of a multi-GPU frame)  [FVSRN_PERSISTENT_RESERVE] */
-    FVSRN_OPT_COUNT_ = 13
+    FVSRN_OPT_CELL_TABLE = 13,       /* network + scene: latent grids of FLOAT / BYTE_LINEAR encoding enter the unshaded renderer through the cell
+                                        table (one MFMA K step on the trilinear weights instead of gathers + dot products; DESIGN.md section 4
+                                        item 16); 0 = off (the gather path), 1 / -1 = on where a kernel variant exists   [FVSRN_CELL_TABLE]    */
+    FVSRN_OPT_COUNT_ = 14
 } fvsrn_option;
 int fvsrn_network_set_option(fvsrn_network* net, int option, int value);
 int fvsrn_network_get_option(const fvsrn_network* net, int option, int* value);
@@ -305,7 +308,8 @@ int fvsrn_camera_on_a_sphere(int orientation, const double center[3], double pit
  * arithmetic (the parity oracle): out = { depth segments K a ray was cut into (1: none; the step count of the feature rotation
  * restarts in each), period in steps of the exact re-derivation of rotated Fourier features (0: the kernel derives the features
  * from the fp16 position at every step, like the reference; FVSRN_OPT_FOURIER_RESYNC), kernel family (0 render_kernel / render_shaded_kernel, 1 register-resident, 2 spill-free
- * stripe variant, 3 render_adjoint_kernel: the adjoint gradient mode up to 64 channels),
+ * stripe variant, 3 render_adjoint_kernel: the adjoint gradient mode up to 64 channels, 4 register-resident with the latent grid through
+ * the cell table, FVSRN_OPT_CELL_TABLE),
  * waves per workgroup }.  No reference counterpart. */
 int fvsrn_scene_last_render_info(fvsrn_scene* scene, int out[4]);
 

@@ -50,7 +50,7 @@ class _OracleScene(C.Structure):
                 ("brdfSpecularExponent", C.c_int), ("brdfMagScale", C.c_float), ("brdfAmbient", C.c_float),
                 ("brdfSpecular", C.c_float), ("brdfMagCenter", C.c_float), ("brdfMagRadius", C.c_float),
                 ("brdfLight", C.c_float * 3), ("tfPreintegration", C.c_int), ("tfPreintegrated", _FP), ("tfGaussianMode", C.c_int),
-                ("rotationResync", C.c_int), ("segments", C.c_int)]
+                ("rotationResync", C.c_int), ("segments", C.c_int), ("rotationHiLo", C.c_int)]
 
 
 _lib = None
@@ -292,12 +292,14 @@ class OracleScene:
     def __init__(self, *, eye, right, up, fov_y_radians, stepsize, density_min=0.0, density_max=1.0, early_out=True,
                  blend_mode=BLEND_BEER_LAMBERT, tf_kind=TF_IDENTITY, tf_scale_absorption=1.0, tf_scale_emission=1.0,
                  tf_table=None, gradient_mode=0, finite_differences_stepsize=0.0, brdf=None, tf_preintegration=0,
-                 adjoint_grid_stepsize=0.0, tf_gaussian_mode=0, rotation_resync=0, segments=1):
-        """rotation_resync / segments: only read by the ACC_DEVICE model (see srn_oracle.h, OracleScene)."""
+                 adjoint_grid_stepsize=0.0, tf_gaussian_mode=0, rotation_resync=0, segments=1, rotation_hilo=1):
+        """rotation_resync / segments / rotation_hilo: only read by the ACC_DEVICE model (see srn_oracle.h, OracleScene); rotation_hilo = 1 is
+        what the kernels do since r04 (re-derivations from the fp32 position), 0 the r01 - r03 statement (from its fp16 rounding)."""
         s = _OracleScene()
         s.tfGaussianMode = tf_gaussian_mode
         assert rotation_resync >= 0 and (rotation_resync & (rotation_resync - 1)) == 0, "resync period: 0 or a power of two"
         s.rotationResync, s.segments = int(rotation_resync), int(segments)
+        s.rotationHiLo = int(rotation_hilo)
         s.eye[:] = [float(v) for v in eye]
         s.right[:] = [float(v) for v in right]
         s.up[:] = [float(v) for v in up]

@@ -276,6 +276,19 @@ static float device_phase_rev(const OracleNet* n, int i, const float in6[6]) {
     return (float)(sum + (double)kh + (double)kl);
 }
 
+/* the linear part of device_phase_rev alone (no constant slot): the contribution of a second operand, e.g. the fp16 residual of a position */
+static double device_phase_lin(const OracleNet* n, int i, const float in6[6]) {
+    const int F = n->F, cols = n->useDirection == 2 ? 6 : 3;
+    double sum = 0;
+    for (int c = 0; c < cols; ++c) {
+        const double v = (double)h2f(n->fourier[i + (size_t)F * c]) / (2.0 * 3.14159265358979323846);
+        const float vh = rh((float)v);
+        const float vl = rh((float)(v - (double)vh));
+        sum += (double)vh * in6[c] + (double)vl * in6[c];
+    }
+    return sum;
+}
+
 /* The padded input vector x[0 .. C) of the first layer: [x, y, z, (time | 0), (dx, dy, dz, 0), cos(0..F-1), sin(0..F-1)] as fp16
  * values, from the normalized position p (renderer_volume_tensorcores.cuh:768-808) */
 static void fourier_inputs(const OracleNet* n, const float p[3], const float dir[3], float* x) {
@@ -832,7 +845,8 @@ static void render_pixel(const OracleNet* n, const OracleScene* s, int W, int H,
     /* ORACLE_ACC_DEVICE with OracleScene::rotationResync: the kernels' feature rotation (fv-srn_amd/csrc/kernels.hpp render_body,
      * srn_device.hpp fourier_advance_piece), stated step by step.  feat / dfeat: the first layer's padded input vector in fp32 and
      * its per-step increment (positions: additive; (cos, sin) pairs: the rotation by the phase increment of one step). */
-    const int rotate = n->accMode == ORACLE_ACC_DEVICE && s->rotationResync > 0 && n->F > 0 && n->G == 0;
+    const int rotate = n->accMode == ORACLE_ACC_DEVICE && s->rotationResync > 0 && n->F > 0; /* (r04: latent-grid networks of the cell-table kernels too) */
+    const int hilo = s->rotationHiLo && s->rotationResync > 1;
     const int K = s->segments > 1 ? s->segments : 1;
     const int nsteps = (tmax - tmin) >= 0.f ? (int)((tmax - tmin) / s->stepsize) + 1 : 0; /* the host's cut of a ray into K step ranges */
     float feat[ORACLE_MAX_C], dfeat[ORACLE_MAX_C], xrot[ORACLE_MAX_C];
@@ -860,14 +874,21 @@ static void render_pixel(const OracleNet* n, const OracleScene* s, int W, int H,
                 for (int pass = (local == 0 ? 1 : 0); pass >= 0; --pass) { /* pass 1: the per-step increment, once per ray and segment */
                     float* f = pass ? dfeat : feat;
                     float in6[6] = {0, 0, 0, 0, 0, 0};
-                    for (int k = 0; k < 3; ++k) in6[k] = rh(pass ? dn[k] * s->stepsize : pd[k]);
+                    float lo6[6] = {0, 0, 0, 0, 0, 0};
+                    for (int k = 0; k < 3; ++k) {
+                        const float v = pass ? dn[k] * s->stepsize : pd[k];
+                        in6[k] = rh(v);
+                        if (hilo) lo6[k] = rh(v - in6[k]); /* second phase MFMA on the residual (constant and direction slots zero) */
+                    }
                     if (!pass && n->useDirection >= 1) for (int k = 0; k < 3; ++k) in6[3 + k] = rh(dir[k]);
                     for (int k = 0; k < C; ++k) f[k] = 0.f;
-                    f[0] = in6[0]; f[1] = in6[1]; f[2] = in6[2];
+                    f[0] = in6[0] + lo6[0]; f[1] = in6[1] + lo6[1]; f[2] = in6[2] + lo6[2];
                     f[3] = (!pass && n->passTime) ? rh(n->gridInterpolation[0]) : 0.f;
                     if (n->useDirection >= 1) { f[4] = in6[3]; f[5] = in6[4]; f[6] = in6[5]; }
                     for (int q = 0; q < F; ++q) {
-                        const double ph = 2.0 * 3.14159265358979323846 * (double)device_phase_rev(n, q, in6);
+                        double rev = (double)device_phase_rev(n, q, in6);
+                        if (hilo) rev = (double)(float)(rev + device_phase_lin(n, q, lo6)); /* accumulated by the second MFMA: fp32 */
+                        const double ph = 2.0 * 3.14159265358979323846 * rev;
                         f[base + q] = (float)cos(ph);
                         f[base + F + q] = (float)sin(ph);
                     }

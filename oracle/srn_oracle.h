@@ -74,6 +74,10 @@ typedef struct {
      * consecutive step ranges a ray was cut into (the step count restarts in each; <= 1: none).  fvsrn_scene_last_render_info
      * reports both for a render. */
     int rotationResync, segments;
+    /* ... and (r04) rotationHiLo != 0: at a re-derivation the phase MFMA runs on the position AND on its fp16 rounding residual (x = hi + lo,
+     * two fp16 values: ~22 bits), so the rotated features follow the fp32 sample positions instead of carrying the rounding of one
+     * position (and of the step vector) coherently over rotationResync steps.  Not used with rotationResync = 1 (the reference's arithmetic). */
+    int rotationHiLo;
 } OracleScene;
 /* tex [R][4] -> out [R][4] (mode 1) or [R][R][4] (mode 2, N quadrature steps, world step size) */
 /* EvaluateTF / EvaluateTFWithPrevious (renderer_tf_kernels.cuh:11-70) with the scene's TF, density range and step size;

@@ -354,7 +354,7 @@ def test_feature_rotation_stays_close_to_per_step_features(activation):
 
 @pytest.mark.parametrize("layers,activation,output_mode,tf,grid", [
     (4, "ReLU", "density:direct", "identity", None), (3, "SnakeAlt", "density", "texture", None), (2, "Sine", "density", "identity", None),
-    # one 16-channel latent chunk: resident too (direct Fourier features); two chunks: the LDS kernel either way
+    # latent grids: resident too, through the cell table (any number of latent channels)
     (4, "ReLU", "density:direct", "identity", (16, 8)), (3, "SnakeAlt", "density", "texture", (16, 12)), (4, "ReLU", "density", "identity", (32, 8)),
 ])
 def test_register_resident_kernel_matches_lds_kernel(layers, activation, output_mode, tf, grid):
@@ -375,12 +375,28 @@ def test_register_resident_kernel_matches_lds_kernel(layers, activation, output_
         kw.update(tf_kind=oracle.TF_IDENTITY)
     net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
     W = H = 96
-    small = capi.Scene(**kw).render(net, W, H)[0].clone()
+    import torch
+    small_scene = capi.Scene(**kw)
+    small = small_scene.render(net, W, H)[0].clone()
+    plan = small_scene.last_render_info()
+    assert plan["resident_kernel"] and plan["cell_table"] == (grid is not None)
     plain = capi.Scene(**kw).set_option("small_kernel", 0).render(net, W, H)[0].clone()
     assert small[3].max() > 0.2
-    import torch
-    diff = float((torch.nan_to_num(small, nan=-7.0) - torch.nan_to_num(plain, nan=-7.0)).abs().max())
-    assert diff < 5e-4, diff
+    nn = lambda a: torch.nan_to_num(a, nan=-7.0)  # noqa: E731
+    if grid is None:  # (both kernels advance their features by rotation)
+        diff = float((nn(small) - nn(plain)).abs().max())
+        assert diff < 5e-4, diff
+    else:
+        # The latent grid enters the resident kernel through the cell table (srn_forward_rotating_resident_cells: one MFMA K step on the
+        # trilinear weights, features advanced by rotation), the LDS kernel gathers and derives the features at every step: the same
+        # arithmetic up to the fp16 rounding of the table entries once the rotation is off (fourier_resync = 1) ...
+        exact = capi.Scene(**kw).set_option("fourier_resync", 1).render(net, W, H)[0].clone()
+        diff = float((nn(exact) - nn(plain)).abs().max())
+        assert diff < 5e-4, diff
+        # ... and the gather variant of the resident kernel (cell_table = 0; one 16-channel chunk) runs the LDS kernel's arithmetic
+        if grid[0] == 16:
+            gathers = capi.Scene(**kw).set_option("cell_table", 0).render(net, W, H)[0].clone()
+            assert float((nn(gathers) - nn(plain)).abs().max()) < 5e-4
     ref, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT), W, H, 0, H)
     assert np.abs(small[:4].cpu().numpy() - ref[:4]).max() < TOL_IMG
     pos = torch.rand(4096, 3, device="cuda", generator=torch.Generator("cuda").manual_seed(3)) - 0.5
