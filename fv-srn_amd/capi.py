@@ -443,7 +443,7 @@ class Scene:
         """How the last render of this scene treated a ray's samples (fvsrn_scene_last_render_info)."""
         a = (_I * 4)()
         _check(lib().fvsrn_scene_last_render_info(self._h, a))
-        return dict(segments=a[0], rotation_resync=a[1], resident_kernel=a[2] in (1, 4), overlap_kernel=a[2] == 2, adjoint_kernel=a[2] == 3, cell_table=a[2] == 4,
+        return dict(segments=a[0], rotation_resync=a[1], resident_kernel=a[2] in (1, 4), overlap_kernel=a[2] == 2, adjoint_kernel=a[2] == 3, cell_table=a[2] in (4, 5),
                     waves_per_block=a[3])
 
     def __del__(self):

@@ -518,6 +518,7 @@ struct fvsrn_network {
         HIP_CHECK(hipFuncSetAttribute(kinfoScaled.renderFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         HIP_CHECK(hipFuncSetAttribute(kinfo.renderShadedFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         if (const void* fn = render_stripe_fn(keyScaled)) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
+        if (const void* fn = render_cells_fn(keyScaled)) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         if (const void* fn = render_adjoint_fn(key)) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         deviceValid = true;
     }
@@ -1041,6 +1042,8 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
                  (smallGrid == 2 && P.gridK == 1 && render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1, 1))))
                 name = "render_small_kernel<act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "," + std::to_string(P.numLayers) +
                        ",SGRID=" + std::to_string(smallGrid) + "> (unshaded; else " + name + ")";
+            else if (cells && render_cells_fn(k))  // the decoded latent grid through the cell table (renderImpl)
+                name = "render_cells_kernel<" + std::to_string(k.CD) + ",act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "> (unshaded; else " + name + ")";
         }
         std::strncpy(buf, name.c_str(), cap - 1);
         buf[cap - 1] = 0;
@@ -1489,9 +1492,13 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             const void* stripeFn = nullptr;
             if (!smallFn && !a.shaded && O[FVSRN_OPT_OVERLAP_KERNEL] == 1)
                 stripeFn = render_stripe_fn(net->keyScaled);
+            // every other unshaded render of a network whose decoded latent grid has a cell table: render_kernel with the grid through that table
+            const void* cellsFn = nullptr;
+            if (!smallFn && !stripeFn && !a.shaded && net->keyScaled.grid == 1 && a.P.cellTable && O[FVSRN_OPT_CELL_TABLE] != 0)
+                cellsFn = render_cells_fn(net->keyScaled);
             // the adjoint gradient mode up to 64 channels: its own kernel (render_adjoint_kernel, kernels.hpp)
             const void* adjointFn = (a.shaded && d.gradient_mode == FVSRN_GRADIENT_ADJOINT_METHOD) ? render_adjoint_fn(net->key) : nullptr;
-            const void* altFn = smallFn ? smallFn : (stripeFn ? stripeFn : adjointFn);
+            const void* altFn = smallFn ? smallFn : (stripeFn ? stripeFn : (cellsFn ? cellsFn : adjointFn));
             const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded, altFn, O[FVSRN_OPT_MAX_BLOCKS_PER_CU]);
             const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));  // workgroups the chip holds at once
             // Depth segments (kernels.hpp): with fewer tiles than ~4x the resident waves (small images, the stripes of one
@@ -1567,10 +1574,11 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                                  !a.shaded;  // kRotate / kRotateLds, kernels.hpp
             scene->lastInfo[0] = K;
             scene->lastInfo[1] = rotates ? S.resyncMask + 1 : 0;
-            scene->lastInfo[2] = smallFn ? (smallGrid == 2 ? 4 : 1) : (stripeFn ? 2 : (adjointFn ? 3 : 0));
+            scene->lastInfo[2] = smallFn ? (smallGrid == 2 ? 4 : 1) : (stripeFn ? 2 : (cellsFn ? 5 : (adjointFn ? 3 : 0)));
             scene->lastInfo[3] = wpb;
             hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid, a, grid, unsigned(64 * wpb), lds, s)
                                    : (stripeFn ? launch_render_stripe(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s)
+                                      : cellsFn ? launch_render_cells(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s)
                                       : (adjointFn ? launch_render_adjoint(net->key, a, grid, unsigned(64 * wpb), lds, s)
                                                    : launch_render(a.shaded ? net->key : net->keyScaled, a, grid, unsigned(64 * wpb), lds, s)));
             if (e == hipSuccess && K > 1) e = launch_composite(S.partial, d_out8, K, plane, S, s);

@@ -631,7 +631,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             if (fusedGradient) o = srn_forward_gradient<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, S.gridDiffStep, fgx, fgy, fgz);
             else o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE, SCHED>(P, lds, px, py, pz, dx, dy, dz);
         } else {
-            o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE, SCHED>(P, lds, px, py, pz, dx, dy, dz);
+            o = srn_forward<CD, ACT, (GRID == 1 && CELLS ? 3 : GRID), HAS_DIR, FMODE, SCHED>(P, lds, px, py, pz, dx, dy, dz, validMask);
         }
 
         FVSRN_MARK(P, 5);  // last layer (+ the other half of the rotation)
@@ -877,13 +877,13 @@ __device__ __forceinline__ float* render_prologue(const NetParams& P, const Scen
     return tfLds;
 }
 
-template <int CD, int ACT, int GRID, bool HAS_DIR, int SHADED, int SCHED = 0>
+template <int CD, int ACT, int GRID, bool HAS_DIR, int SHADED, int SCHED = 0, bool CELLS = false>
 __device__ __forceinline__ void render_entry(const NetParams& P, const SceneParams& S, float* __restrict__ out,
                                              unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* tfLds = render_prologue(P, S, lds);
     if constexpr (GRID == 0) {
-        if (P.noFourier) return render_body<CD, ACT, GRID, HAS_DIR, FM_FIRST_LAYER, SHADED, TAIL_GENERIC, 0, SCHED>(P, S, lds, tfLds, out, stats);
+        if (P.noFourier) return render_body<CD, ACT, GRID, HAS_DIR, FM_FIRST_LAYER, SHADED, TAIL_GENERIC, 0, SCHED, CELLS>(P, S, lds, tfLds, out, stats);
     }
     if constexpr (!SHADED) {
         // The straight-line tails: a scalar network behind an Identity or Texture TF with Beer-Lambert blending, phases inside the v_cos /
@@ -892,19 +892,27 @@ __device__ __forceinline__ void render_entry(const NetParams& P, const ScenePara
         const bool scalarNet = P.outputMode == FVSRN_OUT_DENSITY || P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
         if (scalarNet && !P.fourierNeedsFract && S.blendMode == FVSRN_BLEND_BEER_LAMBERT) {
             if (S.tfKind == FVSRN_TF_IDENTITY && S.tfAbsorptionStepLog2e <= 0.f)
-                return render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_SCALAR_IDENTITY, 0, SCHED>(P, S, lds, tfLds, out, stats);
+                return render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_SCALAR_IDENTITY, 0, SCHED, CELLS>(P, S, lds, tfLds, out, stats);
             if (S.tfKind == FVSRN_TF_TEXTURE && S.tfOpacityNonNegative)  // (a negative opacity: the generic tail skips the sample, stepping_dvr.cuh:137)
-                return render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_SCALAR_TEXTURE, 0, SCHED>(P, S, lds, tfLds, out, stats);
+                return render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_SCALAR_TEXTURE, 0, SCHED, CELLS>(P, S, lds, tfLds, out, stats);
         }
     }
-    if (P.fourierNeedsFract) return render_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS, SHADED, TAIL_GENERIC, 0, SCHED>(P, S, lds, tfLds, out, stats);
-    render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_GENERIC, 0, SCHED>(P, S, lds, tfLds, out, stats);
+    if (P.fourierNeedsFract) return render_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS, SHADED, TAIL_GENERIC, 0, SCHED, CELLS>(P, S, lds, tfLds, out, stats);
+    render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_GENERIC, 0, SCHED, CELLS>(P, S, lds, tfLds, out, stats);
 }
 
 template <int CD, int ACT, int GRID, bool HAS_DIR>
 __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                unsigned long long* __restrict__ stats) {
     render_entry<CD, ACT, GRID, HAS_DIR, 0>(P, S, out, stats);
+}
+
+// render_kernel<CD, ACT, 1, HAS_DIR> with the decoded latent grid through the cell table (r04: srn_device.hpp cell_prepare / cells_accumulate; the
+// unshaded renderer of every network with a FLOAT / BYTE_LINEAR grid that has a table, FVSRN_OPT_CELL_TABLE)
+template <int CD, int ACT, bool HAS_DIR>
+__global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, 1)) void render_cells_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+                                                                     unsigned long long* __restrict__ stats) {
+    render_entry<CD, ACT, 1, HAS_DIR, 0, 0, true>(P, S, out, stats);
 }
 
 // render_kernel for 48- and 64-wide latent-grid networks in the fragment-major layer order: 218 registers and no scratch against the 76

@@ -385,6 +385,120 @@ __device__ __forceinline__ half8_t grid_features(const NetParams& P, const GridT
     return grid_pack(acc);
 }
 
+// ---- latent grid through the cell table (r04) --------------------------------------------------------------------------------------
+// The samples a wave evaluates in one step belong to the rays of an 8 x 8 pixel tile at (almost) the same depth: a patch of a hundredth of
+// the box, against grid cells of 1/15 .. 1/31.  Nearly always the 32 samples of an MFMA column tile lie in ONE cell, sometimes in two.  Inside
+// a cell the trilinear fetch is linear in its eight weights, and so is the first layer behind it:
+//     W_latent . (sum_c w_c G_c) = sum_c w_c (W_latent . G_c) = T_cell . w,        T_cell = [W_latent G_c]_c   (C x 8, fp16, NetParams::cellTable)
+// i.e. ONE MFMA K step whose A operand is the cell's table entry and whose B operand holds the sample's eight weights -- K = 16 takes two
+// cells (lane half 0: slots of cell A, lane half 1: cell B; a sample's weights are zero in the slots of the cell it is not in).  That
+// replaces, per wave step, 16 x 16-byte gathers per lane, 64 v_dot2_f32_f16, the record address arithmetic and 8 converts by 2 coalesced
+// 512-byte loads, 8 v_cndmask and a handful of scalar instructions, with the same number of MFMAs as the latent K step it stands in for
+// (and any number of latent channels costs the same).  Tiles whose samples touch more than two cells (corners of the cell lattice) run the
+// network again for the samples not covered yet -- wave-uniform, a few percent of the steps.
+// Same texture semantics as grid_tap: texel coordinate p N - 0.5 clamped to [0, N - 1], cell x0 = min(floor, N - 2), weight wx = coordinate - x0
+// (1 exactly on the last texel); fp16 weights like there; the table entries carry one fp16 rounding of W.G where the gather path rounds
+// the interpolated feature.
+struct CellTap {
+    unsigned w[4];  // packed fp16 weight pairs {w_zy (1 - wx), w_zy wx}, zy = 2 dz + dy: the eight K slots of the sample's cell
+    unsigned cell;
+};
+
+__device__ __forceinline__ CellTap cell_tap(const NetParams& P, float px, float py, float pz) {
+    const float xm = P.gridXf - 1.f, ym = P.gridYf - 1.f, zm = P.gridZf - 1.f;
+    const float fx = __builtin_amdgcn_fmed3f(fmaf(px, P.gridXf, -0.5f), 0.f, xm);
+    const float fy = __builtin_amdgcn_fmed3f(fmaf(py, P.gridYf, -0.5f), 0.f, ym);
+    const float fz = __builtin_amdgcn_fmed3f(fmaf(pz, P.gridZf, -0.5f), 0.f, zm);
+    const float x0 = fminf(floorf(fx), xm - 1.f), y0 = fminf(floorf(fy), ym - 1.f), z0 = fminf(floorf(fz), zm - 1.f);
+    const float wx = fx - x0, wy = fy - y0, wz = fz - z0;
+    CellTap t;
+    // (exact in fp32: fewer than 2^24 cells; positions of rays that miss the box may be anything, also NaN: any valid cell will do)
+    t.cell = min(unsigned(fmaf(fmaf(z0, ym, y0), xm, x0)), P.cellCount - 1u);
+    const float ux = 1.f - wx, uy = 1.f - wy, uz = 1.f - wz;
+    const float w4[4] = {uz * uy, uz * wy, wz * uy, wz * wy};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float2_t v = {w4[k] * ux, w4[k] * wx};
+        t.w[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
+    }
+    return t;
+}
+
+__device__ __forceinline__ unsigned select_bits_by_mask(unsigned long long m, unsigned x) {
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
+    return r;
+}
+
+// One step of a tile's cell bookkeeping: the next (up to) two cells among the tile samples whose bit is set in `rem` (the wave mask of the
+// samples still to cover, 32 bits: both lane halves hold the same sample), the weights of the samples in them as the B fragment, the
+// cells' table entries (one per M tile) as the A fragments.  Returns the samples covered.
+template <int MT>
+__device__ __forceinline__ unsigned cell_pair(const NetParams& P, const unsigned (&w)[4], unsigned cell, unsigned rem, int h, unsigned laneOff,
+                                              half8_t& bfrag, half8_t (&afrag)[MT]) {
+    const unsigned cA = __builtin_amdgcn_readlane(cell, rem ? __builtin_ctz(rem) : 0);
+    const unsigned long long mA = __builtin_amdgcn_ballot_w64(cell == cA);
+    const unsigned rem1 = rem & ~unsigned(mA);
+    const unsigned cB = __builtin_amdgcn_readlane(cell, rem1 ? __builtin_ctz(rem1) : 0);
+    const unsigned long long mB = rem1 ? __builtin_amdgcn_ballot_w64(cell == cB) : 0ull;
+    const unsigned long long sel = (mA & 0xffffffffull) | (mB & 0xffffffff00000000ull);
+    uint4_t b;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = select_bits_by_mask(sel, w[k]);
+    bfrag = __builtin_bit_cast(half8_t, b);
+    const unsigned off = __umul24(h ? cB : cA, P.cellStride) + laneOff;  // (both below 2^24, the table below 2^31 bytes: api.cpp)
+    const char* base = static_cast<const char*>(P.cellTable) + off;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) afrag[m] = *reinterpret_cast<const half8_t*>(base + 512 * m);
+    return unsigned(mA) | unsigned(mB);
+}
+
+// What the first layer needs of a wave step's latent grid: per tile the samples' weights and cells, the first cell pair's fragments
+// (loaded ahead of the Fourier work) and the samples they do not cover
+template <int MT>
+struct CellPre {
+    unsigned w[2][4];
+    unsigned cell[2];
+    unsigned rem[2];
+    half8_t gf[2];
+    half8_t ga[2][MT];
+};
+
+template <int MT>
+__device__ __forceinline__ void cell_prepare(const NetParams& P, float px, float py, float pz, unsigned long long validMask, int h, unsigned laneOff,
+                                             CellPre<MT>& C) {
+    const CellTap own = cell_tap(P, px, py, pz);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        auto a = lane_half_swap(own.w[k], own.w[k]);
+        C.w[0][k] = a[0]; C.w[1][k] = a[1];
+    }
+    {
+        auto c = lane_half_swap(own.cell, own.cell);
+        C.cell[0] = c[0]; C.cell[1] = c[1];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const unsigned valid = unsigned(validMask >> (32 * t));
+        C.rem[t] = valid & ~cell_pair<MT>(P, C.w[t], C.cell[t], valid, h, laneOff, C.gf[t], C.ga[t]);
+    }
+}
+
+// The latent K step(s) of tile t into the first layer's accumulators: the prepared pair, then -- wave-uniform, a few percent of the steps --
+// further pairs until every valid sample of the tile has met its cell
+template <int MT>
+__device__ __forceinline__ void cells_accumulate(const NetParams& P, const CellPre<MT>& C, int t, int h, unsigned laneOff, floatx16* acc) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(C.ga[t][m], C.gf[t], acc[m], 0, 0, 0);
+    unsigned rem = C.rem[t];
+    while (rem) {
+        half8_t gf, ga[MT];
+        rem &= ~cell_pair<MT>(P, C.w[t], C.cell[t], rem, h, laneOff, gf, ga);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[m], gf, acc[m], 0, 0, 0);
+    }
+}
+
 // ---- building blocks of the forward pass -------------------------------------------------------------------
 constexpr int mtiles(int CD) { return (16 * CD + 31) / 32; }
 
@@ -701,7 +815,9 @@ struct GridPre {
 
 template <int CD, int ACT, int GRID, bool HAS_DIR, int NFILL, class Pre, class Fill>
 __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, const char* lds, half8_t (&xb)[2][2 * mtiles(CD)],
-                                                         float px, float py, float pz, Pre&& pre, Fill&& fill, const GridPre* gpre = nullptr) {
+                                                         float px, float py, float pz, Pre&& pre, Fill&& fill, const GridPre* gpre = nullptr,
+                                                         const CellPre<mtiles(CD)>* cells = nullptr) {
+    // GRID = 3: the decoded latent grid through the cell table (`cells`: cell_prepare / cells_accumulate) instead of gathers
     constexpr int MT = mtiles(CD), KS = CD, NM = MT * KS, NV = 4 * MT;
     const int lane = lane_id();
     const int h = lane >> 5;
@@ -739,13 +855,13 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
         for (int m = 0; m < MT; ++m) acc[t][m] = bias(P.offBias + m * 128);
     const int offGridW = P.offLayer0 + NM * kFragBytes;  // [g][m] fragments of the latent K steps
     // (the latent-step fragments are only prefetched where registers allow: at 64 wide it would spill)
-    constexpr bool PREFETCH_AG = MT == 1;
+    constexpr bool PREFETCH_AG = MT == 1 && GRID != 3;
     // first latent chunk fetched ahead and reduced behind the first layer's MFMAs: only where its 32 registers fit
     constexpr bool GRID_AHEAD = GRID == 1 && MT == 1;
     half8_t ag[MT];
     GridTap gt[2];
     GridRaw raw;
-    if constexpr (GRID != 0) {
+    if constexpr (GRID != 0 && GRID != 3) {
         if constexpr (PREFETCH_AG) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) ag[m] = frag(offGridW + m * kFragBytes);
@@ -783,7 +899,9 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
         interleave<NM, NF0>([&](int i) { acc[0][i / KS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], xb[0][i % KS], acc[0][i / KS], 0, 0, 0); },
                             [&](int j) { fill(j); });
     }
-    if constexpr (GRID != 0) {
+    if constexpr (GRID == 3) {
+        cells_accumulate<MT>(P, *cells, 0, h, unsigned(lane & 31) * 16u, acc[0]);
+    } else if constexpr (GRID != 0) {
         for (int g = 0; g < P.gridK; ++g) {
             if (havePre && g == 0) gf = gpre->gf[0];
             else if (!GRID_AHEAD || g > 0) gf = grid_features<GRID>(P, gt[0], g, h, kTapHalfInOffset);
@@ -841,7 +959,10 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
 
     // ---- first layer, tile 1 || convert tile 0 -----------------------------------------------------------------------
     slot(T1{}, Yes{}, P.offBias + kBiasLayer, NL > 1 ? P.offHidden : P.offLast);
-    if constexpr (GRID != 0) {
+    if constexpr (GRID == 3) {
+        cells_accumulate<MT>(P, *cells, 1, h, unsigned(lane & 31) * 16u, acc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (GRID != 0) {
         for (int g = 0; g < P.gridK; ++g) {
             if (GRID_AHEAD && g == 0) {
                 float gacc[8];
@@ -907,13 +1028,14 @@ __device__ __forceinline__ float4_t srn_layers_pipelined(const NetParams& P, con
 // networks (measured r01: there the extra registers of the pipelined order cost more occupancy than the schedule gains).
 template <int CD, int ACT, int GRID, bool HAS_DIR, int NFILL, class Pre, class Fill>
 __device__ __forceinline__ float4_t srn_layers_kmajor(const NetParams& P, const char* lds, half8_t (&xb)[2][2 * mtiles(CD)],
-                                                      float px, float py, float pz, Pre&& pre, Fill&& fill, const GridPre* gpre = nullptr) {
+                                                      float px, float py, float pz, Pre&& pre, Fill&& fill, const GridPre* gpre = nullptr,
+                                                      const CellPre<mtiles(CD)>* cells = nullptr) {
     constexpr int MT = mtiles(CD), KS = CD;
     const int lane = lane_id();
     const int h = lane >> 5;
     const float actA = P.actA, actB = P.actB;
     GridTap gt[2];
-    if constexpr (GRID != 0) {
+    if constexpr (GRID != 0 && GRID != 3) {
         if (gpre) { gt[0] = gpre->gt[0]; gt[1] = gpre->gt[1]; }
         else grid_tap_bcast<GRID == 2>(grid_tap(P, px, py, pz), gt[0], gt[1]);
     }
@@ -939,7 +1061,12 @@ __device__ __forceinline__ float4_t srn_layers_kmajor(const NetParams& P, const 
                 acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xb[1][s], s == 0 ? bias : acc[1][m], 0, 0, 0);
             }
         }
-        if constexpr (GRID != 0) {
+        if constexpr (GRID == 3) {
+            if (l == 0) {
+                cells_accumulate<MT>(P, *cells, 0, h, unsigned(lane & 31) * 16u, acc[0]);
+                cells_accumulate<MT>(P, *cells, 1, h, unsigned(lane & 31) * 16u, acc[1]);
+            }
+        } else if constexpr (GRID != 0) {
             if (l == 0) {
                 for (int g = 0; g < P.gridK; ++g) {
                     const half8_t g0 = (havePre && g == 0) ? gpre->gf[0] : grid_features<GRID>(P, gt[0], g, h, kTapHalfInOffset);
@@ -983,7 +1110,8 @@ __device__ __forceinline__ float4_t srn_layers_kmajor(const NetParams& P, const 
 // SCHED = 1: the fragment-major order for every width (render_stripe_kernel: no register spills, see kernels.hpp)
 template <int CD, int ACT, int GRID, bool HAS_DIR, int NFILL, bool MAYBE_NO_LAYERS, int SCHED = 0, class Pre, class Fill>
 __device__ __forceinline__ float4_t srn_layers(const NetParams& P, const char* lds, half8_t (&xb)[2][2 * mtiles(CD)], float px,
-                                               float py, float pz, Pre&& pre, Fill&& fill, const GridPre* gpre = nullptr) {
+                                               float py, float pz, Pre&& pre, Fill&& fill, const GridPre* gpre = nullptr,
+                                               const CellPre<mtiles(CD)>* cells = nullptr) {
 #ifndef FVSRN_NO_PIPELINE
     // measured (r01, 1024^2 x 512): the pipelined order wins for Fourier-only networks (32x4: 106.7 -> 110.3 Gsamples/s) and
     // for 64-wide latent-grid networks (23.1 -> 23.9); for 32-wide ones with a grid its extra registers cost more
@@ -991,12 +1119,12 @@ __device__ __forceinline__ float4_t srn_layers(const NetParams& P, const char* l
     if constexpr (SCHED == 0 && CD >= 2 && CD <= 4 && (GRID == 0 || CD >= 3)) {  // (16 channels: one K step, the fragment-major order)
         if constexpr (MAYBE_NO_LAYERS) {
             if (P.numLayers == 0)  // wave-uniform
-                return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill, gpre);
+                return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill, gpre, cells);
         }
-        return srn_layers_pipelined<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill, gpre);
+        return srn_layers_pipelined<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill, gpre, cells);
     } else
 #endif
-        return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill, gpre);
+        return srn_layers_kmajor<CD, ACT, GRID, HAS_DIR, NFILL>(P, lds, xb, px, py, pz, pre, fill, gpre, cells);
 }
 
 // positions -> raw network outputs (evaluate_points, and render steps of networks without the rotation shortcut)
@@ -1005,9 +1133,18 @@ __device__ __forceinline__ float4_t srn_layers(const NetParams& P, const char* l
 #endif
 template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, int SCHED = 0>
 __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* lds, float px, float py, float pz,
-                                                float dx, float dy, float dz) {
+                                                float dx, float dy, float dz, unsigned long long validMask = ~0ull) {
     half8_t xb[2][2 * mtiles(CD)];
-    if constexpr (GRID == 1 && FVSRN_GRID_PRE) {
+    if constexpr (GRID == 3) {
+        // latent grid through the cell table: weights, cells and the first cell pair's fragments ahead of the Fourier work (validMask: the
+        // samples that count -- the others need no cell of their own)
+        const int lane = lane_id();
+        CellPre<mtiles(CD)> C;
+        cell_prepare<mtiles(CD)>(P, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
+        __builtin_amdgcn_sched_barrier(0);
+        return srn_layers<CD, ACT, GRID, HAS_DIR, 0, false, SCHED>(
+            P, lds, xb, px, py, pz, [&]() { fourier_fragments<CD, ACT, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, xb); }, [](int) {}, nullptr, &C);
+    } else if constexpr (GRID == 1 && FVSRN_GRID_PRE) {
         // Latent grid with decoded working values: the 8 gathers of a tile's first 16-channel chunk are issued in FRONT of that
         // tile's Fourier work (phase MFMA, v_cos, converts), which covers their L1 / L2 latency; one 32-register buffer serves
         // both tiles in turn (see GridPre).
@@ -1145,10 +1282,14 @@ __device__ __forceinline__ void load_resident(const NetParams& P, const char* ld
 // colour networks; otherwise only output 0)
 template <int ACT, int NLC, int NFILL, bool ALL4, int RGRID = 0, class Pre, class Fill>
 __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, const ResidentNet<NLC, RGRID>& R, half8_t (&xb)[2][2], Pre&& pre, Fill&& fill,
-                                                        const half8_t* gf = nullptr, const half8_t* ga = nullptr) {
-    // gf: B fragments of the two tiles' latent K step; its A fragment is R.wg[0] (RGRID = 1: the first layer's latent columns) or ga[tile]
-    // (RGRID = 2: the cell-table fragments of the tile's cells, gf = the trilinear weights)
-    auto latentA = [&](int T) -> half8_t { if constexpr (RGRID == 2) return ga[T]; else return R.wg[0]; };
+                                                        const half8_t* gf = nullptr, const CellPre<1>* cells = nullptr) {
+    // the latent K step of layer 0: RGRID = 1: gf = B fragments of the two tiles' latent features, A = R.wg[0] (the first layer's latent
+    // columns); RGRID = 2: through the cell table (cells_accumulate)
+    [[maybe_unused]] const int lane_ = lane_id();
+    auto latent = [&](int T, floatx16& a) {
+        if constexpr (RGRID == 2) cells_accumulate<1>(P, *cells, T, lane_ >> 5, unsigned(lane_ & 31) * 16u, &a);
+        else a = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wg[0], gf[T], a, 0, 0, 0);
+    };
     const float actA = P.actA, actB = P.actB;
     constexpr int NF0 = NFILL / 2;
     floatx16 acc[2];
@@ -1164,7 +1305,7 @@ __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, cons
     interleave<2, NF0>([&](int i) { acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.w[i], xb[0][i], i == 0 ? (RGRID ? zero16 : R.b[0]) : acc[0], 0, 0, 0); },
                        [&](int j) { fill(j); });
     if constexpr (RGRID != 0) {  // latent K step of layer 0 (gf: B fragments of the two tiles' latent features)
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(latentA(0), gf[0], acc[0], 0, 0, 0);
+        latent(0, acc[0]);
         __builtin_amdgcn_sched_barrier(0);
     }
     // half-layer slot: layer l for tile T || activation + convert of the other tile
@@ -1185,7 +1326,7 @@ __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, cons
                          [&](int q) { act_pack_quarter<ACT>(acc[O], q, actA, actB, xb[O][0], xb[O][1]); });
 #endif
         if constexpr (RGRID != 0 && L == 0) {
-            acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(latentA(T), gf[T], acc[T], 0, 0, 0);
+            latent(T, acc[T]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -1248,121 +1389,31 @@ __device__ __forceinline__ float4_t srn_forward_resident_grid(const NetParams& P
     return srn_layers_resident<ACT, NLC, 0, ALL4, 1>(P, R, xb, []() {}, [](int) {}, gf);
 }
 
-// ---- latent grid through the cell table (r04) --------------------------------------------------------------------------------------
-// The samples a wave evaluates in one step belong to the rays of an 8 x 8 pixel tile at (almost) the same depth: a patch of a hundredth of
-// the box, against grid cells of 1/15 .. 1/31.  Nearly always the 32 samples of an MFMA column tile lie in ONE cell, sometimes in two.  Inside
-// a cell the trilinear fetch is linear in its eight weights, and so is the first layer behind it:
-//     W_latent . (sum_c w_c G_c) = sum_c w_c (W_latent . G_c) = T_cell . w,        T_cell = [W_latent G_c]_c   (C x 8, fp16, NetParams::cellTable)
-// i.e. ONE MFMA K step whose A operand is the cell's table entry and whose B operand holds the sample's eight weights -- K = 16 takes two
-// cells (lane half 0: slots of cell A, lane half 1: cell B; a sample's weights are zero in the slots of the cell it is not in).  That
-// replaces, per wave step, 16 x 16-byte gathers per lane, 64 v_dot2_f32_f16, the record address arithmetic and 8 converts by 2 coalesced
-// 512-byte loads, 8 v_cndmask and a handful of scalar instructions, with the same number of MFMAs as the latent K step it stands in for
-// (and any number of latent channels costs the same).  Tiles whose samples touch more than two cells (corners of the cell lattice) run the
-// network again for the samples not covered yet -- wave-uniform, a few percent of the steps.
-// Same texture semantics as grid_tap: texel coordinate p N - 0.5 clamped to [0, N - 1], cell x0 = min(floor, N - 2), weight wx = coordinate - x0
-// (1 exactly on the last texel); fp16 weights like there; the table entries carry one fp16 rounding of W.G where the gather path rounds
-// the interpolated feature.
-struct CellTap {
-    unsigned w[4];  // packed fp16 weight pairs {w_zy (1 - wx), w_zy wx}, zy = 2 dz + dy: the eight K slots of the sample's cell
-    unsigned cell;
-};
-
-__device__ __forceinline__ CellTap cell_tap(const NetParams& P, float px, float py, float pz) {
-    const float xm = P.gridXf - 1.f, ym = P.gridYf - 1.f, zm = P.gridZf - 1.f;
-    const float fx = __builtin_amdgcn_fmed3f(fmaf(px, P.gridXf, -0.5f), 0.f, xm);
-    const float fy = __builtin_amdgcn_fmed3f(fmaf(py, P.gridYf, -0.5f), 0.f, ym);
-    const float fz = __builtin_amdgcn_fmed3f(fmaf(pz, P.gridZf, -0.5f), 0.f, zm);
-    const float x0 = fminf(floorf(fx), xm - 1.f), y0 = fminf(floorf(fy), ym - 1.f), z0 = fminf(floorf(fz), zm - 1.f);
-    const float wx = fx - x0, wy = fy - y0, wz = fz - z0;
-    CellTap t;
-    // (exact in fp32: fewer than 2^24 cells; positions of rays that miss the box may be anything, also NaN: any valid cell will do)
-    t.cell = min(unsigned(fmaf(fmaf(z0, ym, y0), xm, x0)), P.cellCount - 1u);
-    const float ux = 1.f - wx, uy = 1.f - wy, uz = 1.f - wz;
-    const float w4[4] = {uz * uy, uz * wy, wz * uy, wz * wy};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float2_t v = {w4[k] * ux, w4[k] * wx};
-        t.w[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
-    }
-    return t;
-}
-
-__device__ __forceinline__ unsigned select_bits_by_mask(unsigned long long m, unsigned x) {
-    unsigned r;
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
-    return r;
-}
-
-// One step of a tile's cell bookkeeping: the next (up to) two cells among the tile samples whose bit is set in `rem` (the wave mask of the
-// samples still to evaluate, 32 bits: both lane halves hold the same sample), the weights of the samples in them as the B fragment, the
-// cells' table entries as the A fragment.  Returns the samples covered.
-__device__ __forceinline__ unsigned cell_pair(const NetParams& P, const unsigned (&w)[4], unsigned cell, unsigned rem, int h, unsigned laneOff,
-                                              half8_t& bfrag, half8_t& afrag) {
-    const unsigned cA = __builtin_amdgcn_readlane(cell, rem ? __builtin_ctz(rem) : 0);
-    const unsigned long long mA = __builtin_amdgcn_ballot_w64(cell == cA);
-    const unsigned rem1 = rem & ~unsigned(mA);
-    const unsigned cB = __builtin_amdgcn_readlane(cell, rem1 ? __builtin_ctz(rem1) : 0);
-    const unsigned long long mB = rem1 ? __builtin_amdgcn_ballot_w64(cell == cB) : 0ull;
-    const unsigned long long sel = (mA & 0xffffffffull) | (mB & 0xffffffff00000000ull);
-    uint4_t b;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) b[k] = select_bits_by_mask(sel, w[k]);
-    bfrag = __builtin_bit_cast(half8_t, b);
-    const unsigned off = __umul24(h ? cB : cA, P.cellStride) + laneOff;  // (both below 2^24, the table below 2^31 bytes: api.cpp)
-    afrag = *reinterpret_cast<const half8_t*>(static_cast<const char*>(P.cellTable) + off);
-    return unsigned(mA) | unsigned(mB);
-}
-
 template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
 __device__ __forceinline__ float4_t srn_forward_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, float px, float py, float pz,
                                                               float dx, float dy, float dz, unsigned long long validMask) {
     constexpr int NPASS = HAS_DIR ? 4 : 2;
     const int lane = lane_id();
     const int h = lane >> 5;
-    const unsigned laneOff = unsigned(lane & 31) * 16u;
-    const CellTap own = cell_tap(P, px, py, pz);
-    unsigned wT[2][4], cT[2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        auto a = lane_half_swap(own.w[k], own.w[k]);
-        wT[0][k] = a[0]; wT[1][k] = a[1];
-    }
-    {
-        auto c = lane_half_swap(own.cell, own.cell);
-        cT[0] = c[0]; cT[1] = c[1];
-    }
-    half8_t b0[2];
+    CellPre<1> C;
+    cell_prepare<1>(P, px, py, pz, validMask, h, unsigned(lane & 31) * 16u, C);
+    half8_t b0[2], xb[2][2];
     phase_operands<HAS_DIR, true>(px, py, pz, dx, dy, dz, h, b0);
-    unsigned rem0 = unsigned(validMask), rem1 = unsigned(validMask >> 32);
-    float4_t out = {0.f, 0.f, 0.f, 0.f};
-    for (;;) {
-        half8_t xb[2][2], gf[2], ga[2];
-        const unsigned cov0 = cell_pair(P, wT[0], cT[0], rem0, h, laneOff, gf[0], ga[0]);
-        const unsigned cov1 = cell_pair(P, wT[1], cT[1], rem1, h, laneOff, gf[1], ga[1]);
-        floatx16 d[2];
-        {
-            const floatx16 z = {0};
-            d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wp[0], b0[0], z, 0, 0, 0);
-            d[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wp[0], b0[1], z, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            phase_cos<FM_COS>(d[t], NPASS);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d[t], q, 0.f, 0.f, xb[t][0], xb[t][1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const float4_t o = srn_layers_resident<ACT, NLC, 0, ALL4, 2>(P, R, xb, []() {}, [](int) {}, gf, ga);
-        const unsigned long long covered = (unsigned long long)cov0 | ((unsigned long long)cov1 << 32);
-        out[0] = select_by_mask_or(covered, o[0], out[0]);
-        if constexpr (ALL4) {
-            out[1] = select_by_mask_or(covered, o[1], out[1]); out[2] = select_by_mask_or(covered, o[2], out[2]); out[3] = select_by_mask_or(covered, o[3], out[3]);
-        }
-        rem0 &= ~cov0; rem1 &= ~cov1;
-        if ((rem0 | rem1) == 0) break;  // wave-uniform; as a rule the first pass covers every sample
+    floatx16 d[2];
+    {
+        const floatx16 z = {0};
+        d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wp[0], b0[0], z, 0, 0, 0);
+        d[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wp[0], b0[1], z, 0, 0, 0);
     }
-    return out;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        phase_cos<FM_COS>(d[t], NPASS);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d[t], q, 0.f, 0.f, xb[t][0], xb[t][1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return srn_layers_resident<ACT, NLC, 0, ALL4, 2>(P, R, xb, []() {}, [](int) {}, nullptr, &C);
 }
 
 // The same with rotated Fourier features (r03): the current features stay in 32 registers (fp32, both tiles), their per-step rotation
@@ -1449,45 +1500,23 @@ __device__ __forceinline__ float4_t srn_forward_rotating_resident(const NetParam
         [&](int j) { fourier_advance_piece<2, HAS_DIR>(feat, dfeat, NP - NFILL + j); });
 }
 
-// srn_forward_resident_cells with rotated Fourier features (the registers the gathers held take the rotation state): the features
-// of the current sample are converted inside the pass loop, the rotation to the next sample runs once, behind it
+// srn_forward_resident_cells with rotated Fourier features (the registers the gathers held take the rotation state)
 template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
 __device__ __forceinline__ float4_t srn_forward_rotating_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, floatx16 (&feat)[2][1],
                                                                        const floatx16 (&dfeat)[2][1], float px, float py, float pz,
                                                                        unsigned long long validMask) {
     const int lane = lane_id();
-    const int h = lane >> 5;
-    const unsigned laneOff = unsigned(lane & 31) * 16u;
-    const CellTap own = cell_tap(P, px, py, pz);
-    unsigned wT[2][4], cT[2];
+    CellPre<1> C;
+    cell_prepare<1>(P, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
+    half8_t xb[2][2];
+    return srn_layers_resident<ACT, NLC, 0, ALL4, 2>(
+        P, R, xb,
+        [&]() {
+            feature_fragments<2>(feat, xb);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        auto a = lane_half_swap(own.w[k], own.w[k]);
-        wT[0][k] = a[0]; wT[1][k] = a[1];
-    }
-    {
-        auto c = lane_half_swap(own.cell, own.cell);
-        cT[0] = c[0]; cT[1] = c[1];
-    }
-    unsigned rem0 = unsigned(validMask), rem1 = unsigned(validMask >> 32);
-    float4_t out = {0.f, 0.f, 0.f, 0.f};
-    for (;;) {
-        half8_t xb[2][2], gf[2], ga[2];
-        const unsigned cov0 = cell_pair(P, wT[0], cT[0], rem0, h, laneOff, gf[0], ga[0]);
-        const unsigned cov1 = cell_pair(P, wT[1], cT[1], rem1, h, laneOff, gf[1], ga[1]);
-        feature_fragments<2>(feat, xb);
-        const float4_t o = srn_layers_resident<ACT, NLC, 0, ALL4, 2>(P, R, xb, []() {}, [](int) {}, gf, ga);
-        const unsigned long long covered = (unsigned long long)cov0 | ((unsigned long long)cov1 << 32);
-        out[0] = select_by_mask_or(covered, o[0], out[0]);
-        if constexpr (ALL4) {
-            out[1] = select_by_mask_or(covered, o[1], out[1]); out[2] = select_by_mask_or(covered, o[2], out[2]); out[3] = select_by_mask_or(covered, o[3], out[3]);
-        }
-        rem0 &= ~cov0; rem1 &= ~cov1;
-        if ((rem0 | rem1) == 0) break;
-    }
-#pragma unroll
-    for (int c = 0; c < 16; ++c) fourier_advance_piece<2, HAS_DIR>(feat, dfeat, c);
-    return out;
+            for (int c = 0; c < 16; ++c) fourier_advance_piece<2, HAS_DIR>(feat, dfeat, c);
+        },
+        [](int) {}, nullptr, &C);
 }
 
 // output parametrization, renderer_volume_tensorcores.cuh:1054-1158. The reference rounds the

@@ -309,7 +309,7 @@ int fvsrn_camera_on_a_sphere(int orientation, const double center[3], double pit
  * restarts in each), period in steps of the exact re-derivation of rotated Fourier features (0: the kernel derives the features
  * from the fp16 position at every step, like the reference; FVSRN_OPT_FOURIER_RESYNC), kernel family (0 render_kernel / render_shaded_kernel, 1 register-resident, 2 spill-free
  * stripe variant, 3 render_adjoint_kernel: the adjoint gradient mode up to 64 channels, 4 register-resident with the latent grid through
- * the cell table, FVSRN_OPT_CELL_TABLE),
+ * the cell table, 5 render_cells_kernel: render_kernel with the latent grid through the cell table, FVSRN_OPT_CELL_TABLE),
  * waves per workgroup }.  No reference counterpart. */
 int fvsrn_scene_last_render_info(fvsrn_scene* scene, int out[4]);
 

@@ -158,6 +158,7 @@ def render_both(vn, scene_kw, W, H, y0=0, y1=None, acc=oracle.ACC_FLOAT, scene_o
     stats = torch.zeros(2, dtype=torch.int64, device="cuda")
     img = scene.render(net, W, H, y0, y1, stats=stats)
     torch.cuda.synchronize()
+    render_both.last_plan = scene.last_render_info()
     ref, count = oracle.OracleScene(**scene_kw).render(oracle.OracleNetwork(vn, acc), W, H, y0, H if y1 is None else y1)
     return img.cpu().numpy()[0], ref, stats.cpu().numpy(), count
 
@@ -297,6 +298,14 @@ def test_render_matches_oracle(case, early_out):
     assert img[3].max() > 0.05, "scene is empty, the comparison would be vacuous"
     img_h, ref_h, _, _ = render_both(vn, kw, 40, 24, acc=oracle.ACC_HALF)
     assert_images_close(img_h, ref_h, TOL_IMG_HALF)
+    if case.get("grid"):
+        # r04: the decoded latent grid reaches the unshaded renderers through the cell table (one MFMA K step on the trilinear weights of a
+        # sample, srn_device.hpp); the gather path -- what the shaded renderers and evaluate_points run -- is scene option cell_table = 0
+        assert render_both.last_plan["cell_table"]
+        img_g, ref_g, stats_g, _ = render_both(vn, kw, 40, 24, scene_options={"cell_table": 0})
+        assert not render_both.last_plan["cell_table"]
+        assert_images_close(img_g, ref_g, TOL_IMG)
+        assert np.abs(np.nan_to_num(img_g[:4]) - np.nan_to_num(img[:4])).max() < TOL_IMG
 
 
 @pytest.mark.parametrize("fourier_std", [None, 1.5])

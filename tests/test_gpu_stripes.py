@@ -242,7 +242,11 @@ DETERMINISM_CASES = [
     # (channels, layers, activation, grid encoding, scene options): the configurations of tools/dev/determinism.py that differed most often
     # in r03 (one launch in twenty ... every launch), a 96-wide network and a BYTE_GAUSSIAN grid (decoded in the kernel)
     (64, 3, "ReLU", 0, dict(overlap_kernel=1)), (64, 3, "SnakeAlt", 0, dict(overlap_kernel=1)), (64, 3, "ReLU", 0, dict(overlap_kernel=1, persistent=0)),
-    (32, 4, "ReLU", 0, dict()), (32, 4, "SnakeAlt", 0, dict(small_kernel=0)), (96, 3, "SnakeAlt", 0, dict()), (64, 3, "ReLU", 2, dict()), (48, 3, "Sine", 2, dict())]
+    # (cell_table = 0: the gather kernels -- grid_tap is where hipcc emitted the selection; the shaded renderers and evaluate_points run that code)
+    (32, 4, "ReLU", 0, dict(cell_table=0)), (32, 4, "SnakeAlt", 0, dict(small_kernel=0, cell_table=0)), (96, 3, "SnakeAlt", 0, dict(cell_table=0)),
+    (64, 3, "ReLU", 2, dict()), (48, 3, "Sine", 2, dict()),
+    # the cell-table kernels (the default of FLOAT / BYTE_LINEAR grids since r04): register-resident, LDS 32 / 64 / 96 wide
+    (32, 4, "ReLU", 0, dict()), (32, 4, "SnakeAlt", 0, dict(small_kernel=0)), (64, 3, "ReLU", 0, dict()), (96, 3, "SnakeAlt", 0, dict())]
 
 
 def _determinism_scene(C, layers, act, enc, opts):
