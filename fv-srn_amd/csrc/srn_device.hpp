@@ -409,7 +409,9 @@ __device__ __forceinline__ CellTap cell_tap(const NetParams& P, float px, float 
     const float fx = __builtin_amdgcn_fmed3f(fmaf(px, P.gridXf, -0.5f), 0.f, xm);
     const float fy = __builtin_amdgcn_fmed3f(fmaf(py, P.gridYf, -0.5f), 0.f, ym);
     const float fz = __builtin_amdgcn_fmed3f(fmaf(pz, P.gridZf, -0.5f), 0.f, zm);
-    const float x0 = fminf(floorf(fx), xm - 1.f), y0 = fminf(floorf(fy), ym - 1.f), z0 = fminf(floorf(fz), zm - 1.f);
+    // min(floor, N - 2) as a median with -1 (floor >= 0): v_med3_f32 takes its operands as they are, fminf would canonicalise the bound at every step
+    const float x0 = __builtin_amdgcn_fmed3f(floorf(fx), -1.f, xm - 1.f), y0 = __builtin_amdgcn_fmed3f(floorf(fy), -1.f, ym - 1.f),
+                z0 = __builtin_amdgcn_fmed3f(floorf(fz), -1.f, zm - 1.f);
     const float wx = fx - x0, wy = fy - y0, wz = fz - z0;
     CellTap t;
     // (exact in fp32: fewer than 2^24 cells; positions of rays that miss the box may be anything, also NaN: any valid cell will do)
@@ -453,15 +455,16 @@ __device__ __forceinline__ unsigned cell_pair(const NetParams& P, const unsigned
     return unsigned(mA) | unsigned(mB);
 }
 
-// What the first layer needs of a wave step's latent grid: per tile the samples' weights and cells, the first cell pair's fragments
-// (loaded ahead of the Fourier work) and the samples they do not cover
+// What the first layer needs of a wave step's latent grid.  The first cell pair is chosen among ALL 64 samples of the step (the rays of an
+// 8 x 8 pixel tile: one selection, one table fetch for both column tiles); the samples it does not cover -- a few percent of the steps have
+// any -- get further pairs tile by tile (cells_accumulate).
 template <int MT>
 struct CellPre {
-    unsigned w[2][4];
-    unsigned cell[2];
-    unsigned rem[2];
-    half8_t gf[2];
-    half8_t ga[2][MT];
+    unsigned w[2][4];        // the tiles' weights (both lane halves hold the tile's sample lane & 31)
+    unsigned cellOwn;        // the cell of this lane's own sample
+    unsigned long long rem;  // valid samples the first pair does not cover
+    half8_t gf[2];           // B fragments of the first pair
+    half8_t ga[MT];          // its A fragments
 };
 
 template <int MT>
@@ -473,29 +476,43 @@ __device__ __forceinline__ void cell_prepare(const NetParams& P, float px, float
         auto a = lane_half_swap(own.w[k], own.w[k]);
         C.w[0][k] = a[0]; C.w[1][k] = a[1];
     }
-    {
-        auto c = lane_half_swap(own.cell, own.cell);
-        C.cell[0] = c[0]; C.cell[1] = c[1];
-    }
+    C.cellOwn = own.cell;
+    const unsigned cA = __builtin_amdgcn_readlane(own.cell, validMask ? __builtin_ctzll(validMask) : 0);
+    const unsigned long long mA = __builtin_amdgcn_ballot_w64(own.cell == cA);
+    const unsigned long long rem1 = validMask & ~mA;
+    const unsigned cB = __builtin_amdgcn_readlane(own.cell, rem1 ? __builtin_ctzll(rem1) : 0);
+    const unsigned long long mB = rem1 ? __builtin_amdgcn_ballot_w64(own.cell == cB) : 0ull;
+    C.rem = rem1 & ~mB;
+    // tile t's samples are the lanes 32 t .. 32 t + 31 of the masks; lane half 0 carries cell A's K slots, lane half 1 cell B's
+    const unsigned long long sel[2] = {(mA & 0xffffffffull) | (mB << 32), (mA >> 32) | (mB & 0xffffffff00000000ull)};
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const unsigned valid = unsigned(validMask >> (32 * t));
-        C.rem[t] = valid & ~cell_pair<MT>(P, C.w[t], C.cell[t], valid, h, laneOff, C.gf[t], C.ga[t]);
+        uint4_t b;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b[k] = select_bits_by_mask(sel[t], C.w[t][k]);
+        C.gf[t] = __builtin_bit_cast(half8_t, b);
     }
+    const char* base = static_cast<const char*>(P.cellTable) + (__umul24(h ? cB : cA, P.cellStride) + laneOff);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) C.ga[m] = *reinterpret_cast<const half8_t*>(base + 512 * m);
 }
 
-// The latent K step(s) of tile t into the first layer's accumulators: the prepared pair, then -- wave-uniform, a few percent of the steps --
-// further pairs until every valid sample of the tile has met its cell
+// The latent K step(s) of tile t into the first layer's accumulators: the prepared pair, then -- wave-uniform, rare -- further pairs until
+// every valid sample of the tile has met its cell
 template <int MT>
 __device__ __forceinline__ void cells_accumulate(const NetParams& P, const CellPre<MT>& C, int t, int h, unsigned laneOff, floatx16* acc) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(C.ga[t][m], C.gf[t], acc[m], 0, 0, 0);
-    unsigned rem = C.rem[t];
-    while (rem) {
-        half8_t gf, ga[MT];
-        rem &= ~cell_pair<MT>(P, C.w[t], C.cell[t], rem, h, laneOff, gf, ga);
+    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(C.ga[m], C.gf[t], acc[m], 0, 0, 0);
+    unsigned rem = unsigned(C.rem >> (32 * t));
+    if (rem) {
+        auto c = lane_half_swap(C.cellOwn, C.cellOwn);
+        const unsigned cellT = t ? c[1] : c[0];
+        do {
+            half8_t gf, ga[MT];
+            rem &= ~cell_pair<MT>(P, C.w[t], cellT, rem, h, laneOff, gf, ga);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[m], gf, acc[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[m], gf, acc[m], 0, 0, 0);
+        } while (rem);
     }
 }
 
