@@ -460,8 +460,8 @@ __device__ __forceinline__ unsigned cell_pair(const NetParams& P, const unsigned
 // any -- get further pairs tile by tile (cells_accumulate).
 template <int MT>
 struct CellPre {
-    unsigned w[2][4];        // the tiles' weights (both lane halves hold the tile's sample lane & 31)
-    unsigned cellOwn;        // the cell of this lane's own sample
+    unsigned wOwn[4];        // the weights of this lane's own sample
+    unsigned cellOwn;        // ... and its cell
     unsigned long long rem;  // valid samples the first pair does not cover
     half8_t gf[2];           // B fragments of the first pair
     half8_t ga[MT];          // its A fragments
@@ -472,10 +472,7 @@ __device__ __forceinline__ void cell_prepare(const NetParams& P, float px, float
                                              CellPre<MT>& C) {
     const CellTap own = cell_tap(P, px, py, pz);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        auto a = lane_half_swap(own.w[k], own.w[k]);
-        C.w[0][k] = a[0]; C.w[1][k] = a[1];
-    }
+    for (int k = 0; k < 4; ++k) C.wOwn[k] = own.w[k];
     C.cellOwn = own.cell;
     const unsigned cA = __builtin_amdgcn_readlane(own.cell, validMask ? __builtin_ctzll(validMask) : 0);
     const unsigned long long mA = __builtin_amdgcn_ballot_w64(own.cell == cA);
@@ -483,15 +480,17 @@ __device__ __forceinline__ void cell_prepare(const NetParams& P, float px, float
     const unsigned cB = __builtin_amdgcn_readlane(own.cell, rem1 ? __builtin_ctzll(rem1) : 0);
     const unsigned long long mB = rem1 ? __builtin_amdgcn_ballot_w64(own.cell == cB) : 0ull;
     C.rem = rem1 & ~mB;
-    // tile t's samples are the lanes 32 t .. 32 t + 31 of the masks; lane half 0 carries cell A's K slots, lane half 1 cell B's
-    const unsigned long long sel[2] = {(mA & 0xffffffffull) | (mB << 32), (mA >> 32) | (mB & 0xffffffff00000000ull)};
+    // Own sample's weights masked for the K slots of cell A and of cell B, then ONE lane-half swap per register: it leaves {A slots of sample c,
+    // B slots of sample c} in the two halves of the first register -- tile 0's B fragment (lane half 0 carries cell A's K slots, lane half 1
+    // cell B's) -- and tile 1's in the second
+    uint4_t b0, b1;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        uint4_t b;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) b[k] = select_bits_by_mask(sel[t], C.w[t][k]);
-        C.gf[t] = __builtin_bit_cast(half8_t, b);
+    for (int k = 0; k < 4; ++k) {
+        auto r = lane_half_swap(select_bits_by_mask(mA, own.w[k]), select_bits_by_mask(mB, own.w[k]));
+        b0[k] = r[0]; b1[k] = r[1];
     }
+    C.gf[0] = __builtin_bit_cast(half8_t, b0);
+    C.gf[1] = __builtin_bit_cast(half8_t, b1);
     const char* base = static_cast<const char*>(P.cellTable) + (__umul24(h ? cB : cA, P.cellStride) + laneOff);
 #pragma unroll
     for (int m = 0; m < MT; ++m) C.ga[m] = *reinterpret_cast<const half8_t*>(base + 512 * m);
@@ -505,11 +504,17 @@ __device__ __forceinline__ void cells_accumulate(const NetParams& P, const CellP
     for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(C.ga[m], C.gf[t], acc[m], 0, 0, 0);
     unsigned rem = unsigned(C.rem >> (32 * t));
     if (rem) {
-        auto c = lane_half_swap(C.cellOwn, C.cellOwn);
+        auto c = lane_half_swap(C.cellOwn, C.cellOwn);  // the tile's cells and weights in both lane halves
         const unsigned cellT = t ? c[1] : c[0];
+        unsigned w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            auto a = lane_half_swap(C.wOwn[k], C.wOwn[k]);
+            w[k] = t ? a[1] : a[0];
+        }
         do {
             half8_t gf, ga[MT];
-            rem &= ~cell_pair<MT>(P, C.w[t], cellT, rem, h, laneOff, gf, ga);
+            rem &= ~cell_pair<MT>(P, w, cellT, rem, h, laneOff, gf, ga);
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[m], gf, acc[m], 0, 0, 0);
         } while (rem);

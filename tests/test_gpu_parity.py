@@ -416,6 +416,19 @@ def test_register_resident_kernel_matches_lds_kernel(layers, activation, output_
     assert float(ev_small.std()) > 1e-3
 
 
+@pytest.mark.parametrize("C,layers,res", [(32, 4, 1), (32, 4, 2), (64, 3, 2), (32, 4, 3), (48, 3, 5)])
+def test_cell_table_smallest_grids(C, layers, res):
+    """The cell table has (N - 1)^3 cells: a 2^3 grid is ONE cell (every sample in it, clamp addressing on all sides), a 1^3 grid has none and
+    keeps the gather path; odd resolutions put texel centres where pixel tiles straddle several cells."""
+    vn = util.random_network(C=C, layers=layers, activation="SnakeAlt", output_mode="density", seed=83, box_min=(-0.5, -0.5, -0.5),
+                             grid=(16, res), grid_scale=0.5)
+    kw = make_scene_kwargs(stepsize=1 / 64, early_out=False, tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=20.0, tf_scale_emission=1.0)
+    img, ref, stats, count = render_both(vn, kw, 40, 24)
+    assert render_both.last_plan["cell_table"] == (res >= 2)
+    assert_images_close(img, ref, TOL_IMG)
+    assert stats[0] == count and img[3].max() > 0.05
+
+
 PHONG = dict(enable_phong=True, ambient=0.2, specular=0.4, magnitude_center=0.6, magnitude_radius=0.5, specular_exponent=8,
              light_type=0, light=(1.0, -1.5, 0.8))
 

@@ -11,6 +11,8 @@ python bench.py --activation SnakeAlt --no-cpu-baseline > gpurun_out/bench_${V}_
 python bench.py --force-collective --no-twin --no-cpu-baseline > gpurun_out/bench_${V}_force_collective_nccl.json 2>/dev/null
 python bench.py --force-collective --no-twin --no-cpu-baseline --config c64l6_grid16_time16_1024x512 > gpurun_out/bench_${V}_force_collective_nccl_c64l6_time16.json 2>/dev/null
 for c in c32l4_fourier_512x256 c32l4_grid16_1024x512 c64l6_grid16_1024x512 c64l6_grid16_time16_1024x512; do python bench.py --config $c --no-cpu-baseline > gpurun_out/bench_${V}_$c.json 2>/dev/null; done
+# the latent-grid lines on the gather path (FVSRN_OPT_CELL_TABLE = 0: what r01 - r03 ran), for the A/B of the cell table
+for c in c32l4_grid16_1024x512 c64l6_grid16_1024x512; do FVSRN_CELL_TABLE=0 python bench.py --config $c --no-cpu-baseline --no-twin > gpurun_out/bench_${V}_${c}_gather_path.json 2>/dev/null; done
 for c in c32l4_fourier_1024x512 c32l4_grid16_1024x512 c64l6_grid16_1024x512; do tools/pmc_profile.sh ${c}_${V} --config $c > /dev/null 2>&1; done
 tools/pmc_profile.sh c32l4_fourier_snakealt_1024x512_${V} --config c32l4_fourier_1024x512 --activation SnakeAlt > /dev/null 2>&1
 python - <<'PY'
