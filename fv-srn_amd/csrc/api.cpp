@@ -367,7 +367,10 @@ struct fvsrn_network {
     // (grid_blend_kernel).  Two of them for networks with more than one key frame: the blend of frame i + 1 writes the grid that
     // frame i does NOT read, so a caller may keep two frames in flight on two streams (tiles.StripeRenderer, BASELINE.json
     // configs[4]); `order` makes a blend wait for every kernel that still reads the grid it overwrites, on whatever stream.
-    struct WorkingGrid { DeviceBuffer a, b, cells; StreamOrder order; };  // cells: the grid's cell table (NetParams::cellTable), rebuilt with every blend
+    // cells: the grid's cell table (NetParams::cellTable) for the image the unshaded renderer runs, rebuilt with every blend; cellsPlain: the one of the plain
+    // image for the shaded renderer, where the network has a re-scaled image as well (otherwise the two are one)
+    struct WorkingGrid { DeviceBuffer a, b, cells, cellsPlain; StreamOrder order; };
+    const void* cellTablePlain = nullptr;  // of the current working grid
     WorkingGrid workGrid[2];
     int numWorkGrids = 1, curWorkGrid = 0;
     size_t cellTableBytes = 0;  // 0: no cell table (no grid, BYTE_GAUSSIAN, a resolution below 2, above the size cap, FVSRN_OPT_CELL_TABLE = 0)
@@ -494,10 +497,11 @@ struct fvsrn_network {
                     cellTableBytes = size_t(cells) * 512 * size_t(MT);
             }
             for (int i = 0; i < 2; ++i) {
-                if (i >= numWorkGrids) { workGrid[i].a.release(); workGrid[i].b.release(); workGrid[i].cells.release(); continue; }
+                if (i >= numWorkGrids) { workGrid[i].a.release(); workGrid[i].b.release(); workGrid[i].cells.release(); workGrid[i].cellsPlain.release(); continue; }
                 workGrid[i].a.ensure(K.records * size_t(K.Gt + K.Ge) * 2 * 2);
                 if (K.enc == FVSRN_GRID_BYTE_GAUSSIAN) workGrid[i].b.ensure(K.records * size_t(K.Gt + K.Ge) * 2 * 2);
                 if (cellTableBytes) workGrid[i].cells.ensure(cellTableBytes); else workGrid[i].cells.release();
+                if (cellTableBytes && scaledImage) workGrid[i].cellsPlain.ensure(cellTableBytes); else workGrid[i].cellsPlain.release();
             }
             packed.params.grid = workGrid[0].a.ptr;
             packed.params.gridB = K.enc == FVSRN_GRID_BYTE_GAUSSIAN ? workGrid[0].b.ptr : nullptr;
@@ -509,6 +513,7 @@ struct fvsrn_network {
         }
         packed.params.cellTable = nullptr;
         packed.params.cellStride = packed.params.cellCount = 0;
+        cellTablePlain = nullptr;
         timeDirty = true;
         imagesOrder.endWrite(stream);  // launches on other streams wait for the uploads above (beginUse)
         // the staging vectors are pageable: the copies above complete before hipMemcpyAsync returns
@@ -519,6 +524,7 @@ struct fvsrn_network {
         HIP_CHECK(hipFuncSetAttribute(kinfo.renderShadedFn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         if (const void* fn = render_stripe_fn(keyScaled)) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         if (const void* fn = render_cells_fn(keyScaled)) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
+        if (const void* fn = render_shaded_cells_fn(key)) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         if (const void* fn = render_adjoint_fn(key)) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         deviceValid = true;
     }
@@ -555,6 +561,13 @@ struct fvsrn_network {
                 ct.out = W.cells.ptr;
                 ct.X = np.gridX; ct.Y = np.gridY; ct.Z = np.gridZ; ct.G = np.gridC; ct.MT = MT;
                 HIP_CHECK(launch_grid_cell_table(ct, stream));
+                cellTablePlain = W.cells.ptr;
+                if (scaledImage) {  // the shaded renderer runs the plain image: its own table
+                    ct.latentFrags = static_cast<const char*>(dLds.ptr) + np.offLayer0 + size_t(MT) * KS * kFragBytes;
+                    ct.out = W.cellsPlain.ptr;
+                    HIP_CHECK(launch_grid_cell_table(ct, stream));
+                    cellTablePlain = W.cellsPlain.ptr;
+                }
                 packed.params.cellTable = W.cells.ptr;
                 packed.params.cellStride = unsigned(512 * MT);
                 packed.params.cellCount = unsigned(cellTableBytes / (512 * size_t(MT)));
@@ -595,7 +608,7 @@ struct fvsrn_network {
         dLds.release();
         dLdsScaled.release();
         dLdsCurvature.release();
-        for (WorkingGrid& w : workGrid) { w.a.release(); w.b.release(); w.cells.release(); w.order.release(); }
+        for (WorkingGrid& w : workGrid) { w.a.release(); w.b.release(); w.cells.release(); w.cellsPlain.release(); w.order.release(); }
         imagesOrder.release();
         imageReaders.clear();
         keyStore.release();
@@ -1498,6 +1511,11 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 cellsFn = render_cells_fn(net->keyScaled);
             // the adjoint gradient mode up to 64 channels: its own kernel (render_adjoint_kernel, kernels.hpp)
             const void* adjointFn = (a.shaded && d.gradient_mode == FVSRN_GRADIENT_ADJOINT_METHOD) ? render_adjoint_fn(net->key) : nullptr;
+            // the shaded renderer with the grid through the cell table of the plain image: every mode but the adjoint one (whose gradient pass keeps its records)
+            if (a.shaded && d.gradient_mode != FVSRN_GRADIENT_ADJOINT_METHOD && net->key.grid == 1 && net->cellTablePlain && O[FVSRN_OPT_CELL_TABLE] != 0) {
+                cellsFn = render_shaded_cells_fn(net->key);
+                if (cellsFn) a.P.cellTable = net->cellTablePlain;
+            }
             const void* altFn = smallFn ? smallFn : (stripeFn ? stripeFn : (cellsFn ? cellsFn : adjointFn));
             const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded, altFn, O[FVSRN_OPT_MAX_BLOCKS_PER_CU]);
             const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));  // workgroups the chip holds at once
@@ -1578,7 +1596,8 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             scene->lastInfo[3] = wpb;
             hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid, a, grid, unsigned(64 * wpb), lds, s)
                                    : (stripeFn ? launch_render_stripe(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s)
-                                      : cellsFn ? launch_render_cells(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s)
+                                      : cellsFn ? (a.shaded ? launch_render_shaded_cells(net->key, a, grid, unsigned(64 * wpb), lds, s)
+                                                             : launch_render_cells(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s))
                                       : (adjointFn ? launch_render_adjoint(net->key, a, grid, unsigned(64 * wpb), lds, s)
                                                    : launch_render(a.shaded ? net->key : net->keyScaled, a, grid, unsigned(64 * wpb), lds, s)));
             if (e == hipSuccess && K > 1) e = launch_composite(S.partial, d_out8, K, plane, S, s);

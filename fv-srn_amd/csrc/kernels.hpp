@@ -547,6 +547,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     float* dfeatLds = nullptr;
     if constexpr (kRotateLds) dfeatLds = const_cast<float*>(tfLds) + S.tfLdsFloats + int(threadIdx.x >> 6) * (64 * 32);
     floatx16 feat[2][mtiles(CD)], dfeat[2][mtiles(CD)];
+    constexpr int FG = (GRID == 1 && CELLS) ? 3 : GRID;  // srn_forward's view of the latent grid: 3 = through the cell table (srn_device.hpp)
     // the adjoint gradient mode lives in this instantiation (render_shaded_kernel except at 48 / 64 channels, render_adjoint_kernel there)
     constexpr bool kAdjointHere = SHADED == 2 || (SHADED == 1 && !adjoint_in_its_own_kernel(CD));
     [[maybe_unused]] bool normalsAtPreviousStep = false;  // (wave-uniform) per ray tile
@@ -629,9 +630,9 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             // same numbers up to the rounding of the two evaluations, <= 5e-4 of the value, tests/test_gpu_parity.py.)
             fusedGradient = S.gradientMode == FVSRN_GRADIENT_ADJOINT_METHOD && !rgboNet && normalsAtPreviousStep;
             if (fusedGradient) o = srn_forward_gradient<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, S.gridDiffStep, fgx, fgy, fgz);
-            else o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE, SCHED>(P, lds, px, py, pz, dx, dy, dz);
+            else o = srn_forward<CD, ACT, FG, HAS_DIR, FMODE, SCHED>(P, lds, px, py, pz, dx, dy, dz, validMask);
         } else {
-            o = srn_forward<CD, ACT, (GRID == 1 && CELLS ? 3 : GRID), HAS_DIR, FMODE, SCHED>(P, lds, px, py, pz, dx, dy, dz, validMask);
+            o = srn_forward<CD, ACT, FG, HAS_DIR, FMODE, SCHED>(P, lds, px, py, pz, dx, dy, dz, validMask);
         }
 
         FVSRN_MARK(P, 5);  // last layer (+ the other half of the rotation)
@@ -751,8 +752,8 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
                     for (int k = 0; k < 6; ++k) {
                         const float sgn = (k & 1) ? -1.f : 1.f;
                         const int axis = k >> 1;
-                        const float4_t ok = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE>(
-                            P, lds, px + (axis == 0 ? sgn * hx : 0.f), py + (axis == 1 ? sgn * hy : 0.f), pz + (axis == 2 ? sgn * hz : 0.f), dx, dy, dz);
+                        const float4_t ok = srn_forward<CD, ACT, FG, HAS_DIR, FMODE>(
+                            P, lds, px + (axis == 0 ? sgn * hx : 0.f), py + (axis == 1 ? sgn * hy : 0.f), pz + (axis == 2 ? sgn * hz : 0.f), dx, dy, dz, validMask);
                         v[k] = sigmoidDensity ? sigmoid_f(ok[0]) : ok[0];
                     }
                     const float inv2h = 1.0f / (2.0f * h);
@@ -947,6 +948,14 @@ template <int CD, int ACT, int GRID, bool HAS_DIR>
 __global__ __launch_bounds__(kBlockThreads, ((CD >= 7 || CD == 5) ? 1 : 2)) void render_shaded_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                unsigned long long* __restrict__ stats) {
     render_entry<CD, ACT, GRID, HAS_DIR, 1>(P, S, out, stats);
+}
+
+// render_shaded_kernel<CD, ACT, 1, HAS_DIR> with the decoded latent grid through the cell table in every plain evaluation -- the sample itself and the
+// six of the finite differences, whose positions share cells like the samples of a step do (r04).  The adjoint mode's gradient pass keeps its records.
+template <int CD, int ACT, bool HAS_DIR>
+__global__ __launch_bounds__(kBlockThreads, ((CD >= 7 || CD == 5) ? 1 : 2)) void render_shaded_cells_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+                                                                     unsigned long long* __restrict__ stats) {
+    render_entry<CD, ACT, 1, HAS_DIR, 1, 0, true>(P, S, out, stats);
 }
 
 // GRADIENT_MODE_ADJOINT_METHOD up to 64 channels: the shaded renderer without the finite-difference code (and render_shaded_kernel without

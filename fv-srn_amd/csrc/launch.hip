@@ -366,6 +366,14 @@ hipError_t launch_render_cells(const VariantKey& k, const RenderArgs& a, unsigne
     FVSRN_DISPATCH_CD(launch_render_cells_cd, k, a, gridDim, blockDim, ldsBytes, s)
     return hipErrorInvalidDeviceFunction;
 }
+const void* render_shaded_cells_fn(const VariantKey& k) {
+    FVSRN_DISPATCH_CD(render_shaded_cells_fn_cd, k)
+    return nullptr;
+}
+hipError_t launch_render_shaded_cells(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s) {
+    FVSRN_DISPATCH_CD(launch_render_shaded_cells_cd, k, a, gridDim, blockDim, ldsBytes, s)
+    return hipErrorInvalidDeviceFunction;
+}
 const void* render_stripe_fn(const VariantKey& k) {
     if (k.CD == 3) return render_stripe_fn_cd<3>(k);
     if (k.CD == 4) return render_stripe_fn_cd<4>(k);

@@ -50,6 +50,8 @@ template <int CD> hipError_t launch_render_shaded_cd(const VariantKey& k, const 
 // render_stripe_kernel (kernels_cd{3,4}_stripe.hip: 48 / 64 wide with a latent grid); other widths: nullptr / hipErrorInvalidDeviceFunction
 template <int CD> const void* render_stripe_fn_cd(const VariantKey& k);
 template <int CD> const void* render_cells_fn_cd(const VariantKey& k);
+template <int CD> const void* render_shaded_cells_fn_cd(const VariantKey& k);
+template <int CD> hipError_t launch_render_shaded_cells_cd(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 template <int CD> hipError_t launch_render_cells_cd(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 template <int CD> hipError_t launch_render_stripe_cd(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 // render_adjoint_kernel (kernels_cd{2,3,4}_adjoint.hip): the adjoint gradient mode up to 64 channels; other widths: nullptr / hipErrorInvalidDeviceFunction
@@ -125,6 +127,9 @@ hipError_t launch_eval(const VariantKey& k, const EvalArgs& a, unsigned gridDim,
 const void* render_stripe_fn(const VariantKey& k);
 // render_cells_kernel: render_kernel with the decoded latent grid through the cell table (NetParams::cellTable); nullptr if not compiled in
 const void* render_cells_fn(const VariantKey& k);
+// render_shaded_cells_kernel: render_shaded_kernel with the grid through the cell table of the PLAIN weight image (finite differences, BRDF, pre-integration)
+const void* render_shaded_cells_fn(const VariantKey& k);
+hipError_t launch_render_shaded_cells(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 hipError_t launch_render_cells(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 const void* render_adjoint_fn(const VariantKey& k);
 hipError_t launch_render_adjoint(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);

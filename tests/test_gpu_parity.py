@@ -460,6 +460,13 @@ def test_shaded_render_matches_oracle(case):
     # central differences amplify the fp16-level differences of two evaluations by 1 / (2h) = 8
     assert_images_close(img, ref, 4 * TOL_IMG if case["fd"] else TOL_IMG)
     assert abs(int(stats[0]) - count) <= max(2, count // 1000)
+    if case["net"].get("grid") and case["net"].get("encoding", 0) != 2:
+        # r04: the shaded renderer reads a decoded latent grid through the cell table of the plain weight image (render_shaded_cells_kernel: the
+        # sample and the six evaluations of its finite differences); scene option cell_table = 0 is the gather form
+        assert render_both.last_plan["cell_table"]
+        img_g, ref_g, _, _ = render_both(vn, kw, 40, 24, scene_options={"cell_table": 0})
+        assert not render_both.last_plan["cell_table"]
+        assert_images_close(img_g, ref_g, 4 * TOL_IMG if case["fd"] else TOL_IMG)
 
 
 @pytest.mark.parametrize("case", [

@@ -57,7 +57,9 @@ CASES = [("64x3 ReLU + grid, stripes (render_stripe_kernel)", dict(C=64, layers=
          ("32x4 ReLU + grid, frame, resident kernel, gather path", dict(C=32, layers=4, activation="ReLU", **G), "frame", dict(cell_table=0)),
          ("32x4 SnakeAlt + grid, frame, LDS kernel, gather path", dict(C=32, layers=4, activation="SnakeAlt", **G), "frame", dict(small_kernel=0, cell_table=0)),
          ("96x3 SnakeAlt + grid, gather path", dict(C=96, layers=3, activation="SnakeAlt", **G), "frame", dict(cell_table=0)),
-         ("128x3 ReLU + grid, gather path", dict(C=128, layers=3, activation="ReLU", **G), "frame", dict(cell_table=0))]
+         ("128x3 ReLU + grid, gather path", dict(C=128, layers=3, activation="ReLU", **G), "frame", dict(cell_table=0)),
+         ("64x3 ReLU + grid, shaded, finite differences, gather path", dict(C=64, layers=3, activation="ReLU", **G), "fd", dict(cell_table=0)),
+         ("32x4 SnakeAlt + grid, shaded, finite differences", dict(C=32, layers=4, activation="SnakeAlt", **G), "fd", {})]
 GAUSS = np.array([[0.9, 0.2, 0.1, 30.0, 0.25, 0.08], [0.1, 0.7, 0.9, 20.0, 0.6, 0.1], [0.9, 0.9, 0.2, 40.0, 0.85, 0.05]], np.float32)
 PIECE = np.array([[0.0, 0, 0, 0, 0], [0.2, 1, 0, 0, 10], [0.5, 0, 1, 0, 30], [0.8, 0, 0, 1, 5], [1.0, 1, 1, 1, 40]], np.float32)
 PHONG = dict(enable_phong=True, ambient=0.2, specular=0.4, magnitude_center=0.6, magnitude_radius=0.5, specular_exponent=8, light_type=0, light=tuple(float(v) for v in eye))
