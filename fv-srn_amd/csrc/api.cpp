@@ -1499,6 +1499,12 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 }
                 lds += size_t(wpb) * kRotationBytes;
             }
+            // FVSRN_OPT_FOURIER_RESYNC = 1 (every step derives its features like the reference): the variants of the rotating resident kernels that
+            // have no rotation to advance
+            bool smallExact = false;
+            if (smallFn && smallGrid != 1 && (O[FVSRN_OPT_FOURIER_RESYNC] ? O[FVSRN_OPT_FOURIER_RESYNC] : kFourierResync) == 1) {
+                if (const void* fn = render_small_exact_fn(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid)) { smallFn = fn; smallExact = true; }
+            }
             // the fragment-major variant of the wide latent-grid renderers (render_stripe_kernel, kernels.hpp: no register spills, 1 % slower):
             // on request only (FVSRN_OPT_OVERLAP_KERNEL = 1) since the launch-to-launch differences it was built around turned out to be a
             // hazard in the tap arithmetic (srn_device.hpp, grid_tap) and not concurrent scratch use
@@ -1594,7 +1600,8 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             scene->lastInfo[1] = rotates ? S.resyncMask + 1 : 0;
             scene->lastInfo[2] = smallFn ? (smallGrid == 2 ? 4 : 1) : (stripeFn ? 2 : (cellsFn ? 5 : (adjointFn ? 3 : 0)));
             scene->lastInfo[3] = wpb;
-            hipError_t e = smallFn ? launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid, a, grid, unsigned(64 * wpb), lds, s)
+            hipError_t e = smallFn ? (smallExact ? launch_render_small_exact(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid, a, grid, unsigned(64 * wpb), lds, s)
+                                                 : launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid, a, grid, unsigned(64 * wpb), lds, s))
                                    : (stripeFn ? launch_render_stripe(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s)
                                       : cellsFn ? (a.shaded ? launch_render_shaded_cells(net->key, a, grid, unsigned(64 * wpb), lds, s)
                                                              : launch_render_cells(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s))

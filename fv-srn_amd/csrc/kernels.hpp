@@ -422,7 +422,7 @@ __device__ __forceinline__ float select_by_mask(unsigned long long m, float x) {
 // 128 channels); 2 = render_adjoint_kernel (up to 64 channels, adjoint mode only, see there)
 constexpr bool adjoint_in_its_own_kernel(int CD) { return CD >= 2 && CD <= 4; }  // (render_adjoint_kernel is built for 32 / 48 / 64 channels)
 // CELLS (render_small_kernel<.., SGRID = 2>): the latent grid enters through the cell table (srn_forward_resident_cells)
-template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, int SHADED, int TAIL = TAIL_GENERIC, int NLC = 0, int SCHED = 0, bool CELLS = false>
+template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, int SHADED, int TAIL = TAIL_GENERIC, int NLC = 0, int SCHED = 0, bool CELLS = false, bool ADVANCE = true>
 __device__ __forceinline__ void render_body(const NetParams& P, const SceneParams& S, const char* lds, const float* tfLds,
                                             float* __restrict__ out, unsigned long long* __restrict__ stats) {
     const int lane = lane_id();
@@ -607,9 +607,13 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
                 if (i == 0)
                     fourier_features<CD, HAS_DIR, FM_COS, true>(P, lds, dnx * S.stepsize, dny * S.stepsize, dnz * S.stepsize, 0.f, 0.f, 0.f, dfeat, nullptr, hilo);
             }
-            if constexpr (NLC > 0 && CELLS) o = srn_forward_rotating_resident_cells<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeat, px, py, pz, validMask);
-            else if constexpr (NLC > 0) o = srn_forward_rotating_resident<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeat);
-            else o = srn_forward_rotating<CD, ACT, GRID, HAS_DIR>(P, lds, feat, dfeat, px, py, pz);
+            // ADVANCE = false: every step re-derives its features (FVSRN_OPT_FOURIER_RESYNC = 1, the reference's arithmetic): nothing to advance.  A
+            // compile-time variant (render_small_kernel<.., ADVANCE>, chosen by the host): as a wave-uniform branch inside the step it cost the
+            // default path 1.7 % (r04: 162.1 -> 159.4 Gsamples/s), leaving it out costs the exact mode 10 - 17 % (121.5 -> 134.6 .. 145.8)
+            constexpr bool advance = ADVANCE;
+            if constexpr (NLC > 0 && CELLS) o = srn_forward_rotating_resident_cells<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeat, px, py, pz, validMask, advance);
+            else if constexpr (NLC > 0) o = srn_forward_rotating_resident<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeat, advance);
+            else o = srn_forward_rotating<CD, ACT, GRID, HAS_DIR>(P, lds, feat, dfeat, px, py, pz, advance);
         } else if constexpr (kRotateLds) {
             if ((i & S.resyncMask) == 0) {  // wave-uniform: exact features; the per-step rotation once per ray (and depth segment) -> LDS
                 fourier_features<CD, HAS_DIR, FM_COS>(P, lds, px, py, pz, dx, dy, dz, feat);  // (phase fragment: from the LDS image)
@@ -934,12 +938,14 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void r
 // the registers of the rotation state hold the grid fetch)
 // SGRID = 2 (r04): a latent grid of any channel count through the cell table -- one MFMA K step on the trilinear weights, no gathers,
 // rotated features (srn_forward_rotating_resident_cells, srn_device.hpp); the default where a table exists (FVSRN_OPT_CELL_TABLE)
-template <int ACT, bool HAS_DIR, int NLC, int TAILK, int SGRID = 0>
+// ADVANCE = false: the variant for FVSRN_OPT_FOURIER_RESYNC = 1 (every step re-derives its features like the reference: no rotation to advance; its own
+// kernel -- as a second copy of the loop inside one kernel it cost the default path 6 % through the shared register allocation)
+template <int ACT, bool HAS_DIR, int NLC, int TAILK, int SGRID = 0, bool ADVANCE = true>
 __global__ __launch_bounds__(kBlockThreads, 2) void render_small_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                       unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* tfLds = render_prologue(P, S, lds);
-    render_body<2, ACT, (SGRID ? 1 : 0), HAS_DIR, FM_COS, 0, TAILK, NLC, 0, SGRID == 2>(P, S, lds, tfLds, out, stats);
+    render_body<2, ACT, (SGRID ? 1 : 0), HAS_DIR, FM_COS, 0, TAILK, NLC, 0, SGRID == 2, ADVANCE>(P, S, lds, tfLds, out, stats);
 }
 
 // finite-difference normals / shading BRDF (SceneParams::gradientMode, brdf*): 7 network evaluations per sample

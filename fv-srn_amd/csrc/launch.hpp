@@ -116,6 +116,9 @@ hipError_t launch_evaluate_tf(const SceneParams& S, const float* density, const 
 // (grid 2: the latent grid through the cell table, kernels_small_cells.hip)
 const void* render_small_fn(int act, bool dir, int numLayers, int tail, int grid = 0);
 const void* render_small_cells_fn(int act, bool dir, int numLayers, int tail);
+// the variants without the feature rotation (FVSRN_OPT_FOURIER_RESYNC = 1; grid 0 or 2), kernels_small_exact.hip
+const void* render_small_exact_fn(int act, bool dir, int numLayers, int tail, int grid);
+hipError_t launch_render_small_exact(int act, bool dir, int numLayers, int tail, int grid, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 hipError_t launch_render_small_cells(int act, bool dir, int numLayers, int tail, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 hipError_t launch_render_small(int act, bool dir, int numLayers, int tail, int grid, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 

@@ -1209,7 +1209,7 @@ __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* 
 // the same from the input features `feat` of the current sample, which are advanced to the next sample of the rays
 template <int CD, int ACT, int GRID, bool HAS_DIR>
 __device__ __forceinline__ float4_t srn_forward_rotating(const NetParams& P, const char* lds, floatx16 (&feat)[2][mtiles(CD)],
-                                                         const floatx16 (&dfeat)[2][mtiles(CD)], float px, float py, float pz) {
+                                                         const floatx16 (&dfeat)[2][mtiles(CD)], float px, float py, float pz, bool advance = true) {
     // rotation pieces behind MFMAs without conversion work of their own (NFILL) vs in pre(), where they also cover the LDS
     // latency of the first layer's reads: all of them in pre() is fastest (r01: NFILL = NP/2 -> 0: 132 -> 137 Gsamples/s)
     constexpr int NP = 16 * mtiles(CD);
@@ -1245,8 +1245,10 @@ __device__ __forceinline__ float4_t srn_forward_rotating(const NetParams& P, con
             P, lds, xb, px, py, pz,
             [&]() {
                 feature_fragments<CD>(feat, xb);
+                if (advance) {  // (wave-uniform; off when every step re-derives its features: FVSRN_OPT_FOURIER_RESYNC = 1)
 #pragma unroll
-                for (int c = 0; c < NP - NFILL; ++c) fourier_advance_piece<CD, HAS_DIR>(feat, dfeat, c);
+                    for (int c = 0; c < NP - NFILL; ++c) fourier_advance_piece<CD, HAS_DIR>(feat, dfeat, c);
+                }
             },
             [&](int j) { fourier_advance_piece<CD, HAS_DIR>(feat, dfeat, NP - NFILL + j); });
     }
@@ -1504,7 +1506,7 @@ __device__ __forceinline__ float4_t srn_forward_rotating_resident_grid(const Net
 // srn_forward_rotating on a ResidentNet
 template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
 __device__ __forceinline__ float4_t srn_forward_rotating_resident(const NetParams& P, const ResidentNet<NLC>& R, floatx16 (&feat)[2][1],
-                                                               const floatx16 (&dfeat)[2][1]) {
+                                                               const floatx16 (&dfeat)[2][1], bool advance = true) {
 #ifndef FVSRN_SMALL_NFILL
 #define FVSRN_SMALL_NFILL 0
 #endif
@@ -1516,8 +1518,10 @@ __device__ __forceinline__ float4_t srn_forward_rotating_resident(const NetParam
         P, R, xb,
         [&]() {
             feature_fragments<2>(feat, xb);
+            if (advance) {  // (wave-uniform; off when every step re-derives its features: FVSRN_OPT_FOURIER_RESYNC = 1, the reference's arithmetic)
 #pragma unroll
-            for (int c = 0; c < NP - NFILL; ++c) fourier_advance_piece<2, HAS_DIR>(feat, dfeat, c);
+                for (int c = 0; c < NP - NFILL; ++c) fourier_advance_piece<2, HAS_DIR>(feat, dfeat, c);
+            }
         },
         [&](int j) { fourier_advance_piece<2, HAS_DIR>(feat, dfeat, NP - NFILL + j); });
 }
@@ -1526,7 +1530,7 @@ __device__ __forceinline__ float4_t srn_forward_rotating_resident(const NetParam
 template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
 __device__ __forceinline__ float4_t srn_forward_rotating_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, floatx16 (&feat)[2][1],
                                                                        const floatx16 (&dfeat)[2][1], float px, float py, float pz,
-                                                                       unsigned long long validMask) {
+                                                                       unsigned long long validMask, bool advance = true) {
     const int lane = lane_id();
     CellPre<1> C;
     cell_prepare<1>(P, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
@@ -1535,8 +1539,10 @@ __device__ __forceinline__ float4_t srn_forward_rotating_resident_cells(const Ne
         P, R, xb,
         [&]() {
             feature_fragments<2>(feat, xb);
+            if (advance) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) fourier_advance_piece<2, HAS_DIR>(feat, dfeat, c);
+                for (int c = 0; c < 16; ++c) fourier_advance_piece<2, HAS_DIR>(feat, dfeat, c);
+            }
         },
         [](int) {}, nullptr, &C);
 }
