@@ -282,11 +282,13 @@ class StripeRenderer:
         return assemble(self.gathered[b], self.H, self.stripe)
 
 
-def frames_match(full: torch.Tensor, gathered: torch.Tensor, tol_image: float = 3e-3, tol_depth: float = 3e-2) -> bool:
+def frames_match(full: torch.Tensor, gathered: torch.Tensor, tol_image: float = 2e-4, tol_depth: float = 3e-2) -> bool:
     """A frame assembled from stripes against the single-GPU render of the same scene.  Same samples, but a rank's stripes
     are a small launch and may be rendered in depth segments (re-associated sums, other restart points of the feature
-    rotation): compare within the image tolerance of the parity tests; depth (NaN where alpha == 0) only on pixels that
-    are not within rounding of empty."""
+    rotation).  Since r04 a restart derives the features from the fp32 position (srn_device.hpp, fourier_features hilo), so
+    where the rotation restarts no longer shows beyond fp32 rounding: measured <= 4.3e-5 between 1 / 2 / 4 / 8 segments and
+    stripes on the bench networks (tools/dev/segment_diff.py; r03: up to the 3e-3 of the parity tests) -- the tolerance is
+    2e-4.  Depth (NaN where alpha == 0) only on pixels that are not within rounding of empty."""
     solid = (full[0, 3] > 1e-4) | (gathered[0, 3] > 1e-4)
     if float((full[0, :7] - gathered[0, :7]).abs().max()) >= tol_image:
         return False
