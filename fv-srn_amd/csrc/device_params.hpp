@@ -76,7 +76,7 @@ struct NetParams {
     int gridEncoding, gridTimeChannels;
     int gridX, gridY, gridZ, gridC;
     float gridXf, gridYf, gridZf;  // the same as floats (grid_tap works in fp32: fewer than 2^24 records, pack.cpp)
-    // Cell table of the working grid (r04; grid_cell_table_kernel in launch.hip, srn_forward_resident_cells in srn_device.hpp): for every
+    // Cell table of the working grid (r04; grid_cell_table_kernel in launch.hip; cell_prepare / cells_accumulate in srn_device.hpp): for every
     // cell (x0, y0, z0) of the grid, 0 <= x0 <= X - 2, the product of the first layer's latent columns with the cell's eight corner vectors,
     // fp16 [cell][m][row 0..31][corner (dz, dy, dx)] -- 512 bytes per cell and M tile, which IS the A fragment of an MFMA K step whose B
     // operand holds the eight trilinear weights of a sample.  null: none (BYTE_GAUSSIAN grids, tables above the size cap).

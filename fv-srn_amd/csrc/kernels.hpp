@@ -421,7 +421,8 @@ __device__ __forceinline__ float select_by_mask(unsigned long long m, float x) {
 // SHADED: 0 = plain renderer; 1 = render_shaded_kernel (finite differences / predicted gradients / BRDF, and the adjoint mode at 96 and
 // 128 channels); 2 = render_adjoint_kernel (up to 64 channels, adjoint mode only, see there)
 constexpr bool adjoint_in_its_own_kernel(int CD) { return CD >= 2 && CD <= 4; }  // (render_adjoint_kernel is built for 32 / 48 / 64 channels)
-// CELLS (render_small_kernel<.., SGRID = 2>): the latent grid enters through the cell table (srn_forward_resident_cells)
+// CELLS (render_small_kernel<.., SGRID = 2>, render_cells_kernel, render_shaded_cells_kernel): the decoded latent grid enters through the cell
+// table (srn_device.hpp: cell_prepare / cells_accumulate)
 template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, int SHADED, int TAIL = TAIL_GENERIC, int NLC = 0, int SCHED = 0, bool CELLS = false, bool ADVANCE = true>
 __device__ __forceinline__ void render_body(const NetParams& P, const SceneParams& S, const char* lds, const float* tfLds,
                                             float* __restrict__ out, unsigned long long* __restrict__ stats) {

@@ -46,13 +46,6 @@ __device__ __forceinline__ uint2_t lane_half_swap(unsigned a, unsigned b) {
     return uint2_t{r[0], r[1]};
 }
 
-// x in the lanes whose bit is set in the wave mask m (an SGPR pair), y elsewhere
-__device__ __forceinline__ float select_by_mask_or(unsigned long long m, float x, float y) {
-    float r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(y), "v"(x), "s"(m));
-    return r;
-}
-
 // own value v (one per lane = per sample) -> value of sample (lane&31) of tile 0 / tile 1
 __device__ __forceinline__ void tile_bcast(float v, float& t0, float& t1) {
     const unsigned u = __float_as_uint(v);
@@ -392,10 +385,10 @@ __device__ __forceinline__ half8_t grid_features(const NetParams& P, const GridT
 //     W_latent . (sum_c w_c G_c) = sum_c w_c (W_latent . G_c) = T_cell . w,        T_cell = [W_latent G_c]_c   (C x 8, fp16, NetParams::cellTable)
 // i.e. ONE MFMA K step whose A operand is the cell's table entry and whose B operand holds the sample's eight weights -- K = 16 takes two
 // cells (lane half 0: slots of cell A, lane half 1: cell B; a sample's weights are zero in the slots of the cell it is not in).  That
-// replaces, per wave step, 16 x 16-byte gathers per lane, 64 v_dot2_f32_f16, the record address arithmetic and 8 converts by 2 coalesced
-// 512-byte loads, 8 v_cndmask and a handful of scalar instructions, with the same number of MFMAs as the latent K step it stands in for
-// (and any number of latent channels costs the same).  Tiles whose samples touch more than two cells (corners of the cell lattice) run the
-// network again for the samples not covered yet -- wave-uniform, a few percent of the steps.
+// replaces, per wave step, 16 x 16-byte gathers per lane, 64 v_dot2_f32_f16, the record address arithmetic and 8 converts by ONE coalesced
+// fetch of the table entry (512 bytes per M tile), 8 v_cndmask + 4 lane-half swaps and a handful of scalar instructions, with the same number of MFMAs as the latent K step it stands in for
+// (and any number of latent channels costs the same).  Samples in a third cell (corners of the cell lattice; a few percent of the steps have any)
+// get further cell pairs, accumulated into the same first-layer accumulators (cells_accumulate: wave-uniform).
 // Same texture semantics as grid_tap: texel coordinate p N - 0.5 clamped to [0, N - 1], cell x0 = min(floor, N - 2), weight wx = coordinate - x0
 // (1 exactly on the last texel); fp16 weights like there; the table entries carry one fp16 rounding of W.G where the gather path rounds
 // the interpolated feature.

@@ -429,6 +429,23 @@ def test_cell_table_smallest_grids(C, layers, res):
     assert stats[0] == count and img[3].max() > 0.05
 
 
+@pytest.mark.parametrize("C,shape", [(32, (5, 9, 12)), (64, (12, 3, 7))])
+def test_cell_table_non_cubic_grid(C, shape):
+    """A latent grid with three different resolutions (Z, Y, X): cell index and table layout follow each axis' own size."""
+    from fvsrn_amd import synthetic, volnet_io
+    a = synthetic.random_arrays(C=C, layers=3, output_mode="density", grid=(16, 4), seed=29, grid_scale=0.5)
+    grids = [np.random.RandomState(30).randn(16, *shape).astype(np.float32) * 0.5]
+    vn = volnet_io.build_volnet(fourier_B=a["B"], weights=a["weights"], biases=a["biases"], activation="SnakeAlt", activation_param=1.0,
+                                output_mode="density", box_min=(-0.5, -0.5, -0.5), box_size=(1, 1, 1), time_grids=grids, grid_encoding=volnet_io.ENC_FLOAT)
+    kw = make_scene_kwargs(stepsize=1 / 64, early_out=False, tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=20.0, tf_scale_emission=1.0)
+    img, ref, stats, count = render_both(vn, kw, 40, 24)
+    assert render_both.last_plan["cell_table"]
+    assert_images_close(img, ref, TOL_IMG)
+    img_g, ref_g, _, _ = render_both(vn, kw, 40, 24, scene_options={"cell_table": 0})
+    assert_images_close(img_g, ref_g, TOL_IMG)
+    assert stats[0] == count and img[3].max() > 0.05
+
+
 PHONG = dict(enable_phong=True, ambient=0.2, specular=0.4, magnitude_center=0.6, magnitude_radius=0.5, specular_exponent=8,
              light_type=0, light=(1.0, -1.5, 0.8))
 
