@@ -1048,7 +1048,7 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
             const bool colourNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
             const bool folded = P.bias0Folded && (!net->scaledImage || net->packed.scaledBias0Exact);
             const bool cells = k.grid == 1 && net->opts[FVSRN_OPT_CELL_TABLE] != 0 && P.gridX >= 2 && P.gridY >= 2 && P.gridZ >= 2 &&
-                               double(P.gridX - 1) * (P.gridY - 1) * (P.gridZ - 1) * 512.0 <= 1073741824.0;  // (ensureDevice: cellTableBytes)
+                               double(P.gridX - 1) * (P.gridY - 1) * (P.gridZ - 1) * 512.0 * ((net->packed.cfg.hiddenChannels + 31) / 32) <= 1073741824.0;  // (ensureDevice: cellTableBytes)
             const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && folded ? (cells ? 2 : (P.gridK == 1 ? 1 : 3)) : 3);
             if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 2 && !P.noFourier && !P.fourierNeedsFractPlain && !P.fourierClampPos && (scalarNet || colourNet) &&
                 (render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1, smallGrid) ||
