@@ -1468,6 +1468,20 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             int wpb = wavesPerBlockFor(lds, O);
             // Small networks in registers (render_small_kernel, kernels.hpp): 32-wide Fourier-only scalar network with at most
             // three C->C layers, phases inside the v_cos domain, a transfer function, no shading.  FVSRN_SMALL_KERNEL=0: off.
+            // The cell table pays while the samples of a wave step (the rays of an 8 x 8 pixel tile at one depth) share one or two grid cells:
+            // footprint of the tile in cells = 8 pixels x pixel size at the box centre x cells per unit length.  Measured r04 (tools/dev/
+            // cell_footprint_sweep.py, 16^3 .. 64^3 grids, 512^2 .. 2048^2 images): 0.72 - 0.82 of the gather path's time up to 0.5 cells, equal at
+            // ~0.9 (32 wide) / ~0.7 (64 wide), 1.2 x at 1.3 -- further cell pairs cost a dependent fetch each (profiles/r04/cell_footprint_sweep_r04.txt).
+            // -1 = this rule, 1 = always, 0 = never.
+            bool useCells = O[FVSRN_OPT_CELL_TABLE] == 1;
+            if (O[FVSRN_OPT_CELL_TABLE] == -1 && a.P.cellTable) {
+                const BoxCenter bc = P_boxCenter(a.P);
+                const double ex = S.eye[0] - bc.c[0], ey = S.eye[1] - bc.c[1], ez = S.eye[2] - bc.c[2];
+                const double dist = std::max(1e-3, std::sqrt(ex * ex + ey * ey + ez * ez));
+                const double pixel = std::max(2.0 * S.tanFovX / std::max(1, width), 2.0 * S.tanFovY / std::max(1, height));
+                const double cellsPerUnit = std::max({(a.P.gridX - 1) / double(a.P.boxSize[0]), (a.P.gridY - 1) / double(a.P.boxSize[1]), (a.P.gridZ - 1) / double(a.P.boxSize[2])});
+                useCells = 8.0 * pixel * dist * cellsPerUnit <= (net->key.CD <= 2 ? 0.8 : 0.7);
+            }
             const void* smallFn = nullptr;
             int smallGrid = 0;
             const int smallTail = rgbo ? 3 : (d.tf_kind == FVSRN_TF_PIECEWISE || d.tf_kind == FVSRN_TF_GAUSSIAN ? 2 : (d.blend_mode != FVSRN_BLEND_BEER_LAMBERT ? 1 : (d.tf_kind == FVSRN_TF_IDENTITY && d.tf_scale_absorption >= 0.f ? FVSRN_IDENTITY_TAIL : (d.tf_kind == FVSRN_TF_TEXTURE && scene->tfOpacityNonNegative ? 5 : 1))));  // kernels.hpp TAIL_*
@@ -1476,7 +1490,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
                 // latent grid: 2 = through the cell table (any number of latent channels), 1 = one decoded 16-channel chunk by gathers;
                 // both need the first layer's bias in its weights (bias0Folded: no time input), the resident kernels drop that bias block
-                smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.bias0Folded ? (a.P.cellTable && O[FVSRN_OPT_CELL_TABLE] != 0 ? 2 : (a.P.gridK == 1 ? 1 : 3)) : 3);
+                smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.bias0Folded ? (a.P.cellTable && useCells ? 2 : (a.P.gridK == 1 ? 1 : 3)) : 3);
                 if (O[FVSRN_OPT_SMALL_KERNEL] != 0 && net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && !a.shaded && k.CD == 2 && smallGrid <= 2 && !a.P.noFourier && !a.P.fourierNeedsFract &&
                     !a.P.fourierClampPos &&  // (the resident kernels compile the position clamp out)
                     a.P.numLayers >= 1 && a.P.numLayers <= 3 && (rgbo || (scalarNet && d.tf_kind != FVSRN_TF_NONE)))
@@ -1513,12 +1527,12 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 stripeFn = render_stripe_fn(net->keyScaled);
             // every other unshaded render of a network whose decoded latent grid has a cell table: render_kernel with the grid through that table
             const void* cellsFn = nullptr;
-            if (!smallFn && !stripeFn && !a.shaded && net->keyScaled.grid == 1 && a.P.cellTable && O[FVSRN_OPT_CELL_TABLE] != 0)
+            if (!smallFn && !stripeFn && !a.shaded && net->keyScaled.grid == 1 && a.P.cellTable && useCells)
                 cellsFn = render_cells_fn(net->keyScaled);
             // the adjoint gradient mode up to 64 channels: its own kernel (render_adjoint_kernel, kernels.hpp)
             const void* adjointFn = (a.shaded && d.gradient_mode == FVSRN_GRADIENT_ADJOINT_METHOD) ? render_adjoint_fn(net->key) : nullptr;
             // the shaded renderer with the grid through the cell table of the plain image: every mode but the adjoint one (whose gradient pass keeps its records)
-            if (a.shaded && d.gradient_mode != FVSRN_GRADIENT_ADJOINT_METHOD && net->key.grid == 1 && net->cellTablePlain && O[FVSRN_OPT_CELL_TABLE] != 0) {
+            if (a.shaded && d.gradient_mode != FVSRN_GRADIENT_ADJOINT_METHOD && net->key.grid == 1 && net->cellTablePlain && useCells) {
                 cellsFn = render_shaded_cells_fn(net->key);
                 if (cellsFn) a.P.cellTable = net->cellTablePlain;
             }

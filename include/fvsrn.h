@@ -198,7 +198,9 @@ typedef enum {
                                         (0 for whole frames, 1/16 of the slots for the stripes of a multi-GPU frame)  [FVSRN_PERSISTENT_RESERVE] */
     FVSRN_OPT_CELL_TABLE = 13,       /* network + scene: latent grids of FLOAT / BYTE_LINEAR encoding enter the unshaded renderer through the cell
                                         table (one MFMA K step on the trilinear weights instead of gathers + dot products; DESIGN.md section 4
-                                        item 16); 0 = off (the gather path), 1 / -1 = on where a kernel variant exists   [FVSRN_CELL_TABLE]    */
+                                        item 16); 0 = off (the gather path; network: no table is built), 1 = on where a kernel variant exists,
+                                        -1 (scene default) = on while an 8 x 8 pixel tile spans less than ~0.6 - 0.8 grid cells at the box
+                                        centre, where it pays (measured: tools/dev/cell_footprint_sweep.py)            [FVSRN_CELL_TABLE]    */
     FVSRN_OPT_COUNT_ = 14
 } fvsrn_option;
 int fvsrn_network_set_option(fvsrn_network* net, int option, int value);

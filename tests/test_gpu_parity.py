@@ -299,13 +299,17 @@ def test_render_matches_oracle(case, early_out):
     img_h, ref_h, _, _ = render_both(vn, kw, 40, 24, acc=oracle.ACC_HALF)
     assert_images_close(img_h, ref_h, TOL_IMG_HALF)
     if case.get("grid"):
-        # r04: the decoded latent grid reaches the unshaded renderers through the cell table (one MFMA K step on the trilinear weights of a
-        # sample, srn_device.hpp); the gather path -- what the shaded renderers and evaluate_points run -- is scene option cell_table = 0
+        # r04: the decoded latent grid reaches the renderers through the cell table (one MFMA K step on the trilinear weights of a sample,
+        # srn_device.hpp) while a pixel tile spans less than a grid cell -- not in a 40 x 24 image: scene option cell_table = 1 forces it, 0 is
+        # the gather path (what evaluate_points and the adjoint mode run)
+        img_c, ref_c, stats_c, count_c = render_both(vn, kw, 40, 24, scene_options={"cell_table": 1})
         assert render_both.last_plan["cell_table"]
+        assert_images_close(img_c, ref_c, TOL_IMG)
+        assert stats_c[0] == count_c or early_out
         img_g, ref_g, stats_g, _ = render_both(vn, kw, 40, 24, scene_options={"cell_table": 0})
         assert not render_both.last_plan["cell_table"]
         assert_images_close(img_g, ref_g, TOL_IMG)
-        assert np.abs(np.nan_to_num(img_g[:4]) - np.nan_to_num(img[:4])).max() < TOL_IMG
+        assert np.abs(np.nan_to_num(img_g[:4]) - np.nan_to_num(img_c[:4])).max() < TOL_IMG
 
 
 @pytest.mark.parametrize("fourier_std", [None, 1.5])
@@ -385,7 +389,7 @@ def test_register_resident_kernel_matches_lds_kernel(layers, activation, output_
     net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
     W = H = 96
     import torch
-    small_scene = capi.Scene(**kw)
+    small_scene = capi.Scene(**kw).set_option("cell_table", 1)  # (a 96 x 96 image: the automatic rule would take the gathers)
     small = small_scene.render(net, W, H)[0].clone()
     plan = small_scene.last_render_info()
     assert plan["resident_kernel"] and plan["cell_table"] == (grid is not None)
@@ -399,7 +403,7 @@ def test_register_resident_kernel_matches_lds_kernel(layers, activation, output_
         # The latent grid enters the resident kernel through the cell table (srn_forward_rotating_resident_cells: one MFMA K step on the
         # trilinear weights, features advanced by rotation), the LDS kernel gathers and derives the features at every step: the same
         # arithmetic up to the fp16 rounding of the table entries once the rotation is off (fourier_resync = 1) ...
-        exact = capi.Scene(**kw).set_option("fourier_resync", 1).render(net, W, H)[0].clone()
+        exact = capi.Scene(**kw).set_option("cell_table", 1).set_option("fourier_resync", 1).render(net, W, H)[0].clone()
         diff = float((nn(exact) - nn(plain)).abs().max())
         assert diff < 5e-4, diff
         # ... and the gather variant of the resident kernel (cell_table = 0; one 16-channel chunk) runs the LDS kernel's arithmetic
@@ -423,7 +427,7 @@ def test_cell_table_smallest_grids(C, layers, res):
     vn = util.random_network(C=C, layers=layers, activation="SnakeAlt", output_mode="density", seed=83, box_min=(-0.5, -0.5, -0.5),
                              grid=(16, res), grid_scale=0.5)
     kw = make_scene_kwargs(stepsize=1 / 64, early_out=False, tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=20.0, tf_scale_emission=1.0)
-    img, ref, stats, count = render_both(vn, kw, 40, 24)
+    img, ref, stats, count = render_both(vn, kw, 40, 24, scene_options={"cell_table": 1})
     assert render_both.last_plan["cell_table"] == (res >= 2)
     assert_images_close(img, ref, TOL_IMG)
     assert stats[0] == count and img[3].max() > 0.05
@@ -438,7 +442,7 @@ def test_cell_table_non_cubic_grid(C, shape):
     vn = volnet_io.build_volnet(fourier_B=a["B"], weights=a["weights"], biases=a["biases"], activation="SnakeAlt", activation_param=1.0,
                                 output_mode="density", box_min=(-0.5, -0.5, -0.5), box_size=(1, 1, 1), time_grids=grids, grid_encoding=volnet_io.ENC_FLOAT)
     kw = make_scene_kwargs(stepsize=1 / 64, early_out=False, tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=20.0, tf_scale_emission=1.0)
-    img, ref, stats, count = render_both(vn, kw, 40, 24)
+    img, ref, stats, count = render_both(vn, kw, 40, 24, scene_options={"cell_table": 1})
     assert render_both.last_plan["cell_table"]
     assert_images_close(img, ref, TOL_IMG)
     img_g, ref_g, _, _ = render_both(vn, kw, 40, 24, scene_options={"cell_table": 0})
@@ -480,7 +484,9 @@ def test_shaded_render_matches_oracle(case):
     if case["net"].get("grid") and case["net"].get("encoding", 0) != 2:
         # r04: the shaded renderer reads a decoded latent grid through the cell table of the plain weight image (render_shaded_cells_kernel: the
         # sample and the six evaluations of its finite differences); scene option cell_table = 0 is the gather form
+        img_c, ref_c, _, _ = render_both(vn, kw, 40, 24, scene_options={"cell_table": 1})
         assert render_both.last_plan["cell_table"]
+        assert_images_close(img_c, ref_c, 4 * TOL_IMG if case["fd"] else TOL_IMG)
         img_g, ref_g, _, _ = render_both(vn, kw, 40, 24, scene_options={"cell_table": 0})
         assert not render_both.last_plan["cell_table"]
         assert_images_close(img_g, ref_g, 4 * TOL_IMG if case["fd"] else TOL_IMG)

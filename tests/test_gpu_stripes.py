@@ -246,7 +246,8 @@ DETERMINISM_CASES = [
     (32, 4, "ReLU", 0, dict(cell_table=0)), (32, 4, "SnakeAlt", 0, dict(small_kernel=0, cell_table=0)), (96, 3, "SnakeAlt", 0, dict(cell_table=0)),
     (64, 3, "ReLU", 2, dict()), (48, 3, "Sine", 2, dict()),
     # the cell-table kernels (the default of FLOAT / BYTE_LINEAR grids since r04): register-resident, LDS 32 / 64 / 96 wide
-    (32, 4, "ReLU", 0, dict()), (32, 4, "SnakeAlt", 0, dict(small_kernel=0)), (64, 3, "ReLU", 0, dict()), (96, 3, "SnakeAlt", 0, dict())]
+    (32, 4, "ReLU", 0, dict(cell_table=1)), (32, 4, "SnakeAlt", 0, dict(small_kernel=0, cell_table=1)), (64, 3, "ReLU", 0, dict(cell_table=1)),
+    (96, 3, "SnakeAlt", 0, dict(cell_table=1))]
 
 
 def _determinism_scene(C, layers, act, enc, opts):

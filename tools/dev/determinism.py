@@ -50,7 +50,7 @@ CASES = [("64x3 ReLU + grid, stripes (render_stripe_kernel)", dict(C=64, layers=
          ("32x4 SnakeAlt rgbo Fourier-only", dict(C=32, layers=4, activation="SnakeAlt", output_mode="rgbo"), "frame", {}),
          ("128x3 ReLU + grid", dict(C=128, layers=3, activation="ReLU", **G), "frame", {}),
          ("96x3 SnakeAlt + grid", dict(C=96, layers=3, activation="SnakeAlt", **G), "frame", {}),
-         # r04: the cases above take the cell table where one exists; the gather kernels of the same frames (grid_tap: where hipcc emitted the
+         # r04: the cases above take the cell table (a 1024 x 512 image of an 8^3 grid: the automatic rule picks it); the gather kernels of the same frames (grid_tap: where hipcc emitted the
          # packed-fp32 selection of profiles/r04/nondeterminism_r04.md)
          ("64x3 ReLU + grid, frame, gather path", dict(C=64, layers=3, activation="ReLU", **G), "frame", dict(cell_table=0)),
          ("64x3 SnakeAlt + grid, stripes, gather path", dict(C=64, layers=3, activation="SnakeAlt", **G), "stripes", dict(overlap_kernel=0, cell_table=0)),
