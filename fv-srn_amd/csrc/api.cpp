@@ -1477,7 +1477,8 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             if (O[FVSRN_OPT_CELL_TABLE] == -1 && a.P.cellTable) {
                 const BoxCenter bc = P_boxCenter(a.P);
                 const double ex = S.eye[0] - bc.c[0], ey = S.eye[1] - bc.c[1], ez = S.eye[2] - bc.c[2];
-                const double dist = std::max(1e-3, std::sqrt(ex * ex + ey * ey + ez * ez));
+                const float* bsz = a.P.boxSize;  // (a camera close to or inside the box: its samples are up to half a box diagonal away)
+                const double dist = std::max(0.5 * std::sqrt(double(bsz[0]) * bsz[0] + double(bsz[1]) * bsz[1] + double(bsz[2]) * bsz[2]), std::sqrt(ex * ex + ey * ey + ez * ez));
                 const double pixel = std::max(2.0 * S.tanFovX / std::max(1, width), 2.0 * S.tanFovY / std::max(1, height));
                 const double cellsPerUnit = std::max({(a.P.gridX - 1) / double(a.P.boxSize[0]), (a.P.gridY - 1) / double(a.P.boxSize[1]), (a.P.gridZ - 1) / double(a.P.boxSize[2])});
                 useCells = 8.0 * pixel * dist * cellsPerUnit <= (net->key.CD <= 2 ? 0.8 : 0.7);
