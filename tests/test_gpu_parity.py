@@ -433,6 +433,23 @@ def test_cell_table_smallest_grids(C, layers, res):
     assert stats[0] == count and img[3].max() > 0.05
 
 
+def test_cell_table_is_chosen_by_the_footprint_of_a_pixel_tile():
+    """Scene option cell_table = -1 (default): fvsrn_render takes the table while an 8 x 8 pixel tile spans less than ~0.8 grid cells at the box
+    centre (32 channels; DESIGN.md section 4 item 16, profiles/r04/cell_footprint_sweep_r04.txt) -- the same scene in a large image does, in a
+    small one it gathers; a fine grid in the large image gathers too.  Either way the same picture up to rounding."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    kw = make_scene_kwargs(stepsize=1 / 64, early_out=False, tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=20.0, tf_scale_emission=1.0)
+    for res, size, expect in ((8, (512, 256), True), (8, (64, 32), False), (64, (512, 256), False)):
+        vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density", seed=84, box_min=(-0.5, -0.5, -0.5), grid=(16, res), grid_scale=0.3)
+        net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+        auto = capi.Scene(**kw)
+        img = torch.nan_to_num(auto.render(net, *size)[0], nan=0.0).clone()
+        assert auto.last_render_info()["cell_table"] is expect, (res, size)
+        other = torch.nan_to_num(capi.Scene(**kw).set_option("cell_table", 0 if expect else 1).render(net, *size)[0], nan=0.0)
+        assert float((img[:4] - other[:4]).abs().max()) < 1e-3 and float(img[3].max()) > 0.05
+
+
 @pytest.mark.parametrize("C,shape", [(32, (5, 9, 12)), (64, (12, 3, 7))])
 def test_cell_table_non_cubic_grid(C, shape):
     """A latent grid with three different resolutions (Z, Y, X): cell index and table layout follow each axis' own size."""
