@@ -179,7 +179,8 @@ typedef enum {
                                         frame pipeline (tiles.StripeRenderer) opts in on its result              [FVSRN_PERSISTENT]    */
     FVSRN_OPT_DEPTH_SEGMENTS = 2,    /* scene: cut rays into k step ranges composited afterwards, 0 auto       [FVSRN_SEGMENTS]      */
     FVSRN_OPT_FOURIER_RESYNC = 3,    /* scene: exact Fourier features every k steps (power of two), 0 = 64; 1 = the reference's
-                                        per-step arithmetic (fp16 position at every sample), no feature rotation [FVSRN_FOURIER_RESYNC] */
+                                        per-step arithmetic (fp16 position at every sample), no feature rotation; k > 1: derived from the
+                                        fp32 position (two fp16 operands) and rotated in between               [FVSRN_FOURIER_RESYNC] */
     FVSRN_OPT_UNIT_QUOTA = 4,        /* scene: work units per bounded wave of a stripe launch, -1 auto          [FVSRN_UNIT_QUOTA]    */
     FVSRN_OPT_TILE_ORDER = 5,        /* scene: 1 = centre-first tile order, 0 = raster, -1 auto                 [FVSRN_TILE_ORDER]    */
     FVSRN_OPT_WAVES_PER_BLOCK = 6,   /* network (evaluate) + scene (render): 1 / 2 / 4, 0 auto                  [FVSRN_WAVES_PER_BLOCK] */
