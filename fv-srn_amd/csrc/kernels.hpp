@@ -938,7 +938,7 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void r
 // SGRID = 1: the same with ONE 16-channel latent grid chunk of decoded values (direct Fourier features instead of the rotation:
 // the registers of the rotation state hold the grid fetch)
 // SGRID = 2 (r04): a latent grid of any channel count through the cell table -- one MFMA K step on the trilinear weights, no gathers,
-// rotated features (srn_forward_rotating_resident_cells, srn_device.hpp); the default where a table exists (FVSRN_OPT_CELL_TABLE)
+// rotated features (srn_forward_rotating_resident_cells, srn_device.hpp); taken while a pixel tile spans less than a grid cell (FVSRN_OPT_CELL_TABLE, api.cpp)
 // ADVANCE = false: the variant for FVSRN_OPT_FOURIER_RESYNC = 1 (every step re-derives its features like the reference: no rotation to advance; its own
 // kernel -- as a second copy of the loop inside one kernel it cost the default path 6 % through the shared register allocation)
 template <int ACT, bool HAS_DIR, int NLC, int TAILK, int SGRID = 0, bool ADVANCE = true>
