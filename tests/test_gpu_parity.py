@@ -1065,12 +1065,18 @@ def test_render_time_dependent_byte_grids(enc):
     kw = make_scene_kwargs(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)
     net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
     scene = capi.Scene(**kw)
+    # (BYTE_LINEAR: also through the cell table, which is rebuilt with every blend of the working grid)
+    cells = capi.Scene(**kw).set_option("cell_table", 1) if enc == 1 else None
     for t in (0.3, 1.6, 0.3, 2.0):
         net.set_time_and_ensemble(t, 0)
         img = scene.render(net, 40, 24)
         torch.cuda.synchronize()
         ref, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(vn, oracle.ACC_FLOAT, time=t), 40, 24)
         assert_images_close(img.cpu().numpy()[0], ref, TOL_IMG)
+        if cells is not None:
+            img_c = cells.render(net, 40, 24)
+            assert cells.last_render_info()["cell_table"]
+            assert_images_close(img_c.cpu().numpy()[0], ref, TOL_IMG)
 
 
 @pytest.mark.parametrize("name", util.golden_names("g1_dir"))
