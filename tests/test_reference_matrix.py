@@ -1,0 +1,187 @@
+"""The cross product of the reference's own SRN parity test (unittests/testSRN.cpp:261-323, createNetworks):
+    9 output modes x {ReLU, Sine, Snake, SnakeAlt} x {2, 4 hidden layers} x {32, 48 channels} x {Fourier features, none}
+    x {no direction, direction as an input, direction inside the Fourier matrix} x {no grid, 16 channels 8^3, 16 channels 12^3, 32 channels 8^3}
+    = 2160 valid networks (a latent grid needs Fourier features, :297), each evaluated at 256 random positions and directions in [0,1)^3
+    (:327-345) with `torch.nn.Linear`-style random weights, a standard-normal Fourier matrix and a standard-normal grid (NetworkPytorch::random,
+    :29-92), the network handed over like NetworkPytorch::toTensorCores does (:221-250: box [0,1]^3, Fourier matrix not pre-multiplied).
+
+Three witnesses per network:
+  * `torch_reference` -- NetworkPytorch::evaluate (:94-207) restated with torch on the CPU in fp32 on the stored (fp16) parameters:
+    `matmul` + cos / sin, `torch.nn.functional.grid_sample(align_corners=False, padding_mode="border")`, `linear`, the activations and the
+    output parametrizations of that function.  Third-party arithmetic (torch), not this repository's restatement.
+  * the oracle's FLOAT model (same statement as the kernels: fp16 activations, fp32 accumulation): 2e-3 (torch: 4e-3, it rounds at other points)
+  * the oracle's HALF model (the reference's CUDA arithmetic): the bar of the reference's test, 1e-2 (:409-411)
+
+Two places where the reference's test and its kernel disagree, and what is checked here: density:direct is clamped to [0,1] by the test's torch
+model (:186-188) but not by the kernel ("No more clamping, done in the TF", renderer_volume_tensorcores.cuh:1086) -- the kernel's form; the
+gradient / curvature modes have no case in the torch model (raw last-layer outputs, :183-205) while `evaluate` returns the density -- its first
+output through the mode's parametrization (sigmoid except for the :direct / :cubic modes, :1076-1158).
+
+CPU part (no GPU): the oracle against `torch_reference` on every 6th network -- pins the oracle's Fourier stage, trilinear fetch and layers to torch.
+GPU part: fvsrn_evaluate_points against all three on all 2160.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+import util
+from oracle import oracle
+
+OUTPUT_MODES = ["density", "density:direct", "rgbo", "rgbo:direct", "densitygrad", "densitygrad:direct", "densitygrad:cubic",
+                "densitycurvature", "densitycurvature:direct"]
+ACTIVATIONS = ["ReLU", "Sine", "Snake", "SnakeAlt"]
+LAYERS_X_CHANNELS = [(2, 32), (2, 48), (4, 32), (4, 48)]
+DIRECTION = [(False, False), (True, False), (True, True)]  # (hasDirection, directionInFourier)
+LATENT = [(0, 0), (16, 8), (16, 12), (32, 8)]
+N_POINTS = 256
+TOL_SAME_MODEL, TOL_REF_BAR = 2e-3, 1e-2
+# torch evaluates the same stored parameters in fp32 but rounds elsewhere (phases in one fp32 product, no fp16 steps inside the trilinear fetch): measured
+# worst over the matrix 1.9e-3 (oracle) / 2.0e-3 (GPU), against 1e-2 of the reference's own comparison with torch
+TOL_TORCH = 4e-3
+
+
+def cases():
+    """createNetworks() order (:286-292)"""
+    i = 0
+    for mode, act, (hidden, C), fourier, (has_dir, dir_f), (G, R) in itertools.product(OUTPUT_MODES, ACTIVATIONS, LAYERS_X_CHANNELS, (False, True), DIRECTION, LATENT):
+        if not fourier and G > 0:
+            continue
+        yield dict(index=i, mode=mode, act=act, hidden=hidden, C=C, fourier=fourier, has_dir=has_dir, dir_f=dir_f, G=G, R=R)
+        i += 1
+
+
+def name(c):
+    F = (c["C"] - (8 if c["has_dir"] else 4)) // 2 if c["fourier"] else 0
+    return "f%d-%s-%s-%d*%d-%s-G%dC%d" % (F, c["mode"], c["act"], c["C"], c["hidden"], ("dirF" if c["dir_f"] else "dirD") if c["has_dir"] else "plain", c["R"], c["G"])
+
+
+def build(c):
+    """NetworkPytorch::random + toTensorCores: fp32 arrays and the VolnetData made of them"""
+    from fvsrn_amd import volnet_io
+    rng = np.random.RandomState(50000 + c["index"])
+    C, cin = c["C"], 6 if c["has_dir"] else 3
+    F = (C - (8 if c["has_dir"] else 4)) // 2 if c["fourier"] else 0
+    B = rng.randn(F, 6 if c["dir_f"] else 3).astype(np.float32) if c["fourier"] else np.zeros((0, 3), np.float32)
+    last = cin + 2 * F + c["G"]
+    grid = rng.randn(c["G"], c["R"], c["R"], c["R"]).astype(np.float32) if c["G"] else None
+    cout = {"density": 1, "density:direct": 1, "rgbo": 4, "rgbo:direct": 4, "densitygrad": 4, "densitygrad:direct": 4, "densitygrad:cubic": 4,
+            "densitycurvature": 6, "densitycurvature:direct": 6}[c["mode"]]
+    weights, biases = [], []
+    for out in [C] * c["hidden"] + [cout]:
+        k = 1.0 / np.sqrt(last)  # torch.nn.Linear: U(-1/sqrt(in), 1/sqrt(in)) for weight and bias
+        weights.append(rng.uniform(-k, k, (out, last)).astype(np.float32))
+        biases.append(rng.uniform(-k, k, out).astype(np.float32))
+        last = out
+    vn = volnet_io.build_volnet(fourier_B=B, weights=weights, biases=biases, activation=c["act"], activation_param=1.0, output_mode=c["mode"],
+                                box_min=(0.0, 0.0, 0.0), box_size=(1.0, 1.0, 1.0), premultiplied=False,
+                                time_grids=[grid] if grid is not None else None, grid_encoding=volnet_io.ENC_FLOAT, has_direction=c["has_dir"])
+    return dict(B=B, weights=weights, biases=biases, grid=grid, vn=vn)
+
+
+def points(c):
+    rng = np.random.RandomState(90000 + c["index"])
+    return rng.rand(N_POINTS, 3).astype(np.float32), rng.rand(N_POINTS, 3).astype(np.float32)
+
+
+def torch_reference(c, net, pos, dirs):
+    """NetworkPytorch::evaluate (testSRN.cpp:94-207) in fp32 on the parameters as stored (fp16 values; the Fourier matrix as half(2 pi B),
+    volume_interpolation_network.cpp:129-156), inputs rounded to fp16 like `position.to(kHalf)` (:101-102).  Returns what `evaluate` of the
+    renderer returns: the density (1 channel) or the colour (4)."""
+    import torch
+    h = lambda a: torch.from_numpy(np.asarray(a, np.float32)).half().float()  # noqa: E731
+    p, d = h(pos), h(dirs)
+    x_base = torch.cat([p, d], 1) if c["has_dir"] else p
+    if c["fourier"]:
+        x_in = torch.cat([p, d], 1) if c["dir_f"] else p
+        Bs = h((2 * np.pi * net["B"].astype(np.float64)).astype(np.float32))
+        f2 = x_in @ Bs.t()
+        y = torch.cat([x_base, torch.cos(f2), torch.sin(f2)], 1).half().float()  # (the first layer's inputs are fp16 values)
+    else:
+        y = x_base
+    if net["grid"] is not None:
+        g = h(net["grid"])[None]  # (1, G, Z, Y, X)
+        gp = (p * 2 - 1)[None, None, None]  # (1, 1, 1, N, 3): x -> W, y -> H, z -> D
+        lat = torch.nn.functional.grid_sample(g, gp, mode="bilinear", padding_mode="border", align_corners=False)[0, :, 0, 0].t()
+        y = torch.cat([y, lat.half().float()], 1)
+    a = 1.0
+    for W, b in zip(net["weights"][:-1], net["biases"][:-1]):
+        y = torch.nn.functional.linear(y, h(W), h(b))
+        if c["act"] == "ReLU":
+            y = torch.relu(y)
+        elif c["act"] == "Sine":
+            y = torch.sin(y * a)
+        elif c["act"] == "Snake":
+            t = torch.sin(a * y)
+            y = y + (1.0 / a) * (t * t)
+        elif c["act"] == "SnakeAlt":
+            y = (y + 1 - torch.cos(2 * a * y)) * (1 / (2.0 * a))
+        y = y.half().float()  # activations are stored as fp16
+    y = torch.nn.functional.linear(y, h(net["weights"][-1]), h(net["biases"][-1]))
+    m = c["mode"]
+    if m == "rgbo":
+        y = torch.cat([torch.sigmoid(y[:, :3]), torch.nn.functional.softplus(y[:, 3:4])], 1)
+    elif m == "rgbo:direct":
+        y = torch.cat([torch.clamp(y[:, :3], 0, 1), torch.clamp(y[:, 3:4], min=0)], 1)
+    elif m in ("density", "densitygrad", "densitycurvature"):
+        y = torch.sigmoid(y[:, :1])
+    else:  # density:direct, densitygrad:direct, densitygrad:cubic, densitycurvature:direct: the kernel does not clamp (:1086)
+        y = y[:, :1]
+    return y.numpy()
+
+
+def check(c, got, net, pos, dirs, label):
+    d = dirs if c["has_dir"] else None
+    ref_t = torch_reference(c, net, pos, dirs)
+    out_f = oracle.OracleNetwork(net["vn"], oracle.ACC_FLOAT).evaluate(pos, d)
+    out_h = oracle.OracleNetwork(net["vn"], oracle.ACC_HALF).evaluate(pos, d)
+    assert got.shape == ref_t.shape == out_f.shape, (label, got.shape, ref_t.shape, out_f.shape)
+    assert np.isfinite(got).all(), label
+    e_t, e_f, e_h = np.abs(got - ref_t).max(), np.abs(got - out_f).max(), np.abs(got - out_h).max()
+    spread = np.abs(out_f - out_h).max()  # the reference's own fp16 arithmetic against fp32 accumulation
+    return e_t, e_f, e_h, spread
+
+
+def test_oracle_matches_the_torch_statement_of_the_reference_test():
+    """CPU: every 6th network of the matrix -- the oracle's FLOAT model against torch (grid_sample, linear, cos / sin)."""
+    worst = (0.0, "")
+    for c in cases():
+        if c["index"] % 6:
+            continue
+        net = build(c)
+        pos, dirs = points(c)
+        ref_t = torch_reference(c, net, pos, dirs)
+        out_f = oracle.OracleNetwork(net["vn"], oracle.ACC_FLOAT).evaluate(pos, dirs if c["has_dir"] else None)
+        assert out_f.shape == ref_t.shape, name(c)
+        e = float(np.abs(out_f - ref_t).max())
+        assert e < TOL_TORCH, (name(c), e)
+        worst = max(worst, (e, name(c)))
+    assert worst[0] > 0.0  # (the two are different programs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", OUTPUT_MODES)
+def test_reference_test_matrix(mode):
+    """GPU: all 240 networks of one output mode through fvsrn_evaluate_points (positions in world = unit-box coordinates)."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    worst = dict(t=(0.0, ""), f=(0.0, ""), h=(0.0, ""))
+    n = 0
+    for c in cases():
+        if c["mode"] != mode:
+            continue
+        net = build(c)
+        pos, dirs = points(c)
+        handle = capi.Network.from_volnet(volnet_io.save_volnet(net["vn"]))
+        tp = torch.from_numpy(pos).cuda()
+        td = torch.from_numpy(dirs).cuda() if c["has_dir"] else None
+        got = handle.evaluate(tp, td, world=True).cpu().numpy()
+        e_t, e_f, e_h, spread = check(c, got, net, pos, dirs, name(c))
+        assert e_f < TOL_SAME_MODEL, (name(c), "FLOAT model", e_f)
+        assert e_t < TOL_TORCH, (name(c), "torch", e_t)
+        assert e_h < max(TOL_REF_BAR, 1.5 * spread), (name(c), "HALF model", e_h, spread)
+        for k, e in (("t", e_t), ("f", e_f), ("h", e_h)):
+            worst[k] = max(worst[k], (float(e), name(c)))
+        n += 1
+    assert n == 240
+    print("%s: worst vs torch %.2e (%s), vs FLOAT %.2e, vs HALF %.2e (%s)" % (mode, worst["t"][0], worst["t"][1], worst["f"][0], worst["h"][0], worst["h"][1]))
