@@ -78,6 +78,26 @@ def test_new_behaviour_scales_by_the_resolution():
     assert np.abs(got - data[idx[:, 0], idx[:, 1], idx[:, 2]]).max() < 1e-6
 
 
+def test_trilinear_restatement_matches_torch_grid_sample():
+    """A third-party witness for the trilinear rows (the reference's CUDA / CPU grid kernels cannot be built here, so this row is restatement-pinned):
+    torch.nn.functional.grid_sample on the same array.  Tensor source, old behaviour -- object coordinate = p (N - 1), nodes at integer coordinates
+    (renderer_volume_grid.cuh:102-120) -- is grid_sample(align_corners=True); texture source, new behaviour -- p N with texel centres at + 0.5
+    (:121-139) -- is grid_sample(align_corners=False) up to the 8 fractional bits of a CUDA texture unit's filter weights.
+    Both with border padding = clamp addressing."""
+    import torch
+    data = make_volume((11, 9, 13), seed=8)
+    rng = np.random.RandomState(4)
+    unit = rng.rand(4096, 3).astype(np.float32)
+    pos = (np.array(BOX_MIN, np.float32) + unit * np.array(BOX_SIZE, np.float32)).astype(np.float32)
+    vol = torch.from_numpy(np.ascontiguousarray(data.transpose(2, 1, 0)))[None, None]  # (1, 1, D = z, H = y, W = x)
+    grid = torch.from_numpy((pos - np.array(BOX_MIN, np.float32)) / np.array(BOX_SIZE, np.float32) * 2 - 1)[None, None, None]  # x -> W, y -> H, z -> D
+    for source, new_behavior, align, tol in ((oracle.VOLUME_SOURCE_TENSOR, False, True, 2e-5), (oracle.VOLUME_SOURCE_TEXTURE, True, False, 4e-3)):
+        want = torch.nn.functional.grid_sample(vol, grid, mode="bilinear", padding_mode="border", align_corners=align)[0, 0, 0, 0].numpy()
+        got = oracle.OracleVolume(data, BOX_MIN, BOX_SIZE, oracle.VOLUME_TRILINEAR, source, new_behavior=new_behavior).evaluate(pos)
+        assert np.abs(got - want).max() < tol, (source, new_behavior, float(np.abs(got - want).max()))
+    assert want.std() > 0.05
+
+
 def test_cvol_round_trip(tmp_path):
     """Volume::save / Volume::Volume(filename), uncompressed (volume.cpp:623-740): header layout and x-fastest voxel order."""
     from fvsrn_amd import capi
