@@ -58,3 +58,42 @@ def test_rotation_model_restarts_in_every_depth_segment():
     d1, _ = oracle.OracleScene(rotation_resync=64, segments=1, **scene_kw).render(net, W, H)
     d4, _ = oracle.OracleScene(rotation_resync=64, segments=4, **scene_kw).render(net, W, H)
     assert 0 < np.abs(d1[:4] - d4[:4]).max() < 2e-2 and 0 < np.abs(d1[:4] - a[:4]).max() < 2e-2
+
+
+def test_transfer_function_restatement_matches_library_interpolation():
+    """The TF rows are restatement-pinned (the reference holds no TF output): hold the restatement of EvaluateTF (renderer_tf_kernels.cuh:11-70
+    over renderer_tf_{identity,texture,piecewise,gaussian}.cuh) to numpy's own interpolation -- a Texture TF is np.interp over the texel centres
+    (i + 0.5) / R with clamped ends, a Piecewise TF np.interp over its control points, a Gaussian TF the plain sum of its Gaussians -- with the
+    density mapped by (d - min) / (max - min), clamped, nothing below `min`, and the opacity times the step size."""
+    rng = np.random.RandomState(12)
+    eye, right, up = oracle.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, 0.7, 1.6)
+    base = dict(eye=eye, right=right, up=up, fov_y_radians=0.7, stepsize=1 / 37, density_min=0.15, density_max=0.85)
+    d = np.concatenate([rng.uniform(-0.2, 1.2, 4000), [0.15, 0.85, 0.0, 1.0]]).astype(np.float32)
+    x = np.clip((d.astype(np.float64) - 0.15) / (0.85 - 0.15), 0.0, 1.0)
+    inside = (d >= np.float32(0.15))[:, None]
+    step = 1 / 37
+    # Texture
+    R = 48
+    tab = rng.uniform(0, 1, (R, 4)).astype(np.float32)
+    tab[:, 3] *= 30
+    got = oracle.OracleScene(tf_kind=oracle.TF_TEXTURE, tf_table=tab, **base).evaluate_tf(d)
+    want = np.stack([np.interp(x, (np.arange(R) + 0.5) / R, tab[:, k]) for k in range(4)], axis=1)
+    want[:, 3] *= step
+    assert np.abs(got - want * inside).max() < 2e-5
+    # Piecewise: rows (r, g, b, opacity, position), positions ascending, the outer two beyond [0, 1]
+    pw = np.array([[0, 0, 0, 0, -1], [0.2, 0.1, 0.8, 0, 0.2], [0.9, 0.5, 0.1, 40, 0.5], [1, 1, 1, 120, 0.9], [1, 1, 1, 120, 2]], np.float32)
+    got = oracle.OracleScene(tf_kind=oracle.TF_PIECEWISE, tf_table=pw, **base).evaluate_tf(d)
+    want = np.stack([np.interp(x, pw[:, 4], pw[:, k]) for k in range(4)], axis=1)
+    want[:, 3] *= step
+    assert np.abs(got - want * inside).max() < 2e-4
+    # Gaussian: rows (r, g, b, opacity, mean, sigma): sum of colour x exp(-(x - mean)^2 / sigma^2)
+    ga = np.array([[0.9, 0.1, 0.1, 30.0, 0.25, 0.08], [0.1, 0.9, 0.2, 60.0, 0.5, 0.05], [0.2, 0.3, 0.95, 90.0, 0.8, 0.1]], np.float32)
+    got = oracle.OracleScene(tf_kind=oracle.TF_GAUSSIAN, tf_table=ga, **base).evaluate_tf(d)
+    w = np.exp(-((x[:, None] - ga[None, :, 4]) ** 2) / (ga[None, :, 5].astype(np.float64) ** 2))
+    want = w @ ga[:, :4].astype(np.float64)
+    want[:, 3] *= step
+    assert np.abs(got - want * inside).max() < 2e-4
+    # Identity: emission = scale x density, opacity = absorption x density x step
+    got = oracle.OracleScene(tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=25.0, tf_scale_emission=0.7, **base).evaluate_tf(d)
+    want = np.stack([0.7 * x, 0.7 * x, 0.7 * x, 25.0 * x * step], axis=1)
+    assert np.abs(got - want * inside).max() < 2e-5
