@@ -1080,7 +1080,8 @@ int fvsrn_network_set_option(fvsrn_network* net, int option, int value) {
         const int old = option >= 0 && option < FVSRN_OPT_COUNT_ ? net->opts[option] : 0;
         const int rc = setOption(net->opts, option, value);
         // the weight image / the key-frame residency are part of the device state
-        if (rc == FVSRN_OK && (option == FVSRN_OPT_RELU_CLAMP || option == FVSRN_OPT_KEYFRAME_SLOTS || option == FVSRN_OPT_WORKING_GRIDS) && old != value) net->invalidate();
+        if (rc == FVSRN_OK && (option == FVSRN_OPT_RELU_CLAMP || option == FVSRN_OPT_KEYFRAME_SLOTS || option == FVSRN_OPT_WORKING_GRIDS ||
+                                 (option == FVSRN_OPT_CELL_TABLE && (old == 0) != (value == 0))) && old != value) net->invalidate();  // (cell table: built or not)
         return rc;
     });
 }

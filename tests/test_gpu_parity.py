@@ -450,6 +450,27 @@ def test_cell_table_is_chosen_by_the_footprint_of_a_pixel_tile():
         assert float((img[:4] - other[:4]).abs().max()) < 1e-3 and float(img[3].max()) > 0.05
 
 
+def test_network_option_cell_table_off_builds_no_table():
+    """Network option cell_table = 0: no table is built (memory), so even a scene that asks for it (cell_table = 1) renders with the gathers; switching the
+    option back on a live network rebuilds the device state with a table."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density", seed=85, box_min=(-0.5, -0.5, -0.5), grid=(16, 8), grid_scale=0.3)
+    kw = make_scene_kwargs(stepsize=1 / 64, early_out=False, tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=20.0, tf_scale_emission=1.0)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    scene = capi.Scene(**kw).set_option("cell_table", 1)
+    a = scene.render(net, 64, 48)[0].clone()
+    assert scene.last_render_info()["cell_table"]
+    net.set_option("cell_table", 0)
+    b = scene.render(net, 64, 48)[0].clone()
+    assert not scene.last_render_info()["cell_table"]
+    net.set_option("cell_table", -1)
+    c = scene.render(net, 64, 48)[0].clone()
+    assert scene.last_render_info()["cell_table"]
+    nn = lambda t: torch.nan_to_num(t, nan=0.0)  # noqa: E731
+    assert torch.equal(nn(a), nn(c)) and float((nn(a)[:4] - nn(b)[:4]).abs().max()) < 1e-3 and float(a[3].max()) > 0.05
+
+
 @pytest.mark.parametrize("C,shape", [(32, (5, 9, 12)), (64, (12, 3, 7))])
 def test_cell_table_non_cubic_grid(C, shape):
     """A latent grid with three different resolutions (Z, Y, X): cell index and table layout follow each axis' own size."""
