@@ -70,15 +70,32 @@ def fuzz_volnet(n, rng):
     return accepted, rejected
 
 
-def fuzz_cvol(n, rng):
+def cvol_seeds(rng):
+    """.cvol seed inputs: the uncompressed version-1 file the library writes, and (r04: the reader also takes them) an LZ4-compressed version-1 file and
+    the old density-only "cvol" format, compressed and not (volume.cpp:647-664, 721-793; written with the test-side LZ4 encoder, tests/util.py)."""
+    import struct
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
     tmp = tempfile.mkdtemp()
     path = os.path.join(tmp, "v.cvol")
     vol = (rng.rand(5, 6, 7) * 255).astype(np.uint8)
     capi.Volume.save_cvol(path, vol, (1.0, 1.0, 1.0))
-    seed = open(path, "rb").read()
+    seeds = [open(path, "rb").read()]
+    x, y, z = np.meshgrid(*[np.linspace(-1, 1, n) for n in (20, 18, 16)], indexing="ij")
+    a = (np.round(np.exp(-3 * (x * x + y * y + z * z)) * 6) * 40).astype(np.uint8)  # plateaus: matches, and literals at their borders
+    raw = np.ascontiguousarray(a.transpose(2, 1, 0)).tobytes()
+    name = b"density"
+    seeds.append(b"CVOL" + struct.pack("<i3f3i", 1, 1.0, 0.9, 0.8, 1, 1, 0) + struct.pack("<i", len(name)) + name + struct.pack("<3Q2i", *a.shape, 1, 0) + util.lz4_messages(raw))
+    for compressed in (0, 1):
+        seeds.append(b"cvol" + struct.pack("<3Q3dIB7x", *a.shape, 1 / 20, 1 / 20, 1 / 20, 0, compressed) + (util.lz4_messages(raw) if compressed else raw))
+    return path, seeds
+
+
+def fuzz_cvol(n, rng):
+    path, seeds = cvol_seeds(rng)
     accepted = rejected = 0
-    for _ in range(n):
-        open(path, "wb").write(mutate(seed, rng))
+    for i in range(n):
+        open(path, "wb").write(mutate(seeds[i % len(seeds)], rng))
         try:
             capi.Volume.load(path)
             accepted += 1
