@@ -120,6 +120,8 @@ SYMBOLS = [
     ("fvsrn_volume_destroy", _I, [_VP]),
     ("fvsrn_volume_load_cvol", _I, [C.c_char_p, _I, C.POINTER(_VP)]),
     ("fvsrn_volume_save_cvol", _I, [C.c_char_p, C.c_char_p, _VP, _I, _I, _I, _I, _F, _F, _F]),
+    ("fvsrn_volume_save_cvol_compressed", _I, [C.c_char_p, C.c_char_p, _VP, _I, _I, _I, _I, _F, _F, _F, _I]),
+    ("fvsrn_cvol_write", _I, [C.c_char_p, C.POINTER(_F), _I, _VP, C.POINTER(_VP), _I]),
     ("fvsrn_volume_info", _I, [_VP, C.POINTER(_I), _FP, _FP]),
     ("fvsrn_volume_get_data", _I, [_VP, _FP, _SZ]),
     ("fvsrn_cvol_read", _I, [C.c_char_p, _FP, _VP, _VP]),
@@ -510,13 +512,14 @@ class Volume:
         return cls(h)
 
     @staticmethod
-    def save_cvol(path: str, data_xyz, world_size=(1.0, 1.0, 1.0), feature_name: str = "density") -> None:
+    def save_cvol(path: str, data_xyz, world_size=(1.0, 1.0, 1.0), feature_name: str = "density", compression: int = 0) -> None:
+        """Volume::save(filename, compression) (volume.cpp:623-682): compression 0 .. 9, > 0 = LZ4 messages (Flag_Compressed)"""
         a = np.asarray(data_xyz)
         if a.ndim != 3 or a.dtype.name not in _VOLUME_DTYPES:
             raise ValueError("expected a (X,Y,Z) uint8 / uint16 / float32 array")
         xfast = np.ascontiguousarray(a.transpose(2, 1, 0))  # file order: x fastest, z slowest
-        _check(lib().fvsrn_volume_save_cvol(os.fsencode(path), feature_name.encode(), xfast.ctypes.data_as(_VP), _VOLUME_DTYPES[a.dtype.name],
-                                            a.shape[0], a.shape[1], a.shape[2], *[float(w) for w in world_size]))
+        _check(lib().fvsrn_volume_save_cvol_compressed(os.fsencode(path), feature_name.encode(), xfast.ctypes.data_as(_VP), _VOLUME_DTYPES[a.dtype.name],
+                                                       a.shape[0], a.shape[1], a.shape[2], *[float(w) for w in world_size], int(compression)))
 
     def info(self):
         res, bmin, bsize = (_I * 3)(), (C.c_float * 3)(), (C.c_float * 3)()

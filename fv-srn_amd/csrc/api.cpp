@@ -1855,37 +1855,120 @@ int fvsrn_volume_info(fvsrn_volume* volume, int resolution[3], float box_min[3],
 }
 
 // Volume::save / Volume::Volume(filename) (volume.cpp:623-668, 685-740), Feature::save / load (:278-332, 346-385)
-int fvsrn_volume_save_cvol(const char* path, const char* feature_name, const void* host_data, int dtype, int sx, int sy, int sz,
-                           float world_x, float world_y, float world_z) {
+// One LZ4 block (the published block format) for `n` bytes at `src`: greedy matcher with a 4-byte hash table, matches inside the block only
+// (an independent block is a valid message of the dependent stream the reader decodes), the format's end-of-block rules: the last sequence is
+// literals only, its last five bytes are literals, no match starts in the last twelve bytes.
+static void lz4CompressBlock(const unsigned char* src, size_t n, std::vector<char>& out) {
+    auto emit = [&](const unsigned char* lit, size_t litLen, size_t matchLen, size_t offset) {
+        const size_t ml = matchLen ? matchLen - 4 : 0;
+        out.push_back(char(((litLen >= 15 ? 15 : litLen) << 4) | (ml >= 15 ? 15 : ml)));
+        if (litLen >= 15) { size_t r = litLen - 15; for (; r >= 255; r -= 255) out.push_back(char(255)); out.push_back(char(r)); }
+        out.insert(out.end(), lit, lit + litLen);
+        if (matchLen) {
+            out.push_back(char(offset & 255)); out.push_back(char(offset >> 8));
+            if (ml >= 15) { size_t r = ml - 15; for (; r >= 255; r -= 255) out.push_back(char(255)); out.push_back(char(r)); }
+        }
+    };
+    std::vector<int> table(1 << 13, -1);
+    const size_t matchStartLimit = n >= 12 ? n - 12 : 0, matchEndLimit = n >= 5 ? n - 5 : 0;
+    size_t i = 0, anchor = 0;
+    while (i < matchStartLimit) {
+        unsigned v;
+        std::memcpy(&v, src + i, 4);
+        const unsigned h = (v * 2654435761u) >> 19;
+        const int cand = table[h];
+        table[h] = int(i);
+        if (cand >= 0 && i - size_t(cand) <= 65535 && std::memcmp(src + cand, src + i, 4) == 0) {
+            size_t len = 4;
+            while (i + len < matchEndLimit && src[size_t(cand) + len] == src[i + len]) ++len;
+            emit(src + anchor, i - anchor, len, i - size_t(cand));
+            i += len;
+            anchor = i;
+        } else {
+            ++i;
+        }
+    }
+    emit(src + anchor, n - anchor, 0, 0);
+}
+
+// Volume::save (volume.cpp:623-682): the version-1 container; compression > 0 sets Flag_Compressed and writes every feature body as LZ4
+// messages in the framing lz4ReadMessages documents (int32 size + one block per <= 64 KiB of input; the reference's levels 1 .. 9 select
+// LZ4 / LZ4-HC effort, here every level is the greedy matcher: the format is the same, the files are larger than LZ4-HC's)
+int fvsrn_cvol_write(const char* path, const float world_size[3], int num_features, const fvsrn_cvol_feature* features, const void* const* data,
+                     int compression) {
     return guarded([&] {
-        if (!path || !feature_name || !host_data) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
-        if (sx <= 0 || sy <= 0 || sz <= 0 || dtype < FVSRN_VOLUME_U8 || dtype > FVSRN_VOLUME_F32) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad volume");
+        if (!path || !world_size || num_features < 0 || (num_features > 0 && (!features || !data))) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        if (compression < 0 || compression > 9) return fail(FVSRN_ERR_INVALID_ARGUMENT, "Illegal compression factor");  // volume.cpp:634-635
+        static const size_t bytesPerType[3] = {1, 2, 4};
+        for (int i = 0; i < num_features; ++i) {
+            const fvsrn_cvol_feature& ft = features[i];
+            if (!data[i] || ft.resolution[0] <= 0 || ft.resolution[1] <= 0 || ft.resolution[2] <= 0 || ft.channels <= 0 || ft.dtype < FVSRN_VOLUME_U8 ||
+                ft.dtype > FVSRN_VOLUME_F32 || !std::memchr(ft.name, 0, sizeof(ft.name)))
+                return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad feature " + std::to_string(i));
+        }
         std::ofstream f(path, std::ios::binary);
         if (!f) return fail(FVSRN_ERR_IO, std::string("cannot write ") + path);
-        const int version = 1, numFeatures = 1, flags = 0, channels = 1;
+        const int version = 1, flags = compression > 0 ? 1 : 0;
         const char pad[4] = {0, 0, 0, 0};
         f.write("CVOL", 4);
         f.write(reinterpret_cast<const char*>(&version), 4);
-        f.write(reinterpret_cast<const char*>(&world_x), 4);
-        f.write(reinterpret_cast<const char*>(&world_y), 4);
-        f.write(reinterpret_cast<const char*>(&world_z), 4);
-        f.write(reinterpret_cast<const char*>(&numFeatures), 4);
+        f.write(reinterpret_cast<const char*>(world_size), 12);
+        f.write(reinterpret_cast<const char*>(&num_features), 4);
         f.write(reinterpret_cast<const char*>(&flags), 4);
         f.write(pad, 4);
-        const int lenName = int(std::strlen(feature_name));
-        const unsigned long long X = sx, Y = sy, Z = sz;
-        f.write(reinterpret_cast<const char*>(&lenName), 4);
-        f.write(feature_name, lenName);
-        f.write(reinterpret_cast<const char*>(&X), 8);
-        f.write(reinterpret_cast<const char*>(&Y), 8);
-        f.write(reinterpret_cast<const char*>(&Z), 8);
-        f.write(reinterpret_cast<const char*>(&channels), 4);
-        f.write(reinterpret_cast<const char*>(&dtype), 4);
-        static const size_t bytesPerType[3] = {1, 2, 4};
-        f.write(static_cast<const char*>(host_data), std::streamsize(bytesPerType[dtype] * X * Y * Z));
+        std::vector<char> block;
+        for (int i = 0; i < num_features; ++i) {
+            const fvsrn_cvol_feature& ft = features[i];
+            const int lenName = int(std::strlen(ft.name));
+            const unsigned long long X = ft.resolution[0], Y = ft.resolution[1], Z = ft.resolution[2];
+            f.write(reinterpret_cast<const char*>(&lenName), 4);
+            f.write(ft.name, lenName);
+            f.write(reinterpret_cast<const char*>(&X), 8);
+            f.write(reinterpret_cast<const char*>(&Y), 8);
+            f.write(reinterpret_cast<const char*>(&Z), 8);
+            f.write(reinterpret_cast<const char*>(&ft.channels), 4);
+            f.write(reinterpret_cast<const char*>(&ft.dtype), 4);
+            const size_t bytes = bytesPerType[ft.dtype] * size_t(ft.channels) * X * Y * Z;
+            if (compression > 0) {
+                const unsigned char* p = static_cast<const unsigned char*>(data[i]);
+                for (size_t pos = 0; pos < bytes; pos += 65536) {
+                    block.clear();
+                    lz4CompressBlock(p + pos, std::min<size_t>(65536, bytes - pos), block);
+                    const int size = int(block.size());
+                    f.write(reinterpret_cast<const char*>(&size), 4);
+                    f.write(block.data(), size);
+                }
+            } else {
+                f.write(static_cast<const char*>(data[i]), std::streamsize(bytes));
+            }
+        }
         if (!f) return fail(FVSRN_ERR_IO, std::string("error while writing ") + path);
         return FVSRN_OK;
     });
+}
+
+static int saveCvol(const char* path, const char* feature_name, const void* host_data, int dtype, int sx, int sy, int sz, float world_x, float world_y,
+                    float world_z, int compression) {
+    if (!path || !feature_name || !host_data) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+    if (sx <= 0 || sy <= 0 || sz <= 0 || dtype < FVSRN_VOLUME_U8 || dtype > FVSRN_VOLUME_F32) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad volume");
+    if (std::strlen(feature_name) >= sizeof(fvsrn_cvol_feature{}.name)) return fail(FVSRN_ERR_INVALID_ARGUMENT, "feature name too long");
+    fvsrn_cvol_feature ft{};
+    std::strcpy(ft.name, feature_name);
+    ft.index = 0; ft.num_features = 1; ft.dtype = dtype; ft.channels = 1;
+    ft.resolution[0] = sx; ft.resolution[1] = sy; ft.resolution[2] = sz;
+    const float world[3] = {world_x, world_y, world_z};
+    const void* ptrs[1] = {host_data};
+    return fvsrn_cvol_write(path, world, 1, &ft, ptrs, compression);
+}
+
+int fvsrn_volume_save_cvol(const char* path, const char* feature_name, const void* host_data, int dtype, int sx, int sy, int sz,
+                           float world_x, float world_y, float world_z) {
+    return saveCvol(path, feature_name, host_data, dtype, sx, sy, sz, world_x, world_y, world_z, 0);
+}
+
+int fvsrn_volume_save_cvol_compressed(const char* path, const char* feature_name, const void* host_data, int dtype, int sx, int sy, int sz,
+                                      float world_x, float world_y, float world_z, int compression) {
+    return saveCvol(path, feature_name, host_data, dtype, sx, sy, sz, world_x, world_y, world_z, compression);
 }
 
 // ---- LZ4 framing of compressed .cvol bodies -------------------------------------------------------------------------------------

@@ -489,33 +489,21 @@ struct Volume {
         }, this));
         worldX = world[0]; worldY = world[1]; worldZ = world[2];
     }
-    void save(const std::string& filename, int compression) const {  // Volume::save, volume.cpp:623-668
-        if (compression != 0) raise("this build writes uncompressed .cvol files only (compression=0)");
-        std::ofstream f(filename, std::ios::binary);
-        if (!f) raise("cannot write " + filename);
-        const int version = 1, numFeatures = int(features.size()), flags = 0;
-        const char pad[4] = {0, 0, 0, 0};
-        f.write("CVOL", 4);
-        f.write(reinterpret_cast<const char*>(&version), 4);
-        f.write(reinterpret_cast<const char*>(&worldX), 4);
-        f.write(reinterpret_cast<const char*>(&worldY), 4);
-        f.write(reinterpret_cast<const char*>(&worldZ), 4);
-        f.write(reinterpret_cast<const char*>(&numFeatures), 4);
-        f.write(reinterpret_cast<const char*>(&flags), 4);
-        f.write(pad, 4);
-        for (const auto& ft : features) {
-            const int lenName = int(ft->name_.size()), type = int(ft->type_);
-            const unsigned long long X = ft->sx, Y = ft->sy, Z = ft->sz;
-            f.write(reinterpret_cast<const char*>(&lenName), 4);
-            f.write(ft->name_.data(), lenName);
-            f.write(reinterpret_cast<const char*>(&X), 8);
-            f.write(reinterpret_cast<const char*>(&Y), 8);
-            f.write(reinterpret_cast<const char*>(&Z), 8);
-            f.write(reinterpret_cast<const char*>(&ft->channels_), 4);
-            f.write(reinterpret_cast<const char*>(&type), 4);
-            f.write(ft->data.data(), std::streamsize(ft->data.size()));
+    void save(const std::string& filename, int compression) const {  // Volume::save, volume.cpp:623-682 (the container is written by the C library)
+        std::vector<fvsrn_cvol_feature> infos(features.size());
+        std::vector<const void*> ptrs(features.size());
+        for (size_t i = 0; i < features.size(); ++i) {
+            const Feature& ft = *features[i];
+            if (ft.name_.size() >= sizeof(infos[i].name)) raise("feature name too long: " + ft.name_);
+            std::memset(&infos[i], 0, sizeof(infos[i]));
+            std::memcpy(infos[i].name, ft.name_.data(), ft.name_.size());
+            infos[i].index = int(i); infos[i].num_features = int(features.size());
+            infos[i].dtype = int(ft.type_); infos[i].channels = ft.channels_;
+            infos[i].resolution[0] = ft.sx; infos[i].resolution[1] = ft.sy; infos[i].resolution[2] = ft.sz;
+            ptrs[i] = ft.data.data();
         }
-        if (!f) raise("error while writing " + filename);
+        const float world[3] = {worldX, worldY, worldZ};
+        check(fvsrn_cvol_write(filename.c_str(), world, int(features.size()), infos.data(), ptrs.data(), compression));
     }
     std::shared_ptr<Feature> getFeature(int index) const {
         if (index < 0 || index >= int(features.size())) raise("feature index out of bounds");

@@ -403,6 +403,15 @@ typedef int (*fvsrn_cvol_feature_callback)(void* user, const fvsrn_cvol_feature*
 int fvsrn_cvol_read(const char* path, float world_size[3], fvsrn_cvol_feature_callback on_feature, void* user);
 int fvsrn_volume_save_cvol(const char* path, const char* feature_name, const void* host_data, int dtype, int sx, int sy, int sz,
                            float world_x, float world_y, float world_z);
+/* Volume::save(filename, compression) (renderer/volume.cpp:623-682): compression 0 .. 9 like there -- 0 writes the file of fvsrn_volume_save_cvol,
+ * > 0 sets Flag_Compressed and writes the body as LZ4 messages (int32 size + one LZ4 block per 64 KiB; every level is one greedy matcher here:
+ * same format, larger files than the reference's LZ4-HC levels).  fvsrn_cvol_read / fvsrn_volume_load_cvol read either. */
+int fvsrn_volume_save_cvol_compressed(const char* path, const char* feature_name, const void* host_data, int dtype, int sx, int sy, int sz,
+                                      float world_x, float world_y, float world_z, int compression);
+/* The writer behind both (and behind the pyrenderer `Volume.save`): any number of features, described like fvsrn_cvol_read reports them (`index` /
+ * `num_features` are ignored), data[i] = feature i's typed voxels, channel fastest, then x, y, z. */
+int fvsrn_cvol_write(const char* path, const float world_size[3], int num_features, const fvsrn_cvol_feature* features, const void* const* data,
+                     int compression);
 int fvsrn_volume_info(fvsrn_volume* volume, int resolution[3], float box_min[3], float box_size[3]);
 /* the voxels as the kernels see them (u8 / u16 normalised to [0,1]), x fastest: index x + sx*(y + sy*z); count = sx*sy*sz host floats
  * (Volume::MipmapLevel::toTensor / dataCpu of level 0, volume.cpp:169-214) */

@@ -124,6 +124,74 @@ def test_cvol_round_trip(tmp_path):
         assert np.allclose(bmin, (-0.5, -0.4, -0.3)) and np.allclose(bsize, (1.0, 0.8, 0.6))
 
 
+def _lz4_block_decode(src: bytes, out: bytearray) -> None:
+    """the published LZ4 block format, decoded by a test-side decoder (independent of the library's)"""
+    i, n = 0, len(src)
+    while i < n:
+        tok = src[i]; i += 1
+        lit = tok >> 4
+        if lit == 15:
+            while True:
+                b = src[i]; i += 1; lit += b
+                if b != 255:
+                    break
+        out += src[i:i + lit]; i += lit
+        if i >= n:
+            break
+        off = src[i] | (src[i + 1] << 8); i += 2
+        ml = tok & 15
+        if ml == 15:
+            while True:
+                b = src[i]; i += 1; ml += b
+                if b != 255:
+                    break
+        ml += 4
+        start = len(out) - off
+        assert 0 < off <= len(out)
+        out += out[start:start + ml] if off >= ml else (bytes(out[start:start + off]) * ((ml + off - 1) // off))[:ml]
+
+
+@pytest.mark.parametrize("compression", [1, 9])
+def test_cvol_compressed_save(tmp_path, compression):
+    """Volume::save(filename, compression > 0) (volume.cpp:623-682): Flag_Compressed, the body as LZ4 messages (int32 size + one block per 64 KiB).
+    The file is decoded by the test's own LZ4 decoder (block format rules: the last sequence is literals only and at least five bytes long) and
+    read back by the library; smooth, noisy, tiny (< 13 bytes: no match possible) and exactly-64-KiB inputs."""
+    from fvsrn_amd import capi
+    rng = np.random.RandomState(6)
+    x, y, z = np.meshgrid(*[np.linspace(-1, 1, n) for n in (64, 40, 36)], indexing="ij")
+    cases = dict(smooth=(np.round(np.exp(-3 * (x * x + y * y + z * z)) * 6) * 40).astype(np.uint8),
+                 noisy16=rng.randint(0, 65536, (33, 20, 50)).astype(np.uint16),
+                 float32=np.round(rng.rand(24, 20, 30) * 4).astype(np.float32) / 4,
+                 tiny=rng.randint(0, 255, (3, 2, 2)).astype(np.uint8),
+                 one_message=np.zeros((64, 32, 32), np.uint8),
+                 constant=np.full((70, 40, 30), 7, np.uint8))
+    for name, data in cases.items():
+        path = str(tmp_path / (name + ".cvol"))
+        capi.Volume.save_cvol(path, data, world_size=(1.0, 0.8, 0.6), feature_name="density", compression=compression)
+        raw = open(path, "rb").read()
+        assert raw[:4] == b"CVOL" and struct.unpack("<2i", raw[20:28]) == (1, 1), name  # one feature, Flag_Compressed
+        ln = struct.unpack("<i", raw[32:36])[0]
+        body, pos, out = raw[68 + ln:], 0, bytearray()
+        want = np.ascontiguousarray(data.transpose(2, 1, 0)).tobytes()
+        while len(out) < len(want):
+            cs = struct.unpack("<i", body[pos:pos + 4])[0]; pos += 4
+            before = len(out)
+            block = body[pos:pos + cs]; pos += cs
+            _lz4_block_decode(block, out)
+            assert len(out) - before == min(65536, len(want) - before), name
+            # end-of-block rule: the last token carries literals only (>= 5 of them unless the whole message is shorter)
+            assert len(out) - before < 5 or bytes(out[-5:]) == bytes(block[-5:]), name
+        assert pos == len(body) and bytes(out) == want, name
+        if name in ("smooth", "one_message", "constant"):
+            assert len(body) < len(want) // 4, (name, len(body), len(want))
+        vol = capi.Volume.load(path)
+        assert vol.info()[0] == data.shape
+        scale = {np.dtype(np.uint8): 255.0, np.dtype(np.uint16): 65535.0, np.dtype(np.float32): 1.0}[data.dtype]
+        assert np.array_equal(vol.data(), data.astype(np.float32) / np.float32(scale)), name
+    with pytest.raises(capi.FvsrnError, match="compression"):
+        capi.Volume.save_cvol(str(tmp_path / "bad.cvol"), cases["tiny"], compression=10)
+
+
 def test_cvol_lz4_and_legacy_files(tmp_path):
     """LZ4-compressed bodies (Flag_Compressed, volume.cpp:647-664,721-735) in the lz4cpp framing -- int32 size + LZ4 block per 64 KiB message, ONE
     dependent-block stream per file, so a match in the second feature may reach into the first -- and the old density-only "cvol" format

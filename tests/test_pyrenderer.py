@@ -460,6 +460,11 @@ def _test_volume(shape=(20, 16, 12)):
     return np.clip(np.exp(-3 * (x * x + y * y + z * z)) + 0.1 * np.sin(7 * x) * np.cos(5 * y), 0, 1).astype(np.float32)
 
 
+def capi_volume_data(path, feature=0):
+    from fvsrn_amd import capi
+    return capi.Volume.load(path, feature).data()
+
+
 def test_volume_container_round_trip(tmp_path):
     """pyrenderer.Volume (renderer/volume.cpp:1244-1400): features from tensors, .cvol save / load (uncompressed)."""
     data = _test_volume()
@@ -473,8 +478,16 @@ def test_volume_container_round_trip(tmp_path):
     w = pr.Volume(path)
     assert w.num_features() == 2 and (w.worldX, w.worldY, w.worldZ) == pytest.approx((1.0, 0.8, 0.6))
     assert w.get_feature(0).name() == "density" and w.get_feature("velocity").channels() == 3 and w.get_feature("nope") is None
+    # Volume::save(filename, compression) (volume.cpp:623-682): LZ4 messages, both features of one file; read back bit for bit
+    packed = str(tmp_path / "vol_lz4.cvol")
+    v.save(packed, 5)
+    assert os.path.getsize(packed) < os.path.getsize(path) // 2  # (a zero velocity field and a smooth density)
+    u = pr.Volume(packed)
+    assert u.num_features() == 2 and u.get_feature(1).channels() == 3 and u.get_feature(0).base_resolution() == data.shape
+    got = capi_volume_data(packed)
+    assert np.array_equal(got, data)
     with pytest.raises(RuntimeError, match="compression"):
-        v.save(path, 5)
+        v.save(path, 10)
     # the same file through the C ABI loader
     from fvsrn_amd import capi
     res, bmin, bsize = capi.Volume.load(path).info()
