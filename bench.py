@@ -478,6 +478,10 @@ def main():
             "nominal_samples_per_frame": W * H * steps,
             "wave_executed_samples_per_frame": executed / args.steps,
             "kernel": net.kernel_name(True),
+            # what the launches of the timed region did (fvsrn_scene_last_render_info): depth segments per ray, period of the exact re-derivation of rotated
+            # Fourier features (0: derived at every step), latent grid through the cell table or by gathers (None: no latent grid)
+            "launch": {"depth_segments": plan["segments"], "rotation_resync": plan["rotation_resync"],
+                       "latent_grid": ("cell_table" if plan["cell_table"] else "gather") if info.grid_channels > 0 else None},
             "roofline": rl,
         }
         if per_rank is not None:
