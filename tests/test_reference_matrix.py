@@ -185,3 +185,51 @@ def test_reference_test_matrix(mode):
         n += 1
     assert n == 240
     print("%s: worst vs torch %.2e (%s), vs FLOAT %.2e, vs HALF %.2e (%s)" % (mode, worst["t"][0], worst["t"][1], worst["f"][0], worst["h"][0], worst["h"][1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("part", range(6))
+def test_reference_test_matrix_renders(part):
+    """The same networks through the RENDERER: every 9th network of the matrix (240 of them, 40 per part; all nine output modes, four activations, both
+    depths and widths, every direction / Fourier / latent-grid combination occurs) as a 40 x 24 frame -- colour networks without a transfer function,
+    density networks behind an Identity or a Gaussian one, early-out on for every other network; latent grids once through the cell table and once by
+    gathers.  Compared like the fuzz scenes (tests/test_fuzz_parity.py): against the oracle's DEVICE model, i.e. the kernels' stated arithmetic with
+    the launch's own facts (fvsrn_scene_last_render_info: depth segments, feature rotation), one absolute tolerance; the distance to the FLOAT model
+    (per-sample features) is reported.  The reference's test stops at `evaluate`; this is the renderer's own variant matrix."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    from test_gpu_parity import GAUSS_TF, TOL_IMG
+    picked = [c for c in cases() if c["index"] % 9 == 4]
+    assert len(picked) == 240
+    worst, worst_float = (0.0, ""), (0.0, "")
+    for k, c in enumerate(picked[40 * part:40 * (part + 1)]):
+        net = build(c)
+        eye, right, up = oracle.camera_on_a_sphere("Ym", (0.5, 0.5, 0.5), 0.4, 0.7 + 0.37 * k, 1.6)
+        kw = dict(eye=eye, right=right, up=up, fov_y_radians=float(np.deg2rad(45.0)), stepsize=1 / 32, early_out=bool(k & 1))
+        unbounded = "direct" in c["mode"] or "cubic" in c["mode"]
+        if c["mode"].startswith("rgbo"):
+            kw.update(tf_kind=oracle.TF_NONE)
+        elif k % 3 == 0:
+            kw.update(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF, density_min=-0.5 if unbounded else 0.1, density_max=1.5 if unbounded else 0.9)
+        else:
+            kw.update(tf_kind=oracle.TF_IDENTITY, tf_scale_absorption=20.0, tf_scale_emission=1.0, density_min=-0.5 if unbounded else 0.1, density_max=1.5 if unbounded else 0.9)
+        handle = capi.Network.from_volnet(volnet_io.save_volnet(net["vn"]))
+        ref_f, _ = oracle.OracleScene(**kw).render(oracle.OracleNetwork(net["vn"], oracle.ACC_FLOAT), 40, 24)
+        for opts in ([{"cell_table": 1}, {"cell_table": 0}] if c["G"] else [{}]):
+            scene = capi.Scene(**kw)
+            for o, v in opts.items():
+                scene.set_option(o, v)
+            stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+            img = scene.render(handle, 40, 24, stats=stats)[0].cpu().numpy()
+            plan = scene.last_render_info()
+            assert plan["cell_table"] == (opts.get("cell_table") == 1), (name(c), plan)
+            dev, count = oracle.OracleScene(rotation_resync=plan["rotation_resync"], segments=plan["segments"], **kw).render(
+                oracle.OracleNetwork(net["vn"], oracle.ACC_DEVICE), 40, 24)
+            # (colour and alpha; the normal planes of predicted-gradient networks go through safeNormalize: profiles/r04/fuzz_1200_summary_r04.txt)
+            e = float(np.abs(np.nan_to_num(img[:4]) - np.nan_to_num(dev[:4])).max())
+            assert e < TOL_IMG, (name(c), opts, e, plan)
+            assert np.array_equal(np.isnan(img[7]), np.isnan(dev[7])), name(c)
+            assert abs(int(stats[0]) - count) <= max(2, count // 1000), name(c)
+            worst = max(worst, (e, name(c)))
+            worst_float = max(worst_float, (float(np.abs(np.nan_to_num(img[:4]) - np.nan_to_num(ref_f[:4])).max()), name(c)))
+    print("part %d: worst |rgba - DEVICE model| %.2e (%s); worst |rgba - FLOAT model| %.2e (%s)" % (part, worst[0], worst[1], worst_float[0], worst_float[1]))
