@@ -111,6 +111,8 @@ SYMBOLS = [
     ("fvsrn_generate_rays", _I, [_FP, _FP, _FP, _F, _I, _I, _VP, _VP, _VP]),
     ("fvsrn_scene_evaluate_tf", _I, [_VP, _VP, _VP, _SZ, _F, _F, _F, _VP, _VP]),
     ("fvsrn_network_kernel_name", _I, [_VP, _I, C.c_char_p, _SZ]),
+    ("fvsrn_scene_last_kernel_name", _I, [_VP, C.c_char_p, _SZ]),
+    ("fvsrn_debug_state", _I, [C.c_char_p, _SZ]),
     ("fvsrn_network_set_option", _I, [_VP, _I, _I]),
     ("fvsrn_network_get_option", _I, [_VP, _I, C.POINTER(_I)]),
     ("fvsrn_scene_set_option", _I, [_VP, _I, _I]),
@@ -448,6 +450,12 @@ class Scene:
         return dict(segments=a[0], rotation_resync=a[1], resident_kernel=a[2] in (1, 4), overlap_kernel=a[2] == 2, adjoint_kernel=a[2] == 3, cell_table=a[2] in (4, 5),
                     waves_per_block=a[3])
 
+    def last_kernel_name(self) -> str:
+        """The kernel the last render of this scene launched (fvsrn_scene_last_kernel_name)."""
+        buf = C.create_string_buffer(256)
+        _check(lib().fvsrn_scene_last_kernel_name(self._h, buf, 256))
+        return buf.value.decode()
+
     def __del__(self):
         try:
             if self._h:
@@ -469,6 +477,13 @@ class Scene:
         _check(lib().fvsrn_render(self._h, net._h, width, height, y0, y1, op, sp,
                                   _current_stream() if stream is None else stream))
         return out
+
+
+def debug_state() -> str:
+    """fvsrn_debug_state: the last launch of every live scene (kernel, launch shape, busy stream, device work counters); never blocks."""
+    buf = C.create_string_buffer(16384)
+    _check(lib().fvsrn_debug_state(buf, 16384))
+    return buf.value.decode(errors="replace")
 
 
 def stripe_rows(height: int, stripe: int, rank: int, world: int) -> int:

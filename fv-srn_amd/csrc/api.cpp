@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <string>
 
@@ -624,7 +625,14 @@ static BoxCenter P_boxCenter(const NetParams& P) {
     return {{P.boxMin[0] + 0.5f * P.boxSize[0], P.boxMin[1] + 0.5f * P.boxSize[1], P.boxMin[2] + 0.5f * P.boxSize[2]}};
 }
 
+// Live scene handles, for fvsrn_debug_state (a watchdog thread asks what the library last launched when a caller hangs).  Leaked on purpose: handles
+// may be destroyed during static destruction.
+struct SceneRegistry { std::mutex mu; std::vector<fvsrn_scene*> live; };
+static SceneRegistry& sceneRegistry() { static SceneRegistry* r = new SceneRegistry; return *r; }
+
 struct fvsrn_scene {
+    fvsrn_scene() { SceneRegistry& r = sceneRegistry(); std::lock_guard<std::mutex> l(r.mu); r.live.push_back(this); }
+    fvsrn_scene(const fvsrn_scene&) = delete;
     fvsrn_scene_desc desc{};
     std::vector<float> tfTable;
     DeviceBuffer dTf, dOrder, dCounters, dPartial, dPreint;
@@ -633,6 +641,7 @@ struct fvsrn_scene {
     float preintStepsize = -1.f;
     unsigned launches = 0;  // parity selects which of the two tile counters a launch uses (the kernel zeroes the other)
     int lastInfo[4] = {0, 0, 0, 0};  // fvsrn_scene_last_render_info
+    std::string lastKernel;          // fvsrn_scene_last_kernel_name: the kernel the last render launched
     bool tfDirty = true;
     int device = -1;  // HIP device of the buffers above (-1: none yet)
     Options opts = defaultOptions();
@@ -640,7 +649,12 @@ struct fvsrn_scene {
     // cached launch order of the 8x8 pixel tiles
     struct OrderKey { int tilesX = -1, tilesY = -1, cx = 0, cy = 0, y0 = 0, stripeRows = 0, stripeRank = 0, stripeWorld = 0; } orderKey;
     std::vector<int> order;
-    ~fvsrn_scene() { dTf.release(); dOrder.release(); dCounters.release(); dPartial.release(); dPreint.release(); }
+    ~fvsrn_scene() {
+        { SceneRegistry& r = sceneRegistry(); std::lock_guard<std::mutex> l(r.mu); r.live.erase(std::remove(r.live.begin(), r.live.end(), this), r.live.end()); }
+        dTf.release(); dOrder.release(); dCounters.release(); dPartial.release(); dPreint.release();
+    }
+    // what the last launch of this scene was, for fvsrn_debug_state: written under `mu` by renderImpl
+    struct LastLaunch { unsigned grid = 0, block = 0; long long units = 0; int width = 0, height = 0, rows = 0, stripeWorld = 1, persistent = 0; void* stream = nullptr; unsigned long long count = 0; } lastLaunch;
 
     // TF table (and, for pre-integrated Texture TFs, its tables) on the device, for step size `stepsize`
     int uploadTf(float stepsize, hipStream_t s) {
@@ -1035,6 +1049,59 @@ int fvsrn_network_get_fourier(const fvsrn_network* net, uint16_t* matrix, int ca
     });
 }
 
+int fvsrn_debug_state(char* buf, size_t cap) {
+    // Never blocks: a scene whose mutex is held (a call of this library is in flight on another host thread) is reported as such, device memory
+    // is read by an asynchronous copy on a stream of its own that is polled for at most a second (a kernel that spins forever keeps the copy engines free).
+    if (!buf || cap == 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+    std::string out;
+    SceneRegistry& r = sceneRegistry();
+    std::unique_lock<std::mutex> lr(r.mu, std::try_to_lock);
+    if (!lr.owns_lock()) out += "scene registry: locked\n";
+    else {
+        out += "live scenes: " + std::to_string(r.live.size()) + "\n";
+        int idx = 0;
+        for (fvsrn_scene* sc : r.live) {
+            out += "scene " + std::to_string(idx++) + ": ";
+            std::unique_lock<std::mutex> ls(sc->mu, std::try_to_lock);
+            if (!ls.owns_lock()) { out += "LOCKED (a library call on this scene is in flight on a host thread)\n"; continue; }
+            const fvsrn_scene::LastLaunch& L = sc->lastLaunch;
+            out += "launches " + std::to_string(L.count) + ", last kernel '" + sc->lastKernel + "' grid " + std::to_string(L.grid) + " x " + std::to_string(L.block) +
+                   ", units " + std::to_string(L.units) + ", image " + std::to_string(L.width) + " x " + std::to_string(L.height) + " (" + std::to_string(L.rows) +
+                   " rows, world " + std::to_string(L.stripeWorld) + "), " + (L.persistent == 1 ? "persistent" : (L.persistent == 2 ? "bounded waves" : "one unit per wave")) +
+                   ", segments " + std::to_string(sc->lastInfo[0]) + ", waves/workgroup " + std::to_string(sc->lastInfo[3]);
+            if (L.count) out += std::string(", stream ") + (hipStreamQuery(static_cast<hipStream_t>(L.stream)) == hipSuccess ? "idle" : "BUSY");
+            (void)hipGetLastError();
+            if (sc->dCounters.ptr) {
+                int host[2] = {-1, -1};
+                hipStream_t cs = nullptr;
+                if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess) {
+                    bool ok = hipMemcpyAsync(host, sc->dCounters.ptr, sizeof(host), hipMemcpyDeviceToHost, cs) == hipSuccess;
+                    for (int i = 0; ok && i < 1000 && hipStreamQuery(cs) == hipErrorNotReady; ++i) { struct timespec ts{0, 1000000}; nanosleep(&ts, nullptr); }
+                    const bool done = ok && hipStreamQuery(cs) == hipSuccess;
+                    out += done ? ", work counters {" + std::to_string(host[0]) + ", " + std::to_string(host[1]) + "} (launch parity " + std::to_string(sc->launches & 1u) + ")"
+                                : std::string(", work counters: copy did not complete in 1 s");
+                    if (done) (void)hipStreamDestroy(cs);  // (a stream with a stuck copy is leaked: destroying it would block)
+                }
+                (void)hipGetLastError();
+            }
+            out += "\n";
+        }
+    }
+    std::strncpy(buf, out.c_str(), cap - 1);
+    buf[cap - 1] = 0;
+    return FVSRN_OK;
+}
+
+int fvsrn_scene_last_kernel_name(fvsrn_scene* scene, char* buf, size_t cap) {
+    return guarded([&] {
+        if (!scene || !buf || cap == 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+        std::lock_guard<std::mutex> lock(scene->mu);
+        std::strncpy(buf, scene->lastKernel.c_str(), cap - 1);
+        buf[cap - 1] = 0;
+        return FVSRN_OK;
+    });
+}
+
 int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t cap) {
     return guarded([&] {
         if (!net || !buf || cap == 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
@@ -1050,13 +1117,15 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
             const bool cells = k.grid == 1 && net->opts[FVSRN_OPT_CELL_TABLE] != 0 && P.gridX >= 2 && P.gridY >= 2 && P.gridZ >= 2 &&
                                double(P.gridX - 1) * (P.gridY - 1) * (P.gridZ - 1) * 512.0 * ((net->packed.cfg.hiddenChannels + 31) / 32) <= 1073741824.0;  // (ensureDevice: cellTableBytes)
             const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && folded ? (cells ? 2 : (P.gridK == 1 ? 1 : 3)) : 3);
+            // (the latent-grid path is chosen per launch: FVSRN_OPT_CELL_TABLE = -1 takes the table by the footprint of a pixel tile, renderImpl)
+            const std::string byFootprint = cells && net->opts[FVSRN_OPT_CELL_TABLE] == -1 ? "; cells or gathers by footprint" : "";
             if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 2 && !P.noFourier && !P.fourierNeedsFractPlain && !P.fourierClampPos && (scalarNet || colourNet) &&
                 (render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1, smallGrid) ||
                  (smallGrid == 2 && P.gridK == 1 && render_small_fn(k.act, k.dir, P.numLayers, colourNet ? 3 : 1, 1))))
                 name = "render_small_kernel<act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "," + std::to_string(P.numLayers) +
-                       ",SGRID=" + std::to_string(smallGrid) + "> (unshaded; else " + name + ")";
+                       ",SGRID=" + std::to_string(smallGrid) + "> (unshaded" + byFootprint + "; else " + name + ")";
             else if (cells && render_cells_fn(k))  // the decoded latent grid through the cell table (renderImpl)
-                name = "render_cells_kernel<" + std::to_string(k.CD) + ",act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "> (unshaded; else " + name + ")";
+                name = "render_cells_kernel<" + std::to_string(k.CD) + ",act " + std::to_string(k.act) + "," + (k.dir ? "true" : "false") + "> (unshaded" + byFootprint + "; else " + name + ")";
         }
         std::strncpy(buf, name.c_str(), cap - 1);
         buf[cap - 1] = 0;
@@ -1612,10 +1681,26 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             // what this launch does to the samples of a ray, for callers that restate it (fvsrn_scene_last_render_info)
             const bool rotates = net->keyScaled.CD == 2 && (net->keyScaled.grid == 0 || (FVSRN_ROTATE_SGRID && smallFn && smallGrid == 1) || (smallFn && smallGrid == 2)) && !a.P.noFourier &&
                                  !a.shaded;  // kRotate / kRotateLds, kernels.hpp
+            scene->lastLaunch.grid = grid; scene->lastLaunch.block = unsigned(64 * wpb); scene->lastLaunch.units = units; scene->lastLaunch.width = width;
+            scene->lastLaunch.height = height; scene->lastLaunch.rows = numLocalRows; scene->lastLaunch.stripeWorld = stripeWorld;
+            scene->lastLaunch.persistent = S.tileCounter ? (S.unitQuota > 0 ? 2 : 1) : 0; scene->lastLaunch.stream = stream; ++scene->lastLaunch.count;
             scene->lastInfo[0] = K;
             scene->lastInfo[1] = rotates ? S.resyncMask + 1 : 0;
             scene->lastInfo[2] = smallFn ? (smallGrid == 2 ? 4 : 1) : (stripeFn ? 2 : (cellsFn ? 5 : (adjointFn ? 3 : 0)));
             scene->lastInfo[3] = wpb;
+            {   // the kernel this launch runs, as rocprofv3 will name it (fvsrn_scene_last_kernel_name)
+                const VariantKey& ks = net->keyScaled;
+                const std::string v = std::to_string(ks.CD) + ",act " + std::to_string(ks.act) + "," + (ks.dir ? "true" : "false");
+                const std::string vp = std::to_string(net->key.CD) + ",act " + std::to_string(net->key.act) + ",grid " + std::to_string(net->key.grid) + "," + (net->key.dir ? "true" : "false");
+                if (smallFn)
+                    scene->lastKernel = "render_small_kernel<act " + std::to_string(ks.act) + "," + (ks.dir ? "true" : "false") + "," + std::to_string(a.P.numLayers) + ",TAIL=" +
+                                        std::to_string(smallTail) + ",SGRID=" + std::to_string(smallGrid) + (smallExact ? ",ADVANCE=false>" : ">");
+                else if (stripeFn) scene->lastKernel = "render_stripe_kernel<" + v + ">";
+                else if (cellsFn) scene->lastKernel = std::string(a.shaded ? "render_shaded_cells_kernel<" + vp : "render_cells_kernel<" + v) + ">";
+                else if (adjointFn) scene->lastKernel = "render_adjoint_kernel<" + vp + ">";
+                else if (a.shaded) scene->lastKernel = "render_shaded_kernel<" + vp + ">";
+                else scene->lastKernel = net->kinfoScaled.renderName;
+            }
             hipError_t e = smallFn ? (smallExact ? launch_render_small_exact(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid, a, grid, unsigned(64 * wpb), lds, s)
                                                  : launch_render_small(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid, a, grid, unsigned(64 * wpb), lds, s))
                                    : (stripeFn ? launch_render_stripe(net->keyScaled, a, grid, unsigned(64 * wpb), lds, s)

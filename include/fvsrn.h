@@ -315,6 +315,16 @@ int fvsrn_camera_on_a_sphere(int orientation, const double center[3], double pit
  * the cell table, 5 render_cells_kernel: render_kernel with the latent grid through the cell table, FVSRN_OPT_CELL_TABLE),
  * waves per workgroup }.  No reference counterpart. */
 int fvsrn_scene_last_render_info(fvsrn_scene* scene, int out[4]);
+/* The kernel the last fvsrn_render / fvsrn_render_stripes of this scene launched, spelled like rocprofv3 lists it (family + template
+ * arguments; "" before the first render).  fvsrn_network_kernel_name only knows the network: whether a latent grid goes through the cell
+ * table or the gathers is decided per launch (image size, camera distance: FVSRN_OPT_CELL_TABLE), so profiles and bench lines quote THIS
+ * name.  No reference counterpart (the reference's kernel name is fixed: "ImageEvaluatorSimpleKernel", image_evaluator_simple.cpp:300). */
+int fvsrn_scene_last_kernel_name(fvsrn_scene* scene, char* buf, size_t cap);
+/* Text report for a watchdog (tests/conftest.py asks when a test runs longer than five minutes): every live scene handle with its last launch --
+ * kernel, grid, work units, launch shape, whether its stream is still busy and the values of its two device work counters (persistent waves take their
+ * tiles from them; a kernel that never finishes shows as a busy stream with a counter below `units`).  Never blocks: handles whose mutex is held are
+ * reported as locked, device memory is read by an asynchronous copy polled for at most a second.  May be called from any thread.  No reference counterpart. */
+int fvsrn_debug_state(char* buf, size_t cap);
 
 /* ImageEvaluatorSimple::render  (renderer/image_evaluator_simple.cpp:198-361, kernel
  * ImageEvaluatorSimpleKernel renderer/renderer_image_evaluator_simple.cuh:36-127).
@@ -425,8 +435,9 @@ int fvsrn_volume_evaluate_points(fvsrn_volume* volume, int source, int interpola
 int fvsrn_render_volume(fvsrn_scene* scene, fvsrn_volume* volume, int source, int interpolation, int grid_resolution_new_behavior,
                         int provide_normals, int width, int height, float* d_out8, unsigned long long* d_stats, void* stream);
 
-/* Kernel name + resources of the variant fvsrn_render / fvsrn_evaluate_points would launch for
- * this network (for profiles and bench): writes a 0-terminated string. */
+/* Kernel name of the variant fvsrn_render / fvsrn_evaluate_points would launch for this network: writes a 0-terminated string.
+ * For renders this is a forecast from the network alone -- a latent grid is reported with the cell-table kernel whenever a table exists,
+ * "(cells or gathers by footprint)" marks the automatic mode; the launch's own choice is fvsrn_scene_last_kernel_name. */
 int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t cap);
 
 #ifdef __cplusplus

@@ -34,6 +34,16 @@ def draw_case(seed):
                box_min=(-0.5, -0.5, -0.5), fourier_std=0.4 if rng.rand() < 0.5 else None)
     if wide:  # (a ladder of (C - 4) / 2 features leaves the half range)
         net.update(fourier_std=0.4, layers=min(layers, 4))
+    if int(seed) >= 2000:
+        # r05: depth.  The reference's study grid goes to (32, 22) and (48, 10) (eval_NetworkConfigsGrid.py:37; 48 KiB of shared memory bound it,
+        # computeMaxWarps volume_interpolation_network.cpp:987-1041): 32-wide 2 .. 22 and 48-wide 2 .. 10 weight matrices, a smooth Fourier matrix and a
+        # weight gain just below the edge of chaos of the activation (synthetic.random_arrays: without it the image is the last bias)
+        rd = np.random.RandomState(seed)
+        C = int(rd.choice([32, 48]))
+        deep_layers = int(rd.randint(2, 23 if C == 32 else 11))
+        act = str(rd.choice(["ReLU", "ReLU", "SnakeAlt", "SnakeAlt", "Sine", "Snake"]))
+        gain = {"ReLU": 2.3, "SnakeAlt": 2.0, "Sine": 2.2, "Snake": 1.3}[act] if deep_layers >= 6 else 1.0
+        net.update(C=C, layers=deep_layers, activation=act, fourier_std=0.4, weight_gain=gain)
     eye, right, up = oracle.camera_on_a_sphere(str(rng.choice(["Ym", "Zp", "Xm"])), (0, 0, 0), float(rng.uniform(-0.6, 0.6)),
                                                float(rng.uniform(0, 6.28)), float(rng.uniform(1.2, 2.2)))
     scene = dict(eye=eye, right=right, up=up, fov_y_radians=float(rng.uniform(0.5, 1.0)), stepsize=float(1.0 / rng.choice([24, 48, 160])),
@@ -142,6 +152,12 @@ def test_random_scene_matches_oracle(seed):
 # r04: the 96- and 128-wide kernels (render_kernel<6|8,...>; the reference's (96, 3) / (128, 2) study networks, eval_NetworkConfigsGrid.py:36)
 @pytest.mark.parametrize("seed", list(range(1000, 1012)) + list(range(1100, 1112)))
 def test_random_wide_scene_matches_oracle(seed):
+    check_case(compare_case(seed))
+
+
+# r05: depth -- 32-wide networks of up to 22 and 48-wide of up to 10 weight matrices (seeds from 2000 on)
+@pytest.mark.parametrize("seed", range(2000, 2024))
+def test_random_deep_scene_matches_oracle(seed):
     check_case(compare_case(seed))
 
 

@@ -29,12 +29,21 @@ def test_network_outputs_match_reference_python(name):
     out_f = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(d["positions"], d.get("directions"))
     out_h = oracle.OracleNetwork(vn, oracle.ACC_HALF).evaluate(d["positions"], d.get("directions"))
     assert np.isfinite(out_f).all() and np.isfinite(out_h).all()
-    assert np.abs(out_f - expected_output(d, meta, "out_fp32")).max() < 5e-4
+    spread = np.abs(expected_output(d, meta, "out_fp32") - expected_output(d, meta, "out_fp16")).max()
+    # r05, the deep networks of the reference's study grid (8 .. 22 weight matrices, eval_NetworkConfigsGrid.py:37): the fp16 rounding of the stored
+    # activations is amplified layer by layer (measured 0.8e-3 .. 3.0e-3 against 1.0e-3 .. 4.6e-3 between the reference's own fp32 and fp16 passes), so
+    # the FLOAT model is held to that spread -- and the EXACT model (the network itself: nothing but the weights rounded to half) pins the restatement
+    # of layer loop, latent grid and output parametrisation to the reference's fp32 pass at 1e-5 (measured <= 2e-6)
+    deep = len(meta["layers"].split(":")) + 1 >= 8
+    assert np.abs(out_f - expected_output(d, meta, "out_fp32")).max() < (max(5e-4, 1.5 * spread) if deep else 5e-4)
+    if deep:
+        out_e = oracle.OracleNetwork(vn, oracle.ACC_EXACT).evaluate(d["positions"], d.get("directions"))
+        assert np.abs(out_e - expected_output(d, meta, "out_fp32")).max() < 1e-5
+        assert expected_output(d, meta, "out_fp32").std(axis=0).max() > 1e-2, "the output does not depend on the position: a vacuous fixture"
     # (fp16 accumulation noise grows with the layer width: the reference's bar is stated for its 32-wide test networks; 96 / 128 wide: 1.5e-2)
     wide = int(meta["layers"].split(":")[0]) > 64
     assert np.abs(out_h - expected_output(d, meta, "out_fp16")).max() < (1.5e-2 if wide else 1e-2)
     # the two arithmetic models differ by no more than the reference's fp16 and fp32 paths do themselves
-    spread = np.abs(expected_output(d, meta, "out_fp32") - expected_output(d, meta, "out_fp16")).max()
     assert np.abs(out_f - out_h).max() < max(1.5e-2 if wide else 1e-2, 1.5 * spread)
 
 

@@ -29,12 +29,12 @@ def regs(tok):
 
 
 def disassemble(obj):
-    with tempfile.TemporaryDirectory() as t:
-        subprocess.check_call([L + "/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, t + "/fat.bin"])
-        if subprocess.run([L + "/clang-offload-bundler", "--type=o", "--input=" + t + "/fat.bin", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                           "--output=" + t + "/dev.co", "--unbundle"], capture_output=True).returncode != 0:
-            return []  # (a host-only translation unit)
-        return subprocess.run([L + "/llvm-objdump", "-d", "--no-show-raw-insn", t + "/dev.co"], capture_output=True, text=True).stdout.splitlines()
+    """every gfx950 code object embedded in `obj` (object file or linked library), disassembled: tools/fix_pk_opsel.py"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fix_pk_opsel", os.path.join(ROOT, "tools", "fix_pk_opsel.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.disassemble(obj)
 
 
 def check(obj, dis=None):

@@ -50,15 +50,34 @@ def rewrite(line):
     return "%s%s %s %s%s" % (indent, op, ", ".join(ops), MOD.sub(swap, mods), comment), True
 
 
+def device_code_objects(path, tmpdir):
+    """gfx950 code objects embedded in an object file or a linked library: the .hip_fatbin section of a library holds ONE offload bundle per
+    translation unit (4 KiB-aligned, each starting with the bundler's magic string); every one of them is unbundled."""
+    fat = os.path.join(tmpdir, "fat.bin")
+    if subprocess.run([L + "/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", path, fat], capture_output=True).returncode != 0 or not os.path.exists(fat):
+        return []
+    data = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), data)]
+    out = []
+    for i, a in enumerate(starts):
+        piece = os.path.join(tmpdir, "bundle%d.bin" % i)
+        open(piece, "wb").write(data[a:starts[i + 1] if i + 1 < len(starts) else len(data)])
+        co = os.path.join(tmpdir, "dev%d.co" % i)
+        if subprocess.run([L + "/clang-offload-bundler", "--type=o", "--input=" + piece, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                           "--output=" + co, "--unbundle"], capture_output=True).returncode == 0 and os.path.exists(co) and os.path.getsize(co) > 0:
+            out.append(co)
+    return out
+
+
 def disassemble(path):
     if path.endswith((".s", ".dis")):
         return open(path).read().splitlines()
     with tempfile.TemporaryDirectory() as t:
-        subprocess.check_call([L + "/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", path, t + "/fat.bin"])
-        if subprocess.run([L + "/clang-offload-bundler", "--type=o", "--input=" + t + "/fat.bin", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                           "--output=" + t + "/dev.co", "--unbundle"], capture_output=True).returncode != 0:
-            return []  # (a host-only translation unit: no device code object)
-        return subprocess.run([L + "/llvm-objdump", "-d", "--no-show-raw-insn", t + "/dev.co"], capture_output=True, text=True).stdout.splitlines()
+        lines = []
+        for co in device_code_objects(path, t):  # (none: a host-only translation unit / library)
+            lines += subprocess.run([L + "/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout.splitlines()
+        return lines
 
 
 def check_lines(lines):
