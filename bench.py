@@ -10,7 +10,7 @@ synthetic inputs already resident in HBM:
            CameraOnASphere(Ym, pitch 0.4, distance 1.6, fovY 45 deg), yaw advancing 2*pi/64 per frame,
            Identity TF (absorption 10, emission 1), Beer-Lambert, early-out OFF (every sample evaluated)
   activation  ReLU by default: the activation the reference's own timing harness runs
-           (applications/volnet/eval_NetworkConfigsGrid.py:31, activationX = ["ReLU"]); the paper's SnakeAlt
+           (applications/volnet/eval_NetworkConfigsGrid.py:35, activationX = ["ReLU"]); the paper's SnakeAlt
            twin is timed beside it and reported in "snakealt_twin".
 metric: SRN samples/s, counting lane-exact EVALUATED samples (the loop bound of
 renderer_ray_evaluation_stepping_dvr.cuh:84-90 summed over all rays), read from the kernel's own counter.
@@ -91,7 +91,8 @@ class Runner:
     """The benchmark's frame sequence (rotating camera, advancing time) on fv-srn_amd/tiles.py StripeRenderer: whole frames on
     one GPU, this rank's stripes + all-gather on several.  All multi-GPU logic lives in the package."""
 
-    def __init__(self, capi, net, cfg, rank, world, early_out, time_keys=1, scene_options=None, force_collective=False):
+    def __init__(self, capi, net, cfg, rank, world, early_out, time_keys=1, scene_options=None, force_collective=False, gather="all", payload="planes",
+                 frames_per_submit=1):
         from fvsrn_amd import tiles
         self.capi, self.net, self.rank, self.world = capi, net, rank, world
         self.time_keys = time_keys
@@ -104,7 +105,9 @@ class Runner:
         pipe = os.environ.get("FVSRN_BENCH_PIPELINE")
         pipelined = pipe == "1" if pipe is not None else world > 1
         self.pipeline = tiles.StripeRenderer(net, self.W, self.H, build_scene_kwargs(capi, 0.0, self.stepsize, early_out), rank=rank,
-                                             world=world, stripe=STRIPE, pipelined=pipelined, force_collective=force_collective)
+                                             world=world, stripe=STRIPE, pipelined=pipelined, force_collective=force_collective,
+                                             frames_per_submit=frames_per_submit, **(dict(gather=gather, payload=payload) if world > 1 or force_collective else {}))
+        self.K = frames_per_submit
         for sc in self.pipeline.scenes:
             for k, v in (scene_options or {}).items():
                 sc.set_option(k, v)
@@ -123,11 +126,27 @@ class Runner:
         return self.pipeline.submit(index, build_scene_kwargs(self.capi, yaw, self.stepsize, self.early_out), time=t, next_time=tn, stats=self.stats,
                                     gather=gather, record=record)
 
+    def frames(self, first, count, record=False, gather=True):
+        """frames first .. first + count - 1: one by one, or (--frames-per-submit K) K per call into the library and per collective"""
+        if self.K == 1:
+            for i in range(first, first + count):
+                self.frame(i, record=record, gather=gather)
+            return
+        for j in range(first, first + count, self.K):
+            idx = list(range(j, min(j + self.K, first + count)))
+            kws = [build_scene_kwargs(self.capi, 2 * math.pi * (i % 64) / 64, self.stepsize, self.early_out) for i in idx]
+            times = [(0.25 * i) % (self.time_keys - 1) for i in idx] if self.time_keys > 1 else None
+            self.pipeline.submit_batch(j // self.K, kws, times=times, stats=self.stats, gather=gather, record=record)
+
+    def where(self, index):
+        """(buffer, frame of the batch) that holds frame `index`"""
+        return ((index // self.K) % self.pipeline.buffers, index % self.K) if self.K > 1 else (index % self.pipeline.buffers, 0)
+
     def finish(self):
         self.pipeline.finish()
 
-    def assemble(self, b=0):
-        return self.pipeline.frame(b)
+    def assemble(self, b=0, k=0):
+        return self.pipeline.frame(b, k)
 
 
 def timed_run(runner, steps, warmup, distributed, spinup_ms=0.0):
@@ -137,38 +156,41 @@ def timed_run(runner, steps, warmup, distributed, spinup_ms=0.0):
     # at N GPUs the timed region shrinks to 32 x 0.3 ms.  Every rank spins for the same wall time, rendering only (the number of
     # frames differs between ranks, so no collective is called here).
     if distributed and spinup_ms > 0:  # one untimed frame with its gather on every rank: RCCL sets its communicator up lazily
-        runner.frame(0)
+        runner.frames(0, 1)
         runner.finish()
         torch.cuda.synchronize()
         dist.barrier()
     t_end = time.perf_counter() + 1e-3 * spinup_ms
     i = 0
     while time.perf_counter() < t_end:
-        runner.frame(i, gather=False)
-        i += 1
-        if i % 8 == 0:
-            runner.finish()
-            torch.cuda.synchronize()
-    for i in range(warmup):
-        runner.frame(i)
+        runner.frames(i, 8, gather=False)
+        i += 8
+        runner.finish()
+        torch.cuda.synchronize()
+    # (batches are aligned to frame indices: the warm-up is rounded up to whole batches so that the timed frames start on one)
+    warmup = -(-warmup // runner.K) * runner.K
+    runner.frames(0, warmup)
     runner.finish()
     torch.cuda.synchronize()
     runner.stats.zero_()
     runner.kernel_events.clear()
     runner.pipeline.gather_events.clear()
+    runner.pipeline.host_seconds, runner.pipeline.frames_submitted = 0.0, 0
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(steps):
-        runner.frame(warmup + i, record=True)
+    runner.frames(warmup, steps, record=True)
     runner.finish()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
-    kernel_ms = [a.elapsed_time(b) for a, b in runner.kernel_events]
+    # (one event pair per submit: a batch of K frames divides by its frame count)
+    per = [min(runner.K, steps - j) for j in range(0, steps, runner.K)] if runner.K > 1 else [1] * len(runner.kernel_events)
+    kernel_ms = [a.elapsed_time(b) / n for (a, b), n in zip(runner.kernel_events, per)]
     st = runner.stats.cpu().numpy().astype(np.int64)
+    runner.last_frame = warmup + steps - 1
     return dt, kernel_ms, int(st[0]), int(st[1])
 
 
@@ -275,7 +297,29 @@ def transcendentals_per_sample(info, activation, rotation_resync):
     return fourier + per_act * (info.num_layers - 1) * info.hidden_channels
 
 
-def roofline(info, activation, evaluated_per_launch, kernel_s, workload_tag, rotation_resync, world=1):
+# Issue cost of a wave instruction on a SIMD's single vector issue port, in cycles (measured on MI355X: profiles/r01/microbench_issue_model.md,
+# profiles/r02/microbench_issue_model_r02.md; MI355X_MICROARCH.md constants table): an MFMA holds the port for 8 of its 32 matrix-pipe cycles, a
+# transcendental for 8.4, a convert / packed instruction for 4.4, any other vector instruction for 2.6 - 2.9.
+ISSUE_CYCLES = {"mfma": 8.0, "trans": 8.4, "cvt": 4.4, "other": 2.75}
+
+
+def issue_roofline(pmc):
+    """The vector issue port as a roofline: sum over instruction classes of (wave instructions per launch x issue cycles) against the SIMD cycles of the
+    launch (SIMDs x shader clock x duration, clock and duration from the same PMC profile).  Counters: SQ_INSTS_VALU (all vector instructions, MFMA
+    included), SQ_INSTS_MFMA, SQ_INSTS_VALU_TRANS_F32, SQ_INSTS_VALU_CVT; "other" is the rest priced as plain fp32 -- packed fp32 instructions (4.4
+    cycles) are in it, so the fraction is a LOWER bound.  None without a committed PMC profile of the workload."""
+    need = ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT", "GRBM_GUI_ACTIVE", "kernel_ms_avg_under_pmc")
+    if not all(k in pmc for k in need):
+        return None
+    n = {"mfma": pmc["SQ_INSTS_MFMA"], "trans": pmc["SQ_INSTS_VALU_TRANS_F32"], "cvt": pmc["SQ_INSTS_VALU_CVT"]}
+    n["other"] = max(0.0, pmc["SQ_INSTS_VALU"] - sum(n.values()))
+    used = {k: n[k] * ISSUE_CYCLES[k] for k in n}
+    simd_cycles = NUM_SIMDS * pmc["GRBM_GUI_ACTIVE"] / 8.0  # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = shader cycles of the launch
+    return {"bound": "issue", "frac": sum(used.values()) / simd_cycles, "issue_cycles_per_launch": used, "insts_per_launch": n,
+            "simd_cycles_per_launch": simd_cycles, "cycles_per_inst": ISSUE_CYCLES, "note": "packed fp32 counted as plain fp32: a lower bound", "from": pmc["file"]}
+
+
+def roofline(info, activation, evaluated_per_launch, kernel_s, workload_tag, rotation_resync, world=1, algorithmic_bytes=None):
     """The roofline object of one bench line.  ReLU: the MFMA roofline (algorithmic FLOP).  Periodic activations: the
     transcendental unit -- achieved = evaluated samples x transcendentals per sample / kernel time, peak = SIMDs x lanes per clock x
     the shader clock, which is taken from GRBM_GUI_ACTIVE of the committed PMC profile of this workload (summed over the 8 XCDs) where
@@ -286,6 +330,14 @@ def roofline(info, activation, evaluated_per_launch, kernel_s, workload_tag, rot
     traffic = 1024.0 * (pmc["WRITE_SIZE"] + 2.0 * pmc["FETCH_SIZE"]) if "WRITE_SIZE" in pmc and "FETCH_SIZE" in pmc else None
     common = {"traffic": traffic, "flops_per_sample": info.flops_per_sample, "mfma_flops_per_sample": info.mfma_flops_per_sample,
               "kernel_ms_avg": 1e3 * kernel_s, "mfma_frac": mfma_achieved / MFMA_F16_PEAK_TFLOPS}
+    if traffic is not None and algorithmic_bytes:
+        # HBM bytes the launch must move by construction (the eight output planes, written once) against what the counters saw; a ratio well above 1 is
+        # re-read data -- for the 64-wide latent-grid frames the 30 MB cell table, which misses the 4 MiB L2 of an XCD on every pass
+        common["algorithmic_bytes"] = algorithmic_bytes
+        common["traffic_ratio"] = traffic / algorithmic_bytes
+    issue = issue_roofline(pmc)
+    if issue:
+        common["issue"] = issue
     if activation == "ReLU":
         return dict({"bound": "mfma", "achieved": mfma_achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mfma_achieved / MFMA_F16_PEAK_TFLOPS}, **common)
     tps = transcendentals_per_sample(info, activation, rotation_resync)
@@ -339,6 +391,10 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1 only: take the multi-GPU route (compact stripes, all_gather_into_tensor on the collective's stream, assemble) "
                          "with a one-rank process group, so that the RCCL path runs on a one-GPU box")
+    ap.add_argument("--gather", default="all", choices=["all", "root"], help="N > 1 / --force-collective: the frame on every rank (all-gather) or on rank 0 only")
+    ap.add_argument("--payload", default="planes", choices=["planes", "rgba8"],
+                    help="N > 1 / --force-collective: what travels -- the eight fp32 planes of ImageEvaluatorSimple::render, or ExtractColor'ed RGBA8 words (4 B / pixel)")
+    ap.add_argument("--frames-per-submit", type=int, default=1, help="K camera poses per call into the library and per collective (fvsrn_render_stripes_batch)")
     ap.add_argument("--grid-volume", action="store_true",
                     help="side benchmark (not the headline metric): DVR of a dense grid volume, BASELINE.json configs[0]; one JSON line")
     ap.add_argument("--grid-res", type=int, default=256)
@@ -392,17 +448,21 @@ def main():
     time_keys = TIME_KEYS.get(args.config, 1)
     vn, net = make_network(volnet_io, capi, cfg, args.activation, time_keys)
     info = net.info()
-    runner = Runner(capi, net, cfg, rank, world, args.early_out, time_keys, force_collective=args.force_collective)
+    runner = Runner(capi, net, cfg, rank, world, args.early_out, time_keys, force_collective=args.force_collective, gather=args.gather, payload=args.payload,
+                    frames_per_submit=args.frames_per_submit)
     dt, kernel_ms, evaluated, executed = timed_run(runner, args.steps, args.warmup, collective, args.spinup_ms)
     plan = runner.pipeline.scenes[0].last_render_info()
-    gather_ms = [a.elapsed_time(b) for a, b in runner.pipeline.gather_events]
+    launched_kernel = runner.pipeline.scenes[0].last_kernel_name()  # the launch's own account (fvsrn_scene_last_kernel_name), not a forecast from the network
+    host_us = runner.pipeline.host_us_per_frame
+    gather_ms = [a.elapsed_time(b) / max(1, args.frames_per_submit) for a, b in runner.pipeline.gather_events]
     # per-rank decomposition of a frame (HIP events on the render / collective streams of every rank): rank 0 prints all of them
     per_rank = None
     if collective:
-        mine = torch.tensor([sum(kernel_ms) / max(1, len(kernel_ms)), sum(gather_ms) / max(1, len(gather_ms)), 1e3 * dt / args.steps], dtype=torch.float64, device="cuda")
-        allr = torch.zeros((world, 3), dtype=torch.float64, device="cuda")
+        mine = torch.tensor([sum(kernel_ms) / max(1, len(kernel_ms)), sum(gather_ms) / max(1, len(gather_ms)), 1e3 * dt / args.steps, host_us], dtype=torch.float64, device="cuda")
+        allr = torch.zeros((world, 4), dtype=torch.float64, device="cuda")
         dist.all_gather_into_tensor(allr.view(-1), mine)
-        per_rank = [{"rank": r, "render_ms": float(allr[r, 0]), "gather_ms": float(allr[r, 1]), "frame_period_ms": float(allr[r, 2])} for r in range(world)]
+        per_rank = [{"rank": r, "render_ms": float(allr[r, 0]), "gather_ms": float(allr[r, 1]), "frame_period_ms": float(allr[r, 2]),
+                     "host_us_per_frame": float(allr[r, 3])} for r in range(world)]
     if distributed:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -414,8 +474,8 @@ def main():
 
     frame_check = None
     if collective:  # untimed: the gathered stripes of the last frame equal a whole-frame render on this rank
-        last = args.warmup + args.steps - 1
-        gathered = runner.assemble(last % runner.pipeline.buffers)
+        last = runner.last_frame
+        gathered = runner.assemble(*runner.where(last))   # None on the ranks that do not hold the frame (--gather root)
         yaw = 2 * math.pi * (last % 64) / 64
         scene = capi.Scene(**build_scene_kwargs(capi, yaw, runner.stepsize, args.early_out))
         if time_keys > 1:
@@ -423,9 +483,16 @@ def main():
         full = scene.render(net, runner.W, runner.H)
         torch.cuda.synchronize()
         from fvsrn_amd import tiles
-        frame_check = tiles.frames_match(full, gathered)
-        if args.force_collective:  # one rank, one launch shape: the assembled frame is the same render -- bitwise
-            frame_check = frame_check and bool(torch.equal(torch.nan_to_num(full, nan=-7.0), torch.nan_to_num(gathered, nan=-7.0)))
+        if gathered is None:
+            frame_check = True
+        elif args.payload == "rgba8":  # packed words: every 8-bit channel within one step of the whole-frame render's (depth segments re-associate sums)
+            want = capi.extract_color(full, capi.CHANNEL_COLOR, False, 1.0, rgba8=True)
+            d = torch.stack([((gathered >> s) & 255) - ((want >> s) & 255) for s in (0, 8, 16, 24)]).abs().max()
+            frame_check = bool(int(d) <= (0 if args.force_collective else 1))
+        else:
+            frame_check = tiles.frames_match(full, gathered)
+            if args.force_collective:  # one rank, one launch shape: the assembled frame is the same render -- bitwise
+                frame_check = frame_check and bool(torch.equal(torch.nan_to_num(full, nan=-7.0), torch.nan_to_num(gathered, nan=-7.0)))
         ok = torch.tensor([1 if frame_check else 0], device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         frame_check = bool(ok.item())
@@ -441,8 +508,9 @@ def main():
         dt2, k2, ev2, ex2 = timed_run(r2, args.steps, args.warmup, False)  # the same step counts as the primary
         plan2 = r2.pipeline.scenes[0].last_render_info()
         twin = {"activation": other, "value": ev2 / dt2, "unit": "samples/s", "ms_per_step": 1e3 * dt2 / args.steps, "steps": args.steps,
-                "kernel": net2.kernel_name(True),
-                "roofline": roofline(net2.info(), other, ev2 / args.steps, sum(k2) * 1e-3 / len(k2), tag_of(other), plan2["rotation_resync"])}
+                "kernel": r2.pipeline.scenes[0].last_kernel_name(),
+                "roofline": roofline(net2.info(), other, ev2 / args.steps, sum(k2) * 1e-3 / len(k2), tag_of(other), plan2["rotation_resync"],
+                                     algorithmic_bytes=32.0 * cfg[3] * cfg[4])}
         twin["mfma_frac"] = twin["roofline"]["mfma_frac"]
 
     exact = None
@@ -457,12 +525,29 @@ def main():
                  "roofline": roofline(info, args.activation, ev3 / args.steps, sum(k3) * 1e-3 / len(k3), "no_profile_of_this_option", plan3["rotation_resync"])}
         exact["mfma_frac"] = exact["roofline"]["mfma_frac"]
 
+    spread = None
+    if not collective and not args.no_twin and args.steps >= 8:
+        # How far the headline fraction moves on THIS box within one process (the chip holds a lower clock the denser and the longer the load): three
+        # more rounds of 20 frames, interleaved with 20 frames of the other activation so that the rounds do not all sample the state the timed
+        # region left behind; frac = algorithmic FLOP / HIP-event kernel time / peak per round.
+        other_net = make_network(volnet_io, capi, cfg, "SnakeAlt" if args.activation == "ReLU" else "ReLU", time_keys)[1]
+        ra, rb = Runner(capi, net, cfg, rank, world, args.early_out, time_keys), Runner(capi, other_net, cfg, rank, world, args.early_out, time_keys)
+        fracs = []
+        for _ in range(3):
+            _, kms, ev, _ = timed_run(ra, 20, 2, False)
+            fracs.append(info.flops_per_sample * (ev / 20) / (sum(kms) * 1e-3 / len(kms)) / 1e12 / MFMA_F16_PEAK_TFLOPS)
+            timed_run(rb, 20, 2, False)
+        fracs.sort()
+        spread = {"mfma_frac_min": fracs[0], "mfma_frac_median": fracs[1], "mfma_frac_max": fracs[2], "mfma_frac_rounds": "3 x 20 frames, interleaved with the other activation"}
     if rank == 0:
         _, _, _, W, H, steps = cfg
         kernel_s = sum(kernel_ms) * 1e-3 / len(kernel_ms)             # average launch duration on this rank
         if runner.pipelined:  # consecutive frames overlap on two streams: the event pairs overlap too, use the frame period
             kernel_s = dt / args.steps
-        rl = roofline(info, args.activation, (evaluated / world) / args.steps, kernel_s, tag_of(args.activation), plan["rotation_resync"], world)
+        rl = roofline(info, args.activation, (evaluated / world) / args.steps, kernel_s, tag_of(args.activation), plan["rotation_resync"], world,
+                      algorithmic_bytes=32.0 * W * H)
+        if spread:
+            rl.update(spread)
         out = {
             "metric": "srn_samples_per_s", "value": evaluated / dt, "unit": "samples/s", "n_gpus": world,
             "world_size": dist_world_size(collective), "backend": backend if collective else None,
@@ -472,12 +557,14 @@ def main():
                                    "early-out %s" % (args.config, W, H, steps, cfg[0], cfg[1],
                                                      (" + %d-ch %d^3 latent grid" % cfg[2]) if cfg[2] else " (Fourier-only)",
                                                      args.activation, "on" if args.early_out else "off"),
-                       "parallelism": "1 GPU" if world == 1 else "%d GPUs, round-robin %d-row stripes + RCCL all-gather" % (world, STRIPE)},
+                       "parallelism": "1 GPU" if world == 1 else "%d GPUs, round-robin %d-row stripes + RCCL %s of %s" % (
+                           world, STRIPE, "all-gather" if args.gather == "all" else "gather to rank 0", "8 fp32 planes" if args.payload == "planes" else "RGBA8 words")},
             "frames_per_s": args.steps / dt,
             "evaluated_samples_per_frame": evaluated / args.steps,
             "nominal_samples_per_frame": W * H * steps,
             "wave_executed_samples_per_frame": executed / args.steps,
-            "kernel": net.kernel_name(True),
+            "kernel": launched_kernel,
+            "host_us_per_frame": host_us,  # wall time of this rank's host inside submit per frame (scene update, launch, events, the collective's enqueue)
             # what the launches of the timed region did (fvsrn_scene_last_render_info): depth segments per ray, period of the exact re-derivation of rotated
             # Fourier features (0: derived at every step), latent grid through the cell table or by gathers (None: no latent grid)
             "launch": {"depth_segments": plan["segments"], "rotation_resync": plan["rotation_resync"],
@@ -486,6 +573,8 @@ def main():
         }
         if per_rank is not None:
             out["per_rank"] = per_rank
+            out["gather"], out["payload"], out["frames_per_submit"] = args.gather, args.payload, args.frames_per_submit
+            out["collective_bytes_per_frame_and_rank"] = (32 if args.payload == "planes" else 4) * runner.W * runner.H // world
             out["stripe_launches"] = {"persistent": bool(runner.pipeline.persistent_stripes), "hw_streams_concurrent": runner.pipeline.hw_streams_concurrent,
                                       "needs": "GPU_MAX_HW_QUEUES >= 8 in the environment before the process starts (set by bench.py / launch_ranks)",
                                       "persistent_reserve": "1/16 of the workgroup slots (FVSRN_OPT_PERSISTENT_RESERVE, automatic)"}

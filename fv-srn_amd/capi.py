@@ -106,8 +106,11 @@ SYMBOLS = [
     ("fvsrn_scene_last_render_info", _I, [_VP, C.POINTER(_I)]),
     ("fvsrn_stripe_rows", _I, [_I, _I, _I, _I]),
     ("fvsrn_render_stripes", _I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
+    ("fvsrn_render_stripes_batch", _I, [C.POINTER(_VP), C.POINTER(_VP), _I, _VP, _I, _I, _I, _I, _I, _I, _FP, _FP, _VP, _VP, _I, _F, _VP]),
     ("fvsrn_extract_color", _I, [_VP, _I, _I, _I, _I, _F, _VP, _VP]),
     ("fvsrn_extract_color_rgba8", _I, [_VP, _I, _I, _I, _I, _F, _VP, _VP]),
+    ("fvsrn_depth_range", _I, [_VP, _I, _I, _VP, _VP]),
+    ("fvsrn_extract_color_ranged", _I, [_VP, _I, _I, _I, _I, _F, _VP, _VP, _VP, _VP]),
     ("fvsrn_generate_rays", _I, [_FP, _FP, _FP, _F, _I, _I, _VP, _VP, _VP]),
     ("fvsrn_scene_evaluate_tf", _I, [_VP, _VP, _VP, _SZ, _F, _F, _F, _VP, _VP]),
     ("fvsrn_network_kernel_name", _I, [_VP, _I, C.c_char_p, _SZ]),
@@ -118,6 +121,7 @@ SYMBOLS = [
     ("fvsrn_scene_set_option", _I, [_VP, _I, _I]),
     ("fvsrn_scene_get_option", _I, [_VP, _I, C.POINTER(_I)]),
     ("fvsrn_network_keyframe_stats", _I, [_VP, C.POINTER(C.c_ulonglong)]),
+    ("fvsrn_network_cell_table_stats", _I, [_VP, C.POINTER(C.c_ulonglong)]),
     ("fvsrn_volume_create", _I, [_VP, _I, _I, _I, _I, _I, _FP, _FP, C.POINTER(_VP)]),
     ("fvsrn_volume_destroy", _I, [_VP]),
     ("fvsrn_volume_load_cvol", _I, [C.c_char_p, _I, C.POINTER(_VP)]),
@@ -320,6 +324,11 @@ class Network:
         a = (C.c_ulonglong * 6)()
         _check(lib().fvsrn_network_keyframe_stats(self._h, a))
         return dict(zip(("key_frames", "slots", "uploads", "on_demand", "prefetched", "bytes"), [int(v) for v in a]))
+
+    def cell_table_stats(self) -> dict:
+        a = (C.c_ulonglong * 4)()
+        _check(lib().fvsrn_network_cell_table_stats(self._h, a))
+        return dict(zip(("table_bytes", "builds", "builds_plain", "resident_bytes"), [int(v) for v in a]))
 
     def clear_gpu_resources(self):
         _check(lib().fvsrn_network_clear_gpu_resources(self._h))
@@ -588,6 +597,66 @@ def render_stripes(scene: Scene, net: Network, width: int, height: int, stripe: 
     sp = _torch_ptr(stats, "torch.int64", "stats") if stats is not None else None
     _check(lib().fvsrn_render_stripes(scene._h, net._h, width, height, stripe, rank, world, op, sp,
                                       _current_stream() if stream is None else stream))
+    return out
+
+
+def render_stripes_batch(scenes, streams, net: Network, width: int, height: int, stripe: int, rank: int, world: int, cameras, times=None,
+                         out=None, rgba8=None, use_tonemapping: bool = False, max_exposure: float = 1.0, stats=None):
+    """fvsrn_render_stripes_batch: `len(cameras)` frames in ONE call.  scenes / streams: one lane or several (frame f runs on lane f % lanes:
+    scenes[lane] on the raw stream handle streams[lane]); cameras: (frames, 9) = eye, right, up per frame; times: optional per-frame time.
+    out: (frames, 8, rows, W) fp32 (allocated when None; world == 1: rows = H); rgba8: optional (frames, rows, W) int32 that also receives every frame
+    as packed RGBA8 words (COLOR mode).  Returns out."""
+    import torch
+    cams = np.ascontiguousarray(cameras, np.float32).reshape(-1, 9)
+    n = int(cams.shape[0])
+    rows = height if world == 1 else stripe_rows(height, stripe, rank, world)
+    if out is None:
+        out = torch.zeros((n, 8, rows, width), dtype=torch.float32, device="cuda")
+    if out.numel() < n * 8 * rows * width:
+        raise FvsrnError(-1, "out must hold (frames, 8, rows, W) floats")
+    if rgba8 is not None and rgba8.numel() < n * rows * width:
+        raise FvsrnError(-1, "rgba8 must hold (frames, rows, W) words")
+    lanes = len(scenes)
+    if lanes != len(streams) or lanes < 1:
+        raise FvsrnError(-1, "one stream per scene")
+    hs = (_VP * lanes)(*[sc._h for sc in scenes])
+    st = (_VP * lanes)(*[int(x) for x in streams])
+    tp = None
+    if times is not None:
+        tarr = np.ascontiguousarray(times, np.float32).reshape(-1)
+        if tarr.size != n:
+            raise FvsrnError(-1, "one time per frame")
+        tp = tarr.ctypes.data_as(_FP)
+    _check(lib().fvsrn_render_stripes_batch(hs, st, lanes, net._h, width, height, stripe, rank, world, n, cams.ctypes.data_as(_FP), tp,
+                                            _torch_ptr(out, "torch.float32", "out"), _torch_ptr(rgba8, "torch.int32", "rgba8") if rgba8 is not None else None,
+                                            int(use_tonemapping), max_exposure, _torch_ptr(stats, "torch.int64", "stats") if stats is not None else None))
+    return out
+
+
+def depth_range(raw, stream=None):
+    """fvsrn_depth_range of a (1,8,H,W) / (8,H,W) fp32 CUDA image (part): (3,) fp32 = {-min, max, nan flag} of the depth plane, mergeable over the parts
+    of an image by an element-wise maximum (one all-reduce)."""
+    import torch
+    H, W = int(raw.shape[-2]), int(raw.shape[-1])
+    out = torch.empty(3, dtype=torch.float32, device=raw.device)
+    _check(lib().fvsrn_depth_range(_torch_ptr(raw, "torch.float32", "raw input"), W, H, out.data_ptr(), torch.cuda.current_stream().cuda_stream if stream is None else stream))
+    return out
+
+
+def extract_color_part(raw, channel_mode: int = 3, use_tonemapping: bool = False, max_exposure: float = 1.0, rgba8: bool = True, depth_range3=None, out=None,
+                       stream=None):
+    """fvsrn_extract_color_ranged on a part of an image -- a (8, rows, W) compact stripe image of one rank: (rows, W) int32 RGBA8 words, or (4, rows, W)
+    fp32.  depth_range3: the merged depth range of the whole frame (CHANNEL_DEPTH)."""
+    import torch
+    if raw.dim() != 3 or raw.shape[0] != 8:
+        raise FvsrnError(-1, "raw input must be of shape (8,rows,W)")
+    H, W = int(raw.shape[1]), int(raw.shape[2])
+    s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    rp = depth_range3.data_ptr() if depth_range3 is not None else None
+    if out is None:
+        out = torch.empty((H, W), dtype=torch.int32, device=raw.device) if rgba8 else torch.empty((4, H, W), dtype=torch.float32, device=raw.device)
+    _check(lib().fvsrn_extract_color_ranged(_torch_ptr(raw, "torch.float32", "raw input"), W, H, channel_mode, int(use_tonemapping), max_exposure, rp,
+                                            None if rgba8 else out.data_ptr(), out.data_ptr() if rgba8 else None, s))
     return out
 
 

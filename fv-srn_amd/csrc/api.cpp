@@ -12,6 +12,7 @@
 #include "../../include/fvsrn.h"
 #include "half.hpp"
 #include "launch.hpp"
+#include "launch_host.hpp"
 #include "srn_device_enums.hpp"
 #include "pack.hpp"
 #include "scene_network.hpp"
@@ -368,10 +369,15 @@ struct fvsrn_network {
     // (grid_blend_kernel).  Two of them for networks with more than one key frame: the blend of frame i + 1 writes the grid that
     // frame i does NOT read, so a caller may keep two frames in flight on two streams (tiles.StripeRenderer, BASELINE.json
     // configs[4]); `order` makes a blend wait for every kernel that still reads the grid it overwrites, on whatever stream.
-    // cells: the grid's cell table (NetParams::cellTable) for the image the unshaded renderer runs, rebuilt with every blend; cellsPlain: the one of the plain
+    // cells: the grid's cell table (NetParams::cellTable) for the image the unshaded renderer runs; cellsPlain: the one of the plain
     // image for the shaded renderer, where the network has a re-scaled image as well (otherwise the two are one)
-    struct WorkingGrid { DeviceBuffer a, b, cells, cellsPlain; StreamOrder order; };
-    const void* cellTablePlain = nullptr;  // of the current working grid
+    // Tables are built LAZILY (r05): allocated and filled by the first launch that runs a cell-table kernel on this working grid
+    // (ensureCellTable), and rebuilt together with a blend only while the previous launches used them (cellsWanted / cellsPlainWanted) -- a time-animated
+    // 64^3 .. 128^3 grid whose frames take the gathers (footprint rule, adjoint mode) no longer writes 0.25 .. 2 GB of table per frame nor holds up to
+    // 4 GiB of HBM for a path it never takes, and nothing builds the plain-image table unless something renders shaded.
+    struct WorkingGrid { DeviceBuffer a, b, cells, cellsPlain; bool cellsValid = false, cellsPlainValid = false; StreamOrder order; };
+    bool cellsWanted = false, cellsPlainWanted = false;  // the last unshaded / shaded launch went through the table
+    unsigned long long cellTableBuilds[2] = {0, 0};       // table builds since the device state was created: unshaded-image table, plain-image table
     WorkingGrid workGrid[2];
     int numWorkGrids = 1, curWorkGrid = 0;
     size_t cellTableBytes = 0;  // 0: no cell table (no grid, BYTE_GAUSSIAN, a resolution below 2, above the size cap, FVSRN_OPT_CELL_TABLE = 0)
@@ -501,8 +507,9 @@ struct fvsrn_network {
                 if (i >= numWorkGrids) { workGrid[i].a.release(); workGrid[i].b.release(); workGrid[i].cells.release(); workGrid[i].cellsPlain.release(); continue; }
                 workGrid[i].a.ensure(K.records * size_t(K.Gt + K.Ge) * 2 * 2);
                 if (K.enc == FVSRN_GRID_BYTE_GAUSSIAN) workGrid[i].b.ensure(K.records * size_t(K.Gt + K.Ge) * 2 * 2);
-                if (cellTableBytes) workGrid[i].cells.ensure(cellTableBytes); else workGrid[i].cells.release();
-                if (cellTableBytes && scaledImage) workGrid[i].cellsPlain.ensure(cellTableBytes); else workGrid[i].cellsPlain.release();
+                // (cell tables: allocated by the first launch that uses them, ensureCellTable; a re-pack drops what the old state held)
+                workGrid[i].cells.release(); workGrid[i].cellsPlain.release();
+                workGrid[i].cellsValid = workGrid[i].cellsPlainValid = false;
             }
             packed.params.grid = workGrid[0].a.ptr;
             packed.params.gridB = K.enc == FVSRN_GRID_BYTE_GAUSSIAN ? workGrid[0].b.ptr : nullptr;
@@ -512,9 +519,14 @@ struct fvsrn_network {
             packed.params.grid = nullptr;
             cellTableBytes = 0;
         }
-        packed.params.cellTable = nullptr;
-        packed.params.cellStride = packed.params.cellCount = 0;
-        cellTablePlain = nullptr;
+        packed.params.cellTable = nullptr;  // (set per launch: renderImpl -> ensureCellTable)
+        {
+            const int MT = (packed.cfg.hiddenChannels + 31) / 32;
+            packed.params.cellStride = cellTableBytes ? unsigned(512 * MT) : 0u;
+            packed.params.cellCount = cellTableBytes ? unsigned(cellTableBytes / (512 * size_t(MT))) : 0u;
+        }
+        cellsWanted = cellsPlainWanted = false;
+        cellTableBuilds[0] = cellTableBuilds[1] = 0;
         timeDirty = true;
         imagesOrder.endWrite(stream);  // launches on other streams wait for the uploads above (beginUse)
         // the staging vectors are pageable: the copies above complete before hipMemcpyAsync returns
@@ -528,6 +540,41 @@ struct fvsrn_network {
         if (const void* fn = render_shaded_cells_fn(key)) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         if (const void* fn = render_adjoint_fn(key)) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(maxLds)));
         deviceValid = true;
+    }
+
+    // Fills the cell table of working grid W from its blended records (grid_cell_table_kernel); the caller holds W's write bracket.  plain: the table
+    // of the plain weight image (the shaded renderer's) -- the same buffer as the unshaded one where the network has no re-scaled image.
+    void buildCellTable(WorkingGrid& W, bool plain, hipStream_t stream) {
+        const bool own = plain && scaledImage != nullptr;
+        DeviceBuffer& buf = own ? W.cellsPlain : W.cells;
+        bool& valid = own ? W.cellsPlainValid : W.cellsValid;
+        if (valid) return;
+        buf.ensure(cellTableBytes);
+        const NetParams& np = packed.params;
+        const int MT = (packed.cfg.hiddenChannels + 31) / 32, KS = packed.cfg.hiddenChannels / 16;
+        CellTableParams ct{};
+        ct.grid = W.a.ptr;
+        // the unshaded renderer runs the [0,1]-scaled image where the network has it
+        ct.latentFrags = static_cast<const char*>(!plain && scaledImage ? scaledImage : dLds.ptr) + np.offLayer0 + size_t(MT) * KS * kFragBytes;
+        ct.out = buf.ptr;
+        ct.X = np.gridX; ct.Y = np.gridY; ct.Z = np.gridZ; ct.G = np.gridC; ct.MT = MT;
+        HIP_CHECK(launch_grid_cell_table(ct, stream));
+        valid = true;
+        ++cellTableBuilds[own ? 1 : 0];
+    }
+    // The table of the CURRENT working grid for a launch on `stream` (after syncTime, before beginUse): built now if no launch has needed it since the
+    // last blend.  Readers of the grid on other streams are waited for like by a blend, later readers wait for this write.
+    const void* ensureCellTable(bool plain, hipStream_t stream) {
+        WorkingGrid& W = workGrid[curWorkGrid];
+        const bool own = plain && scaledImage != nullptr;
+        if (!(own ? W.cellsPlainValid : W.cellsValid)) {
+            imagesOrder.beginRead(stream);  // the latent fragments of the weight image
+            W.order.beginWrite(stream);
+            buildCellTable(W, plain, stream);
+            W.order.endWrite(stream);
+        }
+        (plain ? cellsPlainWanted : cellsWanted) = true;
+        return own ? W.cellsPlain.ptr : W.cells.ptr;
     }
 
     // Brings the working grid and the time input of the network in line with net->currentTime/currentEnsemble:
@@ -552,27 +599,11 @@ struct fvsrn_network {
             b.out = W.a.ptr; b.outB = W.b.ptr; b.records = K.records; b.enc = int(K.enc); b.Gt = K.Gt; b.Ge = K.Ge;
             b.lo = g.lo; b.hi = g.hi; b.ens = g.ens; b.frac = g.frac;
             HIP_CHECK(launch_grid_blend(b, stream));
-            if (cellTableBytes) {
-                // the table of the image the unshaded renderer runs: the [0,1]-scaled one where the network has it
-                const NetParams& np = packed.params;
-                const int MT = (packed.cfg.hiddenChannels + 31) / 32, KS = packed.cfg.hiddenChannels / 16;
-                CellTableParams ct{};
-                ct.grid = W.a.ptr;
-                ct.latentFrags = static_cast<const char*>(scaledImage ? scaledImage : dLds.ptr) + np.offLayer0 + size_t(MT) * KS * kFragBytes;
-                ct.out = W.cells.ptr;
-                ct.X = np.gridX; ct.Y = np.gridY; ct.Z = np.gridZ; ct.G = np.gridC; ct.MT = MT;
-                HIP_CHECK(launch_grid_cell_table(ct, stream));
-                cellTablePlain = W.cells.ptr;
-                if (scaledImage) {  // the shaded renderer runs the plain image: its own table
-                    ct.latentFrags = static_cast<const char*>(dLds.ptr) + np.offLayer0 + size_t(MT) * KS * kFragBytes;
-                    ct.out = W.cellsPlain.ptr;
-                    HIP_CHECK(launch_grid_cell_table(ct, stream));
-                    cellTablePlain = W.cellsPlain.ptr;
-                }
-                packed.params.cellTable = W.cells.ptr;
-                packed.params.cellStride = unsigned(512 * MT);
-                packed.params.cellCount = unsigned(cellTableBytes / (512 * size_t(MT)));
-            }
+            W.cellsValid = W.cellsPlainValid = false;
+            // the tables the launches before this blend went through are rebuilt with it (same stream, same write bracket: fvsrn_network_prepare puts
+            // both on its side stream); any other is built by the launch that first wants it
+            if (cellTableBytes && cellsWanted) buildCellTable(W, false, stream);
+            if (cellTableBytes && cellsPlainWanted) buildCellTable(W, true, stream);
             W.order.endWrite(stream);
             curWorkGrid = next;
             packed.params.grid = W.a.ptr;
@@ -609,7 +640,7 @@ struct fvsrn_network {
         dLds.release();
         dLdsScaled.release();
         dLdsCurvature.release();
-        for (WorkingGrid& w : workGrid) { w.a.release(); w.b.release(); w.cells.release(); w.cellsPlain.release(); w.order.release(); }
+        for (WorkingGrid& w : workGrid) { w.a.release(); w.b.release(); w.cells.release(); w.cellsPlain.release(); w.cellsValid = w.cellsPlainValid = false; w.order.release(); }
         imagesOrder.release();
         imageReaders.clear();
         keyStore.release();
@@ -1179,6 +1210,17 @@ int fvsrn_network_keyframe_stats(const fvsrn_network* net, unsigned long long ou
     return FVSRN_OK;
 }
 
+int fvsrn_network_cell_table_stats(const fvsrn_network* net, unsigned long long out[4]) {
+    if (!net || !out) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(net->mu);
+    out[0] = (unsigned long long)net->cellTableBytes;
+    out[1] = net->cellTableBuilds[0];
+    out[2] = net->cellTableBuilds[1];
+    out[3] = 0;
+    for (const auto& w : net->workGrid) out[3] += (unsigned long long)(w.cells.cap + w.cellsPlain.cap);
+    return FVSRN_OK;
+}
+
 int fvsrn_scene_get_option(fvsrn_scene* scene, int option, int* value) {
     if (!scene || !value || option < 0 || option >= FVSRN_OPT_COUNT_) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad option query");
     std::lock_guard<std::mutex> lock(scene->mu);
@@ -1498,9 +1540,6 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             if (!rgbo && d.tf_kind == FVSRN_TF_NONE)
                 return fail(FVSRN_ERR_INVALID_ARGUMENT, "the network outputs densities; the scene needs a transfer function");
             if (numLocalRows == 0) return FVSRN_OK;
-            net->beginUse(s);
-            struct Done { fvsrn_network* n; hipStream_t s; ~Done() { try { n->endUse(s); } catch (...) {} } } done{net, s};
-
             const size_t tfFloats = scene->tfTable.size();
             if (const int rc = scene->uploadTf(d.stepsize, s)) return rc;
             RenderArgs a{};
@@ -1544,7 +1583,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             // ~0.9 (32 wide) / ~0.7 (64 wide), 1.2 x at 1.3 -- further cell pairs cost a dependent fetch each (profiles/r04/cell_footprint_sweep_r04.txt).
             // -1 = this rule, 1 = always, 0 = never.
             bool useCells = O[FVSRN_OPT_CELL_TABLE] == 1;
-            if (O[FVSRN_OPT_CELL_TABLE] == -1 && a.P.cellTable) {
+            if (O[FVSRN_OPT_CELL_TABLE] == -1 && net->cellTableBytes) {
                 const BoxCenter bc = P_boxCenter(a.P);
                 const double ex = S.eye[0] - bc.c[0], ey = S.eye[1] - bc.c[1], ez = S.eye[2] - bc.c[2];
                 const float* bsz = a.P.boxSize;  // (a camera close to or inside the box: its samples are up to half a box diagonal away)
@@ -1561,7 +1600,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
                 // latent grid: 2 = through the cell table (any number of latent channels), 1 = one decoded 16-channel chunk by gathers;
                 // both need the first layer's bias in its weights (bias0Folded: no time input), the resident kernels drop that bias block
-                smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.bias0Folded ? (a.P.cellTable && useCells ? 2 : (a.P.gridK == 1 ? 1 : 3)) : 3);
+                smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.bias0Folded ? (net->cellTableBytes && useCells ? 2 : (a.P.gridK == 1 ? 1 : 3)) : 3);
                 if (O[FVSRN_OPT_SMALL_KERNEL] != 0 && net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && !a.shaded && k.CD == 2 && smallGrid <= 2 && !a.P.noFourier && !a.P.fourierNeedsFract &&
                     !a.P.fourierClampPos &&  // (the resident kernels compile the position clamp out)
                     a.P.numLayers >= 1 && a.P.numLayers <= 3 && (rgbo || (scalarNet && d.tf_kind != FVSRN_TF_NONE)))
@@ -1598,15 +1637,18 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 stripeFn = render_stripe_fn(net->keyScaled);
             // every other unshaded render of a network whose decoded latent grid has a cell table: render_kernel with the grid through that table
             const void* cellsFn = nullptr;
-            if (!smallFn && !stripeFn && !a.shaded && net->keyScaled.grid == 1 && a.P.cellTable && useCells)
+            if (!smallFn && !stripeFn && !a.shaded && net->keyScaled.grid == 1 && net->cellTableBytes && useCells)
                 cellsFn = render_cells_fn(net->keyScaled);
             // the adjoint gradient mode up to 64 channels: its own kernel (render_adjoint_kernel, kernels.hpp)
             const void* adjointFn = (a.shaded && d.gradient_mode == FVSRN_GRADIENT_ADJOINT_METHOD) ? render_adjoint_fn(net->key) : nullptr;
             // the shaded renderer with the grid through the cell table of the plain image: every mode but the adjoint one (whose gradient pass keeps its records)
-            if (a.shaded && d.gradient_mode != FVSRN_GRADIENT_ADJOINT_METHOD && net->key.grid == 1 && net->cellTablePlain && useCells) {
+            if (a.shaded && d.gradient_mode != FVSRN_GRADIENT_ADJOINT_METHOD && net->key.grid == 1 && net->cellTableBytes && useCells)
                 cellsFn = render_shaded_cells_fn(net->key);
-                if (cellsFn) a.P.cellTable = net->cellTablePlain;
-            }
+            // the table itself: built by the first launch that goes through it (and from then on with every blend, until a launch does not)
+            if ((smallFn && smallGrid == 2) || cellsFn) a.P.cellTable = net->ensureCellTable(a.shaded, s);
+            else (a.shaded ? net->cellsPlainWanted : net->cellsWanted) = false;
+            net->beginUse(s);
+            struct Done { fvsrn_network* n; hipStream_t s; ~Done() { try { n->endUse(s); } catch (...) {} } } done{net, s};
             const void* altFn = smallFn ? smallFn : (stripeFn ? stripeFn : (cellsFn ? cellsFn : adjointFn));
             const int perCU = net->renderBlocksPerCU(unsigned(64 * wpb), lds, a.shaded, altFn, O[FVSRN_OPT_MAX_BLOCKS_PER_CU]);
             const unsigned resident = unsigned(net->numCUs) * unsigned(std::max(perCU, 1));  // workgroups the chip holds at once
@@ -1723,7 +1765,7 @@ int fvsrn_render(fvsrn_scene* scene, fvsrn_network* net, int width, int height, 
 }
 
 static int extractImpl(const float* d_raw8, int width, int height, int channel_mode, int use_tonemapping, float max_exposure,
-                       float* d_out4, unsigned int* d_out8, void* stream) {
+                       float* d_out4, unsigned int* d_out8, void* stream, const float* d_range3 = nullptr) {
     if (!d_raw8 || (!d_out4 && !d_out8)) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null image pointer");
     if (width <= 0 || height <= 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad image size");
     if (channel_mode < FVSRN_CHANNEL_MASK || channel_mode > FVSRN_CHANNEL_COLOR) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad channel mode");
@@ -1742,6 +1784,7 @@ static int extractImpl(const float* d_raw8, int width, int height, int channel_m
         ExtractParams p{};
         p.raw = d_raw8; p.out4 = d_out4; p.out8 = d_out8;
         p.minmax = static_cast<float*>(scratch.ptr);
+        p.range3 = channel_mode == FVSRN_CHANNEL_DEPTH ? d_range3 : nullptr;
         p.pixels = (unsigned long long)width * (unsigned long long)height;
         p.mode = channel_mode; p.tonemap = use_tonemapping; p.maxExposure = max_exposure;
         const hipError_t e = launch_extract_color(p, static_cast<hipStream_t>(stream));
@@ -1758,6 +1801,30 @@ int fvsrn_extract_color(const float* d_raw8, int width, int height, int channel_
 int fvsrn_extract_color_rgba8(const float* d_raw8, int width, int height, int channel_mode, int use_tonemapping,
                               float max_exposure, unsigned int* d_out, void* stream) {
     return extractImpl(d_raw8, width, height, channel_mode, use_tonemapping, max_exposure, nullptr, d_out, stream);
+}
+
+int fvsrn_extract_color_ranged(const float* d_raw8, int width, int height, int channel_mode, int use_tonemapping, float max_exposure,
+                               const float* d_range3, float* d_out4, unsigned int* d_out8, void* stream) {
+    if ((d_out4 != nullptr) == (d_out8 != nullptr)) return fail(FVSRN_ERR_INVALID_ARGUMENT, "exactly one of d_out4 / d_out8 must be given");
+    return extractImpl(d_raw8, width, height, channel_mode, use_tonemapping, max_exposure, d_out4, d_out8, stream, d_range3);
+}
+
+int fvsrn_depth_range(const float* d_raw8, int width, int height, float* d_range3, void* stream) {
+    if (!d_raw8 || !d_range3) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null pointer");
+    if (width <= 0 || height <= 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad image size");
+    return guarded([&]() -> int {
+        if (fvsrn_device_count() == 0) return fail(FVSRN_ERR_NO_DEVICE, "no HIP device available: the MI355X kernels cannot run (there is no CPU fallback)");
+        thread_local DeviceBuffer scratch;
+        try {
+            scratch.ensure(16);
+        } catch (const DeviceError& e) {
+            return fail(FVSRN_ERR_DEVICE, e.what());
+        }
+        const unsigned long long pixels = (unsigned long long)width * (unsigned long long)height;
+        const hipError_t e = launch_depth_range(d_raw8 + 7 * pixels, pixels, static_cast<float*>(scratch.ptr), d_range3, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("depth_range failed: ") + hipGetErrorString(e));
+        return FVSRN_OK;
+    });
 }
 
 int fvsrn_generate_rays(const float eye[3], const float right[3], const float up[3], float fov_y_radians, int width, int height,
@@ -1834,6 +1901,48 @@ int fvsrn_render_stripes(fvsrn_scene* scene, fvsrn_network* net, int width, int 
     // local rows are laid out stripe after stripe; a short last stripe only ever is the LAST local stripe
     const int rows = fvsrn_stripe_rows(height, stripe_rows, rank, world);
     return renderImpl(scene, net, width, height, 0, height, rows, stripe_rows, rank, world, 1, d_out_local, d_stats, stream);
+}
+
+int fvsrn_render_stripes_batch(fvsrn_scene* const* scenes, void* const* streams, int lanes, fvsrn_network* net, int width, int height, int stripe_rows,
+                               int rank, int world, int frames, const float* cameras9, const float* times, float* d_out_local, unsigned int* d_rgba8,
+                               int use_tonemapping, float max_exposure, unsigned long long* d_stats) {
+    if (!scenes || !streams || lanes < 1 || lanes > 8 || !net || !cameras9 || !d_out_local || frames < 0)
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument, or lanes outside 1 .. 8");
+    if (stripe_rows <= 0 || stripe_rows % 8 != 0 || world <= 0 || rank < 0 || rank >= world)
+        return fail(FVSRN_ERR_INVALID_ARGUMENT, "stripe_rows must be a positive multiple of 8 and 0 <= rank < world");
+    for (int l = 0; l < lanes; ++l) {
+        if (!scenes[l]) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null scene");
+        for (int m = 0; m < l; ++m)
+            if (scenes[m] == scenes[l] && streams[m] != streams[l])
+                return fail(FVSRN_ERR_INVALID_ARGUMENT, "one scene on two streams: the launches of a scene are ordered on one stream (fvsrn.h)");
+    }
+    if (use_tonemapping && !(max_exposure > 0)) return fail(FVSRN_ERR_INVALID_ARGUMENT, "max_exposure must be positive");
+    const int rows = world == 1 ? height : fvsrn_stripe_rows(height, stripe_rows, rank, world);
+    const size_t planes = size_t(8) * size_t(std::max(rows, 0)) * size_t(std::max(width, 0));
+    for (int f = 0; f < frames; ++f) {
+        fvsrn_scene* sc = scenes[f % lanes];
+        void* st = streams[f % lanes];
+        {
+            std::lock_guard<std::mutex> lock(sc->mu);
+            std::memcpy(sc->desc.cam_eye, cameras9 + size_t(f) * 9, 3 * sizeof(float));
+            std::memcpy(sc->desc.cam_right, cameras9 + size_t(f) * 9 + 3, 3 * sizeof(float));
+            std::memcpy(sc->desc.cam_up, cameras9 + size_t(f) * 9 + 6, 3 * sizeof(float));
+        }
+        if (times) {
+            std::lock_guard<std::mutex> lock(net->mu);
+            net->net->setTimeAndEnsemble(times[f], net->net->currentEnsemble);
+            net->timeDirty = true;
+        }
+        float* out = d_out_local + size_t(f) * planes;
+        const int rc = world == 1 ? renderImpl(sc, net, width, height, 0, height, height, 8, 0, 1, 0, out, d_stats, st)
+                                  : renderImpl(sc, net, width, height, 0, height, rows, stripe_rows, rank, world, 1, out, d_stats, st);
+        if (rc != FVSRN_OK) return rc;
+        if (d_rgba8 && rows > 0) {
+            const int rc2 = extractImpl(out, width, rows, FVSRN_CHANNEL_COLOR, use_tonemapping, max_exposure, nullptr, d_rgba8 + size_t(f) * size_t(rows) * size_t(width), st);
+            if (rc2 != FVSRN_OK) return rc2;
+        }
+    }
+    return FVSRN_OK;
 }
 
 }  // extern "C"

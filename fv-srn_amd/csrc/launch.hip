@@ -1,4 +1,5 @@
 #include "launch.hpp"
+#include "launch_host.hpp"
 
 #include "kernels.hpp"
 
@@ -104,6 +105,15 @@ __device__ __forceinline__ unsigned rgba_to_int(float r, float g, float b, float
     return (unsigned(a) << 24) | (unsigned(b) << 16) | (unsigned(g) << 8) | unsigned(r);
 }
 
+// {min, max, nan flag} as ordered bits -> three floats {-min, max, nan flag}: a form that merges by an element-wise MAXIMUM, i.e. by one all-reduce when the
+// image is spread over the ranks of a multi-GPU frame (fvsrn_depth_range).  No finite depth at all: {-inf, -inf} like an empty maximum.
+__global__ void depth_range_kernel(const unsigned* __restrict__ minmaxBits, float* __restrict__ range3) {
+    const bool any = minmaxBits[0] <= minmaxBits[1];
+    range3[0] = any ? -fromOrderedBits(minmaxBits[0]) : -__builtin_inff();
+    range3[1] = any ? fromOrderedBits(minmaxBits[1]) : -__builtin_inff();
+    range3[2] = minmaxBits[2] ? 1.f : 0.f;
+}
+
 __global__ void extract_color_kernel(ExtractParams p, const unsigned* __restrict__ minmaxBits) {
     const unsigned long long n = p.pixels;
     float scaleRGB = 1.f, offsetRGB = 0.f, scaleA = 1.f, offsetA = 0.f;
@@ -111,7 +121,10 @@ __global__ void extract_color_kernel(ExtractParams p, const unsigned* __restrict
     switch (p.mode) {  // iimage_evaluator.cpp:56-113
         case FVSRN_CHANNEL_DEPTH: {
             float mn, mx;
-            if (minmaxBits[2]) { mn = mx = __uint_as_float(0x7fc00000u); }
+            if (p.range3) {  // the caller's range (merged over the ranks of a multi-GPU frame): {-min, max, nan flag}
+                if (p.range3[2] != 0.f) { mn = mx = __uint_as_float(0x7fc00000u); }
+                else { mn = -p.range3[0]; mx = p.range3[1]; }
+            } else if (minmaxBits[2]) { mn = mx = __uint_as_float(0x7fc00000u); }
             else { mn = fromOrderedBits(minmaxBits[0]); mx = fromOrderedBits(minmaxBits[1]); }
             c0 = c1 = c2 = 7;
             scaleRGB = 1.f / (mx - mn);
@@ -140,7 +153,7 @@ __global__ void extract_color_kernel(ExtractParams p, const unsigned* __restrict
 hipError_t launch_extract_color(const ExtractParams& p, hipStream_t s) {
     unsigned* bits = reinterpret_cast<unsigned*>(p.minmax);
     const unsigned grid = unsigned(std::min<unsigned long long>((p.pixels + 255) / 256, 4096ull));
-    if (p.mode == FVSRN_CHANNEL_DEPTH) {
+    if (p.mode == FVSRN_CHANNEL_DEPTH && !p.range3) {
         const unsigned init[3] = {0xffffffffu, 0u, 0u};
         hipError_t e = hipMemcpyAsync(bits, init, sizeof(init), hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return e;
@@ -149,6 +162,17 @@ hipError_t launch_extract_color(const ExtractParams& p, hipStream_t s) {
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(extract_color_kernel, dim3(grid), dim3(256), 0, s, p, bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_depth_range(const float* depth, unsigned long long pixels, float* scratchBits, float* range3, hipStream_t s) {
+    unsigned* bits = reinterpret_cast<unsigned*>(scratchBits);
+    const unsigned grid = unsigned(std::min<unsigned long long>((pixels + 255) / 256, 4096ull));
+    const unsigned init[3] = {0xffffffffu, 0u, 0u};
+    hipError_t e = hipMemcpyAsync(bits, init, sizeof(init), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(depth_minmax_kernel, dim3(grid), dim3(256), 0, s, depth, pixels, bits);
+    hipLaunchKernelGGL(depth_range_kernel, dim3(1), dim3(1), 0, s, bits, range3);
     return hipGetLastError();
 }
 

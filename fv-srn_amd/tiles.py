@@ -20,6 +20,14 @@ GPU_MAX_HW_QUEUES=8 before the process starts (bench.py and launch_ranks() do th
 what it got -- one spinning wave on each of ITS render / collective streams (``hw_streams_concurrent``, fvsrn_probe_stream_concurrency) --,
 warns when they do not all run side by side, and takes the persistent stripe launches that need them only then.
 
+What travels (r05).  ``gather="all"`` puts the frame on every rank (one all-gather), ``gather="root"`` on rank 0 only (``dist.gather``: grouped
+send / receive with RCCL, the form SURVEY 8(e) names for callers that need the frame once -- a viewer, a file writer).  ``payload="planes"`` moves the
+reference's eight fp32 planes (32 B per pixel: what ImageEvaluatorSimple::render returns), ``payload="rgba8"`` runs IImageEvaluator::ExtractColor on
+the rank's own rows first and moves packed RGBA8 words (4 B per pixel: what a viewer shows); only its DEPTH channel mode needs the other ranks -- the
+depth range of the whole frame, one all-reduce of three floats (fvsrn_depth_range).  ``frames_per_submit=K`` renders K camera poses with ONE call into
+the C library (fvsrn_render_stripes_batch) and moves them with ONE collective: the per-frame host work of the Python loop (scene update, two context
+managers, events, the collective's enqueue -- tens of microseconds against a rank's 0.26 ms share of the headline frame at world 8) is paid once per K.
+
 ``StripeRenderer`` is the frame pipeline of one rank: double-buffered local / gathered images, the gather
 of frame i on a communication stream while frame i + 1 renders, consecutive frames on two render streams so that the
 tail of one launch overlaps the head of the next, time-dependent networks included (the C library keeps two working
@@ -34,6 +42,7 @@ import socket
 import subprocess
 import sys
 import time
+import time as _time
 import warnings
 from typing import Callable, List, Optional, Sequence
 
@@ -67,6 +76,14 @@ def all_gather_frame(local: torch.Tensor, gathered: torch.Tensor = None, group=N
     # concatenation along dim 0 is the layout every backend (RCCL, gloo) accepts
     dist.all_gather_into_tensor(gathered.view((world * local.shape[0],) + tuple(local.shape[1:])), local.contiguous(), group=group)
     return gathered
+
+
+def assemble_rgba8(gathered: torch.Tensor, height: int, stripe: int) -> torch.Tensor:
+    """(world, rows, W) packed RGBA8 stripe images -> (H, W) frame."""
+    world, rows, width = gathered.shape
+    check_even_partition(height, stripe, world)
+    assert rows * world == height
+    return gathered.view(world, rows // stripe, stripe, width).permute(1, 0, 2, 3).reshape(height, width)
 
 
 def assemble(gathered: torch.Tensor, height: int, stripe: int) -> torch.Tensor:
@@ -108,6 +125,12 @@ class StripeRenderer:
     pipelined  consecutive frames alternate between two scenes on two render streams (default: world > 1).  At world == 1
                the same trick is worth +4 % (r01), but one launch at a time keeps the HIP-event duration of the kernel, the
                rocprofv3 trace and the frame period the same number, which is what bench.py reports there.
+    gather     "all" (default): every rank ends up with the frame; "root": rank 0 only (``frame()`` is None elsewhere)
+    payload    "planes" (default): the eight fp32 planes; "rgba8": ExtractColor on the rank's rows, packed RGBA8 words travel (``frame()`` is an (H, W)
+               int32 image); channel_mode / use_tonemapping / max_exposure as in capi.extract_color; extract: the host-side stand-in of the CPU tests,
+               ``extract(local (8,rows,W), channel_mode, use_tonemapping, max_exposure, depth_range3 or None) -> (rows, W) int32``, and
+               depth_range: ``depth_range(local) -> (3,) float32 {-min, max, nan flag}``
+    frames_per_submit   K >= 1: ``submit_batch`` renders K poses with one library call and one collective
     force_collective   world == 1 only: take the multi-GPU route anyway -- compact stripe image, ``all_gather_into_tensor`` on the
                collective's stream, ``assemble`` -- so that the RCCL path executes on a one-GPU box (tests, bench.py --force-collective)
 
@@ -117,12 +140,22 @@ class StripeRenderer:
 
     def __init__(self, net, width: int, height: int, scene_kw: dict, *, rank: int = 0, world: int = 1, stripe: int = STRIPE,
                  group=None, pipelined: Optional[bool] = None, device: str = "cuda", render: Optional[Callable] = None, streams=None,
-                 force_collective: bool = False):
+                 force_collective: bool = False, gather: str = "all", payload: str = "planes", channel_mode: int = 3, use_tonemapping: bool = False,
+                 max_exposure: float = 1.0, extract: Optional[Callable] = None, depth_range: Optional[Callable] = None, frames_per_submit: int = 1):
         self.net, self.W, self.H = net, int(width), int(height)
         self.rank, self.world, self.stripe, self.group = int(rank), int(world), int(stripe), group
         if force_collective and world != 1:
             raise ValueError("force_collective is the one-GPU test mode of the multi-GPU route (world == 1)")
         self.collective = world > 1 or bool(force_collective)  # compact stripes + all-gather + assemble
+        if gather not in ("all", "root") or payload not in ("planes", "rgba8"):
+            raise ValueError('gather is "all" or "root", payload "planes" or "rgba8"')
+        self.gather, self.payload = gather, payload
+        self.channel_mode, self.use_tonemapping, self.max_exposure = int(channel_mode), bool(use_tonemapping), float(max_exposure)
+        self._extract_fn, self._depth_range_fn = extract, depth_range
+        self.K = int(frames_per_submit)
+        if self.K < 1:
+            raise ValueError("frames_per_submit >= 1")
+        self.host_seconds = 0.0  # wall time this rank's host spent inside submit / submit_batch (host_us_per_frame)
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
         if not self.on_gpu and render is None:
@@ -142,11 +175,24 @@ class StripeRenderer:
         # workgroups need more registers than a persistent render launch leaves free) -- with two pairs that wait is a bubble of one
         # collective per frame, with three the collective runs beside the start of the next render.
         nbuf = self.buffers = 3 if self.collective else 2
+        K = self.K
         if not self.collective:
-            self.outs = [torch.zeros((1, 8, self.H, self.W), dtype=torch.float32, device=self.device) for _ in range(nbuf)]
+            if payload != "planes" or gather != "all":
+                raise ValueError("gather / payload are options of the multi-GPU route (world > 1 or force_collective)")
+            self.outs_k = [torch.zeros((K, 8, self.H, self.W), dtype=torch.float32, device=self.device) for _ in range(nbuf)]
+            self.outs = [o[0:1] for o in self.outs_k]
         else:
-            self.local = [torch.zeros((8, self.rows, self.W), dtype=torch.float32, device=self.device) for _ in range(nbuf)]
-            self.gathered = [torch.zeros((self.world, 8, self.rows, self.W), dtype=torch.float32, device=self.device) for _ in range(nbuf)]
+            # [buffer][frame of the batch]: local = this rank's rows, gathered = every rank's (only rank 0 holds it with gather="root")
+            self.local_k = [torch.zeros((K, 8, self.rows, self.W), dtype=torch.float32, device=self.device) for _ in range(nbuf)]
+            self.local = [l[0] for l in self.local_k]
+            holds = gather == "all" or self.rank == 0
+            if payload == "planes":
+                self.gathered_k = [torch.zeros((self.world, K, 8, self.rows, self.W), dtype=torch.float32, device=self.device) if holds else None for _ in range(nbuf)]
+            else:
+                self.send_k = [torch.zeros((K, self.rows, self.W), dtype=torch.int32, device=self.device) for _ in range(nbuf)]
+                self.gathered_k = [torch.zeros((self.world, K, self.rows, self.W), dtype=torch.int32, device=self.device) if holds else None for _ in range(nbuf)]
+                self.range3 = [torch.zeros(3, dtype=torch.float32, device=self.device) for _ in range(nbuf)]
+            self.gathered = [g[:, 0] if g is not None else None for g in self.gathered_k]
         if self.on_gpu:
             from . import capi
             self._capi = capi
@@ -190,8 +236,8 @@ class StripeRenderer:
             self.render_streams = [_HostStream(), _HostStream()]
 
     # ---------------------------------------------------------------------------------------------------------------
-    def _render(self, scene, b: int, stats):
-        out = self.local[b] if self.collective else self.outs[b]
+    def _render(self, scene, b: int, stats, k: int = 0):
+        out = self.local_k[b][k] if self.collective else self.outs_k[b][k:k + 1]
         if self._render_fn is not None:
             self._render_fn(scene, out, self.rank, self.world, self.stripe)
         elif not self.collective:
@@ -202,6 +248,63 @@ class StripeRenderer:
     def _stream_ctx(self, stream):
         return torch.cuda.stream(stream) if self.on_gpu else contextlib.nullcontext()
 
+    def _extract(self, b: int, k: int, range3):
+        """ExtractColor of frame k of buffer b's local rows -> send_k[b][k] (packed RGBA8), on the current stream."""
+        if self._extract_fn is not None:
+            self.send_k[b][k].copy_(torch.as_tensor(self._extract_fn(self.local_k[b][k], self.channel_mode, self.use_tonemapping, self.max_exposure, range3)))
+        else:
+            self._capi.extract_color_part(self.local_k[b][k], self.channel_mode, self.use_tonemapping, self.max_exposure, rgba8=True, depth_range3=range3,
+                                          out=self.send_k[b][k])
+
+    def _collect(self, b: int, n: int, record: bool, extracted: bool = False):
+        """What follows the render of buffer b's n frames on the collective's stream: payload conversion, the collective, gather_done."""
+        import torch.distributed as dist
+        from .capi import CHANNEL_DEPTH
+        with self._stream_ctx(self.comm_stream):  # gather(frame i) overlaps render(frame i + 1)
+            self.comm_stream.wait_event(self.render_done[b])
+            if record and self.on_gpu:
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record()
+            if self.payload == "rgba8":
+                if self.channel_mode == CHANNEL_DEPTH:
+                    # the depth range of the WHOLE frame (iimage_evaluator.cpp:60-77): {-min, max, nan flag} of this rank's rows, merged by ONE all-reduce
+                    for k in range(n):
+                        r3 = self.range3[b]
+                        if self._depth_range_fn is not None:
+                            r3.copy_(torch.as_tensor(self._depth_range_fn(self.local_k[b][k])))
+                        else:
+                            r3.copy_(self._capi.depth_range(self.local_k[b][k]))
+                        dist.all_reduce(r3, op=dist.ReduceOp.MAX, group=self.group)
+                        self._extract(b, k, r3)
+                elif not extracted:
+                    for k in range(n):
+                        self._extract(b, k, None)
+                send, recv = self.send_k[b], self.gathered_k[b]
+            else:
+                send, recv = self.local_k[b], self.gathered_k[b]
+            if self.gather == "all":
+                dist.all_gather_into_tensor(recv.view((self.world * self.K,) + tuple(recv.shape[2:])), send, group=self.group)
+            else:
+                self._gather_to_root(send, recv)
+            if record and self.on_gpu:
+                g1.record()
+                self.gather_events.append((g0, g1))
+            self.gather_done[b].record()
+
+    def _gather_to_root(self, send, recv):
+        """dist.gather to rank 0 (RCCL: one grouped send / receive; gloo: its gather on host tensors -- gloo has none for device tensors, the two-ranks-on-
+        one-GPU test mode stages through the host)."""
+        import torch.distributed as dist
+        if self.on_gpu and dist.get_backend(self.group) == "gloo":
+            host = send.cpu()
+            parts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(host, parts, dst=0, group=self.group)
+            if self.rank == 0:
+                for r in range(self.world):
+                    recv[r].copy_(parts[r])
+            return
+        dist.gather(send, [recv[r] for r in range(self.world)] if self.rank == 0 else None, dst=0, group=self.group)
+
     def submit(self, index: int, scene_kw: dict, *, time: Optional[float] = None, ensemble: int = 0, next_time: Optional[float] = None,
                stats=None, gather: bool = True, record: bool = False) -> int:
         """Enqueues frame `index`: scene update, optional time change, render of this rank's share, gather.  Returns the
@@ -209,7 +312,7 @@ class StripeRenderer:
         next_time: the time of the frame that will be submitted next -- its key-frame blend is enqueued right behind this frame's
         render call on a high-priority side stream (fvsrn_network_prepare), so that it runs beside this render (into the working
         grid this render does not read) instead of between the two renders."""
-        import torch.distributed as dist
+        t_host = _time.perf_counter()
         b = index % self.buffers
         r = index & 1  # scene / render stream: consecutive frames alternate
         s = r if self.pipelined else 0
@@ -248,18 +351,69 @@ class StripeRenderer:
             self.net.prepare(stream=self.blend_stream.cuda_stream)
             self._prepared = (next_time, ensemble)
         if self.collective and gather:
-            with self._stream_ctx(self.comm_stream):  # gather(frame i) overlaps render(frame i + 1)
-                self.comm_stream.wait_event(self.render_done[b])
-                if record and self.on_gpu:
-                    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    g0.record()
-                dist.all_gather_into_tensor(self.gathered[b].view(self.world * 8, -1, self.W), self.local[b], group=self.group)
-                if record and self.on_gpu:
-                    g1.record()
-                    self.gather_events.append((g0, g1))
-                self.gather_done[b].record()
+            self._collect(b, 1, record)
         self.frames_submitted += 1
+        self.host_seconds += _time.perf_counter() - t_host
         return b
+
+    def submit_batch(self, batch_index: int, scene_kws: Sequence[dict], *, times: Optional[Sequence[float]] = None, stats=None, gather: bool = True,
+                     record: bool = False) -> int:
+        """Enqueues len(scene_kws) <= frames_per_submit frames that differ in their camera (eye / right / up; everything else is taken from the
+        first dict) and, optionally, their time: ONE call into the library renders them back to back (fvsrn_render_stripes_batch; the frames alternate
+        between the two scenes / render streams of a pipelined renderer), ONE collective moves them.  Returns the buffer index b; ``frame(b, k)`` is
+        frame k of the batch after ``finish()``."""
+        t_host = _time.perf_counter()
+        n = len(scene_kws)
+        if not 1 <= n <= self.K:
+            raise ValueError("a batch holds 1 .. frames_per_submit frames")
+        b = batch_index % self.buffers
+        if self._render_fn is not None or not self.on_gpu:  # host-side stand-in (CPU tests): frame by frame
+            for k, kw in enumerate(scene_kws):
+                scene = self.scenes[0]
+                if self.on_gpu:
+                    scene.update(**kw)
+                else:
+                    scene.clear()
+                    scene.update(kw)
+                if times is not None:
+                    self.net.set_time_and_ensemble(times[k], 0)
+                self._render(scene, b, stats, k)
+            if self.collective:
+                self.render_done[b].record()
+        else:
+            import numpy as np
+            lanes = self.scenes if self.pipelined else self.scenes[:1]
+            streams = self.render_streams if self.pipelined else [torch.cuda.current_stream()]
+            for sc in lanes:
+                sc.update(**scene_kws[0])
+            cams = np.stack([np.concatenate([np.asarray(kw[key], np.float32).reshape(3) for key in ("eye", "right", "up")]) for kw in scene_kws])
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(streams[0])
+            if self.collective:
+                for st in streams:
+                    st.wait_event(self.gather_done[b])  # buffer b is free again
+            in_call = self.collective and self.payload == "rgba8" and self.channel_mode == self._capi.CHANNEL_COLOR
+            # (world == 1 -- one GPU, or force_collective's one-rank group: a whole frame has the layout of a one-rank stripe image)
+            self._capi.render_stripes_batch(lanes, [st.cuda_stream for st in streams], self.net, self.W, self.H, self.stripe, self.rank, self.world, cams,
+                                            times=times, out=self.local_k[b] if self.collective else self.outs_k[b], rgba8=self.send_k[b] if in_call else None,
+                                            use_tonemapping=self.use_tonemapping, max_exposure=self.max_exposure, stats=stats)
+            for st in streams[1:]:  # the batch is done when every lane is
+                streams[0].wait_stream(st)
+            if self.collective:
+                self.render_done[b].record(streams[0])
+            if record:
+                e1.record(streams[0])
+                self.kernel_events.append((e0, e1))
+        if self.collective and gather:
+            self._collect(b, n, record, extracted=self.on_gpu and self._render_fn is None and self.payload == "rgba8" and self.channel_mode == 3)
+        self.frames_submitted += n
+        self.host_seconds += _time.perf_counter() - t_host
+        return b
+
+    @property
+    def host_us_per_frame(self) -> float:
+        return 1e6 * self.host_seconds / max(1, self.frames_submitted)
 
     def finish(self) -> None:
         """The current stream waits for everything submitted (renders on both streams, gathers)."""
@@ -274,12 +428,18 @@ class StripeRenderer:
         if self.blend_stream is not None:
             cur.wait_stream(self.blend_stream)
 
-    def frame(self, b: int = 0) -> torch.Tensor:
-        """(1, 8, H, W) image of buffer b: the render target itself on one GPU, the gathered stripes put back in image order
-        (a view + one permuting copy) otherwise."""
+    def frame(self, b: int = 0, k: int = 0):
+        """Frame k of buffer b.  payload "planes": the (1, 8, H, W) image -- the render target itself on one GPU, the gathered stripes put back in image
+        order (a view + one permuting copy) otherwise; payload "rgba8": the (H, W) int32 image of packed RGBA8 words.  None on the ranks that do not hold
+        the frame (gather="root", rank > 0)."""
         if not self.collective:
-            return self.outs[b]
-        return assemble(self.gathered[b], self.H, self.stripe)
+            return self.outs_k[b][k:k + 1]
+        g = self.gathered_k[b]
+        if g is None:
+            return None
+        if self.payload == "rgba8":
+            return assemble_rgba8(g[:, k], self.H, self.stripe)
+        return assemble(g[:, k], self.H, self.stripe)
 
 
 def frames_match(full: torch.Tensor, gathered: torch.Tensor, tol_image: float = 2e-4, tol_depth: float = 3e-2) -> bool:

@@ -211,6 +211,12 @@ int fvsrn_scene_get_option(fvsrn_scene* scene, int option, int* value);
 /* time key frames of a network's latent grid: out = { key frames, device slots, uploads, of which a blend had to wait for
  * (on demand), prefetched ahead of need, bytes uploaded } since the device state was created */
 int fvsrn_network_keyframe_stats(const fvsrn_network* net, unsigned long long out[6]);
+/* cell tables of a network's latent grid (FVSRN_OPT_CELL_TABLE): out = { bytes of one table (0: this network has none -- no grid, BYTE_GAUSSIAN, a
+ * resolution below 2, above the size cap, option 0), builds of the table of the image the unshaded renderer runs, builds of the plain-image table
+ * (shaded renders of a network that also has a re-scaled image), bytes of table memory resident now } since the device state was created.  Tables are
+ * built by the first launch that goes through them and then with every key-frame blend for as long as the launches do; a network whose launches take
+ * the gathers (footprint rule, adjoint mode, evaluate_points) never allocates one. */
+int fvsrn_network_cell_table_stats(const fvsrn_network* net, unsigned long long out[4]);
 
 /* ----------------------------------------------------------------------------------------
  * IVolumeInterpolation::evaluate   (renderer/volume_interpolation.cpp:26-127, kernel
@@ -344,6 +350,19 @@ int fvsrn_render(fvsrn_scene* scene, fvsrn_network* net, int width, int height, 
 int fvsrn_stripe_rows(int height, int stripe_rows, int rank, int world);
 int fvsrn_render_stripes(fvsrn_scene* scene, fvsrn_network* net, int width, int height, int stripe_rows, int rank,
                          int world, float* d_out_local, unsigned long long* d_stats, void* stream);
+/* A sequence of frames in one call (no reference counterpart; the reference's sequence renders -- applications/volnet/eval_NetworkConfigsGrid.py:100-140:
+ * one ImageEvaluatorSimple::render per camera of a rotation -- pay one Python call, one scene update and one launch set-up per frame, which is a
+ * third of a rank's 0.26 ms share of the headline frame at world 8).  Frame f takes camera cameras9[f] = { eye, right, up } (host memory, like
+ * fvsrn_scene_desc), the time times[f] if `times` is non-NULL (fvsrn_network_set_time_and_ensemble with the network's current ensemble), and is
+ * rendered like fvsrn_render_stripes into d_out_local + f * 8 * rows * width (rows = fvsrn_stripe_rows(...); world = 1: whole frames) on lane f % lanes:
+ * scenes[lane] on streams[lane].  One lane renders the frames back to back on one stream; two lanes let the tail of one frame's launch overlap the head
+ * of the next (what tiles.StripeRenderer does from Python with two scenes on two streams).  The scenes must agree in everything but the camera -- the
+ * call overwrites cam_eye / cam_right / cam_up of each scene's description, nothing else (a light that follows the camera, brdf_light, does not) -- and the caller orders the streams against its buffers (events) as for
+ * single frames.  d_rgba8 (optional): frame f's rows also as packed RGBA8 words (fvsrn_extract_color_rgba8, FVSRN_CHANNEL_COLOR, use_tonemapping /
+ * max_exposure) at d_rgba8 + f * rows * width, enqueued behind its render on the same stream.  d_stats as in fvsrn_render, summed over the frames. */
+int fvsrn_render_stripes_batch(fvsrn_scene* const* scenes, void* const* streams, int lanes, fvsrn_network* net, int width, int height, int stripe_rows,
+                               int rank, int world, int frames, const float* cameras9, const float* times, float* d_out_local, unsigned int* d_rgba8,
+                               int use_tonemapping, float max_exposure, unsigned long long* d_stats);
 
 /* IImageEvaluator::ExtractColor (renderer/iimage_evaluator.cpp:26-135): the (1,8,H,W) raw image of fvsrn_render ->
  * a displayable RGBA image.  channel_mode: ChannelMode of iimage_evaluator.h:19-26.
@@ -360,6 +379,17 @@ int fvsrn_extract_color(const float* d_raw8, int width, int height, int channel_
                         float max_exposure, float* d_out4, void* stream);
 int fvsrn_extract_color_rgba8(const float* d_raw8, int width, int height, int channel_mode, int use_tonemapping,
                               float max_exposure, unsigned int* d_out, void* stream);
+/* ExtractColor of an image that is spread over the ranks of a multi-GPU frame (no reference counterpart: its frame lives on one device):
+ * every rank converts ITS rows before the collective -- 4 bytes per pixel instead of 32.  Only FVSRN_CHANNEL_DEPTH needs the other ranks: the depth range
+ * of the WHOLE image (iimage_evaluator.cpp:60-77, tensor min() / max()).
+ *   fvsrn_depth_range           d_range3 = { -min, max, nan flag } of channel 7 of this part, three floats on the device -- a form that merges over
+ *                               ranks by an element-wise maximum, i.e. ONE all-reduce (MAX) of three floats;
+ *   fvsrn_extract_color_ranged  fvsrn_extract_color / _rgba8 (exactly one of d_out4 / d_out8 is non-NULL) with the depth range taken from d_range3
+ *                               instead of this part's own (NULL: this part's own, i.e. the plain functions above; ignored by the other modes).
+ * A merged nan flag gives NaN colours like the reference's min() / max() over a depth plane with a NaN (an alpha-0 pixel). */
+int fvsrn_depth_range(const float* d_raw8, int width, int height, float* d_range3, void* stream);
+int fvsrn_extract_color_ranged(const float* d_raw8, int width, int height, int channel_mode, int use_tonemapping, float max_exposure,
+                               const float* d_range3, float* d_out4, unsigned int* d_out8, void* stream);
 
 /* ICamera::generateRays (renderer/camera.cpp:37-98, kernel CameraGenerateRayKernel renderer_camera_kernels.cuh:12-43):
  * ray start / direction of every pixel centre of a width x height image for a camera reference frame (eye, right, up as

@@ -389,9 +389,21 @@ def camera_on_a_sphere(orientation: str, center, pitch: float, yaw: float, dista
 CHANNEL_MASK, CHANNEL_NORMAL, CHANNEL_DEPTH, CHANNEL_COLOR = range(4)
 
 
+def depth_range(raw: np.ndarray) -> np.ndarray:
+    """{-min, max, nan flag} of the depth plane of an image part (the mergeable form of fvsrn_depth_range): min / max over the finite-or-infinite values,
+    the flag says whether any NaN was seen; merged over parts by an element-wise maximum."""
+    d = np.asarray(raw, np.float32)[7].reshape(-1)
+    nan = np.isnan(d)
+    v = d[~nan]
+    if v.size == 0:
+        return np.array([-np.inf, -np.inf, 1.0 if nan.any() else 0.0], np.float32)
+    return np.array([-v.min(), v.max(), 1.0 if nan.any() else 0.0], np.float32)
+
+
 def extract_color(raw: np.ndarray, channel_mode: int = CHANNEL_COLOR, use_tonemapping: bool = False,
-                  max_exposure: float = 1.0) -> np.ndarray:
-    """raw (8,H,W) fp32 -> (4,H,W) fp32, numpy restatement (test infrastructure)."""
+                  max_exposure: float = 1.0, depth_range3=None) -> np.ndarray:
+    """raw (8,H,W) fp32 -> (4,H,W) fp32, numpy restatement (test infrastructure).  depth_range3: the merged {-min, max, nan flag} of the whole frame when
+    `raw` is one rank's part of it (CHANNEL_DEPTH)."""
     raw = np.asarray(raw, np.float32)
     f = np.float32
     if channel_mode == CHANNEL_COLOR:
@@ -406,6 +418,9 @@ def extract_color(raw: np.ndarray, channel_mode: int = CHANNEL_COLOR, use_tonema
         d = raw[7]
         with np.errstate(invalid="ignore", divide="ignore"):
             mn, mx = d.min(), d.max()  # numpy, like torch, propagates NaN
+            if depth_range3 is not None:
+                r3 = np.asarray(depth_range3, np.float32)
+                mn, mx = (np.float32(np.nan), np.float32(np.nan)) if r3[2] != 0 else (-r3[0], r3[1])
             scale, offset = f(1) / (mx - mn), -mn / (mx - mn)
             v = d * scale + offset
         return np.stack([v, v, v, np.ones_like(v)], axis=0).astype(np.float32)

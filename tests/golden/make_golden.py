@@ -388,7 +388,7 @@ def generate():
         ("g1_c32l10_grid16r8_snakealt_density-direct", dict(C=32, L=10, activation="SnakeAlt:1", outputmode="density:direct", gc=16, gr=8)),
         ("g1_c32l10_grid16r32_relu_density-direct", dict(C=32, L=10, activation="ReLU", outputmode="density:direct", gc=16, gr=32)),
         ("g1_c32l16_grid16r8_relu_density-direct", dict(C=32, L=16, activation="ReLU", outputmode="density:direct", gc=16, gr=8)),
-        ("g1_c32l16_snakealt_density", dict(C=32, L=16, activation="SnakeAlt:1", outputmode="density", gain=2.15)),
+        ("g1_c32l16_snakealt_density", dict(C=32, L=16, activation="SnakeAlt:1", outputmode="density", gain=2.1)),
         ("g1_c32l22_relu_density-direct", dict(C=32, L=22, activation="ReLU", outputmode="density:direct")),
         ("g1_c32l22_grid16r8_relu_density-direct", dict(C=32, L=22, activation="ReLU", outputmode="density:direct", gc=16, gr=8)),
         ("g1_c32l22_grid16r8_snakealt_rgbo", dict(C=32, L=22, activation="SnakeAlt:1", outputmode="rgbo", gc=16, gr=8, gain=1.98)),

@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 import util
 from fvsrn_amd import capi
 
@@ -63,9 +65,28 @@ def test_built_kernels_keep_the_dot_hazard_distance_and_have_no_bad_packed_fp32_
     objs = sorted(glob.glob(os.path.join(util.ROOT, "fv-srn_amd", "csrc", "build", "*.o")))
     if not objs:
         pytest.skip("no object files (the library was built elsewhere)")
-    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tools", "check_isa.py"), "-j", "6"] + objs, capture_output=True, text=True, timeout=1200)
+    # r05: without arguments the scan covers everything with device code that a GPU box can load -- the objects, the linked libfvsrn.so (every code object in
+    # it must be one of the scanned objects, byte for byte), the aggressor helper, the microbenchmark binaries -- holds the pyrenderer extension to "no device
+    # code at all", and fails on any other .o / .so below fv-srn_amd/ or tools/dev/bin/
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tools", "check_isa.py"), "-j", "6"], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert "kernels_small_render.o" in r.stdout and "kernels_cd8_shaded.o" in r.stdout
+    assert "code objects, 0 of them NOT from the scanned objects" in r.stdout and "host-only extension: no device code" in r.stdout
+
+
+def test_isa_scan_refuses_binaries_outside_the_checked_build(tmp_path):
+    """A translation unit built next to the Makefile (hipcc directly, no erratum pass) and dropped into the package must fail the scan by its presence."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(util.ROOT, "tools", "check_isa.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    stray = os.path.join(util.ROOT, "fv-srn_amd", "stray_kernel_test_%d.o" % os.getpid())
+    try:
+        open(stray, "wb").write(b"\x7fELF")
+        assert stray in m.default_targets()[5]
+    finally:
+        os.remove(stray)
+    assert not m.default_targets()[5], m.default_targets()[5]
 
 
 def test_packed_fp32_rewrite_exchanges_sources_and_modifiers():

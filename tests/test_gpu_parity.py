@@ -52,10 +52,14 @@ def test_evaluate_points_golden(name):
     out_h = oracle.OracleNetwork(vn, oracle.ACC_HALF).evaluate(d["positions"], d.get("directions"))
     ref32, ref16 = expected_output(d, meta, "out_fp32"), expected_output(d, meta, "out_fp16")
     spread = np.abs(ref32 - ref16).max()
-    assert np.abs(out - out_f).max() < TOL_SAME_MODEL
-    # (r05, the 8 .. 22-layer fixtures: the stored fp16 activations of any fp16 evaluator are 1e-3 .. 3e-3 away from the fp32 pass, see tests/test_oracle_golden.py)
+    # (r05, the 8 .. 22-layer fixtures sit just below the gain at which the stack turns chaotic in its own roundings, tests/golden/make_golden.py G1h: every
+    # fp16 rounding of a stored activation is carried through up to 21 layers at gain ~1 -- the reference's own fp32 and fp16 passes differ by 1e-3 .. 4.6e-3
+    # there, the oracle's fp32-accumulate model is 0.8e-3 .. 3e-3 from the fp32 pass (tests/test_oracle_golden.py), and two evaluators that order their fp32 sums
+    # differently are held to that spread, not to the bar of the shallow fixtures)
     deep = len(meta["layers"].split(":")) + 1 >= 8
-    assert np.abs(out - ref32).max() < (max(TOL_SAME_MODEL, 1.5 * spread) if deep else TOL_SAME_MODEL)
+    same = max(TOL_SAME_MODEL, 1.5 * spread) if deep else TOL_SAME_MODEL
+    assert np.abs(out - out_f).max() < same
+    assert np.abs(out - ref32).max() < same
     # (fp16-accumulate models at 96 / 128 channels: 1.5e-2, see tests/test_oracle_golden.py)
     bar = 1.5e-2 if int(meta["layers"].split(":")[0]) > 64 else TOL_REF_BAR
     assert np.abs(out - ref16).max() < max(bar, 1.5 * spread)
@@ -1036,7 +1040,7 @@ def test_relu_scaled_image_at_the_exponent_guard(C, layers, grid):
             assert np.abs(plain - img[:4]).max() < 1e-3, np.abs(plain - img[:4]).max()
         pos = torch.rand(4096, 3, device="cuda", generator=torch.Generator("cuda").manual_seed(4)) - 0.5
         out = net.evaluate(pos, world=True).cpu().numpy()
-        ref_e = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos.cpu().numpy() + 0.5)
+        ref_e = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos.cpu().numpy())  # (world positions: the oracle applies the box like world=True)
         assert np.abs(out - ref_e.reshape(out.shape)).max() < TOL_SAME_MODEL
 
 

@@ -345,6 +345,157 @@ def test_rccl_route_runs_on_one_gpu_with_a_one_rank_group(config):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--gather", "root"], ["--gather", "root", "--payload", "rgba8", "--frames-per-submit", "4"], ["--payload", "rgba8"],
+                                   ["--frames-per-submit", "3"]])
+def test_rccl_route_gather_to_root_rgba8_payload_and_batches_on_one_gpu(extra):
+    """r05: the other forms of the exchange with the REAL backend (RCCL, one-rank group): dist.gather to rank 0, packed RGBA8 words (ExtractColor before
+    the collective; with a batch: inside fvsrn_render_stripes_batch), K frames per library call and collective.  bench.py checks the last frame against a
+    whole-frame render -- bitwise for the planes, word for word for RGBA8 -- and reports the host time per frame."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="29548")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FVSRN_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "1", "--force-collective", "--steps", "8", "--warmup", "1", "--spinup-ms", "0",
+                        "--no-twin", "--no-cpu-baseline", "--config", "c32l4_fourier_512x256"] + extra, capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    line = json.loads(lines[-1])
+    assert line["backend"] == "nccl" and line["gathered_frame_matches_single_gpu_frame"] is True
+    assert line["gather"] == ("root" if "root" in extra else "all") and line["payload"] == ("rgba8" if "rgba8" in extra else "planes")
+    assert line["per_rank"][0]["host_us_per_frame"] > 0 and line["per_rank"][0]["gather_ms"] > 0
+    assert line["collective_bytes_per_frame_and_rank"] == (4 if "rgba8" in extra else 32) * 512 * 512
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,rank", [(1, 0), (4, 1)])
+@pytest.mark.parametrize("grid,keys", [(None, 1), ((16, 8), 4)])
+def test_batch_render_equals_frame_by_frame_renders(world, rank, grid, keys):
+    """fvsrn_render_stripes_batch: K camera poses (and times) in one call, on one lane and on two (two scenes on two streams), are bit for bit the frames
+    fvsrn_render / fvsrn_render_stripes give one by one; the RGBA8 copy of every frame is fvsrn_extract_color_rgba8 of its planes."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode="density", grid=grid, seed=61, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4,
+                             time_grids=keys)
+    blob = volnet_io.save_volnet(vn)
+    net, serial = capi.Network.from_volnet(blob), capi.Network.from_volnet(blob)
+    W, H, stripe, K = 72, 64, 8, 5
+    kws = [_scene_kw(0.4 + 0.9 * i) for i in range(K)]
+    times = [0.3 + 0.55 * i for i in range(K)] if keys > 1 else None
+    ref, ref8 = [], []
+    scene = capi.Scene(**kws[0])
+    for i, kw in enumerate(kws):
+        scene.update(**kw)
+        if times:
+            serial.set_time_and_ensemble(times[i], 0)
+        img = scene.render(serial, W, H)[0] if world == 1 else capi.render_stripes(scene, serial, W, H, stripe, rank, world)
+        ref.append(img.clone())
+        ref8.append(capi.extract_color_part(img, capi.CHANNEL_COLOR, True, 1.5))
+        torch.cuda.synchronize()
+    cams = np.stack([np.concatenate([kw["eye"], kw["right"], kw["up"]]) for kw in kws])
+    for lanes in (1, 2):
+        scenes = [capi.Scene(**kws[0]) for _ in range(lanes)]
+        streams = [torch.cuda.Stream() for _ in range(lanes)]
+        rows = H if world == 1 else capi.stripe_rows(H, stripe, rank, world)
+        rgba = torch.zeros((K, rows, W), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        out = capi.render_stripes_batch(scenes, [st.cuda_stream for st in streams], net, W, H, stripe, rank, world, cams, times=times, rgba8=rgba,
+                                        use_tonemapping=True, max_exposure=1.5)
+        torch.cuda.synchronize()
+        for i in range(K):
+            assert torch.equal(torch.nan_to_num(out[i], nan=-7.0), torch.nan_to_num(ref[i], nan=-7.0)), (lanes, i)
+            assert torch.equal(rgba[i], ref8[i]), (lanes, i)
+        assert float(out[:, 3].max()) > 0.05
+    with pytest.raises(capi.FvsrnError):  # one scene on two streams
+        capi.render_stripes_batch([scenes[0], scenes[0]], [s.cuda_stream for s in (torch.cuda.Stream(), torch.cuda.Stream())], net, W, H, stripe, rank, world, cams)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["depth", "depth_with_empty_pixels", "color", "normal"])
+def test_extract_color_of_image_parts_with_a_merged_depth_range(mode):
+    """ExtractColor on the stripes of a frame before they travel (payload "rgba8"): the parts of an image, each converted on its own with the depth range
+    merged over the parts (fvsrn_depth_range: {-min, max, nan flag}, element-wise maximum = the all-reduce of tiles.StripeRenderer), equal the conversion
+    of the whole image -- RGBA8 words and fp32 planes, bitwise; a NaN depth in any part poisons all of them like the reference's min() / max()."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="densitygrad", seed=62, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    W, H = 96, 64
+    img = capi.Scene(**_scene_kw(0.9, tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)).render(net, W, H).clone()
+    if mode == "depth":
+        img[0, 7] = torch.nan_to_num(img[0, 7], nan=5.0)
+    ch = {"depth": capi.CHANNEL_DEPTH, "depth_with_empty_pixels": capi.CHANNEL_DEPTH, "color": capi.CHANNEL_COLOR, "normal": capi.CHANNEL_NORMAL}[mode]
+    whole8 = capi.extract_color(img, ch, mode == "color", 2.0, rgba8=True)
+    whole4 = capi.extract_color(img, ch, mode == "color", 2.0)[0]
+    parts = [img[0, :, :24].contiguous(), img[0, :, 24:40].contiguous(), img[0, :, 40:].contiguous()]
+    r3 = torch.stack([capi.depth_range(p) for p in parts]).max(dim=0).values
+    full_r3 = capi.depth_range(img)
+    assert torch.equal(r3, full_r3)
+    if mode == "depth_with_empty_pixels":
+        assert float(r3[2]) == 1.0  # (rays that miss the box: alpha 0, depth NaN)
+    else:
+        assert float(r3[2]) == 0.0 or ch != capi.CHANNEL_DEPTH
+    got8 = torch.cat([capi.extract_color_part(p, ch, mode == "color", 2.0, rgba8=True, depth_range3=r3) for p in parts], dim=0)
+    got4 = torch.cat([capi.extract_color_part(p, ch, mode == "color", 2.0, rgba8=False, depth_range3=r3) for p in parts], dim=1)
+    torch.cuda.synchronize()
+    assert torch.equal(got8, whole8)
+    assert torch.equal(torch.nan_to_num(got4, nan=-7.0), torch.nan_to_num(whole4, nan=-7.0))
+    if mode == "depth":
+        assert len(torch.unique(whole8)) > 16
+    # the restatement of the merged form
+    ref_r3 = np.max(np.stack([oracle.depth_range(p.cpu().numpy()) for p in parts]), axis=0)
+    assert np.array_equal(ref_r3, r3.cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_cell_tables_are_built_by_the_launches_that_use_them():
+    """the cell tables of a latent grid are built lazily.  A time-animated network whose launches take the gathers (small image: footprint
+    rule) allocates and builds none; the first launch through the table builds it; from then on a time change rebuilds it with the blend; a shaded launch
+    builds the plain-image table on its own; a launch that gathers again stops the rebuilds."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density", grid=(16, 8), seed=63, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4, time_grids=4)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    kw = _scene_kw(0.7)
+    small, large = capi.Scene(**kw), capi.Scene(**kw)
+    t = [0.2]
+
+    def step(scene, size):
+        t[0] += 0.3
+        net.set_time_and_ensemble(t[0], 0)
+        img = scene.render(net, size, size)
+        torch.cuda.synchronize()
+        return img, scene.last_render_info()["cell_table"], net.cell_table_stats()
+
+    for _ in range(3):
+        _, used, st = step(small, 64)
+        assert not used and st["table_bytes"] > 0 and st["builds"] == 0 and st["builds_plain"] == 0 and st["resident_bytes"] == 0, st
+    img_c, used, st = step(large, 512)
+    assert used and st["builds"] == 1 and st["builds_plain"] == 0 and st["resident_bytes"] == st["table_bytes"], st
+    for i in range(3):  # (two working grids: the second one's buffer appears with the next blend)
+        _, used, st = step(large, 512)
+        assert used and st["builds"] == 2 + i and st["builds_plain"] == 0, st
+    assert st["resident_bytes"] == 2 * st["table_bytes"]
+    before = st["builds"]
+    for _ in range(2):
+        _, used, st = step(small, 64)
+        assert not used
+    assert st["builds"] <= before + 1, st  # (the blend of the first gathering frame still saw the flag of the frame before)
+    # same picture either way (and against the forced gather path)
+    net.set_time_and_ensemble(1.3, 0)
+    a = capi.Scene(**kw).render(net, 512, 512).clone()
+    b = capi.Scene(**kw).set_option("cell_table", 0).render(net, 512, 512)
+    assert float((torch.nan_to_num(a[0, :4]) - torch.nan_to_num(b[0, :4])).abs().max()) < 1e-3
+    # a shaded render (the plain weight image): its own table, built by that launch
+    shaded = capi.Scene(**dict(kw, gradient_mode=capi.GRADIENT_FINITE_DIFFERENCES, finite_differences_stepsize=0.01, brdf=dict(enable_phong=True, ambient=0.2, specular=0.3)))
+    shaded.render(net, 512, 512)
+    torch.cuda.synchronize()
+    st2 = net.cell_table_stats()
+    assert shaded.last_render_info()["cell_table"] and st2["builds_plain"] == 1, st2
+
+
+@pytest.mark.gpu
 def test_stream_concurrency_probe_and_the_shared_queue_warning():
     """fvsrn_probe_stream_concurrency measures what the process got (n fresh streams on q hardware queues run n / ceil(n / q)-wide), and
     StripeRenderer measures ITS streams: in a child limited to two hardware queues the collective's stream shares one with a render stream --

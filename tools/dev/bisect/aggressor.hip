@@ -3,7 +3,7 @@
 // SIMD and not with two (profiles/r04/nondeterminism_r04.md); with the kernel under test held at one wave per SIMD and these as its
 // neighbours, the class of the neighbour's instruction that disturbs it can be read off.  Each wave keeps ~72 VGPRs live so that two
 // aggressor waves + ONE wave of the kernel under test (224 registers) fill a SIMD's 512 and a second victim wave does not fit.
-// build: hipcc --offload-arch=gfx950 -O2 -shared -fPIC -o tools/dev/bin/libaggressor.so tools/dev/bisect/aggressor.hip
+// build: __graft_entry__.build() (fv-srn_amd/csrc/hipcc_fixed.sh + link -> tools/dev/bin/libaggressor.so)
 #include <hip/hip_runtime.h>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));

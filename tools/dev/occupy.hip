@@ -1,6 +1,6 @@
 // Developer tool: a kernel that holds `blocks` workgroups of `threads` threads for `microseconds` on a stream -- a stand-in for the
 // collective of another rank's frame when a rank's frame pipeline is timed on one GPU (tools/stripe_efficiency.py,
-// FVSRN_STRIPE_EMULATE_GATHER=blocks,threads,microseconds).  build: hipcc --offload-arch=gfx950 -O2 -shared -fPIC -o tools/dev/bin/liboccupy.so tools/dev/occupy.hip
+// FVSRN_STRIPE_EMULATE_GATHER=blocks,threads,microseconds).  build: __graft_entry__.build() (through fv-srn_amd/csrc/hipcc_fixed.sh -> tools/dev/bin/liboccupy.so)
 #include <hip/hip_runtime.h>
 
 __global__ void occupy_kernel(long long ticks, unsigned* sink) {
