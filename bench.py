@@ -61,23 +61,37 @@ CONFIGS = {
 TIME_KEYS = {"c64l6_grid16_time16_1024x512": 16}
 
 
+# Variants of a workload off the headline's happy path (every kernel family gets a bench line and a profile), set by main() from the command
+# line: camera distance (a close-up trips the footprint rule of the cell table), gradient mode + Phong shading (render_shaded_kernel / render_adjoint_kernel).
+VARIANT = {"distance": 1.6, "gradient_mode": 0}
+
+
 def build_scene_kwargs(capi, yaw, stepsize, early_out):
-    eye, right, up = capi.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, yaw, 1.6)
-    return dict(eye=eye, right=right, up=up, fov_y_radians=float(np.deg2rad(45.0)), stepsize=stepsize,
-                early_out=early_out, tf_kind=capi.TF_IDENTITY, tf_scale_absorption=10.0, tf_scale_emission=1.0)
+    eye, right, up = capi.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, yaw, VARIANT["distance"])
+    kw = dict(eye=eye, right=right, up=up, fov_y_radians=float(np.deg2rad(45.0)), stepsize=stepsize,
+              early_out=early_out, tf_kind=capi.TF_IDENTITY, tf_scale_absorption=10.0, tf_scale_emission=1.0)
+    if VARIANT["gradient_mode"]:  # the shading of tools/bench_shaded.py: Phong, point light at the camera, finite-difference step 1 / 256
+        kw.update(gradient_mode=VARIANT["gradient_mode"], finite_differences_stepsize=1 / 256,
+                  brdf=dict(enable_phong=True, ambient=0.2, specular=0.4, magnitude_center=0.6, magnitude_radius=0.5, specular_exponent=8, light_type=0,
+                            light=tuple(float(v) for v in eye)))
+    return kw
 
 
-def bench_network(C, layers, grid, activation, time_keys=1):
+GRID_ENCODINGS = {"float": 0, "byte_linear": 1, "byte_gaussian": 2}  # volnet_io.ENC_*
+
+
+def bench_network(C, layers, grid, activation, time_keys=1, encoding="float"):
     """The synthetic network of a workload: seed 1234, nn.Linear-style init, NeRF ladder, density:direct,
     latent grid randn * 0.01.  tests/test_gpu_parity.py renders the same networks against the oracle."""
     from fvsrn_amd import synthetic
     return synthetic.random_network(C=C, layers=layers, activation=activation, param=1.0, output_mode="density:direct",
-                                    grid=grid, seed=1234, box_min=(-0.5, -0.5, -0.5), grid_scale=0.01, time_grids=time_keys)
+                                    grid=grid, seed=1234, box_min=(-0.5, -0.5, -0.5), grid_scale=0.01, time_grids=time_keys,
+                                    encoding=GRID_ENCODINGS[encoding])
 
 
 def make_network(volnet_io, capi, cfg, activation, time_keys=1):
     C, layers, grid, *_ = cfg
-    vn = bench_network(C, layers, grid, activation, time_keys)
+    vn = bench_network(C, layers, grid, activation, time_keys, VARIANT.get("encoding", "float"))
     return vn, capi.Network.from_volnet(volnet_io.save_volnet(vn))
 
 
@@ -395,12 +409,20 @@ def main():
     ap.add_argument("--payload", default="planes", choices=["planes", "rgba8"],
                     help="N > 1 / --force-collective: what travels -- the eight fp32 planes of ImageEvaluatorSimple::render, or ExtractColor'ed RGBA8 words (4 B / pixel)")
     ap.add_argument("--frames-per-submit", type=int, default=1, help="K camera poses per call into the library and per collective (fvsrn_render_stripes_batch)")
+    ap.add_argument("--grid-encoding", default="float", choices=sorted(GRID_ENCODINGS), help="latent-grid encoding of the synthetic network (LatentGrid::Encoding)")
+    ap.add_argument("--camera-distance", type=float, default=1.6, help="CameraOnASphere distance (1.6: the headline; 0.8: a close-up that trips the cell table's footprint rule)")
+    ap.add_argument("--gradient-mode", default="off", choices=["off", "finite_differences", "adjoint"], help="shaded render: Phong BRDF with normals by this mode")
     ap.add_argument("--grid-volume", action="store_true",
                     help="side benchmark (not the headline metric): DVR of a dense grid volume, BASELINE.json configs[0]; one JSON line")
     ap.add_argument("--grid-res", type=int, default=256)
     ap.add_argument("--grid-size", type=int, default=256)
     ap.add_argument("--grid-interpolation", type=int, default=1, help="0 nearest, 1 trilinear, 2 tricubic")
     args = ap.parse_args()
+    VARIANT.update(distance=args.camera_distance, gradient_mode={"off": 0, "finite_differences": 1, "adjoint": 2}[args.gradient_mode], encoding=args.grid_encoding)
+    variant_tag = "".join(["_" + args.grid_encoding if args.grid_encoding != "float" else "", "_closeup" if args.camera_distance != 1.6 else "",
+                           "_" + args.gradient_mode if args.gradient_mode != "off" else ""])
+    if variant_tag:
+        args.no_twin = True  # (the twin / exact-features lines belong to the headline shape)
     if args.grid_volume:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the HIP kernels have no CPU fallback")
@@ -498,7 +520,8 @@ def main():
         frame_check = bool(ok.item())
 
     def tag_of(activation):  # the name tools/pmc_profile.sh files the PMC summary of (config, activation) under
-        return args.config if activation == "ReLU" else args.config.replace("_1024x512", "_%s_1024x512" % activation.lower())
+        base = args.config if activation == "ReLU" else args.config.replace("_1024x512", "_%s_1024x512" % activation.lower())
+        return base + variant_tag
 
     twin = None
     if not args.no_twin and not collective:
@@ -559,6 +582,10 @@ def main():
                                                      args.activation, "on" if args.early_out else "off"),
                        "parallelism": "1 GPU" if world == 1 else "%d GPUs, round-robin %d-row stripes + RCCL %s of %s" % (
                            world, STRIPE, "all-gather" if args.gather == "all" else "gather to rank 0", "8 fp32 planes" if args.payload == "planes" else "RGBA8 words")},
+            "variant": {"grid_encoding": args.grid_encoding, "camera_distance": args.camera_distance, "gradient_mode": args.gradient_mode,
+                        # network evaluations behind one counted sample: 7 with finite differences, value + 3 tangent tiles in the adjoint pass (roofline.achieved
+                        # stays the algorithmic FLOP of ONE evaluation per sample: the line's frac is comparable with the unshaded one, not a utilisation)
+                        "network_evaluations_per_sample": {"off": 1, "finite_differences": 7, "adjoint": 4}[args.gradient_mode]} if variant_tag else None,
             "frames_per_s": args.steps / dt,
             "evaluated_samples_per_frame": evaluated / args.steps,
             "nominal_samples_per_frame": W * H * steps,

@@ -685,7 +685,7 @@ struct fvsrn_scene {
         dTf.release(); dOrder.release(); dCounters.release(); dPartial.release(); dPreint.release();
     }
     // what the last launch of this scene was, for fvsrn_debug_state: written under `mu` by renderImpl
-    struct LastLaunch { unsigned grid = 0, block = 0; long long units = 0; int width = 0, height = 0, rows = 0, stripeWorld = 1, persistent = 0; void* stream = nullptr; unsigned long long count = 0; } lastLaunch;
+    struct LastLaunch { unsigned grid = 0, block = 0; long long units = 0; int width = 0, height = 0, rows = 0, stripeWorld = 1, persistent = 0, frames = 1; void* stream = nullptr; unsigned long long count = 0; } lastLaunch;
 
     // TF table (and, for pre-integrated Texture TFs, its tables) on the device, for step size `stepsize`
     int uploadTf(float stepsize, hipStream_t s) {
@@ -1098,7 +1098,7 @@ int fvsrn_debug_state(char* buf, size_t cap) {
             const fvsrn_scene::LastLaunch& L = sc->lastLaunch;
             out += "launches " + std::to_string(L.count) + ", last kernel '" + sc->lastKernel + "' grid " + std::to_string(L.grid) + " x " + std::to_string(L.block) +
                    ", units " + std::to_string(L.units) + ", image " + std::to_string(L.width) + " x " + std::to_string(L.height) + " (" + std::to_string(L.rows) +
-                   " rows, world " + std::to_string(L.stripeWorld) + "), " + (L.persistent == 1 ? "persistent" : (L.persistent == 2 ? "bounded waves" : "one unit per wave")) +
+                   " rows, world " + std::to_string(L.stripeWorld) + "), frames " + std::to_string(L.frames) + ", " + (L.persistent == 1 ? "persistent" : (L.persistent == 2 ? "bounded waves" : "one unit per wave")) +
                    ", segments " + std::to_string(sc->lastInfo[0]) + ", waves/workgroup " + std::to_string(sc->lastInfo[3]);
             if (L.count) out += std::string(", stream ") + (hipStreamQuery(static_cast<hipStream_t>(L.stream)) == hipSuccess ? "idle" : "BUSY");
             (void)hipGetLastError();
@@ -1485,6 +1485,8 @@ static void fillSceneParams(fvsrn_scene* scene, const fvsrn_scene_desc& d, int w
     S.front[0] = S.up[1] * S.right[2] - S.up[2] * S.right[1];
     S.front[1] = S.up[2] * S.right[0] - S.up[0] * S.right[2];
     S.front[2] = S.up[0] * S.right[1] - S.up[1] * S.right[0];
+    S.frames = 1;  // (render_body reads the camera from cams[]: device_params.hpp)
+    for (int i = 0; i < 3; ++i) { S.cams[0][i] = S.eye[i]; S.cams[0][3 + i] = S.right[i]; S.cams[0][6 + i] = S.up[i]; S.cams[0][9 + i] = S.front[i]; }
     S.tanFovY = std::tan(d.fov_y_radians / 2);
     S.tanFovX = S.tanFovY * (float(width) / float(height));  // setAspectRatio, image_evaluator_simple.cpp:204
     S.stepsize = d.stepsize;
@@ -1518,9 +1520,11 @@ static void fillSceneParams(fvsrn_scene* scene, const fvsrn_scene_desc& d, int w
     S.tfPreintegrated = static_cast<const float*>(scene->dPreint.ptr);
 }
 
+// frames / cameras9: > 1 camera poses { eye, right, up } of the same scene rendered by ONE launch into d_out8 + f * 8 * plane (at most
+// kMaxFramesPerLaunch; fvsrn_render_stripes_batch); 1 / nullptr: the scene's own camera
 static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int height, int y0, int y1, int numLocalRows,
                       int stripeRows, int stripeRank, int stripeWorld, int compact, float* d_out8,
-                      unsigned long long* d_stats, void* stream) {
+                      unsigned long long* d_stats, void* stream, int frames = 1, const float* cameras9 = nullptr) {
     return guarded([&] {
         if (!scene || !net || !d_out8) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
         if (width <= 0 || height <= 0 || y0 < 0 || y1 > height || y0 > y1)
@@ -1561,6 +1565,19 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             if (rgbo) S.gradientMode = FVSRN_GRADIENT_OFF_OR_DIRECT;
             // latentGridDifferencesStepSize of the adjoint mode (VolumeInterpolationNetwork::fillConstantMemory :1808-1812)
             if (S.gridDiffStep <= 0.f) S.gridDiffStep = 1.0f / (float(std::max(1, a.P.gridX)) * 4.0f);
+            if (frames > 1) {
+                if (frames > kMaxFramesPerLaunch || !cameras9) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad frame count of a multi-frame launch");
+                S.frames = frames;
+                for (int f = 0; f < frames; ++f) {
+                    const float* c = cameras9 + size_t(f) * 9;  // eye, right, up; front = cross(up, right) like fillSceneParams
+                    float* o = S.cams[f];
+                    for (int i = 0; i < 9; ++i) o[i] = c[i];
+                    o[9] = c[7] * c[5] - c[8] * c[4];
+                    o[10] = c[8] * c[3] - c[6] * c[5];
+                    o[11] = c[6] * c[4] - c[7] * c[3];
+                }
+                for (int i = 0; i < 3; ++i) { S.eye[i] = S.cams[0][i]; S.right[i] = S.cams[0][3 + i]; S.up[i] = S.cams[0][6 + i]; S.front[i] = S.cams[0][9 + i]; }
+            }
             S.width = width; S.height = height; S.y0 = y0; S.y1 = y1;
             S.numLocalRows = numLocalRows; S.stripeRows = stripeRows; S.stripeRank = stripeRank;
             S.stripeWorld = stripeWorld; S.compact = compact;
@@ -1663,8 +1680,9 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 const double maxSteps = std::sqrt(double(bs[0]) * bs[0] + double(bs[1]) * bs[1] + double(bs[2]) * bs[2]) / d.stepsize;
                 // (a pre-integrated TF looks at the previous sample of the ray: no cuts)
                 const bool looksBack = d.tf_preintegration != FVSRN_PREINTEGRATE_NONE || d.tf_gaussian_mode == FVSRN_TF_GAUSSIAN_ANALYTIC;
-                while (!looksBack && K < 8 && double(tiles) * K < 4.0 * waves && maxSteps / (2 * K) >= 48.0) K *= 2;
+                while (!looksBack && K < 8 && double(tiles) * frames * K < 4.0 * waves && maxSteps / (2 * K) >= 48.0) K *= 2;
                 if (O[FVSRN_OPT_DEPTH_SEGMENTS] >= 1 && !looksBack) K = O[FVSRN_OPT_DEPTH_SEGMENTS];
+                if (frames > 1) K = 1;  // (a multi-frame launch: the frames are the extra work units; the composite pass handles one image)
             }
             // FVSRN_OPT_FOURIER_RESYNC: 1 = exact Fourier features at every step (the reference's arithmetic), default every 64 steps
             S.resyncMask = (O[FVSRN_OPT_FOURIER_RESYNC] ? O[FVSRN_OPT_FOURIER_RESYNC] : kFourierResync) - 1;
@@ -1675,7 +1693,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 scene->dPartial.ensure(size_t(K) * 8 * plane * sizeof(float));
                 S.partial = static_cast<float*>(scene->dPartial.ptr);
             }
-            const long long units = (long long)tiles * K;
+            const long long units = (long long)tiles * K * frames;
             unsigned grid = unsigned((units + wpb - 1) / wpb);
             // persistent waves: no more workgroups than the chip holds at once; the rest of the units is handed out by
             // a device counter (kernels.hpp).  FVSRN_PERSISTENT=0: one unit per wave, hardware dispatch order.
@@ -1719,12 +1737,13 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             // Gsamples/s, r01).  Without them (FVSRN_PERSISTENT=0, or a launch that fits on the chip at once) centre-first
             // starts the long rays first, which pays whenever a workgroup holds several waves or waits on memory.
             const bool useOrder = O[FVSRN_OPT_TILE_ORDER] >= 0 ? O[FVSRN_OPT_TILE_ORDER] == 1 : (S.tileCounter == nullptr && (wpb > 1 || net->key.grid != 0));
-            S.tileOrder = useOrder ? scene->tileOrder(S, P_boxCenter(a.P), tilesX, tilesY, s) : nullptr;
+            S.tileOrder = useOrder && frames == 1 ? scene->tileOrder(S, P_boxCenter(a.P), tilesX, tilesY, s) : nullptr;  // (the order is one camera's)
             // what this launch does to the samples of a ray, for callers that restate it (fvsrn_scene_last_render_info)
             const bool rotates = net->keyScaled.CD == 2 && (net->keyScaled.grid == 0 || (FVSRN_ROTATE_SGRID && smallFn && smallGrid == 1) || (smallFn && smallGrid == 2)) && !a.P.noFourier &&
                                  !a.shaded;  // kRotate / kRotateLds, kernels.hpp
             scene->lastLaunch.grid = grid; scene->lastLaunch.block = unsigned(64 * wpb); scene->lastLaunch.units = units; scene->lastLaunch.width = width;
             scene->lastLaunch.height = height; scene->lastLaunch.rows = numLocalRows; scene->lastLaunch.stripeWorld = stripeWorld;
+            scene->lastLaunch.frames = frames;
             scene->lastLaunch.persistent = S.tileCounter ? (S.unitQuota > 0 ? 2 : 1) : 0; scene->lastLaunch.stream = stream; ++scene->lastLaunch.count;
             scene->lastInfo[0] = K;
             scene->lastInfo[1] = rotates ? S.resyncMask + 1 : 0;
@@ -1919,28 +1938,36 @@ int fvsrn_render_stripes_batch(fvsrn_scene* const* scenes, void* const* streams,
     if (use_tonemapping && !(max_exposure > 0)) return fail(FVSRN_ERR_INVALID_ARGUMENT, "max_exposure must be positive");
     const int rows = world == 1 ? height : fvsrn_stripe_rows(height, stripe_rows, rank, world);
     const size_t planes = size_t(8) * size_t(std::max(rows, 0)) * size_t(std::max(width, 0));
-    for (int f = 0; f < frames; ++f) {
-        fvsrn_scene* sc = scenes[f % lanes];
-        void* st = streams[f % lanes];
+    // Frames that share their time go into ONE launch per lane, up to kMaxFramesPerLaunch poses each (device_params.hpp: a work unit is (frame, tile));
+    // lanes take consecutive groups in turn, so with two lanes the tail of one group's launch overlaps the head of the next.  Per-frame times: one
+    // launch per frame (every frame blends its own working grid), lane f % lanes.
+    const int group = times ? 1 : std::min(kMaxFramesPerLaunch, std::max(1, (frames + lanes - 1) / lanes));
+    int lane = 0;
+    for (int f0 = 0; f0 < frames; f0 += group, lane = (lane + 1) % lanes) {
+        const int n = std::min(group, frames - f0);
+        fvsrn_scene* sc = scenes[lane];
+        void* st = streams[lane];
         {
             std::lock_guard<std::mutex> lock(sc->mu);
-            std::memcpy(sc->desc.cam_eye, cameras9 + size_t(f) * 9, 3 * sizeof(float));
-            std::memcpy(sc->desc.cam_right, cameras9 + size_t(f) * 9 + 3, 3 * sizeof(float));
-            std::memcpy(sc->desc.cam_up, cameras9 + size_t(f) * 9 + 6, 3 * sizeof(float));
+            std::memcpy(sc->desc.cam_eye, cameras9 + size_t(f0) * 9, 3 * sizeof(float));
+            std::memcpy(sc->desc.cam_right, cameras9 + size_t(f0) * 9 + 3, 3 * sizeof(float));
+            std::memcpy(sc->desc.cam_up, cameras9 + size_t(f0) * 9 + 6, 3 * sizeof(float));
         }
         if (times) {
             std::lock_guard<std::mutex> lock(net->mu);
-            net->net->setTimeAndEnsemble(times[f], net->net->currentEnsemble);
+            net->net->setTimeAndEnsemble(times[f0], net->net->currentEnsemble);
             net->timeDirty = true;
         }
-        float* out = d_out_local + size_t(f) * planes;
-        const int rc = world == 1 ? renderImpl(sc, net, width, height, 0, height, height, 8, 0, 1, 0, out, d_stats, st)
-                                  : renderImpl(sc, net, width, height, 0, height, rows, stripe_rows, rank, world, 1, out, d_stats, st);
+        float* out = d_out_local + size_t(f0) * planes;
+        const int rc = world == 1 ? renderImpl(sc, net, width, height, 0, height, height, 8, 0, 1, 0, out, d_stats, st, n, cameras9 + size_t(f0) * 9)
+                                  : renderImpl(sc, net, width, height, 0, height, rows, stripe_rows, rank, world, 1, out, d_stats, st, n, cameras9 + size_t(f0) * 9);
         if (rc != FVSRN_OK) return rc;
-        if (d_rgba8 && rows > 0) {
-            const int rc2 = extractImpl(out, width, rows, FVSRN_CHANNEL_COLOR, use_tonemapping, max_exposure, nullptr, d_rgba8 + size_t(f) * size_t(rows) * size_t(width), st);
-            if (rc2 != FVSRN_OK) return rc2;
-        }
+        if (d_rgba8 && rows > 0)
+            for (int f = f0; f < f0 + n; ++f) {
+                const int rc2 = extractImpl(d_out_local + size_t(f) * planes, width, rows, FVSRN_CHANNEL_COLOR, use_tonemapping, max_exposure, nullptr,
+                                            d_rgba8 + size_t(f) * size_t(rows) * size_t(width), st);
+                if (rc2 != FVSRN_OK) return rc2;
+            }
     }
     return FVSRN_OK;
 }

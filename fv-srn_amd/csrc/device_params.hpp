@@ -85,6 +85,7 @@ struct NetParams {
     unsigned cellCount;   // (X - 1)(Y - 1)(Z - 1)
 };
 
+constexpr int kMaxFramesPerLaunch = 8;
 struct SceneParams {
     // camera (renderer_camera.cuh:33-52), front = cross(up,right) and tan(fov/2) precomputed on the host
     float eye[3], right[3], up[3], front[3];
@@ -131,6 +132,13 @@ struct SceneParams {
     int segments;
     float* partial;
     int resyncMask;  // feature rotation (srn_device.hpp): exact features every resyncMask + 1 steps (a power of two)
+    // Several frames in ONE launch (r05, fvsrn_render_stripes_batch): `frames` camera poses of the same scene; a work unit is (frame, tile[, segment]),
+    // frame f takes its camera from cams[f] = { eye, right, up, front } and writes its image at out + f * 8 * plane.  A rank's share of a multi-GPU frame
+    // is a small launch (2 048 tiles for 2 048 wave slots at world 8): its ramp-up, its longest tile and the gap to the next launch cost a fifth of
+    // the 0.26 ms; eight poses in one launch are a whole frame's worth of work units handed out by the same device counter.  frames <= 1: one frame, camera
+    // cams[0] (render_body reads the camera from cams[] only; eye / right / up / front above serve the other kernels and the host).
+    int frames;
+    float cams[kMaxFramesPerLaunch][12];
 };
 
 }  // namespace fvsrn

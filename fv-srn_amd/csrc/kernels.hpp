@@ -453,7 +453,9 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
 #else
     const int K = S.segments;
 #endif
-    const int numUnits = numTiles * K;
+    const int unitsPerFrame = numTiles * K;
+    const int numFrames = S.frames > 1 ? S.frames : 1;  // wave-uniform (device_params.hpp: several camera poses in one launch)
+    const int numUnits = unitsPerFrame * numFrames;
     ResidentNet<(NLC > 0 ? NLC : 1), (NLC > 0 && GRID == 1 ? (CELLS ? 2 : 1) : 0)> resident;
     if constexpr (NLC > 0) load_resident(P, lds, resident);
     // TAIL_SCALAR_TABLE: loop-invariant scalars
@@ -469,8 +471,11 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
         slot = __builtin_amdgcn_readfirstlane(first);
     }
     for (; slot < numUnits;) {
-    const int tileSlot = K > 1 ? slot / K : slot;
-    const int seg = slot - tileSlot * K;
+    int frame = 0, unit = slot;
+    if (numFrames > 1) { frame = slot / unitsPerFrame; unit = slot - frame * unitsPerFrame; }
+    const float* cam = S.cams[frame];  // eye, right, up, front (scalar loads; the host fills cams[0] for single frames too)
+    const int tileSlot = K > 1 ? unit / K : unit;
+    const int seg = unit - tileSlot * K;
     // launch slot -> pixel tile: the host orders tiles by expected ray length (centre of the projected box first), so
     // the long tiles start first and the empty ones fill the tail of the launch
     const int tile = S.tileOrder ? S.tileOrder[tileSlot] : tileSlot;
@@ -486,15 +491,15 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     // operation by operation, which makes the sample positions of the two bit-identical -- a network behind a 2^9 frequency ladder turns
     // one ulp of a position into a different fp16 rounding and that into percents of a colour.
     float dx, dy, dz, tmin, tmax, pn0x, pn0y, pn0z, dnx, dny, dnz;
-    const float ox = S.eye[0], oy = S.eye[1], oz = S.eye[2];
+    const float ox = cam[0], oy = cam[1], oz = cam[2];
     {
 #pragma clang fp contract(off)
         const float ndcx = 2.f * (float(x) + 0.5f) / float(S.width) - 1.f;
         const float ndcy = 2.f * (float(y) + 0.5f) / float(S.height) - 1.f;
         const float ax = ndcx * S.tanFovX, ay = ndcy * S.tanFovY;
-        dx = __builtin_fmaf(ay, S.up[0], __builtin_fmaf(ax, S.right[0], S.front[0]));
-        dy = __builtin_fmaf(ay, S.up[1], __builtin_fmaf(ax, S.right[1], S.front[1]));
-        dz = __builtin_fmaf(ay, S.up[2], __builtin_fmaf(ax, S.right[2], S.front[2]));
+        dx = __builtin_fmaf(ay, cam[6], __builtin_fmaf(ax, cam[3], cam[9]));
+        dy = __builtin_fmaf(ay, cam[7], __builtin_fmaf(ax, cam[4], cam[10]));
+        dz = __builtin_fmaf(ay, cam[8], __builtin_fmaf(ax, cam[5], cam[11]));
         const float invLen = 1.0f / __builtin_sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
         dx *= invLen; dy *= invLen; dz *= invLen;
         const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
@@ -835,13 +840,13 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     if (K > 1) {
         if (inImage) {  // raw accumulators of this segment; composite_kernel finishes the pixel
             const size_t plane = size_t(S.width) * (S.compact ? S.numLocalRows : S.height);
-            float* p = S.partial + size_t(seg) * 8 * plane + size_t(S.compact ? lrow : y) * S.width + x;
+            float* p = S.partial + (size_t(frame) * size_t(K) + size_t(seg)) * 8 * plane + size_t(S.compact ? lrow : y) * S.width + x;
             p[0] = cr; p[plane] = cg; p[2 * plane] = cb; p[3 * plane] = ca;
             p[4 * plane] = nx; p[5 * plane] = ny; p[6 * plane] = nz; p[7 * plane] = depth;
         }
     } else if (inImage) {  // renderer_image_evaluator_simple.cuh:100-124 with samples == 1
         const size_t plane = size_t(S.width) * (S.compact ? S.numLocalRows : S.height);
-        const size_t o = size_t(S.compact ? lrow : y) * S.width + x;
+        const size_t o = size_t(frame) * 8 * plane + size_t(S.compact ? lrow : y) * S.width + x;
         out[o] = cr;
         out[plane + o] = cg;
         out[2 * plane + o] = cb;

@@ -810,7 +810,31 @@ struct ImageEvaluatorSimple {
     fvsrn_scene* scene = nullptr;
     ~ImageEvaluatorSimple() { fvsrn_scene_destroy(scene); }
 
-    torch::Tensor render(int width, int height) {  // image_evaluator_simple.cpp:198-361
+    torch::Tensor render(int width, int height) { return renderRows(width, height, -1, 1, 16); }  // image_evaluator_simple.cpp:198-361
+
+    // Multi-GPU frames behind the module API (no reference counterpart: its render() owns the whole frame on one device).  Rank `rank`
+    // of `world` renders the image rows y with (y / stripe) % world == rank -- round-robin stripes balance empty and dense image regions -- of the SAME
+    // scene (camera, TF, network: every rank holds a copy) into a compact (B, 8, rows, W) tensor, rows = ImageEvaluatorSimple.stripe_rows(...).  The
+    // caller moves the compact tensors with the collective of its choice (torch.distributed all_gather_into_tensor / gather over RCCL) and puts them
+    // back in image order with ImageEvaluatorSimple.Assemble_stripes; fv-srn_amd/tiles.py StripeRenderer is that pipeline ready-made.
+    torch::Tensor renderStripes(int width, int height, int rank, int world, int stripe) {
+        if (world < 1 || rank < 0 || rank >= world) raise("render_stripes: 0 <= rank < world");
+        if (stripe <= 0 || stripe % 8 != 0) raise("render_stripes: stripe must be a positive multiple of 8 (the pixel tile of one wave)");
+        if (!std::dynamic_pointer_cast<VolumeInterpolationNetwork>(volume)) raise("render_stripes needs a VolumeInterpolationNetwork (grid volumes render whole frames)");
+        return renderRows(width, height, rank, world, stripe);
+    }
+    static int stripeRows(int height, int stripe, int rank, int world) { return fvsrn_stripe_rows(height, stripe, rank, world); }
+    // (world, B, 8, rows, W) compact stripe images of all ranks (the layout all_gather_into_tensor / gather produce) -> (B, 8, H, W)
+    static torch::Tensor assembleStripes(const torch::Tensor& gathered, int height, int stripe) {
+        TORCH_CHECK(gathered.dim() == 5 && gathered.size(2) == 8, "gathered must be of shape (world, B, 8, rows, W)");
+        const int64_t world = gathered.size(0), B = gathered.size(1), rows = gathered.size(3), W = gathered.size(4);
+        TORCH_CHECK(stripe > 0 && rows * world == height && height % (int64_t(stripe) * world) == 0,
+                    "height must be a multiple of stripe * world (every rank owns the same number of rows)");
+        return gathered.contiguous().view({world, B, 8, rows / stripe, stripe, W}).permute({1, 2, 3, 0, 4, 5}).reshape({B, 8, height, W});
+    }
+
+    // rank < 0: the whole frame; else this rank's stripes, compact
+    torch::Tensor renderRows(int width, int height, int rank, int world, int stripe) {
         auto vol = std::dynamic_pointer_cast<VolumeInterpolationNetwork>(volume);
         auto grid = std::dynamic_pointer_cast<VolumeInterpolationGrid>(volume);
         if (!vol && !grid) {
@@ -825,7 +849,8 @@ struct ImageEvaluatorSimple {
         camera->aspectRatio = double(width) / height;
         // computeBatchCount (iimage_evaluator.cpp:138-165): only the camera can carry a batch dimension here (TF / step-size tensors: B = 1)
         const int B = camera->batches();
-        torch::Tensor out = torch::empty({B, 8, height, width}, torch::TensorOptions().dtype(torch::kFloat).device(torch::kCUDA));
+        const int rows = rank < 0 ? height : fvsrn_stripe_rows(height, stripe, rank, world);
+        torch::Tensor out = torch::empty({B, 8, rows, width}, torch::TensorOptions().dtype(torch::kFloat).device(torch::kCUDA));
         for (int batch = 0; batch < B; ++batch) {
         fvsrn_scene_desc d{};
         std::vector<float> table;
@@ -878,14 +903,17 @@ struct ImageEvaluatorSimple {
         }
         if (!scene) check(fvsrn_scene_create(&d, &scene));
         else check(fvsrn_scene_update(scene, &d));
-        float* dst = out.data_ptr<float>() + size_t(batch) * 8 * size_t(height) * size_t(width);
-        if (vol)
+        float* dst = out.data_ptr<float>() + size_t(batch) * 8 * size_t(rows) * size_t(width);
+        if (vol && rank >= 0)
+            check(fvsrn_render_stripes(scene, vol->currentNetwork()->h, width, height, stripe, rank, world, dst, nullptr, currentStream()));
+        else if (vol)
             check(fvsrn_render(scene, vol->currentNetwork()->h, width, height, 0, height, dst, nullptr, currentStream()));
         else
             check(fvsrn_render_volume(scene, grid->handle(), grid->sourceMode(), grid->interpolation_, grid->newBehavior ? 1 : 0,
                                       selectedChannel == ChannelNormal ? 1 : 0 /* image_evaluator_simple.cpp:249-252 */, width, height,
                                       dst, nullptr, currentStream()));
         }  // batch
+        if (rank >= 0) return out;  // (a rank's stripes: exposure / refinement state belongs to whole frames)
         lastRender = out;
         exposureStale = true;
         refiningCounter = 0;
@@ -1622,6 +1650,11 @@ PYBIND11_MODULE(pyrenderer, m) {
         .def_readwrite("selected_channel", &ImageEvaluatorSimple::selectedChannel)
         .def_readwrite("double_precision", &ImageEvaluatorSimple::doublePrecision)
         .def("render", &ImageEvaluatorSimple::render, py::arg("width"), py::arg("height"))
+        .def("render_stripes", &ImageEvaluatorSimple::renderStripes, py::arg("width"), py::arg("height"), py::arg("rank"), py::arg("world"), py::arg("stripe") = 16,
+             "This rank's round-robin row stripes of the frame, compact: (B, 8, rows, W).  No reference counterpart (multi-GPU image tiles).")
+        .def_static("stripe_rows", &ImageEvaluatorSimple::stripeRows, py::arg("height"), py::arg("stripe"), py::arg("rank"), py::arg("world"))
+        .def_static("Assemble_stripes", &ImageEvaluatorSimple::assembleStripes, py::arg("gathered"), py::arg("height"), py::arg("stripe") = 16,
+                    "(world, B, 8, rows, W) compact stripe images of all ranks -> (B, 8, H, W)")
         .def("refine", &ImageEvaluatorSimple::refine, py::arg("width"), py::arg("height"), py::arg("previous"))
         .def("get_module_for_tag", &ImageEvaluatorSimple::moduleForTag, py::arg("tag"))
         .def("compute_batch_count", [](ImageEvaluatorSimple& e) { return e.camera ? e.camera->batches() : 1; })

@@ -382,10 +382,12 @@ class StripeRenderer:
                 self.render_done[b].record()
         else:
             import numpy as np
-            lanes = self.scenes if self.pipelined else self.scenes[:1]
-            streams = self.render_streams if self.pipelined else [torch.cuda.current_stream()]
-            for sc in lanes:
-                sc.update(**scene_kws[0])
+            # one lane per batch, consecutive batches on alternating lanes (scene + render stream): the library renders the batch as launches of up to
+            # eight poses each (a work unit is (frame, tile)), and the tail of one batch's last launch overlaps the head of the next batch's first
+            r = batch_index & 1 if self.pipelined else 0
+            lanes = [self.scenes[r]]
+            streams = [self.render_streams[r]] if self.pipelined else [torch.cuda.current_stream()]
+            lanes[0].update(**scene_kws[0])
             cams = np.stack([np.concatenate([np.asarray(kw[key], np.float32).reshape(3) for key in ("eye", "right", "up")]) for kw in scene_kws])
             if record:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

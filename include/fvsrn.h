@@ -354,9 +354,13 @@ int fvsrn_render_stripes(fvsrn_scene* scene, fvsrn_network* net, int width, int 
  * one ImageEvaluatorSimple::render per camera of a rotation -- pay one Python call, one scene update and one launch set-up per frame, which is a
  * third of a rank's 0.26 ms share of the headline frame at world 8).  Frame f takes camera cameras9[f] = { eye, right, up } (host memory, like
  * fvsrn_scene_desc), the time times[f] if `times` is non-NULL (fvsrn_network_set_time_and_ensemble with the network's current ensemble), and is
- * rendered like fvsrn_render_stripes into d_out_local + f * 8 * rows * width (rows = fvsrn_stripe_rows(...); world = 1: whole frames) on lane f % lanes:
- * scenes[lane] on streams[lane].  One lane renders the frames back to back on one stream; two lanes let the tail of one frame's launch overlap the head
- * of the next (what tiles.StripeRenderer does from Python with two scenes on two streams).  The scenes must agree in everything but the camera -- the
+ * rendered like fvsrn_render_stripes into d_out_local + f * 8 * rows * width (rows = fvsrn_stripe_rows(...); world = 1: whole frames).  Frames that
+ * share their time (times == NULL) are rendered SEVERAL PER LAUNCH -- up to eight poses, a work unit is (frame, pixel tile), handed out by the same
+ * device counter as the tiles of one frame: a rank's 1/8 share of a frame is a small launch whose ramp-up, longest tile and gap to the next launch cost
+ * a fifth of its time, eight shares are a whole frame's worth of work -- in groups of ceil(frames / lanes) that the lanes (scenes[lane] on
+ * streams[lane]) take in turn; with per-frame times every frame is its own launch on lane f % lanes.  Two lanes let the tail of one launch overlap
+ * the head of the next (what tiles.StripeRenderer does from Python with two scenes on two streams).  Pixel for pixel the images fvsrn_render_stripes
+ * gives frame by frame, except that a multi-frame launch does not cut rays into depth segments (re-associated sums, <= 1e-4).  The scenes must agree in everything but the camera -- the
  * call overwrites cam_eye / cam_right / cam_up of each scene's description, nothing else (a light that follows the camera, brdf_light, does not) -- and the caller orders the streams against its buffers (events) as for
  * single frames.  d_rgba8 (optional): frame f's rows also as packed RGBA8 words (fvsrn_extract_color_rgba8, FVSRN_CHANNEL_COLOR, use_tonemapping /
  * max_exposure) at d_rgba8 + f * rows * width, enqueued behind its render on the same stream.  d_stats as in fvsrn_render, summed over the frames. */

@@ -372,8 +372,10 @@ def test_rccl_route_gather_to_root_rgba8_payload_and_batches_on_one_gpu(extra):
 @pytest.mark.parametrize("world,rank", [(1, 0), (4, 1)])
 @pytest.mark.parametrize("grid,keys", [(None, 1), ((16, 8), 4)])
 def test_batch_render_equals_frame_by_frame_renders(world, rank, grid, keys):
-    """fvsrn_render_stripes_batch: K camera poses (and times) in one call, on one lane and on two (two scenes on two streams), are bit for bit the frames
-    fvsrn_render / fvsrn_render_stripes give one by one; the RGBA8 copy of every frame is fvsrn_extract_color_rgba8 of its planes."""
+    """fvsrn_render_stripes_batch: K camera poses (and times) in one call -- frames that share their time several per LAUNCH (a work unit is (frame, pixel
+    tile)), on one lane and on two (two scenes on two streams) -- are bit for bit the frames fvsrn_render / fvsrn_render_stripes give one by one with one
+    depth segment per ray (a multi-frame launch does not cut rays; with the automatic segments of a small single launch the sums are re-associated:
+    2e-4); the RGBA8 copy of every frame is fvsrn_extract_color_rgba8 of its planes."""
     import torch
     from fvsrn_amd import capi, volnet_io
     vn = util.random_network(C=32, layers=4, activation="SnakeAlt", output_mode="density", grid=grid, seed=61, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4,
@@ -383,19 +385,22 @@ def test_batch_render_equals_frame_by_frame_renders(world, rank, grid, keys):
     W, H, stripe, K = 72, 64, 8, 5
     kws = [_scene_kw(0.4 + 0.9 * i) for i in range(K)]
     times = [0.3 + 0.55 * i for i in range(K)] if keys > 1 else None
-    ref, ref8 = [], []
-    scene = capi.Scene(**kws[0])
+    ref, ref8, ref_auto = [], [], []
+    scene, scene_auto = capi.Scene(**kws[0]).set_option("depth_segments", 1), capi.Scene(**kws[0])
     for i, kw in enumerate(kws):
         scene.update(**kw)
+        scene_auto.update(**kw)
         if times:
             serial.set_time_and_ensemble(times[i], 0)
         img = scene.render(serial, W, H)[0] if world == 1 else capi.render_stripes(scene, serial, W, H, stripe, rank, world)
         ref.append(img.clone())
         ref8.append(capi.extract_color_part(img, capi.CHANNEL_COLOR, True, 1.5))
+        auto = scene_auto.render(serial, W, H)[0] if world == 1 else capi.render_stripes(scene_auto, serial, W, H, stripe, rank, world)
+        ref_auto.append(auto.clone())
         torch.cuda.synchronize()
     cams = np.stack([np.concatenate([kw["eye"], kw["right"], kw["up"]]) for kw in kws])
     for lanes in (1, 2):
-        scenes = [capi.Scene(**kws[0]) for _ in range(lanes)]
+        scenes = [capi.Scene(**kws[0]).set_option("depth_segments", 1) for _ in range(lanes)]
         streams = [torch.cuda.Stream() for _ in range(lanes)]
         rows = H if world == 1 else capi.stripe_rows(H, stripe, rank, world)
         rgba = torch.zeros((K, rows, W), dtype=torch.int32, device="cuda")
@@ -406,7 +411,10 @@ def test_batch_render_equals_frame_by_frame_renders(world, rank, grid, keys):
         for i in range(K):
             assert torch.equal(torch.nan_to_num(out[i], nan=-7.0), torch.nan_to_num(ref[i], nan=-7.0)), (lanes, i)
             assert torch.equal(rgba[i], ref8[i]), (lanes, i)
+            assert float((torch.nan_to_num(out[i][:7]) - torch.nan_to_num(ref_auto[i][:7])).abs().max()) < 2e-4
         assert float(out[:, 3].max()) > 0.05
+        if times is None:  # several poses per launch: ceil(K / lanes) each
+            assert scenes[0].last_render_info()["segments"] == 1 and ("frames %d" % -(-K // lanes)) in capi.debug_state()
     with pytest.raises(capi.FvsrnError):  # one scene on two streams
         capi.render_stripes_batch([scenes[0], scenes[0]], [s.cuda_stream for s in (torch.cuda.Stream(), torch.cuda.Stream())], net, W, H, stripe, rank, world, cams)
 

@@ -302,6 +302,43 @@ def test_batched_camera_matrices_render_one_image_per_batch_entry():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,stripe", [(2, 16), (4, 8)])
+def test_render_stripes_through_the_module_api(world, stripe):
+    """Multi-GPU frames behind the module API (VERDICT r04 missing 2): ImageEvaluatorSimple.render_stripes(width, height, rank, world, stripe) is this
+    rank's round-robin row stripes of the frame render() gives, compact; the stripes of all ranks -- stacked like all_gather_into_tensor / gather deliver
+    them -- go back into image order with Assemble_stripes and equal the whole frame bit for bit (batched cameras included)."""
+    d, meta = util.load_golden("g3_trace_rgbo_32x32")
+    n = export_like_the_reference(d, meta)
+    n.box_min = pr.float3(*meta["box_min"])
+    n.box_size = pr.float3(*meta["box_size"])
+    vol = pr.VolumeInterpolationNetwork()
+    vol.set_network(n)
+    ev = pr.ImageEvaluatorSimple()
+    ev.volume = vol
+    ev.camera.orientation = pr.CameraOnASphere.Ym
+    ev.camera.fov_y_radians = meta["fov_y"]
+    ev.ray_evaluator.stepsize = meta["stepsize"]
+    mats = []
+    for yaw in (0.2, 1.4):
+        ev.camera.pitchYawDistance.value = pr.double3(meta["pitch"], yaw, meta["distance"])
+        mats.append(ev.camera.get_parameters())
+    ev.camera.set_parameters(torch.cat(mats, dim=0))
+    W, H = 40, 64
+    full = ev.render(W, H).clone()
+    parts = [ev.render_stripes(W, H, r, world, stripe).clone() for r in range(world)]
+    for r in range(world):
+        rows = pr.ImageEvaluatorSimple.stripe_rows(H, stripe, r, world)
+        assert tuple(parts[r].shape) == (2, 8, rows, W) and rows == H // world
+    frame = pr.ImageEvaluatorSimple.Assemble_stripes(torch.stack(parts), H, stripe)
+    assert torch.equal(torch.nan_to_num(frame, nan=-7.0), torch.nan_to_num(full, nan=-7.0))
+    assert float(full[:, 3].max()) > 0.05
+    with pytest.raises(Exception):
+        ev.render_stripes(W, H, world, world, stripe)
+    with pytest.raises(Exception):
+        ev.render_stripes(W, H, 0, world, 12)
+
+
+@pytest.mark.gpu
 def test_shaded_configuration_through_the_module_api():
     """The shaded scene files of the reference (e.g. config-files/ejecta1024-v7-shaded.json) select finite-difference
     gradients on the volume and Phong shading on the BRDF: same image as the C ABI driven directly, and as the oracle."""
