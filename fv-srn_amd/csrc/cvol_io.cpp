@@ -287,6 +287,17 @@ int fvsrn_cvol_read(const char* path, float world_size[3], fvsrn_cvol_feature_ca
         f.read(magic, 4);
         static const size_t bytesPerType[3] = {1, 2, 4};
         constexpr size_t kMaxBytes = size_t(1) << 34;  // 16 GiB of decoded host data per feature
+        // the header's sizes are not trusted before a body is read -- an uncompressed body cannot be longer than what is left of the file, an
+        // LZ4 body decodes to at most 255 x its bytes (a match token extends by 255 per byte): a 40-byte file that declares 16 GiB fails here instead
+        // of zero-filling them
+        f.seekg(0, std::ios::end);
+        const unsigned long long fileSize = f.tellg() < 0 ? 0ull : (unsigned long long)f.tellg();
+        f.seekg(4, std::ios::beg);
+        auto bodyFits = [&](size_t bytes, bool lz4) {
+            const std::streamoff at = f.tellg();
+            const unsigned long long left = at < 0 || (unsigned long long)at > fileSize ? 0ull : fileSize - (unsigned long long)at;
+            return lz4 ? bytes / 255 <= left : bytes <= left;
+        };
         fvsrn_cvol_feature info;
         std::memset(&info, 0, sizeof info);
         if (f && std::memcmp(magic, "cvol", 4) == 0) {
@@ -304,9 +315,9 @@ int fvsrn_cvol_read(const char* path, float world_size[3], fvsrn_cvol_feature_ca
                 return fail(FVSRN_ERR_FORMAT, "corrupt header of a legacy 'cvol' file");
             const size_t bytes = bytesPerType[type] * X * Y * Z;
             if (bytes > kMaxBytes) return fail(FVSRN_ERR_UNSUPPORTED, "volume too large");
+            if (!bodyFits(bytes, useCompression != 0)) return fail(FVSRN_ERR_FORMAT, "the header declares more voxels than the file can hold");
             std::vector<unsigned char> raw;
             if (useCompression) {
-                raw.reserve(bytes);
                 if (const char* why = lz4ReadMessages(f, raw, bytes)) return fail(FVSRN_ERR_FORMAT, why);
             } else {
                 raw.resize(bytes);
@@ -349,6 +360,7 @@ int fvsrn_cvol_read(const char* path, float world_size[3], fvsrn_cvol_feature_ca
                 return fail(FVSRN_ERR_FORMAT, "corrupt feature header");
             const size_t bytes = bytesPerType[type] * X * Y * Z * size_t(channels);
             if (bytes > kMaxBytes) return fail(FVSRN_ERR_UNSUPPORTED, "volume too large");
+            if (!bodyFits(bytes, compressed)) return fail(FVSRN_ERR_FORMAT, "a feature header declares more voxels than the file can hold");
             if (compressed) {
                 if (stream.size() > (size_t(1) << 16)) stream.erase(stream.begin(), stream.end() - (1 << 16));  // only the last 64 KiB can be referenced
                 if (const char* why = lz4ReadMessages(f, stream, bytes)) return fail(FVSRN_ERR_FORMAT, why);

@@ -171,11 +171,14 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             if (smallFn && smallGrid != 1 && (O[FVSRN_OPT_FOURIER_RESYNC] ? O[FVSRN_OPT_FOURIER_RESYNC] : kFourierResync) == 1) {
                 if (const void* fn = render_small_exact_fn(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid)) { smallFn = fn; smallExact = true; }
             }
-            // the fragment-major variant of the wide latent-grid renderers (render_stripe_kernel, kernels.hpp: no register spills, 1 % slower):
-            // on request only (FVSRN_OPT_OVERLAP_KERNEL = 1) since the launch-to-launch differences it was built around turned out to be a
-            // hazard in the tap arithmetic (srn_device.hpp, grid_tap) and not concurrent scratch use
+            // The fragment-major variant of the 48- / 64-wide latent-grid renderers (render_stripe_kernel, kernels.hpp) is what the GATHER path of those
+            // widths runs by default since r05 (FVSRN_OPT_OVERLAP_KERNEL: -1 automatic = on, 0 = the pipelined order of render_kernel, 1 = also instead of
+            // the cell table).  Measured r05 on 64x6 + 32^3 grid, 1024^2 x 512 (profiles/r05/experiments_r05.md): FLOAT / BYTE_LINEAR gathers 25.8 - 26.1 against
+            // 26.3 Gsamples/s with no scratch at all (the pipelined order spills 76 registers); BYTE_GAUSSIAN 14.0 against 13.8 (117 against 172 spilled
+            // registers); one wave per SIMD with the 512-register budget, the other way to lose the spills, renders 8.9.
             const void* stripeFn = nullptr;
-            if (!smallFn && !a.shaded && O[FVSRN_OPT_OVERLAP_KERNEL] == 1)
+            const bool wantCellsKernel = net->keyScaled.grid == 1 && net->cellTableBytes && useCells && O[FVSRN_OPT_OVERLAP_KERNEL] != 1;
+            if (!smallFn && !a.shaded && O[FVSRN_OPT_OVERLAP_KERNEL] != 0 && !wantCellsKernel)
                 stripeFn = render_stripe_fn(net->keyScaled);
             // every other unshaded render of a network whose decoded latent grid has a cell table: render_kernel with the grid through that table
             const void* cellsFn = nullptr;

@@ -228,6 +228,11 @@ class StripeRenderer:
                     for sc in self.scenes:
                         if sc.get_option("persistent") < 0:  # (an explicit setting of the caller / the environment stays)
                             sc.set_option("persistent", 1)
+                        # Batches (several poses per launch, consecutive batches on alternating lanes): the slots a persistent launch would leave free for
+                        # the collective of the previous frame (1/16 of the chip) are taken by the other lane's launch at once, and a collective that waits
+                        # for the end of a 2 ms batch costs latency (three buffer pairs), not throughput -- no reserve (r05: 88 -> 9x % of frame / world)
+                        if self.K > 1 and sc.get_option("persistent_reserve") < 0:
+                            sc.set_option("persistent_reserve", 0)
         else:
             self.scenes = [dict(scene_kw) for _ in range(2 if self.pipelined else 1)]
             self.comm_stream = _HostStream() if self.collective else None

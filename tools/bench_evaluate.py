@@ -22,13 +22,16 @@ HBM_PEAK_GBPS = 8000.0
 def main():
     """One JSON line per network and batch size.  evaluate_points sits between two rooflines: 12 B in + 4 B out per point against
     HBM, the network's algorithmic FLOP per point against the matrix cores -- both are reported, the larger fraction names the bound."""
-    sizes = [int(a) for a in sys.argv[1:]] or [1 << 24, 1 << 26]
+    sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1 << 24, 1 << 26]
+    only = [a for a in sys.argv[1:] if not a.isdigit()]  # workload names (default: all four)
     for n in sizes:
         pos = torch.rand(n, 3, device="cuda")
         for name, kw in [("c32l4_fourier_relu", dict(C=32, layers=4, activation="ReLU")),
                          ("c32l4_fourier_snakealt", dict(C=32, layers=4, activation="SnakeAlt")),
                          ("c32l4_grid16_relu", dict(C=32, layers=4, activation="ReLU", grid=(16, 16))),
                          ("c64l6_grid16_relu", dict(C=64, layers=6, activation="ReLU", grid=(16, 32)))]:
+            if only and name not in only:
+                continue
             vn = util.random_network(output_mode="density:direct", seed=1234, **kw)
             net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
             out = net.evaluate(pos)
@@ -54,7 +57,14 @@ def main():
             info = net.info()
             tflops = info.flops_per_sample * n / ms / 1e9
             gbps = 16.0 * n / ms / 1e6
-            print(json.dumps({"workload": "evaluate_points:" + name, "points": n, "ms": ms, "points_per_s": n / ms * 1e3,
+            # the issue roofline of bench.py (vector issue port: MFMA 8, transcendental 8.4, convert 4.4, other 2.75 cycles per wave instruction) from the
+            # committed PMC profile of this kernel (profiles/r*/evaluate_points_<name>_*pmc.csv), where there is one
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+            bench = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(bench)
+            issue = bench.issue_roofline(bench.pmc_counters("evaluate_points_" + name))
+            print(json.dumps({"workload": "evaluate_points:" + name, "points": n, "ms": ms, "points_per_s": n / ms * 1e3, "issue": issue,
                               "kernel": net.kernel_name(False),
                               "roofline": {"bound": "mfma" if tflops / MFMA_F16_PEAK_TFLOPS > gbps / HBM_PEAK_GBPS else "hbm",
                                            "mfma": {"achieved": tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F16_PEAK_TFLOPS,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): tools/pmc_profile.sh <tag> [bench args...]
+# usage (on the GPU box): tools/pmc_profile.sh <tag> [bench args...]          PMC_PROGRAM="tools/bench_evaluate.py 16777216": profile that program instead of bench.py
 # Runs rocprofv3 --kernel-trace --stats once and the PMC passes (separate runs, counters only) for bench.py with the
 # given arguments and writes the per-launch summary of the render kernel to gpurun_out/<tag>_{stats,pmc}.csv.
 tag=$1; shift
@@ -7,9 +7,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
 B="$R/bench.py --steps 6 --warmup 2 --no-twin --no-cpu-baseline $*"
+S="$R/bench.py --steps 40 --warmup 4 --no-twin --no-cpu-baseline $*"
+if [ -n "$PMC_PROGRAM" ]; then B="$R/$PMC_PROGRAM"; S="$R/$PMC_PROGRAM"; fi
 # kernel-trace + stats of a run long enough that the warm-up launches (clock ramp) do not dominate the average; the JSON
 # line bench.py printed during THIS run is kept next to it (its roofline.kernel_ms_avg is the figure to compare)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 40 --warmup 4 --no-twin --no-cpu-baseline $* > $R/gpurun_out/${tag}_bench_under_rocprof.json 2> $O/stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $S > $R/gpurun_out/${tag}_bench_under_rocprof.json 2> $O/stats.log
 i=0
 for set in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" \

@@ -13,7 +13,8 @@ for d in sorted(glob.glob(root + "/pmc*")):
         dur = collections.defaultdict(dict)  # kernel -> dispatch -> ns (the launch durations of THIS pass: GRBM_GUI_ACTIVE / 8 XCDs / duration = shader clock)
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            name = next((n for n in ("render_small_kernel", "render_shaded_kernel", "render_adjoint_kernel", "render_stripe_kernel", "render_cells_kernel", "render_kernel") if n in k), None)
+            name = next((n for n in ("render_small_kernel", "render_shaded_cells_kernel", "render_shaded_kernel", "render_adjoint_kernel", "render_stripe_kernel", "render_cells_kernel",
+                                     "render_kernel", "evaluate_small_kernel", "evaluate_gradient_kernel", "evaluate_kernel") if n in k), None)
             if name is None:
                 continue
             k = k[k.index(name):].split("(")[0]
