@@ -200,9 +200,11 @@ def timed_run(runner, steps, warmup, distributed, spinup_ms=0.0):
     if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
-    # (one event pair per submit: a batch of K frames divides by its frame count)
+    # (one event pair per submit = per launch: a batch of K frames is K frames' worth of work)
     per = [min(runner.K, steps - j) for j in range(0, steps, runner.K)] if runner.K > 1 else [1] * len(runner.kernel_events)
-    kernel_ms = [a.elapsed_time(b) / n for (a, b), n in zip(runner.kernel_events, per)]
+    runner.launch_ms = [a.elapsed_time(b) for a, b in runner.kernel_events]
+    runner.frames_per_launch = per
+    kernel_ms = [t / n for t, n in zip(runner.launch_ms, per)]
     st = runner.stats.cpu().numpy().astype(np.int64)
     runner.last_frame = warmup + steps - 1
     return dt, kernel_ms, int(st[0]), int(st[1])
@@ -415,7 +417,9 @@ def main():
     ap.add_argument("--gather", default="all", choices=["all", "root"], help="N > 1 / --force-collective: the frame on every rank (all-gather) or on rank 0 only")
     ap.add_argument("--payload", default="planes", choices=["planes", "rgba8"],
                     help="N > 1 / --force-collective: what travels -- the eight fp32 planes of ImageEvaluatorSimple::render, or ExtractColor'ed RGBA8 words (4 B / pixel)")
-    ap.add_argument("--frames-per-submit", type=int, default=1, help="K camera poses per call into the library and per collective (fvsrn_render_stripes_batch)")
+    ap.add_argument("--frames-per-submit", type=int, default=8,
+                    help="K camera poses of the rotation per call into the library, per LAUNCH (a work unit is (frame, pixel tile)) and per collective "
+                         "(fvsrn_render_stripes_batch); 1 = one launch per frame, what a caller of render(width, height) gets frame by frame")
     ap.add_argument("--grid-encoding", default="float", choices=sorted(GRID_ENCODINGS), help="latent-grid encoding of the synthetic network (LatentGrid::Encoding)")
     ap.add_argument("--camera-distance", type=float, default=1.6, help="CameraOnASphere distance (1.6: the headline; 0.8: a close-up that trips the cell table's footprint rule)")
     ap.add_argument("--gradient-mode", default="off", choices=["off", "finite_differences", "adjoint"], help="shaded render: Phong BRDF with normals by this mode")
@@ -531,11 +535,18 @@ def main():
         base = args.config if activation == "ReLU" else args.config.replace("_1024x512", "_%s_1024x512" % activation.lower())
         return base + variant_tag
 
+    single = None
+    if not args.no_twin and not collective and args.frames_per_submit > 1:
+        # the same frames one launch per frame: what a caller of the reference's render(width, height) gets when it renders a sequence frame by frame
+        r1 = Runner(capi, net, cfg, rank, world, args.early_out, time_keys, frames_per_submit=1)
+        dt1, k1, ev1, _ = timed_run(r1, args.steps, args.warmup, False)
+        single = {"frames_per_launch": 1, "value": ev1 / dt1, "unit": "samples/s", "ms_per_step": 1e3 * dt1 / args.steps, "steps": args.steps,
+                  "kernel_ms_avg": sum(k1) / len(k1), "mfma_frac": info.flops_per_sample * (ev1 / args.steps) / (sum(k1) * 1e-3 / len(k1)) / 1e12 / MFMA_F16_PEAK_TFLOPS}
     twin = None
     if not args.no_twin and not collective:
         other = "SnakeAlt" if args.activation == "ReLU" else "ReLU"
         _, net2 = make_network(volnet_io, capi, cfg, other, time_keys)
-        r2 = Runner(capi, net2, cfg, rank, world, args.early_out, time_keys)
+        r2 = Runner(capi, net2, cfg, rank, world, args.early_out, time_keys, frames_per_submit=args.frames_per_submit)
         dt2, k2, ev2, ex2 = timed_run(r2, args.steps, args.warmup, False)  # the same step counts as the primary
         plan2 = r2.pipeline.scenes[0].last_render_info()
         twin = {"activation": other, "value": ev2 / dt2, "unit": "samples/s", "ms_per_step": 1e3 * dt2 / args.steps, "steps": args.steps,
@@ -548,7 +559,7 @@ def main():
     if not args.no_twin and not collective:
         # the same frames with exact Fourier features at every step (FVSRN_OPT_FOURIER_RESYNC = 1: the reference's per-sample
         # arithmetic, positions rounded to fp16 at every sample, no feature rotation)
-        r3 = Runner(capi, net, cfg, rank, world, args.early_out, time_keys, scene_options={"fourier_resync": 1})
+        r3 = Runner(capi, net, cfg, rank, world, args.early_out, time_keys, scene_options={"fourier_resync": 1}, frames_per_submit=args.frames_per_submit)
         dt3, k3, ev3, ex3 = timed_run(r3, args.steps, args.warmup, False)
         plan3 = r3.pipeline.scenes[0].last_render_info()
         exact = {"option": "FVSRN_OPT_FOURIER_RESYNC=1", "activation": args.activation, "value": ev3 / dt3, "unit": "samples/s",
@@ -562,7 +573,8 @@ def main():
         # more rounds of 20 frames, interleaved with 20 frames of the other activation so that the rounds do not all sample the state the timed
         # region left behind; frac = algorithmic FLOP / HIP-event kernel time / peak per round.
         other_net = make_network(volnet_io, capi, cfg, "SnakeAlt" if args.activation == "ReLU" else "ReLU", time_keys)[1]
-        ra, rb = Runner(capi, net, cfg, rank, world, args.early_out, time_keys), Runner(capi, other_net, cfg, rank, world, args.early_out, time_keys)
+        ra = Runner(capi, net, cfg, rank, world, args.early_out, time_keys, frames_per_submit=args.frames_per_submit)
+        rb = Runner(capi, other_net, cfg, rank, world, args.early_out, time_keys, frames_per_submit=args.frames_per_submit)
         fracs = []
         for _ in range(3):
             _, kms, ev, _ = timed_run(ra, 20, 2, False)
@@ -579,6 +591,10 @@ def main():
                       algorithmic_bytes=32.0 * W * H)
         if spread:
             rl.update(spread)
+        # roofline.kernel_ms_avg is per FRAME; one launch renders frames_per_launch frames and lasts launch_ms_avg -- the duration rocprofv3 lists for the kernel
+        full_launches = [t for t, n in zip(runner.launch_ms, runner.frames_per_launch) if n == max(runner.frames_per_launch)]
+        rl["frames_per_launch"] = max(runner.frames_per_launch)
+        rl["launch_ms_avg"] = sum(full_launches) / len(full_launches)
         out = {
             "metric": "srn_samples_per_s", "value": evaluated / dt, "unit": "samples/s", "n_gpus": world,
             "world_size": dist_world_size(collective), "backend": backend if collective else None,
@@ -599,6 +615,7 @@ def main():
             "nominal_samples_per_frame": W * H * steps,
             "wave_executed_samples_per_frame": executed / args.steps,
             "kernel": launched_kernel,
+            "frames_per_submit": args.frames_per_submit,  # camera poses per library call / launch / collective (1: frame by frame)
             "host_us_per_frame": host_us,  # wall time of this rank's host inside submit per frame (scene update, launch, events, the collective's enqueue)
             # what the launches of the timed region did (fvsrn_scene_last_render_info): depth segments per ray, period of the exact re-derivation of rotated
             # Fourier features (0: derived at every step), latent grid through the cell table or by gathers (None: no latent grid)
@@ -608,7 +625,7 @@ def main():
         }
         if per_rank is not None:
             out["per_rank"] = per_rank
-            out["gather"], out["payload"], out["frames_per_submit"] = args.gather, args.payload, args.frames_per_submit
+            out["gather"], out["payload"] = args.gather, args.payload
             out["collective_bytes_per_frame_and_rank"] = (32 if args.payload == "planes" else 4) * runner.W * runner.H // world
             out["stripe_launches"] = {"persistent": bool(runner.pipeline.persistent_stripes), "hw_streams_concurrent": runner.pipeline.hw_streams_concurrent,
                                       "needs": "GPU_MAX_HW_QUEUES >= 8 in the environment before the process starts (set by bench.py / launch_ranks)",
@@ -617,6 +634,8 @@ def main():
             out["force_collective"] = True
         if frame_check is not None:
             out["gathered_frame_matches_single_gpu_frame"] = frame_check
+        if single:
+            out["single_frame_launches"] = single
         if twin:
             out["twin"] = twin
         if exact:

@@ -6,7 +6,9 @@ tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
-B="$R/bench.py --steps 6 --warmup 2 --no-twin --no-cpu-baseline $*"
+# (the counter passes render one frame per launch: their per-launch averages are per-frame figures, comparable across rounds; the stats run is the bench's
+# own command line -- eight frames per launch since r05 -- and its average duration is roofline.launch_ms_avg of the line)
+B="$R/bench.py --steps 6 --warmup 2 --no-twin --no-cpu-baseline --frames-per-submit 1 $*"
 S="$R/bench.py --steps 40 --warmup 4 --no-twin --no-cpu-baseline $*"
 if [ -n "$PMC_PROGRAM" ]; then B="$R/$PMC_PROGRAM"; S="$R/$PMC_PROGRAM"; fi
 # kernel-trace + stats of a run long enough that the warm-up launches (clock ramp) do not dominate the average; the JSON
