@@ -293,7 +293,7 @@ def pmc_counters(workload):
     there is none.  The counters cannot be read inside the timed run; tools/pmc_profile.sh collects them in separate --pmc passes."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", workload + "_*pmc.csv")))
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", workload + "_r[0-9][0-9]_pmc.csv")))
     if not files:
         return {}
     per_kernel = {}

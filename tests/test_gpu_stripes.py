@@ -424,6 +424,53 @@ def test_batch_render_equals_frame_by_frame_renders(world, rank, grid, keys):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["shaded_fd_64", "adjoint_48_grid", "rgbo_96", "byte_gaussian_64", "direction_32"])
+def test_batch_render_through_the_other_kernel_families(case):
+    """Several poses per launch is a property of render_body, which every render kernel family shares: the LDS kernels with finite-difference / adjoint
+    shading, a colour network at 96 channels, the BYTE_GAUSSIAN gather kernel (fragment-major), a view-dependent network -- each batch against its frames
+    rendered one by one (one depth segment per ray: bit for bit)."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    net_kw, scene_extra = {
+        "shaded_fd_64": (dict(C=64, layers=3, activation="ReLU", output_mode="density"),
+                         dict(gradient_mode=capi.GRADIENT_FINITE_DIFFERENCES, finite_differences_stepsize=0.01, brdf=dict(enable_phong=True, ambient=0.2, specular=0.3))),
+        "adjoint_48_grid": (dict(C=48, layers=3, activation="SnakeAlt", output_mode="density", grid=(16, 8)),
+                            dict(gradient_mode=capi.GRADIENT_ADJOINT_METHOD, brdf=dict(enable_phong=True, ambient=0.2, specular=0.3))),
+        "rgbo_96": (dict(C=96, layers=3, activation="SnakeAlt", output_mode="rgbo"), dict(tf_kind=oracle.TF_NONE)),
+        "byte_gaussian_64": (dict(C=64, layers=3, activation="ReLU", output_mode="density", grid=(16, 8), encoding=2), dict()),
+        "direction_32": (None, dict(tf_kind=oracle.TF_NONE)),
+    }[case]
+    if net_kw is None:
+        d, meta = util.load_golden("g1_dir1_c32l4_snakealt_rgbo")
+        vn = util.golden_to_volnet(d, meta, box_min=(-0.5, -0.5, -0.5))
+    else:
+        vn = util.random_network(seed=64, box_min=(-0.5, -0.5, -0.5), fourier_std=0.4, **net_kw)
+    net, serial = capi.Network.from_volnet(volnet_io.save_volnet(vn)), capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    W, H, stripe, K = 56, 48, 8, 3
+    base = dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)
+    base.update(scene_extra)
+    kws = [_scene_kw(0.5 + 1.1 * i, **base) for i in range(K)]
+    if base.get("tf_kind") == oracle.TF_NONE:
+        for kw in kws:
+            kw.pop("tf_scale_absorption", None)
+    cams = np.stack([np.concatenate([kw["eye"], kw["right"], kw["up"]]) for kw in kws])
+    for world, rank in ((1, 0), (2, 1)):
+        scene = capi.Scene(**kws[0]).set_option("depth_segments", 1)
+        ref = []
+        for kw in kws:
+            scene.update(**kw)
+            ref.append((scene.render(serial, W, H)[0] if world == 1 else capi.render_stripes(scene, serial, W, H, stripe, rank, world)).clone())
+        family = scene.last_kernel_name()
+        batch_scene = capi.Scene(**kws[0]).set_option("depth_segments", 1)
+        out = capi.render_stripes_batch([batch_scene], [torch.cuda.current_stream().cuda_stream], net, W, H, stripe, rank, world, cams)
+        torch.cuda.synchronize()
+        assert batch_scene.last_kernel_name() == family and "frames %d" % K in capi.debug_state()
+        for i in range(K):
+            assert torch.equal(torch.nan_to_num(out[i], nan=-7.0), torch.nan_to_num(ref[i], nan=-7.0)), (case, world, i, family)
+        assert float(out[:, 3].max()) > 0.05
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["depth", "depth_with_empty_pixels", "color", "normal"])
 def test_extract_color_of_image_parts_with_a_merged_depth_range(mode):
     """ExtractColor on the stripes of a frame before they travel (payload "rgba8"): the parts of an image, each converted on its own with the depth range
