@@ -449,10 +449,9 @@ def test_batch_render_through_the_other_kernel_families(case):
     W, H, stripe, K = 56, 48, 8, 3
     base = dict(tf_kind=oracle.TF_GAUSSIAN, tf_table=GAUSS_TF)
     base.update(scene_extra)
+    if base["tf_kind"] == oracle.TF_NONE:
+        base.pop("tf_table")
     kws = [_scene_kw(0.5 + 1.1 * i, **base) for i in range(K)]
-    if base.get("tf_kind") == oracle.TF_NONE:
-        for kw in kws:
-            kw.pop("tf_scale_absorption", None)
     cams = np.stack([np.concatenate([kw["eye"], kw["right"], kw["up"]]) for kw in kws])
     for world, rank in ((1, 0), (2, 1)):
         scene = capi.Scene(**kws[0]).set_option("depth_segments", 1)
