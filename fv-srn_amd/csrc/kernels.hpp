@@ -912,10 +912,16 @@ __device__ __forceinline__ void render_entry(const NetParams& P, const ScenePara
     render_body<CD, ACT, GRID, HAS_DIR, FM_COS, SHADED, TAIL_GENERIC, 0, SCHED, CELLS>(P, S, lds, tfLds, out, stats);
 }
 
+// The layer order of the 48- / 64-wide latent-grid variants (the gather path: BYTE_GAUSSIAN grids, launches outside the cell table's footprint rule) is the
+// fragment-major one (SCHED = 1) since r05: the pipelined order of srn_layers spilled 67 - 79 (FLOAT / BYTE_LINEAR gathers) and 172 - 213 registers
+// (BYTE_GAUSSIAN) there, the fragment-major order none / one, at 25.8 - 26.1 against 26.3 and 14.0 against 13.8 Gsamples/s (64x6 + 32^3 grid; r03 built it as a
+// separate render_stripe_kernel, r05 measured it against one wave per SIMD -- 8.9 -- and made it THE kernel of these variants: profiles/r05/experiments_r05.md).
+constexpr int render_layer_schedule(int CD, int GRID) { return GRID != 0 && (CD == 3 || CD == 4) ? 1 : 0; }
+
 template <int CD, int ACT, int GRID, bool HAS_DIR>
 __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void render_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                unsigned long long* __restrict__ stats) {
-    render_entry<CD, ACT, GRID, HAS_DIR, 0>(P, S, out, stats);
+    render_entry<CD, ACT, GRID, HAS_DIR, 0, render_layer_schedule(CD, GRID)>(P, S, out, stats);
 }
 
 // render_kernel<CD, ACT, 1, HAS_DIR> with the decoded latent grid through the cell table (r04: srn_device.hpp cell_prepare / cells_accumulate; the
@@ -924,16 +930,6 @@ template <int CD, int ACT, bool HAS_DIR>
 __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, 1)) void render_cells_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                      unsigned long long* __restrict__ stats) {
     render_entry<CD, ACT, 1, HAS_DIR, 0, 0, true>(P, S, out, stats);
-}
-
-// render_kernel for 48- and 64-wide latent-grid networks in the fragment-major layer order: 218 registers and no scratch against the 76
-// spilled registers of the pipelined order, 1.2 % slower on one stream (64x6 + 32^3 grid: 24.45 vs 24.75 Gsamples/s).  Built in r03 for
-// overlapping launches when kernels with scratch were serialised across streams; that rule is gone, the variant is
-// taken on request only (FVSRN_OPT_OVERLAP_KERNEL = 1).
-template <int CD, int ACT, int GRID, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void render_stripe_kernel(NetParams P, SceneParams S, float* __restrict__ out,
-                                                                      unsigned long long* __restrict__ stats) {
-    render_entry<CD, ACT, GRID, HAS_DIR, 0, 1>(P, S, out, stats);
 }
 
 // 32-wide Fourier-only scalar networks with NLC <= 3 C->C layers behind a transfer function, phases inside the v_cos domain

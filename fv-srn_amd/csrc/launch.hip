@@ -399,13 +399,14 @@ hipError_t launch_render_shaded_cells(const VariantKey& k, const RenderArgs& a, 
     return hipErrorInvalidDeviceFunction;
 }
 const void* render_stripe_fn(const VariantKey& k) {
-    if (k.CD == 3) return render_stripe_fn_cd<3>(k);
-    if (k.CD == 4) return render_stripe_fn_cd<4>(k);
+    if (k.grid == 0) return nullptr;
+    if (k.CD == 3) return render_fn_cd<3>(k);
+    if (k.CD == 4) return render_fn_cd<4>(k);
     return nullptr;
 }
 hipError_t launch_render_stripe(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s) {
-    if (k.CD == 3) return launch_render_stripe_cd<3>(k, a, gridDim, blockDim, ldsBytes, s);
-    if (k.CD == 4) return launch_render_stripe_cd<4>(k, a, gridDim, blockDim, ldsBytes, s);
+    if (k.grid != 0 && k.CD == 3) return launch_render_plain_cd<3>(k, a, gridDim, blockDim, ldsBytes, s);
+    if (k.grid != 0 && k.CD == 4) return launch_render_plain_cd<4>(k, a, gridDim, blockDim, ldsBytes, s);
     return hipErrorInvalidDeviceFunction;
 }
 const void* render_adjoint_fn(const VariantKey& k) {

@@ -47,13 +47,10 @@ template <int CD> const void* render_fn_cd(const VariantKey& k);
 template <int CD> const void* render_shaded_fn_cd(const VariantKey& k);
 template <int CD> hipError_t launch_render_plain_cd(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 template <int CD> hipError_t launch_render_shaded_cd(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
-// render_stripe_kernel (kernels_cd{3,4}_stripe.hip: 48 / 64 wide with a latent grid); other widths: nullptr / hipErrorInvalidDeviceFunction
-template <int CD> const void* render_stripe_fn_cd(const VariantKey& k);
 template <int CD> const void* render_cells_fn_cd(const VariantKey& k);
 template <int CD> const void* render_shaded_cells_fn_cd(const VariantKey& k);
 template <int CD> hipError_t launch_render_shaded_cells_cd(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 template <int CD> hipError_t launch_render_cells_cd(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
-template <int CD> hipError_t launch_render_stripe_cd(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
 // render_adjoint_kernel (kernels_cd{2,3,4}_adjoint.hip): the adjoint gradient mode up to 64 channels; other widths: nullptr / hipErrorInvalidDeviceFunction
 template <int CD> const void* render_adjoint_fn_cd(const VariantKey& k);
 template <int CD> hipError_t launch_render_adjoint_cd(const VariantKey& k, const RenderArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
@@ -78,6 +75,7 @@ hipError_t launch_eval_small(int act, bool dir, int numLayers, int grid, const E
 
 bool kernel_info(const VariantKey& k, KernelInfo* info);
 hipError_t launch_eval(const VariantKey& k, const EvalArgs& a, unsigned gridDim, unsigned blockDim, size_t ldsBytes, hipStream_t s);
+// the 48- / 64-wide latent-grid variants of render_kernel (fragment-major layer order, kernels.hpp render_layer_schedule): the gather path of those widths; nullptr elsewhere
 const void* render_stripe_fn(const VariantKey& k);
 // render_cells_kernel: render_kernel with the decoded latent grid through the cell table (NetParams::cellTable); nullptr if not compiled in
 const void* render_cells_fn(const VariantKey& k);

@@ -171,14 +171,12 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             if (smallFn && smallGrid != 1 && (O[FVSRN_OPT_FOURIER_RESYNC] ? O[FVSRN_OPT_FOURIER_RESYNC] : kFourierResync) == 1) {
                 if (const void* fn = render_small_exact_fn(net->keyScaled.act, net->keyScaled.dir, a.P.numLayers, smallTail, smallGrid)) { smallFn = fn; smallExact = true; }
             }
-            // The fragment-major variant of the 48- / 64-wide latent-grid renderers (render_stripe_kernel, kernels.hpp) is what the GATHER path of those
-            // widths runs by default since r05 (FVSRN_OPT_OVERLAP_KERNEL: -1 automatic = on, 0 = the pipelined order of render_kernel, 1 = also instead of
-            // the cell table).  Measured r05 on 64x6 + 32^3 grid, 1024^2 x 512 (profiles/r05/experiments_r05.md): FLOAT / BYTE_LINEAR gathers 25.8 - 26.1 against
-            // 26.3 Gsamples/s with no scratch at all (the pipelined order spills 76 registers); BYTE_GAUSSIAN 14.0 against 13.8 (117 against 172 spilled
-            // registers); one wave per SIMD with the 512-register budget, the other way to lose the spills, renders 8.9.
+            // 48- / 64-wide latent-grid networks on the GATHER path: render_kernel<3|4, *, 1|2, *> in the fragment-major layer order (kernels.hpp,
+            // render_layer_schedule; r03 - r04: a separate render_stripe_kernel on request).  FVSRN_OPT_OVERLAP_KERNEL = 1 takes it in place of the cell-table
+            // kernel too (A/B of the two latent-grid paths at these widths); 0 / -1: by the footprint rule.
             const void* stripeFn = nullptr;
             const bool wantCellsKernel = net->keyScaled.grid == 1 && net->cellTableBytes && useCells && O[FVSRN_OPT_OVERLAP_KERNEL] != 1;
-            if (!smallFn && !a.shaded && O[FVSRN_OPT_OVERLAP_KERNEL] != 0 && !wantCellsKernel)
+            if (!smallFn && !a.shaded && !wantCellsKernel)
                 stripeFn = render_stripe_fn(net->keyScaled);
             // every other unshaded render of a network whose decoded latent grid has a cell table: render_kernel with the grid through that table
             const void* cellsFn = nullptr;
@@ -284,7 +282,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 if (smallFn)
                     scene->lastKernel = "render_small_kernel<act " + std::to_string(ks.act) + "," + (ks.dir ? "true" : "false") + "," + std::to_string(a.P.numLayers) + ",TAIL=" +
                                         std::to_string(smallTail) + ",SGRID=" + std::to_string(smallGrid) + (smallExact ? ",ADVANCE=false>" : ">");
-                else if (stripeFn) scene->lastKernel = "render_stripe_kernel<" + v + ">";
+                else if (stripeFn) scene->lastKernel = net->kinfoScaled.renderName;  // (render_kernel<3|4, ...>: fragment-major order)
                 else if (cellsFn) scene->lastKernel = std::string(a.shaded ? "render_shaded_cells_kernel<" + vp : "render_cells_kernel<" + v) + ">";
                 else if (adjointFn) scene->lastKernel = "render_adjoint_kernel<" + vp + ">";
                 else if (a.shaded) scene->lastKernel = "render_shaded_kernel<" + vp + ">";

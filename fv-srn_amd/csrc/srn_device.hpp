@@ -373,15 +373,22 @@ __device__ __forceinline__ half8_t grid_features(const NetParams& P, const GridT
                 acc[j] = mean[j] + ya * sd[j];
             }
         } else {
+            // key frame A is decoded before key frame B is fetched (a scheduling barrier in between): the two sets of sums, records and filter
+            // weights are not live at once
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xa = acc[j] * (1.0f / 255.0f);
+                acc[j] = mean[j] + 1.4142135623730950488f * erfinv_dev((2.0f - 1e-4f) * (xa - 0.5f)) * sd[j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             float accB[8];
             grid_fetch8<true, true>(P.gridB, t, g, hLoad, accB);
             const float f = isTime ? P.gridFrac : 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float xa = acc[j] * (1.0f / 255.0f), xb = accB[j] * (1.0f / 255.0f);
-                const float ya = 1.4142135623730950488f * erfinv_dev((2.0f - 1e-4f) * (xa - 0.5f));
+                const float xb = accB[j] * (1.0f / 255.0f);
                 const float yb = 1.4142135623730950488f * erfinv_dev((2.0f - 1e-4f) * (xb - 0.5f));
-                const float va = mean[j] + ya * sd[j], vb = mean[j] + yb * sd[j];
+                const float va = acc[j], vb = mean[j] + yb * sd[j];
                 acc[j] = va + f * (vb - va);
             }
         }
@@ -1133,7 +1140,7 @@ __device__ __forceinline__ float4_t srn_layers_kmajor(const NetParams& P, const 
 }
 
 // MAYBE_NO_LAYERS: the network may consist of first + last layer only (possible without Fourier features)
-// SCHED = 1: the fragment-major order for every width (render_stripe_kernel: no register spills, see kernels.hpp)
+// SCHED = 1: the fragment-major order for every width (render_kernel<3|4, *, 1|2, *>: no register spills, kernels.hpp render_layer_schedule)
 template <int CD, int ACT, int GRID, bool HAS_DIR, int NFILL, bool MAYBE_NO_LAYERS, int SCHED = 0, class Pre, class Fill>
 __device__ __forceinline__ float4_t srn_layers(const NetParams& P, const char* lds, half8_t (&xb)[2][2 * mtiles(CD)], float px,
                                                float py, float pz, Pre&& pre, Fill&& fill, const GridPre* gpre = nullptr,

@@ -192,9 +192,9 @@ typedef enum {
     FVSRN_OPT_WORKING_GRIDS = 10,    /* network: blended fp16 working grids (what the kernels read); 0 = auto: 2 for a network with several
                                         key frames -- a time change then blends into the grid the frame in flight does not read, so
                                         two frames at different times may be in flight on two streams --, 1 otherwise  [FVSRN_WORKING_GRIDS] */
-    FVSRN_OPT_OVERLAP_KERNEL = 11,   /* scene: 48 / 64-wide latent-grid networks on the GATHER path (no cell table for this launch): -1 (default) /
-                                        1 = the fragment-major kernel variant (render_stripe_kernel: no register spills with FLOAT / BYTE_LINEAR
-                                        grids), 1 also in place of the cell-table kernel, 0 = the pipelined order     [FVSRN_OVERLAP_KERNEL] */
+    FVSRN_OPT_OVERLAP_KERNEL = 11,   /* scene: 48 / 64-wide latent-grid networks: 1 = render with the gather kernel (fragment-major layer order, no
+                                        register spills) also where the cell table would be taken; 0 / -1 = by the footprint rule
+                                        (r03 - r04: a separate spill-free kernel variant on request; r05: THE gather kernel)   [FVSRN_OVERLAP_KERNEL] */
     FVSRN_OPT_PERSISTENT_RESERVE = 12, /* scene: persistent launches leave this many workgroup slots of the chip unused, so that a kernel on
                                         another stream (the all-gather of the previous frame) finds room while the frame renders; -1 auto
                                         (0 for whole frames, 1/16 of the slots for the stripes of a multi-GPU frame)  [FVSRN_PERSISTENT_RESERVE] */

@@ -24,12 +24,12 @@ kw = dict(eye=eye, right=right, up=up, fov_y_radians=float(np.deg2rad(45.0)), st
           tf_kind=capi.TF_IDENTITY, tf_scale_absorption=20.0, tf_scale_emission=1.0)
 W, H = 1024, 512
 G = dict(grid=(16, 8))
-CASES = [("64x3 ReLU + grid, stripes (render_stripe_kernel)", dict(C=64, layers=3, activation="ReLU", **G), "stripes", {}),
+CASES = [("64x3 ReLU + grid, stripes (render_kernel, fragment-major order)", dict(C=64, layers=3, activation="ReLU", **G), "stripes", {}),
          ("64x3 ReLU + grid, stripes, render_kernel", dict(C=64, layers=3, activation="ReLU", **G), "stripes", dict(overlap_kernel=0)),
          ("64x3 ReLU + grid, frame, render_kernel", dict(C=64, layers=3, activation="ReLU", **G), "frame", {}),
-         ("64x3 ReLU + grid, frame, render_stripe_kernel", dict(C=64, layers=3, activation="ReLU", **G), "frame", dict(overlap_kernel=1)),
-         ("64x3 ReLU + grid, frame, render_stripe_kernel, not persistent", dict(C=64, layers=3, activation="ReLU", **G), "frame", dict(overlap_kernel=1, persistent=0)),
-         ("64x3 SnakeAlt + grid, stripes (render_stripe_kernel)", dict(C=64, layers=3, activation="SnakeAlt", **G), "stripes", {}),
+         ("64x3 ReLU + grid, frame, render_kernel, fragment-major order", dict(C=64, layers=3, activation="ReLU", **G), "frame", dict(overlap_kernel=1)),
+         ("64x3 ReLU + grid, frame, render_kernel, fragment-major order, not persistent", dict(C=64, layers=3, activation="ReLU", **G), "frame", dict(overlap_kernel=1, persistent=0)),
+         ("64x3 SnakeAlt + grid, stripes (render_kernel, fragment-major order)", dict(C=64, layers=3, activation="SnakeAlt", **G), "stripes", {}),
          ("64x3 SnakeAlt + grid, stripes, render_kernel", dict(C=64, layers=3, activation="SnakeAlt", **G), "stripes", dict(overlap_kernel=0)),
          ("64x3 SnakeAlt + grid, stripes, not persistent", dict(C=64, layers=3, activation="SnakeAlt", **G), "stripes", dict(persistent=0, unit_quota=0)),
          ("64x3 SnakeAlt, no grid, stripes", dict(C=64, layers=3, activation="SnakeAlt"), "stripes", {}),
