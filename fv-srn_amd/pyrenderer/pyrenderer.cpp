@@ -904,6 +904,17 @@ struct ImageEvaluatorSimple {
         if (!scene) check(fvsrn_scene_create(&d, &scene));
         else check(fvsrn_scene_update(scene, &d));
         float* dst = out.data_ptr<float>() + size_t(batch) * 8 * size_t(rows) * size_t(width);
+        // The batch dimension B of ImageEvaluatorSimpleKernel (virtual_size.z, renderer_image_evaluator_simple.cuh:36-127: ONE launch over all batch
+        // entries) as one call into the library: fvsrn_render_stripes_batch renders up to eight camera poses per launch (a work unit is (frame, pixel
+        // tile): r05).  Scenes whose light follows the camera have a per-entry scene description and keep one launch per entry.
+        if (vol && B > 1 && batch == 0 && !(dvr->brdf && dvr->brdf->lightFollowsCamera)) {
+            std::vector<float> cams(size_t(B) * 9);
+            for (int b = 0; b < B; ++b) camera->frame(&cams[size_t(b) * 9], &cams[size_t(b) * 9 + 3], &cams[size_t(b) * 9 + 6], b);
+            void* st = currentStream();
+            check(fvsrn_render_stripes_batch(&scene, &st, 1, vol->currentNetwork()->h, width, height, rank >= 0 ? stripe : 8, rank >= 0 ? rank : 0,
+                                             rank >= 0 ? world : 1, B, cams.data(), nullptr, out.data_ptr<float>(), nullptr, 0, 1.0f, nullptr));
+            break;
+        }
         if (vol && rank >= 0)
             check(fvsrn_render_stripes(scene, vol->currentNetwork()->h, width, height, stripe, rank, world, dst, nullptr, currentStream()));
         else if (vol)

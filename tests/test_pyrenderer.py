@@ -295,7 +295,10 @@ def test_batched_camera_matrices_render_one_image_per_batch_entry():
     img = ev.render(40, 24)
     assert tuple(img.shape) == (3, 8, 24, 40) and tuple(ev.extract_color(img).shape) == (3, 4, 24, 40)
     for b in range(3):
-        assert torch.equal(torch.nan_to_num(img[b], nan=-7.0), torch.nan_to_num(singles[b][0], nan=-7.0))
+        # (r05: the batch is ONE call into the library and, up to eight entries, one launch -- without the depth segments a small single launch is cut
+        # into: the same samples, re-associated sums)
+        assert torch.equal(torch.isnan(img[b]), torch.isnan(singles[b][0]))
+        assert float((torch.nan_to_num(img[b]) - torch.nan_to_num(singles[b][0])).abs().max()) < 2e-4
     assert float((img[0, :4] - img[1, :4]).abs().max()) > 1e-2
     ev.camera.set_parameters(torch.empty(0))  # back to pitch / yaw / distance
     assert ev.compute_batch_count() == 1 and tuple(ev.render(40, 24).shape) == (1, 8, 24, 40)
@@ -330,7 +333,7 @@ def test_render_stripes_through_the_module_api(world, stripe):
         rows = pr.ImageEvaluatorSimple.stripe_rows(H, stripe, r, world)
         assert tuple(parts[r].shape) == (2, 8, rows, W) and rows == H // world
     frame = pr.ImageEvaluatorSimple.Assemble_stripes(torch.stack(parts), H, stripe)
-    assert torch.equal(torch.nan_to_num(frame, nan=-7.0), torch.nan_to_num(full, nan=-7.0))
+    assert torch.equal(torch.nan_to_num(frame, nan=-7.0), torch.nan_to_num(full, nan=-7.0))  # (both sides: two cameras per launch, one depth segment)
     assert float(full[:, 3].max()) > 0.05
     with pytest.raises(Exception):
         ev.render_stripes(W, H, world, world, stripe)
