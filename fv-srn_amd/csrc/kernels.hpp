@@ -19,11 +19,18 @@ constexpr int kBlockThreads = 256;  // upper bound (launch bounds)
 #ifndef FVSRN_WAVES_PER_EU_CD2_GRID
 #define FVSRN_WAVES_PER_EU_CD2_GRID 3
 #endif
+// 112 / 128 channels: TWO waves per SIMD since r05.  r04 gave these widths the 512-register budget of one wave because their gather kernels spilled; measured r05
+// (tools/dev/wide_ab.py, 1024^2 x 512, 16-channel 32^3 grid: profiles/r05/wide_two_waves_ab_r05.txt) the second wave is worth far more than the 63 - 82 spilled registers
+// cost -- 128x2 through the cell table 18.7 -> 11.7 ms per frame, on the gather path 19.5 -> 12.6, BYTE_GAUSSIAN 29.6 -> 20.7, Fourier-only 11.7 -> 10.1, evaluate_points
+// 0.300 -> 0.206 ms per 2^22 points; 112x2 16.7 -> 10.4 ms; 128x3 28.2 -> 24.1 (its BYTE_GAUSSIAN variants +-4 %).  The shaded kernels keep one wave (> 1000 spilled registers at 256).
+#ifndef FVSRN_WAVES_PER_EU_WIDE
+#define FVSRN_WAVES_PER_EU_WIDE 2
+#endif
 constexpr int min_waves_per_simd(int CD, int GRID) {
     // 32 wide: Fourier-only and decoded-grid kernels fit the 168 registers of 3 waves per SIMD (r02, 32x4 + 16^3 grid: gathers hoisted
     // in front of the Fourier work, GridPre: 2 waves 66.8, 3 waves 69.5 Gsamples/s; without the hoist 68.5); BYTE_GAUSSIAN would spill
-    // (112 channels with a latent grid spill at 256 registers like 128: one wave per SIMD from 112 on)
-    return CD >= 7 ? 1 : (CD == 2 ? (GRID == 0 ? FVSRN_WAVES_PER_EU_CD2 : (GRID == 1 ? FVSRN_WAVES_PER_EU_CD2_GRID : FVSRN_WAVES_PER_EU)) : FVSRN_WAVES_PER_EU);
+    // (112 / 128 channels: FVSRN_WAVES_PER_EU_WIDE above)
+    return CD >= 7 ? FVSRN_WAVES_PER_EU_WIDE : (CD == 2 ? (GRID == 0 ? FVSRN_WAVES_PER_EU_CD2 : (GRID == 1 ? FVSRN_WAVES_PER_EU_CD2_GRID : FVSRN_WAVES_PER_EU)) : FVSRN_WAVES_PER_EU);
 }
 // __launch_bounds__(256, 2): at most 256 registers per lane, which also makes hipcc use the VGPR form of the MFMA
 // (accumulators in AGPRs cost one v_accvgpr_read per value before the VALU can touch them: +32 VALU per layer).

@@ -29,9 +29,12 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--stepsize", type=float, default=1.0 / 256)
     ap.add_argument("--cameras", type=int, default=64)
+    ap.add_argument("--only", default=None, help="comma-separated networks, e.g. 128x2,96x3")
     a = ap.parse_args()
     with tempfile.TemporaryDirectory() as tmp:
         for C, L in NETWORKS:
+            if a.only and "%dx%d" % (C, L) not in a.only.split(","):
+                continue
             gain = 1.0 if L < 6 else (2.3 if a.activation == "ReLU" else 2.0)
             vn = synthetic.random_network(C=C, layers=L, activation=a.activation, param=1.0, output_mode="density:direct", grid=(16, 32), seed=1234,
                                           box_min=(-0.5, -0.5, -0.5), fourier_std=1.0, grid_scale=0.01, weight_gain=gain)
