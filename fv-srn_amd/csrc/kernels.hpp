@@ -26,6 +26,12 @@ constexpr int kBlockThreads = 256;  // upper bound (launch bounds)
 #ifndef FVSRN_WAVES_PER_EU_WIDE
 #define FVSRN_WAVES_PER_EU_WIDE 2
 #endif
+// ... and the shaded renderers at 80 / 112 / 128 channels (r04: one wave, "> 1000 spilled registers at 256").  Measured r05 (tools/dev/shaded_wide_ab.py, finite
+// differences + Phong, 512^2 x 256, one -> two waves): 80x3 + grid 18.2 -> 12.3 ms through the cell table, 19.3 -> 11.9 gathering, 5.0 -> 3.4 Fourier-only; 128x2 12.4 -> 10.3
+// gathering, 8.4 -> 6.6 Fourier-only, 12.5 -> 12.8 through the cell table (profiles/r05/shaded_wide_two_waves_ab_r05.txt).
+#ifndef FVSRN_WAVES_PER_EU_SHADED_WIDE
+#define FVSRN_WAVES_PER_EU_SHADED_WIDE 2
+#endif
 constexpr int min_waves_per_simd(int CD, int GRID) {
     // 32 wide: Fourier-only and decoded-grid kernels fit the 168 registers of 3 waves per SIMD (r02, 32x4 + 16^3 grid: gathers hoisted
     // in front of the Fourier work, GridPre: 2 waves 66.8, 3 waves 69.5 Gsamples/s; without the hoist 68.5); BYTE_GAUSSIAN would spill
@@ -959,8 +965,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void render_small_kernel(NetParam
 
 // finite-difference normals / shading BRDF (SceneParams::gradientMode, brdf*): 7 network evaluations per sample
 template <int CD, int ACT, int GRID, bool HAS_DIR>
-// (r04: 80 and 112 channels spill > 1000 registers at the 256 of two waves per SIMD: one wave; 96 keeps the two it was measured with)
-__global__ __launch_bounds__(kBlockThreads, ((CD >= 7 || CD == 5) ? 1 : 2)) void render_shaded_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+// (80 / 112 / 128 channels: FVSRN_WAVES_PER_EU_SHADED_WIDE above)
+__global__ __launch_bounds__(kBlockThreads, ((CD >= 7 || CD == 5) ? FVSRN_WAVES_PER_EU_SHADED_WIDE : 2)) void render_shaded_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                unsigned long long* __restrict__ stats) {
     render_entry<CD, ACT, GRID, HAS_DIR, 1>(P, S, out, stats);
 }
@@ -968,7 +974,7 @@ __global__ __launch_bounds__(kBlockThreads, ((CD >= 7 || CD == 5) ? 1 : 2)) void
 // render_shaded_kernel<CD, ACT, 1, HAS_DIR> with the decoded latent grid through the cell table in every plain evaluation -- the sample itself and the
 // six of the finite differences, whose positions share cells like the samples of a step do (r04).  The adjoint mode's gradient pass keeps its records.
 template <int CD, int ACT, bool HAS_DIR>
-__global__ __launch_bounds__(kBlockThreads, ((CD >= 7 || CD == 5) ? 1 : 2)) void render_shaded_cells_kernel(NetParams P, SceneParams S, float* __restrict__ out,
+__global__ __launch_bounds__(kBlockThreads, ((CD >= 7 || CD == 5) ? FVSRN_WAVES_PER_EU_SHADED_WIDE : 2)) void render_shaded_cells_kernel(NetParams P, SceneParams S, float* __restrict__ out,
                                                                      unsigned long long* __restrict__ stats) {
     render_entry<CD, ACT, 1, HAS_DIR, 1, 0, true>(P, S, out, stats);
 }

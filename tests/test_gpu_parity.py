@@ -573,6 +573,10 @@ PHONG = dict(enable_phong=True, ambient=0.2, specular=0.4, magnitude_center=0.6,
     dict(net=dict(activation="Sine", output_mode="densitygrad"), fd=False, brdf=PHONG),
     # density:direct: differences of the un-clamped value
     dict(net=dict(activation="Snake", param=2.0, output_mode="density:direct"), fd=True, brdf=PHONG, tf=dict(density_min=-1.0, density_max=1.0)),
+    # r05: 80 / 112 / 128 channels run two waves per SIMD (with hundreds of spilled registers: kernels.hpp FVSRN_WAVES_PER_EU_SHADED_WIDE), both latent-grid paths
+    dict(net=dict(activation="ReLU", output_mode="density", C=80, layers=3, grid=(16, 8)), fd=True, brdf=PHONG),
+    dict(net=dict(activation="SnakeAlt", output_mode="density", C=128, layers=2, grid=(16, 8)), fd=True, brdf=PHONG),
+    dict(net=dict(activation="Sine", output_mode="density", C=112, layers=2), fd=True, brdf=PHONG),
 ])
 def test_shaded_render_matches_oracle(case):
     """GRADIENT_MODE_FINITE_DIFFERENCES (renderer_volume_tensorcores.cuh:1185-1196) and
