@@ -95,6 +95,7 @@ SYMBOLS = [
     ("fvsrn_network_get_layer", _I, [_VP, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _FP, _U16P, _U16P]),
     ("fvsrn_network_get_fourier", _I, [_VP, _U16P, _I, C.POINTER(_I)]),
     ("fvsrn_evaluate_points", _I, [_VP, _VP, _VP, _SZ, _VP, _I, _VP]),
+    ("fvsrn_evaluate_points_half", _I, [_VP, _VP, _VP, _SZ, _VP, _I, _VP]),
     ("fvsrn_evaluate_points_adjoint", _I, [_VP, _VP, _VP, _SZ, _VP, _F, _I, _VP]),
     ("fvsrn_scene_desc_size", _SZ, []),
     ("fvsrn_network_info_size", _SZ, []),
@@ -154,6 +155,8 @@ def lib() -> C.CDLL:
             pass
         l = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
+            if os.environ.get("FVSRN_LIBRARY") and not hasattr(l, name):
+                continue  # (an A/B library of an older build, tools/variant.sh: entries it lacks fail when they are called)
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
@@ -334,18 +337,23 @@ class Network:
         _check(lib().fvsrn_network_clear_gpu_resources(self._h))
 
     # -- IVolumeInterpolation.evaluate (volume_interpolation.cpp:26-127) ---------------------------------
-    def evaluate(self, positions, directions=None, out=None, stream: Optional[int] = None, world: bool = False):
-        """positions: unit-box coordinates like the reference; world=True maps world positions through the box."""
+    def evaluate(self, positions, directions=None, out=None, stream: Optional[int] = None, world: bool = False, predicted_gradient: bool = False):
+        """positions: unit-box coordinates like the reference; world=True maps world positions through the box.  The dtype of `positions`
+        picks the entry point like the reference's scalar-type dispatch: float32 -> fvsrn_evaluate_points, float16 (positions, directions
+        and values all fp16, 8 bytes per point of a scalar network) -> fvsrn_evaluate_points_half.  predicted_gradient: (n,4) = value +
+        the gradient a densitygrad* / densitycurvature* network predicts (FVSRN_EVAL_WITH_PREDICTED_GRADIENT)."""
         import torch
         n = positions.shape[0]
-        pp = _torch_ptr(positions, "torch.float32", "positions")
-        dp = _torch_ptr(directions, "torch.float32", "directions") if directions is not None else None
-        oc = self.info().output_channels
+        half = positions.dtype == torch.float16
+        dt = "torch.float16" if half else "torch.float32"
+        pp = _torch_ptr(positions, dt, "positions")
+        dp = _torch_ptr(directions, dt, "directions") if directions is not None else None
+        oc = 4 if predicted_gradient else self.info().output_channels
         if out is None:
-            out = torch.empty((n, oc), dtype=torch.float32, device=positions.device)
-        op = _torch_ptr(out, "torch.float32", "out")
-        _check(lib().fvsrn_evaluate_points(self._h, pp, dp, n, op, 1 if world else 0,
-                                           _current_stream() if stream is None else stream))
+            out = torch.empty((n, oc), dtype=positions.dtype, device=positions.device)
+        op = _torch_ptr(out, dt, "out")
+        fn = lib().fvsrn_evaluate_points_half if half else lib().fvsrn_evaluate_points
+        _check(fn(self._h, pp, dp, n, op, (1 if world else 0) | (2 if predicted_gradient else 0), _current_stream() if stream is None else stream))
         return out
 
     def evaluate_with_gradients_and_curvature(self, positions, directions=None, stream: Optional[int] = None, world: bool = False):

@@ -305,6 +305,7 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
         std::lock_guard<std::mutex> lock(net->mu);
         if (!net->deviceValid) net->pack();  // (a live network keeps its packed state: it carries the device pointers)
         std::string name = render ? net->kinfoScaled.renderName : net->kinfoScaled.evalName;  // (evaluate_points runs the re-scaled image too, r03)
+        if (!render && net->keyScaled.act == ACT_RELU01 && net->keyScaled.grid == 2) name = net->kinfo.evalName;  // (... but for BYTE_GAUSSIAN grids: evaluateImpl)
         if (render) {  // the register-resident kernel takes over for scenes with an Identity / Texture TF and no shading (renderImpl)
             const NetParams& P = net->packed.params;
             const VariantKey& k = net->keyScaled;
@@ -396,7 +397,7 @@ int fvsrn_scene_get_option(fvsrn_scene* scene, int option, int* value) {
 
 // ------------------------------------------------------------------------------------------- evaluation
 static int evaluateImpl(fvsrn_network* net, const float* d_positions, const float* d_directions, size_t n, float* d_out, int flags,
-                        bool adjoint, float adjointGridStep, void* stream) {
+                        bool adjoint, float adjointGridStep, void* stream, bool halfIO = false) {
     return guarded([&] {
         if (!net || (n > 0 && (!d_positions || !d_out))) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
         std::lock_guard<std::mutex> lock(net->mu);
@@ -412,25 +413,19 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
             EvalArgs a{net->packed.params, d_positions, d_directions, n, d_out, net->net->outputChannels()};
             // The re-scaled weight images (pack.cpp) serve evaluate_points too: SnakeAlt with its affine part in the next layer is exact
             // algebra for any input; the [0,1]-scaled ReLU image is bounded for points inside the unit box, so the kernel checks every
-            // batch of 64 points and evaluates a batch with a point outside from the plain image in global memory (kernels.hpp).
+            // batch of 64 points and runs a batch with a point outside through the same image with the unclamped activation (kernels.hpp,
+            // eval_batch_outside; r05: one launch for every n -- r03 / r04 deferred such batches to a second launch through a per-call list,
+            // ~9 us per call, and therefore took the plain image below 2^23 points).
             VariantKey evalKey = net->key;
-            a.P.evalTodo = nullptr;
-            void* evalTodo = nullptr;
-            struct FreeTodo { void*& p; hipStream_t s; ~FreeTodo() { if (p) (void)hipFreeAsync(p, s); } } freeTodo{evalTodo, s};
-            // The [0,1]-scaled ReLU image costs a second launch and a per-call list (below): ~9 us.  Measured r04 (32x4, best of interleaved
-            // repetitions, tools/dev/eval_knobs.py): 2^20 points 48 G points/s with it against 83 G on the plain image, 2^22: 93 against 107,
-            // 2^24: 119 against 116, 2^26: 117 against 110 -- the plain image below 2^23 points.
-            const bool scaledPays = net->keyScaled.act != ACT_RELU01 || n >= (size_t(1) << 23);
-            if (net->scaledImage && !adjoint && scaledPays) {
+            a.P.evalHalfIO = halfIO ? 1 : 0;
+            if (halfIO && (adjoint || (flags & FVSRN_EVAL_WITH_PREDICTED_CURVATURE)))
+                return fail(FVSRN_ERR_INVALID_ARGUMENT, "fp16 positions / values: plain evaluation and predicted gradients only");
+            // (BYTE_GAUSSIAN grids keep the plain ReLU image: their kernels decode the grid themselves and have no registers left for a second pass)
+            if (net->scaledImage && !adjoint && !(net->keyScaled.act == ACT_RELU01 && net->keyScaled.grid == 2)) {
                 evalKey = net->keyScaled;
                 a.P.ldsImage = net->scaledImage;
                 if (!net->packed.scaledBias0Exact) a.P.bias0Folded = 0;  // (a residue of the folded bias sits in the fp32 block: pack.cpp)
                 a.P.reluClamp = net->keyScaled.act == ACT_RELU01 ? 1 : 0;
-                if (net->keyScaled.act == ACT_RELU01) {  // two launches, see kernels.hpp (eval_batch_deferred); stream-ordered scratch per call
-                    evalTodo = g_temporaries.alloc(net->device, (1 + (n + 63) / 64) * sizeof(unsigned), s);
-                    HIP_CHECK(hipMemsetAsync(evalTodo, 0, sizeof(unsigned), s));
-                    a.P.evalTodo = static_cast<unsigned*>(evalTodo);
-                }
             }
             void* evalTmp = nullptr;
             struct FreeTmp { void*& p; hipStream_t s; ~FreeTmp() { if (p) (void)hipFreeAsync(p, s); } } freeTmp{evalTmp, s};
@@ -492,21 +487,6 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
             }
             if (e == hipErrorInvalidDeviceFunction)
                 e = launch_eval(evalKey, a, grid, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
-            if (e == hipSuccess && a.P.evalTodo) {  // the batches the scaled-image launch deferred (as a rule: none), from the plain image
-                EvalArgs b2 = a;
-                // (one workgroup per CU walks the list: as a rule it is empty and the launch costs a few microseconds)
-                const unsigned gridTodo = unsigned(std::min<size_t>(blocks, size_t(net->numCUs)));
-                b2.P.ldsImage = net->packed.params.ldsImage;
-                b2.P.reluClamp = 0;
-                hipError_t e2 = hipErrorInvalidDeviceFunction;
-                const VariantKey& k = net->key;
-                const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && b2.P.gridK == 1 && b2.P.bias0Folded ? 1 : 2);
-                if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 1 && !b2.P.noFourier && !b2.P.fourierNeedsFractEval && b2.P.numLayers >= 1 &&
-                    b2.P.numLayers <= 3)
-                    e2 = launch_eval_small(k.act, k.dir, b2.P.numLayers, smallGrid, b2, gridTodo, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
-                if (e2 == hipErrorInvalidDeviceFunction) e2 = launch_eval(k, b2, gridTodo, unsigned(64 * wpb), size_t(net->packed.params.ldsBytes), s);
-                e = e2;
-            }
             if (e == hipSuccess && curvature) {
                 EvalArgs c = a;
                 c.P = net->packed.params;  // (the curvature image is a variant of the plain image)
@@ -532,6 +512,12 @@ static int evaluateImpl(fvsrn_network* net, const float* d_positions, const floa
 int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const float* d_directions, size_t n, float* d_out, int flags,
                           void* stream) {
     return evaluateImpl(net, d_positions, d_directions, n, d_out, flags, false, 0.f, stream);
+}
+
+int fvsrn_evaluate_points_half(fvsrn_network* net, const void* d_positions_f16, const void* d_directions_f16, size_t n, void* d_out_f16, int flags,
+                               void* stream) {
+    return evaluateImpl(net, static_cast<const float*>(d_positions_f16), static_cast<const float*>(d_directions_f16), n, static_cast<float*>(d_out_f16), flags, false,
+                        0.f, stream, true);
 }
 
 int fvsrn_evaluate_points_adjoint(fvsrn_network* net, const float* d_positions, const float* d_directions, size_t n, float* d_out4,

@@ -40,10 +40,7 @@ struct NetParams {
     mutable unsigned long long profLast;
 #endif
     const void* ldsImage;  // device pointer
-    // evaluate_points of a ReLU network with the [0,1]-scaled image (two launches, api.cpp): evalTodo[0] = number of batches of 64 points
-    // that hold a point outside the unit box, evalTodo[1..] = their indices.  The ACT_RELU01 launch appends the batches it must not
-    // evaluate (the bound behind the scaled image does not hold there), the launch with the plain image walks that list.  null: all batches.
-    unsigned* evalTodo;
+    int evalHalfIO;        // fvsrn_evaluate_points_half: positions / directions / values of evaluate_points are fp16 (load_eval_point, write_eval_outputs)
     int ldsBytes;          // multiple of 16
     int numLayers;         // NL: number of C->C Linear layers, the first one consumes Fourier(+grid) features; 0 only with noFourier
     int noFourier;         // the "phase" fragments are the scalar first layer (3|6 -> C, bias in the constant slot): activation instead of cos

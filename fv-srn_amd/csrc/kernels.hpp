@@ -61,93 +61,139 @@ __device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* ld
 // (r04: 5 v_lshl_add_u64, 3 v_cmp_*_u64 and 4 exec-mask regions per batch of evaluate_small_kernel)
 __device__ __forceinline__ unsigned wave_in_block() { return unsigned(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))); }
 
+// A/B switches of the evaluate kernels (tools/variant.sh; the shipped build has both on)
+#ifndef FVSRN_EVAL_HALF_IO
+#define FVSRN_EVAL_HALF_IO 1
+#endif
+#ifndef FVSRN_EVAL_OUTSIDE_PASS
+#define FVSRN_EVAL_OUTSIDE_PASS 1
+#endif
+__device__ __forceinline__ bool eval_half_io(const NetParams& P) { return FVSRN_EVAL_HALF_IO && P.evalHalfIO; }
+
 template <bool HAS_DIR>
-__device__ __forceinline__ void load_eval_point(const float* __restrict__ pos, const float* __restrict__ dir, size_t n, size_t b, int lane,
+__device__ __forceinline__ void load_eval_point(const NetParams& P, const float* __restrict__ pos, const float* __restrict__ dir, size_t n, size_t b, int lane,
                                                 float (&p)[3], float (&d)[3]) {
     const size_t first = b * 64;                        // wave-uniform (scalar registers: b comes from wave_in_block())
     const unsigned cnt = unsigned(n - first < 64 ? n - first : 64);
     const unsigned j = unsigned(lane) < cnt ? unsigned(lane) : 0u;
+    if (eval_half_io(P)) {  // wave-uniform: fvsrn_evaluate_points_half -- (n,3) fp16 positions / directions, 6 bytes per point
+        const unsigned off = 6u * j;
+        const char* pb = reinterpret_cast<const char*>(pos) + 6 * first;
+        p[0] = float(*reinterpret_cast<const _Float16*>(pb + off)); p[1] = float(*reinterpret_cast<const _Float16*>(pb + (off + 2u)));
+        p[2] = float(*reinterpret_cast<const _Float16*>(pb + (off + 4u)));
+        if constexpr (HAS_DIR) {
+            const char* db = reinterpret_cast<const char*>(dir) + 6 * first;
+            d[0] = float(*reinterpret_cast<const _Float16*>(db + off)); d[1] = float(*reinterpret_cast<const _Float16*>(db + (off + 2u)));
+            d[2] = float(*reinterpret_cast<const _Float16*>(db + (off + 4u)));
+        } else { d[0] = d[1] = d[2] = 0.f; }
+        return;
+    }
     const unsigned off = 12u * j;                        // 32-bit byte offset of the lane: SGPR base + VGPR offset loads
+    // (one global_load_dwordx3 per point: r02 - r04 issued three dword loads with three offset registers)
+    typedef float float3a4_t __attribute__((ext_vector_type(3), aligned(4)));
     const char* pb = reinterpret_cast<const char*>(pos + 3 * first);
-    p[0] = *reinterpret_cast<const float*>(pb + off); p[1] = *reinterpret_cast<const float*>(pb + (off + 4u)); p[2] = *reinterpret_cast<const float*>(pb + (off + 8u));
+    const float3a4_t pv = *reinterpret_cast<const float3a4_t*>(pb + off);
+    p[0] = pv[0]; p[1] = pv[1]; p[2] = pv[2];
     if constexpr (HAS_DIR) {
         const char* db = reinterpret_cast<const char*>(dir + 3 * first);
-        d[0] = *reinterpret_cast<const float*>(db + off); d[1] = *reinterpret_cast<const float*>(db + (off + 4u)); d[2] = *reinterpret_cast<const float*>(db + (off + 8u));
+        const float3a4_t dv = *reinterpret_cast<const float3a4_t*>(db + off);
+        d[0] = dv[0]; d[1] = dv[1]; d[2] = dv[2];
     } else { d[0] = d[1] = d[2] = 0.f; }
 }
 
 // evaluate_points of a ReLU network runs the weight image whose activations are scaled into [0,1] (pack.cpp: convert + ReLU is one clamped
 // v_cvt_pk_f16_f32; the plain ReLU costs 48 v_pk_max_f16 per batch of a 32x4 network on top of the converts).  Its bound holds for positions
 // inside the unit box and directions inside [-1,1]^3 -- what a caller evaluates as a rule, but not a promise of this entry point.  So the
-// ACT_RELU01 launch checks the 64 points of every batch and hands a batch with a point outside to a second launch with the plain image
-// (NetParams::evalTodo), which as a rule finds an empty list.
-template <int ACT, bool HAS_DIR>
-__device__ __forceinline__ bool eval_batch_deferred(const NetParams& P, size_t b, int lane, float px, float py, float pz, float dx, float dy, float dz) {
-    if constexpr (ACT == ACT_RELU01) {
-        // inside the unit box <=> max |p - 1/2| <= 1/2 (a NaN fails the comparison: outside): three subtractions, one v_max3_f32 with |.|, one compare
-        // (v_max3_f32 drops NaN operands: a NaN coordinate is caught by the unordered compare of the sums; `|` instead of `||`: no exec-mask regions)
-        bool outside = bool(int(!(__builtin_fmaxf(__builtin_fmaxf(fabsf(px - 0.5f), fabsf(py - 0.5f)), fabsf(pz - 0.5f)) <= 0.5f)) | int(__builtin_isunordered(px + py, pz)));
-        if constexpr (HAS_DIR)
-            outside = bool(int(outside) | int(!(__builtin_fmaxf(__builtin_fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) <= 1.f)) | int(__builtin_isunordered(dx + dy, dz)));
-        if (__builtin_amdgcn_ballot_w64(outside) != 0) {  // wave-uniform
-            if (lane == 0) P.evalTodo[1 + atomicAdd(P.evalTodo, 1u)] = unsigned(b);
-            return true;
-        }
-    }
-    return false;
+// ACT_RELU01 kernels check the 64 points of every batch (wave-uniform result) and run a batch with a point outside through the SAME image with
+// the unclamped activation (convert, then v_pk_max_f16 with 0): the scales are powers of two, so relu(x) 2^-e is what the clamped convert
+// returns wherever the bound holds and the exact scaled activation where it does not, and the last layer takes the scale out again; the
+// phases of such a batch go through v_fract.  (r03 - r04 handed these batches to a second launch with the plain image through a per-call
+// list: a memset and a launch per call, ~9 us, which made the scaled image lose below 2^23 points.)
+template <bool HAS_DIR>
+__device__ __forceinline__ bool eval_batch_outside(float px, float py, float pz, float dx, float dy, float dz) {
+    // inside the unit box <=> max |p - 1/2| <= 1/2 (a NaN fails the comparison: outside): three subtractions, one v_max3_f32 with |.|, one compare
+    // (v_max3_f32 drops NaN operands: a NaN coordinate is caught by the unordered compare of the sums; `|` instead of `||`: no exec-mask regions)
+    bool outside = bool(int(!(__builtin_fmaxf(__builtin_fmaxf(fabsf(px - 0.5f), fabsf(py - 0.5f)), fabsf(pz - 0.5f)) <= 0.5f)) | int(__builtin_isunordered(px + py, pz)));
+    if constexpr (HAS_DIR)
+        outside = bool(int(outside) | int(!(__builtin_fmaxf(__builtin_fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) <= 1.f)) | int(__builtin_isunordered(dx + dy, dz)));
+    return FVSRN_EVAL_OUTSIDE_PASS && __builtin_expect(__builtin_amdgcn_ballot_w64(outside) != 0, 0);  // wave-uniform; the rare case
 }
-// batch index of loop iteration k: the k-th entry of the list (plain-image launch behind an ACT_RELU01 launch) or k itself
-template <int ACT>
-__device__ __forceinline__ size_t eval_batch_index(const NetParams& P, size_t k) {
-    if constexpr (ACT != ACT_RELU01) {
-        if (P.evalTodo) return size_t(unsigned(__builtin_amdgcn_readfirstlane(int(P.evalTodo[1 + k]))));
-    }
-    return k;
-}
-// the plain-image launch behind an ACT_RELU01 launch: a workgroup whose first wave is beyond the list leaves before it copies the network
-template <int ACT>
-__device__ __forceinline__ bool eval_block_has_nothing_to_do(const NetParams& P) {
-    if constexpr (ACT != ACT_RELU01) {
-        if (P.evalTodo) return size_t(blockIdx.x) * (blockDim.x >> 6) >= size_t(P.evalTodo[0]);  // workgroup-uniform
-    }
-    return false;
-}
-template <int ACT>
-__device__ __forceinline__ size_t eval_batch_count(const NetParams& P, size_t n) {
-    if constexpr (ACT != ACT_RELU01) {
-        if (P.evalTodo) return P.evalTodo[0];
-    }
-    return (n + 63) / 64;
-}
+// Fourier mode of such a batch: v_fract in front of the cosines (FM_FIRST_LAYER networks have no phases)
+constexpr int eval_outside_fmode(int FMODE) { return FMODE == FM_FIRST_LAYER ? FM_FIRST_LAYER : FM_FRACT_COS; }
 
 // output parametrization of IVolumeInterpolation::evaluate for point i (renderer_volume_tensorcores.cuh:1054-1158)
-__device__ __forceinline__ void write_eval_outputs(const NetParams& P, const float4_t& o, float* __restrict__ out, unsigned i, int outChannels) {
+template <class T>
+__device__ __forceinline__ void write_eval_outputs_as(const NetParams& P, const float4_t& o, T* __restrict__ out, unsigned i, int outChannels) {
     switch (P.outputMode) {
         case FVSRN_OUT_DENSITY:
         case FVSRN_OUT_DENSITY_GRADIENT:
         case FVSRN_OUT_DENSITY_CURVATURE:
-            out[i * outChannels] = sigmoid_f(o[0]);
+            out[i * outChannels] = T(sigmoid_f(o[0]));
             break;
         case FVSRN_OUT_RGBO:
-            out[i * 4 + 0] = sigmoid_f(o[0]);
-            out[i * 4 + 1] = sigmoid_f(o[1]);
-            out[i * 4 + 2] = sigmoid_f(o[2]);
-            out[i * 4 + 3] = softplus_f(o[3]);
+            out[i * 4 + 0] = T(sigmoid_f(o[0]));
+            out[i * 4 + 1] = T(sigmoid_f(o[1]));
+            out[i * 4 + 2] = T(sigmoid_f(o[2]));
+            out[i * 4 + 3] = T(softplus_f(o[3]));
             break;
         case FVSRN_OUT_RGBO_DIRECT:
-            out[i * 4 + 0] = fminf(fmaxf(o[0], 0.f), 1.f);
-            out[i * 4 + 1] = fminf(fmaxf(o[1], 0.f), 1.f);
-            out[i * 4 + 2] = fminf(fmaxf(o[2], 0.f), 1.f);
-            out[i * 4 + 3] = fmaxf(o[3], 0.f);
+            out[i * 4 + 0] = T(fminf(fmaxf(o[0], 0.f), 1.f));
+            out[i * 4 + 1] = T(fminf(fmaxf(o[1], 0.f), 1.f));
+            out[i * 4 + 2] = T(fminf(fmaxf(o[2], 0.f), 1.f));
+            out[i * 4 + 3] = T(fmaxf(o[3], 0.f));
             break;
         default:  // density:direct and the direct gradient modes: un-clamped
-            out[i * outChannels] = o[0];
+            out[i * outChannels] = T(o[0]);
             break;
     }
     if (outChannels == 4 && P.outputMode >= FVSRN_OUT_DENSITY_GRADIENT) {  // FVSRN_EVAL_WITH_PREDICTED_GRADIENT
         const bool cubic = P.outputMode == FVSRN_OUT_DENSITY_GRADIENT_CUBIC;  // evalNormal :1166-1183
-        for (int k = 1; k < 4; ++k) out[i * 4 + k] = cubic ? o[k] * o[k] * o[k] : o[k];
+        for (int k = 1; k < 4; ++k) out[i * 4 + k] = T(cubic ? o[k] * o[k] * o[k] : o[k]);
     }
+}
+// `out`: the first value of batch b (fp32, or fp16 behind fvsrn_evaluate_points_half: wave-uniform branch)
+__device__ __forceinline__ void write_eval_outputs(const NetParams& P, const float4_t& o, float* __restrict__ out, unsigned i, int outChannels) {
+    if (eval_half_io(P)) write_eval_outputs_as(P, o, reinterpret_cast<_Float16*>(out), i, outChannels);
+    else write_eval_outputs_as(P, o, out, i, outChannels);
+}
+// first output value of batch b
+__device__ __forceinline__ float* eval_out_of_batch(const NetParams& P, float* __restrict__ out, size_t b, int outChannels) {
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(out) + b * 64 * size_t(outChannels) * (eval_half_io(P) ? 2 : 4));
+}
+
+// positions (directions) of batch b as loaded: three fp32 values, or (HIO) three fp16 values in the low halves -- converted where they are
+// used, so that nothing waits for the load where it is issued
+template <bool HAS_DIR, bool HIO>
+__device__ __forceinline__ void load_eval_raw(const float* __restrict__ pos, const float* __restrict__ dir, size_t n, size_t b, int lane,
+                                              unsigned (&p)[3], unsigned (&d)[3]) {
+    const size_t first = b * 64;
+    const unsigned cnt = unsigned(n - first < 64 ? n - first : 64);
+    const unsigned j = unsigned(lane) < cnt ? unsigned(lane) : 0u;
+    if constexpr (HIO) {
+        const unsigned off = 6u * j;
+        const char* pb = reinterpret_cast<const char*>(pos) + 6 * first;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[c] = *reinterpret_cast<const unsigned short*>(pb + off + 2 * c);
+        if constexpr (HAS_DIR) {
+            const char* db = reinterpret_cast<const char*>(dir) + 6 * first;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d[c] = *reinterpret_cast<const unsigned short*>(db + off + 2 * c);
+        }
+    } else {
+        typedef unsigned uint3a4_t __attribute__((ext_vector_type(3), aligned(4)));
+        const unsigned off = 12u * j;
+        const uint3a4_t pv = *reinterpret_cast<const uint3a4_t*>(reinterpret_cast<const char*>(pos + 3 * first) + off);
+        p[0] = pv[0]; p[1] = pv[1]; p[2] = pv[2];
+        if constexpr (HAS_DIR) {
+            const uint3a4_t dv = *reinterpret_cast<const uint3a4_t*>(reinterpret_cast<const char*>(dir + 3 * first) + off);
+            d[0] = dv[0]; d[1] = dv[1]; d[2] = dv[2];
+        }
+    }
+}
+template <bool HIO>
+__device__ __forceinline__ float eval_raw_value(unsigned u) {
+    if constexpr (HIO) return float(__builtin_bit_cast(_Float16, static_cast<unsigned short>(u)));
+    else return __uint_as_float(u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -160,21 +206,31 @@ __device__ __forceinline__ void evaluate_body(const NetParams& P, const char* ld
     const size_t wavesPerBlock = blockDim.x >> 6;
     const size_t wave = size_t(blockIdx.x) * wavesPerBlock + wave_in_block();
     const size_t numWaves = size_t(gridDim.x) * wavesPerBlock;
-    const size_t batches = eval_batch_count<ACT>(P, n);
-    for (size_t k = wave; k < batches; k += numWaves) {  // wave-uniform trip count (scalar loop control): EXEC stays full
-        const size_t b = eval_batch_index<ACT>(P, k);
+    const size_t batches = (n + 63) / 64;
+    for (size_t b = wave; b < batches; b += numWaves) {  // wave-uniform trip count (scalar loop control): EXEC stays full
         const bool valid = unsigned(lane) < unsigned(n - b * 64 < 64 ? n - b * 64 : 64);
-        float np_[3], nd_[3];  // (the next batch is not fetched ahead here: six more live registers for the wide kernels, +3 % at 32 wide)
-        load_eval_point<HAS_DIR>(pos, dir, n, b, lane, np_, nd_);
+        // (the next batch is not fetched ahead here.  r03: six more live registers for the wide kernels, +3 % at 32 wide; r05, with one dwordx3 per
+        // point and three registers: 48x5, 64x6 and 64x6 + grid the same within 0.5 %, two waves per SIMD hide the fetch)
+        float np_[3], nd_[3];
+        load_eval_point<HAS_DIR>(P, pos, dir, n, b, lane, np_, nd_);
         float px = np_[0], py = np_[1], pz = np_[2];
         const float dx = nd_[0], dy = nd_[1], dz = nd_[2];
         // renderer_volume_tensorcores.cuh:744-746
         px = (px - P.boxMin[0]) * P.invBoxSize[0];
         py = (py - P.boxMin[1]) * P.invBoxSize[1];
         pz = (pz - P.boxMin[2]) * P.invBoxSize[2];
-        if (eval_batch_deferred<ACT, HAS_DIR>(P, b, lane, px, py, pz, dx, dy, dz)) continue;
-        const float4_t o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz);
-        if (valid) write_eval_outputs(P, o, out + b * 64 * size_t(outChannels), unsigned(lane), outChannels);  // (wave-uniform base, 32-bit lane offset)
+        float4_t o;
+        if constexpr (ACT == ACT_RELU01 && GRID == 2) {
+            // BYTE_GAUSSIAN grids (decode in the kernel): two copies of the forward pass cost 110 - 170 spilled registers in both; evaluate_points takes
+            // the plain image for these networks (api.cpp), and this variant is the unclamped pass for every batch -- correct for any position
+            o = srn_forward<CD, ACT_RELU, GRID, HAS_DIR, eval_outside_fmode(FMODE)>(P, lds, px, py, pz, dx, dy, dz);
+        } else if constexpr (ACT == ACT_RELU01) {
+            if (eval_batch_outside<HAS_DIR>(px, py, pz, dx, dy, dz)) o = srn_forward<CD, ACT_RELU, GRID, HAS_DIR, eval_outside_fmode(FMODE)>(P, lds, px, py, pz, dx, dy, dz);
+            else o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz);
+        } else {
+            o = srn_forward<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz);
+        }
+        if (valid) write_eval_outputs(P, o, eval_out_of_batch(P, out, b, outChannels), unsigned(lane), outChannels);  // (wave-uniform base, 32-bit lane offset)
     }
 }
 
@@ -186,14 +242,13 @@ __global__ __launch_bounds__(kBlockThreads, min_waves_per_simd(CD, GRID)) void e
                                                                  const float* __restrict__ dir, size_t n,
                                                                  float* __restrict__ out, int outChannels) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    if (eval_block_has_nothing_to_do<ACT>(P)) return;
     load_network_to_lds(P, lds);
     if constexpr (GRID == 0) {  // a latent grid needs Fourier features (SceneNetwork::valid)
         if (P.noFourier) return evaluate_body<CD, ACT, GRID, HAS_DIR, FM_FIRST_LAYER>(P, lds, pos, dir, n, out, outChannels);
     }
-    // the [0,1]-scaled ReLU image only ever sees positions inside the unit box (eval_batch_deferred hands the others to the plain image):
-    // the renderer's bound on the phases holds for it, not the one for arbitrary positions (r03: no v_fract for the 2^9 ladder of the 64-wide
-    // bench network, like in the renderer since r02)
+    // the batches the [0,1]-scaled ReLU image takes on its fast path hold positions inside the unit box only (evaluate_body): the renderer's
+    // bound on the phases holds for them, not the one for arbitrary positions (r03: no v_fract for the 2^9 ladder of the 64-wide bench
+    // network, like in the renderer since r02)
     const int needsFract = ACT == ACT_RELU01 ? P.fourierNeedsFractPlain : P.fourierNeedsFractEval;
     if (needsFract) evaluate_body<CD, ACT, GRID, HAS_DIR, FM_FRACT_COS>(P, lds, pos, dir, n, out, outChannels);
     else evaluate_body<CD, ACT, GRID, HAS_DIR, FM_COS>(P, lds, pos, dir, n, out, outChannels);
@@ -215,7 +270,7 @@ __device__ __forceinline__ void evaluate_gradient_body(const NetParams& P, const
     for (size_t b = wave; b < batches; b += numWaves) {
         const size_t i = b * 64 + lane;
         float np_[3], nd_[3];
-        load_eval_point<HAS_DIR>(pos, dir, n, b, lane, np_, nd_);
+        load_eval_point<HAS_DIR>(P, pos, dir, n, b, lane, np_, nd_);
         const float px = (np_[0] - P.boxMin[0]) * P.invBoxSize[0];
         const float py = (np_[1] - P.boxMin[1]) * P.invBoxSize[1];
         const float pz = (np_[2] - P.boxMin[2]) * P.invBoxSize[2];
@@ -225,7 +280,7 @@ __device__ __forceinline__ void evaluate_gradient_body(const NetParams& P, const
             o[1] = o[2] = o[3] = 0.f;
             float v[4];
             // (value through the same switch as evaluate; a scalar network's parametrization only touches channel 0)
-            write_eval_outputs(P, o, v, 0, 1);
+            write_eval_outputs_as(P, o, v, 0u, 1);
             *reinterpret_cast<float4_t*>(out + 4 * i) = float4_t{v[0], gx, gy, gz};
         }
     }
@@ -248,11 +303,29 @@ __global__ __launch_bounds__(kBlockThreads, 1) void evaluate_gradient_kernel(Net
 // evaluate_kernel for 32-wide Fourier-only networks with NLC <= 3 C->C layers: weights and biases in registers (ResidentNet,
 // srn_device.hpp), 2 waves per SIMD; the phase fragments of the Fourier stage are the only LDS reads of a batch
 // EGRID = 1: with one decoded 16-channel latent chunk (srn_forward_resident_grid)
-template <int ACT, bool HAS_DIR, int NLC, int EGRID = 0>
+template <int ACT, bool HAS_DIR, int NLC, int EGRID, int FMODE>
+__device__ __forceinline__ float4_t evaluate_small_forward(const NetParams& P, const ResidentNet<NLC, EGRID>& R, const char* lds, float px, float py, float pz,
+                                                           float dx, float dy, float dz) {
+    if constexpr (EGRID == 1) {
+        return srn_forward_resident_grid<ACT, HAS_DIR, NLC, true, FMODE>(P, R, px, py, pz, dx, dy, dz);
+    } else {
+        half8_t xb[2][2];
+        return srn_layers_resident<ACT, NLC, 0, true>(
+#ifndef FVSRN_EVAL_PHASES_AHEAD
+#define FVSRN_EVAL_PHASES_AHEAD 1
+#endif
+            P, R, xb, [&]() {
+                if constexpr (FVSRN_EVAL_PHASES_AHEAD != 0) fourier_fragments_ahead<HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, xb);
+                else fourier_fragments<2, ACT, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, xb);
+            }, [](int) {});
+    }
+}
+
+// HIO: fvsrn_evaluate_points_half (fp16 positions / directions / values) as a compile-time case of this kernel
+template <int ACT, bool HAS_DIR, int NLC, int EGRID = 0, bool HIO = false>
 __global__ __launch_bounds__(kBlockThreads, 2) void evaluate_small_kernel(NetParams P, const float* __restrict__ pos, const float* __restrict__ dir,
                                                                         size_t n, float* __restrict__ out, int outChannels) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    if (eval_block_has_nothing_to_do<ACT>(P)) return;
     load_network_to_lds(P, lds);
     ResidentNet<NLC, EGRID> R;
     load_resident(P, lds, R);
@@ -260,33 +333,45 @@ __global__ __launch_bounds__(kBlockThreads, 2) void evaluate_small_kernel(NetPar
     const size_t wavesPerBlock = blockDim.x >> 6;
     const size_t wave = size_t(blockIdx.x) * wavesPerBlock + wave_in_block();
     const size_t numWaves = size_t(gridDim.x) * wavesPerBlock;
-    const size_t batches = eval_batch_count<ACT>(P, n);
+    const size_t batches = (n + 63) / 64;
+    if (wave >= batches) return;
     // Two batches of positions in flight per wave (r03): at 90 G points/s the kernel streams 1.4 TB/s of positions and values; with one
     // batch ahead a CU had 12 waves x 768 B = 9 KB of loads outstanding, which at ~2 us of HBM latency under load is what bounds it.
-    float np_[3], nd_[3], nq_[3], ne_[3];
-    if (wave < batches) load_eval_point<HAS_DIR>(pos, dir, n, eval_batch_index<ACT>(P, wave), lane, np_, nd_);
-    if (wave + numWaves < batches) load_eval_point<HAS_DIR>(pos, dir, n, eval_batch_index<ACT>(P, wave + numWaves), lane, nq_, ne_);
-    for (size_t k = wave; k < batches; k += numWaves) {
-        const size_t b = eval_batch_index<ACT>(P, k);
+    // r05: two named buffers, the loop unrolled by two, every load unconditional (beyond the end: the last batch again), one dwordx3 per point,
+    // its values converted where they are used.  The r03 form rotated one register set into the other at the top of every iteration and
+    // loaded under a condition: the wave waited at the loop head for the loads issued ONE iteration earlier -- and, the vector memory counter
+    // being in order, for the store of the previous batch behind them (s_waitcnt vmcnt(0)).  Now the store stays in flight (vmcnt(1) / (2); the
+    // first pair of batches peeled out of the loop did not get the compiler to leave more in flight: its copies of the loop-carried buffers
+    // at the latch wait for everything again): 2^24 points 128.3 -> 131.6 G points/s on one box.
+    unsigned pa[3], da[3] = {0, 0, 0}, pb[3], db[3] = {0, 0, 0};
+    const size_t lastBatch = batches - 1;
+    auto clampB = [&](size_t b) { return b < lastBatch ? b : lastBatch; };  // (scalar)
+    load_eval_raw<HAS_DIR, HIO>(pos, dir, n, wave, lane, pa, da);
+    load_eval_raw<HAS_DIR, HIO>(pos, dir, n, clampB(wave + numWaves), lane, pb, db);
+    auto batch = [&](size_t b, unsigned (&pp)[3], unsigned (&dd)[3]) {
         const bool valid = unsigned(lane) < unsigned(n - b * 64 < 64 ? n - b * 64 : 64);
-        float px = np_[0], py = np_[1], pz = np_[2];
-        const float dx = nd_[0], dy = nd_[1], dz = nd_[2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { np_[c] = nq_[c]; nd_[c] = ne_[c]; }
-        if (k + 2 * numWaves < batches) load_eval_point<HAS_DIR>(pos, dir, n, eval_batch_index<ACT>(P, k + 2 * numWaves), lane, nq_, ne_);
+        float px = eval_raw_value<HIO>(pp[0]), py = eval_raw_value<HIO>(pp[1]), pz = eval_raw_value<HIO>(pp[2]);
+        const float dx = HAS_DIR ? eval_raw_value<HIO>(dd[0]) : 0.f, dy = HAS_DIR ? eval_raw_value<HIO>(dd[1]) : 0.f, dz = HAS_DIR ? eval_raw_value<HIO>(dd[2]) : 0.f;
+        __builtin_amdgcn_sched_barrier(0);  // (the values above are read before their registers are loaded again)
+        load_eval_raw<HAS_DIR, HIO>(pos, dir, n, clampB(b + 2 * numWaves), lane, pp, dd);
         px = (px - P.boxMin[0]) * P.invBoxSize[0];
         py = (py - P.boxMin[1]) * P.invBoxSize[1];
         pz = (pz - P.boxMin[2]) * P.invBoxSize[2];
-        if (eval_batch_deferred<ACT, HAS_DIR>(P, b, lane, px, py, pz, dx, dy, dz)) continue;
         float4_t o;
-        if constexpr (EGRID == 1) {
-            o = srn_forward_resident_grid<ACT, HAS_DIR, NLC, true>(P, R, px, py, pz, dx, dy, dz);
+        if constexpr (ACT == ACT_RELU01) {  // (see eval_batch_outside)
+            if (eval_batch_outside<HAS_DIR>(px, py, pz, dx, dy, dz)) o = evaluate_small_forward<ACT_RELU, HAS_DIR, NLC, EGRID, FM_FRACT_COS>(P, R, lds, px, py, pz, dx, dy, dz);
+            else o = evaluate_small_forward<ACT, HAS_DIR, NLC, EGRID, FM_COS>(P, R, lds, px, py, pz, dx, dy, dz);
         } else {
-            half8_t xb[2][2];
-            o = srn_layers_resident<ACT, NLC, 0, true>(
-                P, R, xb, [&]() { fourier_fragments<2, ACT, HAS_DIR, FM_COS>(P, lds, px, py, pz, dx, dy, dz, xb); }, [](int) {});
+            o = evaluate_small_forward<ACT, HAS_DIR, NLC, EGRID, FM_COS>(P, R, lds, px, py, pz, dx, dy, dz);
         }
-        if (valid) write_eval_outputs(P, o, out + b * 64 * size_t(outChannels), unsigned(lane), outChannels);
+        if (valid) {
+            if constexpr (HIO) write_eval_outputs_as(P, o, reinterpret_cast<_Float16*>(out) + b * 64 * size_t(outChannels), unsigned(lane), outChannels);
+            else write_eval_outputs_as(P, o, out + b * 64 * size_t(outChannels), unsigned(lane), outChannels);
+        }
+    };
+    for (size_t b = wave; b < batches; b += 2 * numWaves) {
+        batch(b, pa, da);
+        if (b + numWaves < batches) batch(b + numWaves, pb, db);
     }
 }
 

@@ -69,8 +69,12 @@ hipError_t launch_eval_small(int act, bool dir, int numLayers, int grid, const E
     if (grid == 1) {
 #define Z(A, D, N)                                                                                                  \
         if (act == A && dir == D && numLayers == N) {                                                               \
-            hipLaunchKernelGGL((evaluate_small_kernel<A, D, N, 1>), dim3(gridDim), dim3(blockDim), ldsBytes, s, a.P, a.pos, a.dir, a.n, a.out, \
-                               a.outChannels);                                                                      \
+            if (a.P.evalHalfIO)                                                                                     \
+                hipLaunchKernelGGL((evaluate_small_kernel<A, D, N, 1, true>), dim3(gridDim), dim3(blockDim), ldsBytes, s, a.P, a.pos, a.dir, a.n, a.out, \
+                                   a.outChannels);                                                                  \
+            else                                                                                                    \
+                hipLaunchKernelGGL((evaluate_small_kernel<A, D, N, 1>), dim3(gridDim), dim3(blockDim), ldsBytes, s, a.P, a.pos, a.dir, a.n, a.out, \
+                                   a.outChannels);                                                                  \
             return hipGetLastError();                                                                               \
         }
         FVSRN_SMALL_EVAL_GRID_VARIANTS(FVSRN_SMALL_EVAL_LAYERS)
@@ -80,8 +84,12 @@ hipError_t launch_eval_small(int act, bool dir, int numLayers, int grid, const E
     if (grid != 0) return hipErrorInvalidDeviceFunction;
 #define Z(A, D, N)                                                                                                  \
     if (act == A && dir == D && numLayers == N) {                                                                   \
-        hipLaunchKernelGGL((evaluate_small_kernel<A, D, N>), dim3(gridDim), dim3(blockDim), ldsBytes, s, a.P, a.pos, a.dir, a.n, a.out, \
-                           a.outChannels);                                                                          \
+        if (a.P.evalHalfIO)                                                                                         \
+            hipLaunchKernelGGL((evaluate_small_kernel<A, D, N, 0, true>), dim3(gridDim), dim3(blockDim), ldsBytes, s, a.P, a.pos, a.dir, a.n, a.out, \
+                               a.outChannels);                                                                      \
+        else                                                                                                        \
+            hipLaunchKernelGGL((evaluate_small_kernel<A, D, N>), dim3(gridDim), dim3(blockDim), ldsBytes, s, a.P, a.pos, a.dir, a.n, a.out, \
+                               a.outChannels);                                                                      \
         return hipGetLastError();                                                                                   \
     }
     FVSRN_SMALL_EVAL_VARIANTS(FVSRN_SMALL_EVAL_LAYERS)

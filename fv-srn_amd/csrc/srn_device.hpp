@@ -762,6 +762,34 @@ __device__ __forceinline__ void fourier_fragments(const NetParams& P, const char
     fourier_fragments_tile<CD, ACT, HAS_DIR, FMODE>(P, lds, b0[1], xb[1]);
 }
 
+// fourier_fragments for CD = 2 (one M tile) with BOTH phase MFMAs ahead of the cosines: the second one runs while the first tile's
+// transcendentals issue -- one exposed MFMA latency per batch instead of two (evaluate_small_kernel, r05; 16 more live registers in the
+// Fourier stage, which is not where that kernel's register peak is)
+template <bool HAS_DIR, int FMODE>
+__device__ __forceinline__ void fourier_fragments_ahead(const NetParams& P, const char* lds, float px, float py, float pz, float dx,
+                                                        float dy, float dz, half8_t (&xb)[2][2]) {
+    static_assert(FMODE != FM_FIRST_LAYER, "Fourier networks only");
+    constexpr int NPASS = HAS_DIR ? 4 : 2;
+    const int lane = lane_id();
+    half8_t b0[2];
+    phase_operands<HAS_DIR, true>(px, py, pz, dx, dy, dz, lane >> 5, b0);
+    const half8_t a = lds_frag(lds, P.offPhase, lane);
+    floatx16 d[2];
+    {
+        const floatx16 z = {0};
+        d[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b0[0], z, 0, 0, 0);
+        d[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b0[1], z, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        phase_cos<FMODE>(d[t], NPASS);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d[t], q, 0.f, 0.f, xb[t][0], xb[t][1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int CD>
 __device__ __forceinline__ void feature_fragments(const floatx16 (&f)[2][mtiles(CD)], half8_t (&xb)[2][2 * mtiles(CD)]) {
 #pragma unroll
@@ -1387,7 +1415,7 @@ __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, cons
 
 // 32-wide network with one 16-channel latent grid chunk, resident in registers: direct Fourier features (one phase MFMA + v_cos per
 // tile), the tile's 8 gathers in flight behind them (GridPre order), then srn_layers_resident with the latent K step
-template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
+template <int ACT, bool HAS_DIR, int NLC, bool ALL4, int FMODE = FM_COS>
 __device__ __forceinline__ float4_t srn_forward_resident_grid(const NetParams& P, const ResidentNet<NLC, 1>& R, float px, float py, float pz,
                                                              float dx, float dy, float dz) {
     constexpr int NPASS = HAS_DIR ? 4 : 2;
@@ -1411,7 +1439,7 @@ __device__ __forceinline__ float4_t srn_forward_resident_grid(const NetParams& P
     for (int t = 0; t < 2; ++t) {
         if (t == 1) grid_load(P.grid, gt[1], 0, kTapHalfInOffset, raw);
         __builtin_amdgcn_sched_barrier(0);
-        phase_cos<FM_COS>(d[t], NPASS);
+        phase_cos<FMODE>(d[t], NPASS);
 #pragma unroll
         for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d[t], q, 0.f, 0.f, xb[t][0], xb[t][1]);
         __builtin_amdgcn_sched_barrier(0);

@@ -440,13 +440,22 @@ struct VolumeInterpolationNetwork : IVolumeInterpolation {
         // IVolumeInterpolation::evaluate, renderer/volume_interpolation.cpp:26-127
         TORCH_CHECK(positions.is_cuda(), "positions must reside on the GPU");
         TORCH_CHECK(positions.dim() == 2 && positions.size(1) == 3, "positions must be of shape (N,3)");
+        if (direction.has_value() && direction->defined())
+            TORCH_CHECK(direction->is_cuda() && direction->dim() == 2 && direction->size(1) == 3, "direction must be a CUDA tensor of shape (N,3)");
+        const int channels = outputChannels();
+        if (positions.scalar_type() == c10::kHalf) {
+            // the scalar-type dispatch of :40-42 for a third type: fp16 positions / directions / values without conversion passes (fvsrn_evaluate_points_half)
+            const torch::Tensor ph = positions.contiguous();
+            torch::Tensor dh;
+            if (direction.has_value() && direction->defined()) dh = direction->to(c10::kHalf).contiguous();
+            torch::Tensor outh = torch::empty({ph.size(0), channels}, ph.options());
+            check(fvsrn_evaluate_points_half(currentNetwork()->h, ph.data_ptr(), dh.defined() ? dh.data_ptr() : nullptr, size_t(ph.size(0)), outh.data_ptr(), 0,
+                                             currentStream()));
+            return outh;
+        }
         torch::Tensor p = positions.to(c10::kFloat).contiguous();
         torch::Tensor d;
-        if (direction.has_value() && direction->defined()) {
-            TORCH_CHECK(direction->is_cuda() && direction->dim() == 2 && direction->size(1) == 3, "direction must be a CUDA tensor of shape (N,3)");
-            d = direction->to(c10::kFloat).contiguous();
-        }
-        const int channels = outputChannels();
+        if (direction.has_value() && direction->defined()) d = direction->to(c10::kFloat).contiguous();
         torch::Tensor out = torch::empty({p.size(0), channels}, p.options());
         check(fvsrn_evaluate_points(currentNetwork()->h, p.data_ptr<float>(), d.defined() ? d.data_ptr<float>() : nullptr,
                                     size_t(p.size(0)), out.data_ptr<float>(), 0, currentStream()));

@@ -239,6 +239,14 @@ int fvsrn_network_cell_table_stats(const fvsrn_network* net, unsigned long long 
 #define FVSRN_EVAL_WITH_PREDICTED_CURVATURE 4
 int fvsrn_evaluate_points(fvsrn_network* net, const float* d_positions, const float* d_directions,
                           size_t n, float* d_out, int flags, void* stream);
+/* The same call with fp16 tensors: d_positions_f16 (n,3), d_directions_f16 (n,3) or NULL, d_out_f16 (n, output_channels | 4) -- 8 instead of
+ * 16 bytes per point of a scalar network.  The reference's kernel rounds the normalized position and the direction to half before its first
+ * layer (renderer_volume_tensorcores.cuh:770-772, 785-787, 813-817) and its network output is a half; with the unit box of this call a
+ * caller that holds its positions in fp16 gets bit for bit the network inputs of the fp32 call, and gives up only the bits of the fp32
+ * output parametrization that do not fit a half.  The reference's entry point dispatches on the tensor's scalar type, float or double
+ * (volume_interpolation.cpp:40-42, KERNEL_DOUBLE_PRECISION :57-59); this is the same dispatch for a third type.  flags: FVSRN_EVAL_WORLD_POSITIONS, FVSRN_EVAL_WITH_PREDICTED_GRADIENT. */
+int fvsrn_evaluate_points_half(fvsrn_network* net, const void* d_positions_f16, const void* d_directions_f16,
+                               size_t n, void* d_out_f16, int flags, void* stream);
 /* IVolumeInterpolation::evaluateWithGradient (volume_interpolation.cpp:128-243) of a VolumeInterpolationNetwork in
  * GRADIENT_MODE_ADJOINT_METHOD: d_out4 is (n,4) = value (as fvsrn_evaluate_points) + the analytic gradient of output 0 w.r.t. the
  * normalized (unit-box) position (evalNormal, renderer_volume_tensorcores.cuh:1198-1540; computed in forward mode,

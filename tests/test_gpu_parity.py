@@ -93,21 +93,32 @@ def test_evaluate_ragged_sizes(n, net_kw):
 
 
 @pytest.mark.parametrize("net_kw", [dict(C=32, layers=4), dict(C=32, layers=4, grid=(16, 8)), dict(C=64, layers=3, grid=(16, 8)), dict(C=48, layers=5),
-                                    dict(C=32, layers=2)])
-@pytest.mark.parametrize("where", ["inside", "mixed", "outside", "one_point_outside"])
+                                    dict(C=32, layers=2), dict(golden="g1_dir2_c32l4_relu_density"), dict(C=96, layers=3, grid=(16, 8), fourier_std=0.5),
+                                    dict(C=32, layers=4, grid=(16, 8), encoding=2)],
+                         ids=lambda k: k["golden"] if "golden" in k else "c%dl%d%s" % (k["C"], k["layers"], "grid" if "grid" in k else "") + ("enc%d" % k["encoding"] if "encoding" in k else ""))
+@pytest.mark.parametrize("where", ["inside", "mixed", "outside", "one_point_outside", "far", "nan"])
 def test_evaluate_points_relu_scaled_image_and_points_outside_the_box(net_kw, where):
     """evaluate_points of a ReLU network runs the [0,1]-scaled weight image (one clamped convert per activation pair); its bound only
-    holds inside the unit box, so batches of 64 points with a point outside are deferred to a second launch with the plain image
-    (kernels.hpp, eval_batch_deferred).  Every mixture must equal the oracle and the network with the scaled image switched off."""
+    holds inside the unit box, so a batch of 64 points with a point outside goes through the same image with the unclamped activation
+    and v_fract in front of its cosines (kernels.hpp, eval_batch_outside; one launch since r05 -- r03 / r04 deferred such batches to a
+    second launch with the plain image).  Every mixture must equal the oracle and the network with the scaled image switched off."""
     import torch
     from fvsrn_amd import capi, volnet_io
-    vn = util.random_network(activation="ReLU", output_mode="density:direct", seed=91, grid_scale=0.3, **net_kw)
+    if "golden" in net_kw:  # a reference-import fixture whose network takes the view direction
+        vn = util.golden_to_volnet(*util.load_golden(net_kw["golden"]))
+    else:
+        vn = util.random_network(activation="ReLU", output_mode="density:direct", seed=91, grid_scale=0.3, **net_kw)
     net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
     plain = capi.Network.from_volnet(volnet_io.save_volnet(vn))
     plain.set_option("relu_clamp", 0)
     rng = np.random.RandomState(17)
     n = 64 * 37 + 19
     pos = rng.uniform(0.0, 1.0, (n, 3)).astype(np.float32)
+    dirs = None
+    if "golden" in net_kw:
+        dirs = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32)
+        if where in ("mixed", "outside"):
+            dirs[rng.rand(n) < 0.2] *= 1.7  # directions outside [-1,1]^3 take the unclamped pass too
     if where == "mixed":
         far = rng.rand(n) < 0.3
         pos[far] = rng.uniform(-0.7, 1.8, (int(far.sum()), 3)).astype(np.float32)
@@ -115,15 +126,82 @@ def test_evaluate_points_relu_scaled_image_and_points_outside_the_box(net_kw, wh
         pos = rng.uniform(1.01, 1.6, (n, 3)).astype(np.float32)
     elif where == "one_point_outside":
         pos[64 * 20 + 5, 1] = -0.01
+    elif where == "far":  # up to four box sizes away: the documented range of the phases (pack.cpp, fourierNeedsFractEval)
+        far = rng.rand(n) < 0.5
+        pos[far] = rng.uniform(-3.0, 4.0, (int(far.sum()), 3)).astype(np.float32)
     pos[0] = (0.0, 1.0, 0.0)  # the faces themselves are inside
+    ref = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos, dirs)
+    if where == "nan":  # a NaN coordinate: its batch is "outside", its own value NaN (or whatever the plain image returns), the other 63 points unharmed
+        pos[64 * 11 + 7, 2] = np.nan
     p = torch.from_numpy(pos).cuda()
-    out, ref_plain = net.evaluate(p), plain.evaluate(p)
+    dd = torch.from_numpy(dirs).cuda() if dirs is not None else None
+    out, ref_plain = net.evaluate(p, dd), plain.evaluate(p, dd)
     torch.cuda.synchronize()
-    ref = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos)
     scale = max(1.0, float(np.abs(ref).max()))
-    assert np.abs(out.cpu().numpy() - ref).max() < TOL_SAME_MODEL * scale
-    assert float((out - ref_plain).abs().max()) < TOL_SAME_MODEL * scale
-    assert "ACT_RELU01" in net.kernel_name(False) and "ACT_RELU," in plain.kernel_name(False)
+    keep = np.ones(n, bool)
+    if where == "nan":
+        keep[64 * 11 + 7] = False
+    assert np.abs(out.cpu().numpy() - ref)[keep].max() < TOL_SAME_MODEL * scale
+    assert float((out - ref_plain).abs()[torch.from_numpy(keep).cuda()].max()) < TOL_SAME_MODEL * scale
+    gaussian = net_kw.get("encoding") == 2  # BYTE_GAUSSIAN grids keep the plain image in evaluate_points (api.cpp)
+    assert ("ACT_RELU," if gaussian else "ACT_RELU01") in net.kernel_name(False) and "ACT_RELU," in plain.kernel_name(False)
+
+
+@pytest.mark.parametrize("case", ["c32l4_relu", "c32l4_snakealt_rgbo", "c32l4_grid_relu", "c64l6_grid_relu_density", "g1_dir1_c32l4_snakealt_rgbo", "g1_dir2_c32l4_relu_density", "c48l5_sine", "c32l4_densitygrad",
+                                  "c32l4_world_box", "c32l4_gaussian_grid"])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 4097 + 64 * 300])
+def test_evaluate_points_half_io(case, n):
+    """fvsrn_evaluate_points_half: fp16 positions / directions in, fp16 values out (8 bytes per point of a scalar network).  With the unit box
+    the network inputs are bit for bit those of the fp32 call on the same (fp16-representable) positions -- the reference rounds the normalized
+    position to half before its first layer (renderer_volume_tensorcores.cuh:770-772) --, so the result is the fp32 call's result rounded to
+    half: checked bitwise against that, and against the oracle at the suite's tolerance plus half an fp16 ulp of the value."""
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    kw = dict(C=32, layers=4, activation="ReLU", output_mode="density:direct", seed=23)
+    if case.startswith("g1_"):  # reference-import fixtures whose networks take the view direction
+        vn = util.golden_to_volnet(*util.load_golden(case))
+    else:
+        kw.update({"c32l4_relu": {}, "c32l4_snakealt_rgbo": dict(activation="SnakeAlt", output_mode="rgbo"), "c32l4_grid_relu": dict(grid=(16, 8)),
+                   "c64l6_grid_relu_density": dict(C=64, layers=6, grid=(16, 8), output_mode="density"),
+                   "c48l5_sine": dict(C=48, layers=5, activation="Sine"), "c32l4_densitygrad": dict(output_mode="densitygrad:direct"),
+                   "c32l4_world_box": dict(box_min=(-0.5, -0.25, 0.1), box_size=(1.0, 0.5, 2.0)), "c32l4_gaussian_grid": dict(grid=(16, 8), encoding=2)}[case])
+        vn = util.random_network(**kw)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    rng = np.random.RandomState(n)
+    world = case == "c32l4_world_box"
+    pos16 = rng.uniform(0.0, 1.0, (n, 3)).astype(np.float16)
+    if world:
+        pos16 = (pos16.astype(np.float32) * np.array([1.0, 0.5, 2.0], np.float32) + np.array([-0.5, -0.25, 0.1], np.float32)).astype(np.float16)
+    if n > 1000:
+        pos16[64 * 3 + 1] = (1.25, 0.5, -0.125) if not world else (0.9, 0.5, 0.0)  # a batch with a point outside the box
+    dir16 = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float16) if case.startswith("g1_") else None
+    grad = case == "c32l4_densitygrad"
+    p16 = torch.from_numpy(pos16).cuda()
+    d16 = torch.from_numpy(dir16).cuda() if dir16 is not None else None
+    out16 = net.evaluate(p16, d16, world=world, predicted_gradient=grad)
+    out32 = net.evaluate(p16.float(), d16.float() if d16 is not None else None, world=world, predicted_gradient=grad)
+    torch.cuda.synchronize()
+    assert out16.dtype == torch.float16 and out16.shape == out32.shape
+    assert torch.equal(out16, out32.half())  # the same arithmetic, one more rounding
+    if not grad:
+        ref = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos16.astype(np.float32), dir16.astype(np.float32) if dir16 is not None else None)
+        err = np.abs(out16.float().cpu().numpy() - ref)
+        assert (err <= TOL_SAME_MODEL * max(1.0, float(np.abs(ref).max())) + np.abs(ref) * 2.0 ** -11).all()
+
+
+def test_evaluate_points_half_io_argument_checks():
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density:direct", seed=2)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    p = torch.rand(100, 3, device="cuda").half()
+    out = torch.empty((100, 4), dtype=torch.float16, device="cuda")
+    with pytest.raises(capi.FvsrnError):  # a network that predicts no gradients
+        net.evaluate(p, predicted_gradient=True)
+    rc = capi.lib().fvsrn_evaluate_points_half(net._h, p.data_ptr(), None, 100, out.data_ptr(), 4, None)  # curvature: fp32 only
+    assert rc != 0 and b"fp16" in capi.lib().fvsrn_last_error()
+    with pytest.raises(capi.FvsrnError):  # mixed dtypes
+        net.evaluate(p, out=torch.empty((100, 1), device="cuda"))
 
 
 @pytest.mark.parametrize("enc", [0, 1, 2])

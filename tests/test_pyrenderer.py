@@ -679,6 +679,9 @@ def test_network_evaluate_with_gradients_and_ray_multisampling(tmp_path):
     vol.finite_differences_stepsize = 1 / 64
     dens, grad = vol.evaluate_with_gradients(pos)
     assert torch.equal(dens, vol.evaluate(pos))
+    # fp16 positions: the scalar-type dispatch takes fvsrn_evaluate_points_half (fp16 in, fp16 out, no conversion passes) -- the fp32 result, rounded once
+    out16 = vol.evaluate(pos.half())
+    assert out16.dtype == torch.float16 and torch.equal(out16, vol.evaluate(pos.half().float()).half())
     h = 1 / 64
     for k in range(3):
         off = torch.zeros(1, 3, device="cuda")

@@ -23,14 +23,21 @@ def main():
     """One JSON line per network and batch size.  evaluate_points sits between two rooflines: 12 B in + 4 B out per point against
     HBM, the network's algorithmic FLOP per point against the matrix cores -- both are reported, the larger fraction names the bound."""
     sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1 << 24, 1 << 26]
-    only = [a for a in sys.argv[1:] if not a.isdigit()]  # workload names (default: all four)
+    only = [a for a in sys.argv[1:] if not a.isdigit() and a != "half"]  # workload names (default: all four)
+    # "half": fp16 positions in, fp16 values out (fvsrn_evaluate_points_half, 8 B per point); the default is the reference's fp32 tensors (16 B)
+    half = "half" in sys.argv[1:]
     for n in sizes:
         pos = torch.rand(n, 3, device="cuda")
+        if half:
+            pos = pos.half()
         for name, kw in [("c32l4_fourier_relu", dict(C=32, layers=4, activation="ReLU")),
                          ("c32l4_fourier_snakealt", dict(C=32, layers=4, activation="SnakeAlt")),
                          ("c32l4_grid16_relu", dict(C=32, layers=4, activation="ReLU", grid=(16, 16))),
-                         ("c64l6_grid16_relu", dict(C=64, layers=6, activation="ReLU", grid=(16, 32)))]:
-            if only and name not in only:
+                         ("c64l6_grid16_relu", dict(C=64, layers=6, activation="ReLU", grid=(16, 32))),
+                         # (only when named: the LDS kernels without a latent grid)
+                         ("c64l6_fourier_relu", dict(C=64, layers=6, activation="ReLU")),
+                         ("c48l5_fourier_snakealt", dict(C=48, layers=5, activation="SnakeAlt"))]:
+            if (only and name not in only) or (not only and name in ("c64l6_fourier_relu", "c48l5_fourier_snakealt")):
                 continue
             vn = util.random_network(output_mode="density:direct", seed=1234, **kw)
             net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
@@ -56,7 +63,8 @@ def main():
                 ms = min(ms, e0.elapsed_time(e1) / reps)
             info = net.info()
             tflops = info.flops_per_sample * n / ms / 1e9
-            gbps = 16.0 * n / ms / 1e6
+            bytes_per_point = 8 if half else 16
+            gbps = bytes_per_point * n / ms / 1e6
             # the issue roofline of bench.py (vector issue port: MFMA 8, transcendental 8.4, convert 4.4, other 2.75 cycles per wave instruction) from the
             # committed PMC profile of this kernel (profiles/r*/evaluate_points_<name>_*pmc.csv), where there is one
             import importlib.util
@@ -64,13 +72,13 @@ def main():
             bench = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(bench)
             issue = bench.issue_roofline(bench.pmc_counters("evaluate_points_" + name))
-            print(json.dumps({"workload": "evaluate_points:" + name, "points": n, "ms": ms, "points_per_s": n / ms * 1e3, "issue": issue,
+            print(json.dumps({"workload": "evaluate_points:" + name + ("_half_io" if half else ""), "points": n, "ms": ms, "points_per_s": n / ms * 1e3, "issue": issue,
                               "kernel": net.kernel_name(False),
                               "roofline": {"bound": "mfma" if tflops / MFMA_F16_PEAK_TFLOPS > gbps / HBM_PEAK_GBPS else "hbm",
                                            "mfma": {"achieved": tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F16_PEAK_TFLOPS,
                                                     "flops_per_point": info.flops_per_sample},
                                            "hbm": {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-                                                   "bytes_per_point": 16}}}), flush=True)
+                                                   "bytes_per_point": bytes_per_point}}}), flush=True)
         del pos
 
 
