@@ -58,7 +58,7 @@ HOST_US = {}
 def frame_period(net, cfg, time_keys, rank, world, frames=24, warm=8, pipelined=None, ahead=True, batch=1):
     _, _, _, W, H, steps = cfg
     kw = lambda i: b.build_scene_kwargs(capi, 2 * math.pi * (i % 64) / 64, 1.0 / steps, False)  # noqa: E731
-    pipe = tiles.StripeRenderer(net, W, H, kw(0), rank=rank, world=world, stripe=b.STRIPE, pipelined=pipelined, streams=_streams(), frames_per_submit=batch)
+    pipe = tiles.StripeRenderer(net, W, H, kw(0), rank=rank, world=world, stripe=int(os.environ.get("FVSRN_STRIPE_ROWS", b.STRIPE)), pipelined=pipelined, streams=_streams(), frames_per_submit=batch)
     t = lambda i: (0.25 * i) % (time_keys - 1) if time_keys > 1 else None  # noqa: E731
     tn = (lambda i: t(i + 1)) if (ahead and pipe.pipelined) else (lambda i: None)
 
@@ -100,8 +100,10 @@ def main():
         row["working_grids"] = net.get_option("working_grids")
         row["emulated_gather"] = os.environ.get("FVSRN_STRIPE_EMULATE_GATHER")
         for world in [int(w) for w in os.environ.get("FVSRN_STRIPE_WORLDS", "2,4,8").split(",")]:
-            worst = max(frame_period(net, cfg, keys, r, world, ahead=ahead, batch=batch, frames=max(24, 6 * batch)) for r in range(world))
+            periods = [frame_period(net, cfg, keys, r, world, ahead=ahead, batch=batch, frames=max(24, 6 * batch)) for r in range(world)]
+            worst = max(periods)
             row["world"][str(world)] = {"slowest_rank_frame_period_ms": worst, "ideal_ms": full / world, "render_only_efficiency": full / world / worst,
+                                        "rank_frame_period_ms": [round(p, 4) for p in periods], "stripe_rows": int(os.environ.get("FVSRN_STRIPE_ROWS", b.STRIPE)),
                                         "host_us_per_frame": max(HOST_US[(r, world)] for r in range(world))}
         print(json.dumps(row), flush=True)
 
