@@ -46,7 +46,9 @@ NUM_SIMDS = 256 * 4
 # (MI355X_MICROARCH.md, constants table "vector-instruction ISSUE cost"; measured here: 8.3 - 8.4, profiles/r01/microbench_issue_model.md).
 # SURVEY 8(d) prices them at a quarter of the plain VALU rate (4 lanes per clock); "frac_at_quarter_rate" restates the line for that figure.
 TRANS_LANES_PER_CLOCK = 8.0
-STRIPE = 16
+# rows per stripe of a multi-GPU frame (round-robin over the ranks).  r05: 8 (one row of pixel tiles) instead of 16 -- the ranks' shares of the headline frame at world 8 differ by
+# 2.7 % instead of 5.5 % (tools/stripe_efficiency.py, profiles/r05/stripe_efficiency_8_rows_r05.jsonl: 98.6 against 96.6 % of frame / 8; configs[2] 96.6 against 94.9 %)
+STRIPE = 8
 
 CONFIGS = {
     # name: (C, layers, grid(ch,res)|None, width, height, steps)

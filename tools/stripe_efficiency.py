@@ -75,10 +75,21 @@ def frame_period(net, cfg, time_keys, rank, world, frames=24, warm=8, pipelined=
     run(0, warm)
     pipe.finish()
     torch.cuda.synchronize()
+    # r05: every pipeline spins up for FVSRN_STRIPE_SPINUP_MS (150) of wall time before it is timed, like bench.py.  Without it the pipeline measured FIRST after a
+    # change of launch shape read 3 - 4 % slow whichever rank it was (rank 0 forward, rank 7 with FVSRN_STRIPE_RANK_ORDER=reverse: 0.303 / 0.312 ms against 0.282 - 0.299 for
+    # the others, headline at world 8) -- and the slowest rank is the figure of this tool.  A rank process of a real run renders nothing else: it is in that steady state.
+    import time
+    t_end = time.perf_counter() + 1e-3 * float(os.environ.get("FVSRN_STRIPE_SPINUP_MS", "150"))
+    first = warm
+    while time.perf_counter() < t_end:
+        run(first, warm)
+        first += warm
+        pipe.finish()
+        torch.cuda.synchronize()
     pipe.host_seconds, pipe.frames_submitted = 0.0, 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    run(warm, frames)
+    run(first, frames)
     pipe.finish()
     e1.record()
     torch.cuda.synchronize()
@@ -100,7 +111,10 @@ def main():
         row["working_grids"] = net.get_option("working_grids")
         row["emulated_gather"] = os.environ.get("FVSRN_STRIPE_EMULATE_GATHER")
         for world in [int(w) for w in os.environ.get("FVSRN_STRIPE_WORLDS", "2,4,8").split(",")]:
-            periods = [frame_period(net, cfg, keys, r, world, ahead=ahead, batch=batch, frames=max(24, 6 * batch)) for r in range(world)]
+            # (FVSRN_STRIPE_RANK_ORDER=reverse: the ranks measured last to first -- is the first pipeline of a configuration slow, or rank 0's rows?)
+            order = list(range(world))[::-1] if os.environ.get("FVSRN_STRIPE_RANK_ORDER") == "reverse" else list(range(world))
+            measured = {r: frame_period(net, cfg, keys, r, world, ahead=ahead, batch=batch, frames=max(24, 6 * batch)) for r in order}
+            periods = [measured[r] for r in range(world)]
             worst = max(periods)
             row["world"][str(world)] = {"slowest_rank_frame_period_ms": worst, "ideal_ms": full / world, "render_only_efficiency": full / world / worst,
                                         "rank_frame_period_ms": [round(p, 4) for p in periods], "stripe_rows": int(os.environ.get("FVSRN_STRIPE_ROWS", b.STRIPE)),
