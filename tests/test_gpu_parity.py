@@ -9,6 +9,8 @@ Tolerances (fp32 outputs; the kernels store activations as fp16 and accumulate i
   * rendered RGBA vs oracle FLOAT image:                                        3e-3
   * rendered RGBA vs oracle HALF image (fp16-accumulation tolerance):           2e-2
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -187,6 +189,30 @@ def test_evaluate_points_half_io(case, n):
         ref = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos16.astype(np.float32), dir16.astype(np.float32) if dir16 is not None else None)
         err = np.abs(out16.float().cpu().numpy() - ref)
         assert (err <= TOL_SAME_MODEL * max(1.0, float(np.abs(ref).max())) + np.abs(ref) * 2.0 ** -11).all()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_evaluate_points_random_cases(seed):
+    """The first 40 cases of tools/dev/fuzz_evaluate.py (3 000 of them: profiles/r05/fuzz_evaluate_3000_summary_r05.txt): random widths 16 .. 128, depths, activations,
+    latent grids in every encoding, positions inside / straddling / outside / far from the unit box, fp32 or fp16 tensors, against the oracle."""
+    import importlib.util
+    import torch
+    from fvsrn_amd import capi, volnet_io
+    spec = importlib.util.spec_from_file_location("fuzz_evaluate", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dev", "fuzz_evaluate.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    net_kw, where, pos, half = fz.draw(seed)
+    vn = util.random_network(**net_kw)
+    net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+    if half:
+        pos = pos.astype(np.float16).astype(np.float32)
+    ref = oracle.OracleNetwork(vn, oracle.ACC_FLOAT).evaluate(pos)
+    p = torch.from_numpy(pos).cuda()
+    out = net.evaluate(p.half() if half else p).float().cpu().numpy()
+    err = np.abs(out - ref) / np.maximum(1.0, np.abs(ref))
+    if half:
+        err = np.maximum(err - 2.0 ** -11, 0.0)
+    assert not np.isnan(out).any() and float(err.max()) < TOL_SAME_MODEL, (net_kw, where, half)
 
 
 def test_evaluate_points_half_io_argument_checks():
