@@ -61,14 +61,9 @@ __device__ __forceinline__ void load_network_to_lds(const NetParams& P, char* ld
 // (r04: 5 v_lshl_add_u64, 3 v_cmp_*_u64 and 4 exec-mask regions per batch of evaluate_small_kernel)
 __device__ __forceinline__ unsigned wave_in_block() { return unsigned(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))); }
 
-// A/B switches of the evaluate kernels (tools/variant.sh; the shipped build has both on)
-#ifndef FVSRN_EVAL_HALF_IO
-#define FVSRN_EVAL_HALF_IO 1
-#endif
-#ifndef FVSRN_EVAL_OUTSIDE_PASS
-#define FVSRN_EVAL_OUTSIDE_PASS 1
-#endif
-__device__ __forceinline__ bool eval_half_io(const NetParams& P) { return FVSRN_EVAL_HALF_IO && P.evalHalfIO; }
+// (r05's A/B of the run-time branches below -- fp16 I/O and the unclamped pass compiled out, profiles/r05/evaluate_ab_r05.txt -- used two build switches that are gone: a
+// build without them would have returned wrong values for fp16 tensors and for points outside the box)
+__device__ __forceinline__ bool eval_half_io(const NetParams& P) { return P.evalHalfIO != 0; }
 
 template <bool HAS_DIR>
 __device__ __forceinline__ void load_eval_point(const NetParams& P, const float* __restrict__ pos, const float* __restrict__ dir, size_t n, size_t b, int lane,
@@ -116,7 +111,7 @@ __device__ __forceinline__ bool eval_batch_outside(float px, float py, float pz,
     bool outside = bool(int(!(__builtin_fmaxf(__builtin_fmaxf(fabsf(px - 0.5f), fabsf(py - 0.5f)), fabsf(pz - 0.5f)) <= 0.5f)) | int(__builtin_isunordered(px + py, pz)));
     if constexpr (HAS_DIR)
         outside = bool(int(outside) | int(!(__builtin_fmaxf(__builtin_fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) <= 1.f)) | int(__builtin_isunordered(dx + dy, dz)));
-    return FVSRN_EVAL_OUTSIDE_PASS && __builtin_expect(__builtin_amdgcn_ballot_w64(outside) != 0, 0);  // wave-uniform; the rare case
+    return __builtin_expect(__builtin_amdgcn_ballot_w64(outside) != 0, 0);  // wave-uniform; the rare case
 }
 // Fourier mode of such a batch: v_fract in front of the cosines (FM_FIRST_LAYER networks have no phases)
 constexpr int eval_outside_fmode(int FMODE) { return FMODE == FM_FIRST_LAYER ? FM_FIRST_LAYER : FM_FRACT_COS; }
