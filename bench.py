@@ -108,7 +108,7 @@ class Runner:
     one GPU, this rank's stripes + all-gather on several.  All multi-GPU logic lives in the package."""
 
     def __init__(self, capi, net, cfg, rank, world, early_out, time_keys=1, scene_options=None, force_collective=False, gather="all", payload="planes",
-                 frames_per_submit=1):
+                 frames_per_submit=1, device="cuda", render=None, extract=None):
         from fvsrn_amd import tiles
         self.capi, self.net, self.rank, self.world = capi, net, rank, world
         self.time_keys = time_keys
@@ -122,13 +122,16 @@ class Runner:
         pipelined = pipe == "1" if pipe is not None else world > 1
         self.pipeline = tiles.StripeRenderer(net, self.W, self.H, build_scene_kwargs(capi, 0.0, self.stepsize, early_out), rank=rank,
                                              world=world, stripe=STRIPE, pipelined=pipelined, force_collective=force_collective,
-                                             frames_per_submit=frames_per_submit, **(dict(gather=gather, payload=payload) if world > 1 or force_collective else {}))
+                                             frames_per_submit=frames_per_submit, device=device, render=render, extract=extract,
+                                             **(dict(gather=gather, payload=payload) if world > 1 or force_collective else {}))
         self.K = frames_per_submit
         for sc in self.pipeline.scenes:
             for k, v in (scene_options or {}).items():
                 sc.set_option(k, v)
         self.pipelined = self.pipeline.pipelined
-        self.stats = torch.zeros(2, dtype=torch.int64, device="cuda")
+        # (device / render / extract: the host-side stand-in of tests/test_bench_record.py -- the partition, the buffers, the collectives and this
+        # file's record with gloo on the CPU; the product path is device="cuda", render=None)
+        self.stats = torch.zeros(2, dtype=torch.int64, device=device)
 
     @property
     def kernel_events(self):
@@ -165,6 +168,11 @@ class Runner:
         return self.pipeline.frame(b, k)
 
 
+def _sync():
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
 def timed_run(runner, steps, warmup, distributed, spinup_ms=0.0):
     import torch.distributed as dist
     # Clock spin-up (untimed, before the W warm-up steps): the shader clock of an idle MI355X needs a few hundred ms of load to
@@ -174,7 +182,7 @@ def timed_run(runner, steps, warmup, distributed, spinup_ms=0.0):
     if distributed and spinup_ms > 0:  # one untimed frame with its gather on every rank: RCCL sets its communicator up lazily
         runner.frames(0, 1)
         runner.finish()
-        torch.cuda.synchronize()
+        _sync()
         dist.barrier()
     t_end = time.perf_counter() + 1e-3 * spinup_ms
     i = 0
@@ -182,23 +190,24 @@ def timed_run(runner, steps, warmup, distributed, spinup_ms=0.0):
         runner.frames(i, 8, gather=False)
         i += 8
         runner.finish()
-        torch.cuda.synchronize()
+        _sync()
     # (batches are aligned to frame indices: the warm-up is rounded up to whole batches so that the timed frames start on one)
     warmup = -(-warmup // runner.K) * runner.K
     runner.frames(0, warmup)
     runner.finish()
-    torch.cuda.synchronize()
+    _sync()
     runner.stats.zero_()
     runner.kernel_events.clear()
     runner.pipeline.gather_events.clear()
+    runner.pipeline.gather_frames.clear()
     runner.pipeline.host_seconds, runner.pipeline.frames_submitted = 0.0, 0
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
+    _sync()
     t0 = time.perf_counter()
     runner.frames(warmup, steps, record=True)
     runner.finish()
-    torch.cuda.synchronize()
+    _sync()
     if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -379,6 +388,109 @@ def roofline(info, activation, evaluated_per_launch, kernel_s, workload_tag, rot
     return r
 
 
+# ---- the multi-GPU record (one invocation, every piece of evidence) -----------------------------------------------------------------
+# north_star: "frames are partitioned by image tile across the 8 GPUs of one node with RCCL gather over xGMI" -- the PRIMARY timed region of --gpus N moves the
+# eight fp32 planes of ImageEvaluatorSimple::render to rank 0; the other three (gather, payload) combinations are timed behind it in the same process group, on
+# the same frames, and ride along as "variants".
+PRIMARY_GATHER, PRIMARY_PAYLOAD = "root", "planes"
+COMBOS = [("root", "planes"), ("all", "planes"), ("root", "rgba8"), ("all", "rgba8")]
+
+
+def init_group_or_exit(backend, device_index=None):
+    """The process group of this run from the launcher's environment (RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT), and a first collective on it (RCCL brings
+    its communicator up lazily: a dead peer or an unreachable port shows there).  Any failure: the reason on stderr and exit code 3 -- never a silent
+    one-GPU measurement.  FVSRN_BENCH_INIT_TIMEOUT_S bounds the wait (default: torch's)."""
+    import datetime
+    import torch.distributed as dist
+    kw = {}
+    if os.environ.get("FVSRN_BENCH_INIT_TIMEOUT_S"):
+        kw["timeout"] = datetime.timedelta(seconds=float(os.environ["FVSRN_BENCH_INIT_TIMEOUT_S"]))
+    try:
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index), **kw)
+        else:
+            dist.init_process_group(backend=backend, **kw)
+        t = torch.ones(1, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        if int(t.item()) != dist.get_world_size():
+            raise RuntimeError("the first all-reduce over %d ranks summed to %d" % (dist.get_world_size(), int(t.item())))
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001 (c10d raises its own exception types; whatever it is, the run is over)
+        print("bench.py: the %s process group did not come up (RANK=%s WORLD_SIZE=%s MASTER_ADDR=%s MASTER_PORT=%s): %s: %s"
+              % ("RCCL" if backend == "nccl" else backend, os.environ.get("RANK"), os.environ.get("WORLD_SIZE"), os.environ.get("MASTER_ADDR"),
+                 os.environ.get("MASTER_PORT"), type(e).__name__, e), file=sys.stderr)
+        sys.stderr.flush()
+        os._exit(3)  # (a half-initialised c10d store may hang interpreter shutdown)
+
+
+def collective_identity(backend, rank, device_index, on_gpu=True):
+    """Who took part: what the group itself reports (world size), the RCCL version torch was built against / loaded, and every rank's device."""
+    import torch.distributed as dist
+    me = {"rank": rank, "pid": os.getpid(), "device_index": device_index, "device_name": None, "pci_bus_id": None}
+    if on_gpu:
+        pr = torch.cuda.get_device_properties(device_index)
+        me["device_name"] = pr.name
+        if hasattr(pr, "pci_bus_id"):
+            me["pci_bus_id"] = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))
+        if hasattr(pr, "uuid"):
+            me["uuid"] = str(pr.uuid)
+    ranks = [None] * dist.get_world_size()
+    dist.all_gather_object(ranks, me)
+    version = None
+    if backend == "nccl":
+        try:
+            version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001
+            version = "unavailable: %s" % e
+    return {"world_size_seen": dist.get_world_size(), "backend": backend, "nccl_version": version, "ranks": ranks,
+            "distinct_devices": len({(r["pci_bus_id"], r.get("uuid"), r["device_index"]) for r in ranks}) if on_gpu else None}
+
+
+def predicted_efficiency(config, world):
+    """What the one-GPU emulation says about this world size (tools/stripe_efficiency.py: every rank's share rendered in turn on ONE GPU, no collective,
+    against the whole frame in the same launch mode): the newest committed profiles/r*/stripe_efficiency*_r*.jsonl that holds the workload.  None if none."""
+    import glob
+    root = os.path.dirname(os.path.abspath(__file__))
+    best = None
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "r*", "stripe_efficiency*_r[0-9][0-9].jsonl"))):
+        with open(f) as fh:
+            for line in fh:
+                try:
+                    row = json.loads(line)
+                except ValueError:
+                    continue
+                w = (row.get("world") or {}).get(str(world))
+                if row.get("workload") == config and w and "render_only_efficiency" in w:
+                    best = {"efficiency_vs_world1": w["render_only_efficiency"], "kind": "one-GPU emulation of every rank's share, render only, no collective",
+                            "frames_per_submit": row.get("frames_per_submit"), "emulated_gather": row.get("emulated_gather"),
+                            "from": os.path.relpath(f, root)}
+    return best
+
+
+def timed_combo(make_runner, gather, payload, steps, warmup, distributed):
+    """One (gather, payload) combination on the group: its own pipeline, `steps` timed frames bracketed like the primary region; MAX over ranks."""
+    import torch.distributed as dist
+    r = make_runner(gather, payload)
+    dt, kms, ev, _ = timed_run(r, steps, warmup, True, 0.0)
+    t = torch.tensor([dt, float(ev)], dtype=torch.float64, device=r.stats.device)
+    if distributed:
+        tm = t[:1].clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        te = t[1:].clone()
+        dist.all_reduce(te, op=dist.ReduceOp.SUM)
+        dt, ev = float(tm.item()), float(te.item())
+    gms = [a.elapsed_time(b) / max(1, n) for (a, b), n in zip(r.pipeline.gather_events, r.pipeline.gather_frames)]
+    world = r.world
+    rec = {"gather": gather, "payload": payload, "steps": steps, "value": ev / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt / steps, "frames_per_s": steps / dt,
+           "collective_bytes_per_frame_and_rank": (32 if payload == "planes" else 4) * r.W * r.H // world,
+           "rank0_render_ms": sum(kms) / len(kms) if kms else None, "rank0_gather_ms": sum(gms) / len(gms) if gms else None}
+    del r
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+    return rec
+
+
 def dist_world_size(distributed):
     if not distributed:
         return 1
@@ -416,9 +528,14 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1 only: take the multi-GPU route (compact stripes, all_gather_into_tensor on the collective's stream, assemble) "
                          "with a one-rank process group, so that the RCCL path runs on a one-GPU box")
-    ap.add_argument("--gather", default="all", choices=["all", "root"], help="N > 1 / --force-collective: the frame on every rank (all-gather) or on rank 0 only")
-    ap.add_argument("--payload", default="planes", choices=["planes", "rgba8"],
+    ap.add_argument("--gather", default=PRIMARY_GATHER, choices=["all", "root"],
+                    help="N > 1 / --force-collective, the PRIMARY timed region: the frame on rank 0 only (north_star's gather; default) or on every rank (all-gather)")
+    ap.add_argument("--payload", default=PRIMARY_PAYLOAD, choices=["planes", "rgba8"],
                     help="N > 1 / --force-collective: what travels -- the eight fp32 planes of ImageEvaluatorSimple::render, or ExtractColor'ed RGBA8 words (4 B / pixel)")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="N > 1 / --force-collective: skip the same-run extras (the whole frame on rank 0 alone before the group run, the three other "
+                         "(gather, payload) combinations behind it)")
+    ap.add_argument("--variant-steps", type=int, default=20, help="timed frames of each same-run extra")
     ap.add_argument("--frames-per-submit", type=int, default=8,
                     help="K camera poses of the rotation per call into the library, per LAUNCH (a work unit is (frame, pixel tile)) and per collective "
                          "(fvsrn_render_stripes_batch); 1 = one launch per frame, what a caller of render(width, height) gets frame by frame")
@@ -470,11 +587,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29541")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend=backend)
-        assert dist.get_world_size() == args.gpus
+        init_group_or_exit(backend, device_index)
+        if dist.get_world_size() != args.gpus:
+            print("bench.py: --gpus %d but the process group holds %d ranks" % (args.gpus, dist.get_world_size()), file=sys.stderr)
+            raise SystemExit(3)
 
     import fvsrn_amd  # noqa: F401
     from fvsrn_amd import capi, volnet_io
@@ -483,13 +599,25 @@ def main():
     time_keys = TIME_KEYS.get(args.config, 1)
     vn, net = make_network(volnet_io, capi, cfg, args.activation, time_keys)
     info = net.info()
+    identity = collective_identity(backend, rank, device_index) if collective else None
+    # Same-run reference (before the group run): rank 0 renders the whole frames alone on the plain one-GPU route, the other ranks wait at the barrier
+    world1 = None
+    if collective and not args.no_variants:
+        if rank == 0:
+            r1 = Runner(capi, net, cfg, 0, 1, args.early_out, time_keys, frames_per_submit=args.frames_per_submit)
+            dt1, k1, ev1, _ = timed_run(r1, args.variant_steps, args.warmup, False, args.spinup_ms)
+            world1 = {"value": ev1 / dt1, "unit": "samples/s", "ms_per_step": 1e3 * dt1 / args.variant_steps, "frames_per_s": args.variant_steps / dt1,
+                      "steps": args.variant_steps, "what": "rank 0 alone, whole frames, no collective, before the group run"}
+            del r1
+            torch.cuda.empty_cache()
+        dist.barrier()
     runner = Runner(capi, net, cfg, rank, world, args.early_out, time_keys, force_collective=args.force_collective, gather=args.gather, payload=args.payload,
                     frames_per_submit=args.frames_per_submit)
     dt, kernel_ms, evaluated, executed = timed_run(runner, args.steps, args.warmup, collective, args.spinup_ms)
     plan = runner.pipeline.scenes[0].last_render_info()
     launched_kernel = runner.pipeline.scenes[0].last_kernel_name()  # the launch's own account (fvsrn_scene_last_kernel_name), not a forecast from the network
     host_us = runner.pipeline.host_us_per_frame
-    gather_ms = [a.elapsed_time(b) / max(1, args.frames_per_submit) for a, b in runner.pipeline.gather_events]
+    gather_ms = [a.elapsed_time(b) / max(1, n) for (a, b), n in zip(runner.pipeline.gather_events, runner.pipeline.gather_frames)]
     # per-rank decomposition of a frame (HIP events on the render / collective streams of every rank): rank 0 prints all of them
     per_rank = None
     if collective:
@@ -532,6 +660,14 @@ def main():
         ok = torch.tensor([1 if frame_check else 0], device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         frame_check = bool(ok.item())
+
+    variants = None
+    if collective and not args.no_variants:
+        def make_runner(g, p):
+            return Runner(capi, net, cfg, rank, world, args.early_out, time_keys, force_collective=args.force_collective, gather=g, payload=p,
+                          frames_per_submit=args.frames_per_submit)
+        variants = [timed_combo(make_runner, g, p, args.variant_steps, args.frames_per_submit, distributed)
+                    for g, p in COMBOS if (g, p) != (args.gather, args.payload)]
 
     def tag_of(activation):  # the name tools/pmc_profile.sh files the PMC summary of (config, activation) under
         base = args.config if activation == "ReLU" else args.config.replace("_1024x512", "_%s_1024x512" % activation.lower())
@@ -628,6 +764,16 @@ def main():
         if per_rank is not None:
             out["per_rank"] = per_rank
             out["gather"], out["payload"] = args.gather, args.payload
+            out["rccl"] = identity
+            if world1:
+                out["world1_same_run"] = world1
+                out["efficiency_vs_same_run_world1"] = (evaluated / dt) / (world * world1["value"])
+            pred = predicted_efficiency(args.config, world) if world > 1 else None
+            if pred and world1:
+                pred["value"] = pred["efficiency_vs_world1"] * world * world1["value"]
+            out["predicted"] = pred
+            if variants is not None:
+                out["variants"] = variants
             out["collective_bytes_per_frame_and_rank"] = (32 if args.payload == "planes" else 4) * runner.W * runner.H // world
             out["stripe_launches"] = {"persistent": bool(runner.pipeline.persistent_stripes), "hw_streams_concurrent": runner.pipeline.hw_streams_concurrent,
                                       "needs": "GPU_MAX_HW_QUEUES >= 8 in the environment before the process starts (set by bench.py / launch_ranks)",

@@ -242,12 +242,19 @@ inline TemporaryPools g_temporaries;
 
 struct WrongDevice : WrongDeviceBase { using WrongDeviceBase::WrongDeviceBase; };
 // A handle's device state lives on the device that was current at its first use; every later call must run there.
+// FVSRN_DEBUG_DEVICE_SKEW=k (developer / test switch, read once): every check AFTER the binding call compares the current device with `bound + k`, i.e. a handle
+// behaves as if it had been bound k devices further on -- its next call meets the refusal below on a one-GPU box (tests/test_gpu_parity.py
+// test_wrong_device_check_fires_on_one_gpu; a second device cannot be had on a one-GPU lease).  The binding call itself and the stored index are untouched.
+inline int debugDeviceSkew() {
+    static const int skew = [] { const char* e = std::getenv("FVSRN_DEBUG_DEVICE_SKEW"); return e ? std::atoi(e) : 0; }();
+    return skew;
+}
 inline void bindOrCheckDevice(int& bound, const char* what) {
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
     if (bound < 0) bound = dev;
-    else if (bound != dev)
-        throw WrongDevice(std::string(what) + " holds resources on HIP device " + std::to_string(bound) + ", but the current device is " +
+    else if (bound + debugDeviceSkew() != dev)
+        throw WrongDevice(std::string(what) + " holds resources on HIP device " + std::to_string(bound + debugDeviceSkew()) + ", but the current device is " +
                           std::to_string(dev) + " (hipSetDevice before the call, or use one handle per device)");
 }
 

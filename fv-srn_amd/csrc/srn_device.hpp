@@ -1569,10 +1569,47 @@ __device__ __forceinline__ float4_t srn_forward_rotating_resident(const NetParam
 template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
 __device__ __forceinline__ float4_t srn_forward_rotating_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, floatx16 (&feat)[2][1],
                                                                        const floatx16 (&dfeat)[2][1], float px, float py, float pz,
-                                                                       unsigned long long validMask, bool advance = true) {
+                                                                       unsigned long long validMask, bool advance = true
+#ifdef FVSRN_ABL_SLABMOCK
+                                                                       , int mockStep = 0, half8_t mockA = half8_t{}
+#endif
+                                                                       ) {
     const int lane = lane_id();
     CellPre<1> C;
+#ifdef FVSRN_ABL_SLABMOCK
+    // TIMING MOCK (wrong results): the per-step instruction mix of a resident slab path -- 3 fma, in-slab test, 4 + 4 monomial products / converts, 4 kink
+    // operations, 3 lane-half swaps, no selection, no table fetch; every FVSRN_ABL_SLABMOCK-th step (0: never) runs the cell path as well
+    {
+        const float cx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, P.gridYf)));
+        const float a = fmaf(px, P.gridXf, cx), b = fmaf(py, P.gridYf, cx), c = fmaf(pz, P.gridZf, cx);
+        const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c));
+        const unsigned long long rem = validMask & ~__builtin_amdgcn_ballot_w64(mx <= P.gridZf * 1e30f);
+        const bool slow = rem != 0 || (FVSRN_ABL_SLABMOCK > 0 && (mockStep % FVSRN_ABL_SLABMOCK) == 0);
+        if (slow) {
+            cell_prepare<1>(P, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
+        } else {
+            const float ab = a * b, ac = a * c, bc = b * c, abc = ab * c;
+            unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{1.f, b}), half2_t));
+            unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{c, bc}), half2_t));
+            unsigned p2 = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{a, ab}), half2_t));
+            unsigned p3 = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{ac, abc}), half2_t));
+            const unsigned sm = unsigned(__builtin_bit_cast(int, a) >> 31) & 0x80008000u;
+            unsigned q2 = p2 ^ sm, q3 = p3 ^ sm;
+            auto s0 = lane_half_swap(p0, p3);
+            auto s1 = lane_half_swap(p1, q2);
+            auto s2 = lane_half_swap(p2, q3);
+            uint4_t b0 = {s0[0], s1[0], s2[0], 0u}, b1 = {s0[1], s1[1], s2[1], 0u};
+            C.gf[0] = __builtin_bit_cast(half8_t, b0);
+            C.gf[1] = __builtin_bit_cast(half8_t, b1);
+            C.ga[0] = mockA;
+            C.rem = 0;
+            C.cellOwn = 0;
+            for (int k = 0; k < 4; ++k) C.wOwn[k] = 0;
+        }
+    }
+#else
     cell_prepare<1>(P, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
+#endif
     half8_t xb[2][2];
     return srn_layers_resident<ACT, NLC, 0, ALL4, 2>(
         P, R, xb,

@@ -164,6 +164,7 @@ class StripeRenderer:
         self.pipelined = (world > 1) if pipelined is None else bool(pipelined)
         self.kernel_events = []
         self.gather_events = []
+        self.gather_frames = []
         self.frames_submitted = 0
         self.hw_streams_concurrent = None
         self.persistent_stripes = False
@@ -294,6 +295,7 @@ class StripeRenderer:
             if record and self.on_gpu:
                 g1.record()
                 self.gather_events.append((g0, g1))
+                self.gather_frames.append(n)  # frames this collective moved (a short last batch moves fewer than frames_per_submit)
             self.gather_done[b].record()
 
     def _gather_to_root(self, send, recv):
@@ -337,11 +339,11 @@ class StripeRenderer:
             self.net.set_time_and_ensemble(time, ensemble)
         self._prepared = None
         with self._stream_ctx(stream):
-            if record and self.on_gpu:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
             if self.collective:
                 stream.wait_event(self.gather_done[b])  # buffer b is free again
+            if record and self.on_gpu:  # (behind the wait: the render's duration does not include the collective that frees buffer b)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             self._render(scene, b, stats)
             if self.collective:
                 self.render_done[b].record()
@@ -400,12 +402,12 @@ class StripeRenderer:
             for sc in lanes:
                 sc.update(**scene_kws[0])
             cams = np.stack([np.concatenate([np.asarray(kw[key], np.float32).reshape(3) for key in ("eye", "right", "up")]) for kw in scene_kws])
-            if record:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(streams[0])
             if self.collective:
                 for st in streams:
                     st.wait_event(self.gather_done[b])  # buffer b is free again
+            if record:  # (behind the wait: the render's duration does not include the collective that frees buffer b)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(streams[0])
             in_call = self.collective and self.payload == "rgba8" and self.channel_mode == self._capi.CHANNEL_COLOR
             # (world == 1 -- one GPU, or force_collective's one-rank group: a whole frame has the layout of a one-rank stripe image)
             self._capi.render_stripes_batch(lanes, [st.cuda_stream for st in streams], self.net, self.W, self.H, self.stripe, self.rank, self.world, cams,

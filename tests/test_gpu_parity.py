@@ -62,6 +62,17 @@ def test_evaluate_points_golden(name):
     same = max(TOL_SAME_MODEL, 1.5 * spread) if deep else TOL_SAME_MODEL
     assert np.abs(out - out_f).max() < same
     assert np.abs(out - ref32).max() < same
+    if deep:
+        # r06: a second check that does NOT ride on the reference's fp32 / fp16 spread.  The oracle without any fp16 rounding of
+        # activations (ACC_EXACT) and its fp32-accumulate model with fp16 storage (ACC_FLOAT) bracket what a correct fp16-storage evaluator may return:
+        # element by element the HIP result is within 2e-3 of the float model, OR no further from the exact result than the float model is (+ 2e-3).
+        # A systematic 3e-3 error passes the widened bar above; it fails here wherever the float model itself sits within 1e-3 of the exact result.
+        out_x = oracle.OracleNetwork(vn, oracle.ACC_EXACT).evaluate(d["positions"], d.get("directions"))
+        near_float = np.abs(out - out_f) <= TOL_SAME_MODEL
+        inside = np.abs(out - out_x) <= np.abs(out_f - out_x) + TOL_SAME_MODEL
+        bad = ~(near_float | inside)
+        assert not bad.any(), "%d of %d elements outside the exact / float-model bracket, worst |hip - float| %.2e" % (
+            int(bad.sum()), bad.size, float(np.abs(out - out_f)[bad].max()))
     # (fp16-accumulate models at 96 / 128 channels: 1.5e-2, see tests/test_oracle_golden.py)
     bar = 1.5e-2 if int(meta["layers"].split(":")[0]) > 64 else TOL_REF_BAR
     assert np.abs(out - ref16).max() < max(bar, 1.5 * spread)
@@ -1039,6 +1050,43 @@ def test_handles_are_bound_to_their_device():
         assert e.value.code == capi.ERR_WRONG_DEVICE
     with torch.cuda.device(0):
         scene.render(net, 16, 16)
+
+
+def test_wrong_device_check_fires_on_one_gpu():
+    """r06: FVSRN_ERR_WRONG_DEVICE on a one-GPU box.  FVSRN_DEBUG_DEVICE_SKEW=1 (read once per process: a fresh interpreter) makes a
+    handle record `current + 1` as its device at its first use; the first call itself runs, every later call on that handle must be refused with the code,
+    a message naming both devices, and nothing launched."""
+    import subprocess
+    import sys
+    code = """
+import numpy as np, torch, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import util
+from oracle import oracle
+from fvsrn_amd import capi, volnet_io
+vn = util.random_network(C=32, layers=4, activation="ReLU", output_mode="density", seed=1)
+net = capi.Network.from_volnet(volnet_io.save_volnet(vn))
+eye, right, up = capi.camera_on_a_sphere("Ym", (0, 0, 0), 0.4, 0.3, 1.6)
+scene = capi.Scene(eye=eye, right=right, up=up, fov_y_radians=0.7, stepsize=1 / 16, tf_kind=capi.TF_IDENTITY, tf_scale_absorption=10.0)
+first = scene.render(net, 16, 16)          # binds: the handles now claim device 1
+torch.cuda.synchronize()
+assert float(first[0, 3].max()) > 0
+out = torch.full((1, 8, 16, 16), -5.0, device="cuda")
+for call in (lambda: scene.render(net, 16, 16, out=out), lambda: net.evaluate(torch.rand(64, 3, device="cuda"))):
+    try:
+        call()
+    except capi.FvsrnError as e:
+        assert e.code == capi.ERR_WRONG_DEVICE, e.code
+        assert "device 1" in str(e) and "current device is 0" in str(e), str(e)
+    else:
+        raise SystemExit("no error")
+torch.cuda.synchronize()
+assert float(out.min()) == -5.0 and float(out.max()) == -5.0   # the refused call wrote nothing
+print("WRONG_DEVICE_OK")
+""" % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, FVSRN_DEBUG_DEVICE_SKEW="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "WRONG_DEVICE_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_errors_are_reported():
