@@ -314,7 +314,8 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
             const bool folded = P.bias0Folded && (!net->scaledImage || net->packed.scaledBias0Exact);
             const bool cells = k.grid == 1 && net->opts[FVSRN_OPT_CELL_TABLE] != 0 && P.gridX >= 2 && P.gridY >= 2 && P.gridZ >= 2 &&
                                double(P.gridX - 1) * (P.gridY - 1) * (P.gridZ - 1) * 512.0 * ((net->packed.cfg.hiddenChannels + 31) / 32) <= 1073741824.0;  // (ensureDevice: cellTableBytes)
-            const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && folded ? (cells ? 2 : (P.gridK == 1 ? 1 : 3)) : 3);
+            const bool slabs = cells && 3.0 * double(P.gridX + 1) * (P.gridY + 1) * (P.gridZ + 1) * 1024.0 <= 1073741824.0;  // (ensureDevice: slabTableBytes)
+            const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && folded ? (slabs ? 2 : (P.gridK == 1 ? 1 : 3)) : 3);
             // (the latent-grid path is chosen per launch: FVSRN_OPT_CELL_TABLE = -1 takes the table by the footprint of a pixel tile, renderImpl)
             const std::string byFootprint = cells && net->opts[FVSRN_OPT_CELL_TABLE] == -1 ? "; cells or gathers by footprint" : "";
             if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 2 && !P.noFourier && !P.fourierNeedsFractPlain && !P.fourierClampPos && (scalarNet || colourNet) &&
@@ -380,11 +381,13 @@ int fvsrn_network_keyframe_stats(const fvsrn_network* net, unsigned long long ou
 int fvsrn_network_cell_table_stats(const fvsrn_network* net, unsigned long long out[4]) {
     if (!net || !out) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> lock(net->mu);
-    out[0] = (unsigned long long)net->cellTableBytes;
-    out[1] = net->cellTableBuilds[0];
+    // (r06: the unshaded launches of the register-resident kernels go through the SLAB table; it is the "unshaded table" of this account while they do)
+    const bool slabsInUse = net->slabTableBytes && (net->slabsWanted || (net->slabTableBuilds && !net->cellTableBuilds[0]));
+    out[0] = (unsigned long long)(slabsInUse ? net->slabTableBytes : net->cellTableBytes);
+    out[1] = net->cellTableBuilds[0] + net->slabTableBuilds;
     out[2] = net->cellTableBuilds[1];
     out[3] = 0;
-    for (const auto& w : net->workGrid) out[3] += (unsigned long long)(w.cells.cap + w.cellsPlain.cap);
+    for (const auto& w : net->workGrid) out[3] += (unsigned long long)(w.cells.cap + w.cellsPlain.cap + w.slabs.cap);
     return FVSRN_OK;
 }
 

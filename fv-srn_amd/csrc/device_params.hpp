@@ -80,6 +80,12 @@ struct NetParams {
     const void* cellTable;
     unsigned cellStride;  // bytes per cell: 512 * MT
     unsigned cellCount;   // (X - 1)(Y - 1)(Z - 1)
+    // Slab table of the working grid (r06; grid_slab_table_kernel in launch.hip; slab_prepare / slab_accumulate in srn_device.hpp): for every axis a and
+    // every cell L of the grid extended by one ghost cell per side ((X + 1)(Y + 1)(Z + 1) cells, the ghost nodes repeat the boundary nodes = clamp-to-edge),
+    // the 12 coefficient vectors of the interpolant over the cell pair (L, L + e_a) in face-centred coordinates, times the first layer's latent columns:
+    // fp16 [axis][cell][m][lane half][row 0..31][8 K slots] -- 1 KiB per slab and M tile, lane-linear: the A fragment of ONE MFMA K step whose B operand
+    // holds the sample's twelve monomials.  null: none (no grid, BYTE_GAUSSIAN, tables above the size cap).
+    // It travels in the fields above (a launch reads one table or the other): cellTable = the slab table, cellCount = (X + 1)(Y + 1)(Z + 1), cellStride = 1024 MT.
 };
 
 constexpr int kMaxFramesPerLaunch = 8;

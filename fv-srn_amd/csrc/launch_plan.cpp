@@ -142,7 +142,8 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
                 // latent grid: 2 = through the cell table (any number of latent channels), 1 = one decoded 16-channel chunk by gathers;
                 // both need the first layer's bias in its weights (bias0Folded: no time input), the resident kernels drop that bias block
-                smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.bias0Folded ? (net->cellTableBytes && useCells ? 2 : (a.P.gridK == 1 ? 1 : 3)) : 3);
+                // (r06: SGRID = 2 reads the SLAB table -- the resident pair of cells, srn_device.hpp -- where r04 / r05 read the cell table)
+                smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.bias0Folded ? (net->slabTableBytes && useCells ? 2 : (a.P.gridK == 1 ? 1 : 3)) : 3);
                 if (O[FVSRN_OPT_SMALL_KERNEL] != 0 && net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && !a.shaded && k.CD == 2 && smallGrid <= 2 && !a.P.noFourier && !a.P.fourierNeedsFract &&
                     !a.P.fourierClampPos &&  // (the resident kernels compile the position clamp out)
                     a.P.numLayers >= 1 && a.P.numLayers <= 3 && (rgbo || (scalarNet && d.tf_kind != FVSRN_TF_NONE)))
@@ -188,8 +189,14 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             if (a.shaded && d.gradient_mode != FVSRN_GRADIENT_ADJOINT_METHOD && net->key.grid == 1 && net->cellTableBytes && useCells)
                 cellsFn = render_shaded_cells_fn(net->key);
             // the table itself: built by the first launch that goes through it (and from then on with every blend, until a launch does not)
-            if ((smallFn && smallGrid == 2) || cellsFn) a.P.cellTable = net->ensureCellTable(a.shaded, s);
+            if (cellsFn) a.P.cellTable = net->ensureCellTable(a.shaded, s);
             else (a.shaded ? net->cellsPlainWanted : net->cellsWanted) = false;
+            if (smallFn && smallGrid == 2) {  // (the slab table travels in the cell table's fields: device_params.hpp)
+                a.P.cellTable = net->ensureSlabTable(s);
+                a.P.cellCount = unsigned(net->slabTableBytes / (3 * 1024));
+                a.P.cellStride = 1024u;
+            }
+            else if (!a.shaded) net->slabsWanted = false;
             net->beginUse(s);
             struct Done { fvsrn_network* n; hipStream_t s; ~Done() { try { n->endUse(s); } catch (...) {} } } done{net, s};
             const void* altFn = smallFn ? smallFn : (stripeFn ? stripeFn : (cellsFn ? cellsFn : adjointFn));

@@ -532,6 +532,174 @@ __device__ __forceinline__ void cells_accumulate(const NetParams& P, const CellP
     }
 }
 
+// ---- latent grid through resident slabs (r06) --------------------------------------------------------------------------------------
+// The cell path above re-derives, at EVERY step, each lane's cell and eight weights (19 + 15 vector instructions), picks the wave's two cells
+// (two v_readlane and their scalar chain), fetches their table entries and assembles the B fragments with eight v_cndmask and four lane-half swaps:
+// 67 vector + 11 scalar instructions per wave step for two MFMAs (r05 PMC, 32 x 4 + 16^3: 197.9 VALU per step against 130.3 without a grid).  But
+// the samples of a wave step move by 0.03 cells per step: the wave stays inside the same PAIR of face-adjacent cells -- a "slab" -- for ten and
+// more steps (tools/dev/slab_sim.py: 85 % of the steps of the 16^3 headline frame, 65 % at 32^3).  Inside a slab (axis a, cells L and L + e_a) the
+// trilinear interpolant is, in coordinates centred on the shared face (xi_a in [-1/2, 1/2] over BOTH cells, xi_b / xi_c over the cell),
+//     f = sum over {1, xi_a, |xi_a|} x {1, xi_b, xi_c, xi_b xi_c} of 12 coefficients        (piecewise linear along a: the kink is the |xi_a| term)
+// with NO reference to which of the two cells a sample is in: no per-lane cell index, no membership mask, no selection.  So the slab's table entry
+// (12 coefficient vectors W_latent . (combination of the 12 corner vectors), fp16, 1 KiB per M tile: grid_slab_table_kernel, launch.hip) stays in four
+// registers as the A fragment, and a step costs three fma for the coordinates, one v_max3 + v_cmp for "every valid lane is inside", four products, six
+// packs (two of them sign flips of a-containing pairs), three lane-half swaps.  The table is indexed over the grid EXTENDED by one ghost cell per
+// side whose outer nodes repeat the boundary nodes: interpolating between equal values is the texture unit's clamp-to-edge, so the coordinate clamps
+// of grid_tap / cell_tap disappear as well.
+// A step with a valid lane outside the resident slab picks a new slab (slab_select: the cell of the first valid lane, paired with the cell of the
+// first valid lane elsewhere, or with its +x neighbour), fetches its entry, and covers the lanes outside it -- a few percent of the steps have any,
+// at the corners of the cell lattice -- with further slabs tile by tile (slab_accumulate), masked.
+constexpr float kSlabHalf = 0.5f + 1.0f / 8192.0f;  // in-slab test with a tolerance (the polynomial extends smoothly: 1e-4 of a cell outside costs nothing)
+
+struct SlabFrame {
+    float ns[3];  // roles a, b, c: position -> slab coordinate scale (N / 2 along the slab axis, N across), wave-uniform
+    float c[3];   // ... and offset
+    int axis;     // the slab axis (0 x, 1 y, 2 z; roles b, c = the next two axes cyclically), -1: no slab yet
+};
+template <int MT>
+struct SlabState {  // what stays resident along a ray tile
+    SlabFrame f;
+    half8_t a[MT];
+};
+struct SlabPre {  // what the first layer needs of this step
+    half8_t gf[2];           // B fragments of the two column tiles for the resident slab
+    unsigned long long rem;  // valid samples outside it
+    float px, py, pz;        // (for their slabs: slab_accumulate)
+};
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ float uniform_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+
+// slab coordinates of this lane's sample and whether it lies inside the slab
+__device__ __forceinline__ bool slab_coords(const SlabFrame& f, float px, float py, float pz, float& a, float& b, float& c) {
+    // wave-uniform branches (the empty asm keeps hipcc from turning them into six v_cndmask)
+    if (f.axis == 0) {
+        asm volatile("");
+        a = fmaf(px, f.ns[0], f.c[0]); b = fmaf(py, f.ns[1], f.c[1]); c = fmaf(pz, f.ns[2], f.c[2]);
+    } else if (f.axis == 1) {
+        asm volatile("");
+        a = fmaf(py, f.ns[0], f.c[0]); b = fmaf(pz, f.ns[1], f.c[1]); c = fmaf(px, f.ns[2], f.c[2]);
+    } else {
+        asm volatile("");
+        a = fmaf(pz, f.ns[0], f.c[0]); b = fmaf(px, f.ns[1], f.c[1]); c = fmaf(py, f.ns[2], f.c[2]);
+    }
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c)) <= kSlabHalf;
+}
+
+// The twelve monomials as six packed fp16 pairs: K slots {1, b | c, bc | a, ab} of lane half 0 and {ac, abc | |a|, |a| b | |a| c, |a| bc} of lane
+// half 1 (the fourth register of either half is zero; grid_slab_table_kernel writes the coefficients in this order).  The |a| pairs are the a pairs
+// with the sign of a flipped away: exact, and two bit operations instead of three products and two converts.
+__device__ __forceinline__ void slab_monomials(float a, float b, float c, unsigned (&r)[6]) {
+    const float bc = b * c, ab = a * b, ac = a * c, abc = ab * c;
+    r[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{1.f, b}), half2_t));
+    r[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{c, bc}), half2_t));
+    r[2] = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{a, ab}), half2_t));
+    r[3] = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{ac, abc}), half2_t));
+    const unsigned flip = unsigned(__builtin_bit_cast(int, a) >> 31) & 0x80008000u;
+    r[4] = r[2] ^ flip;
+    r[5] = r[3] ^ flip;
+}
+
+// -> the B fragments of the two column tiles: registers {r0, r1, r2, 0} are the K slots of lane half 0, {r3, r4, r5, 0} those of lane half 1; one
+// lane-half swap per register pair leaves tile 0's fragment register in the first result and tile 1's in the second (see cell_prepare)
+__device__ __forceinline__ void slab_fragments(const unsigned (&r)[6], half8_t (&gf)[2]) {
+    const auto s0 = lane_half_swap(r[0], r[3]);
+    const auto s1 = lane_half_swap(r[1], r[4]);
+    const auto s2 = lane_half_swap(r[2], r[5]);
+    const uint4_t b0 = {s0[0], s1[0], s2[0], 0u}, b1 = {s0[1], s1[1], s2[1], 0u};
+    gf[0] = __builtin_bit_cast(half8_t, b0);
+    gf[1] = __builtin_bit_cast(half8_t, b1);
+}
+
+// A slab for the samples whose bit is set in `cand` (not empty): the extended cell of the first of them, paired along the first axis in which the
+// first candidate in ANOTHER cell differs (towards that cell), else with its +x neighbour (-x at the far ghost cell).  Everything here is wave-uniform
+// scalar bookkeeping on three v_readlane pairs; its table entry is fetched (one coalesced 1 KiB read per M tile).
+template <int MT>
+__device__ __forceinline__ void slab_select(const NetParams& P, float px, float py, float pz, unsigned long long cand, int lane, SlabFrame& F, half8_t (&A)[MT]) {
+    // extended cell index per axis: floor(texel coordinate) + 1 = floor(p N + 1/2) in [0, N]  (cell k spans the texel coordinates [k - 1, k])
+    const float ex = __builtin_amdgcn_fmed3f(floorf(fmaf(px, P.gridXf, 0.5f)), 0.f, P.gridXf);
+    const float ey = __builtin_amdgcn_fmed3f(floorf(fmaf(py, P.gridYf, 0.5f)), 0.f, P.gridYf);
+    const float ez = __builtin_amdgcn_fmed3f(floorf(fmaf(pz, P.gridZf, 0.5f)), 0.f, P.gridZf);
+    const int r0 = __builtin_ctzll(cand);
+    const float c0x = readlane_f(ex, r0), c0y = readlane_f(ey, r0), c0z = readlane_f(ez, r0);
+    const unsigned long long same = __builtin_amdgcn_ballot_w64(ex == c0x) & __builtin_amdgcn_ballot_w64(ey == c0y) & __builtin_amdgcn_ballot_w64(ez == c0z);
+    const unsigned long long others = cand & ~same;
+    int axis = 0;
+    bool up = c0x < P.gridXf;
+    if (others) {
+        const int r1 = __builtin_ctzll(others);
+        const float c1x = readlane_f(ex, r1), c1y = readlane_f(ey, r1), c1z = readlane_f(ez, r1);
+        axis = c1x != c0x ? 0 : (c1y != c0y ? 1 : 2);
+        up = axis == 0 ? c1x > c0x : (axis == 1 ? c1y > c0y : c1z > c0z);
+    }
+    const float step = up ? 0.f : 1.f;  // the slab's LOWER cell
+    const float lx = c0x - (axis == 0 ? step : 0.f), ly = c0y - (axis == 1 ? step : 0.f), lz = c0z - (axis == 2 ? step : 0.f);
+    // roles: a = the slab axis, b / c the next two axes.  xi_a = (texel - l_a) / 2 = p N_a / 2 - (l_a + 1/2) / 2 (the shared face is the node l_a);
+    // xi_b = texel - (l_b - 1/2) = p N_b - l_b (the cell's centre)
+    const float na = axis == 0 ? P.gridXf : (axis == 1 ? P.gridYf : P.gridZf), nb = axis == 0 ? P.gridYf : (axis == 1 ? P.gridZf : P.gridXf),
+                nc = axis == 0 ? P.gridZf : (axis == 1 ? P.gridXf : P.gridYf);
+    const float la = axis == 0 ? lx : (axis == 1 ? ly : lz), lb = axis == 0 ? ly : (axis == 1 ? lz : lx), lc = axis == 0 ? lz : (axis == 1 ? lx : ly);
+    F.axis = axis;
+    F.ns[0] = uniform_f(0.5f * na); F.ns[1] = uniform_f(nb); F.ns[2] = uniform_f(nc);
+    F.c[0] = -0.5f * (la + 0.5f); F.c[1] = -lb; F.c[2] = -lc;
+    // (exact in fp32: fewer than 2^24 extended cells, the table below 2^31 bytes: keyframes.cpp)
+    const unsigned lin = unsigned(__builtin_amdgcn_readfirstlane(int(fmaf(fmaf(lz, P.gridYf + 1.f, ly), P.gridXf + 1.f, lx))));
+    // (NetParams::cellTable / cellCount of a slab launch: the slab table and its extended cell count, device_params.hpp)
+    const unsigned slab = min(unsigned(axis) * P.cellCount + lin, 3u * P.cellCount - 1u);
+    const char* base = static_cast<const char*>(P.cellTable) + size_t(slab) * size_t(1024 * MT) + unsigned(lane) * 16u;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) A[m] = *reinterpret_cast<const half8_t*>(base + 1024 * m);
+}
+
+// One wave step's latent grid for the first layer: the resident slab (replaced if a valid sample lies outside it) and what it leaves uncovered
+template <int MT>
+__device__ __forceinline__ void slab_prepare(const NetParams& P, SlabState<MT>& S, float px, float py, float pz, unsigned long long validMask, int lane, SlabPre& C) {
+    C.px = px; C.py = py; C.pz = pz;
+    float a = 0.f, b = 0.f, c = 0.f;
+    unsigned long long in = 0ull;
+    if (S.f.axis >= 0) in = __builtin_amdgcn_ballot_w64(slab_coords(S.f, px, py, pz, a, b, c));
+    unsigned long long rem = validMask & ~in;
+    if (rem != 0ull || S.f.axis < 0) {  // wave-uniform: 15 % of the steps of the 16^3 headline frame, 35 % at 32^3
+        const unsigned long long cand = validMask ? validMask : 1ull;  // (a step always has a valid lane: kernels.hpp breaks otherwise)
+        slab_select<MT>(P, px, py, pz, cand, lane, S.f, S.a);
+        in = __builtin_amdgcn_ballot_w64(slab_coords(S.f, px, py, pz, a, b, c)) | (1ull << __builtin_ctzll(cand));
+        rem = validMask & ~in;
+    }
+    unsigned r[6];
+    slab_monomials(a, b, c, r);
+    if (rem != 0ull) {  // samples outside get zero columns here and their own slabs in slab_accumulate
+#pragma unroll
+        for (int k = 0; k < 6; ++k) r[k] = select_bits_by_mask(in, r[k]);
+    }
+    slab_fragments(r, C.gf);
+    C.rem = rem;
+}
+
+// The latent K step of tile t into the first layer's accumulators: the resident slab, then -- wave-uniform, rare -- slabs for the tile's samples outside it
+template <int MT>
+__device__ __forceinline__ void slab_accumulate(const NetParams& P, const SlabState<MT>& S, const SlabPre& C, int t, int lane, floatx16* acc) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(S.a[m], C.gf[t], acc[m], 0, 0, 0);
+    unsigned long long rem = C.rem & (t ? 0xffffffff00000000ull : 0x00000000ffffffffull);
+    while (rem != 0ull) {
+        SlabFrame F;
+        half8_t A[MT], gf[2];
+        slab_select<MT>(P, C.px, C.py, C.pz, rem, lane, F, A);
+        float a, b, c;
+        const unsigned long long in = (__builtin_amdgcn_ballot_w64(slab_coords(F, C.px, C.py, C.pz, a, b, c)) & rem) | (1ull << __builtin_ctzll(rem));
+        unsigned r[6];
+        slab_monomials(a, b, c, r);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) r[k] = select_bits_by_mask(in, r[k]);
+        slab_fragments(r, gf);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[m], t ? gf[1] : gf[0], acc[m], 0, 0, 0);
+        rem &= ~in;
+    }
+}
+
 // ---- building blocks of the forward pass -------------------------------------------------------------------
 constexpr int mtiles(int CD) { return (16 * CD + 31) / 32; }
 
@@ -1345,12 +1513,12 @@ __device__ __forceinline__ void load_resident(const NetParams& P, const char* ld
 // colour networks; otherwise only output 0)
 template <int ACT, int NLC, int NFILL, bool ALL4, int RGRID = 0, class Pre, class Fill>
 __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, const ResidentNet<NLC, RGRID>& R, half8_t (&xb)[2][2], Pre&& pre, Fill&& fill,
-                                                        const half8_t* gf = nullptr, const CellPre<1>* cells = nullptr) {
+                                                        const half8_t* gf = nullptr, const SlabState<1>* slab = nullptr, const SlabPre* slabPre = nullptr) {
     // the latent K step of layer 0: RGRID = 1: gf = B fragments of the two tiles' latent features, A = R.wg[0] (the first layer's latent
-    // columns); RGRID = 2: through the cell table (cells_accumulate)
+    // columns); RGRID = 2: the resident slab of the slab table (slab_accumulate; r04 - r05: the cell table)
     [[maybe_unused]] const int lane_ = lane_id();
     auto latent = [&](int T, floatx16& a) {
-        if constexpr (RGRID == 2) cells_accumulate<1>(P, *cells, T, lane_ >> 5, unsigned(lane_ & 31) * 16u, &a);
+        if constexpr (RGRID == 2) slab_accumulate<1>(P, *slab, *slabPre, T, lane_, &a);
         else a = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wg[0], gf[T], a, 0, 0, 0);
     };
     const float actA = P.actA, actB = P.actB;
@@ -1453,13 +1621,13 @@ __device__ __forceinline__ float4_t srn_forward_resident_grid(const NetParams& P
 }
 
 template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
-__device__ __forceinline__ float4_t srn_forward_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, float px, float py, float pz,
+__device__ __forceinline__ float4_t srn_forward_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, SlabState<1>& slab, float px, float py, float pz,
                                                               float dx, float dy, float dz, unsigned long long validMask) {
     constexpr int NPASS = HAS_DIR ? 4 : 2;
     const int lane = lane_id();
     const int h = lane >> 5;
-    CellPre<1> C;
-    cell_prepare<1>(P, px, py, pz, validMask, h, unsigned(lane & 31) * 16u, C);
+    SlabPre C;
+    slab_prepare<1>(P, slab, px, py, pz, validMask, lane, C);
     half8_t b0[2], xb[2][2];
     phase_operands<HAS_DIR, true>(px, py, pz, dx, dy, dz, h, b0);
     floatx16 d[2];
@@ -1476,7 +1644,7 @@ __device__ __forceinline__ float4_t srn_forward_resident_cells(const NetParams& 
         for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d[t], q, 0.f, 0.f, xb[t][0], xb[t][1]);
         __builtin_amdgcn_sched_barrier(0);
     }
-    return srn_layers_resident<ACT, NLC, 0, ALL4, 2>(P, R, xb, []() {}, [](int) {}, nullptr, &C);
+    return srn_layers_resident<ACT, NLC, 0, ALL4, 2>(P, R, xb, []() {}, [](int) {}, nullptr, &slab, &C);
 }
 
 // The same with rotated Fourier features (r03): the current features stay in 32 registers (fp32, both tiles), their per-step rotation
@@ -1567,49 +1735,12 @@ __device__ __forceinline__ float4_t srn_forward_rotating_resident(const NetParam
 
 // srn_forward_resident_cells with rotated Fourier features (the registers the gathers held take the rotation state)
 template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
-__device__ __forceinline__ float4_t srn_forward_rotating_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, floatx16 (&feat)[2][1],
+__device__ __forceinline__ float4_t srn_forward_rotating_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, SlabState<1>& slab, floatx16 (&feat)[2][1],
                                                                        const floatx16 (&dfeat)[2][1], float px, float py, float pz,
-                                                                       unsigned long long validMask, bool advance = true
-#ifdef FVSRN_ABL_SLABMOCK
-                                                                       , int mockStep = 0, half8_t mockA = half8_t{}
-#endif
-                                                                       ) {
+                                                                       unsigned long long validMask, bool advance = true) {
     const int lane = lane_id();
-    CellPre<1> C;
-#ifdef FVSRN_ABL_SLABMOCK
-    // TIMING MOCK (wrong results): the per-step instruction mix of a resident slab path -- 3 fma, in-slab test, 4 + 4 monomial products / converts, 4 kink
-    // operations, 3 lane-half swaps, no selection, no table fetch; every FVSRN_ABL_SLABMOCK-th step (0: never) runs the cell path as well
-    {
-        const float cx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, P.gridYf)));
-        const float a = fmaf(px, P.gridXf, cx), b = fmaf(py, P.gridYf, cx), c = fmaf(pz, P.gridZf, cx);
-        const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c));
-        const unsigned long long rem = validMask & ~__builtin_amdgcn_ballot_w64(mx <= P.gridZf * 1e30f);
-        const bool slow = rem != 0 || (FVSRN_ABL_SLABMOCK > 0 && (mockStep % FVSRN_ABL_SLABMOCK) == 0);
-        if (slow) {
-            cell_prepare<1>(P, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
-        } else {
-            const float ab = a * b, ac = a * c, bc = b * c, abc = ab * c;
-            unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{1.f, b}), half2_t));
-            unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{c, bc}), half2_t));
-            unsigned p2 = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{a, ab}), half2_t));
-            unsigned p3 = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{ac, abc}), half2_t));
-            const unsigned sm = unsigned(__builtin_bit_cast(int, a) >> 31) & 0x80008000u;
-            unsigned q2 = p2 ^ sm, q3 = p3 ^ sm;
-            auto s0 = lane_half_swap(p0, p3);
-            auto s1 = lane_half_swap(p1, q2);
-            auto s2 = lane_half_swap(p2, q3);
-            uint4_t b0 = {s0[0], s1[0], s2[0], 0u}, b1 = {s0[1], s1[1], s2[1], 0u};
-            C.gf[0] = __builtin_bit_cast(half8_t, b0);
-            C.gf[1] = __builtin_bit_cast(half8_t, b1);
-            C.ga[0] = mockA;
-            C.rem = 0;
-            C.cellOwn = 0;
-            for (int k = 0; k < 4; ++k) C.wOwn[k] = 0;
-        }
-    }
-#else
-    cell_prepare<1>(P, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
-#endif
+    SlabPre C;
+    slab_prepare<1>(P, slab, px, py, pz, validMask, lane, C);
     half8_t xb[2][2];
     return srn_layers_resident<ACT, NLC, 0, ALL4, 2>(
         P, R, xb,
@@ -1620,7 +1751,7 @@ __device__ __forceinline__ float4_t srn_forward_rotating_resident_cells(const Ne
                 for (int c = 0; c < 16; ++c) fourier_advance_piece<2, HAS_DIR>(feat, dfeat, c);
             }
         },
-        [](int) {}, nullptr, &C);
+        [](int) {}, nullptr, &slab, &C);
 }
 
 // output parametrization, renderer_volume_tensorcores.cuh:1054-1158. The reference rounds the

@@ -216,7 +216,9 @@ int fvsrn_network_keyframe_stats(const fvsrn_network* net, unsigned long long ou
  * resolution below 2, above the size cap, option 0), builds of the table of the image the unshaded renderer runs, builds of the plain-image table
  * (shaded renders of a network that also has a re-scaled image), bytes of table memory resident now } since the device state was created.  Tables are
  * built by the first launch that goes through them and then with every key-frame blend for as long as the launches do; a network whose launches take
- * the gathers (footprint rule, adjoint mode, evaluate_points) never allocates one. */
+ * the gathers (footprint rule, adjoint mode, evaluate_points) never allocates one.  r06: the register-resident kernels of 32-wide networks read the
+ * SLAB table (one entry per pair of face-adjacent cells of the grid extended by a ghost cell per side, 3 (X+1)(Y+1)(Z+1) KiB); while the unshaded
+ * launches go through it, it is the table the first two and the last figure count. */
 int fvsrn_network_cell_table_stats(const fvsrn_network* net, unsigned long long out[4]);
 
 /* ----------------------------------------------------------------------------------------

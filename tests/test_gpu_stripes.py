@@ -350,7 +350,7 @@ def test_rccl_route_runs_on_one_gpu_with_a_one_rank_group(config):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [["--gather", "root"], ["--gather", "root", "--payload", "rgba8", "--frames-per-submit", "4"], ["--payload", "rgba8"],
+@pytest.mark.parametrize("extra", [["--gather", "all"], ["--gather", "root", "--payload", "rgba8", "--frames-per-submit", "4"], ["--gather", "all", "--payload", "rgba8"],
                                    ["--frames-per-submit", "3"]])
 def test_rccl_route_gather_to_root_rgba8_payload_and_batches_on_one_gpu(extra):
     """r05: the other forms of the exchange with the REAL backend (RCCL, one-rank group): dist.gather to rank 0, packed RGBA8 words (ExtractColor before
@@ -368,8 +368,15 @@ def test_rccl_route_gather_to_root_rgba8_payload_and_batches_on_one_gpu(extra):
     assert r.returncode == 0 and lines, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
     line = json.loads(lines[-1])
     assert line["backend"] == "nccl" and line["gathered_frame_matches_single_gpu_frame"] is True
-    assert line["gather"] == ("root" if "root" in extra else "all") and line["payload"] == ("rgba8" if "rgba8" in extra else "planes")
+    # (r06: the default of --gather is north_star's form, the gather to rank 0)
+    assert line["gather"] == ("all" if "all" in extra else "root") and line["payload"] == ("rgba8" if "rgba8" in extra else "planes")
     assert line["per_rank"][0]["host_us_per_frame"] > 0 and line["per_rank"][0]["gather_ms"] > 0
+    # r06: the record of the one multi-GPU shot -- who took part, the same-run world-1 reference, the three other (gather, payload) combinations
+    assert line["rccl"]["world_size_seen"] == 1 and line["rccl"]["nccl_version"] and line["rccl"]["ranks"][0]["device_name"]
+    assert line["world1_same_run"]["value"] > 0 and 0.3 < line["efficiency_vs_same_run_world1"] < 1.3
+    combos = {(v["gather"], v["payload"]) for v in line["variants"]} | {(line["gather"], line["payload"])}
+    assert len(line["variants"]) == 3 and combos == {("root", "planes"), ("all", "planes"), ("root", "rgba8"), ("all", "rgba8")}
+    assert all(v["value"] > 0 and v["steps"] == 20 for v in line["variants"])
     assert line["collective_bytes_per_frame_and_rank"] == (4 if "rgba8" in extra else 32) * 512 * 512
 
 
