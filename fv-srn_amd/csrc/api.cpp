@@ -313,9 +313,8 @@ int fvsrn_network_kernel_name(fvsrn_network* net, int render, char* buf, size_t 
             const bool colourNet = P.outputMode == FVSRN_OUT_RGBO || P.outputMode == FVSRN_OUT_RGBO_DIRECT;
             const bool folded = P.bias0Folded && (!net->scaledImage || net->packed.scaledBias0Exact);
             const bool cells = k.grid == 1 && net->opts[FVSRN_OPT_CELL_TABLE] != 0 && P.gridX >= 2 && P.gridY >= 2 && P.gridZ >= 2 &&
-                               double(P.gridX - 1) * (P.gridY - 1) * (P.gridZ - 1) * 512.0 * ((net->packed.cfg.hiddenChannels + 31) / 32) <= 1073741824.0;  // (ensureDevice: cellTableBytes)
-            const bool slabs = cells && 3.0 * double(P.gridX + 1) * (P.gridY + 1) * (P.gridZ + 1) * 1024.0 <= 1073741824.0;  // (ensureDevice: slabTableBytes)
-            const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && folded ? (slabs ? 2 : (P.gridK == 1 ? 1 : 3)) : 3);
+                               double(P.gridX + 1) * (P.gridY + 1) * (P.gridZ + 1) * 512.0 * ((net->packed.cfg.hiddenChannels + 31) / 32) <= 1073741824.0;  // (ensureDevice: cellTableBytes)
+            const int smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && folded ? (cells ? 2 : (P.gridK == 1 ? 1 : 3)) : 3);
             // (the latent-grid path is chosen per launch: FVSRN_OPT_CELL_TABLE = -1 takes the table by the footprint of a pixel tile, renderImpl)
             const std::string byFootprint = cells && net->opts[FVSRN_OPT_CELL_TABLE] == -1 ? "; cells or gathers by footprint" : "";
             if (net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && k.CD == 2 && smallGrid <= 2 && !P.noFourier && !P.fourierNeedsFractPlain && !P.fourierClampPos && (scalarNet || colourNet) &&
@@ -381,13 +380,11 @@ int fvsrn_network_keyframe_stats(const fvsrn_network* net, unsigned long long ou
 int fvsrn_network_cell_table_stats(const fvsrn_network* net, unsigned long long out[4]) {
     if (!net || !out) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> lock(net->mu);
-    // (r06: the unshaded launches of the register-resident kernels go through the SLAB table; it is the "unshaded table" of this account while they do)
-    const bool slabsInUse = net->slabTableBytes && (net->slabsWanted || (net->slabTableBuilds && !net->cellTableBuilds[0]));
-    out[0] = (unsigned long long)(slabsInUse ? net->slabTableBytes : net->cellTableBytes);
-    out[1] = net->cellTableBuilds[0] + net->slabTableBuilds;
+    out[0] = (unsigned long long)net->cellTableBytes;
+    out[1] = net->cellTableBuilds[0];
     out[2] = net->cellTableBuilds[1];
     out[3] = 0;
-    for (const auto& w : net->workGrid) out[3] += (unsigned long long)(w.cells.cap + w.cellsPlain.cap + w.slabs.cap);
+    for (const auto& w : net->workGrid) out[3] += (unsigned long long)(w.cells.cap + w.cellsPlain.cap);
     return FVSRN_OK;
 }
 
@@ -647,16 +644,21 @@ int extractImpl(const float* d_raw8, int width, int height, int channel_mode, in
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
             return fail(FVSRN_ERR_NO_DEVICE, "no HIP device available: the MI355X kernels cannot run (there is no CPU fallback)");
-        // 3 words of scratch for the depth range: one small allocation per thread, reused
-        thread_local DeviceBuffer scratch;
+        // 3 words of scratch for the depth range, allocated per call in stream order on the CURRENT device (r06, ADVICE r05: a thread_local buffer was shared
+        // by every stream a thread drives -- two DEPTH extracts on two streams raced on it -- and lived on the device of its first use)
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        int dev = 0;
+        void* scratch = nullptr;
         try {
-            scratch.ensure(16);
+            HIP_CHECK(hipGetDevice(&dev));
+            scratch = g_temporaries.alloc(dev, 16, st);
         } catch (const DeviceError& e) {
             return fail(FVSRN_ERR_DEVICE, e.what());
         }
+        struct Free { void* p; hipStream_t s; ~Free() { (void)hipFreeAsync(p, s); } } freeScratch{scratch, st};
         ExtractParams p{};
         p.raw = d_raw8; p.out4 = d_out4; p.out8 = d_out8;
-        p.minmax = static_cast<float*>(scratch.ptr);
+        p.minmax = static_cast<float*>(scratch);
         p.range3 = channel_mode == FVSRN_CHANNEL_DEPTH ? d_range3 : nullptr;
         p.pixels = (unsigned long long)width * (unsigned long long)height;
         p.mode = channel_mode; p.tonemap = use_tonemapping; p.maxExposure = max_exposure;
@@ -689,14 +691,18 @@ int fvsrn_depth_range(const float* d_raw8, int width, int height, float* d_range
     if (width <= 0 || height <= 0) return fail(FVSRN_ERR_INVALID_ARGUMENT, "bad image size");
     return guarded([&]() -> int {
         if (fvsrn_device_count() == 0) return fail(FVSRN_ERR_NO_DEVICE, "no HIP device available: the MI355X kernels cannot run (there is no CPU fallback)");
-        thread_local DeviceBuffer scratch;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        int dev = 0;
+        void* scratch = nullptr;  // (per call, stream-ordered, on the current device: see extractImpl)
         try {
-            scratch.ensure(16);
+            HIP_CHECK(hipGetDevice(&dev));
+            scratch = g_temporaries.alloc(dev, 16, st);
         } catch (const DeviceError& e) {
             return fail(FVSRN_ERR_DEVICE, e.what());
         }
+        struct Free { void* p; hipStream_t s; ~Free() { (void)hipFreeAsync(p, s); } } freeScratch{scratch, st};
         const unsigned long long pixels = (unsigned long long)width * (unsigned long long)height;
-        const hipError_t e = launch_depth_range(d_raw8 + 7 * pixels, pixels, static_cast<float*>(scratch.ptr), d_range3, static_cast<hipStream_t>(stream));
+        const hipError_t e = launch_depth_range(d_raw8 + 7 * pixels, pixels, static_cast<float*>(scratch), d_range3, st);
         if (e != hipSuccess) return fail(FVSRN_ERR_DEVICE, std::string("depth_range failed: ") + hipGetErrorString(e));
         return FVSRN_OK;
     });

@@ -318,13 +318,8 @@ struct fvsrn_network {
     // (ensureCellTable), and rebuilt together with a blend only while the previous launches used them (cellsWanted / cellsPlainWanted) -- a time-animated
     // 64^3 .. 128^3 grid whose frames take the gathers (footprint rule, adjoint mode) no longer writes 0.25 .. 2 GB of table per frame nor holds up to
     // 4 GiB of HBM for a path it never takes, and nothing builds the plain-image table unless something renders shaded.
-    // slabs (r06): the slab table (NetParams::slabTable) of the image the unshaded renderer runs -- what render_small_kernel<.., SGRID = 2> reads instead of
-    // the cell table; lazily built and kept up like it (ensureSlabTable, slabsWanted)
-    struct WorkingGrid { DeviceBuffer a, b, cells, cellsPlain, slabs; bool cellsValid = false, cellsPlainValid = false, slabsValid = false; StreamOrder order; };
+    struct WorkingGrid { DeviceBuffer a, b, cells, cellsPlain; bool cellsValid = false, cellsPlainValid = false; StreamOrder order; };
     bool cellsWanted = false, cellsPlainWanted = false;  // the last unshaded / shaded launch went through the table
-    bool slabsWanted = false;                            // the last unshaded launch of a register-resident kernel went through the slab table
-    size_t slabTableBytes = 0;  // 0: no slab table (no cell table either, more than 32 channels wide, above the size cap)
-    unsigned long long slabTableBuilds = 0;
     unsigned long long cellTableBuilds[2] = {0, 0};       // table builds since the device state was created: unshaded-image table, plain-image table
     WorkingGrid workGrid[2];
     int numWorkGrids = 1, curWorkGrid = 0;
@@ -382,9 +377,6 @@ struct fvsrn_network {
     // The table of the CURRENT working grid for a launch on `stream` (after syncTime, before beginUse): built now if no launch has needed it since the
     // last blend.  Readers of the grid on other streams are waited for like by a blend, later readers wait for this write.
     const void* ensureCellTable(bool plain, hipStream_t stream);
-    // the same for the slab table (grid_slab_table_kernel; the unshaded image only)
-    void buildSlabTable(WorkingGrid& W, hipStream_t stream);
-    const void* ensureSlabTable(hipStream_t stream);
 
     // Brings the working grid and the time input of the network in line with net->currentTime/currentEnsemble:
     // one small kernel + (networks that take the time as input) a 2-byte patch, both stream-ordered -- no host

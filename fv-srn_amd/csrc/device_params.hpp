@@ -73,19 +73,14 @@ struct NetParams {
     int gridEncoding, gridTimeChannels;
     int gridX, gridY, gridZ, gridC;
     float gridXf, gridYf, gridZf;  // the same as floats (grid_tap works in fp32: fewer than 2^24 records, pack.cpp)
-    // Cell table of the working grid (r04; grid_cell_table_kernel in launch.hip; cell_prepare / cells_accumulate in srn_device.hpp): for every
-    // cell (x0, y0, z0) of the grid, 0 <= x0 <= X - 2, the product of the first layer's latent columns with the cell's eight corner vectors,
-    // fp16 [cell][m][row 0..31][corner (dz, dy, dx)] -- 512 bytes per cell and M tile, which IS the A fragment of an MFMA K step whose B
-    // operand holds the eight trilinear weights of a sample.  null: none (BYTE_GAUSSIAN grids, tables above the size cap).
+    // Cell table of the working grid (r04; r06: monomial coefficients and ghost cells; grid_cell_table_kernel in launch.hip; cell_tap / cell_prepare /
+    // cells_accumulate in srn_device.hpp): for every cell of the grid extended by one ghost cell per side (cell e spans the nodes e - 1, e per axis, the
+    // ghost nodes repeat the boundary = clamp-to-edge), the eight coefficient vectors of the cell's interpolant in cell-centred coordinates times the first
+    // layer's latent columns, fp16 [cell][m][row 0..31][slot 4 c + 2 b + a = coefficient of x^a y^b z^c] -- 512 bytes per cell and M tile, which IS the A
+    // fragment of an MFMA K step whose B operand holds the eight monomials of a sample.  null: none (BYTE_GAUSSIAN grids, tables above the size cap).
     const void* cellTable;
     unsigned cellStride;  // bytes per cell: 512 * MT
-    unsigned cellCount;   // (X - 1)(Y - 1)(Z - 1)
-    // Slab table of the working grid (r06; grid_slab_table_kernel in launch.hip; slab_prepare / slab_accumulate in srn_device.hpp): for every axis a and
-    // every cell L of the grid extended by one ghost cell per side ((X + 1)(Y + 1)(Z + 1) cells, the ghost nodes repeat the boundary nodes = clamp-to-edge),
-    // the 12 coefficient vectors of the interpolant over the cell pair (L, L + e_a) in face-centred coordinates, times the first layer's latent columns:
-    // fp16 [axis][cell][m][lane half][row 0..31][8 K slots] -- 1 KiB per slab and M tile, lane-linear: the A fragment of ONE MFMA K step whose B operand
-    // holds the sample's twelve monomials.  null: none (no grid, BYTE_GAUSSIAN, tables above the size cap).
-    // It travels in the fields above (a launch reads one table or the other): cellTable = the slab table, cellCount = (X + 1)(Y + 1)(Z + 1), cellStride = 1024 MT.
+    unsigned cellCount;   // (X + 1)(Y + 1)(Z + 1)
 };
 
 constexpr int kMaxFramesPerLaunch = 8;

@@ -652,9 +652,6 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     [[maybe_unused]] bool normalsAtPreviousStep = false;  // (wave-uniform) per ray tile
     float stepIndex = float(i0);
     const float stepEnd = float(i1);  // INT_MAX -> 2^31: never reached
-    // render_small_kernel<.., SGRID = 2>: the latent grid's resident slab (srn_device.hpp); none at the start of a work unit
-    [[maybe_unused]] SlabState<1> slab;
-    slab.f.axis = -1;
 
 #ifdef FVSRN_PROF_SECTIONS
     P.profLast = __builtin_readcyclecounter();
@@ -713,7 +710,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             // compile-time variant (render_small_kernel<.., ADVANCE>, chosen by the host): as a wave-uniform branch inside the step it cost the
             // default path 1.7 % (r04: 162.1 -> 159.4 Gsamples/s), leaving it out costs the exact mode 10 - 17 % (121.5 -> 134.6 .. 145.8)
             constexpr bool advance = ADVANCE;
-            if constexpr (NLC > 0 && CELLS) o = srn_forward_rotating_resident_cells<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, slab, feat, dfeat, px, py, pz, validMask, advance);
+            if constexpr (NLC > 0 && CELLS) o = srn_forward_rotating_resident_cells<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeat, px, py, pz, validMask, advance);
             else if constexpr (NLC > 0) o = srn_forward_rotating_resident<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeat, advance);
             else o = srn_forward_rotating<CD, ACT, GRID, HAS_DIR>(P, lds, feat, dfeat, px, py, pz, advance);
         } else if constexpr (kRotateLds) {
@@ -726,7 +723,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             }
             o = srn_forward_rotating_resident_grid<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeatLds, px, py, pz);
         } else if constexpr (NLC > 0 && GRID == 1 && CELLS) {
-            o = srn_forward_resident_cells<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, slab, px, py, pz, dx, dy, dz, validMask);
+            o = srn_forward_resident_cells<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, px, py, pz, dx, dy, dz, validMask);
         } else if constexpr (NLC > 0 && GRID == 1) {
             o = srn_forward_resident_grid<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, px, py, pz, dx, dy, dz);
         } else if constexpr (kAdjointHere) {

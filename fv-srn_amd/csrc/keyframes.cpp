@@ -155,23 +155,19 @@ void fvsrn_network::ensureDevice(hipStream_t stream) {
         cellTableBytes = 0;
         {
             const NetParams& np = packed.params;
-            const double cells = double(np.gridX - 1) * double(np.gridY - 1) * double(np.gridZ - 1);
+            const double cells = double(np.gridX + 1) * double(np.gridY + 1) * double(np.gridZ + 1);  // (the grid extended by one ghost cell per side: cell_tap)
             const int MT = (packed.cfg.hiddenChannels + 31) / 32;
             if (opts[FVSRN_OPT_CELL_TABLE] != 0 && K.enc != FVSRN_GRID_BYTE_GAUSSIAN && np.gridX >= 2 && np.gridY >= 2 && np.gridZ >= 2 &&
                 np.numLayers >= 1 && cells * 512.0 * MT <= 1073741824.0)
                 cellTableBytes = size_t(cells) * 512 * size_t(MT);
-            // Slab table (device_params.hpp): 1 KiB per axis and cell of the grid extended by a ghost cell per side; 32-wide networks only (the register-
-            // resident kernels are its only readers), under the same 1 GiB cap
-            const double slabs = 3.0 * double(np.gridX + 1) * double(np.gridY + 1) * double(np.gridZ + 1);
-            slabTableBytes = (cellTableBytes && MT == 1 && slabs * 1024.0 <= 1073741824.0) ? size_t(slabs) * 1024 : 0;
         }
         for (int i = 0; i < 2; ++i) {
-            if (i >= numWorkGrids) { workGrid[i].a.release(); workGrid[i].b.release(); workGrid[i].cells.release(); workGrid[i].cellsPlain.release(); workGrid[i].slabs.release(); continue; }
+            if (i >= numWorkGrids) { workGrid[i].a.release(); workGrid[i].b.release(); workGrid[i].cells.release(); workGrid[i].cellsPlain.release(); continue; }
             workGrid[i].a.ensure(K.records * size_t(K.Gt + K.Ge) * 2 * 2);
             if (K.enc == FVSRN_GRID_BYTE_GAUSSIAN) workGrid[i].b.ensure(K.records * size_t(K.Gt + K.Ge) * 2 * 2);
             // (cell tables: allocated by the first launch that uses them, ensureCellTable; a re-pack drops what the old state held)
-            workGrid[i].cells.release(); workGrid[i].cellsPlain.release(); workGrid[i].slabs.release();
-            workGrid[i].cellsValid = workGrid[i].cellsPlainValid = workGrid[i].slabsValid = false;
+            workGrid[i].cells.release(); workGrid[i].cellsPlain.release();
+            workGrid[i].cellsValid = workGrid[i].cellsPlainValid = false;
         }
         packed.params.grid = workGrid[0].a.ptr;
         packed.params.gridB = K.enc == FVSRN_GRID_BYTE_GAUSSIAN ? workGrid[0].b.ptr : nullptr;
@@ -180,10 +176,7 @@ void fvsrn_network::ensureDevice(hipStream_t stream) {
     } else {
         packed.params.grid = nullptr;
         cellTableBytes = 0;
-        slabTableBytes = 0;
     }
-    slabsWanted = false;
-    slabTableBuilds = 0;
     packed.params.cellTable = nullptr;  // (set per launch: renderImpl -> ensureCellTable)
     {
         const int MT = (packed.cfg.hiddenChannels + 31) / 32;
@@ -226,33 +219,6 @@ void fvsrn_network::buildCellTable(WorkingGrid& W, bool plain, hipStream_t strea
     ++cellTableBuilds[own ? 1 : 0];
 }
 
-void fvsrn_network::buildSlabTable(WorkingGrid& W, hipStream_t stream) {
-    if (W.slabsValid) return;
-    W.slabs.ensure(slabTableBytes);
-    const NetParams& np = packed.params;
-    const int MT = (packed.cfg.hiddenChannels + 31) / 32, KS = packed.cfg.hiddenChannels / 16;
-    CellTableParams ct{};
-    ct.grid = W.a.ptr;
-    ct.latentFrags = static_cast<const char*>(scaledImage ? scaledImage : dLds.ptr) + np.offLayer0 + size_t(MT) * KS * kFragBytes;  // (the unshaded renderer's image)
-    ct.out = W.slabs.ptr;
-    ct.X = np.gridX; ct.Y = np.gridY; ct.Z = np.gridZ; ct.G = np.gridC; ct.MT = MT;
-    HIP_CHECK(launch_grid_slab_table(ct, stream));
-    W.slabsValid = true;
-    ++slabTableBuilds;
-}
-
-const void* fvsrn_network::ensureSlabTable(hipStream_t stream) {
-    WorkingGrid& W = workGrid[curWorkGrid];
-    if (!W.slabsValid) {
-        imagesOrder.beginRead(stream);  // the latent fragments of the weight image
-        W.order.beginWrite(stream);
-        buildSlabTable(W, stream);
-        W.order.endWrite(stream);
-    }
-    slabsWanted = true;
-    return W.slabs.ptr;
-}
-
 const void* fvsrn_network::ensureCellTable(bool plain, hipStream_t stream) {
     WorkingGrid& W = workGrid[curWorkGrid];
     const bool own = plain && scaledImage != nullptr;
@@ -284,12 +250,11 @@ void fvsrn_network::syncTime(hipStream_t stream) {
         b.out = W.a.ptr; b.outB = W.b.ptr; b.records = K.records; b.enc = int(K.enc); b.Gt = K.Gt; b.Ge = K.Ge;
         b.lo = g.lo; b.hi = g.hi; b.ens = g.ens; b.frac = g.frac;
         HIP_CHECK(launch_grid_blend(b, stream));
-        W.cellsValid = W.cellsPlainValid = W.slabsValid = false;
+        W.cellsValid = W.cellsPlainValid = false;
         // the tables the launches before this blend went through are rebuilt with it (same stream, same write bracket: fvsrn_network_prepare puts
         // both on its side stream); any other is built by the launch that first wants it
         if (cellTableBytes && cellsWanted) buildCellTable(W, false, stream);
         if (cellTableBytes && cellsPlainWanted) buildCellTable(W, true, stream);
-        if (slabTableBytes && slabsWanted) buildSlabTable(W, stream);
         W.order.endWrite(stream);
         curWorkGrid = next;
         packed.params.grid = W.a.ptr;
@@ -314,7 +279,7 @@ void fvsrn_network::releaseDevice() {
     dLds.release();
     dLdsScaled.release();
     dLdsCurvature.release();
-    for (WorkingGrid& w : workGrid) { w.a.release(); w.b.release(); w.cells.release(); w.cellsPlain.release(); w.slabs.release(); w.cellsValid = w.cellsPlainValid = w.slabsValid = false; w.order.release(); }
+    for (WorkingGrid& w : workGrid) { w.a.release(); w.b.release(); w.cells.release(); w.cellsPlain.release(); w.cellsValid = w.cellsPlainValid = false; w.order.release(); }
     imagesOrder.release();
     imageReaders.clear();
     keyStore.release();

@@ -310,111 +310,49 @@ hipError_t launch_evaluate_tf(const SceneParams& S, const float* density, const 
     return hipGetLastError();
 }
 
-// One thread per (cell, M tile, row): 8 corner values.  Records: the pair {v(x0), v(x0 + 1)} of channel c sits at dword c of record
-// (z, y, x0 + 1) (x clamping is baked into the records, pack.cpp); the fragment of (g, m) holds row r's weights of channels 16 g + 8 h .. + 7
-// in lane 32 h + r.
+// One thread per (cell, M tile, row) over the grid extended by one ghost cell per side (cell e spans the nodes e - 1, e per axis, clamped to the grid: the
+// ghost nodes repeat the boundary = clamp-to-edge).  V[corner] = sum over the latent channels of (first-layer latent column of the row) x (grid value at the
+// corner); the entry holds the coefficients of the interpolant in cell-centred coordinates, slot 4 c + 2 b + a = the coefficient of x^a y^b z^c:
+//     coefficient = sum over the corners of V[corner] s_x^a s_y^b s_z^c / 2^(3 - a - b - c),   s = -1 / +1 for the lower / upper node  (cell_tap, srn_device.hpp)
+// v(x) is the first half of the x-pair record x + 1; the fragment of (g, m) holds row r's weights of channels 16 g + 8 h .. + 7 in lane 32 h + r.
 __global__ void grid_cell_table_kernel(CellTableParams p) {
-    const unsigned cx = unsigned(p.X - 1), cy = unsigned(p.Y - 1), cz = unsigned(p.Z - 1);
+    const unsigned cx = unsigned(p.X + 1), cy = unsigned(p.Y + 1), cz = unsigned(p.Z + 1);
     const unsigned long long total = (unsigned long long)cx * cy * cz * unsigned(p.MT) * 32ull;
     const int KG = p.G / 16;
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
         const unsigned r = unsigned(i & 31);
         const unsigned m = unsigned((i >> 5) % unsigned(p.MT));
         const unsigned long long cell = (i >> 5) / unsigned(p.MT);
-        const unsigned x0 = unsigned(cell % cx), y0 = unsigned((cell / cx) % cy), z0 = unsigned(cell / (cx * (unsigned long long)cy));
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int ex = int(cell % cx), ey = int((cell / cx) % cy), ez = int(cell / (cx * (unsigned long long)cy));
+        float V[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // corner 4 dz + 2 dy + dx
         for (int g = 0; g < KG; ++g)
             for (int h = 0; h < 2; ++h) {
                 const _Float16* w = reinterpret_cast<const _Float16*>(static_cast<const char*>(p.latentFrags) + (size_t(g) * p.MT + m) * kFragBytes +
                                                                       (32 * h + r) * 16);
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned long long rec = ((unsigned long long)(z0 + (k >> 1)) * unsigned(p.Y) + (y0 + (k & 1))) * unsigned(p.X + 1) + (x0 + 1);
+                for (int k = 0; k < 8; ++k) {
+                    const int nx = min(max(ex - 1 + (k & 1), 0), p.X - 1), ny = min(max(ey - 1 + ((k >> 1) & 1), 0), p.Y - 1), nz = min(max(ez - 1 + (k >> 2), 0), p.Z - 1);
+                    const unsigned long long rec = ((unsigned long long)nz * unsigned(p.Y) + unsigned(ny)) * unsigned(p.X + 1) + unsigned(nx + 1);
                     const _Float16* v = reinterpret_cast<const _Float16*>(p.grid) + (rec * unsigned(p.G) + unsigned(16 * g + 8 * h)) * 2;
-                    for (int j = 0; j < 8; ++j) {
-                        acc[2 * k] = fmaf(float(w[j]), float(v[2 * j]), acc[2 * k]);
-                        acc[2 * k + 1] = fmaf(float(w[j]), float(v[2 * j + 1]), acc[2 * k + 1]);
-                    }
+                    for (int j = 0; j < 8; ++j) V[k] = fmaf(float(w[j]), float(v[2 * j]), V[k]);
                 }
             }
         _Float16* o = static_cast<_Float16*>(p.out) + i * 8;
-        for (int j = 0; j < 8; ++j) o[j] = _Float16(acc[j]);
+        for (int s = 0; s < 8; ++s) {  // slot s: exponents a = s & 1, b = (s >> 1) & 1, c = s >> 2
+            float acc = 0.f;
+            for (int k = 0; k < 8; ++k) {
+                const int flips = __popc(unsigned(~k & s));  // lower nodes (bit 0 of the corner) along the axes the monomial contains
+                acc += (flips & 1) ? -V[k] : V[k];
+            }
+            o[s] = _Float16(acc * (1.0f / float(1 << (3 - __popc(unsigned(s))))));
+        }
     }
 }
 
 hipError_t launch_grid_cell_table(const CellTableParams& p, hipStream_t s) {
-    const unsigned long long total = (unsigned long long)(p.X - 1) * (p.Y - 1) * (p.Z - 1) * unsigned(p.MT) * 32ull;
+    const unsigned long long total = (unsigned long long)(p.X + 1) * (p.Y + 1) * (p.Z + 1) * unsigned(p.MT) * 32ull;
     if (total == 0) return hipSuccess;
     const unsigned blocks = unsigned(std::min<unsigned long long>((total + 255) / 256, 16384ull));
     hipLaunchKernelGGL(grid_cell_table_kernel, dim3(blocks), dim3(256), 0, s, p);
-    return hipGetLastError();
-}
-
-// Slab table (srn_device.hpp, "latent grid through resident slabs"): one thread per (axis, extended cell L, M tile, row).  The slab (a, L) covers the cells
-// L and L + e_a of the grid extended by one ghost cell per side; its 3 x 2 x 2 nodes are (l_a - 1, l_a, l_a + 1) x (l_b - 1, l_b) x (l_c - 1, l_c), b and
-// c the next two axes cyclically, node indices clamped to the grid (ghost nodes repeat the boundary: clamp-to-edge).  With V[i][j][k] = W_row . G(node)
-// the interpolant in face-centred coordinates (xi_a = (texel_a - l_a) / 2, xi_b = texel_b - (l_b - 1/2)) is
-//     sum over A in {1, xi_a, |xi_a|}, B in {1, xi_b, xi_c, xi_b xi_c} of coef[A][B] A B,
-//     along a: P[0] = V[1], P[1] = V[2] - V[0], P[2] = V[2] + V[0] - 2 V[1]; across, for Q = P[i]: mean, b slope, c slope, twist.
-// K slots as slab_monomials packs them: lane half 0 {1, b, c, bc, a, ab, 0, 0}, lane half 1 {ac, abc, |a|, |a| b, |a| c, |a| bc, 0, 0}.
-__global__ void grid_slab_table_kernel(CellTableParams p) {
-    const unsigned ex = unsigned(p.X + 1), ey = unsigned(p.Y + 1), ez = unsigned(p.Z + 1);
-    const unsigned long long cells = (unsigned long long)ex * ey * ez;
-    const unsigned long long total = 3ull * cells * unsigned(p.MT) * 32ull;
-    const int KG = p.G / 16;
-    const int N[3] = {p.X, p.Y, p.Z};
-    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
-        const unsigned r = unsigned(i & 31);
-        const unsigned m = unsigned((i >> 5) % unsigned(p.MT));
-        const unsigned long long slab = (i >> 5) / unsigned(p.MT);
-        const int axis = int(slab / cells);
-        const unsigned long long cell = slab % cells;
-        const int l[3] = {int(cell % ex), int((cell / ex) % ey), int(cell / ((unsigned long long)ex * ey))};
-        const int ra = axis, rb = (axis + 1) % 3, rc = (axis + 2) % 3;
-        float V[3][2][2] = {};
-        for (int g = 0; g < KG; ++g)
-            for (int h = 0; h < 2; ++h) {
-                const _Float16* w = reinterpret_cast<const _Float16*>(static_cast<const char*>(p.latentFrags) + (size_t(g) * p.MT + m) * kFragBytes +
-                                                                      (32 * h + r) * 16);
-                float wf[8];
-                for (int j = 0; j < 8; ++j) wf[j] = float(w[j]);
-                for (int ia = 0; ia < 3; ++ia)
-                    for (int ib = 0; ib < 2; ++ib)
-                        for (int ic = 0; ic < 2; ++ic) {
-                            int n[3];
-                            n[ra] = min(max(l[ra] - 1 + ia, 0), N[ra] - 1);
-                            n[rb] = min(max(l[rb] - 1 + ib, 0), N[rb] - 1);
-                            n[rc] = min(max(l[rc] - 1 + ic, 0), N[rc] - 1);
-                            // v(x) = the first half of the x-pair record x + 1 (grid_cell_table_kernel)
-                            const unsigned long long rec = ((unsigned long long)n[2] * unsigned(p.Y) + unsigned(n[1])) * unsigned(p.X + 1) + unsigned(n[0] + 1);
-                            const _Float16* v = reinterpret_cast<const _Float16*>(p.grid) + (rec * unsigned(p.G) + unsigned(16 * g + 8 * h)) * 2;
-                            float acc = V[ia][ib][ic];
-                            for (int j = 0; j < 8; ++j) acc = fmaf(wf[j], float(v[2 * j]), acc);
-                            V[ia][ib][ic] = acc;
-                        }
-            }
-        float coef[3][4];
-        for (int k = 0; k < 3; ++k) {
-            float Q[2][2];
-            for (int ib = 0; ib < 2; ++ib)
-                for (int ic = 0; ic < 2; ++ic)
-                    Q[ib][ic] = k == 0 ? V[1][ib][ic] : (k == 1 ? V[2][ib][ic] - V[0][ib][ic] : V[2][ib][ic] + V[0][ib][ic] - 2.f * V[1][ib][ic]);
-            coef[k][0] = 0.25f * (Q[0][0] + Q[1][0] + Q[0][1] + Q[1][1]);
-            coef[k][1] = 0.5f * ((Q[1][0] + Q[1][1]) - (Q[0][0] + Q[0][1]));
-            coef[k][2] = 0.5f * ((Q[0][1] + Q[1][1]) - (Q[0][0] + Q[1][0]));
-            coef[k][3] = Q[1][1] - Q[1][0] - Q[0][1] + Q[0][0];
-        }
-        const float k0[8] = {coef[0][0], coef[0][1], coef[0][2], coef[0][3], coef[1][0], coef[1][1], 0.f, 0.f};
-        const float k1[8] = {coef[1][2], coef[1][3], coef[2][0], coef[2][1], coef[2][2], coef[2][3], 0.f, 0.f};
-        _Float16* o = static_cast<_Float16*>(p.out) + ((slab * unsigned(p.MT) + m) * 1024ull) / 2;
-        for (int j = 0; j < 8; ++j) { o[r * 8 + j] = _Float16(k0[j]); o[256 + r * 8 + j] = _Float16(k1[j]); }
-    }
-}
-
-hipError_t launch_grid_slab_table(const CellTableParams& p, hipStream_t s) {
-    const unsigned long long total = 3ull * (unsigned long long)(p.X + 1) * (p.Y + 1) * (p.Z + 1) * unsigned(p.MT) * 32ull;
-    if (total == 0) return hipSuccess;
-    const unsigned blocks = unsigned(std::min<unsigned long long>((total + 255) / 256, 16384ull));
-    hipLaunchKernelGGL(grid_slab_table_kernel, dim3(blocks), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

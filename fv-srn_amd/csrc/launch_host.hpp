@@ -32,8 +32,6 @@ struct CellTableParams {
     int MT;                  // M tiles of the network
 };
 hipError_t launch_grid_cell_table(const CellTableParams& p, hipStream_t s);
-// Slab table of a working grid (NetParams::slabTable, device_params.hpp; same parameters, out = fp16 [3][(X+1)(Y+1)(Z+1)][MT][2][32][8])
-hipError_t launch_grid_slab_table(const CellTableParams& p, hipStream_t s);
 
 // IImageEvaluator::ExtractColor: raw (8,H,W) -> planar fp32 (4,H,W) or packed RGBA8; d_minmax: 2 floats of scratch
 struct ExtractParams {

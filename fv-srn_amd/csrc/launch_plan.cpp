@@ -142,8 +142,7 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
                 const bool scalarNet = a.P.outputMode == FVSRN_OUT_DENSITY || a.P.outputMode == FVSRN_OUT_DENSITY_DIRECT;
                 // latent grid: 2 = through the cell table (any number of latent channels), 1 = one decoded 16-channel chunk by gathers;
                 // both need the first layer's bias in its weights (bias0Folded: no time input), the resident kernels drop that bias block
-                // (r06: SGRID = 2 reads the SLAB table -- the resident pair of cells, srn_device.hpp -- where r04 / r05 read the cell table)
-                smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.bias0Folded ? (net->slabTableBytes && useCells ? 2 : (a.P.gridK == 1 ? 1 : 3)) : 3);
+                smallGrid = k.grid == 0 ? 0 : (k.grid == 1 && a.P.bias0Folded ? (net->cellTableBytes && useCells ? 2 : (a.P.gridK == 1 ? 1 : 3)) : 3);
                 if (O[FVSRN_OPT_SMALL_KERNEL] != 0 && net->opts[FVSRN_OPT_SMALL_KERNEL] != 0 && !a.shaded && k.CD == 2 && smallGrid <= 2 && !a.P.noFourier && !a.P.fourierNeedsFract &&
                     !a.P.fourierClampPos &&  // (the resident kernels compile the position clamp out)
                     a.P.numLayers >= 1 && a.P.numLayers <= 3 && (rgbo || (scalarNet && d.tf_kind != FVSRN_TF_NONE)))
@@ -189,14 +188,8 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             if (a.shaded && d.gradient_mode != FVSRN_GRADIENT_ADJOINT_METHOD && net->key.grid == 1 && net->cellTableBytes && useCells)
                 cellsFn = render_shaded_cells_fn(net->key);
             // the table itself: built by the first launch that goes through it (and from then on with every blend, until a launch does not)
-            if (cellsFn) a.P.cellTable = net->ensureCellTable(a.shaded, s);
+            if ((smallFn && smallGrid == 2) || cellsFn) a.P.cellTable = net->ensureCellTable(a.shaded, s);
             else (a.shaded ? net->cellsPlainWanted : net->cellsWanted) = false;
-            if (smallFn && smallGrid == 2) {  // (the slab table travels in the cell table's fields: device_params.hpp)
-                a.P.cellTable = net->ensureSlabTable(s);
-                a.P.cellCount = unsigned(net->slabTableBytes / (3 * 1024));
-                a.P.cellStride = 1024u;
-            }
-            else if (!a.shaded) net->slabsWanted = false;
             net->beginUse(s);
             struct Done { fvsrn_network* n; hipStream_t s; ~Done() { try { n->endUse(s); } catch (...) {} } } done{net, s};
             const void* altFn = smallFn ? smallFn : (stripeFn ? stripeFn : (cellsFn ? cellsFn : adjointFn));
@@ -336,7 +329,17 @@ int fvsrn_debug_state(char* buf, size_t cap) {
                    ", units " + std::to_string(L.units) + ", image " + std::to_string(L.width) + " x " + std::to_string(L.height) + " (" + std::to_string(L.rows) +
                    " rows, world " + std::to_string(L.stripeWorld) + "), frames " + std::to_string(L.frames) + ", " + (L.persistent == 1 ? "persistent" : (L.persistent == 2 ? "bounded waves" : "one unit per wave")) +
                    ", segments " + std::to_string(sc->lastInfo[0]) + ", waves/workgroup " + std::to_string(sc->lastInfo[3]);
-            if (L.count) out += std::string(", stream ") + (hipStreamQuery(static_cast<hipStream_t>(L.stream)) == hipSuccess ? "idle" : "BUSY");
+            // r06: this runs on a watchdog thread whose current device is 0 by default -- the copy stream below belongs on the SCENE's device
+            // (a rank process bound to GPU r would otherwise open a context on GPU 0 and copy across devices); restored on the way out.  The launch's stream
+            // is the caller's: it is only queried while it is the legacy / per-thread default stream (handles that cannot have been destroyed).
+            int prevDev = -1;
+            (void)hipGetDevice(&prevDev);
+            struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{sc->device >= 0 && sc->device != prevDev ? prevDev : -1};
+            if (sc->device >= 0 && sc->device != prevDev) (void)hipSetDevice(sc->device);
+            const hipStream_t ls_ = static_cast<hipStream_t>(L.stream);
+            if (L.count && (ls_ == nullptr || ls_ == hipStreamPerThread || ls_ == hipStreamLegacy))
+                out += std::string(", stream ") + (hipStreamQuery(ls_) == hipSuccess ? "idle" : "BUSY");
+            else if (L.count) out += ", stream: the caller's (not queried: it may be gone)";
             (void)hipGetLastError();
             if (sc->dCounters.ptr) {
                 int host[2] = {-1, -1};
@@ -397,8 +400,13 @@ int fvsrn_render_stripes_batch(fvsrn_scene* const* scenes, void* const* streams,
                                int use_tonemapping, float max_exposure, unsigned long long* d_stats) {
     if (!scenes || !streams || lanes < 1 || lanes > 8 || !net || !cameras9 || !d_out_local || frames < 0)
         return fail(FVSRN_ERR_INVALID_ARGUMENT, "null argument, or lanes outside 1 .. 8");
-    if (stripe_rows <= 0 || stripe_rows % 8 != 0 || world <= 0 || rank < 0 || rank >= world)
+    // (world == 1: a whole frame, the stripe height is not used)
+    if ((world != 1 && (stripe_rows <= 0 || stripe_rows % 8 != 0)) || world <= 0 || rank < 0 || rank >= world)
         return fail(FVSRN_ERR_INVALID_ARGUMENT, "stripe_rows must be a positive multiple of 8 and 0 <= rank < world");
+    // r06: like every entry point, nothing thrown below crosses the C boundary.  What a failure in the MIDDLE of a batch leaves behind is stated in
+    // include/fvsrn.h: the frames before the failing group are enqueued, the scenes of the lanes carry the camera of their last group, the network the time of
+    // the failing frame -- the caller re-sends both with its next call (a batch always does).
+    return guarded([&]() -> int {
     for (int l = 0; l < lanes; ++l) {
         if (!scenes[l]) return fail(FVSRN_ERR_INVALID_ARGUMENT, "null scene");
         for (int m = 0; m < l; ++m)
@@ -440,6 +448,7 @@ int fvsrn_render_stripes_batch(fvsrn_scene* const* scenes, void* const* streams,
             }
     }
     return FVSRN_OK;
+    });
 }
 
 }  // extern "C"

@@ -407,33 +407,34 @@ __device__ __forceinline__ half8_t grid_features(const NetParams& P, const GridT
 // fetch of the table entry (512 bytes per M tile), 8 v_cndmask + 4 lane-half swaps and a handful of scalar instructions, with the same number of MFMAs as the latent K step it stands in for
 // (and any number of latent channels costs the same).  Samples in a third cell (corners of the cell lattice; a few percent of the steps have any)
 // get further cell pairs, accumulated into the same first-layer accumulators (cells_accumulate: wave-uniform).
-// Same texture semantics as grid_tap: texel coordinate p N - 0.5 clamped to [0, N - 1], cell x0 = min(floor, N - 2), weight wx = coordinate - x0
-// (1 exactly on the last texel); fp16 weights like there; the table entries carry one fp16 rounding of W.G where the gather path rounds
-// the interpolated feature.
+// Same texture semantics as grid_tap (clamp-to-edge, through the ghost cells of the table: cell_tap); the B operand is in fp16 like the weights there; the
+// table entries carry one fp16 rounding of W.(combination of the corner vectors) where the gather path rounds the interpolated feature.
 struct CellTap {
-    unsigned w[4];  // packed fp16 weight pairs {w_zy (1 - wx), w_zy wx}, zy = 2 dz + dy: the eight K slots of the sample's cell
+    unsigned w[4];  // packed fp16 monomial pairs {1, x}, {y, xy}, {z, xz}, {yz, xyz} of the sample's cell-centred coordinates: the eight K slots of its cell
     unsigned cell;
 };
 
+// r06: MONOMIALS instead of corner weights, GHOST cells instead of clamps.  Inside a cell the trilinear interpolant is sum c_abc x^a y^b z^c over a, b, c in
+// {0, 1} in coordinates centred on the cell (x, y, z in [-1/2, 1/2]); the table entry holds the eight coefficient vectors (the corner vectors combined on
+// the host side of the table build, grid_cell_table_kernel) in K slot 4 c + 2 b + a.  The table runs over the grid extended by one ghost cell per side whose
+// outer nodes repeat the boundary nodes (= the texture unit's clamp-to-edge), cell e = round(p N) in [0, N] per axis spans the texel coordinates [e - 1, e].
+// Per sample: 3 x (mul, round, sub) + two fma, a convert and a min for the cell index, one product + two packed products, four converts = 20 vector
+// instructions where the corner form took 34 (three clamps, floors and clamps again, three 1 - w, twelve products).  A sample exactly on a cell face may
+// land in either cell: the interpolant is continuous.  fp16 error against the corner form: 1.4 x on random data (tools/dev/slab_precision.py).
 __device__ __forceinline__ CellTap cell_tap(const NetParams& P, float px, float py, float pz) {
-    const float xm = P.gridXf - 1.f, ym = P.gridYf - 1.f, zm = P.gridZf - 1.f;
-    const float fx = __builtin_amdgcn_fmed3f(fmaf(px, P.gridXf, -0.5f), 0.f, xm);
-    const float fy = __builtin_amdgcn_fmed3f(fmaf(py, P.gridYf, -0.5f), 0.f, ym);
-    const float fz = __builtin_amdgcn_fmed3f(fmaf(pz, P.gridZf, -0.5f), 0.f, zm);
-    // min(floor, N - 2) as a median with -1 (floor >= 0): v_med3_f32 takes its operands as they are, fminf would canonicalise the bound at every step
-    const float x0 = __builtin_amdgcn_fmed3f(floorf(fx), -1.f, xm - 1.f), y0 = __builtin_amdgcn_fmed3f(floorf(fy), -1.f, ym - 1.f),
-                z0 = __builtin_amdgcn_fmed3f(floorf(fz), -1.f, zm - 1.f);
-    const float wx = fx - x0, wy = fy - y0, wz = fz - z0;
+    const float gx = px * P.gridXf, gy = py * P.gridYf, gz = pz * P.gridZf;
+    const float ex = __builtin_rintf(gx), ey = __builtin_rintf(gy), ez = __builtin_rintf(gz);
+    const float x = gx - ex, y = gy - ey, z = gz - ez;
     CellTap t;
-    // (exact in fp32: fewer than 2^24 cells; positions of rays that miss the box may be anything, also NaN: any valid cell will do)
-    t.cell = min(unsigned(fmaf(fmaf(z0, ym, y0), xm, x0)), P.cellCount - 1u);
-    const float ux = 1.f - wx, uy = 1.f - wy, uz = 1.f - wz;
-    const float w4[4] = {uz * uy, uz * wy, wz * uy, wz * wy};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float2_t v = {w4[k] * ux, w4[k] * wx};
-        t.w[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
-    }
+    // (exact in fp32: fewer than 2^24 cells; positions of rays that miss the box may be anything, also NaN: any valid cell will do -- the convert saturates)
+    t.cell = min(unsigned(fmaf(fmaf(ez, P.gridYf + 1.f, ey), P.gridXf + 1.f, ex)), P.cellCount - 1u);
+    const float2_t a = {1.f, x}, b = {y, x * y};
+    const float2_t zz = {z, z};
+    const float2_t c = a * zz, d = b * zz;
+    t.w[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(a, half2_t));
+    t.w[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(b, half2_t));
+    t.w[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(c, half2_t));
+    t.w[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(d, half2_t));
     return t;
 }
 
@@ -459,7 +460,11 @@ __device__ __forceinline__ unsigned cell_pair(const NetParams& P, const unsigned
 #pragma unroll
     for (int k = 0; k < 4; ++k) b[k] = select_bits_by_mask(sel, w[k]);
     bfrag = __builtin_bit_cast(half8_t, b);
+#ifdef FVSRN_ABL_CELL0
+    const unsigned off = __umul24((h ? cB : cA) & 63u, P.cellStride) + laneOff;
+#else
     const unsigned off = __umul24(h ? cB : cA, P.cellStride) + laneOff;  // (both below 2^24, the table below 2^31 bytes: api.cpp)
+#endif
     const char* base = static_cast<const char*>(P.cellTable) + off;
 #pragma unroll
     for (int m = 0; m < MT; ++m) afrag[m] = *reinterpret_cast<const half8_t*>(base + 512 * m);
@@ -502,7 +507,12 @@ __device__ __forceinline__ void cell_prepare(const NetParams& P, float px, float
     }
     C.gf[0] = __builtin_bit_cast(half8_t, b0);
     C.gf[1] = __builtin_bit_cast(half8_t, b1);
+#ifdef FVSRN_ABL_CELL0  // ablation (wrong image, same instruction stream): every table fetch reads cell (index & 63) -- a 64-entry working set that stays in L2 --
+                        // to price the table's L2 misses of the 64-wide latent-grid frames (291 MB per frame for 33.5 MB of output)
+    const char* base = static_cast<const char*>(P.cellTable) + (__umul24((h ? cB : cA) & 63u, P.cellStride) + laneOff);
+#else
     const char* base = static_cast<const char*>(P.cellTable) + (__umul24(h ? cB : cA, P.cellStride) + laneOff);
+#endif
 #pragma unroll
     for (int m = 0; m < MT; ++m) C.ga[m] = *reinterpret_cast<const half8_t*>(base + 512 * m);
 }
@@ -529,174 +539,6 @@ __device__ __forceinline__ void cells_accumulate(const NetParams& P, const CellP
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[m], gf, acc[m], 0, 0, 0);
         } while (rem);
-    }
-}
-
-// ---- latent grid through resident slabs (r06) --------------------------------------------------------------------------------------
-// The cell path above re-derives, at EVERY step, each lane's cell and eight weights (19 + 15 vector instructions), picks the wave's two cells
-// (two v_readlane and their scalar chain), fetches their table entries and assembles the B fragments with eight v_cndmask and four lane-half swaps:
-// 67 vector + 11 scalar instructions per wave step for two MFMAs (r05 PMC, 32 x 4 + 16^3: 197.9 VALU per step against 130.3 without a grid).  But
-// the samples of a wave step move by 0.03 cells per step: the wave stays inside the same PAIR of face-adjacent cells -- a "slab" -- for ten and
-// more steps (tools/dev/slab_sim.py: 85 % of the steps of the 16^3 headline frame, 65 % at 32^3).  Inside a slab (axis a, cells L and L + e_a) the
-// trilinear interpolant is, in coordinates centred on the shared face (xi_a in [-1/2, 1/2] over BOTH cells, xi_b / xi_c over the cell),
-//     f = sum over {1, xi_a, |xi_a|} x {1, xi_b, xi_c, xi_b xi_c} of 12 coefficients        (piecewise linear along a: the kink is the |xi_a| term)
-// with NO reference to which of the two cells a sample is in: no per-lane cell index, no membership mask, no selection.  So the slab's table entry
-// (12 coefficient vectors W_latent . (combination of the 12 corner vectors), fp16, 1 KiB per M tile: grid_slab_table_kernel, launch.hip) stays in four
-// registers as the A fragment, and a step costs three fma for the coordinates, one v_max3 + v_cmp for "every valid lane is inside", four products, six
-// packs (two of them sign flips of a-containing pairs), three lane-half swaps.  The table is indexed over the grid EXTENDED by one ghost cell per
-// side whose outer nodes repeat the boundary nodes: interpolating between equal values is the texture unit's clamp-to-edge, so the coordinate clamps
-// of grid_tap / cell_tap disappear as well.
-// A step with a valid lane outside the resident slab picks a new slab (slab_select: the cell of the first valid lane, paired with the cell of the
-// first valid lane elsewhere, or with its +x neighbour), fetches its entry, and covers the lanes outside it -- a few percent of the steps have any,
-// at the corners of the cell lattice -- with further slabs tile by tile (slab_accumulate), masked.
-constexpr float kSlabHalf = 0.5f + 1.0f / 8192.0f;  // in-slab test with a tolerance (the polynomial extends smoothly: 1e-4 of a cell outside costs nothing)
-
-struct SlabFrame {
-    float ns[3];  // roles a, b, c: position -> slab coordinate scale (N / 2 along the slab axis, N across), wave-uniform
-    float c[3];   // ... and offset
-    int axis;     // the slab axis (0 x, 1 y, 2 z; roles b, c = the next two axes cyclically), -1: no slab yet
-};
-template <int MT>
-struct SlabState {  // what stays resident along a ray tile
-    SlabFrame f;
-    half8_t a[MT];
-};
-struct SlabPre {  // what the first layer needs of this step
-    half8_t gf[2];           // B fragments of the two column tiles for the resident slab
-    unsigned long long rem;  // valid samples outside it
-    float px, py, pz;        // (for their slabs: slab_accumulate)
-};
-
-__device__ __forceinline__ float readlane_f(float v, int l) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-__device__ __forceinline__ float uniform_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
-
-// slab coordinates of this lane's sample and whether it lies inside the slab
-__device__ __forceinline__ bool slab_coords(const SlabFrame& f, float px, float py, float pz, float& a, float& b, float& c) {
-    // wave-uniform branches (the empty asm keeps hipcc from turning them into six v_cndmask)
-    if (f.axis == 0) {
-        asm volatile("");
-        a = fmaf(px, f.ns[0], f.c[0]); b = fmaf(py, f.ns[1], f.c[1]); c = fmaf(pz, f.ns[2], f.c[2]);
-    } else if (f.axis == 1) {
-        asm volatile("");
-        a = fmaf(py, f.ns[0], f.c[0]); b = fmaf(pz, f.ns[1], f.c[1]); c = fmaf(px, f.ns[2], f.c[2]);
-    } else {
-        asm volatile("");
-        a = fmaf(pz, f.ns[0], f.c[0]); b = fmaf(px, f.ns[1], f.c[1]); c = fmaf(py, f.ns[2], f.c[2]);
-    }
-    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c)) <= kSlabHalf;
-}
-
-// The twelve monomials as six packed fp16 pairs: K slots {1, b | c, bc | a, ab} of lane half 0 and {ac, abc | |a|, |a| b | |a| c, |a| bc} of lane
-// half 1 (the fourth register of either half is zero; grid_slab_table_kernel writes the coefficients in this order).  The |a| pairs are the a pairs
-// with the sign of a flipped away: exact, and two bit operations instead of three products and two converts.
-__device__ __forceinline__ void slab_monomials(float a, float b, float c, unsigned (&r)[6]) {
-    const float bc = b * c, ab = a * b, ac = a * c, abc = ab * c;
-    r[0] = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{1.f, b}), half2_t));
-    r[1] = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{c, bc}), half2_t));
-    r[2] = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{a, ab}), half2_t));
-    r[3] = __builtin_bit_cast(unsigned, __builtin_convertvector((float2_t{ac, abc}), half2_t));
-    const unsigned flip = unsigned(__builtin_bit_cast(int, a) >> 31) & 0x80008000u;
-    r[4] = r[2] ^ flip;
-    r[5] = r[3] ^ flip;
-}
-
-// -> the B fragments of the two column tiles: registers {r0, r1, r2, 0} are the K slots of lane half 0, {r3, r4, r5, 0} those of lane half 1; one
-// lane-half swap per register pair leaves tile 0's fragment register in the first result and tile 1's in the second (see cell_prepare)
-__device__ __forceinline__ void slab_fragments(const unsigned (&r)[6], half8_t (&gf)[2]) {
-    const auto s0 = lane_half_swap(r[0], r[3]);
-    const auto s1 = lane_half_swap(r[1], r[4]);
-    const auto s2 = lane_half_swap(r[2], r[5]);
-    const uint4_t b0 = {s0[0], s1[0], s2[0], 0u}, b1 = {s0[1], s1[1], s2[1], 0u};
-    gf[0] = __builtin_bit_cast(half8_t, b0);
-    gf[1] = __builtin_bit_cast(half8_t, b1);
-}
-
-// A slab for the samples whose bit is set in `cand` (not empty): the extended cell of the first of them, paired along the first axis in which the
-// first candidate in ANOTHER cell differs (towards that cell), else with its +x neighbour (-x at the far ghost cell).  Everything here is wave-uniform
-// scalar bookkeeping on three v_readlane pairs; its table entry is fetched (one coalesced 1 KiB read per M tile).
-template <int MT>
-__device__ __forceinline__ void slab_select(const NetParams& P, float px, float py, float pz, unsigned long long cand, int lane, SlabFrame& F, half8_t (&A)[MT]) {
-    // extended cell index per axis: floor(texel coordinate) + 1 = floor(p N + 1/2) in [0, N]  (cell k spans the texel coordinates [k - 1, k])
-    const float ex = __builtin_amdgcn_fmed3f(floorf(fmaf(px, P.gridXf, 0.5f)), 0.f, P.gridXf);
-    const float ey = __builtin_amdgcn_fmed3f(floorf(fmaf(py, P.gridYf, 0.5f)), 0.f, P.gridYf);
-    const float ez = __builtin_amdgcn_fmed3f(floorf(fmaf(pz, P.gridZf, 0.5f)), 0.f, P.gridZf);
-    const int r0 = __builtin_ctzll(cand);
-    const float c0x = readlane_f(ex, r0), c0y = readlane_f(ey, r0), c0z = readlane_f(ez, r0);
-    const unsigned long long same = __builtin_amdgcn_ballot_w64(ex == c0x) & __builtin_amdgcn_ballot_w64(ey == c0y) & __builtin_amdgcn_ballot_w64(ez == c0z);
-    const unsigned long long others = cand & ~same;
-    int axis = 0;
-    bool up = c0x < P.gridXf;
-    if (others) {
-        const int r1 = __builtin_ctzll(others);
-        const float c1x = readlane_f(ex, r1), c1y = readlane_f(ey, r1), c1z = readlane_f(ez, r1);
-        axis = c1x != c0x ? 0 : (c1y != c0y ? 1 : 2);
-        up = axis == 0 ? c1x > c0x : (axis == 1 ? c1y > c0y : c1z > c0z);
-    }
-    const float step = up ? 0.f : 1.f;  // the slab's LOWER cell
-    const float lx = c0x - (axis == 0 ? step : 0.f), ly = c0y - (axis == 1 ? step : 0.f), lz = c0z - (axis == 2 ? step : 0.f);
-    // roles: a = the slab axis, b / c the next two axes.  xi_a = (texel - l_a) / 2 = p N_a / 2 - (l_a + 1/2) / 2 (the shared face is the node l_a);
-    // xi_b = texel - (l_b - 1/2) = p N_b - l_b (the cell's centre)
-    const float na = axis == 0 ? P.gridXf : (axis == 1 ? P.gridYf : P.gridZf), nb = axis == 0 ? P.gridYf : (axis == 1 ? P.gridZf : P.gridXf),
-                nc = axis == 0 ? P.gridZf : (axis == 1 ? P.gridXf : P.gridYf);
-    const float la = axis == 0 ? lx : (axis == 1 ? ly : lz), lb = axis == 0 ? ly : (axis == 1 ? lz : lx), lc = axis == 0 ? lz : (axis == 1 ? lx : ly);
-    F.axis = axis;
-    F.ns[0] = uniform_f(0.5f * na); F.ns[1] = uniform_f(nb); F.ns[2] = uniform_f(nc);
-    F.c[0] = -0.5f * (la + 0.5f); F.c[1] = -lb; F.c[2] = -lc;
-    // (exact in fp32: fewer than 2^24 extended cells, the table below 2^31 bytes: keyframes.cpp)
-    const unsigned lin = unsigned(__builtin_amdgcn_readfirstlane(int(fmaf(fmaf(lz, P.gridYf + 1.f, ly), P.gridXf + 1.f, lx))));
-    // (NetParams::cellTable / cellCount of a slab launch: the slab table and its extended cell count, device_params.hpp)
-    const unsigned slab = min(unsigned(axis) * P.cellCount + lin, 3u * P.cellCount - 1u);
-    const char* base = static_cast<const char*>(P.cellTable) + size_t(slab) * size_t(1024 * MT) + unsigned(lane) * 16u;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) A[m] = *reinterpret_cast<const half8_t*>(base + 1024 * m);
-}
-
-// One wave step's latent grid for the first layer: the resident slab (replaced if a valid sample lies outside it) and what it leaves uncovered
-template <int MT>
-__device__ __forceinline__ void slab_prepare(const NetParams& P, SlabState<MT>& S, float px, float py, float pz, unsigned long long validMask, int lane, SlabPre& C) {
-    C.px = px; C.py = py; C.pz = pz;
-    float a = 0.f, b = 0.f, c = 0.f;
-    unsigned long long in = 0ull;
-    if (S.f.axis >= 0) in = __builtin_amdgcn_ballot_w64(slab_coords(S.f, px, py, pz, a, b, c));
-    unsigned long long rem = validMask & ~in;
-    if (rem != 0ull || S.f.axis < 0) {  // wave-uniform: 15 % of the steps of the 16^3 headline frame, 35 % at 32^3
-        const unsigned long long cand = validMask ? validMask : 1ull;  // (a step always has a valid lane: kernels.hpp breaks otherwise)
-        slab_select<MT>(P, px, py, pz, cand, lane, S.f, S.a);
-        in = __builtin_amdgcn_ballot_w64(slab_coords(S.f, px, py, pz, a, b, c)) | (1ull << __builtin_ctzll(cand));
-        rem = validMask & ~in;
-    }
-    unsigned r[6];
-    slab_monomials(a, b, c, r);
-    if (rem != 0ull) {  // samples outside get zero columns here and their own slabs in slab_accumulate
-#pragma unroll
-        for (int k = 0; k < 6; ++k) r[k] = select_bits_by_mask(in, r[k]);
-    }
-    slab_fragments(r, C.gf);
-    C.rem = rem;
-}
-
-// The latent K step of tile t into the first layer's accumulators: the resident slab, then -- wave-uniform, rare -- slabs for the tile's samples outside it
-template <int MT>
-__device__ __forceinline__ void slab_accumulate(const NetParams& P, const SlabState<MT>& S, const SlabPre& C, int t, int lane, floatx16* acc) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(S.a[m], C.gf[t], acc[m], 0, 0, 0);
-    unsigned long long rem = C.rem & (t ? 0xffffffff00000000ull : 0x00000000ffffffffull);
-    while (rem != 0ull) {
-        SlabFrame F;
-        half8_t A[MT], gf[2];
-        slab_select<MT>(P, C.px, C.py, C.pz, rem, lane, F, A);
-        float a, b, c;
-        const unsigned long long in = (__builtin_amdgcn_ballot_w64(slab_coords(F, C.px, C.py, C.pz, a, b, c)) & rem) | (1ull << __builtin_ctzll(rem));
-        unsigned r[6];
-        slab_monomials(a, b, c, r);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) r[k] = select_bits_by_mask(in, r[k]);
-        slab_fragments(r, gf);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[m], t ? gf[1] : gf[0], acc[m], 0, 0, 0);
-        rem &= ~in;
     }
 }
 
@@ -1513,12 +1355,12 @@ __device__ __forceinline__ void load_resident(const NetParams& P, const char* ld
 // colour networks; otherwise only output 0)
 template <int ACT, int NLC, int NFILL, bool ALL4, int RGRID = 0, class Pre, class Fill>
 __device__ __forceinline__ float4_t srn_layers_resident(const NetParams& P, const ResidentNet<NLC, RGRID>& R, half8_t (&xb)[2][2], Pre&& pre, Fill&& fill,
-                                                        const half8_t* gf = nullptr, const SlabState<1>* slab = nullptr, const SlabPre* slabPre = nullptr) {
+                                                        const half8_t* gf = nullptr, const CellPre<1>* cells = nullptr) {
     // the latent K step of layer 0: RGRID = 1: gf = B fragments of the two tiles' latent features, A = R.wg[0] (the first layer's latent
-    // columns); RGRID = 2: the resident slab of the slab table (slab_accumulate; r04 - r05: the cell table)
+    // columns); RGRID = 2: through the cell table (cells_accumulate)
     [[maybe_unused]] const int lane_ = lane_id();
     auto latent = [&](int T, floatx16& a) {
-        if constexpr (RGRID == 2) slab_accumulate<1>(P, *slab, *slabPre, T, lane_, &a);
+        if constexpr (RGRID == 2) cells_accumulate<1>(P, *cells, T, lane_ >> 5, unsigned(lane_ & 31) * 16u, &a);
         else a = __builtin_amdgcn_mfma_f32_32x32x16_f16(R.wg[0], gf[T], a, 0, 0, 0);
     };
     const float actA = P.actA, actB = P.actB;
@@ -1621,13 +1463,13 @@ __device__ __forceinline__ float4_t srn_forward_resident_grid(const NetParams& P
 }
 
 template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
-__device__ __forceinline__ float4_t srn_forward_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, SlabState<1>& slab, float px, float py, float pz,
+__device__ __forceinline__ float4_t srn_forward_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, float px, float py, float pz,
                                                               float dx, float dy, float dz, unsigned long long validMask) {
     constexpr int NPASS = HAS_DIR ? 4 : 2;
     const int lane = lane_id();
     const int h = lane >> 5;
-    SlabPre C;
-    slab_prepare<1>(P, slab, px, py, pz, validMask, lane, C);
+    CellPre<1> C;
+    cell_prepare<1>(P, px, py, pz, validMask, h, unsigned(lane & 31) * 16u, C);
     half8_t b0[2], xb[2][2];
     phase_operands<HAS_DIR, true>(px, py, pz, dx, dy, dz, h, b0);
     floatx16 d[2];
@@ -1644,7 +1486,7 @@ __device__ __forceinline__ float4_t srn_forward_resident_cells(const NetParams& 
         for (int q = 0; q < 4; ++q) act_pack_quarter<ACT_NONE>(d[t], q, 0.f, 0.f, xb[t][0], xb[t][1]);
         __builtin_amdgcn_sched_barrier(0);
     }
-    return srn_layers_resident<ACT, NLC, 0, ALL4, 2>(P, R, xb, []() {}, [](int) {}, nullptr, &slab, &C);
+    return srn_layers_resident<ACT, NLC, 0, ALL4, 2>(P, R, xb, []() {}, [](int) {}, nullptr, &C);
 }
 
 // The same with rotated Fourier features (r03): the current features stay in 32 registers (fp32, both tiles), their per-step rotation
@@ -1735,23 +1577,31 @@ __device__ __forceinline__ float4_t srn_forward_rotating_resident(const NetParam
 
 // srn_forward_resident_cells with rotated Fourier features (the registers the gathers held take the rotation state)
 template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
-__device__ __forceinline__ float4_t srn_forward_rotating_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, SlabState<1>& slab, floatx16 (&feat)[2][1],
+__device__ __forceinline__ float4_t srn_forward_rotating_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, floatx16 (&feat)[2][1],
                                                                        const floatx16 (&dfeat)[2][1], float px, float py, float pz,
                                                                        unsigned long long validMask, bool advance = true) {
     const int lane = lane_id();
-    SlabPre C;
-    slab_prepare<1>(P, slab, px, py, pz, validMask, lane, C);
+    CellPre<1> C;
+    cell_prepare<1>(P, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
     half8_t xb[2][2];
     return srn_layers_resident<ACT, NLC, 0, ALL4, 2>(
         P, R, xb,
         [&]() {
             feature_fragments<2>(feat, xb);
+#ifndef FVSRN_CELLS_NO_CVT_BARRIER
+            // r06: both tiles' converts BEFORE the rotation.  Without the barrier hipcc sinks tile 1's eight converts behind tile 0's first-layer MFMAs, which
+            // keeps tile 1's un-rotated features alive across its rotation: the rotation then writes fresh registers and the loop ends with eight v_mov_b64
+            // back into place (seen in the r05 listing of render_small_kernel<4,false,3,4,2>; the kernel without a grid has none).
+            // (an empty asm that ties tile 1's fragments and its features together: a sched_barrier alone does not stop the IR-level sinking)
+            asm volatile("" : "+v"(feat[1][0]), "+v"(xb[1][0]), "+v"(xb[1][1]));
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             if (advance) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) fourier_advance_piece<2, HAS_DIR>(feat, dfeat, c);
             }
         },
-        [](int) {}, nullptr, &slab, &C);
+        [](int) {}, nullptr, &C);
 }
 
 // output parametrization, renderer_volume_tensorcores.cuh:1054-1158. The reference rounds the

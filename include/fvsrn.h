@@ -41,7 +41,8 @@ extern "C" {
 #define FVSRN_ERR_DEVICE (-5)           /* HIP runtime error                               */
 #define FVSRN_ERR_NO_DEVICE (-6)        /* no GPU / kernels not usable                     */
 #define FVSRN_ERR_IO (-7)               /* file cannot be opened / written                   */
-#define FVSRN_ERR_WRONG_DEVICE (-8)     /* the handle's device state lives on another HIP device than the current one */
+#define FVSRN_ERR_WRONG_DEVICE (-8)     /* the handle's device state lives on another HIP device than the current one (exercised on one-GPU boxes
+                                          through FVSRN_DEBUG_DEVICE_SKEW: tests/test_gpu_parity.py test_wrong_device_check_fires_on_one_gpu) */
 
 /* activation of the hidden layers: renderer/volume_interpolation_network.cpp:223-230 */
 typedef enum {
@@ -216,9 +217,7 @@ int fvsrn_network_keyframe_stats(const fvsrn_network* net, unsigned long long ou
  * resolution below 2, above the size cap, option 0), builds of the table of the image the unshaded renderer runs, builds of the plain-image table
  * (shaded renders of a network that also has a re-scaled image), bytes of table memory resident now } since the device state was created.  Tables are
  * built by the first launch that goes through them and then with every key-frame blend for as long as the launches do; a network whose launches take
- * the gathers (footprint rule, adjoint mode, evaluate_points) never allocates one.  r06: the register-resident kernels of 32-wide networks read the
- * SLAB table (one entry per pair of face-adjacent cells of the grid extended by a ghost cell per side, 3 (X+1)(Y+1)(Z+1) KiB); while the unshaded
- * launches go through it, it is the table the first two and the last figure count. */
+ * the gathers (footprint rule, adjoint mode, evaluate_points) never allocates one. */
 int fvsrn_network_cell_table_stats(const fvsrn_network* net, unsigned long long out[4]);
 
 /* ----------------------------------------------------------------------------------------
@@ -374,7 +373,10 @@ int fvsrn_render_stripes(fvsrn_scene* scene, fvsrn_network* net, int width, int 
  * gives frame by frame, except that a multi-frame launch does not cut rays into depth segments (re-associated sums, <= 1e-4).  The scenes must agree in everything but the camera -- the
  * call overwrites cam_eye / cam_right / cam_up of each scene's description, nothing else (a light that follows the camera, brdf_light, does not) -- and the caller orders the streams against its buffers (events) as for
  * single frames.  d_rgba8 (optional): frame f's rows also as packed RGBA8 words (fvsrn_extract_color_rgba8, FVSRN_CHANNEL_COLOR, use_tonemapping /
- * max_exposure) at d_rgba8 + f * rows * width, enqueued behind its render on the same stream.  d_stats as in fvsrn_render, summed over the frames. */
+ * max_exposure) at d_rgba8 + f * rows * width, enqueued behind its render on the same stream.  d_stats as in fvsrn_render, summed over the frames.
+ * Errors: arguments are checked before anything is enqueued (world == 1 renders whole frames: stripe_rows is not used there).  A failure in the middle of
+ * a batch returns its code at once: the frames of the groups before it are enqueued, each lane's scene carries the camera of its last group and the
+ * network the time of the failing frame -- state every later batch call overwrites. */
 int fvsrn_render_stripes_batch(fvsrn_scene* const* scenes, void* const* streams, int lanes, fvsrn_network* net, int width, int height, int stripe_rows,
                                int rank, int world, int frames, const float* cameras9, const float* times, float* d_out_local, unsigned int* d_rgba8,
                                int use_tonemapping, float max_exposure, unsigned long long* d_stats);
