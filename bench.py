@@ -696,7 +696,7 @@ def main():
     exact = None
     if not args.no_twin and not collective:
         # the same frames with exact Fourier features at every step (FVSRN_OPT_FOURIER_RESYNC = 1: the reference's per-sample
-        # arithmetic, positions rounded to fp16 at every sample, no feature rotation; DESIGN.md section 4, INTEGRATION.md)
+        # arithmetic, positions rounded to fp16 at every sample, no feature rotation; DESIGN.md section 3, INTEGRATION.md)
         r3 = Runner(capi, net, cfg, rank, world, args.early_out, time_keys, scene_options={"fourier_resync": 1}, frames_per_submit=args.frames_per_submit)
         dt3, k3, ev3, ex3 = timed_run(r3, args.steps, args.warmup, False)
         plan3 = r3.pipeline.scenes[0].last_render_info()

@@ -324,6 +324,7 @@ struct fvsrn_network {
     WorkingGrid workGrid[2];
     int numWorkGrids = 1, curWorkGrid = 0;
     size_t cellTableBytes = 0;  // 0: no cell table (no grid, BYTE_GAUSSIAN, a resolution below 2, above the size cap, FVSRN_OPT_CELL_TABLE = 0)
+    size_t cellTableBytesCorners = 0;  // the shaded renderer's table (corner form over the grid's own cells)
     StreamOrder imagesOrder;  // weight images, ensemble key frames, decode coefficients: written at first use
     // streams that have launched kernels reading the images (handles only: recording an event behind every launch cost 3 % of a 0.3 ms
     // frame, r03): a re-pack of a live network waits for THESE streams, not for the device (hipDeviceSynchronize stalled the

@@ -646,7 +646,8 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     float* dfeatLds = nullptr;
     if constexpr (kRotateLds) dfeatLds = const_cast<float*>(tfLds) + S.tfLdsFloats + int(threadIdx.x >> 6) * (64 * 32);
     floatx16 feat[2][mtiles(CD)], dfeat[2][mtiles(CD)];
-    constexpr int FG = (GRID == 1 && CELLS) ? 3 : GRID;  // srn_forward's view of the latent grid: 3 = through the cell table (srn_device.hpp)
+    // srn_forward's view of the latent grid: 3 = through the cell table (monomial form), 4 = through the corner-weight table of the shaded kernels (srn_device.hpp)
+    constexpr int FG = (GRID == 1 && CELLS) ? (SHADED ? 4 : 3) : GRID;
     // the adjoint gradient mode lives in this instantiation (render_shaded_kernel except at 48 / 64 channels, render_adjoint_kernel there)
     constexpr bool kAdjointHere = SHADED == 2 || (SHADED == 1 && !adjoint_in_its_own_kernel(CD));
     [[maybe_unused]] bool normalsAtPreviousStep = false;  // (wave-uniform) per ray tile

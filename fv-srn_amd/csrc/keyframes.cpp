@@ -160,6 +160,8 @@ void fvsrn_network::ensureDevice(hipStream_t stream) {
             if (opts[FVSRN_OPT_CELL_TABLE] != 0 && K.enc != FVSRN_GRID_BYTE_GAUSSIAN && np.gridX >= 2 && np.gridY >= 2 && np.gridZ >= 2 &&
                 np.numLayers >= 1 && cells * 512.0 * MT <= 1073741824.0)
                 cellTableBytes = size_t(cells) * 512 * size_t(MT);
+            // (the shaded kernels' table keeps the corner form over the grid's own cells: buildCellTable(plain))
+            cellTableBytesCorners = cellTableBytes ? size_t(np.gridX - 1) * size_t(np.gridY - 1) * size_t(np.gridZ - 1) * 512 * size_t(MT) : 0;
         }
         for (int i = 0; i < 2; ++i) {
             if (i >= numWorkGrids) { workGrid[i].a.release(); workGrid[i].b.release(); workGrid[i].cells.release(); workGrid[i].cellsPlain.release(); continue; }
@@ -201,11 +203,11 @@ void fvsrn_network::ensureDevice(hipStream_t stream) {
 }
 
 void fvsrn_network::buildCellTable(WorkingGrid& W, bool plain, hipStream_t stream) {
-    const bool own = plain && scaledImage != nullptr;
+    const bool own = plain;  // (r06: the shaded renderer's table is its own since it keeps the corner form)
     DeviceBuffer& buf = own ? W.cellsPlain : W.cells;
     bool& valid = own ? W.cellsPlainValid : W.cellsValid;
     if (valid) return;
-    buf.ensure(cellTableBytes);
+    buf.ensure(plain ? cellTableBytesCorners : cellTableBytes);
     const NetParams& np = packed.params;
     const int MT = (packed.cfg.hiddenChannels + 31) / 32, KS = packed.cfg.hiddenChannels / 16;
     CellTableParams ct{};
@@ -214,6 +216,7 @@ void fvsrn_network::buildCellTable(WorkingGrid& W, bool plain, hipStream_t strea
     ct.latentFrags = static_cast<const char*>(!plain && scaledImage ? scaledImage : dLds.ptr) + np.offLayer0 + size_t(MT) * KS * kFragBytes;
     ct.out = buf.ptr;
     ct.X = np.gridX; ct.Y = np.gridY; ct.Z = np.gridZ; ct.G = np.gridC; ct.MT = MT;
+    ct.corners = plain ? 1 : 0;
     HIP_CHECK(launch_grid_cell_table(ct, stream));
     valid = true;
     ++cellTableBuilds[own ? 1 : 0];
@@ -221,7 +224,7 @@ void fvsrn_network::buildCellTable(WorkingGrid& W, bool plain, hipStream_t strea
 
 const void* fvsrn_network::ensureCellTable(bool plain, hipStream_t stream) {
     WorkingGrid& W = workGrid[curWorkGrid];
-    const bool own = plain && scaledImage != nullptr;
+    const bool own = plain;
     if (!(own ? W.cellsPlainValid : W.cellsValid)) {
         imagesOrder.beginRead(stream);  // the latent fragments of the weight image
         W.order.beginWrite(stream);

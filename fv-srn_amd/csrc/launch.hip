@@ -348,11 +348,43 @@ __global__ void grid_cell_table_kernel(CellTableParams p) {
     }
 }
 
+// The corner form (r04 / r05; CellTableParams::corners): out[cell][m][row][corner (dz, dy, dx)] over the (X - 1)(Y - 1)(Z - 1) cells of the grid itself -- the table
+// of the shaded kernels (cell_tap_corners, srn_device.hpp).  Records: the pair {v(x0), v(x0 + 1)} of channel c sits at dword c of record (z, y, x0 + 1).
+__global__ void grid_cell_table_corners_kernel(CellTableParams p) {
+    const unsigned cx = unsigned(p.X - 1), cy = unsigned(p.Y - 1), cz = unsigned(p.Z - 1);
+    const unsigned long long total = (unsigned long long)cx * cy * cz * unsigned(p.MT) * 32ull;
+    const int KG = p.G / 16;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned r = unsigned(i & 31);
+        const unsigned m = unsigned((i >> 5) % unsigned(p.MT));
+        const unsigned long long cell = (i >> 5) / unsigned(p.MT);
+        const unsigned x0 = unsigned(cell % cx), y0 = unsigned((cell / cx) % cy), z0 = unsigned(cell / (cx * (unsigned long long)cy));
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int g = 0; g < KG; ++g)
+            for (int h = 0; h < 2; ++h) {
+                const _Float16* w = reinterpret_cast<const _Float16*>(static_cast<const char*>(p.latentFrags) + (size_t(g) * p.MT + m) * kFragBytes +
+                                                                      (32 * h + r) * 16);
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned long long rec = ((unsigned long long)(z0 + (k >> 1)) * unsigned(p.Y) + (y0 + (k & 1))) * unsigned(p.X + 1) + (x0 + 1);
+                    const _Float16* v = reinterpret_cast<const _Float16*>(p.grid) + (rec * unsigned(p.G) + unsigned(16 * g + 8 * h)) * 2;
+                    for (int j = 0; j < 8; ++j) {
+                        acc[2 * k] = fmaf(float(w[j]), float(v[2 * j]), acc[2 * k]);
+                        acc[2 * k + 1] = fmaf(float(w[j]), float(v[2 * j + 1]), acc[2 * k + 1]);
+                    }
+                }
+            }
+        _Float16* o = static_cast<_Float16*>(p.out) + i * 8;
+        for (int j = 0; j < 8; ++j) o[j] = _Float16(acc[j]);
+    }
+}
+
+
 hipError_t launch_grid_cell_table(const CellTableParams& p, hipStream_t s) {
-    const unsigned long long total = (unsigned long long)(p.X + 1) * (p.Y + 1) * (p.Z + 1) * unsigned(p.MT) * 32ull;
+    const unsigned long long total = (p.corners ? (unsigned long long)(p.X - 1) * (p.Y - 1) * (p.Z - 1) : (unsigned long long)(p.X + 1) * (p.Y + 1) * (p.Z + 1)) * unsigned(p.MT) * 32ull;
     if (total == 0) return hipSuccess;
     const unsigned blocks = unsigned(std::min<unsigned long long>((total + 255) / 256, 16384ull));
-    hipLaunchKernelGGL(grid_cell_table_kernel, dim3(blocks), dim3(256), 0, s, p);
+    if (p.corners) hipLaunchKernelGGL(grid_cell_table_corners_kernel, dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(grid_cell_table_kernel, dim3(blocks), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

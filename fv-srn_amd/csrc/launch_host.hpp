@@ -27,9 +27,10 @@ hipError_t launch_grid_blend(const BlendParams& p, hipStream_t s);
 struct CellTableParams {
     const void* grid;        // working grid, fp16 x-pair records [Z][Y][X+1][G][2]
     const void* latentFrags; // the weight image's latent K-step fragments of layer 0, [g][m] x 1 KiB (pack.cpp)
-    void* out;               // fp16 [cells][MT][32][8]
+    void* out;               // fp16 [cells][MT][32][8]  (cells: (X+1)(Y+1)(Z+1), corners: (X-1)(Y-1)(Z-1))
     int X, Y, Z, G;          // grid resolution, latent channels (a multiple of 16)
     int MT;                  // M tiles of the network
+    int corners;             // 0: monomial coefficients over the ghost-extended cells (cell_tap); 1: corner vectors over the grid's own cells (cell_tap_corners: shaded kernels)
 };
 hipError_t launch_grid_cell_table(const CellTableParams& p, hipStream_t s);
 

@@ -188,7 +188,11 @@ static int renderImpl(fvsrn_scene* scene, fvsrn_network* net, int width, int hei
             if (a.shaded && d.gradient_mode != FVSRN_GRADIENT_ADJOINT_METHOD && net->key.grid == 1 && net->cellTableBytes && useCells)
                 cellsFn = render_shaded_cells_fn(net->key);
             // the table itself: built by the first launch that goes through it (and from then on with every blend, until a launch does not)
-            if ((smallFn && smallGrid == 2) || cellsFn) a.P.cellTable = net->ensureCellTable(a.shaded, s);
+            if ((smallFn && smallGrid == 2) || cellsFn) {
+                a.P.cellTable = net->ensureCellTable(a.shaded, s);
+                // (the shaded kernels read the corner-form table over the grid's own cells: srn_device.hpp cell_tap_corners)
+                if (a.shaded) a.P.cellCount = unsigned(net->cellTableBytesCorners / size_t(a.P.cellStride ? a.P.cellStride : 512));
+            }
             else (a.shaded ? net->cellsPlainWanted : net->cellsWanted) = false;
             net->beginUse(s);
             struct Done { fvsrn_network* n; hipStream_t s; ~Done() { try { n->endUse(s); } catch (...) {} } } done{net, s};

@@ -438,6 +438,32 @@ __device__ __forceinline__ CellTap cell_tap(const NetParams& P, float px, float 
     return t;
 }
 
+// The corner-weight form of r04 / r05 (weights {w_zy (1 - wx), w_zy wx}, zy = 2 dz + dy, of the cell x0 = min(floor(texel), N - 2) with clamped coordinates; table over
+// the (X - 1)(Y - 1)(Z - 1) cells of the grid itself, CellTableParams::corners).  The SHADED cell-table kernels keep it: central differences amplify the fp16
+// noise of an evaluation by 1 / 2h, and the monomial form carries 1.4 x the noise of this one on rough grids (the 64-wide finite-difference case of
+// tests/test_gpu_parity.py::test_shaded_render_matches_oracle read 1.9e-2 against a bar of 1.2e-2 with monomials).
+__device__ __forceinline__ CellTap cell_tap_corners(const NetParams& P, float px, float py, float pz) {
+    const float xm = P.gridXf - 1.f, ym = P.gridYf - 1.f, zm = P.gridZf - 1.f;
+    const float fx = __builtin_amdgcn_fmed3f(fmaf(px, P.gridXf, -0.5f), 0.f, xm);
+    const float fy = __builtin_amdgcn_fmed3f(fmaf(py, P.gridYf, -0.5f), 0.f, ym);
+    const float fz = __builtin_amdgcn_fmed3f(fmaf(pz, P.gridZf, -0.5f), 0.f, zm);
+    // min(floor, N - 2) as a median with -1 (floor >= 0): v_med3_f32 takes its operands as they are, fminf would canonicalise the bound at every step
+    const float x0 = __builtin_amdgcn_fmed3f(floorf(fx), -1.f, xm - 1.f), y0 = __builtin_amdgcn_fmed3f(floorf(fy), -1.f, ym - 1.f),
+                z0 = __builtin_amdgcn_fmed3f(floorf(fz), -1.f, zm - 1.f);
+    const float wx = fx - x0, wy = fy - y0, wz = fz - z0;
+    CellTap t;
+    // (exact in fp32: fewer than 2^24 cells; positions of rays that miss the box may be anything, also NaN: any valid cell will do)
+    t.cell = min(unsigned(fmaf(fmaf(z0, ym, y0), xm, x0)), P.cellCount - 1u);
+    const float ux = 1.f - wx, uy = 1.f - wy, uz = 1.f - wz;
+    const float w4[4] = {uz * uy, uz * wy, wz * uy, wz * wy};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float2_t v = {w4[k] * ux, w4[k] * wx};
+        t.w[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
+    }
+    return t;
+}
+
 __device__ __forceinline__ unsigned select_bits_by_mask(unsigned long long m, unsigned x) {
     unsigned r;
     asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
@@ -483,10 +509,10 @@ struct CellPre {
     half8_t ga[MT];          // its A fragments
 };
 
-template <int MT>
+template <int MT, bool MONO = true>
 __device__ __forceinline__ void cell_prepare(const NetParams& P, float px, float py, float pz, unsigned long long validMask, int h, unsigned laneOff,
                                              CellPre<MT>& C) {
-    const CellTap own = cell_tap(P, px, py, pz);
+    const CellTap own = MONO ? cell_tap(P, px, py, pz) : cell_tap_corners(P, px, py, pz);
 #pragma unroll
     for (int k = 0; k < 4; ++k) C.wOwn[k] = own.w[k];
     C.cellOwn = own.cell;
@@ -1206,14 +1232,14 @@ template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, int SCHED = 0>
 __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* lds, float px, float py, float pz,
                                                 float dx, float dy, float dz, unsigned long long validMask = ~0ull) {
     half8_t xb[2][2 * mtiles(CD)];
-    if constexpr (GRID == 3) {
+    if constexpr (GRID == 3 || GRID == 4) {  // (4: the cell table in its corner-weight form -- the shaded kernels; the layer code sees 3 either way)
         // latent grid through the cell table: weights, cells and the first cell pair's fragments ahead of the Fourier work (validMask: the
         // samples that count -- the others need no cell of their own)
         const int lane = lane_id();
         CellPre<mtiles(CD)> C;
-        cell_prepare<mtiles(CD)>(P, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
+        cell_prepare<mtiles(CD), GRID == 3>(P, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
         __builtin_amdgcn_sched_barrier(0);
-        return srn_layers<CD, ACT, GRID, HAS_DIR, 0, false, SCHED>(
+        return srn_layers<CD, ACT, 3, HAS_DIR, 0, false, SCHED>(
             P, lds, xb, px, py, pz, [&]() { fourier_fragments<CD, ACT, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, xb); }, [](int) {}, nullptr, &C);
     } else if constexpr (GRID == 1 && FVSRN_GRID_PRE) {
         // Latent grid with decoded working values: the 8 gathers of a tile's first 16-channel chunk are issued in FRONT of that
@@ -1594,7 +1620,6 @@ __device__ __forceinline__ float4_t srn_forward_rotating_resident_cells(const Ne
             // back into place (seen in the r05 listing of render_small_kernel<4,false,3,4,2>; the kernel without a grid has none).
             // (an empty asm that ties tile 1's fragments and its features together: a sched_barrier alone does not stop the IR-level sinking)
             asm volatile("" : "+v"(feat[1][0]), "+v"(xb[1][0]), "+v"(xb[1][1]));
-            __builtin_amdgcn_sched_barrier(0);
 #endif
             if (advance) {
 #pragma unroll

@@ -214,8 +214,8 @@ int fvsrn_scene_get_option(fvsrn_scene* scene, int option, int* value);
  * (on demand), prefetched ahead of need, bytes uploaded } since the device state was created */
 int fvsrn_network_keyframe_stats(const fvsrn_network* net, unsigned long long out[6]);
 /* cell tables of a network's latent grid (FVSRN_OPT_CELL_TABLE): out = { bytes of one table (0: this network has none -- no grid, BYTE_GAUSSIAN, a
- * resolution below 2, above the size cap, option 0), builds of the table of the image the unshaded renderer runs, builds of the plain-image table
- * (shaded renders of a network that also has a re-scaled image), bytes of table memory resident now } since the device state was created.  Tables are
+ * resolution below 2, above the size cap, option 0), builds of the table of the image the unshaded renderer runs, builds of the shaded renderer's table
+ * (its own since r06: corner vectors of the plain image, where the unshaded renderer's holds monomial coefficients), bytes of table memory resident now } since the device state was created.  Tables are
  * built by the first launch that goes through them and then with every key-frame blend for as long as the launches do; a network whose launches take
  * the gathers (footprint rule, adjoint mode, evaluate_points) never allocates one. */
 int fvsrn_network_cell_table_stats(const fvsrn_network* net, unsigned long long out[4]);

@@ -619,7 +619,7 @@ def test_cell_table_smallest_grids(C, layers, res):
 
 def test_cell_table_is_chosen_by_the_footprint_of_a_pixel_tile():
     """Scene option cell_table = -1 (default): fvsrn_render takes the table while an 8 x 8 pixel tile spans less than ~0.8 grid cells at the box
-    centre (32 channels; DESIGN.md section 4 item 16, profiles/r04/cell_footprint_sweep_r04.txt) -- the same scene in a large image does, in a
+    centre (32 channels; HISTORY.md section 4 item 16, profiles/r04/cell_footprint_sweep_r04.txt) -- the same scene in a large image does, in a
     small one it gathers; a fine grid in the large image gathers too.  Either way the same picture up to rounding."""
     import torch
     from fvsrn_amd import capi, volnet_io

@@ -3,7 +3,7 @@
 CPU: the C restatement (oracle/srn_oracle.c, vol_*) against hand-computed properties of renderer_volume_grid.cuh:89-232 and
 the .cvol container (volume.cpp:623-740).  GPU: fvsrn_volume_evaluate_points / fvsrn_render_volume against the restatement.
 Parity of this row is restatement-pinned only: the reference evaluates grids in CUDA / its CPU kernels, none of which can be
-built here (DESIGN.md section 5)."""
+built here (DESIGN.md section 4)."""
 import os
 import struct
 import sys
