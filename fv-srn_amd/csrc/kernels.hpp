@@ -653,6 +653,10 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     [[maybe_unused]] bool normalsAtPreviousStep = false;  // (wave-uniform) per ray tile
     float stepIndex = float(i0);
     const float stepEnd = float(i1);  // INT_MAX -> 2^31: never reached
+    // render_small_kernel<.., SGRID = 2>: the wave's cell pair and its table fragment, kept from step to step (srn_device.hpp); none at the start of a work unit
+    [[maybe_unused]] CellResident<1> cellPair;
+    cellPair.valid = 0; cellPair.cA = cellPair.cB = kNoCell;
+    [[maybe_unused]] const float gdnx = dnx * P.gridXf, gdny = dny * P.gridYf, gdnz = dnz * P.gridZf, gp0x = pn0x * P.gridXf, gp0y = pn0y * P.gridYf, gp0z = pn0z * P.gridZf;
 
 #ifdef FVSRN_PROF_SECTIONS
     P.profLast = __builtin_readcyclecounter();
@@ -711,7 +715,13 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             // compile-time variant (render_small_kernel<.., ADVANCE>, chosen by the host): as a wave-uniform branch inside the step it cost the
             // default path 1.7 % (r04: 162.1 -> 159.4 Gsamples/s), leaving it out costs the exact mode 10 - 17 % (121.5 -> 134.6 .. 145.8)
             constexpr bool advance = ADVANCE;
-            if constexpr (NLC > 0 && CELLS) o = srn_forward_rotating_resident_cells<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeat, px, py, pz, validMask, advance);
+#ifdef FVSRN_CELLS_SCALED_POS
+            // the cell table's coordinates p N straight from the ray parameter (per-ray constants gdn = dn N, gp0 = pn0 N): the position itself is only
+            // needed where the features are re-derived
+            if constexpr (NLC > 0 && CELLS) o = srn_forward_rotating_resident_cells<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, cellPair, feat, dfeat, fmaf(gdnx, t, gp0x), fmaf(gdny, t, gp0y), fmaf(gdnz, t, gp0z), validMask, advance);
+#else
+            if constexpr (NLC > 0 && CELLS) o = srn_forward_rotating_resident_cells<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, cellPair, feat, dfeat, px, py, pz, validMask, advance);
+#endif
             else if constexpr (NLC > 0) o = srn_forward_rotating_resident<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, feat, dfeat, advance);
             else o = srn_forward_rotating<CD, ACT, GRID, HAS_DIR>(P, lds, feat, dfeat, px, py, pz, advance);
         } else if constexpr (kRotateLds) {

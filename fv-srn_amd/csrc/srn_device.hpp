@@ -421,8 +421,9 @@ struct CellTap {
 // Per sample: 3 x (mul, round, sub) + two fma, a convert and a min for the cell index, one product + two packed products, four converts = 20 vector
 // instructions where the corner form took 34 (three clamps, floors and clamps again, three 1 - w, twelve products).  A sample exactly on a cell face may
 // land in either cell: the interpolant is continuous.  fp16 error against the corner form: 1.4 x on random data (tools/dev/slab_precision.py).
+template <bool SCALED = false>  // SCALED: the arguments are p N already (render_small_kernel derives them from the ray parameter, kernels.hpp)
 __device__ __forceinline__ CellTap cell_tap(const NetParams& P, float px, float py, float pz) {
-    const float gx = px * P.gridXf, gy = py * P.gridYf, gz = pz * P.gridZf;
+    const float gx = SCALED ? px : px * P.gridXf, gy = SCALED ? py : py * P.gridYf, gz = SCALED ? pz : pz * P.gridZf;
     const float ex = __builtin_rintf(gx), ey = __builtin_rintf(gy), ez = __builtin_rintf(gz);
     const float x = gx - ex, y = gy - ey, z = gz - ez;
     CellTap t;
@@ -512,7 +513,7 @@ struct CellPre {
 template <int MT, bool MONO = true>
 __device__ __forceinline__ void cell_prepare(const NetParams& P, float px, float py, float pz, unsigned long long validMask, int h, unsigned laneOff,
                                              CellPre<MT>& C) {
-    const CellTap own = MONO ? cell_tap(P, px, py, pz) : cell_tap_corners(P, px, py, pz);
+    const CellTap own = MONO ? cell_tap<false>(P, px, py, pz) : cell_tap_corners(P, px, py, pz);
 #pragma unroll
     for (int k = 0; k < 4; ++k) C.wOwn[k] = own.w[k];
     C.cellOwn = own.cell;
@@ -541,6 +542,56 @@ __device__ __forceinline__ void cell_prepare(const NetParams& P, float px, float
 #endif
 #pragma unroll
     for (int m = 0; m < MT; ++m) C.ga[m] = *reinterpret_cast<const half8_t*>(base + 512 * m);
+}
+
+// The cell pair of a wave KEPT across the steps of a ray tile (r06; render_small_kernel<.., SGRID = 2>): the samples of a step move by 0.03 cells per step, so
+// the pair (A, B) the previous step picked still holds every valid sample on 87 % of the steps of the 16^3 headline frame (tools/dev/slab_sim_cells.py).
+// While it does, the step needs neither the two v_readlane chains of the pick nor the table fetch (the A fragments stay in four registers): two compares
+// against the kept indices give the masks.  A valid sample in neither cell -> the pick of cell_prepare, which replaces the pair.
+constexpr unsigned kNoCell = 0xffffffffu;
+template <int MT>
+struct CellResident {
+    unsigned cA, cB;  // wave-uniform; cB = kNoCell: no second cell
+    int valid;
+    half8_t ga[MT];   // lane half 0: A's entry row, lane half 1: B's (A's where there is no B)
+};
+
+template <int MT>
+__device__ __forceinline__ void cell_prepare_resident(const NetParams& P, CellResident<MT>& S, float px, float py, float pz, unsigned long long validMask, int h,
+                                                      unsigned laneOff, CellPre<MT>& C) {
+#ifdef FVSRN_CELLS_SCALED_POS
+    const CellTap own = cell_tap<true>(P, px, py, pz);
+#else
+    const CellTap own = cell_tap<false>(P, px, py, pz);
+#endif
+#pragma unroll
+    for (int k = 0; k < 4; ++k) C.wOwn[k] = own.w[k];
+    C.cellOwn = own.cell;
+    unsigned long long mA = __builtin_amdgcn_ballot_w64(own.cell == S.cA), mB = __builtin_amdgcn_ballot_w64(own.cell == S.cB);
+    unsigned long long rem = validMask & ~(mA | mB);
+    if (!S.valid || rem != 0ull) {  // wave-uniform
+        const unsigned cA = __builtin_amdgcn_readlane(own.cell, validMask ? __builtin_ctzll(validMask) : 0);
+        mA = __builtin_amdgcn_ballot_w64(own.cell == cA);
+        const unsigned long long rem1 = validMask & ~mA;
+        const unsigned cB = rem1 ? unsigned(__builtin_amdgcn_readlane(own.cell, __builtin_ctzll(rem1))) : kNoCell;
+        mB = rem1 ? __builtin_amdgcn_ballot_w64(own.cell == cB) : 0ull;
+        rem = rem1 & ~mB;
+        S.cA = cA; S.cB = cB; S.valid = 1;
+        const char* base = static_cast<const char*>(P.cellTable) + (__umul24(h && cB != kNoCell ? cB : cA, P.cellStride) + laneOff);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) S.ga[m] = *reinterpret_cast<const half8_t*>(base + 512 * m);
+    }
+    C.rem = rem;
+    uint4_t b0, b1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        auto r = lane_half_swap(select_bits_by_mask(mA, own.w[k]), select_bits_by_mask(mB, own.w[k]));
+        b0[k] = r[0]; b1[k] = r[1];
+    }
+    C.gf[0] = __builtin_bit_cast(half8_t, b0);
+    C.gf[1] = __builtin_bit_cast(half8_t, b1);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) C.ga[m] = S.ga[m];
 }
 
 // The latent K step(s) of tile t into the first layer's accumulators: the prepared pair, then -- wave-uniform, rare -- further pairs until
@@ -1603,12 +1654,16 @@ __device__ __forceinline__ float4_t srn_forward_rotating_resident(const NetParam
 
 // srn_forward_resident_cells with rotated Fourier features (the registers the gathers held take the rotation state)
 template <int ACT, bool HAS_DIR, int NLC, bool ALL4>
-__device__ __forceinline__ float4_t srn_forward_rotating_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, floatx16 (&feat)[2][1],
+__device__ __forceinline__ float4_t srn_forward_rotating_resident_cells(const NetParams& P, const ResidentNet<NLC, 2>& R, CellResident<1>& cells, floatx16 (&feat)[2][1],
                                                                        const floatx16 (&dfeat)[2][1], float px, float py, float pz,
                                                                        unsigned long long validMask, bool advance = true) {
     const int lane = lane_id();
     CellPre<1> C;
+#ifdef FVSRN_CELLS_NO_RESIDENT_PAIR  // (A/B build: the pick and the table fetch at every step, r04 / r05)
     cell_prepare<1>(P, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
+#else
+    cell_prepare_resident<1>(P, cells, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
+#endif
     half8_t xb[2][2];
     return srn_layers_resident<ACT, NLC, 0, ALL4, 2>(
         P, R, xb,
