@@ -715,7 +715,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             // compile-time variant (render_small_kernel<.., ADVANCE>, chosen by the host): as a wave-uniform branch inside the step it cost the
             // default path 1.7 % (r04: 162.1 -> 159.4 Gsamples/s), leaving it out costs the exact mode 10 - 17 % (121.5 -> 134.6 .. 145.8)
             constexpr bool advance = ADVANCE;
-#ifdef FVSRN_CELLS_SCALED_POS
+#if FVSRN_CELLS_SCALED_POS
             // the cell table's coordinates p N straight from the ray parameter (per-ray constants gdn = dn N, gp0 = pn0 N): the position itself is only
             // needed where the features are re-derived
             if constexpr (NLC > 0 && CELLS) o = srn_forward_rotating_resident_cells<ACT, HAS_DIR, NLC, TAIL == TAIL_RGBO>(P, resident, cellPair, feat, dfeat, fmaf(gdnx, t, gp0x), fmaf(gdny, t, gp0y), fmaf(gdnz, t, gp0z), validMask, advance);

@@ -548,6 +548,11 @@ __device__ __forceinline__ void cell_prepare(const NetParams& P, float px, float
 // the pair (A, B) the previous step picked still holds every valid sample on 87 % of the steps of the 16^3 headline frame (tools/dev/slab_sim_cells.py).
 // While it does, the step needs neither the two v_readlane chains of the pick nor the table fetch (the A fragments stay in four registers): two compares
 // against the kept indices give the masks.  A valid sample in neither cell -> the pick of cell_prepare, which replaces the pair.
+// (and its coordinates p N come straight from the ray parameter, FVSRN_CELLS_SCALED_POS: kernels.hpp.  Same-box A/B, profiles/r06/cells_resident_pair_ab_r06.txt:
+// 128.8 -> 130.8 G samples/s with the kept pair, 132.5 with both, 32 x 4 + 16^3)
+#ifndef FVSRN_CELLS_SCALED_POS
+#define FVSRN_CELLS_SCALED_POS 1
+#endif
 constexpr unsigned kNoCell = 0xffffffffu;
 template <int MT>
 struct CellResident {
@@ -559,7 +564,7 @@ struct CellResident {
 template <int MT>
 __device__ __forceinline__ void cell_prepare_resident(const NetParams& P, CellResident<MT>& S, float px, float py, float pz, unsigned long long validMask, int h,
                                                       unsigned laneOff, CellPre<MT>& C) {
-#ifdef FVSRN_CELLS_SCALED_POS
+#if FVSRN_CELLS_SCALED_POS
     const CellTap own = cell_tap<true>(P, px, py, pz);
 #else
     const CellTap own = cell_tap<false>(P, px, py, pz);
