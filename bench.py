@@ -453,7 +453,8 @@ def predicted_efficiency(config, world):
     import glob
     root = os.path.dirname(os.path.abspath(__file__))
     best = None
-    for f in sorted(glob.glob(os.path.join(root, "profiles", "r*", "stripe_efficiency*_r[0-9][0-9].jsonl"))):
+    # (exactly stripe_efficiency_rNN.jsonl: the round's default run -- not its frame-by-frame / stand-in / one-working-grid siblings)
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "r*", "stripe_efficiency_r[0-9][0-9].jsonl"))):
         with open(f) as fh:
             for line in fh:
                 try:
