@@ -656,6 +656,10 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     // render_small_kernel<.., SGRID = 2>: the wave's cell pair and its table fragment, kept from step to step (srn_device.hpp); none at the start of a work unit
     [[maybe_unused]] CellResident<1> cellPair;
     cellPair.valid = 0; cellPair.cA = cellPair.cB = kNoCell;
+#ifdef FVSRN_CELLS_WIDE_RESIDENT_PAIR  // (A/B build: the kept pair in render_cells_kernel too; 4 more registers per M tile across the step loop)
+    [[maybe_unused]] CellResident<mtiles(CD)> cellPairWide;
+    cellPairWide.valid = 0; cellPairWide.cA = cellPairWide.cB = kNoCell;
+#endif
     [[maybe_unused]] const float gdnx = dnx * P.gridXf, gdny = dny * P.gridYf, gdnz = dnz * P.gridZf, gp0x = pn0x * P.gridXf, gp0y = pn0y * P.gridYf, gp0z = pn0z * P.gridZf;
 
 #ifdef FVSRN_PROF_SECTIONS
@@ -746,6 +750,10 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             if (fusedGradient) o = srn_forward_gradient<CD, ACT, GRID, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, S.gridDiffStep, fgx, fgy, fgz);
             else o = srn_forward<CD, ACT, FG, HAS_DIR, FMODE, SCHED>(P, lds, px, py, pz, dx, dy, dz, validMask);
         } else {
+#ifdef FVSRN_CELLS_WIDE_RESIDENT_PAIR
+            if constexpr (FG == 3) o = srn_forward<CD, ACT, FG, HAS_DIR, FMODE, SCHED>(P, lds, px, py, pz, dx, dy, dz, validMask, &cellPairWide);
+            else
+#endif
             o = srn_forward<CD, ACT, FG, HAS_DIR, FMODE, SCHED>(P, lds, px, py, pz, dx, dy, dz, validMask);
         }
 

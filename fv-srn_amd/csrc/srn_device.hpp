@@ -561,14 +561,10 @@ struct CellResident {
     half8_t ga[MT];   // lane half 0: A's entry row, lane half 1: B's (A's where there is no B)
 };
 
-template <int MT>
+template <int MT, bool SCALED = false>  // SCALED: the position arguments are p N already (cell_tap)
 __device__ __forceinline__ void cell_prepare_resident(const NetParams& P, CellResident<MT>& S, float px, float py, float pz, unsigned long long validMask, int h,
                                                       unsigned laneOff, CellPre<MT>& C) {
-#if FVSRN_CELLS_SCALED_POS
-    const CellTap own = cell_tap<true>(P, px, py, pz);
-#else
-    const CellTap own = cell_tap<false>(P, px, py, pz);
-#endif
+    const CellTap own = cell_tap<SCALED>(P, px, py, pz);
 #pragma unroll
     for (int k = 0; k < 4; ++k) C.wOwn[k] = own.w[k];
     C.cellOwn = own.cell;
@@ -1284,16 +1280,18 @@ __device__ __forceinline__ float4_t srn_layers(const NetParams& P, const char* l
 #ifndef FVSRN_GRID_PRE
 #define FVSRN_GRID_PRE 1
 #endif
+// keep (GRID = 3, render_cells_kernel): the wave's cell pair kept from step to step (cell_prepare_resident); null: a pick and a fetch at every call
 template <int CD, int ACT, int GRID, bool HAS_DIR, int FMODE, int SCHED = 0>
 __device__ __forceinline__ float4_t srn_forward(const NetParams& P, const char* lds, float px, float py, float pz,
-                                                float dx, float dy, float dz, unsigned long long validMask = ~0ull) {
+                                                float dx, float dy, float dz, unsigned long long validMask = ~0ull, CellResident<mtiles(CD)>* keep = nullptr) {
     half8_t xb[2][2 * mtiles(CD)];
     if constexpr (GRID == 3 || GRID == 4) {  // (4: the cell table in its corner-weight form -- the shaded kernels; the layer code sees 3 either way)
         // latent grid through the cell table: weights, cells and the first cell pair's fragments ahead of the Fourier work (validMask: the
         // samples that count -- the others need no cell of their own)
         const int lane = lane_id();
         CellPre<mtiles(CD)> C;
-        cell_prepare<mtiles(CD), GRID == 3>(P, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
+        if (GRID == 3 && keep) cell_prepare_resident<mtiles(CD), false>(P, *keep, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
+        else cell_prepare<mtiles(CD), GRID == 3>(P, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
         __builtin_amdgcn_sched_barrier(0);
         return srn_layers<CD, ACT, 3, HAS_DIR, 0, false, SCHED>(
             P, lds, xb, px, py, pz, [&]() { fourier_fragments<CD, ACT, HAS_DIR, FMODE>(P, lds, px, py, pz, dx, dy, dz, xb); }, [](int) {}, nullptr, &C);
@@ -1667,7 +1665,7 @@ __device__ __forceinline__ float4_t srn_forward_rotating_resident_cells(const Ne
 #ifdef FVSRN_CELLS_NO_RESIDENT_PAIR  // (A/B build: the pick and the table fetch at every step, r04 / r05)
     cell_prepare<1>(P, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
 #else
-    cell_prepare_resident<1>(P, cells, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
+    cell_prepare_resident<1, FVSRN_CELLS_SCALED_POS != 0>(P, cells, px, py, pz, validMask, lane >> 5, unsigned(lane & 31) * 16u, C);
 #endif
     half8_t xb[2][2];
     return srn_layers_resident<ACT, NLC, 0, ALL4, 2>(
