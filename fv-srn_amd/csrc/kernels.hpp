@@ -553,6 +553,13 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     if constexpr (NLC > 0) load_resident(P, lds, resident);
     // TAIL_SCALAR_TABLE: loop-invariant scalars
     const float alphaLimit = S.earlyOut ? S.alphaEarlyOut : __builtin_inff();
+#ifdef FVSRN_TAIL_BIAS_VGPR
+    // A/B build: the density bias of the straight-line tails kept in a vector register (their fma has two scalar operands otherwise: one v_mov per step)
+    float densityBiasV = S.densityBias;
+    asm volatile("" : "+v"(densityBiasV));
+#else
+    const float densityBiasV = S.densityBias;
+#endif
     const bool sigmoidNet = P.outputMode == FVSRN_OUT_DENSITY;
     const bool textureTf = S.tfKind == FVSRN_TF_TEXTURE;
     const bool beerLambert = S.blendMode == FVSRN_BLEND_BEER_LAMBERT;
@@ -791,7 +798,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
                 // Identity TF + Beer-Lambert blending (the host routes Alpha blending to TAIL_SCALAR_TABLE), with every constant folded on the
                 // host: density = clamp01(value * s + b), alpha = 1 - 2^(density * k), k = -absorption * stepsize * log2 e.  The sample
                 // counts where it is valid and value >= densityMin; "absorption > 0" of the reference is implied (density 0 gives alpha 0).
-                const float density = __builtin_amdgcn_fmed3f(fmaf(value, S.divDensityRange, S.densityBias), 0.f, 1.f);
+                const float density = __builtin_amdgcn_fmed3f(fmaf(value, S.divDensityRange, densityBiasV), 0.f, 1.f);
                 const float a = 1.f - __builtin_amdgcn_exp2f(density * S.tfAbsorptionStepLog2e);
                 const float w = select_by_mask(validMask & __builtin_amdgcn_ballot_w64(value >= S.densityMin), (1.f - ca) * a);
                 cr += w * density;  // emission scale behind the loop
@@ -802,7 +809,7 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             if constexpr (TAIL == TAIL_SCALAR_TEXTURE) {
                 // Texture TF (renderer_tf_texture.cuh:46-55) + Beer-Lambert blending, constants folded like in TAIL_SCALAR_IDENTITY:
                 // alpha = 1 - 2^(opacity * k), k = -stepsize * log2 e
-                const float density = __builtin_amdgcn_fmed3f(fmaf(value, S.divDensityRange, S.densityBias), 0.f, 1.f);
+                const float density = __builtin_amdgcn_fmed3f(fmaf(value, S.divDensityRange, densityBiasV), 0.f, 1.f);
                 const int R = S.tfRows;
                 const float d = fmaf(density, S.tfRowsF, -0.5f);
                 const float fl = floorf(d);
