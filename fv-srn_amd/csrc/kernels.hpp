@@ -553,8 +553,10 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     if constexpr (NLC > 0) load_resident(P, lds, resident);
     // TAIL_SCALAR_TABLE: loop-invariant scalars
     const float alphaLimit = S.earlyOut ? S.alphaEarlyOut : __builtin_inff();
-#ifdef FVSRN_TAIL_BIAS_VGPR
-    // A/B build: the density bias of the straight-line tails kept in a vector register (their fma has two scalar operands otherwise: one v_mov per step)
+    // r06: the density bias of the straight-line tails kept in a vector register (their fma has two scalar operands otherwise: one v_mov per step), and the end of
+    // a unit's step range folded into the ray's far end (below: two compares per step instead of three).  Same-box A/B of the two, profiles/r06/tail_bias_fold_ab_r06.txt:
+    // headline 163.5 -> 165.7 G samples/s (+ 1.3 %), latent-grid and small-frame lines unchanged.  -DFVSRN_NO_TAIL_BIAS_FOLD builds the r05 form.
+#ifndef FVSRN_NO_TAIL_BIAS_FOLD
     float densityBiasV = S.densityBias;
     asm volatile("" : "+v"(densityBiasV));
 #else
@@ -660,6 +662,10 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
     [[maybe_unused]] bool normalsAtPreviousStep = false;  // (wave-uniform) per ray tile
     float stepIndex = float(i0);
     const float stepEnd = float(i1);  // INT_MAX -> 2^31: never reached
+#ifndef FVSRN_NO_TAIL_BIAS_FOLD
+    const float tSegEnd = fmaf(stepEnd - 0.5f, S.stepsize, tmin);
+    [[maybe_unused]] const float tmaxEff = tSegEnd < tmax ? tSegEnd : tmax;  // (a NaN far end stays NaN: never valid)
+#endif
     // render_small_kernel<.., SGRID = 2>: the wave's cell pair and its table fragment, kept from step to step (srn_device.hpp); none at the start of a work unit
     [[maybe_unused]] CellResident<1> cellPair;
     cellPair.valid = 0; cellPair.cA = cellPair.cB = kNoCell;
@@ -682,8 +688,13 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
             // The lane predicates live as wave masks in scalar registers only (three v_cmp, two s_and): kept as `bool`s hipcc
             // materialises them in VGPRs across the network code (v_cndmask + v_cmp_ne per step).
             t = fmaf(stepIndex, S.stepsize, tmin);
+#ifndef FVSRN_NO_TAIL_BIAS_FOLD
+            // the end of this unit's step range is part of the ray's far end (tmaxEff: t_i <= tmin + (i1 - 1/2) stepsize <=> i < i1): two compares
+            validMask = __builtin_amdgcn_ballot_w64(t <= tmaxEff) & __builtin_amdgcn_ballot_w64(ca < alphaLimit);
+#else
             validMask = __builtin_amdgcn_ballot_w64(t <= tmax) & __builtin_amdgcn_ballot_w64(stepIndex < stepEnd) &
                         __builtin_amdgcn_ballot_w64(ca < alphaLimit);
+#endif
             stepIndex += 1.f;
             inRange = valid = false;  // (unused in the straight-line tails)
         } else {
@@ -800,7 +811,11 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
                 // counts where it is valid and value >= densityMin; "absorption > 0" of the reference is implied (density 0 gives alpha 0).
                 const float density = __builtin_amdgcn_fmed3f(fmaf(value, S.divDensityRange, densityBiasV), 0.f, 1.f);
                 const float a = 1.f - __builtin_amdgcn_exp2f(density * S.tfAbsorptionStepLog2e);
+#ifdef FVSRN_TAIL_FMA_WEIGHT  // A/B build: (1 - ca) a as a - ca a: one fma where the product form takes a copy, a packed subtract and a product
+                const float w = select_by_mask(validMask & __builtin_amdgcn_ballot_w64(value >= S.densityMin), fmaf(-ca, a, a));
+#else
                 const float w = select_by_mask(validMask & __builtin_amdgcn_ballot_w64(value >= S.densityMin), (1.f - ca) * a);
+#endif
                 cr += w * density;  // emission scale behind the loop
                 depth += w * t;
                 ca += w;
