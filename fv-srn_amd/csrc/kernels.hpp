@@ -811,7 +811,8 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
                 // counts where it is valid and value >= densityMin; "absorption > 0" of the reference is implied (density 0 gives alpha 0).
                 const float density = __builtin_amdgcn_fmed3f(fmaf(value, S.divDensityRange, densityBiasV), 0.f, 1.f);
                 const float a = 1.f - __builtin_amdgcn_exp2f(density * S.tfAbsorptionStepLog2e);
-#ifdef FVSRN_TAIL_FMA_WEIGHT  // A/B build: (1 - ca) a as a - ca a: one fma where the product form takes a copy, a packed subtract and a product
+#ifndef FVSRN_NO_TAIL_FMA_WEIGHT  // r06: (1 - ca) a as a - ca a -- one fma where the product form takes a copy, a packed subtract and a product: headline 167.9 -> 170.4 G samples/s
+                                   // same box (profiles/r06/tail_fma_weight_ab_r06.txt; the transmittance form T' = T e, w = T - T' of the same file gained nothing)
                 const float w = select_by_mask(validMask & __builtin_amdgcn_ballot_w64(value >= S.densityMin), fmaf(-ca, a, a));
 #else
                 const float w = select_by_mask(validMask & __builtin_amdgcn_ballot_w64(value >= S.densityMin), (1.f - ca) * a);
@@ -833,7 +834,11 @@ __device__ __forceinline__ void render_body(const NetParams& P, const SceneParam
                 const float4_t ta = *reinterpret_cast<const float4_t*>(tfLds + 4 * min(max(di, 0), R - 1));
                 const float4_t tb = *reinterpret_cast<const float4_t*>(tfLds + 4 * min(max(di + 1, 0), R - 1));
                 const float a = 1.f - __builtin_amdgcn_exp2f((ta[3] + df * (tb[3] - ta[3])) * S.stepLog2e);
+#ifndef FVSRN_NO_TAIL_FMA_WEIGHT
+                const float w = select_by_mask(validMask & __builtin_amdgcn_ballot_w64(value >= S.densityMin), fmaf(-ca, a, a));
+#else
                 const float w = select_by_mask(validMask & __builtin_amdgcn_ballot_w64(value >= S.densityMin), (1.f - ca) * a);
+#endif
                 cr += w * (ta[0] + df * (tb[0] - ta[0]));
                 cg += w * (ta[1] + df * (tb[1] - ta[1]));
                 cb += w * (ta[2] + df * (tb[2] - ta[2]));
